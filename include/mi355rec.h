@@ -1,0 +1,203 @@
+/*
+ * mi355rec.h -- C ABI of libmi355rec.so, the MI355X (gfx950) implementation of the baseline training
+ * kernels of MaurizioFD/RecSys2019_DeepLearning_Evaluation.
+ *
+ * The reference has no C/FFI boundary on this path: its "operator API" is the Python-level interface of
+ * three Cython `cdef class`es and one NumPy loop.  Each group of entry points below replaces one of them;
+ * the reference interface it stands in for is cited as file:line (relative to the reference root).  The
+ * ctypes stub a maintainer would add on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MI355REC_E_* code otherwise;
+ *     mi355rec_last_error() returns a thread-local human-readable message for the last failure;
+ *   - host buffers are owned by the caller and only read/written for the duration of the call;
+ *     *_create copies its inputs to HBM; handles own device memory and one HIP stream;
+ *   - pointers named d_* are DEVICE pointers (e.g. torch tensor .data_ptr()), everything else is host;
+ *   - all calls are blocking unless stated; one handle must not be used from two threads at once;
+ *   - the HIP context is created lazily by the first *_create in the calling process (fork-safe import);
+ *   - indices are int32, values float32; CSR rows must have sorted column indices.
+ */
+#ifndef MI355REC_H
+#define MI355REC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355REC_OK              0
+#define MI355REC_E_INVALID      -1   /* bad argument (maps to ValueError on the Python side) */
+#define MI355REC_E_HIP          -2   /* HIP runtime failure */
+#define MI355REC_E_NO_DEVICE    -3   /* no gfx950 device visible */
+#define MI355REC_E_UNSUPPORTED  -4   /* valid in the reference, not (yet) covered by the device path */
+#define MI355REC_E_NUMERIC      -5   /* non-finite value / not positive definite */
+
+const char *mi355rec_last_error(void);
+/* Number of visible HIP devices (0 and MI355REC_OK when none). */
+int mi355rec_device_count(int *count);
+/* Select the device used by handles created afterwards in this process (one process per GPU: LOCAL_RANK). */
+int mi355rec_set_device(int device);
+/* "gfx950:..." architecture string of the current device. */
+int mi355rec_device_name(char *buf, int buf_len);
+
+/* Timing of the hot kernels of the last run/compute call on a handle, measured with HIP events recorded
+ * on the handle's own stream (bench.py's roofline figure comes from here). */
+typedef struct {
+    double  kernel_ms;      /* elapsed ms between the events bracketing the hot kernels of the last call */
+    int64_t n_launches;     /* number of launches of the dominant kernel inside that bracket */
+    int64_t n_units;        /* units processed: samples (mf, slim), columns (sim), row solves (ials) */
+    double  algorithmic_bytes; /* ALGORITHMIC bytes moved by those launches (definition: DESIGN.md section 4) */
+    double  algorithmic_flops; /* ALGORITHMIC flops (ials), 0 elsewhere */
+    double  loss;           /* cumulative x_uij^2 / squared error of the last call where defined, else 0 */
+} mi355rec_stats;
+
+/* ------------------------------------------------------------------------------------------------------
+ * Compute_Similarity  (Base/Similarity/Cython/Compute_Similarity_Cython.pyx:51  cdef class
+ * Compute_Similarity_Cython; __init__ :72-213; compute_similarity(start_col, end_col) :411-607)
+ * ---------------------------------------------------------------------------------------------------- */
+
+enum {                       /* `similarity=` strings of Compute_Similarity_Cython.__init__ (.pyx:118-143) */
+    MI355REC_SIM_COSINE     = 0,
+    MI355REC_SIM_ADJUSTED   = 1,
+    MI355REC_SIM_ASYMMETRIC = 2,
+    MI355REC_SIM_PEARSON    = 3,
+    MI355REC_SIM_JACCARD    = 4,   /* == "tanimoto" */
+    MI355REC_SIM_DICE       = 5,
+    MI355REC_SIM_TVERSKY    = 6
+};
+
+typedef struct {
+    int32_t topK;            /* 0 = dense output only (.pyx:507-510); clamped to n_cols like .pyx:146 */
+    int32_t shrink;          /* already truncated to int, as `cdef int shrink` does (.pyx:64) */
+    int32_t normalize;
+    int32_t similarity;      /* MI355REC_SIM_* */
+    float   asymmetric_alpha, tversky_alpha, tversky_beta;   /* `cdef float` in the reference (.pyx:65) */
+} mi355rec_sim_config;
+
+typedef struct mi355rec_sim *mi355rec_sim_t;
+
+/* dataMatrix (n_rows x n_cols) as CSR; similarities are computed between its COLUMNS.  row_weights is
+ * nullable (length n_rows).  Pre-processing (mean-centring / binarisation / column norms, .pyx:153-192),
+ * the CSR->CSC transposition (.pyx:198-207) and the cost-ordered column schedule are done on the device. */
+int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, int32_t n_rows, int32_t n_cols,
+                        const int32_t *csr_indptr, const int32_t *csr_indices, const float *csr_data,
+                        const float *row_weights);
+/* Columns [start_col, end_col): for local column c the topK (neighbour, value) pairs in descending value
+ * order at nbr_idx/nbr_val[(c - start_col) * topK ...], padded with (-1, 0).  Zero similarities are never
+ * emitted (.pyx:555). */
+int mi355rec_sim_compute(mi355rec_sim_t h, int32_t start_col, int32_t end_col, int32_t *nbr_idx, float *nbr_val);
+/* Same, results left in device memory (for the RCCL gather of the column-sharded build); asynchronous on
+ * the handle's stream -- call mi355rec_sim_sync before another stream/library reads the buffers. */
+int mi355rec_sim_compute_device(mi355rec_sim_t h, int32_t start_col, int32_t end_col, int32_t *d_nbr_idx, float *d_nbr_val);
+/* topK == 0 variant (.pyx:507-510): W[j * ld + (c - start_col)] = similarity(j, c); W is host, row-major, ld >= end_col-start_col. */
+int mi355rec_sim_compute_dense(mi355rec_sim_t h, int32_t start_col, int32_t end_col, float *W, int64_t ld);
+/* cost(c) = sum over users of column c of their profile length: the work of one column; used to cut
+ * cost-balanced column ranges for multi-GPU sharding. */
+int mi355rec_sim_column_costs(mi355rec_sim_t h, int64_t *cost /* n_cols */);
+int mi355rec_sim_sync(mi355rec_sim_t h);
+int mi355rec_sim_get_stats(mi355rec_sim_t h, mi355rec_stats *stats);
+void mi355rec_sim_destroy(mi355rec_sim_t h);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Matrix-factorisation SGD epochs  (MatrixFactorization/Cython/MatrixFactorization_Cython_Epoch.pyx:50
+ * cdef class MatrixFactorization_Cython_Epoch; __init__ :95-148; epochIteration_Cython :273;
+ * get_USER_factors ... get_GLOBAL_bias :685-702)
+ * ---------------------------------------------------------------------------------------------------- */
+
+enum { MI355REC_MF_BPR = 0, MI355REC_MF_FUNK_SVD = 1 };                       /* algorithm_name (.pyx:93) */
+enum { MI355REC_SGD = 0, MI355REC_ADAGRAD = 1, MI355REC_RMSPROP = 2, MI355REC_ADAM = 3 };  /* sgd_mode (.pyx:92) */
+
+typedef struct {
+    int32_t algorithm;       /* MI355REC_MF_* */
+    int32_t n_factors;
+    int32_t batch_size;
+    int32_t use_bias;
+    int32_t sgd_mode;        /* MI355REC_SGD ... */
+    float   learning_rate;
+    float   user_reg, item_reg, bias_reg, positive_reg, negative_reg;
+    float   negative_interactions_quota;
+    float   gamma, beta_1, beta_2;
+    uint64_t random_seed;    /* seeds the on-device counter-based sampler */
+} mi355rec_mf_config;
+
+typedef struct mi355rec_mf *mi355rec_mf_t;
+
+/* URM (n_users x n_items) as CSR with sorted indices.  U0 (n_users x k) and V0 (n_items x k) are the initial
+ * factors, row-major float32 (the host draws them exactly like .pyx:174-175 does). */
+int mi355rec_mf_create(mi355rec_mf_t *out, const mi355rec_mf_config *cfg, int32_t n_users, int32_t n_items,
+                       const int32_t *indptr, const int32_t *indices, const float *data,
+                       const float *U0, const float *V0);
+/* n_epochs x epochIteration_Cython(): each epoch is n_users/B+1 (BPR, .pyx:583) or nnz/B+1 (FunkSVD, :289)
+ * mini-batches of B samples drawn ON THE DEVICE. */
+int mi355rec_mf_run_epochs(mi355rec_mf_t h, int32_t n_epochs);
+/* Parity mode: the same arithmetic on a caller-provided sample stream, cut into consecutive mini-batches of
+ * batch_size (the last one may be short but is still averaged over batch_size, like .pyx:802).
+ * BPR: (u, i, j); FunkSVD: (u, i, rating) with j == NULL. */
+int mi355rec_mf_run_samples(mi355rec_mf_t h, const int32_t *u, const int32_t *i, const int32_t *j,
+                            const float *rating, int64_t n);
+/* Any output pointer may be NULL.  bu/bi/mu are only written when use_bias. */
+int mi355rec_mf_get_factors(mi355rec_mf_t h, float *U, float *V, float *bu, float *bi, float *mu);
+/* Copy the (u, i, j|rating) stream drawn by the LAST mi355rec_mf_run_epochs call (at most cap entries);
+ * returns the number of samples of that call in *n. */
+int mi355rec_mf_get_last_samples(mi355rec_mf_t h, int32_t *u, int32_t *i, int32_t *j, float *rating, int64_t cap, int64_t *n);
+int mi355rec_mf_get_stats(mi355rec_mf_t h, mi355rec_stats *stats);
+void mi355rec_mf_destroy(mi355rec_mf_t h);
+
+/* ------------------------------------------------------------------------------------------------------
+ * SLIM-BPR epoch  (SLIM_BPR/Cython/SLIM_BPR_Cython_Epoch.pyx:59 cdef class SLIM_BPR_Cython_Epoch;
+ * __init__ :87-135; epochIteration_Cython :212; get_S :343-391; _dealloc :195)
+ * ---------------------------------------------------------------------------------------------------- */
+
+typedef struct {
+    int32_t symmetric;       /* 1: S[i,s] aliases S[s,i] (Triangular_Matrix, .pyx:1290-1330) */
+    int32_t sgd_mode;
+    float   learning_rate, li_reg, lj_reg;
+    float   gamma, beta_1, beta_2;
+    uint64_t random_seed;
+} mi355rec_slim_config;
+
+typedef struct mi355rec_slim *mi355rec_slim_t;
+
+int mi355rec_slim_create(mi355rec_slim_t *out, const mi355rec_slim_config *cfg, int32_t n_users, int32_t n_items,
+                         const int32_t *indptr, const int32_t *indices);
+/* n_epochs x epochIteration_Cython() with the wrapper's batch_size = 1 (SLIM_BPR_Cython.py:140): n_users+1
+ * strictly ordered samples per epoch, drawn on the device and executed in stream order. */
+int mi355rec_slim_run_epochs(mi355rec_slim_t h, int32_t n_epochs);
+int mi355rec_slim_run_samples(mi355rec_slim_t h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t n);
+/* get_S: diagonal zeroed, per-ROW top-K (.pyx:343-391): nbr_idx/nbr_val[(row) * topK ...], descending,
+ * (-1, 0) padded, zeros never emitted. */
+int mi355rec_slim_get_S_topk(mi355rec_slim_t h, int32_t topK, int32_t *nbr_idx, float *nbr_val);
+/* Dense S (n_items x n_items, row-major, diagonal zeroed, symmetric mode mirrored). */
+int mi355rec_slim_get_S_dense(mi355rec_slim_t h, float *S);
+int mi355rec_slim_get_stats(mi355rec_slim_t h, mi355rec_stats *stats);
+void mi355rec_slim_destroy(mi355rec_slim_t h);
+
+/* ------------------------------------------------------------------------------------------------------
+ * IALS solve step  (MatrixFactorization/IALSRecommender.py:137 _run_epoch, :170 _update_row)
+ * ---------------------------------------------------------------------------------------------------- */
+
+typedef struct mi355rec_ials *mi355rec_ials_t;
+
+/* C (confidence, n_users x n_items) as CSR with float32 data = 1 + alpha*r etc. (IALSRecommender.py:111-123,
+ * computed by the host exactly as the reference does).  V0: initial item factors (n_items x k); U0: initial
+ * user factors (only cold users keep them; nullable = zeros). */
+int mi355rec_ials_create(mi355rec_ials_t *out, int32_t n_users, int32_t n_items, int32_t n_factors, double reg,
+                         const int32_t *indptr, const int32_t *indices, const float *confidence,
+                         const double *U0, const double *V0);
+/* Restrict the row solves of subsequent epochs to users [u0,u1) and items [i0,i1) (multi-GPU sharding);
+ * the caller all-gathers the factor shards between the two half-steps through the *_half entry points. */
+int mi355rec_ials_run_epochs(mi355rec_ials_t h, int32_t n_epochs);
+int mi355rec_ials_user_half(mi355rec_ials_t h, int32_t u0, int32_t u1);
+int mi355rec_ials_item_half(mi355rec_ials_t h, int32_t i0, int32_t i1);
+/* Device pointers to the float64 factor matrices (n_users x k, n_items x k), for the RCCL all-gather. */
+int mi355rec_ials_device_factors(mi355rec_ials_t h, double **d_U, double **d_V);
+int mi355rec_ials_sync(mi355rec_ials_t h);
+int mi355rec_ials_get_factors(mi355rec_ials_t h, double *U, double *V);
+int mi355rec_ials_get_stats(mi355rec_ials_t h, mi355rec_stats *stats);
+void mi355rec_ials_destroy(mi355rec_ials_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355REC_H */

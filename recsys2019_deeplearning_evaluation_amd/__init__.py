@@ -1,0 +1,14 @@
+"""MI355X-native (gfx950) training kernels for the baseline recommenders of
+MaurizioFD/RecSys2019_DeepLearning_Evaluation, behind the reference's own recommender surface.
+
+Hot path only: Compute_Similarity (ItemKNN build), BPR-MF / FunkSVD SGD epochs, SLIM-BPR epoch,
+IALS solve step.  Python host code + ctypes C-ABI (include/mi355rec.h) + hand-written HIP kernels (csrc/).
+Nothing here imports torch; torch.distributed is only used by `sharding` for the multi-GPU gather.
+"""
+from .similarity import Compute_Similarity, Compute_Similarity_MI355X  # noqa: F401
+from .knn import ItemKNNCFRecommender, UserKNNCFRecommender  # noqa: F401
+from .matrix_factorization import (MatrixFactorization_MI355X_Epoch, MatrixFactorization_BPR_MI355X,  # noqa: F401
+                                   MatrixFactorization_FunkSVD_MI355X)
+
+__all__ = ["Compute_Similarity", "Compute_Similarity_MI355X", "ItemKNNCFRecommender", "UserKNNCFRecommender",
+           "MatrixFactorization_MI355X_Epoch", "MatrixFactorization_BPR_MI355X", "MatrixFactorization_FunkSVD_MI355X"]

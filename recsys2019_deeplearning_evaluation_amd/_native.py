@@ -1,0 +1,166 @@
+"""ctypes binding of libmi355rec.so (C ABI declared in include/mi355rec.h).
+
+There is NO CPU fallback: if the shared library is missing, or no gfx950 device is visible when a handle is
+created, the call raises.  The library is only dlopen()ed on first use and the HIP context is only created
+by the first *_create call, so importing this package before a fork (the reference's hyper-parameter search
+forks one worker per configuration, ParameterTuning/run_parameter_search.py:498) is safe.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355rec.so")
+
+E_INVALID, E_HIP, E_NO_DEVICE, E_UNSUPPORTED, E_NUMERIC = -1, -2, -3, -4, -5
+
+SIMILARITY_CODES = {"cosine": 0, "adjusted": 1, "asymmetric": 2, "pearson": 3, "jaccard": 4, "tanimoto": 4,
+                    "dice": 5, "tversky": 6}
+SGD_MODE_CODES = {"sgd": 0, "adagrad": 1, "rmsprop": 2, "adam": 3}
+ALGORITHM_CODES = {"MF_BPR": 0, "FUNK_SVD": 1}
+
+
+class NativeLibraryError(RuntimeError):
+    """libmi355rec.so is missing, or the HIP runtime / device failed."""
+
+
+class Stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("n_launches", C.c_int64), ("n_units", C.c_int64),
+                ("algorithmic_bytes", C.c_double), ("algorithmic_flops", C.c_double), ("loss", C.c_double)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class SimConfig(C.Structure):
+    _fields_ = [("topK", C.c_int32), ("shrink", C.c_int32), ("normalize", C.c_int32), ("similarity", C.c_int32),
+                ("asymmetric_alpha", C.c_float), ("tversky_alpha", C.c_float), ("tversky_beta", C.c_float)]
+
+
+class MFConfig(C.Structure):
+    _fields_ = [("algorithm", C.c_int32), ("n_factors", C.c_int32), ("batch_size", C.c_int32),
+                ("use_bias", C.c_int32), ("sgd_mode", C.c_int32), ("learning_rate", C.c_float),
+                ("user_reg", C.c_float), ("item_reg", C.c_float), ("bias_reg", C.c_float),
+                ("positive_reg", C.c_float), ("negative_reg", C.c_float),
+                ("negative_interactions_quota", C.c_float),
+                ("gamma", C.c_float), ("beta_1", C.c_float), ("beta_2", C.c_float),
+                ("random_seed", C.c_uint64)]
+
+
+class SlimConfig(C.Structure):
+    _fields_ = [("symmetric", C.c_int32), ("sgd_mode", C.c_int32), ("learning_rate", C.c_float),
+                ("li_reg", C.c_float), ("lj_reg", C.c_float),
+                ("gamma", C.c_float), ("beta_1", C.c_float), ("beta_2", C.c_float), ("random_seed", C.c_uint64)]
+
+
+_vp = C.c_void_p
+_i32, _i64, _f32, _f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
+
+# name -> (restype, argtypes); must list every symbol declared in include/mi355rec.h
+SIGNATURES = {
+    "mi355rec_last_error": (C.c_char_p, []),
+    "mi355rec_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mi355rec_set_device": (C.c_int, [C.c_int]),
+    "mi355rec_device_name": (C.c_int, [C.c_char_p, C.c_int]),
+    "mi355rec_sim_create": (C.c_int, [C.POINTER(_vp), C.POINTER(SimConfig), _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mi355rec_sim_compute": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "mi355rec_sim_compute_device": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "mi355rec_sim_compute_dense": (C.c_int, [_vp, _i32, _i32, _vp, _i64]),
+    "mi355rec_sim_column_costs": (C.c_int, [_vp, _vp]),
+    "mi355rec_sim_sync": (C.c_int, [_vp]),
+    "mi355rec_sim_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "mi355rec_sim_destroy": (None, [_vp]),
+    "mi355rec_mf_create": (C.c_int, [C.POINTER(_vp), C.POINTER(MFConfig), _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mi355rec_mf_run_epochs": (C.c_int, [_vp, _i32]),
+    "mi355rec_mf_run_samples": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64]),
+    "mi355rec_mf_get_factors": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi355rec_mf_get_last_samples": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
+    "mi355rec_mf_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "mi355rec_mf_destroy": (None, [_vp]),
+    "mi355rec_slim_create": (C.c_int, [C.POINTER(_vp), C.POINTER(SlimConfig), _i32, _i32, _vp, _vp]),
+    "mi355rec_slim_run_epochs": (C.c_int, [_vp, _i32]),
+    "mi355rec_slim_run_samples": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
+    "mi355rec_slim_get_S_topk": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "mi355rec_slim_get_S_dense": (C.c_int, [_vp, _vp]),
+    "mi355rec_slim_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "mi355rec_slim_destroy": (None, [_vp]),
+    "mi355rec_ials_create": (C.c_int, [C.POINTER(_vp), _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp]),
+    "mi355rec_ials_run_epochs": (C.c_int, [_vp, _i32]),
+    "mi355rec_ials_user_half": (C.c_int, [_vp, _i32, _i32]),
+    "mi355rec_ials_item_half": (C.c_int, [_vp, _i32, _i32]),
+    "mi355rec_ials_device_factors": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "mi355rec_ials_sync": (C.c_int, [_vp]),
+    "mi355rec_ials_get_factors": (C.c_int, [_vp, _vp, _vp]),
+    "mi355rec_ials_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "mi355rec_ials_destroy": (None, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libmi355rec.so (built by __graft_entry__.build() / `make -C csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise NativeLibraryError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, exc)) from exc
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header and library out of sync
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Map a C-ABI return code to the exception the reference would raise at the same point."""
+    if rc == 0:
+        return
+    msg = load().mi355rec_last_error().decode("utf-8", "replace")
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    if rc == E_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == E_NUMERIC:
+        raise FloatingPointError(msg)
+    raise NativeLibraryError(msg)
+
+
+def ptr(array):
+    """Host pointer of a C-contiguous ndarray (or None)."""
+    if array is None:
+        return None
+    assert array.flags["C_CONTIGUOUS"]
+    return array.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().mi355rec_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(index):
+    check(load().mi355rec_set_device(int(index)))
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    check(load().mi355rec_device_name(buf, 256))
+    return buf.value.decode()
+
+
+def as_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def as_f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)

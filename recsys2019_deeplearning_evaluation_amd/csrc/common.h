@@ -1,0 +1,116 @@
+// common.h -- shared host-side helpers of libmi355rec.so (error reporting, device buffers, timing).
+// gfx950 only; no CUDA path, no compatibility macros.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355rec.h"
+
+namespace mi355rec {
+
+// ---- error plumbing --------------------------------------------------------------------------------
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const char *msg);
+[[noreturn]] void fail(int code, const char *fmt, ...);
+
+#define MI_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            ::mi355rec::fail(MI355REC_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                             __FILE__, __LINE__);                                                     \
+    } while (0)
+
+#define MI_REQUIRE(cond, ...)                                                                         \
+    do {                                                                                              \
+        if (!(cond)) ::mi355rec::fail(MI355REC_E_INVALID, __VA_ARGS__);                               \
+    } while (0)
+
+// Wraps the body of every extern "C" entry point: exceptions never cross the C ABI.
+template <class F>
+static inline int guarded(F &&f) {
+    try {
+        f();
+        return MI355REC_OK;
+    } catch (const Error &e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return MI355REC_E_HIP;
+    }
+}
+
+// Lazily binds this process to its device (mi355rec_set_device or device 0) and checks that it is gfx950.
+void ensure_device();
+int multiprocessor_count();
+
+// ---- device memory ---------------------------------------------------------------------------------
+template <class T>
+struct DeviceBuffer {
+    T *ptr = nullptr;
+    size_t count = 0;
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    ~DeviceBuffer() { release(); }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+    void alloc(size_t n) {
+        release();
+        count = n;
+        if (n) MI_HIP(hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T)));
+    }
+    void alloc_zero(size_t n, hipStream_t s) {
+        alloc(n);
+        if (n) MI_HIP(hipMemsetAsync(ptr, 0, n * sizeof(T), s));
+    }
+    void upload(const T *host, size_t n, hipStream_t s) {
+        alloc(n);
+        if (n) MI_HIP(hipMemcpyAsync(ptr, host, n * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void download(T *host, size_t n, hipStream_t s) const {
+        if (n) MI_HIP(hipMemcpyAsync(host, ptr, n * sizeof(T), hipMemcpyDeviceToHost, s));
+    }
+};
+
+// ---- event-pair timer on a stream -------------------------------------------------------------------
+struct StreamTimer {
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    void init() {
+        MI_HIP(hipEventCreate(&t0));
+        MI_HIP(hipEventCreate(&t1));
+    }
+    void destroy() {
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+        t0 = t1 = nullptr;
+    }
+    void start(hipStream_t s) { MI_HIP(hipEventRecord(t0, s)); }
+    void stop(hipStream_t s) { MI_HIP(hipEventRecord(t1, s)); }
+    // valid after the stream has been synchronised past stop()
+    double elapsed_ms() const {
+        float ms = 0.f;
+        MI_HIP(hipEventElapsedTime(&ms, t0, t1));
+        return ms;
+    }
+};
+
+static inline int div_up(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
+
+}  // namespace mi355rec

@@ -1,0 +1,576 @@
+// mf.hip -- BPR-MF and FunkSVD mini-batch SGD epochs on MI355X (gfx950).
+//
+// Replaces MatrixFactorization/Cython/MatrixFactorization_Cython_Epoch.pyx (reference):
+//   epochIteration_Cython_BPR_SGD :580-649, epochIteration_Cython_FUNK_SVD_SGD :286-361,
+//   sampleBPR_Cython :940-985, sampleMSE_Cython :878-935, _add_*_sample_in_minibatch :737-766,
+//   _apply_minibatch_updates_to_latent_factors :770-829, adaptive_gradient :835-873.
+//
+// Design.  The reference's mini-batch semantics make the B samples of a batch independent:
+// every gradient is taken against start-of-batch factors, summed per row, and the sum is applied once.
+// That maps to two kernels per mini-batch:
+//   mf_grad_kernel   one 64-lane wavefront per sample: on-device sampling (counter-based RNG, rejection
+//                    against the sorted CSR row by binary search), row gather, wavefront-shuffle dot product,
+//                    gradient rows scattered into the fp32 accumulators with device-scope float atomics,
+//                    first-toucher registers the row in the batch's touched list (the reference's flag arrays);
+//   mf_apply_kernel  one wavefront per touched row: mean over batch_size, optimiser step, += lr * step,
+//                    accumulator and flag reset.
+// There is no dense contraction here, hence no MFMA; the path is bound by row gather/scatter bandwidth and,
+// at the reference's batch sizes (<= 1024), by the dependent-launch latency between mini-batches.
+#include "common.h"
+
+#include <memory>
+
+namespace mi355rec {
+namespace {
+
+struct MfState {           // lives in device memory so that launches carry no per-batch host arguments
+    long long grad_batch;  // index (since create) of the batch the next grad kernel works on
+    long long apply_batch; // same for the next apply kernel
+    unsigned touched[2];   // number of rows in the touched list, by batch parity
+    double loss;           // cumulative x_uij^2 / err^2 of the current call
+};
+
+struct MfParams {
+    int n_users, n_items, k, batch_size;
+    int use_bias, sgd_mode, sample_negatives;
+    float lr, user_reg, bias_reg, positive_reg, negative_reg, quota, gamma, beta_1, beta_2;
+    unsigned long long seed;
+    const int *indptr, *indices;
+    const float *data;
+    float *U, *V, *accU, *accV;
+    float *bu, *bi, *mu, *acc_bu, *acc_bi, *acc_mu;
+    float *c1U, *c2U, *c1V, *c2V;        // optimiser state: c1 = cache / first moment, c2 = second moment
+    float *c1_bu, *c2_bu, *c1_bi, *c2_bi, *c_mu;  // c_mu[0] = cache/m1, c_mu[1] = m2
+    int *flag;                           // [n_users + n_items]
+    int *list;                           // touched rows of the batch (items are stored as n_users + item)
+    MfState *state;
+    // sample stream of the current call (recorded in native mode, consumed in replay mode)
+    int *su, *si, *sj;
+    float *sr;
+    long long stream_base;               // batch index (since create) at which the current call started
+    long long record_period;             // native mode: samples are recorded modulo one epoch
+    int n_in_batch;                      // replay: samples in this launch's batch (<= batch_size)
+};
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// draw number `d` of sample `sid`: stateless, so every lane of the wavefront computes the same value
+__device__ __forceinline__ unsigned draw32(unsigned long long seed, unsigned long long sid, unsigned d) {
+    return (unsigned)(mix64(seed ^ mix64(sid * 0xD1B54A32D192ED03ull + d)) >> 32);
+}
+__device__ __forceinline__ int bounded(unsigned r, int n) { return (int)(((unsigned long long)r * (unsigned)n) >> 32); }
+
+// is `item` absent from the sorted profile [row, row + n)?  (the reference scans linearly, .pyx:975-983)
+__device__ __forceinline__ bool profile_lacks(const int *row, int n, int item) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (row[mid] < item) lo = mid + 1; else hi = mid;
+    }
+    return lo == n || row[lo] != item;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ void touch(const MfParams &p, int entry, unsigned parity) {
+    if (atomicExch(&p.flag[entry], 1) == 0) {
+        unsigned at = atomicAdd(&p.state->touched[parity], 1u);
+        p.list[at] = entry;
+    }
+}
+
+// KI = ceil(k / 64) rows-in-registers specialisation (1..4); KI == 0: any k, rows are re-read for the scatter.
+template <int ALGO, bool REPLAY, int KI>
+__global__ __launch_bounds__(256) void mf_grad_kernel(const MfParams p) {
+    __shared__ double s_loss[4];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int w = blockIdx.x * 4 + wib;                  // sample slot inside the batch
+    const long long batch = p.state->grad_batch;
+    const unsigned parity = (unsigned)(batch & 1);
+    const int n_here = REPLAY ? p.n_in_batch : p.batch_size;
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.state->apply_batch = batch;   // consumed by the apply kernel that follows
+    double my_loss = 0.0;
+    if (w < n_here) {
+        const long long sid = batch * (long long)p.batch_size + w;          // global sample id
+        const long long slot = (batch - p.stream_base) * (long long)p.batch_size + w;
+        int u, i, j = -1;
+        float rating = 0.f;
+        if (REPLAY) {
+            u = p.su[slot];
+            i = p.si[slot];
+            if (ALGO == MI355REC_MF_BPR) j = p.sj[slot]; else rating = p.sr[slot];
+        } else {
+            unsigned d = 0;
+            int start = 0, n_seen = 0;
+            do {   // users with no interactions or with no negative item are skipped (.pyx:950-958)
+                u = bounded(draw32(p.seed, sid, d++), p.n_users);
+                start = p.indptr[u];
+                n_seen = p.indptr[u + 1] - start;
+            } while (n_seen == 0 || n_seen == p.n_items);
+            const int *row = p.indices + start;
+            if (ALGO == MI355REC_MF_BPR) {
+                i = row[bounded(draw32(p.seed, sid, d++), n_seen)];
+                do { j = bounded(draw32(p.seed, sid, d++), p.n_items); } while (!profile_lacks(row, n_seen, j));
+            } else {
+                // .pyx:898: a POSITIVE is drawn with probability `quota` (sic); no quota -> always positive
+                bool positive = true;
+                if (p.sample_negatives) positive = (float)draw32(p.seed, sid, d++) * 2.3283064365386963e-10f <= p.quota;
+                if (positive) {
+                    int at = bounded(draw32(p.seed, sid, d++), n_seen);
+                    i = row[at];
+                    rating = p.data[start + at];
+                } else {
+                    do { i = bounded(draw32(p.seed, sid, d++), p.n_items); } while (!profile_lacks(row, n_seen, i));
+                    rating = 0.f;
+                }
+            }
+            if (lane == 0) {
+                const long long rec = slot % p.record_period;
+                p.su[rec] = u;
+                p.si[rec] = i;
+                if (ALGO == MI355REC_MF_BPR) p.sj[rec] = j; else p.sr[rec] = rating;
+            }
+        }
+        if (lane == 0) {   // _add_*_sample_in_minibatch (.pyx:737-766)
+            touch(p, p.n_users + i, parity);
+            if (ALGO == MI355REC_MF_BPR) touch(p, p.n_users + j, parity);
+            touch(p, u, parity);
+        }
+        const int k = p.k;
+        const float *Wu = p.U + (size_t)u * k, *Hi = p.V + (size_t)i * k;
+        float *aU = p.accU + (size_t)u * k, *aI = p.accV + (size_t)i * k;
+        if (ALGO == MI355REC_MF_BPR) {
+            const float *Hj = p.V + (size_t)j * k;
+            float *aJ = p.accV + (size_t)j * k;
+            float wu[KI ? KI : 1], hi[KI ? KI : 1], hj[KI ? KI : 1];
+            float x = 0.f;
+            if (KI) {
+#pragma unroll
+                for (int t = 0; t < KI; ++t) {
+                    const int f = lane + 64 * t;
+                    const bool ok = f < k;
+                    wu[t] = ok ? Wu[f] : 0.f;
+                    hi[t] = ok ? Hi[f] : 0.f;
+                    hj[t] = ok ? Hj[f] : 0.f;
+                    x += wu[t] * (hi[t] - hj[t]);
+                }
+            } else {
+                for (int f = lane; f < k; f += 64) x += Wu[f] * (Hi[f] - Hj[f]);
+            }
+            x = wave_sum(x);
+            const float s = 1.f / (1.f + __expf(x));          // gradient of log(sigm(-x_uij)), .pyx:619
+            my_loss = (double)x * x;
+            if (KI) {
+#pragma unroll
+                for (int t = 0; t < KI; ++t) {
+                    const int f = lane + 64 * t;
+                    if (f < k) {
+                        atomicAdd(&aU[f], s * (hi[t] - hj[t]) - p.user_reg * wu[t]);
+                        atomicAdd(&aI[f], s * wu[t] - p.positive_reg * hi[t]);
+                        atomicAdd(&aJ[f], -s * wu[t] - p.negative_reg * hj[t]);
+                    }
+                }
+            } else {
+                for (int f = lane; f < k; f += 64) {
+                    const float a = Wu[f], b = Hi[f], c = Hj[f];
+                    atomicAdd(&aU[f], s * (b - c) - p.user_reg * a);
+                    atomicAdd(&aI[f], s * a - p.positive_reg * b);
+                    atomicAdd(&aJ[f], -s * a - p.negative_reg * c);
+                }
+            }
+        } else {
+            float wu[KI ? KI : 1], hi[KI ? KI : 1];
+            float dot = 0.f;
+            if (KI) {
+#pragma unroll
+                for (int t = 0; t < KI; ++t) {
+                    const int f = lane + 64 * t;
+                    const bool ok = f < k;
+                    wu[t] = ok ? Wu[f] : 0.f;
+                    hi[t] = ok ? Hi[f] : 0.f;
+                    dot += wu[t] * hi[t];
+                }
+            } else {
+                for (int f = lane; f < k; f += 64) dot += Wu[f] * Hi[f];
+            }
+            dot = wave_sum(dot);
+            float pred = dot;
+            if (p.use_bias) pred += p.mu[0] + p.bu[u] + p.bi[i];
+            const float err = rating - pred;
+            my_loss = (double)err * err;
+            if (p.use_bias && lane == 0) {   // .pyx:329-336
+                atomicAdd(p.acc_mu, err - p.bias_reg * p.mu[0]);
+                atomicAdd(&p.acc_bi[i], err - p.bias_reg * p.bi[i]);
+                atomicAdd(&p.acc_bu[u], err - p.bias_reg * p.bu[u]);
+            }
+            // NB the item gradient is regularised with positive_reg (sic, .pyx:346), never item_reg
+            if (KI) {
+#pragma unroll
+                for (int t = 0; t < KI; ++t) {
+                    const int f = lane + 64 * t;
+                    if (f < k) {
+                        atomicAdd(&aI[f], err * wu[t] - p.positive_reg * hi[t]);
+                        atomicAdd(&aU[f], err * hi[t] - p.user_reg * wu[t]);
+                    }
+                }
+            } else {
+                for (int f = lane; f < k; f += 64) {
+                    const float a = Wu[f], b = Hi[f];
+                    atomicAdd(&aI[f], err * a - p.positive_reg * b);
+                    atomicAdd(&aU[f], err * b - p.user_reg * a);
+                }
+            }
+        }
+    }
+    if (lane == 0) s_loss[wib] = my_loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
+        if (t != 0.0) atomicAdd(&p.state->loss, t);
+    }
+}
+
+// adaptive_gradient (.pyx:835-873) on one cell; pw1/pw2 = 1 - beta^t
+__device__ __forceinline__ float adapt(const MfParams &p, float g, float *c1, float *c2, size_t at, float pw1, float pw2) {
+    switch (p.sgd_mode) {
+        case MI355REC_ADAGRAD: {
+            float c = c1[at] + g * g;
+            c1[at] = c;
+            return g / (sqrtf(c) + 1e-8f);
+        }
+        case MI355REC_RMSPROP: {
+            float c = c1[at] * p.gamma + (1.f - p.gamma) * (g * g);
+            c1[at] = c;
+            return g / (sqrtf(c) + 1e-8f);
+        }
+        case MI355REC_ADAM: {
+            float m1 = c1[at] * p.beta_1 + (1.f - p.beta_1) * g;
+            float m2 = c2[at] * p.beta_2 + (1.f - p.beta_2) * (g * g);
+            c1[at] = m1;
+            c2[at] = m2;
+            return (m1 / pw1) / (sqrtf(m2 / pw2) + 1e-8f);
+        }
+        default:
+            return g;
+    }
+}
+
+// _apply_minibatch_updates_to_latent_factors (.pyx:770-829): one wavefront per touched row.
+__global__ __launch_bounds__(256) void mf_apply_kernel(const MfParams p) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long batch = p.state->apply_batch;
+    const unsigned parity = (unsigned)(batch & 1);
+    const unsigned n_touched = p.state->touched[parity];
+    const float invB = 1.f / (float)p.batch_size;      // mean over batch_size, NOT over the row's count (.pyx:802)
+    float pw1 = 1.f, pw2 = 1.f;
+    if (p.sgd_mode == MI355REC_ADAM) {                  // beta^(t) with t = batch + 1 (.pyx:217-218, :646-649)
+        pw1 = (float)(1.0 - pow((double)p.beta_1, (double)(batch + 1)));
+        pw2 = (float)(1.0 - pow((double)p.beta_2, (double)(batch + 1)));
+    }
+    if (w == 0 && lane == 0) {
+        if (p.use_bias) {
+            float g = adapt(p, p.acc_mu[0] * invB, p.c_mu, p.c_mu + 1, 0, pw1, pw2);
+            p.mu[0] += p.lr * g;
+            p.acc_mu[0] = 0.f;
+        }
+        p.state->touched[parity ^ 1u] = 0;              // list of the NEXT batch starts empty
+        p.state->grad_batch = batch + 1;
+    }
+    if ((unsigned)w >= n_touched) return;
+    const int entry = p.list[w];
+    const bool is_item = entry >= p.n_users;
+    const int row = is_item ? entry - p.n_users : entry;
+    const int k = p.k;
+    float *W = (is_item ? p.V : p.U) + (size_t)row * k;
+    float *A = (is_item ? p.accV : p.accU) + (size_t)row * k;
+    float *c1 = is_item ? p.c1V : p.c1U, *c2 = is_item ? p.c2V : p.c2U;
+    for (int f = lane; f < k; f += 64) {
+        float g = A[f] * invB;
+        g = adapt(p, g, c1, c2, (size_t)row * k + f, pw1, pw2);
+        W[f] += p.lr * g;
+        A[f] = 0.f;
+    }
+    if (lane == 0) {
+        if (p.use_bias) {
+            float *b = is_item ? p.bi : p.bu, *ab = is_item ? p.acc_bi : p.acc_bu;
+            float *b1 = is_item ? p.c1_bi : p.c1_bu, *b2 = is_item ? p.c2_bi : p.c2_bu;
+            float g = adapt(p, ab[row] * invB, b1, b2, (size_t)row, pw1, pw2);
+            b[row] += p.lr * g;
+            ab[row] = 0.f;
+        }
+        p.flag[entry] = 0;
+    }
+}
+
+}  // namespace
+}  // namespace mi355rec
+
+using namespace mi355rec;
+
+struct mi355rec_mf {
+    mi355rec_mf_config cfg{};
+    int n_users = 0, n_items = 0, k = 0;
+    size_t nnz = 0;
+    hipStream_t stream = nullptr;
+    StreamTimer timer;
+    DeviceBuffer<int> indptr, indices, flag, list, su, si, sj;
+    DeviceBuffer<float> data, U, V, accU, accV, bu, bi, mu, acc_bu, acc_bi, acc_mu;
+    DeviceBuffer<float> c1U, c2U, c1V, c2V, c1_bu, c2_bu, c1_bi, c2_bi, c_mu, sr;
+    DeviceBuffer<MfState> state;
+    long long batches_done = 0;      // batches executed since create (device state mirrors this)
+    long long last_call_samples = 0; // samples of the last native call
+    long long record_period = 0;
+    size_t stream_capacity = 0;
+    mi355rec_stats stats{};
+    bool timer_valid = false;
+};
+
+namespace {
+
+void fill_params(mi355rec_mf *h, MfParams &p) {
+    const auto &c = h->cfg;
+    p.n_users = h->n_users; p.n_items = h->n_items; p.k = h->k; p.batch_size = c.batch_size;
+    p.use_bias = c.use_bias && c.algorithm == MI355REC_MF_FUNK_SVD;
+    p.sgd_mode = c.sgd_mode;
+    p.sample_negatives = c.negative_interactions_quota != 0.f;
+    p.lr = c.learning_rate; p.user_reg = c.user_reg; p.bias_reg = c.bias_reg;
+    p.positive_reg = c.positive_reg; p.negative_reg = c.negative_reg; p.quota = c.negative_interactions_quota;
+    p.gamma = c.gamma; p.beta_1 = c.beta_1; p.beta_2 = c.beta_2;
+    p.seed = c.random_seed;
+    p.indptr = h->indptr.ptr; p.indices = h->indices.ptr; p.data = h->data.ptr;
+    p.U = h->U.ptr; p.V = h->V.ptr; p.accU = h->accU.ptr; p.accV = h->accV.ptr;
+    p.bu = h->bu.ptr; p.bi = h->bi.ptr; p.mu = h->mu.ptr;
+    p.acc_bu = h->acc_bu.ptr; p.acc_bi = h->acc_bi.ptr; p.acc_mu = h->acc_mu.ptr;
+    p.c1U = h->c1U.ptr; p.c2U = h->c2U.ptr; p.c1V = h->c1V.ptr; p.c2V = h->c2V.ptr;
+    p.c1_bu = h->c1_bu.ptr; p.c2_bu = h->c2_bu.ptr; p.c1_bi = h->c1_bi.ptr; p.c2_bi = h->c2_bi.ptr; p.c_mu = h->c_mu.ptr;
+    p.flag = h->flag.ptr; p.list = h->list.ptr; p.state = h->state.ptr;
+    p.su = h->su.ptr; p.si = h->si.ptr; p.sj = h->sj.ptr; p.sr = h->sr.ptr;
+    p.stream_base = h->batches_done;
+    p.record_period = h->record_period > 0 ? h->record_period : 1;
+    p.n_in_batch = c.batch_size;
+}
+
+template <int ALGO, bool REPLAY>
+void launch_grad_ki(mi355rec_mf *h, const MfParams &p, int grid) {
+    const int ki = h->k <= 256 ? (h->k + 63) / 64 : 0;
+    switch (ki) {
+        case 1: hipLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 1>), dim3(grid), dim3(256), 0, h->stream, p); break;
+        case 2: hipLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 2>), dim3(grid), dim3(256), 0, h->stream, p); break;
+        case 3: hipLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 3>), dim3(grid), dim3(256), 0, h->stream, p); break;
+        case 4: hipLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 4>), dim3(grid), dim3(256), 0, h->stream, p); break;
+        default: hipLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 0>), dim3(grid), dim3(256), 0, h->stream, p); break;
+    }
+}
+
+void launch_batch(mi355rec_mf *h, const MfParams &p, bool replay) {
+    const int grad_grid = div_up(p.n_in_batch, 4);
+    const bool bpr = h->cfg.algorithm == MI355REC_MF_BPR;
+    if (bpr) {
+        if (replay) launch_grad_ki<MI355REC_MF_BPR, true>(h, p, grad_grid);
+        else launch_grad_ki<MI355REC_MF_BPR, false>(h, p, grad_grid);
+    } else {
+        if (replay) launch_grad_ki<MI355REC_MF_FUNK_SVD, true>(h, p, grad_grid);
+        else launch_grad_ki<MI355REC_MF_FUNK_SVD, false>(h, p, grad_grid);
+    }
+    const int max_touched = (bpr ? 3 : 2) * p.n_in_batch;
+    hipLaunchKernelGGL(mf_apply_kernel, dim3(div_up(max_touched, 4)), dim3(256), 0, h->stream, p);
+}
+
+void ensure_stream_capacity(mi355rec_mf *h, size_t n) {
+    if (h->stream_capacity >= n) return;
+    h->su.alloc(n);
+    h->si.alloc(n);
+    h->sj.alloc(n);
+    h->sr.alloc(n);
+    h->stream_capacity = n;
+}
+
+double bytes_per_sample(const mi355rec_mf *h) {
+    // ALGORITHMIC lower bound of DESIGN.md section 4: every row a sample touches is read once and written once
+    // (3 rows for BPR, 2 for FunkSVD), fp32.
+    const double rows = h->cfg.algorithm == MI355REC_MF_BPR ? 3.0 : 2.0;
+    return rows * 2.0 * 4.0 * (double)h->k;
+}
+
+void finish_call(mi355rec_mf *h, long long n_samples, long long n_batches) {
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(h->stream));
+    MfState st{};
+    MI_HIP(hipMemcpy(&st, h->state.ptr, sizeof(MfState), hipMemcpyDeviceToHost));
+    h->stats.kernel_ms = h->timer.elapsed_ms();
+    h->stats.n_launches = n_batches;            // launches of the dominant (gradient) kernel
+    h->stats.n_units = n_samples;
+    h->stats.algorithmic_bytes = bytes_per_sample(h) * (double)n_samples;
+    h->stats.algorithmic_flops = 0;
+    h->stats.loss = st.loss;
+}
+
+}  // namespace
+
+extern "C" int mi355rec_mf_create(mi355rec_mf_t *out, const mi355rec_mf_config *cfg, int32_t n_users, int32_t n_items,
+                                  const int32_t *indptr, const int32_t *indices, const float *data, const float *U0,
+                                  const float *V0) {
+    return guarded([&] {
+        MI_REQUIRE(out && cfg && indptr && indices && data && U0 && V0, "NULL argument");
+        MI_REQUIRE(n_users > 0 && n_items > 0, "empty URM");
+        MI_REQUIRE(cfg->algorithm == MI355REC_MF_BPR || cfg->algorithm == MI355REC_MF_FUNK_SVD,
+                   "Value for 'algorithm_name' not recognized (%d)", cfg->algorithm);
+        MI_REQUIRE(cfg->sgd_mode >= MI355REC_SGD && cfg->sgd_mode <= MI355REC_ADAM, "Value for 'sgd_mode' not recognized (%d)",
+                   cfg->sgd_mode);
+        MI_REQUIRE(cfg->n_factors >= 1, "n_factors must be >= 1");
+        MI_REQUIRE(cfg->batch_size >= 1, "batch_size must be >= 1");
+        ensure_device();
+        std::unique_ptr<mi355rec_mf> h(new mi355rec_mf());
+        h->cfg = *cfg;
+        h->n_users = n_users;
+        h->n_items = n_items;
+        h->k = cfg->n_factors;
+        h->nnz = (size_t)indptr[n_users];
+        MI_REQUIRE(h->nnz > 0, "URM has no interactions");
+        MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->timer.init();
+        hipStream_t s = h->stream;
+        const size_t nu = (size_t)n_users * h->k, ni = (size_t)n_items * h->k;
+        h->indptr.upload(indptr, (size_t)n_users + 1, s);
+        h->indices.upload(indices, h->nnz, s);
+        h->data.upload(data, h->nnz, s);
+        h->U.upload(U0, nu, s);
+        h->V.upload(V0, ni, s);
+        h->accU.alloc_zero(nu, s);
+        h->accV.alloc_zero(ni, s);
+        h->bu.alloc_zero(n_users, s);
+        h->bi.alloc_zero(n_items, s);
+        h->mu.alloc_zero(1, s);
+        h->acc_bu.alloc_zero(n_users, s);
+        h->acc_bi.alloc_zero(n_items, s);
+        h->acc_mu.alloc_zero(1, s);
+        if (cfg->sgd_mode != MI355REC_SGD) {
+            h->c1U.alloc_zero(nu, s);
+            h->c1V.alloc_zero(ni, s);
+            h->c1_bu.alloc_zero(n_users, s);
+            h->c1_bi.alloc_zero(n_items, s);
+            h->c_mu.alloc_zero(2, s);
+            if (cfg->sgd_mode == MI355REC_ADAM) {
+                h->c2U.alloc_zero(nu, s);
+                h->c2V.alloc_zero(ni, s);
+                h->c2_bu.alloc_zero(n_users, s);
+                h->c2_bi.alloc_zero(n_items, s);
+            }
+        }
+        h->flag.alloc_zero((size_t)n_users + n_items, s);
+        h->list.alloc((size_t)cfg->batch_size * 3);
+        h->state.alloc_zero(1, s);
+        MI_HIP(hipStreamSynchronize(s));
+        *out = h.release();
+    });
+}
+
+extern "C" int mi355rec_mf_run_epochs(mi355rec_mf_t h, int32_t n_epochs) {
+    return guarded([&] {
+        MI_REQUIRE(h, "NULL handle");
+        MI_REQUIRE(n_epochs >= 0, "n_epochs must be >= 0");
+        ensure_device();
+        const long long B = h->cfg.batch_size;
+        // number of mini-batches per epoch: .pyx:583 (BPR) / :289 (FunkSVD)
+        const long long per_epoch = (h->cfg.algorithm == MI355REC_MF_BPR ? (long long)h->n_users / B : (long long)h->nnz / B) + 1;
+        const long long n_batches = per_epoch * n_epochs;
+        h->record_period = per_epoch * B;
+        ensure_stream_capacity(h, (size_t)h->record_period);
+        MfParams p{};
+        fill_params(h, p);
+        MI_HIP(hipMemsetAsync(&h->state.ptr->loss, 0, sizeof(double), h->stream));
+        h->timer.start(h->stream);
+        for (long long b = 0; b < n_batches; ++b) launch_batch(h, p, false);
+        h->timer.stop(h->stream);
+        h->batches_done += n_batches;
+        h->last_call_samples = std::min<long long>(n_batches, per_epoch) * B;
+        finish_call(h, n_batches * B, n_batches);
+    });
+}
+
+extern "C" int mi355rec_mf_run_samples(mi355rec_mf_t h, const int32_t *u, const int32_t *i, const int32_t *j,
+                                       const float *rating, int64_t n) {
+    return guarded([&] {
+        MI_REQUIRE(h && u && i, "NULL argument");
+        const bool bpr = h->cfg.algorithm == MI355REC_MF_BPR;
+        MI_REQUIRE(bpr ? j != nullptr : rating != nullptr, "%s", bpr ? "BPR replay needs the negative items" : "FunkSVD replay needs the ratings");
+        MI_REQUIRE(n >= 0, "n must be >= 0");
+        ensure_device();
+        if (n == 0) return;
+        const long long B = h->cfg.batch_size;
+        ensure_stream_capacity(h, (size_t)n);
+        hipStream_t s = h->stream;
+        MI_HIP(hipMemcpyAsync(h->su.ptr, u, sizeof(int) * n, hipMemcpyHostToDevice, s));
+        MI_HIP(hipMemcpyAsync(h->si.ptr, i, sizeof(int) * n, hipMemcpyHostToDevice, s));
+        if (bpr) MI_HIP(hipMemcpyAsync(h->sj.ptr, j, sizeof(int) * n, hipMemcpyHostToDevice, s));
+        else MI_HIP(hipMemcpyAsync(h->sr.ptr, rating, sizeof(float) * n, hipMemcpyHostToDevice, s));
+        h->record_period = 0;
+        h->last_call_samples = 0;
+        MfParams p{};
+        fill_params(h, p);
+        MI_HIP(hipMemsetAsync(&h->state.ptr->loss, 0, sizeof(double), s));
+        const long long n_batches = (n + B - 1) / B;
+        h->timer.start(s);
+        for (long long b = 0; b < n_batches; ++b) {
+            p.n_in_batch = (int)std::min<long long>(B, n - b * B);
+            launch_batch(h, p, true);
+        }
+        h->timer.stop(s);
+        h->batches_done += n_batches;
+        finish_call(h, n, n_batches);
+    });
+}
+
+extern "C" int mi355rec_mf_get_factors(mi355rec_mf_t h, float *U, float *V, float *bu, float *bi, float *mu) {
+    return guarded([&] {
+        MI_REQUIRE(h, "NULL handle");
+        ensure_device();
+        hipStream_t s = h->stream;
+        if (U) h->U.download(U, (size_t)h->n_users * h->k, s);
+        if (V) h->V.download(V, (size_t)h->n_items * h->k, s);
+        if (bu) h->bu.download(bu, h->n_users, s);
+        if (bi) h->bi.download(bi, h->n_items, s);
+        if (mu) h->mu.download(mu, 1, s);
+        MI_HIP(hipStreamSynchronize(s));
+    });
+}
+
+extern "C" int mi355rec_mf_get_last_samples(mi355rec_mf_t h, int32_t *u, int32_t *i, int32_t *j, float *rating, int64_t cap,
+                                            int64_t *n) {
+    return guarded([&] {
+        MI_REQUIRE(h && n, "NULL argument");
+        ensure_device();
+        *n = h->last_call_samples;
+        const size_t m = (size_t)std::min<long long>(cap, h->last_call_samples);
+        hipStream_t s = h->stream;
+        if (u) h->su.download(u, m, s);
+        if (i) h->si.download(i, m, s);
+        if (j && h->cfg.algorithm == MI355REC_MF_BPR) h->sj.download(j, m, s);
+        if (rating && h->cfg.algorithm == MI355REC_MF_FUNK_SVD) h->sr.download(rating, m, s);
+        MI_HIP(hipStreamSynchronize(s));
+    });
+}
+
+extern "C" int mi355rec_mf_get_stats(mi355rec_mf_t h, mi355rec_stats *stats) {
+    return guarded([&] {
+        MI_REQUIRE(h && stats, "NULL argument");
+        *stats = h->stats;
+    });
+}
+
+extern "C" void mi355rec_mf_destroy(mi355rec_mf_t h) {
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->timer.destroy();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}

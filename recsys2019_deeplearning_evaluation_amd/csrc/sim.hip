@@ -1,0 +1,768 @@
+// sim.hip -- Compute_Similarity on MI355X (gfx950).
+//
+// Replaces Base/Similarity/Cython/Compute_Similarity_Cython.pyx (reference): __init__ :72-213 (pre-processing,
+// column norms, CSR+CSC views), computeItemSimilarities :325-406 (the hot loop), compute_similarity :411-607
+// (normalisation :473-504, per-column top-K :523-562).
+//
+// Design: one persistent workgroup per CU pulls columns from a cost-ordered queue;
+// the per-column accumulator `this_item_weights` lives in LDS (4 B x n_cols), the co-occurrence products are
+// accumulated with LDS float atomics, normalised in place and reduced to the top-K by an in-LDS 4-pass radix
+// select (bank-replicated histograms) followed by a bitonic sort of the K survivors.  The URM is read through
+// L2 / Infinity Cache; nothing but the K results per column is written to HBM.
+#include "common.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <memory>
+#include <numeric>
+
+namespace mi355rec {
+namespace {
+
+constexpr uint32_t ZERO_KEY = 0x80000000u;
+constexpr int AUX_WORDS = 8192;  // 32 KiB: 256 bins x 32 bank replicas, later re-used as the candidate buffer
+constexpr int MAX_TOPK = 4096;   // AUX_WORDS * 4 B / 8 B per candidate
+
+struct SimParams {
+    int n_rows, n_cols, n_cols_pad;
+    int topK, sortP;
+    int kind, normalize;
+    float shrink, tversky_alpha, tversky_beta;
+    const int *csr_ptr, *csr_idx;
+    const float *csr_val;
+    const int *csc_ptr, *csc_idx;
+    const float *csc_val;
+    const float *row_w;
+    const float *norm, *norm_alpha, *norm_1ma;
+    const int *order;  // columns of this call, most expensive first
+    int n_local, start_col;
+    unsigned *queue;
+    int *out_idx;
+    float *out_val;
+    float *out_dense;  // [n_local][n_cols] when topK == 0
+};
+
+// Order-preserving map float -> uint32 (larger float <=> larger key); +0.0 maps to ZERO_KEY.
+__device__ __forceinline__ uint32_t float_key(float v) {
+    uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) {
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(b);
+}
+
+// Denominators of compute_similarity (.pyx:473-504); the +1e-6 is the reference's.
+__device__ __forceinline__ float normalise(const SimParams &p, float v, int c, int j) {
+    if (p.normalize) {
+        float den = (p.kind == MI355REC_SIM_ASYMMETRIC) ? p.norm_alpha[c] * p.norm_1ma[j] : p.norm[c] * p.norm[j];
+        return v / (den + p.shrink + 1e-6f);
+    }
+    if (p.kind == MI355REC_SIM_JACCARD) return v / (p.norm[c] + p.norm[j] - v + p.shrink + 1e-6f);
+    if (p.kind == MI355REC_SIM_DICE) return v / (p.norm[c] + p.norm[j] + p.shrink + 1e-6f);
+    if (p.kind == MI355REC_SIM_TVERSKY)
+        return v / (v + (p.norm[c] - v) * p.tversky_alpha + (p.norm[j] - v) * p.tversky_beta + p.shrink + 1e-6f);
+    if (p.shrink != 0.f) return v / p.shrink;
+    return v;
+}
+
+struct SelectScratch {
+    uint32_t wave_tot[4];
+    uint32_t digit, want, bin_count;
+};
+
+// Block-wide radix select: key of the `want`-th largest element (1-based) of
+//   { kf(j).key : j < n, kf(j).active }  U  { virt_key repeated virt_cnt times }.
+// On return every thread holds T (that key), need_eq (how many elements equal to T belong to the top `want`)
+// and eq_total (how many elements equal T, virtual ones included).
+template <int THREADS, class KeyFn>
+__device__ void block_select(KeyFn kf, int n, uint32_t want, uint32_t virt_key, uint32_t virt_cnt, uint32_t *hist,
+                             SelectScratch &sc, uint32_t &T, uint32_t &need_eq, uint32_t &eq_total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t prefix = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int w = tid; w < AUX_WORDS; w += THREADS) hist[w] = 0;
+        __syncthreads();
+        for (int j = tid; j < n; j += THREADS) {
+            uint32_t key;
+            if (kf(j, key) && (pass == 0 || (key >> (shift + 8)) == prefix))
+                atomicAdd(&hist[((key >> shift) & 255u) * 32 + (lane & 31)], 1u);
+        }
+        __syncthreads();
+        uint32_t cnt = 0, suffix = 0;
+        if (tid < 256) {
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) cnt += hist[tid * 32 + ((r + tid) & 31)];
+            if (virt_cnt && (pass == 0 || (virt_key >> (shift + 8)) == prefix) && ((virt_key >> shift) & 255u) == (uint32_t)tid)
+                cnt += virt_cnt;
+            suffix = cnt;  // inclusive suffix sum inside the wave (towards higher bins)
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t t = __shfl_down(suffix, off);
+                if (lane + off < 64) suffix += t;
+            }
+            if (lane == 0) sc.wave_tot[wave] = suffix;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            for (int w = wave + 1; w < 4; ++w) suffix += sc.wave_tot[w];
+            const uint32_t above = suffix - cnt;
+            if (suffix >= want && above < want) {
+                sc.digit = tid;
+                sc.want = want - above;
+                sc.bin_count = cnt;
+            }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | sc.digit;
+        want = sc.want;
+        eq_total = sc.bin_count;
+        __syncthreads();
+    }
+    T = prefix;
+    need_eq = want;
+}
+
+template <int THREADS>
+__device__ void bitonic_sort_desc(uint64_t *a, int P) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < P; t += THREADS) {
+                int ixj = t ^ j;
+                if (ixj > t) {
+                    uint64_t x = a[t], y = a[ixj];
+                    bool desc = (t & k) == 0;
+                    if (desc ? (x < y) : (x > y)) {
+                        a[t] = y;
+                        a[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// THREADS: workgroup size; G: lanes that cooperate on one user profile (sub-wave group);
+// UNIT: all stored values are 1.0 (implicit / set-based data) -> the value arrays are never read.
+template <int THREADS, int G, bool UNIT>
+__global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *acc = smem;
+    uint32_t *aux = reinterpret_cast<uint32_t *>(smem + p.n_cols_pad);
+    __shared__ SelectScratch sc;
+    __shared__ int s_col;
+    __shared__ uint32_t s_npos, s_nneg, s_ncand;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int GROUPS = THREADS / G;
+    const int gid = tid / G, gl = tid % G;
+
+    for (;;) {
+        if (tid == 0) {
+            s_col = (int)atomicAdd(p.queue, 1u);
+            s_npos = 0;
+            s_nneg = 0;
+            s_ncand = 0;
+        }
+        __syncthreads();
+        const int slot = s_col;
+        if (slot >= p.n_local) break;
+        const int c = p.order[slot];
+
+        // ---- clear this_item_weights (.pyx:365-370) ----
+        {
+            float4 *a4 = reinterpret_cast<float4 *>(acc);
+            for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) a4[w] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+
+        // ---- computeItemSimilarities (.pyx:376-406): users of column c, then every item of each user ----
+        const int cbeg = p.csc_ptr[c], cend = p.csc_ptr[c + 1];
+        for (int q = cbeg + gid; q < cend; q += GROUPS) {
+            const int u = p.csc_idx[q];
+            float r = UNIT ? 1.f : p.csc_val[q];
+            if (p.row_w) r *= p.row_w[u];
+            const int rs = p.csr_ptr[u], re = p.csr_ptr[u + 1];
+            for (int t = rs + gl; t < re; t += G) {
+                const int j = p.csr_idx[t];
+                const float v = UNIT ? r : r * p.csr_val[t];
+                if (j != c) atomicAdd(&acc[j], v);
+            }
+        }
+        __syncthreads();
+
+        // ---- normalisation (.pyx:473-504), in place; count signs for the selection ----
+        uint32_t npos = 0, nneg = 0;
+        for (int j = tid; j < p.n_cols; j += THREADS) {
+            float v = acc[j];
+            if (v != 0.f) {
+                v = normalise(p, v, c, j);
+                acc[j] = v;
+                npos += v > 0.f;
+                nneg += v < 0.f;
+            }
+        }
+        if (p.topK == 0) {  // dense output (.pyx:507-510)
+            __syncthreads();
+            float *dst = p.out_dense + (size_t)(c - p.start_col) * p.n_cols;
+            for (int j = tid; j < p.n_cols; j += THREADS) dst[j] = acc[j];
+            __syncthreads();
+            continue;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            npos += __shfl_down(npos, off);
+            nneg += __shfl_down(nneg, off);
+        }
+        if (lane == 0) {
+            if (npos) atomicAdd(&s_npos, npos);
+            if (nneg) atomicAdd(&s_nneg, nneg);
+        }
+        __syncthreads();
+        npos = s_npos;
+        nneg = s_nneg;
+        const uint32_t nzero = (uint32_t)p.n_cols - npos - nneg;
+        const uint32_t K = (uint32_t)p.topK;
+
+        // ---- top-K: the K largest cells of the FULL column (zeros compete, then are dropped) ----
+        uint32_t T = ZERO_KEY, need_eq = 0, eq_total = 0;
+        const bool take_all_positive = npos <= K && (nneg == 0 || npos + nzero >= K);
+        auto value_key = [&](int j, uint32_t &key) {
+            float v = acc[j];
+            key = float_key(v);
+            return v != 0.f;
+        };
+        if (!take_all_positive) {
+            block_select<THREADS>(value_key, p.n_cols, K, ZERO_KEY, nzero, aux, sc, T, need_eq, eq_total);
+            if (T == ZERO_KEY) need_eq = 0;  // zeros are never emitted (.pyx:555)
+        }
+        uint32_t T2 = 0;  // tie-break on the index when more cells equal T than fit: lowest index wins
+        const bool partial_ties = need_eq > 0 && need_eq < eq_total;
+        if (partial_ties) {
+            uint32_t dummy_need, dummy_tot;
+            auto index_key = [&](int j, uint32_t &key) {
+                float v = acc[j];
+                key = ~(uint32_t)j;
+                return v != 0.f && float_key(v) == T;
+            };
+            block_select<THREADS>(index_key, p.n_cols, need_eq, 0u, 0u, aux, sc, T2, dummy_need, dummy_tot);
+        }
+        __syncthreads();
+        uint64_t *cand = reinterpret_cast<uint64_t *>(aux);
+        for (int j = tid; j < p.n_cols; j += THREADS) {
+            float v = acc[j];
+            if (v == 0.f) continue;
+            uint32_t key = float_key(v);
+            bool take = key > T || (need_eq > 0 && key == T && (!partial_ties || ~(uint32_t)j >= T2));
+            if (take) {
+                uint32_t slot_c = atomicAdd(&s_ncand, 1u);
+                if (slot_c < (uint32_t)p.sortP) cand[slot_c] = ((uint64_t)key << 32) | (uint32_t)(~(uint32_t)j);
+            }
+        }
+        __syncthreads();
+        const int ncand = min((int)s_ncand, p.topK);
+        for (int t = ncand + tid; t < p.sortP; t += THREADS) cand[t] = 0ull;
+        __syncthreads();
+        bitonic_sort_desc<THREADS>(cand, p.sortP);
+
+        // ---- emit (value descending; -1 padding), like the COO triples of .pyx:550-562 ----
+        const size_t base = (size_t)(c - p.start_col) * p.topK;
+        for (int t = tid; t < p.topK; t += THREADS) {
+            int idx = -1;
+            float val = 0.f;
+            if (t < ncand) {
+                uint64_t e = cand[t];
+                idx = (int)(~(uint32_t)(e & 0xFFFFFFFFull));
+                val = key_float((uint32_t)(e >> 32));
+            }
+            p.out_idx[base + t] = idx;
+            p.out_val[base + t] = val;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------- set-up kernels -------------------------------------------
+
+__global__ void fill_kernel(float *x, size_t n, float v) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = v;
+}
+
+// applyAdjustedCosine (.pyx:275-310): subtract from every stored cell the mean of its row.
+__global__ void row_center_kernel(const int *ptr, float *val, int n_rows) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_rows) return;
+    const int s = ptr[wave], e = ptr[wave + 1];
+    if (e == s) return;
+    double sum = 0.0;
+    for (int q = s + lane; q < e; q += 64) sum += (double)val[q];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = (float)(sum / (double)(e - s));
+    for (int q = s + lane; q < e; q += 64) val[q] -= mean;
+}
+
+__global__ void count_cols_kernel(const int *idx, size_t nnz, int *cnt) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x)
+        atomicAdd(&cnt[idx[i]], 1);
+}
+
+// Single-workgroup exclusive scan: out[0..n] from cnt[0..n-1]; cursor[] gets a copy of out[0..n-1].
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int *cnt, int *out, int *cursor, int n) {
+    __shared__ long long part[1024];
+    const int tid = threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int b = tid * chunk, e = min(n, b + chunk);
+    long long s = 0;
+    for (int i = b; i < e; ++i) s += cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        long long t = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    long long run = tid ? part[tid - 1] : 0;
+    for (int i = b; i < e; ++i) {
+        out[i] = (int)run;
+        cursor[i] = (int)run;
+        run += cnt[i];
+    }
+    if (tid == 1023) out[n] = (int)part[1023];
+}
+
+// Row id of every stored cell (one wave per row), and the identity permutation 0..nnz-1.
+__global__ void expand_rows_kernel(const int *ptr, int n_rows, int *row_of, int *pos) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_rows) return;
+    for (int q = ptr[wave] + lane; q < ptr[wave + 1]; q += 64) {
+        row_of[q] = wave;
+        pos[q] = q;
+    }
+}
+
+// CSC view from the stable (column-key) sort permutation: users inside a column stay in ascending order.
+__global__ void gather_csc_kernel(const int *perm, const int *row_of, const float *val, size_t nnz, int *csc_idx, float *csc_val) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = perm[i];
+        csc_idx[i] = row_of[q];
+        csc_val[i] = val[q];
+    }
+}
+
+// Per column (one wave each): mean of the stored cells (pearson), sum of squares, cost = sum of profile lengths.
+__global__ void column_stats_kernel(const int *csc_ptr, const int *csc_idx, const float *csc_val, const int *csr_ptr,
+                                    int n_cols, float *mean, double *sumsq, long long *cost) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_cols) return;
+    const int s = csc_ptr[wave], e = csc_ptr[wave + 1];
+    double sum = 0.0, sq = 0.0;
+    long long c = 0;
+    for (int q = s + lane; q < e; q += 64) {
+        const double v = csc_val[q];
+        sum += v;
+        sq += v * v;
+        const int u = csc_idx[q];
+        c += csr_ptr[u + 1] - csr_ptr[u];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off);
+        sq += __shfl_xor(sq, off);
+        c += __shfl_xor(c, off);
+    }
+    if (lane == 0) {
+        if (mean) mean[wave] = e > s ? (float)(sum / (double)(e - s)) : 0.f;
+        if (sumsq) sumsq[wave] = sq;
+        if (cost) cost[wave] = c;
+    }
+}
+
+// applyPearsonCorrelation (.pyx:234-271): subtract the column mean from every stored cell, both views.
+__global__ void col_center_kernel(const int *col_of, float *val, size_t nnz, const float *mean) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x)
+        val[i] -= mean[col_of[i]];
+}
+__global__ void col_center_csc_kernel(const int *csc_ptr, float *csc_val, int n_cols, const float *mean) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_cols) return;
+    const float m = mean[wave];
+    for (int q = csc_ptr[wave] + lane; q < csc_ptr[wave + 1]; q += 64) csc_val[q] -= m;
+}
+
+// sumOfSquared -> norms (.pyx:169-177)
+__global__ void norms_kernel(const double *sumsq, int n_cols, int set_based, int asymmetric, float alpha, float *norm,
+                             float *norm_alpha, float *norm_1ma) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cols) return;
+    double s = sumsq[c];
+    if (!set_based) s = sqrt(s);
+    norm[c] = (float)s;
+    if (asymmetric) {
+        norm_1ma[c] = (float)pow(s, 2.0 * (1.0 - (double)alpha));
+        norm_alpha[c] = (float)pow(s, 2.0 * (double)alpha);
+    }
+}
+
+__global__ void minmax_kernel(const float *val, size_t nnz, int *not_unit) {
+    int bad = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x)
+        bad |= val[i] != 1.0f;
+    if (bad) atomicOr(not_unit, 1);
+}
+
+// [n_local][n_cols] -> [n_cols][n_local] (32x32 tiles through LDS)
+__global__ void transpose_kernel(const float *in, float *out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    int x = blockIdx.x * 32 + threadIdx.x, y = blockIdx.y * 32 + threadIdx.y;
+    for (int k = 0; k < 32; k += 8)
+        if (x < cols && y + k < rows) tile[threadIdx.y + k][threadIdx.x] = in[(size_t)(y + k) * cols + x];
+    __syncthreads();
+    x = blockIdx.y * 32 + threadIdx.x;
+    y = blockIdx.x * 32 + threadIdx.y;
+    for (int k = 0; k < 32; k += 8)
+        if (x < rows && y + k < cols) out[(size_t)(y + k) * rows + x] = tile[threadIdx.x][threadIdx.y + k];
+}
+
+}  // namespace
+}  // namespace mi355rec
+
+using namespace mi355rec;
+
+struct mi355rec_sim {
+    mi355rec_sim_config cfg{};
+    int n_rows = 0, n_cols = 0;
+    size_t nnz = 0;
+    bool unit_values = false;
+    hipStream_t stream = nullptr;
+    StreamTimer timer;
+    DeviceBuffer<int> csr_ptr, csr_idx, csc_ptr, csc_idx, order;
+    DeviceBuffer<float> csr_val, csc_val, row_w, norm, norm_alpha, norm_1ma;
+    DeviceBuffer<unsigned> queue;
+    DeviceBuffer<int> out_idx;
+    DeviceBuffer<float> out_val;
+    std::vector<long long> cost;   // host copy
+    std::vector<int> cost_order;   // all columns, most expensive first
+    std::vector<int> range_order;  // host staging for the current call
+    int group_lanes = 64;
+    mi355rec_stats stats{};
+    // last call
+    int last_start = -1, last_end = -1;
+};
+
+namespace {
+
+template <int THREADS, int G>
+void launch_sim(mi355rec_sim *h, const SimParams &p, int grid, size_t lds) {
+    if (h->unit_values) {
+        auto k = sim_column_kernel<THREADS, G, true>;
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(THREADS), lds, h->stream, p);
+    } else {
+        auto k = sim_column_kernel<THREADS, G, false>;
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(THREADS), lds, h->stream, p);
+    }
+    MI_HIP(hipGetLastError());
+}
+
+template <int THREADS>
+void launch_sim_g(mi355rec_sim *h, const SimParams &p, int grid, size_t lds) {
+    switch (h->group_lanes) {
+        case 16: launch_sim<THREADS, 16>(h, p, grid, lds); break;
+        case 32: launch_sim<THREADS, 32>(h, p, grid, lds); break;
+        default: launch_sim<THREADS, 64>(h, p, grid, lds); break;
+    }
+}
+
+void clamp_range(const mi355rec_sim *h, int32_t &s, int32_t &e) {
+    // same rule as .pyx:447-451: out-of-range bounds fall back to the full range
+    int32_t s_in = s, e_in = e;
+    s = 0;
+    e = h->n_cols;
+    if (s_in > 0 && s_in < h->n_cols) s = s_in;
+    if (e_in > s && e_in < h->n_cols) e = e_in;
+}
+
+// Runs the column kernel for [start,end) leaving results in d_idx/d_val (or d_dense when topK == 0).
+void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, float *d_dense) {
+    const int n_local = end - start;
+    h->range_order.clear();
+    h->range_order.reserve(n_local);
+    long long cost_sum = 0;
+    for (int c : h->cost_order)
+        if (c >= start && c < end) {
+            h->range_order.push_back(c);
+            cost_sum += h->cost[c];
+        }
+    MI_HIP(hipMemcpyAsync(h->order.ptr, h->range_order.data(), sizeof(int) * n_local, hipMemcpyHostToDevice, h->stream));
+    MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(unsigned), h->stream));
+
+    SimParams p{};
+    p.n_rows = h->n_rows;
+    p.n_cols = h->n_cols;
+    p.n_cols_pad = (h->n_cols + 3) & ~3;
+    p.topK = h->cfg.topK;
+    int P = 1;
+    while (P < std::max(2, p.topK)) P <<= 1;
+    p.sortP = P;
+    p.kind = h->cfg.similarity;
+    p.normalize = h->cfg.normalize;
+    p.shrink = (float)h->cfg.shrink;
+    p.tversky_alpha = h->cfg.tversky_alpha;
+    p.tversky_beta = h->cfg.tversky_beta;
+    p.csr_ptr = h->csr_ptr.ptr;
+    p.csr_idx = h->csr_idx.ptr;
+    p.csr_val = h->csr_val.ptr;
+    p.csc_ptr = h->csc_ptr.ptr;
+    p.csc_idx = h->csc_idx.ptr;
+    p.csc_val = h->csc_val.ptr;
+    p.row_w = h->row_w.ptr;
+    p.norm = h->norm.ptr;
+    p.norm_alpha = h->norm_alpha.ptr;
+    p.norm_1ma = h->norm_1ma.ptr;
+    p.order = h->order.ptr;
+    p.n_local = n_local;
+    p.start_col = start;
+    p.queue = h->queue.ptr;
+    p.out_idx = d_idx;
+    p.out_val = d_val;
+    p.out_dense = d_dense;
+
+    const size_t lds = (size_t)p.n_cols_pad * 4 + (size_t)AUX_WORDS * 4;
+    const int cus = multiprocessor_count();
+    h->timer.start(h->stream);
+    if (lds > 72 * 1024) {
+        // one 16-wave workgroup per CU (the accumulator owns most of the 160 KiB LDS)
+        launch_sim_g<1024>(h, p, std::min(n_local, cus), lds);
+    } else {
+        int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (lds + 1024))));
+        launch_sim_g<512>(h, p, std::min(n_local, cus * per_cu), lds);
+    }
+    h->timer.stop(h->stream);
+
+    h->stats.n_launches = 1;
+    h->stats.n_units = n_local;
+    // ALGORITHMIC bytes: every (user-of-column, item-of-user) pair is one index (+ one value
+    // unless the data is all-ones) read; every user of the column one index (+ value); plus the K results.
+    const double per_pair = h->unit_values ? 4.0 : 8.0;
+    h->stats.algorithmic_bytes = per_pair * (double)cost_sum + 8.0 * (double)n_local * (double)h->cfg.topK;
+    h->stats.algorithmic_flops = 0;
+    h->last_start = start;
+    h->last_end = end;
+}
+
+}  // namespace
+
+extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, int32_t n_rows, int32_t n_cols,
+                                   const int32_t *csr_indptr, const int32_t *csr_indices, const float *csr_data,
+                                   const float *row_weights) {
+    return guarded([&] {
+        MI_REQUIRE(out && cfg && csr_indptr && csr_indices && csr_data, "NULL argument");
+        MI_REQUIRE(n_rows > 0 && n_cols > 0, "empty matrix (%d x %d)", n_rows, n_cols);
+        MI_REQUIRE(cfg->similarity >= MI355REC_SIM_COSINE && cfg->similarity <= MI355REC_SIM_TVERSKY,
+                   "Cosine_Similarity: value for parameter 'mode' not recognized (%d)", cfg->similarity);
+        MI_REQUIRE(cfg->topK >= 0, "topK must be >= 0");
+        ensure_device();
+        const size_t lds_needed = ((size_t)((n_cols + 3) & ~3)) * 4 + (size_t)AUX_WORDS * 4 + 2048;
+        if (lds_needed > 160 * 1024)
+            fail(MI355REC_E_UNSUPPORTED,
+                 "n_cols = %d needs %zu B of LDS for the per-column accumulator (limit 160 KiB); the tiled "
+                 "accumulator variant is not available yet",
+                 n_cols, lds_needed);
+        std::unique_ptr<mi355rec_sim> h(new mi355rec_sim());
+        h->cfg = *cfg;
+        h->cfg.topK = std::min(cfg->topK, n_cols);  // .pyx:146
+        if (h->cfg.topK > MAX_TOPK)
+            fail(MI355REC_E_UNSUPPORTED, "topK = %d exceeds the in-LDS selection limit of %d (use topK=0 for the dense build)",
+                 h->cfg.topK, MAX_TOPK);
+        const bool set_based = cfg->similarity == MI355REC_SIM_JACCARD || cfg->similarity == MI355REC_SIM_DICE ||
+                               cfg->similarity == MI355REC_SIM_TVERSKY;
+        if (set_based) h->cfg.normalize = 0;  // .pyx:124-135
+        h->n_rows = n_rows;
+        h->n_cols = n_cols;
+        h->nnz = (size_t)csr_indptr[n_rows];
+        MI_REQUIRE(h->nnz > 0, "matrix has no stored values");
+        MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->timer.init();
+        hipStream_t s = h->stream;
+        const size_t nnz = h->nnz;
+        h->csr_ptr.upload(csr_indptr, (size_t)n_rows + 1, s);
+        h->csr_idx.upload(csr_indices, nnz, s);
+        h->csr_val.upload(csr_data, nnz, s);
+        if (row_weights) h->row_w.upload(row_weights, n_rows, s);
+        const int eb = 256, eg = std::min<size_t>((nnz + eb - 1) / eb, 4096);
+
+        // pre-processing of the stored values (.pyx:158-164)
+        if (set_based) hipLaunchKernelGGL(fill_kernel, dim3(eg), dim3(eb), 0, s, h->csr_val.ptr, nnz, 1.0f);
+        if (cfg->similarity == MI355REC_SIM_ADJUSTED)
+            hipLaunchKernelGGL(row_center_kernel, dim3(div_up((int64_t)n_rows * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr,
+                               h->csr_val.ptr, n_rows);
+
+        // CSR -> CSC (.pyx:203-207), on the device: stable radix sort of the cell positions by column
+        DeviceBuffer<int> cnt, cursor, row_of, pos_in, pos_out, key_out;
+        DeviceBuffer<float> mean;
+        DeviceBuffer<double> sumsq;
+        DeviceBuffer<long long> cost;
+        DeviceBuffer<char> sort_tmp;
+        cnt.alloc_zero((size_t)n_cols, s);
+        cursor.alloc((size_t)n_cols);
+        h->csc_ptr.alloc((size_t)n_cols + 1);
+        h->csc_idx.alloc(nnz);
+        h->csc_val.alloc(nnz);
+        row_of.alloc(nnz);
+        pos_in.alloc(nnz);
+        pos_out.alloc(nnz);
+        key_out.alloc(nnz);
+        hipLaunchKernelGGL(count_cols_kernel, dim3(eg), dim3(eb), 0, s, h->csr_idx.ptr, nnz, cnt.ptr);
+        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, cnt.ptr, h->csc_ptr.ptr, cursor.ptr, n_cols);
+        hipLaunchKernelGGL(expand_rows_kernel, dim3(div_up((int64_t)n_rows * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr, n_rows,
+                           row_of.ptr, pos_in.ptr);
+        int key_bits = 1;
+        while ((1ll << key_bits) < (long long)n_cols) ++key_bits;
+        size_t tmp_bytes = 0;
+        MI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, pos_in.ptr, pos_out.ptr,
+                                                  (int)nnz, 0, key_bits, s));
+        sort_tmp.alloc(tmp_bytes);
+        MI_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp.ptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, pos_in.ptr, pos_out.ptr,
+                                                  (int)nnz, 0, key_bits, s));
+        hipLaunchKernelGGL(gather_csc_kernel, dim3(eg), dim3(eb), 0, s, pos_out.ptr, row_of.ptr, h->csr_val.ptr, nnz,
+                           h->csc_idx.ptr, h->csc_val.ptr);
+
+        const int cg = div_up((int64_t)n_cols * 64, 256);
+        if (cfg->similarity == MI355REC_SIM_PEARSON) {
+            mean.alloc((size_t)n_cols);
+            hipLaunchKernelGGL(column_stats_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_idx.ptr, h->csc_val.ptr,
+                               h->csr_ptr.ptr, n_cols, mean.ptr, (double *)nullptr, (long long *)nullptr);
+            hipLaunchKernelGGL(col_center_kernel, dim3(eg), dim3(eb), 0, s, h->csr_idx.ptr, h->csr_val.ptr, nnz, mean.ptr);
+            hipLaunchKernelGGL(col_center_csc_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_val.ptr, n_cols, mean.ptr);
+        }
+        sumsq.alloc((size_t)n_cols);
+        cost.alloc((size_t)n_cols);
+        hipLaunchKernelGGL(column_stats_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_idx.ptr, h->csc_val.ptr,
+                           h->csr_ptr.ptr, n_cols, (float *)nullptr, sumsq.ptr, cost.ptr);
+        h->norm.alloc((size_t)n_cols);
+        const bool asym = cfg->similarity == MI355REC_SIM_ASYMMETRIC;
+        if (asym) {
+            h->norm_alpha.alloc((size_t)n_cols);
+            h->norm_1ma.alloc((size_t)n_cols);
+        }
+        hipLaunchKernelGGL(norms_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, s, sumsq.ptr, n_cols, (int)set_based,
+                           (int)asym, cfg->asymmetric_alpha, h->norm.ptr, h->norm_alpha.ptr, h->norm_1ma.ptr);
+        // all-ones data -> value arrays never read by the hot kernel
+        DeviceBuffer<int> not_unit;
+        not_unit.alloc_zero(1, s);
+        hipLaunchKernelGGL(minmax_kernel, dim3(eg), dim3(eb), 0, s, h->csr_val.ptr, nnz, not_unit.ptr);
+        MI_HIP(hipGetLastError());
+        int nu = 1;
+        not_unit.download(&nu, 1, s);
+        h->cost.resize(n_cols);
+        cost.download(h->cost.data(), n_cols, s);
+        MI_HIP(hipStreamSynchronize(s));
+        h->unit_values = (nu == 0);
+
+        h->cost_order.resize(n_cols);
+        std::iota(h->cost_order.begin(), h->cost_order.end(), 0);
+        std::stable_sort(h->cost_order.begin(), h->cost_order.end(),
+                         [&](int a, int b) { return h->cost[a] > h->cost[b]; });
+        h->order.alloc((size_t)n_cols);
+        h->queue.alloc(1);
+        // lanes per user profile: sized to the profile length seen from an item (cost-weighted mean)
+        long long total_cost = 0;
+        for (long long c : h->cost) total_cost += c;
+        const double weighted_len = (double)total_cost / (double)nnz;
+        h->group_lanes = weighted_len >= 96 ? 64 : (weighted_len >= 40 ? 32 : 16);
+        *out = h.release();
+    });
+}
+
+extern "C" int mi355rec_sim_compute_device(mi355rec_sim_t h, int32_t start_col, int32_t end_col, int32_t *d_nbr_idx,
+                                           float *d_nbr_val) {
+    return guarded([&] {
+        MI_REQUIRE(h && d_nbr_idx && d_nbr_val, "NULL argument");
+        MI_REQUIRE(h->cfg.topK > 0, "topK == 0: use mi355rec_sim_compute_dense");
+        ensure_device();
+        clamp_range(h, start_col, end_col);
+        run_columns(h, start_col, end_col, d_nbr_idx, d_nbr_val, nullptr);
+    });
+}
+
+extern "C" int mi355rec_sim_compute(mi355rec_sim_t h, int32_t start_col, int32_t end_col, int32_t *nbr_idx, float *nbr_val) {
+    return guarded([&] {
+        MI_REQUIRE(h && nbr_idx && nbr_val, "NULL argument");
+        MI_REQUIRE(h->cfg.topK > 0, "topK == 0: use mi355rec_sim_compute_dense");
+        ensure_device();
+        clamp_range(h, start_col, end_col);
+        const size_t n = (size_t)(end_col - start_col) * h->cfg.topK;
+        if (h->out_idx.count < n) {
+            h->out_idx.alloc(n);
+            h->out_val.alloc(n);
+        }
+        run_columns(h, start_col, end_col, h->out_idx.ptr, h->out_val.ptr, nullptr);
+        h->out_idx.download(nbr_idx, n, h->stream);
+        h->out_val.download(nbr_val, n, h->stream);
+        MI_HIP(hipStreamSynchronize(h->stream));
+        h->stats.kernel_ms = h->timer.elapsed_ms();
+    });
+}
+
+extern "C" int mi355rec_sim_compute_dense(mi355rec_sim_t h, int32_t start_col, int32_t end_col, float *W, int64_t ld) {
+    return guarded([&] {
+        MI_REQUIRE(h && W, "NULL argument");
+        ensure_device();
+        clamp_range(h, start_col, end_col);
+        const int n_local = end_col - start_col;
+        MI_REQUIRE(ld >= n_local, "ld (%lld) < number of columns (%d)", (long long)ld, n_local);
+        mi355rec_sim_config saved = h->cfg;
+        h->cfg.topK = 0;
+        DeviceBuffer<float> slab, slab_t;
+        slab.alloc((size_t)n_local * h->n_cols);
+        slab_t.alloc((size_t)n_local * h->n_cols);
+        try {
+            run_columns(h, start_col, end_col, nullptr, nullptr, slab.ptr);
+        } catch (...) {
+            h->cfg = saved;
+            throw;
+        }
+        h->cfg = saved;
+        hipLaunchKernelGGL(transpose_kernel, dim3(div_up(h->n_cols, 32), div_up(n_local, 32)), dim3(32, 8), 0, h->stream,
+                           slab.ptr, slab_t.ptr, n_local, h->n_cols);
+        MI_HIP(hipGetLastError());
+        MI_HIP(hipMemcpy2DAsync(W, (size_t)ld * sizeof(float), slab_t.ptr, (size_t)n_local * sizeof(float),
+                                (size_t)n_local * sizeof(float), (size_t)h->n_cols, hipMemcpyDeviceToHost, h->stream));
+        MI_HIP(hipStreamSynchronize(h->stream));
+        h->stats.kernel_ms = h->timer.elapsed_ms();
+    });
+}
+
+extern "C" int mi355rec_sim_column_costs(mi355rec_sim_t h, int64_t *cost) {
+    return guarded([&] {
+        MI_REQUIRE(h && cost, "NULL argument");
+        for (int c = 0; c < h->n_cols; ++c) cost[c] = h->cost[c];
+    });
+}
+
+extern "C" int mi355rec_sim_sync(mi355rec_sim_t h) {
+    return guarded([&] {
+        MI_REQUIRE(h, "NULL handle");
+        MI_HIP(hipStreamSynchronize(h->stream));
+        if (h->last_start >= 0) h->stats.kernel_ms = h->timer.elapsed_ms();
+    });
+}
+
+extern "C" int mi355rec_sim_get_stats(mi355rec_sim_t h, mi355rec_stats *stats) {
+    return guarded([&] {
+        MI_REQUIRE(h && stats, "NULL argument");
+        *stats = h->stats;
+    });
+}
+
+extern "C" void mi355rec_sim_destroy(mi355rec_sim_t h) {
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->timer.destroy();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}

@@ -1,0 +1,233 @@
+"""BPR-MF / FunkSVD SGD on MI355X: host front-end of the mf_* entry points of libmi355rec.so.
+
+Mirrors
+  MatrixFactorization_Cython_Epoch      MatrixFactorization/Cython/MatrixFactorization_Cython_Epoch.pyx:50
+                                        (ctor :95-148, epochIteration_Cython :273, get_* :685-702)
+  _MatrixFactorization_Cython           MatrixFactorization/Cython/MatrixFactorization_Cython.py:20 (fit :37)
+  MatrixFactorization_BPR_Cython        :171      MatrixFactorization_FunkSVD_Cython  :192
+The epoch object keeps the reference constructor's argument names / defaults / ValueErrors; factors are
+initialised on the host exactly as the reference does (np.random.seed(seed); normal(init_mean, init_std_dev)
+for U then V, .pyx:142-175) and live in HBM as float32 afterwards.  Sampling happens on the device
+(counter-based RNG seeded by random_seed); `replay_samples` runs the identical arithmetic on a given sample
+stream (parity mode).  AsySVD ("ASY_SVD") is not on the device path yet and raises NotImplementedError.
+"""
+import ctypes as C
+import sys
+
+import numpy as np
+
+from . import _native as N
+from .recommender_base import (BaseMatrixFactorizationRecommender, Incremental_Training_Early_Stopping,
+                               check_matrix)
+
+
+class MatrixFactorization_MI355X_Epoch:
+    SGD_MODE_VALUES = ["sgd", "adam", "adagrad", "rmsprop"]
+    ALGORITHM_NAME_VALUES = ["FUNK_SVD", "ASY_SVD", "MF_BPR"]
+
+    def __init__(self, URM_train, n_factors=1, algorithm_name=None, batch_size=1, negative_interactions_quota=0.5,
+                 learning_rate=1e-3, use_bias=False, user_reg=0.0, item_reg=0.0, bias_reg=0.0, positive_reg=0.0,
+                 negative_reg=0.0, verbose=False, random_seed=None, init_mean=0.0, init_std_dev=0.1,
+                 sgd_mode="sgd", gamma=0.995, beta_1=0.9, beta_2=0.999,
+                 initial_USER_factors=None, initial_ITEM_factors=None):
+        if sgd_mode not in self.SGD_MODE_VALUES:
+            raise ValueError("Value for 'sgd_mode' not recognized. Acceptable values are {}, provided was '{}'".format(
+                self.SGD_MODE_VALUES, sgd_mode))
+        if algorithm_name not in self.ALGORITHM_NAME_VALUES:
+            raise ValueError("Value for 'algorithm_name' not recognized. Acceptable values are {}, provided was '{}'".format(
+                self.ALGORITHM_NAME_VALUES, algorithm_name))
+        if algorithm_name == "ASY_SVD":
+            raise NotImplementedError("ASY_SVD is not on the MI355X device path yet")
+        URM_train = check_matrix(URM_train, "csr")
+        URM_train = URM_train.sorted_indices()
+        self.n_users, self.n_items = URM_train.shape
+        self.n_factors = int(n_factors)
+        self.batch_size = int(batch_size)
+        self.algorithm_name = algorithm_name
+        self.use_bias = bool(use_bias)
+        self.verbose = verbose
+        if random_seed is not None:
+            np.random.seed(seed=random_seed)
+        # same draw order as .pyx:174-175; an explicit initial model (parity tests) overrides the draw
+        U0 = np.random.normal(init_mean, init_std_dev, (self.n_users, self.n_factors))
+        V0 = np.random.normal(init_mean, init_std_dev, (self.n_items, self.n_factors))
+        if initial_USER_factors is not None:
+            U0 = np.asarray(initial_USER_factors)
+        if initial_ITEM_factors is not None:
+            V0 = np.asarray(initial_ITEM_factors)
+        assert U0.shape == (self.n_users, self.n_factors) and V0.shape == (self.n_items, self.n_factors)
+        seed = int(random_seed) if random_seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
+        cfg = N.MFConfig(N.ALGORITHM_CODES[algorithm_name], self.n_factors, self.batch_size, int(self.use_bias),
+                         N.SGD_MODE_CODES[sgd_mode], learning_rate, user_reg, item_reg, bias_reg, positive_reg,
+                         negative_reg, negative_interactions_quota, gamma, beta_1, beta_2, seed & (2 ** 64 - 1))
+        indptr, indices, data = N.as_i32(URM_train.indptr), N.as_i32(URM_train.indices), N.as_f32(URM_train.data)
+        U0, V0 = N.as_f32(U0), N.as_f32(V0)
+        self._lib = N.load()
+        self._h = C.c_void_p()
+        N.check(self._lib.mi355rec_mf_create(C.byref(self._h), C.byref(cfg), self.n_users, self.n_items,
+                                             N.ptr(indptr), N.ptr(indices), N.ptr(data), N.ptr(U0), N.ptr(V0)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi355rec_mf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- training ----
+    def epochIteration_Cython(self, n_epochs=1):
+        """One reference epoch (n_users/B+1 or nnz/B+1 mini-batches); n_epochs>1 fuses several into one call."""
+        N.check(self._lib.mi355rec_mf_run_epochs(self._h, int(n_epochs)))
+        if self.verbose:
+            st = self.stats()
+            print("{}: Processed {} samples in {:.3f} seconds. loss {:.2E}. Sample per second: {:.0f}".format(
+                self.algorithm_name, st["n_units"], st["kernel_ms"] * 1e-3, st["loss"] / max(1, st["n_units"]),
+                st["n_units"] / max(1e-9, st["kernel_ms"] * 1e-3)))
+            sys.stdout.flush()
+
+    def replay_samples(self, user, item, neg_item=None, rating=None):
+        user, item = N.as_i32(user), N.as_i32(item)
+        neg_item = None if neg_item is None else N.as_i32(neg_item)
+        rating = None if rating is None else N.as_f32(rating)
+        N.check(self._lib.mi355rec_mf_run_samples(self._h, N.ptr(user), N.ptr(item), N.ptr(neg_item), N.ptr(rating), len(user)))
+
+    def last_epoch_samples(self):
+        """(user, item, neg_item | rating) drawn on the device during the last epoch of the last native call."""
+        n = C.c_int64(0)
+        N.check(self._lib.mi355rec_mf_get_last_samples(self._h, None, None, None, None, 0, C.byref(n)))
+        u = np.empty(n.value, np.int32); i = np.empty(n.value, np.int32)
+        j = np.empty(n.value, np.int32); r = np.empty(n.value, np.float32)
+        N.check(self._lib.mi355rec_mf_get_last_samples(self._h, N.ptr(u), N.ptr(i), N.ptr(j), N.ptr(r), n.value, C.byref(n)))
+        return (u, i, j) if self.algorithm_name == "MF_BPR" else (u, i, r)
+
+    def stats(self):
+        st = N.Stats()
+        N.check(self._lib.mi355rec_mf_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    # ---- model read-back (fresh host copies, float32) ----
+    def _download(self, want_bias):
+        U = np.empty((self.n_users, self.n_factors), np.float32)
+        V = np.empty((self.n_items, self.n_factors), np.float32)
+        bu = bi = mu = None
+        if want_bias:
+            bu = np.empty(self.n_users, np.float32); bi = np.empty(self.n_items, np.float32); mu = np.empty(1, np.float32)
+        N.check(self._lib.mi355rec_mf_get_factors(self._h, N.ptr(U), N.ptr(V), N.ptr(bu), N.ptr(bi), N.ptr(mu)))
+        return U, V, bu, bi, mu
+
+    def get_factors(self):
+        U, V, _, _, _ = self._download(False)
+        return U, V
+
+    def get_USER_factors(self):
+        return self._download(False)[0]
+
+    def get_ITEM_factors(self):
+        return self._download(False)[1]
+
+    def get_USER_bias(self):
+        return self._download(True)[2]
+
+    def get_ITEM_bias(self):
+        return self._download(True)[3]
+
+    def get_GLOBAL_bias(self):
+        return np.array(self._download(True)[4][0])
+
+
+class _MatrixFactorization_MI355X(BaseMatrixFactorizationRecommender, Incremental_Training_Early_Stopping):
+    RECOMMENDER_NAME = "MatrixFactorization_MI355X_Recommender"
+
+    def __init__(self, URM_train, verbose=True, algorithm_name="MF_BPR"):
+        super(_MatrixFactorization_MI355X, self).__init__(URM_train, verbose=verbose)
+        self.n_users, self.n_items = self.URM_train.shape
+        self.normalize = False
+        self.algorithm_name = algorithm_name
+
+    def fit(self, epochs=300, batch_size=1000, num_factors=10, positive_threshold_BPR=None, learning_rate=0.001,
+            use_bias=True, sgd_mode="sgd", negative_interactions_quota=0.0, init_mean=0.0, init_std_dev=0.1,
+            user_reg=0.0, item_reg=0.0, bias_reg=0.0, positive_reg=0.0, negative_reg=0.0, random_seed=None,
+            **earlystopping_kwargs):
+        self.num_factors = num_factors
+        self.use_bias = use_bias
+        self.sgd_mode = sgd_mode
+        self.positive_threshold_BPR = positive_threshold_BPR
+        self.learning_rate = learning_rate
+        assert 0.0 <= negative_interactions_quota < 1.0, \
+            "{}: negative_interactions_quota must be a float value >=0 and < 1.0, provided was '{}'".format(
+                self.RECOMMENDER_NAME, negative_interactions_quota)
+        self.negative_interactions_quota = negative_interactions_quota
+        common = dict(algorithm_name=self.algorithm_name, n_factors=num_factors, learning_rate=learning_rate,
+                      sgd_mode=sgd_mode, user_reg=user_reg, batch_size=batch_size, use_bias=use_bias,
+                      init_mean=init_mean, init_std_dev=init_std_dev, verbose=self.verbose, random_seed=random_seed)
+        if self.algorithm_name == "FUNK_SVD":
+            # as in the reference wrapper (.py:63-77) positive_reg is NOT forwarded, so items end up unregularised
+            self.epoch_kernel = MatrixFactorization_MI355X_Epoch(
+                self.URM_train, item_reg=item_reg, bias_reg=bias_reg,
+                negative_interactions_quota=negative_interactions_quota, **common)
+        else:
+            URM_positive = self.URM_train.copy()
+            if positive_threshold_BPR is not None:
+                URM_positive.data = URM_positive.data >= positive_threshold_BPR
+                URM_positive.eliminate_zeros()
+                assert URM_positive.nnz > 0, \
+                    "MatrixFactorization_Cython: URM_train_positive is empty, positive threshold is too high"
+            self.epoch_kernel = MatrixFactorization_MI355X_Epoch(
+                URM_positive, positive_reg=positive_reg, negative_reg=negative_reg, **common)
+        self._prepare_model_for_validation()
+        self._update_best_model()
+        self._train_with_early_stopping(epochs, algorithm_name=self.algorithm_name, **earlystopping_kwargs)
+        self.USER_factors = self.USER_factors_best
+        self.ITEM_factors = self.ITEM_factors_best
+        if self.use_bias:
+            self.USER_bias = self.USER_bias_best
+            self.ITEM_bias = self.ITEM_bias_best
+            self.GLOBAL_bias = self.GLOBAL_bias_best
+        self.epoch_kernel.close()
+        sys.stdout.flush()
+
+    def _prepare_model_for_validation(self):     # the only device -> host copy of the training loop
+        self.USER_factors, self.ITEM_factors = self.epoch_kernel.get_factors()
+        if self.use_bias:
+            self.USER_bias = self.epoch_kernel.get_USER_bias()
+            self.ITEM_bias = self.epoch_kernel.get_ITEM_bias()
+            self.GLOBAL_bias = self.epoch_kernel.get_GLOBAL_bias()
+
+    def _update_best_model(self):
+        self.USER_factors_best = self.USER_factors.copy()
+        self.ITEM_factors_best = self.ITEM_factors.copy()
+        if self.use_bias:
+            self.USER_bias_best = self.USER_bias.copy()
+            self.ITEM_bias_best = self.ITEM_bias.copy()
+            self.GLOBAL_bias_best = self.GLOBAL_bias
+
+    def _run_epoch(self, num_epoch):
+        self.epoch_kernel.epochIteration_Cython()
+
+
+class MatrixFactorization_BPR_MI355X(_MatrixFactorization_MI355X):
+    """Drop-in for MatrixFactorization_BPR_Cython (forces use_bias=False, negative_interactions_quota=0)."""
+    RECOMMENDER_NAME = "MatrixFactorization_BPR_MI355X_Recommender"
+
+    def __init__(self, *pos_args, **key_args):
+        super(MatrixFactorization_BPR_MI355X, self).__init__(*pos_args, algorithm_name="MF_BPR", **key_args)
+
+    def fit(self, **key_args):
+        key_args["use_bias"] = False
+        key_args["negative_interactions_quota"] = 0.0
+        super(MatrixFactorization_BPR_MI355X, self).fit(**key_args)
+
+
+class MatrixFactorization_FunkSVD_MI355X(_MatrixFactorization_MI355X):
+    """Drop-in for MatrixFactorization_FunkSVD_Cython."""
+    RECOMMENDER_NAME = "MatrixFactorization_FunkSVD_MI355X_Recommender"
+
+    def __init__(self, *pos_args, **key_args):
+        super(MatrixFactorization_FunkSVD_MI355X, self).__init__(*pos_args, algorithm_name="FUNK_SVD", **key_args)
+
+    def fit(self, **key_args):
+        super(MatrixFactorization_FunkSVD_MI355X, self).fit(**key_args)

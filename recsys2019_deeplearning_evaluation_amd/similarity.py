@@ -1,0 +1,147 @@
+"""Compute_Similarity on MI355X: host front-end of the sim_* entry points of libmi355rec.so.
+
+Mirrors
+  Compute_Similarity_Cython   Base/Similarity/Cython/Compute_Similarity_Cython.pyx:51 (ctor :72, compute_similarity :411)
+  Compute_Similarity          Base/Similarity/Compute_Similarity.py:32  (the dispatcher every KNN recommender calls)
+with the same constructor arguments, the same `compute_similarity(start_col=None, end_col=None)` signature,
+the same return types (csr_matrix (n_cols, n_cols) float32 with column = source item; dense ndarray when
+topK == 0) and the same ValueError on bad enum arguments.  All arithmetic happens on the device; there is
+no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sps
+
+from . import _native as N
+from .recommender_base import check_matrix
+
+
+def slabs_to_csr(nbr_idx, nbr_val, start_col, n_columns):
+    """(n_local, topK) neighbour / value slabs (-1 padded, value-descending) -> csr_matrix whose column
+    start_col + r holds row r of the slabs: the COO assembly of Compute_Similarity_Cython.pyx:603-605."""
+    keep = nbr_idx >= 0
+    per_col = keep.sum(axis=1)
+    indptr = np.zeros(n_columns + 1, dtype=np.int64)
+    indptr[start_col + 1:start_col + 1 + len(per_col)] = per_col
+    np.cumsum(indptr, out=indptr)
+    W = sps.csc_matrix((nbr_val[keep], nbr_idx[keep], indptr), shape=(n_columns, n_columns), dtype=np.float32)
+    return W.tocsr()
+
+
+class Compute_Similarity_MI355X:
+    """Drop-in for Compute_Similarity_Cython backed by the gfx950 kernels."""
+
+    SIMILARITY_VALUES = ("cosine", "pearson", "adjusted", "asymmetric", "jaccard", "tanimoto", "dice", "tversky")
+
+    def __init__(self, dataMatrix, topK=100, shrink=0, normalize=True, asymmetric_alpha=0.5, tversky_alpha=1.0,
+                 tversky_beta=1.0, similarity="cosine", row_weights=None):
+        if similarity not in self.SIMILARITY_VALUES:
+            raise ValueError("Cosine_Similarity: value for parameter 'mode' not recognized."
+                             " Allowed values are: 'cosine', 'pearson', 'adjusted', 'asymmetric', 'jaccard', 'tanimoto',"
+                             "dice, tversky. Passed value was '{}'".format(similarity))
+        self.n_rows, self.n_columns = dataMatrix.shape
+        self.TopK = min(int(topK), self.n_columns)
+        self.similarity = similarity
+        if row_weights is not None and self.n_rows != len(row_weights):
+            raise ValueError("Cosine_Similarity: provided row_weights and dataMatrix have different number of rows."
+                             "Row_weights has {} rows, dataMatrix has {}.".format(len(row_weights), self.n_rows))
+        csr = check_matrix(dataMatrix, "csr", dtype=np.float32)
+        if not csr.has_sorted_indices:
+            csr = csr.sorted_indices()
+        indptr, indices, data = N.as_i32(csr.indptr), N.as_i32(csr.indices), N.as_f32(csr.data)
+        rw = None if row_weights is None else N.as_f32(row_weights)
+        cfg = N.SimConfig(self.TopK, int(shrink), int(bool(normalize)), N.SIMILARITY_CODES[similarity],
+                          float(asymmetric_alpha), float(tversky_alpha), float(tversky_beta))
+        self._lib = N.load()
+        self._h = C.c_void_p()
+        N.check(self._lib.mi355rec_sim_create(C.byref(self._h), C.byref(cfg), self.n_rows, self.n_columns,
+                                              N.ptr(indptr), N.ptr(indices), N.ptr(data), N.ptr(rw)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi355rec_sim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _range(self, start_col, end_col):
+        # same acceptance rule as Compute_Similarity_Cython.pyx:447-451
+        s, e = 0, self.n_columns
+        if start_col is not None and 0 < start_col < self.n_columns:
+            s = int(start_col)
+        if end_col is not None and s < end_col < self.n_columns:
+            e = int(end_col)
+        return s, e
+
+    def compute_slabs(self, start_col=None, end_col=None):
+        """Raw device output for columns [start_col, end_col): (idx int32 (n_local, topK), val float32)."""
+        s, e = self._range(start_col, end_col)
+        idx = np.empty((e - s, self.TopK), dtype=np.int32)
+        val = np.empty((e - s, self.TopK), dtype=np.float32)
+        N.check(self._lib.mi355rec_sim_compute(self._h, s, e, N.ptr(idx), N.ptr(val)))
+        return idx, val, s
+
+    def compute_slabs_device(self, start_col, end_col, d_idx_ptr, d_val_ptr):
+        """Asynchronous variant writing into device buffers (data_ptr() of int32 / float32 tensors)."""
+        s, e = self._range(start_col, end_col)
+        N.check(self._lib.mi355rec_sim_compute_device(self._h, s, e, C.c_void_p(d_idx_ptr), C.c_void_p(d_val_ptr)))
+        return s, e
+
+    def synchronize(self):
+        N.check(self._lib.mi355rec_sim_sync(self._h))
+
+    def column_costs(self):
+        cost = np.empty(self.n_columns, dtype=np.int64)
+        N.check(self._lib.mi355rec_sim_column_costs(self._h, N.ptr(cost)))
+        return cost
+
+    def stats(self):
+        st = N.Stats()
+        N.check(self._lib.mi355rec_sim_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def compute_similarity(self, start_col=None, end_col=None):
+        if self.TopK == 0:
+            s, e = self._range(start_col, end_col)
+            W = np.zeros((self.n_columns, self.n_columns), dtype=np.float32)
+            slab = np.empty((self.n_columns, e - s), dtype=np.float32)
+            N.check(self._lib.mi355rec_sim_compute_dense(self._h, s, e, N.ptr(slab), e - s))
+            W[:, s:e] = slab
+            return W
+        idx, val, s = self.compute_slabs(start_col, end_col)
+        return slabs_to_csr(idx, val, s, self.n_columns)
+
+
+class Compute_Similarity:
+    """Dispatcher with the reference's signature (Compute_Similarity.py:32).  `use_implementation` accepts
+    "mi355x" (also chosen by the reference's default "density" rule and by "cython"): on this path every
+    implementation name resolves to the device kernels; "python" and similarity="euclidean" are outside the
+    hot path and raise NotImplementedError instead of silently running on the CPU."""
+
+    def __init__(self, dataMatrix, use_implementation="density", similarity=None, **args):
+        assert np.all(np.isfinite(dataMatrix.data)), \
+            "Compute_Similarity: Data matrix contains {} non finite values".format(
+                np.sum(np.logical_not(np.isfinite(dataMatrix.data))))
+        if similarity == "euclidean":
+            raise NotImplementedError("Compute_Similarity: 'euclidean' is not on the MI355X hot path")
+        assert not (dataMatrix.shape[0] == 1 and dataMatrix.nnz == dataMatrix.shape[1]), \
+            "Compute_Similarity: data has only 1 feature (shape: {}) with dense values," \
+            " vector and set based similarities are not defined on 1-dimensional dense data," \
+            " use Euclidean similarity instead.".format(dataMatrix.shape)
+        if similarity is not None:
+            args["similarity"] = similarity
+        if use_implementation not in ("density", "cython", "mi355x"):
+            if use_implementation == "python":
+                raise NotImplementedError("Compute_Similarity: the NumPy implementation is not provided here")
+            raise ValueError("Compute_Similarity: value for argument 'use_implementation' not recognized")
+        if isinstance(dataMatrix, np.ndarray):
+            dataMatrix = sps.csr_matrix(dataMatrix)
+        self.compute_similarity_object = Compute_Similarity_MI355X(dataMatrix, **args)
+
+    def compute_similarity(self, **args):
+        return self.compute_similarity_object.compute_similarity(**args)

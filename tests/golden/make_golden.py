@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Run in the build container (where /root/reference exists):   python tests/golden/make_golden.py
+It imports the reference's compiled Cython kernels (built by oracle/build_ref.py into oracle/_ref/) and its
+pure-Python IALSRecommender, runs them on small seeded inputs and stores inputs + outputs as .npz files.
+The fixtures are what pins the oracle (tests/test_oracle_golden.py) and, through it, the HIP kernels on
+machines where /root/reference does not exist (the GPU box).
+
+Stored per case: the input matrix (CSR triplet), the keyword arguments (JSON) and the reference outputs.
+"""
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import scipy.sparse as sps
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import build_ref, ref_loader  # noqa: E402
+
+
+def small_urm(n_users, n_items, density, seed, real):
+    rng = np.random.default_rng(seed)
+    X = sps.random(n_users, n_items, density, format="csr", random_state=np.random.RandomState(seed), dtype=np.float32)
+    if real:
+        X.data = (rng.integers(1, 6, X.nnz) + 1e-3 * rng.random(X.nnz)).astype(np.float32)
+    else:
+        X.data[:] = 1.0
+    # no empty rows / columns
+    X = X.tolil()
+    for u in range(n_users):
+        if X[u].nnz == 0:
+            X[u, rng.integers(0, n_items)] = 1.0
+    X = X.tocsc().tolil()
+    Xc = X.tocsc()
+    for i in np.flatnonzero(np.diff(Xc.indptr) == 0):
+        X[rng.integers(0, n_users), i] = 1.0
+    X = sps.csr_matrix(X, dtype=np.float32)
+    X.sort_indices()
+    return X
+
+
+def pack_csr(prefix, X):
+    return {prefix + "_indptr": X.indptr.astype(np.int32), prefix + "_indices": X.indices.astype(np.int32),
+            prefix + "_data": X.data.astype(np.float32), prefix + "_shape": np.array(X.shape, dtype=np.int64)}
+
+
+def quiet(fn, *a, **k):
+    with redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def main():
+    assert build_ref.build(), "reference sources not available: run this where /root/reference exists"
+    MF, SLIM, SIM = ref_loader.load("mf"), ref_loader.load("slim"), ref_loader.load("sim")
+
+    # ---------------- similarity ----------------
+    X = small_urm(90, 40, 0.12, 11, real=True)
+    out = pack_csr("X", X)
+    cases = []
+    rw = np.random.default_rng(5).random(X.shape[0])
+    for sim in ["cosine", "adjusted", "asymmetric", "pearson", "jaccard", "dice", "tversky"]:
+        for shrink, normalize in [(0, True), (7, True), (3, False)]:
+            kw = dict(shrink=shrink, normalize=normalize, similarity=sim, asymmetric_alpha=0.3, tversky_alpha=0.7, tversky_beta=1.3)
+            cases.append(kw)
+    for n, kw in enumerate(cases):
+        dense = quiet(lambda: SIM(X, topK=0, **kw).compute_similarity())
+        top = quiet(lambda: SIM(X, topK=6, **kw).compute_similarity())
+        out["dense_%d" % n] = np.asarray(dense, dtype=np.float64)
+        out["top6_%d" % n] = top.toarray().astype(np.float32)
+    out["dense_rw"] = np.asarray(quiet(lambda: SIM(X, topK=0, shrink=2, row_weights=rw).compute_similarity()))
+    out["row_weights"] = rw
+    out["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(HERE, "similarity.npz"), **out)
+
+    # ---------------- BPR-MF / FunkSVD ----------------
+    Xb = small_urm(70, 50, 0.15, 12, real=False)
+    Xr = small_urm(70, 50, 0.15, 13, real=True)
+    out = dict(pack_csr("Xb", Xb), **pack_csr("Xr", Xr))
+    cases = []
+    for mode in ["sgd", "adagrad", "rmsprop", "adam"]:
+        cases.append(dict(matrix="Xb", epochs=3, kw=dict(n_factors=12, algorithm_name="MF_BPR", batch_size=8, random_seed=101,
+                          sgd_mode=mode, learning_rate=0.05, user_reg=0.01, positive_reg=0.02, negative_reg=0.03)))
+        cases.append(dict(matrix="Xr", epochs=2, kw=dict(n_factors=12, algorithm_name="FUNK_SVD", batch_size=16, random_seed=202,
+                          sgd_mode=mode, learning_rate=0.02, user_reg=0.01, item_reg=0.4, bias_reg=0.05, use_bias=True,
+                          negative_interactions_quota=0.3)))
+    cases.append(dict(matrix="Xr", epochs=2, kw=dict(n_factors=5, algorithm_name="FUNK_SVD", batch_size=1, random_seed=7,
+                      sgd_mode="sgd", learning_rate=0.02, use_bias=False, negative_interactions_quota=0.0)))
+    for n, case in enumerate(cases):
+        Xc = Xb if case["matrix"] == "Xb" else Xr
+        m = MF(Xc, **case["kw"])
+        for _ in range(case["epochs"]):
+            quiet(m.epochIteration_Cython)
+        out["U_%d" % n] = m.get_USER_factors()
+        out["V_%d" % n] = m.get_ITEM_factors()
+        if case["kw"].get("use_bias"):
+            out["bu_%d" % n] = m.get_USER_bias(); out["bi_%d" % n] = m.get_ITEM_bias(); out["mu_%d" % n] = m.get_GLOBAL_bias()
+    out["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(HERE, "matrix_factorization.npz"), **out)
+
+    # ---------------- SLIM-BPR ----------------
+    Xs = small_urm(80, 30, 0.2, 14, real=False)
+    out = pack_csr("X", Xs)
+    cases = []
+    for symmetric in [False, True]:
+        for mode in ["sgd", "adagrad", "rmsprop", "adam"]:
+            cases.append(dict(epochs=3, kw=dict(symmetric=symmetric, random_seed=303, sgd_mode=mode, learning_rate=0.05,
+                                                li_reg=0.01, lj_reg=0.02)))
+    for n, case in enumerate(cases):
+        e = SLIM(Xs, topK=False, final_model_sparse_weights=False, **case["kw"])
+        for _ in range(case["epochs"]):
+            quiet(e.epochIteration_Cython)
+        S = quiet(e.get_S)
+        out["S_%d" % n] = S.toarray() if sps.issparse(S) else np.asarray(S)
+        quiet(e._dealloc)
+    out["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(HERE, "slim_bpr.npz"), **out)
+
+    # ---------------- IALS (pure-Python reference) ----------------
+    IALS = ref_loader.load_python_reference("MatrixFactorization.IALSRecommender", "IALSRecommender")
+    Xi = small_urm(60, 45, 0.15, 15, real=True)
+    out = pack_csr("X", Xi)
+    cases = [dict(epochs=2, kw=dict(num_factors=8, confidence_scaling="linear", alpha=1.0, reg=1e-3)),
+             dict(epochs=2, kw=dict(num_factors=16, confidence_scaling="log", alpha=3.0, epsilon=0.5, reg=0.05))]
+    for n, case in enumerate(cases):
+        np.random.seed(404 + n)
+        rec = quiet(lambda: IALS(Xi, verbose=False))
+        state = np.random.get_state()
+        quiet(lambda: rec.fit(epochs=case["epochs"], **case["kw"]))
+        np.random.set_state(state)
+        k = case["kw"]["num_factors"]
+        out["V0_%d" % n] = k ** -0.5 * np.random.random_sample((Xi.shape[1], k))   # same draw as _init_factors (:204-210)
+        out["U_%d" % n] = rec.USER_factors
+        out["V_%d" % n] = rec.ITEM_factors
+    out["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(HERE, "ials.npz"), **out)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,198 @@
+"""Parity of the HIP BPR-MF / FunkSVD epochs (through the C ABI) against the CPU oracle.
+
+Replay mode: the oracle draws the sample stream with glibc rand() exactly like the reference; the device runs
+the same stream from the same initial factors; float32 factors must agree within 1e-5 relative (north_star).
+Native mode: the device draws its own samples; they must be valid samples of the reference's sampler, and
+replaying THAT stream through the oracle must reproduce the device factors.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from recsys2019_deeplearning_evaluation_amd import (MatrixFactorization_BPR_MI355X, MatrixFactorization_FunkSVD_MI355X,
+                                                    MatrixFactorization_MI355X_Epoch)
+from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm, synthetic_urm
+from _util import load_golden, rel_err, unpack_csr
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+MODES = ["sgd", "adagrad", "rmsprop", "adam"]
+
+
+def _replay_case(X, kw, epochs, rtol=RTOL):
+    orc = O.OracleMF(X, **kw)
+    orc.record_samples(10 ** 7)
+    for _ in range(epochs):
+        orc.epochIteration_Cython()
+    u, i, j, r = orc.recorded()
+    dev = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=orc.initial_USER_factors,
+                                           initial_ITEM_factors=orc.initial_ITEM_factors, **kw)
+    if kw["algorithm_name"] == "MF_BPR":
+        dev.replay_samples(u, i, neg_item=j)
+    else:
+        dev.replay_samples(u, i, rating=r)
+    assert rel_err(dev.get_USER_factors(), orc.get_USER_factors()) < rtol
+    assert rel_err(dev.get_ITEM_factors(), orc.get_ITEM_factors()) < rtol
+    if kw.get("use_bias"):
+        assert rel_err(dev.get_USER_bias(), orc.get_USER_bias()) < rtol
+        assert rel_err(dev.get_ITEM_bias(), orc.get_ITEM_bias()) < rtol
+        assert abs(float(dev.get_GLOBAL_bias()) - float(orc.get_GLOBAL_bias())) < rtol * max(1e-3, abs(float(orc.get_GLOBAL_bias())))
+    st = dev.stats()
+    assert st["n_units"] == len(u)
+    assert abs(st["loss"] - orc.cumulative_loss()) <= 1e-3 * max(1.0, orc.cumulative_loss()) or epochs > 1
+    dev.close()
+    return dev
+
+
+def test_golden_fixture_replay(gpu):
+    """The committed reference outputs: oracle stream replayed on the device lands on the reference's factors."""
+    z, cases = load_golden("matrix_factorization")
+    mats = {"Xb": unpack_csr(z, "Xb"), "Xr": unpack_csr(z, "Xr")}
+    for n, case in enumerate(cases):
+        X, kw = mats[case["matrix"]], case["kw"]
+        orc = O.OracleMF(X, **kw)
+        orc.record_samples(10 ** 6)
+        for _ in range(case["epochs"]):
+            orc.epochIteration_Cython()
+        u, i, j, r = orc.recorded()
+        dev = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=orc.initial_USER_factors,
+                                               initial_ITEM_factors=orc.initial_ITEM_factors, **kw)
+        dev.replay_samples(u, i, neg_item=j, rating=r) if kw["algorithm_name"] == "MF_BPR" else dev.replay_samples(u, i, rating=r)
+        assert rel_err(dev.get_USER_factors(), z["U_%d" % n]) < RTOL, (n, kw)
+        assert rel_err(dev.get_ITEM_factors(), z["V_%d" % n]) < RTOL, (n, kw)
+        if kw.get("use_bias"):
+            assert rel_err(dev.get_ITEM_bias(), z["bi_%d" % n]) < RTOL
+            assert rel_err(dev.get_USER_bias(), z["bu_%d" % n]) < RTOL
+        dev.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("k", [1, 10, 64, 128, 200, 300])
+def test_bpr_replay_parity(gpu, mode, k):
+    X = named_urm("ml1m", "binary", scale=0.2)
+    kw = dict(n_factors=k, algorithm_name="MF_BPR", batch_size=100, random_seed=11, sgd_mode=mode, learning_rate=0.05,
+              user_reg=0.002, positive_reg=0.003, negative_reg=0.004)
+    _replay_case(X, kw, epochs=4)
+
+
+@pytest.mark.parametrize("batch_size", [1, 7, 1000, 5000])
+def test_bpr_batch_sizes(gpu, batch_size):
+    X = named_urm("ml1m", "binary", scale=0.2)
+    kw = dict(n_factors=64, algorithm_name="MF_BPR", batch_size=batch_size, random_seed=5, sgd_mode="sgd", learning_rate=0.05)
+    _replay_case(X, kw, epochs=2 if batch_size > 1 else 1)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("use_bias", [False, True])
+def test_funk_replay_parity(gpu, mode, use_bias):
+    X = named_urm("ml1m", "real", scale=0.12)
+    kw = dict(n_factors=32, algorithm_name="FUNK_SVD", batch_size=256, random_seed=21, sgd_mode=mode, learning_rate=0.01,
+              user_reg=0.01, item_reg=0.5, positive_reg=0.0, bias_reg=0.02, use_bias=use_bias, negative_interactions_quota=0.35)
+    _replay_case(X, kw, epochs=1)
+
+
+def test_config1_ml1m_k64_replay(gpu):
+    """BASELINE config 2 at full ML-1M shape: k=64, batch 1000, sgd; 5 replayed epochs."""
+    X = named_urm("ml1m", "binary")
+    kw = dict(n_factors=64, algorithm_name="MF_BPR", batch_size=1000, random_seed=42, sgd_mode="sgd", learning_rate=1e-3,
+              init_std_dev=0.1)
+    _replay_case(X, kw, epochs=5)
+
+
+def _assert_valid_bpr_stream(X, u, i, j):
+    indptr, indices = X.indptr, X.indices
+    assert ((u >= 0) & (u < X.shape[0])).all() and ((j >= 0) & (j < X.shape[1])).all()
+    seen = set(zip(np.repeat(np.arange(X.shape[0]), np.diff(indptr)).tolist(), indices.tolist()))
+    pairs_pos = list(zip(u.tolist(), i.tolist())); pairs_neg = list(zip(u.tolist(), j.tolist()))
+    assert all(p in seen for p in pairs_pos), "positive item not in the user's profile"
+    assert not any(p in seen for p in pairs_neg), "negative item is in the user's profile"
+
+
+def test_native_sampler_is_a_valid_reference_sampler(gpu):
+    X = synthetic_urm(2000, 300, 60000, 1, 299, seed=3, values="binary")
+    # a user with every item and a user with none must never be drawn (.pyx:950-958)
+    X = X.tolil(); X[0, :] = 1.0; X[1, :] = 0.0; X = X.tocsr(); X.sort_indices()
+    dev = MatrixFactorization_MI355X_Epoch(X, n_factors=16, algorithm_name="MF_BPR", batch_size=500, random_seed=77, learning_rate=0.05)
+    dev.epochIteration_Cython()
+    u, i, j = dev.last_epoch_samples()
+    assert len(u) == (X.shape[0] // 500 + 1) * 500                 # .pyx:583
+    _assert_valid_bpr_stream(X, u, i, j)
+    assert 0 not in set(u.tolist()) and 1 not in set(u.tolist())
+    # users uniform among eligible ones: chi-square on 20 buckets
+    counts = np.bincount(u // 100, minlength=20).astype(float)
+    expected = len(u) / 20.0
+    assert ((counts - expected) ** 2 / expected).sum() < 60
+    # different epochs draw different streams; same seed reproduces the stream
+    dev.epochIteration_Cython()
+    u2, _, _ = dev.last_epoch_samples()
+    assert (u2 != u).any()
+    again = MatrixFactorization_MI355X_Epoch(X, n_factors=16, algorithm_name="MF_BPR", batch_size=500, random_seed=77, learning_rate=0.05)
+    again.epochIteration_Cython()
+    np.testing.assert_array_equal(again.last_epoch_samples()[0], u)
+
+
+@pytest.mark.parametrize("algorithm", ["MF_BPR", "FUNK_SVD"])
+def test_native_epoch_equals_oracle_on_the_device_stream(gpu, algorithm):
+    X = named_urm("ml1m", "real" if algorithm == "FUNK_SVD" else "binary", scale=0.2)
+    kw = dict(n_factors=48, algorithm_name=algorithm, batch_size=200, random_seed=31, sgd_mode="adagrad", learning_rate=0.05,
+              user_reg=0.01, positive_reg=0.01, negative_reg=0.01)
+    if algorithm == "FUNK_SVD":
+        kw.update(use_bias=True, bias_reg=0.01, negative_interactions_quota=0.4, batch_size=2000)
+    orc = O.OracleMF(X, **kw)
+    dev = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=orc.initial_USER_factors,
+                                           initial_ITEM_factors=orc.initial_ITEM_factors, **kw)
+    dev.epochIteration_Cython()
+    u, i, third = dev.last_epoch_samples()
+    if algorithm == "MF_BPR":
+        orc.replay(u, i, j=third)
+    else:
+        # positives carry the stored rating, negatives 0 and are absent from the profile (.pyx:900-931)
+        dense = X.toarray()
+        np.testing.assert_array_equal(dense[u, i], third)
+        frac_pos = (third != 0).mean()
+        assert abs(frac_pos - 0.4) < 0.03           # quota is the probability of a POSITIVE (sic, .pyx:898)
+        orc.replay(u, i, rating=third.astype(np.float64))
+    assert rel_err(dev.get_USER_factors(), orc.get_USER_factors()) < RTOL
+    assert rel_err(dev.get_ITEM_factors(), orc.get_ITEM_factors()) < RTOL
+
+
+def test_recommender_fit_surface(gpu):
+    X = named_urm("ml1m", "binary", scale=0.15)
+    rec = MatrixFactorization_BPR_MI355X(X, verbose=False)
+    rec.fit(epochs=30, batch_size=200, num_factors=16, learning_rate=0.1, sgd_mode="adagrad", random_seed=1)
+    assert rec.USER_factors.shape == (X.shape[0], 16) and rec.ITEM_factors.shape == (X.shape[1], 16)
+    assert rec.use_bias is False
+    # training must have learned to rank seen items above unseen ones (AUC-like check on the training data)
+    scores = rec._compute_item_score(np.arange(100))
+    dense = X[:100].toarray() > 0
+    pos = np.array([scores[r][dense[r]].mean() for r in range(100)]); neg = np.array([scores[r][~dense[r]].mean() for r in range(100)])
+    assert (pos > neg).mean() > 0.9
+    ranked = rec.recommend(np.arange(10), cutoff=5)
+    assert all(len(r) == 5 for r in ranked)
+    f = MatrixFactorization_FunkSVD_MI355X(named_urm("ml1m", "real", scale=0.1), verbose=False)
+    f.fit(epochs=2, batch_size=500, num_factors=8, learning_rate=0.01, use_bias=True, random_seed=2)
+    assert f.USER_bias.shape == (f.n_users,) and np.isfinite(f.ITEM_factors).all()
+
+
+def test_full_size_ml20m_k128_properties(gpu):
+    """BASELINE headline shape (138k x 27k, k=128, batch 1000).  Size-independent properties: with lr = 0 nothing
+    moves; with lr > 0 only sampled rows move, and the batch update is linear in the learning rate for sgd."""
+    X = named_urm("ml20m", "binary")
+    base = dict(n_factors=128, algorithm_name="MF_BPR", batch_size=1000, random_seed=9, sgd_mode="sgd")
+    frozen = MatrixFactorization_MI355X_Epoch(X, learning_rate=0.0, **base)
+    U0, V0 = frozen.get_factors()
+    frozen.epochIteration_Cython()
+    U1, V1 = frozen.get_factors()
+    np.testing.assert_array_equal(U0, U1); np.testing.assert_array_equal(V0, V1)
+    u, i, j = frozen.last_epoch_samples()
+    # first mini-batch only: update is linear in lr (same seed => same samples, same start-of-batch factors)
+    a = MatrixFactorization_MI355X_Epoch(X, learning_rate=0.01, **base); a.replay_samples(u[:1000], i[:1000], neg_item=j[:1000])
+    b = MatrixFactorization_MI355X_Epoch(X, learning_rate=0.02, **base); b.replay_samples(u[:1000], i[:1000], neg_item=j[:1000])
+    Ua, Va = a.get_factors(); Ub, Vb = b.get_factors()
+    moved = np.unique(u[:1000])
+    untouched = np.setdiff1d(np.arange(X.shape[0]), moved)
+    np.testing.assert_array_equal(Ua[untouched], U0[untouched])
+    dA, dB = (Ua - U0)[moved], (Ub - U0)[moved]
+    assert np.abs(dB - 2 * dA).max() <= 1e-4 * np.abs(dB).max()
+    st = a.stats()
+    assert st["n_units"] == 1000

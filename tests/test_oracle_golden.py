@@ -1,0 +1,87 @@
+"""The CPU oracle (oracle/) reproduces the fixtures generated from the reference itself (tests/golden/)."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from oracle import oracle as O
+from _util import load_golden, unpack_csr
+
+
+def test_similarity_oracle_matches_reference_outputs():
+    z, cases = load_golden("similarity")
+    X = unpack_csr(z, "X")
+    for n, kw in enumerate(cases):
+        dense = O.OracleSimilarity(X, topK=0, **kw).compute_similarity()
+        np.testing.assert_array_equal(dense, z["dense_%d" % n])
+        top = O.OracleSimilarity(X, topK=6, **kw).compute_similarity(exact_numpy_topk=True)
+        np.testing.assert_array_equal(top.toarray(), z["top6_%d" % n])
+    dense = O.OracleSimilarity(X, topK=0, shrink=2, row_weights=z["row_weights"]).compute_similarity()
+    np.testing.assert_array_equal(dense, z["dense_rw"])
+
+
+def test_similarity_oracle_c_topk_is_inside_reference_tie_class():
+    z, cases = load_golden("similarity")
+    X = unpack_csr(z, "X")
+    for n, kw in enumerate(cases):
+        top = O.OracleSimilarity(X, topK=6, **kw).compute_similarity().toarray()
+        ref = z["top6_%d" % n]
+        # same multiset of values per column; the chosen indices may differ only among equal values
+        for c in range(ref.shape[1]):
+            np.testing.assert_allclose(np.sort(top[:, c]), np.sort(ref[:, c]), rtol=0, atol=0)
+
+
+def test_mf_oracle_is_bit_exact_with_reference_outputs():
+    z, cases = load_golden("matrix_factorization")
+    mats = {"Xb": unpack_csr(z, "Xb"), "Xr": unpack_csr(z, "Xr")}
+    for n, case in enumerate(cases):
+        m = O.OracleMF(mats[case["matrix"]], **case["kw"])
+        for _ in range(case["epochs"]):
+            m.epochIteration_Cython()
+        np.testing.assert_array_equal(m.get_USER_factors(), z["U_%d" % n])
+        np.testing.assert_array_equal(m.get_ITEM_factors(), z["V_%d" % n])
+        if case["kw"].get("use_bias"):
+            np.testing.assert_array_equal(m.get_USER_bias(), z["bu_%d" % n])
+            np.testing.assert_array_equal(m.get_ITEM_bias(), z["bi_%d" % n])
+            np.testing.assert_array_equal(m.get_GLOBAL_bias(), z["mu_%d" % n])
+
+
+def test_mf_oracle_replay_equals_native_sampling():
+    z, cases = load_golden("matrix_factorization")
+    mats = {"Xb": unpack_csr(z, "Xb"), "Xr": unpack_csr(z, "Xr")}
+    for n, case in enumerate(cases[:4]):
+        X = mats[case["matrix"]]
+        a = O.OracleMF(X, **case["kw"])
+        a.record_samples(10 ** 6)
+        for _ in range(case["epochs"]):
+            a.epochIteration_Cython()
+        u, i, j, r = a.recorded()
+        b = O.OracleMF(X, **case["kw"])
+        b.replay(u, i, j, r)
+        np.testing.assert_array_equal(a.get_USER_factors(), b.get_USER_factors())
+        np.testing.assert_array_equal(a.get_ITEM_factors(), b.get_ITEM_factors())
+        np.testing.assert_array_equal(a.get_USER_factors(), z["U_%d" % n])
+
+
+def test_slim_oracle_is_bit_exact_with_reference_outputs():
+    z, cases = load_golden("slim_bpr")
+    X = unpack_csr(z, "X")
+    for n, case in enumerate(cases):
+        e = O.OracleSLIM(X, topK=False, final_model_sparse_weights=False, **case["kw"])
+        for _ in range(case["epochs"]):
+            e.epochIteration_Cython()
+        np.testing.assert_array_equal(e.get_S_dense(), z["S_%d" % n])
+
+
+def test_ials_oracle_matches_reference_outputs():
+    z, cases = load_golden("ials")
+    X = unpack_csr(z, "X")
+    for n, case in enumerate(cases):
+        kw = case["kw"]
+        Cm = O.oracle_ials_confidence(X, kw["confidence_scaling"], kw["alpha"], kw.get("epsilon", 1.0))
+        Cc = sps.csc_matrix(Cm)
+        V = z["V0_%d" % n].copy()
+        U = np.zeros((X.shape[0], kw["num_factors"]))
+        for _ in range(case["epochs"]):
+            O.oracle_ials_epoch(Cm, Cc, U, V, kw["reg"])
+        np.testing.assert_allclose(U, z["U_%d" % n], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(V, z["V_%d" % n], rtol=1e-10, atol=1e-12)
