@@ -114,10 +114,12 @@ typedef struct {
     int32_t batch_size;
     int32_t use_bias;
     int32_t sgd_mode;        /* MI355REC_SGD ... */
-    float   learning_rate;
-    float   user_reg, item_reg, bias_reg, positive_reg, negative_reg;
-    float   negative_interactions_quota;
-    float   gamma, beta_1, beta_2;
+    /* hyper-parameters are double like the reference's `cdef double` attributes (.pyx:55-56): derived constants
+     * such as (1 - gamma) = 0.005 must not be formed from float-rounded inputs */
+    double  learning_rate;
+    double  user_reg, item_reg, bias_reg, positive_reg, negative_reg;
+    double  negative_interactions_quota;
+    double  gamma, beta_1, beta_2;
     uint64_t random_seed;    /* seeds the on-device counter-based sampler */
 } mi355rec_mf_config;
 
@@ -152,8 +154,8 @@ void mi355rec_mf_destroy(mi355rec_mf_t h);
 typedef struct {
     int32_t symmetric;       /* 1: S[i,s] aliases S[s,i] (Triangular_Matrix, .pyx:1290-1330) */
     int32_t sgd_mode;
-    float   learning_rate, li_reg, lj_reg;
-    float   gamma, beta_1, beta_2;
+    double  learning_rate, li_reg, lj_reg;
+    double  gamma, beta_1, beta_2;
     uint64_t random_seed;
 } mi355rec_slim_config;
 

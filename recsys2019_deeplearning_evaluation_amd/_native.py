@@ -40,18 +40,18 @@ class SimConfig(C.Structure):
 
 class MFConfig(C.Structure):
     _fields_ = [("algorithm", C.c_int32), ("n_factors", C.c_int32), ("batch_size", C.c_int32),
-                ("use_bias", C.c_int32), ("sgd_mode", C.c_int32), ("learning_rate", C.c_float),
-                ("user_reg", C.c_float), ("item_reg", C.c_float), ("bias_reg", C.c_float),
-                ("positive_reg", C.c_float), ("negative_reg", C.c_float),
-                ("negative_interactions_quota", C.c_float),
-                ("gamma", C.c_float), ("beta_1", C.c_float), ("beta_2", C.c_float),
+                ("use_bias", C.c_int32), ("sgd_mode", C.c_int32), ("learning_rate", C.c_double),
+                ("user_reg", C.c_double), ("item_reg", C.c_double), ("bias_reg", C.c_double),
+                ("positive_reg", C.c_double), ("negative_reg", C.c_double),
+                ("negative_interactions_quota", C.c_double),
+                ("gamma", C.c_double), ("beta_1", C.c_double), ("beta_2", C.c_double),
                 ("random_seed", C.c_uint64)]
 
 
 class SlimConfig(C.Structure):
-    _fields_ = [("symmetric", C.c_int32), ("sgd_mode", C.c_int32), ("learning_rate", C.c_float),
-                ("li_reg", C.c_float), ("lj_reg", C.c_float),
-                ("gamma", C.c_float), ("beta_1", C.c_float), ("beta_2", C.c_float), ("random_seed", C.c_uint64)]
+    _fields_ = [("symmetric", C.c_int32), ("sgd_mode", C.c_int32), ("learning_rate", C.c_double),
+                ("li_reg", C.c_double), ("lj_reg", C.c_double),
+                ("gamma", C.c_double), ("beta_1", C.c_double), ("beta_2", C.c_double), ("random_seed", C.c_uint64)]
 
 
 _vp = C.c_void_p

@@ -33,7 +33,9 @@ struct MfState {           // lives in device memory so that launches carry no p
 struct MfParams {
     int n_users, n_items, k, batch_size;
     int use_bias, sgd_mode, sample_negatives;
-    float lr, user_reg, bias_reg, positive_reg, negative_reg, quota, gamma, beta_1, beta_2;
+    float lr, user_reg, bias_reg, positive_reg, negative_reg, quota;
+    float gamma, beta_1, beta_2, one_m_gamma, one_m_beta_1, one_m_beta_2;   // 1 - x formed in double on the host
+    double beta_1_d, beta_2_d;
     unsigned long long seed;
     const int *indptr, *indices;
     const float *data;
@@ -247,13 +249,13 @@ __device__ __forceinline__ float adapt(const MfParams &p, float g, float *c1, fl
             return g / (sqrtf(c) + 1e-8f);
         }
         case MI355REC_RMSPROP: {
-            float c = c1[at] * p.gamma + (1.f - p.gamma) * (g * g);
+            float c = c1[at] * p.gamma + p.one_m_gamma * (g * g);
             c1[at] = c;
             return g / (sqrtf(c) + 1e-8f);
         }
         case MI355REC_ADAM: {
-            float m1 = c1[at] * p.beta_1 + (1.f - p.beta_1) * g;
-            float m2 = c2[at] * p.beta_2 + (1.f - p.beta_2) * (g * g);
+            float m1 = c1[at] * p.beta_1 + p.one_m_beta_1 * g;
+            float m2 = c2[at] * p.beta_2 + p.one_m_beta_2 * (g * g);
             c1[at] = m1;
             c2[at] = m2;
             return (m1 / pw1) / (sqrtf(m2 / pw2) + 1e-8f);
@@ -273,8 +275,8 @@ __global__ __launch_bounds__(256) void mf_apply_kernel(const MfParams p) {
     const float invB = 1.f / (float)p.batch_size;      // mean over batch_size, NOT over the row's count (.pyx:802)
     float pw1 = 1.f, pw2 = 1.f;
     if (p.sgd_mode == MI355REC_ADAM) {                  // beta^(t) with t = batch + 1 (.pyx:217-218, :646-649)
-        pw1 = (float)(1.0 - pow((double)p.beta_1, (double)(batch + 1)));
-        pw2 = (float)(1.0 - pow((double)p.beta_2, (double)(batch + 1)));
+        pw1 = (float)(1.0 - pow(p.beta_1_d, (double)(batch + 1)));
+        pw2 = (float)(1.0 - pow(p.beta_2_d, (double)(batch + 1)));
     }
     if (w == 0 && lane == 0) {
         if (p.use_bias) {
@@ -341,10 +343,13 @@ void fill_params(mi355rec_mf *h, MfParams &p) {
     p.n_users = h->n_users; p.n_items = h->n_items; p.k = h->k; p.batch_size = c.batch_size;
     p.use_bias = c.use_bias && c.algorithm == MI355REC_MF_FUNK_SVD;
     p.sgd_mode = c.sgd_mode;
-    p.sample_negatives = c.negative_interactions_quota != 0.f;
-    p.lr = c.learning_rate; p.user_reg = c.user_reg; p.bias_reg = c.bias_reg;
-    p.positive_reg = c.positive_reg; p.negative_reg = c.negative_reg; p.quota = c.negative_interactions_quota;
-    p.gamma = c.gamma; p.beta_1 = c.beta_1; p.beta_2 = c.beta_2;
+    p.sample_negatives = c.negative_interactions_quota != 0.0;
+    p.lr = (float)c.learning_rate; p.user_reg = (float)c.user_reg; p.bias_reg = (float)c.bias_reg;
+    p.positive_reg = (float)c.positive_reg; p.negative_reg = (float)c.negative_reg;
+    p.quota = (float)c.negative_interactions_quota;
+    p.gamma = (float)c.gamma; p.beta_1 = (float)c.beta_1; p.beta_2 = (float)c.beta_2;
+    p.one_m_gamma = (float)(1.0 - c.gamma); p.one_m_beta_1 = (float)(1.0 - c.beta_1); p.one_m_beta_2 = (float)(1.0 - c.beta_2);
+    p.beta_1_d = c.beta_1; p.beta_2_d = c.beta_2;
     p.seed = c.random_seed;
     p.indptr = h->indptr.ptr; p.indices = h->indices.ptr; p.data = h->data.ptr;
     p.U = h->U.ptr; p.V = h->V.ptr; p.accU = h->accU.ptr; p.accV = h->accV.ptr;

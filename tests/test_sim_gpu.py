@@ -82,15 +82,14 @@ def test_csr_assembly_matches_reference_layout(gpu):
 
 
 def test_column_ranges_equal_full_build(gpu):
-    X = named_urm("ml1m", "real", scale=0.2)
+    # binary data: co-occurrence counts are exact in fp32 whatever the accumulation order, so two builds are
+    # bit-identical (on real-valued data the LDS float atomics reorder sums at the 1e-7 level)
+    X = named_urm("ml1m", "binary", scale=0.2)
     n = X.shape[1]
     dev = Compute_Similarity_MI355X(X, topK=30, shrink=1)
     full_idx, full_val, _ = dev.compute_slabs()
     cuts = [0, n // 5, n // 2, n - 1, n]
     for s, e in zip(cuts[:-1], cuts[1:]):
-        W = dev.compute_similarity(start_col=s if s else None, end_col=e)
-        if e == n:                                    # end_col == n_cols is rejected by the reference rule -> full range from s
-            pass
         idx, val, s0 = dev.compute_slabs(s, e)
         np.testing.assert_array_equal(idx, full_idx[s0:s0 + len(idx)])
         np.testing.assert_array_equal(val, full_val[s0:s0 + len(idx)])
