@@ -41,15 +41,22 @@ int mi355rec_set_device(int device);
 /* "gfx950:..." architecture string of the current device. */
 int mi355rec_device_name(char *buf, int buf_len);
 
-/* Timing of the hot kernels of the last run/compute call on a handle, measured with HIP events recorded
- * on the handle's own stream (bench.py's roofline figure comes from here). */
+/* Timing of the last run/compute call on a handle, measured with HIP events on the handle's own stream
+ * (bench.py's throughput and roofline figures come from here).
+ *   call_ms    events recorded on the stream immediately before the first and after the last kernel of the call;
+ *   kernel_ms  SUM of the durations of the timed launches of the DOMINANT kernel (mf: gradient kernel, sim: column
+ *              kernel, slim: step kernel, ials: row-solve kernel), each measured by the start/stop events the
+ *              dispatch itself carries (hipExtLaunchKernelGGL) -- the same begin/end timestamps rocprofv3
+ *              --kernel-trace reports; n_timed of the n_launches launches were timed (see *_set_profiling). */
 typedef struct {
-    double  kernel_ms;      /* elapsed ms between the events bracketing the hot kernels of the last call */
-    int64_t n_launches;     /* number of launches of the dominant kernel inside that bracket */
+    double  call_ms;
+    double  kernel_ms;
+    int64_t n_launches;     /* launches of the dominant kernel in the call */
+    int64_t n_timed;        /* how many of them carry timing events (kernel_ms / n_timed = average launch duration) */
     int64_t n_units;        /* units processed: samples (mf, slim), columns (sim), row solves (ials) */
-    double  algorithmic_bytes; /* ALGORITHMIC bytes moved by those launches (definition: DESIGN.md section 4) */
-    double  algorithmic_flops; /* ALGORITHMIC flops (ials), 0 elsewhere */
-    double  loss;           /* cumulative x_uij^2 / squared error of the last call where defined, else 0 */
+    double  algorithmic_bytes; /* ALGORITHMIC bytes of the WHOLE call (definition: DESIGN.md section 4) */
+    double  algorithmic_flops; /* ALGORITHMIC flops of the whole call (ials), 0 elsewhere */
+    double  loss;           /* cumulative x_uij^2 / squared error of the call where defined, else 0 */
 } mi355rec_stats;
 
 /* ------------------------------------------------------------------------------------------------------
@@ -143,6 +150,9 @@ int mi355rec_mf_get_factors(mi355rec_mf_t h, float *U, float *V, float *bu, floa
 /* Copy the (u, i, j|rating) stream drawn by the LAST mi355rec_mf_run_epochs call (at most cap entries);
  * returns the number of samples of that call in *n. */
 int mi355rec_mf_get_last_samples(mi355rec_mf_t h, int32_t *u, int32_t *i, int32_t *j, float *rating, int64_t cap, int64_t *n);
+/* Time (at most) the first max_timed_launches gradient-kernel launches of every subsequent call with per-dispatch
+ * events; 0 (default) disables it. */
+int mi355rec_mf_set_profiling(mi355rec_mf_t h, int32_t max_timed_launches);
 int mi355rec_mf_get_stats(mi355rec_mf_t h, mi355rec_stats *stats);
 void mi355rec_mf_destroy(mi355rec_mf_t h);
 

@@ -26,8 +26,9 @@ class NativeLibraryError(RuntimeError):
 
 
 class Stats(C.Structure):
-    _fields_ = [("kernel_ms", C.c_double), ("n_launches", C.c_int64), ("n_units", C.c_int64),
-                ("algorithmic_bytes", C.c_double), ("algorithmic_flops", C.c_double), ("loss", C.c_double)]
+    _fields_ = [("call_ms", C.c_double), ("kernel_ms", C.c_double), ("n_launches", C.c_int64), ("n_timed", C.c_int64),
+                ("n_units", C.c_int64), ("algorithmic_bytes", C.c_double), ("algorithmic_flops", C.c_double),
+                ("loss", C.c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -76,6 +77,7 @@ SIGNATURES = {
     "mi355rec_mf_run_samples": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64]),
     "mi355rec_mf_get_factors": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mi355rec_mf_get_last_samples": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
+    "mi355rec_mf_set_profiling": (C.c_int, [_vp, _i32]),
     "mi355rec_mf_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "mi355rec_mf_destroy": (None, [_vp]),
     "mi355rec_slim_create": (C.c_int, [C.POINTER(_vp), C.POINTER(SlimConfig), _i32, _i32, _vp, _vp]),

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -108,6 +109,45 @@ struct StreamTimer {
         float ms = 0.f;
         MI_HIP(hipEventElapsedTime(&ms, t0, t1));
         return ms;
+    }
+};
+
+// Pool of (start, stop) event pairs attached to individual dispatches (hipExtLaunchKernelGGL).
+struct DispatchTimers {
+    std::vector<hipEvent_t> start, stop;
+    int used = 0;
+    void reserve(int n) {
+        while ((int)start.size() < n) {
+            hipEvent_t a, b;
+            MI_HIP(hipEventCreate(&a));
+            MI_HIP(hipEventCreate(&b));
+            start.push_back(a);
+            stop.push_back(b);
+        }
+    }
+    void reset() { used = 0; }
+    bool next(hipEvent_t &a, hipEvent_t &b, int limit) {
+        if (used >= limit || used >= (int)start.size()) return false;
+        a = start[used];
+        b = stop[used];
+        ++used;
+        return true;
+    }
+    // valid after the stream has been synchronised
+    double total_ms() const {
+        double t = 0;
+        for (int i = 0; i < used; ++i) {
+            float ms = 0.f;
+            MI_HIP(hipEventElapsedTime(&ms, start[i], stop[i]));
+            t += ms;
+        }
+        return t;
+    }
+    void destroy() {
+        for (auto e : start) (void)hipEventDestroy(e);
+        for (auto e : stop) (void)hipEventDestroy(e);
+        start.clear();
+        stop.clear();
     }
 };
 

@@ -333,7 +333,8 @@ struct mi355rec_mf {
     long long record_period = 0;
     size_t stream_capacity = 0;
     mi355rec_stats stats{};
-    bool timer_valid = false;
+    DispatchTimers dispatch_timers;
+    int max_timed = 0;
 };
 
 namespace {
@@ -367,12 +368,14 @@ void fill_params(mi355rec_mf *h, MfParams &p) {
 template <int ALGO, bool REPLAY>
 void launch_grad_ki(mi355rec_mf *h, const MfParams &p, int grid) {
     const int ki = h->k <= 256 ? (h->k + 63) / 64 : 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    h->dispatch_timers.next(e0, e1, h->max_timed);     // null events = plain launch
     switch (ki) {
-        case 1: hipLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 1>), dim3(grid), dim3(256), 0, h->stream, p); break;
-        case 2: hipLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 2>), dim3(grid), dim3(256), 0, h->stream, p); break;
-        case 3: hipLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 3>), dim3(grid), dim3(256), 0, h->stream, p); break;
-        case 4: hipLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 4>), dim3(grid), dim3(256), 0, h->stream, p); break;
-        default: hipLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 0>), dim3(grid), dim3(256), 0, h->stream, p); break;
+        case 1: hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 1>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p); break;
+        case 2: hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 2>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p); break;
+        case 3: hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 3>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p); break;
+        case 4: hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 4>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p); break;
+        default: hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 0>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p); break;
     }
 }
 
@@ -411,7 +414,9 @@ void finish_call(mi355rec_mf *h, long long n_samples, long long n_batches) {
     MI_HIP(hipStreamSynchronize(h->stream));
     MfState st{};
     MI_HIP(hipMemcpy(&st, h->state.ptr, sizeof(MfState), hipMemcpyDeviceToHost));
-    h->stats.kernel_ms = h->timer.elapsed_ms();
+    h->stats.call_ms = h->timer.elapsed_ms();
+    h->stats.kernel_ms = h->dispatch_timers.total_ms();
+    h->stats.n_timed = h->dispatch_timers.used;
     h->stats.n_launches = n_batches;            // launches of the dominant (gradient) kernel
     h->stats.n_units = n_samples;
     h->stats.algorithmic_bytes = bytes_per_sample(h) * (double)n_samples;
@@ -493,6 +498,7 @@ extern "C" int mi355rec_mf_run_epochs(mi355rec_mf_t h, int32_t n_epochs) {
         MfParams p{};
         fill_params(h, p);
         MI_HIP(hipMemsetAsync(&h->state.ptr->loss, 0, sizeof(double), h->stream));
+        h->dispatch_timers.reset();
         h->timer.start(h->stream);
         for (long long b = 0; b < n_batches; ++b) launch_batch(h, p, false);
         h->timer.stop(h->stream);
@@ -524,6 +530,7 @@ extern "C" int mi355rec_mf_run_samples(mi355rec_mf_t h, const int32_t *u, const 
         fill_params(h, p);
         MI_HIP(hipMemsetAsync(&h->state.ptr->loss, 0, sizeof(double), s));
         const long long n_batches = (n + B - 1) / B;
+        h->dispatch_timers.reset();
         h->timer.start(s);
         for (long long b = 0; b < n_batches; ++b) {
             p.n_in_batch = (int)std::min<long long>(B, n - b * B);
@@ -565,6 +572,16 @@ extern "C" int mi355rec_mf_get_last_samples(mi355rec_mf_t h, int32_t *u, int32_t
     });
 }
 
+extern "C" int mi355rec_mf_set_profiling(mi355rec_mf_t h, int32_t max_timed_launches) {
+    return guarded([&] {
+        MI_REQUIRE(h, "NULL handle");
+        MI_REQUIRE(max_timed_launches >= 0 && max_timed_launches <= 65536, "max_timed_launches out of range");
+        ensure_device();
+        h->max_timed = max_timed_launches;
+        h->dispatch_timers.reserve(max_timed_launches);
+    });
+}
+
 extern "C" int mi355rec_mf_get_stats(mi355rec_mf_t h, mi355rec_stats *stats) {
     return guarded([&] {
         MI_REQUIRE(h && stats, "NULL argument");
@@ -576,6 +593,7 @@ extern "C" void mi355rec_mf_destroy(mi355rec_mf_t h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->timer.destroy();
+    h->dispatch_timers.destroy();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

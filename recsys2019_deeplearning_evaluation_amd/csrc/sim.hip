@@ -437,7 +437,8 @@ struct mi355rec_sim {
     size_t nnz = 0;
     bool unit_values = false;
     hipStream_t stream = nullptr;
-    StreamTimer timer;
+    StreamTimer timer;       // start/stop events carried by the column-kernel dispatch itself
+    StreamTimer call_timer;  // events around the whole call (H2D of the schedule, kernel, D2H of the result)
     DeviceBuffer<int> csr_ptr, csr_idx, csc_ptr, csc_idx, order;
     DeviceBuffer<float> csr_val, csc_val, row_w, norm, norm_alpha, norm_1ma;
     DeviceBuffer<unsigned> queue;
@@ -459,11 +460,11 @@ void launch_sim(mi355rec_sim *h, const SimParams &p, int grid, size_t lds) {
     if (h->unit_values) {
         auto k = sim_column_kernel<THREADS, G, true>;
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(THREADS), lds, h->stream, p);
+        hipExtLaunchKernelGGL(k, dim3(grid), dim3(THREADS), (unsigned)lds, h->stream, h->timer.t0, h->timer.t1, 0, p);
     } else {
         auto k = sim_column_kernel<THREADS, G, false>;
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(THREADS), lds, h->stream, p);
+        hipExtLaunchKernelGGL(k, dim3(grid), dim3(THREADS), (unsigned)lds, h->stream, h->timer.t0, h->timer.t1, 0, p);
     }
     MI_HIP(hipGetLastError());
 }
@@ -533,7 +534,7 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
 
     const size_t lds = (size_t)p.n_cols_pad * 4 + (size_t)AUX_WORDS * 4;
     const int cus = multiprocessor_count();
-    h->timer.start(h->stream);
+    h->call_timer.start(h->stream);
     if (lds > 72 * 1024) {
         // one 16-wave workgroup per CU (the accumulator owns most of the 160 KiB LDS)
         launch_sim_g<1024>(h, p, std::min(n_local, cus), lds);
@@ -541,9 +542,10 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
         int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (lds + 1024))));
         launch_sim_g<512>(h, p, std::min(n_local, cus * per_cu), lds);
     }
-    h->timer.stop(h->stream);
+    h->call_timer.stop(h->stream);
 
     h->stats.n_launches = 1;
+    h->stats.n_timed = 1;
     h->stats.n_units = n_local;
     // ALGORITHMIC bytes: every (user-of-column, item-of-user) pair is one index (+ one value
     // unless the data is all-ones) read; every user of the column one index (+ value); plus the K results.
@@ -587,6 +589,7 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         MI_REQUIRE(h->nnz > 0, "matrix has no stored values");
         MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->timer.init();
+        h->call_timer.init();
         hipStream_t s = h->stream;
         const size_t nnz = h->nnz;
         h->csr_ptr.upload(csr_indptr, (size_t)n_rows + 1, s);
@@ -704,7 +707,7 @@ extern "C" int mi355rec_sim_compute(mi355rec_sim_t h, int32_t start_col, int32_t
         h->out_idx.download(nbr_idx, n, h->stream);
         h->out_val.download(nbr_val, n, h->stream);
         MI_HIP(hipStreamSynchronize(h->stream));
-        h->stats.kernel_ms = h->timer.elapsed_ms();
+        h->stats.kernel_ms = h->timer.elapsed_ms(), h->stats.call_ms = h->call_timer.elapsed_ms();
     });
 }
 
@@ -733,7 +736,7 @@ extern "C" int mi355rec_sim_compute_dense(mi355rec_sim_t h, int32_t start_col, i
         MI_HIP(hipMemcpy2DAsync(W, (size_t)ld * sizeof(float), slab_t.ptr, (size_t)n_local * sizeof(float),
                                 (size_t)n_local * sizeof(float), (size_t)h->n_cols, hipMemcpyDeviceToHost, h->stream));
         MI_HIP(hipStreamSynchronize(h->stream));
-        h->stats.kernel_ms = h->timer.elapsed_ms();
+        h->stats.kernel_ms = h->timer.elapsed_ms(), h->stats.call_ms = h->call_timer.elapsed_ms();
     });
 }
 
@@ -748,7 +751,7 @@ extern "C" int mi355rec_sim_sync(mi355rec_sim_t h) {
     return guarded([&] {
         MI_REQUIRE(h, "NULL handle");
         MI_HIP(hipStreamSynchronize(h->stream));
-        if (h->last_start >= 0) h->stats.kernel_ms = h->timer.elapsed_ms();
+        if (h->last_start >= 0) h->stats.kernel_ms = h->timer.elapsed_ms(), h->stats.call_ms = h->call_timer.elapsed_ms();
     });
 }
 
@@ -763,6 +766,7 @@ extern "C" void mi355rec_sim_destroy(mi355rec_sim_t h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->timer.destroy();
+    h->call_timer.destroy();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

@@ -85,8 +85,8 @@ class MatrixFactorization_MI355X_Epoch:
         if self.verbose:
             st = self.stats()
             print("{}: Processed {} samples in {:.3f} seconds. loss {:.2E}. Sample per second: {:.0f}".format(
-                self.algorithm_name, st["n_units"], st["kernel_ms"] * 1e-3, st["loss"] / max(1, st["n_units"]),
-                st["n_units"] / max(1e-9, st["kernel_ms"] * 1e-3)))
+                self.algorithm_name, st["n_units"], st["call_ms"] * 1e-3, st["loss"] / max(1, st["n_units"]),
+                st["n_units"] / max(1e-9, st["call_ms"] * 1e-3)))
             sys.stdout.flush()
 
     def replay_samples(self, user, item, neg_item=None, rating=None):
@@ -108,6 +108,10 @@ class MatrixFactorization_MI355X_Epoch:
         st = N.Stats()
         N.check(self._lib.mi355rec_mf_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def set_profiling(self, max_timed_launches):
+        """Attach start/stop events to (at most) that many gradient-kernel dispatches of every following call."""
+        N.check(self._lib.mi355rec_mf_set_profiling(self._h, int(max_timed_launches)))
 
     # ---- model read-back (fresh host copies, float32) ----
     def _download(self, want_bias):
