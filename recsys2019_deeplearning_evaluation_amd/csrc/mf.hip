@@ -7,13 +7,18 @@
 //
 // Design.  The reference's mini-batch semantics make the B samples of a batch independent:
 // every gradient is taken against start-of-batch factors, summed per row, and the sum is applied once.
-// That maps to two kernels per mini-batch:
-//   mf_grad_kernel   one 64-lane wavefront per sample: on-device sampling (counter-based RNG, rejection
-//                    against the sorted CSR row by binary search), row gather, wavefront-shuffle dot product,
-//                    gradient rows scattered into the fp32 accumulators with device-scope float atomics,
-//                    first-toucher registers the row in the batch's touched list (the reference's flag arrays);
-//   mf_apply_kernel  one wavefront per touched row: mean over batch_size, optimiser step, += lr * step,
+// That maps to one sampling kernel per epoch and two kernels per mini-batch:
+//   mf_sample_kernel one thread per sample of the epoch: counter-based RNG, user / positive draw, negative by
+//                    rejection against the sorted CSR row (binary search); sampling does not depend on the
+//                    factors, so it is taken off the per-batch critical path;
+//   mf_grad_kernel   one 64-lane wavefront per sample: row gather, wavefront-shuffle dot product, gradient rows
+//                    scattered into the fp32 accumulators with device-scope float atomics; the first toucher of
+//                    a row (flag exchange, the reference's flag arrays) files it in the sample's own slot of the
+//                    batch's touched list -- no shared counter, no same-address atomics;
+//   mf_apply_kernel  one wavefront per list slot: mean over batch_size, optimiser step, += lr * step,
 //                    accumulator and flag reset.
+// A whole epoch (1 + 2*n_batches launches) is captured once into a hipGraph and replayed: all per-batch state
+// (batch index -> RNG counter, Adam's beta^t) lives in device memory, so the launches carry no host arguments.
 // There is no dense contraction here, hence no MFMA; the path is bound by row gather/scatter bandwidth and,
 // at the reference's batch sizes (<= 1024), by the dependent-launch latency between mini-batches.
 #include "common.h"
@@ -26,13 +31,12 @@ namespace {
 struct MfState {           // lives in device memory so that launches carry no per-batch host arguments
     long long grad_batch;  // index (since create) of the batch the next grad kernel works on
     long long apply_batch; // same for the next apply kernel
-    unsigned touched[2];   // number of rows in the touched list, by batch parity
-    double loss;           // cumulative x_uij^2 / err^2 of the current call
+    long long epoch;       // index (since create) of the epoch the next sampling kernel draws
 };
 
 struct MfParams {
     int n_users, n_items, k, batch_size;
-    int use_bias, sgd_mode, sample_negatives;
+    int use_bias, sgd_mode, sample_negatives, algorithm_is_bpr;
     float lr, user_reg, bias_reg, positive_reg, negative_reg, quota;
     float gamma, beta_1, beta_2, one_m_gamma, one_m_beta_1, one_m_beta_2;   // 1 - x formed in double on the host
     double beta_1_d, beta_2_d;
@@ -44,14 +48,16 @@ struct MfParams {
     float *c1U, *c2U, *c1V, *c2V;        // optimiser state: c1 = cache / first moment, c2 = second moment
     float *c1_bu, *c2_bu, *c1_bi, *c2_bi, *c_mu;  // c_mu[0] = cache/m1, c_mu[1] = m2
     int *flag;                           // [n_users + n_items]
-    int *list;                           // touched rows of the batch (items are stored as n_users + item)
+    int *list;                           // touched-row slots of the batch: 3 (BPR) / 2 (FunkSVD) per sample, -1 = not first toucher
+    double *loss_slots;                  // [batch_size] per-sample-slot running loss (summed on the host)
     MfState *state;
-    // sample stream of the current call (recorded in native mode, consumed in replay mode)
+    // sample stream: one epoch drawn by mf_sample_kernel (native) or the caller's stream (replay)
     int *su, *si, *sj;
     float *sr;
-    long long stream_base;               // batch index (since create) at which the current call started
-    long long record_period;             // native mode: samples are recorded modulo one epoch
-    int n_in_batch;                      // replay: samples in this launch's batch (<= batch_size)
+    long long stream_base;               // batch index (since create) at which the stream buffer starts
+    long long stream_batches;            // number of mini-batches the stream buffer holds (it is read cyclically)
+    long long samples_per_epoch;
+    int n_in_batch;                      // samples in this launch's batch (<= batch_size; short only in replay)
 };
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
@@ -82,69 +88,71 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ void touch(const MfParams &p, int entry, unsigned parity) {
-    if (atomicExch(&p.flag[entry], 1) == 0) {
-        unsigned at = atomicAdd(&p.state->touched[parity], 1u);
-        p.list[at] = entry;
+// _add_*_sample_in_minibatch (.pyx:737-766): the first toucher of a row owns its apply
+__device__ __forceinline__ void touch(const MfParams &p, int entry, int slot) {
+    p.list[slot] = atomicExch(&p.flag[entry], 1) == 0 ? entry : -1;
+}
+
+// One thread per sample of one epoch (sampleBPR_Cython .pyx:940-985 / sampleMSE_Cython :878-935).
+template <int ALGO>
+__global__ __launch_bounds__(256) void mf_sample_kernel(const MfParams p) {
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long epoch = p.state->epoch;
+    if (t < p.samples_per_epoch) {
+        const unsigned long long sid = (unsigned long long)(epoch * p.samples_per_epoch + t);   // global sample id
+        unsigned d = 0;
+        int u, start = 0, n_seen = 0;
+        do {   // users with no interactions or with no negative item are skipped (.pyx:950-958)
+            u = bounded(draw32(p.seed, sid, d++), p.n_users);
+            start = p.indptr[u];
+            n_seen = p.indptr[u + 1] - start;
+        } while (n_seen == 0 || n_seen == p.n_items);
+        const int *row = p.indices + start;
+        p.su[t] = u;
+        if (ALGO == MI355REC_MF_BPR) {
+            p.si[t] = row[bounded(draw32(p.seed, sid, d++), n_seen)];
+            int j;
+            do { j = bounded(draw32(p.seed, sid, d++), p.n_items); } while (!profile_lacks(row, n_seen, j));
+            p.sj[t] = j;
+        } else {
+            // .pyx:898: a POSITIVE is drawn with probability `quota` (sic); no quota -> always positive
+            bool positive = true;
+            if (p.sample_negatives) positive = (float)draw32(p.seed, sid, d++) * 2.3283064365386963e-10f <= p.quota;
+            if (positive) {
+                const int at = bounded(draw32(p.seed, sid, d++), n_seen);
+                p.si[t] = row[at];
+                p.sr[t] = p.data[start + at];
+            } else {
+                int i;
+                do { i = bounded(draw32(p.seed, sid, d++), p.n_items); } while (!profile_lacks(row, n_seen, i));
+                p.si[t] = i;
+                p.sr[t] = 0.f;
+            }
+        }
     }
+    // the grid is fully drained before the next kernel starts: a plain store by one thread is enough
+    if (t == 0) p.state->epoch = epoch + 1;
 }
 
 // KI = ceil(k / 64) rows-in-registers specialisation (1..4); KI == 0: any k, rows are re-read for the scatter.
-template <int ALGO, bool REPLAY, int KI>
+template <int ALGO, int KI>
 __global__ __launch_bounds__(256) void mf_grad_kernel(const MfParams p) {
-    __shared__ double s_loss[4];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int w = blockIdx.x * 4 + wib;                  // sample slot inside the batch
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);   // sample slot inside the batch
     const long long batch = p.state->grad_batch;
-    const unsigned parity = (unsigned)(batch & 1);
-    const int n_here = REPLAY ? p.n_in_batch : p.batch_size;
     if (blockIdx.x == 0 && threadIdx.x == 0) p.state->apply_batch = batch;   // consumed by the apply kernel that follows
     double my_loss = 0.0;
-    if (w < n_here) {
-        const long long sid = batch * (long long)p.batch_size + w;          // global sample id
-        const long long slot = (batch - p.stream_base) * (long long)p.batch_size + w;
-        int u, i, j = -1;
+    if (w < p.n_in_batch) {
+        const long long slot = ((batch - p.stream_base) % p.stream_batches) * (long long)p.batch_size + w;
+        const int u = p.su[slot], i = p.si[slot];
+        int j = -1;
         float rating = 0.f;
-        if (REPLAY) {
-            u = p.su[slot];
-            i = p.si[slot];
-            if (ALGO == MI355REC_MF_BPR) j = p.sj[slot]; else rating = p.sr[slot];
-        } else {
-            unsigned d = 0;
-            int start = 0, n_seen = 0;
-            do {   // users with no interactions or with no negative item are skipped (.pyx:950-958)
-                u = bounded(draw32(p.seed, sid, d++), p.n_users);
-                start = p.indptr[u];
-                n_seen = p.indptr[u + 1] - start;
-            } while (n_seen == 0 || n_seen == p.n_items);
-            const int *row = p.indices + start;
-            if (ALGO == MI355REC_MF_BPR) {
-                i = row[bounded(draw32(p.seed, sid, d++), n_seen)];
-                do { j = bounded(draw32(p.seed, sid, d++), p.n_items); } while (!profile_lacks(row, n_seen, j));
-            } else {
-                // .pyx:898: a POSITIVE is drawn with probability `quota` (sic); no quota -> always positive
-                bool positive = true;
-                if (p.sample_negatives) positive = (float)draw32(p.seed, sid, d++) * 2.3283064365386963e-10f <= p.quota;
-                if (positive) {
-                    int at = bounded(draw32(p.seed, sid, d++), n_seen);
-                    i = row[at];
-                    rating = p.data[start + at];
-                } else {
-                    do { i = bounded(draw32(p.seed, sid, d++), p.n_items); } while (!profile_lacks(row, n_seen, i));
-                    rating = 0.f;
-                }
-            }
-            if (lane == 0) {
-                const long long rec = slot % p.record_period;
-                p.su[rec] = u;
-                p.si[rec] = i;
-                if (ALGO == MI355REC_MF_BPR) p.sj[rec] = j; else p.sr[rec] = rating;
-            }
-        }
-        if (lane == 0) {   // _add_*_sample_in_minibatch (.pyx:737-766)
-            touch(p, p.n_users + i, parity);
-            if (ALGO == MI355REC_MF_BPR) touch(p, p.n_users + j, parity);
-            touch(p, u, parity);
+        if (ALGO == MI355REC_MF_BPR) j = p.sj[slot]; else rating = p.sr[slot];
+        if (lane == 0) {
+            constexpr int PER = ALGO == MI355REC_MF_BPR ? 3 : 2;
+            touch(p, p.n_users + i, PER * w);
+            if (ALGO == MI355REC_MF_BPR) touch(p, p.n_users + j, PER * w + 1);
+            touch(p, u, PER * w + PER - 1);
         }
         const int k = p.k;
         const float *Wu = p.U + (size_t)u * k, *Hi = p.V + (size_t)i * k;
@@ -232,12 +240,7 @@ __global__ __launch_bounds__(256) void mf_grad_kernel(const MfParams p) {
             }
         }
     }
-    if (lane == 0) s_loss[wib] = my_loss;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
-        if (t != 0.0) atomicAdd(&p.state->loss, t);
-    }
+    if (lane == 0 && w < p.n_in_batch) p.loss_slots[w] += my_loss;   // slot w is private to this wavefront
 }
 
 // adaptive_gradient (.pyx:835-873) on one cell; pw1/pw2 = 1 - beta^t
@@ -270,8 +273,6 @@ __global__ __launch_bounds__(256) void mf_apply_kernel(const MfParams p) {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long batch = p.state->apply_batch;
-    const unsigned parity = (unsigned)(batch & 1);
-    const unsigned n_touched = p.state->touched[parity];
     const float invB = 1.f / (float)p.batch_size;      // mean over batch_size, NOT over the row's count (.pyx:802)
     float pw1 = 1.f, pw2 = 1.f;
     if (p.sgd_mode == MI355REC_ADAM) {                  // beta^(t) with t = batch + 1 (.pyx:217-218, :646-649)
@@ -284,11 +285,12 @@ __global__ __launch_bounds__(256) void mf_apply_kernel(const MfParams p) {
             p.mu[0] += p.lr * g;
             p.acc_mu[0] = 0.f;
         }
-        p.state->touched[parity ^ 1u] = 0;              // list of the NEXT batch starts empty
         p.state->grad_batch = batch + 1;
     }
-    if ((unsigned)w >= n_touched) return;
+    const int per = p.algorithm_is_bpr ? 3 : 2;
+    if (w >= per * p.n_in_batch) return;
     const int entry = p.list[w];
+    if (entry < 0) return;                              // this sample was not the first toucher of that row
     const bool is_item = entry >= p.n_users;
     const int row = is_item ? entry - p.n_users : entry;
     const int k = p.k;
@@ -327,23 +329,33 @@ struct mi355rec_mf {
     DeviceBuffer<int> indptr, indices, flag, list, su, si, sj;
     DeviceBuffer<float> data, U, V, accU, accV, bu, bi, mu, acc_bu, acc_bi, acc_mu;
     DeviceBuffer<float> c1U, c2U, c1V, c2V, c1_bu, c2_bu, c1_bi, c2_bi, c_mu, sr;
+    DeviceBuffer<double> loss_slots;
     DeviceBuffer<MfState> state;
     long long batches_done = 0;      // batches executed since create (device state mirrors this)
-    long long last_call_samples = 0; // samples of the last native call
-    long long record_period = 0;
+    long long last_call_samples = 0; // samples in the stream buffer after the last native call
     size_t stream_capacity = 0;
     mi355rec_stats stats{};
     DispatchTimers dispatch_timers;
     int max_timed = 0;
+    hipGraphExec_t epoch_graph = nullptr;   // one native epoch: sample kernel + n_batches x (grad, apply)
+    long long graph_stream_base = -1;
+    std::vector<double> host_loss;
 };
 
 namespace {
+
+long long batches_per_epoch(const mi355rec_mf *h) {
+    // .pyx:583 (BPR: n_users / B + 1) and :289 (FunkSVD: nnz / B + 1)
+    const long long B = h->cfg.batch_size;
+    return (h->cfg.algorithm == MI355REC_MF_BPR ? (long long)h->n_users / B : (long long)h->nnz / B) + 1;
+}
 
 void fill_params(mi355rec_mf *h, MfParams &p) {
     const auto &c = h->cfg;
     p.n_users = h->n_users; p.n_items = h->n_items; p.k = h->k; p.batch_size = c.batch_size;
     p.use_bias = c.use_bias && c.algorithm == MI355REC_MF_FUNK_SVD;
     p.sgd_mode = c.sgd_mode;
+    p.algorithm_is_bpr = c.algorithm == MI355REC_MF_BPR;
     p.sample_negatives = c.negative_interactions_quota != 0.0;
     p.lr = (float)c.learning_rate; p.user_reg = (float)c.user_reg; p.bias_reg = (float)c.bias_reg;
     p.positive_reg = (float)c.positive_reg; p.negative_reg = (float)c.negative_reg;
@@ -358,43 +370,79 @@ void fill_params(mi355rec_mf *h, MfParams &p) {
     p.acc_bu = h->acc_bu.ptr; p.acc_bi = h->acc_bi.ptr; p.acc_mu = h->acc_mu.ptr;
     p.c1U = h->c1U.ptr; p.c2U = h->c2U.ptr; p.c1V = h->c1V.ptr; p.c2V = h->c2V.ptr;
     p.c1_bu = h->c1_bu.ptr; p.c2_bu = h->c2_bu.ptr; p.c1_bi = h->c1_bi.ptr; p.c2_bi = h->c2_bi.ptr; p.c_mu = h->c_mu.ptr;
-    p.flag = h->flag.ptr; p.list = h->list.ptr; p.state = h->state.ptr;
+    p.flag = h->flag.ptr; p.list = h->list.ptr; p.loss_slots = h->loss_slots.ptr; p.state = h->state.ptr;
     p.su = h->su.ptr; p.si = h->si.ptr; p.sj = h->sj.ptr; p.sr = h->sr.ptr;
     p.stream_base = h->batches_done;
-    p.record_period = h->record_period > 0 ? h->record_period : 1;
+    p.stream_batches = 1;
+    p.samples_per_epoch = batches_per_epoch(h) * (long long)c.batch_size;
     p.n_in_batch = c.batch_size;
 }
 
-template <int ALGO, bool REPLAY>
-void launch_grad_ki(mi355rec_mf *h, const MfParams &p, int grid) {
+template <int ALGO, int KI>
+void launch_grad(mi355rec_mf *h, const MfParams &p, int grid, hipEvent_t e0, hipEvent_t e1) {
+    if (e0) hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, KI>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p);
+    else hipLaunchKernelGGL((mf_grad_kernel<ALGO, KI>), dim3(grid), dim3(256), 0, h->stream, p);   // capturable
+}
+
+template <int ALGO>
+void launch_grad_ki(mi355rec_mf *h, const MfParams &p, int grid, bool timed) {
     const int ki = h->k <= 256 ? (h->k + 63) / 64 : 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    h->dispatch_timers.next(e0, e1, h->max_timed);     // null events = plain launch
+    if (timed) h->dispatch_timers.next(e0, e1, h->max_timed);
     switch (ki) {
-        case 1: hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 1>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p); break;
-        case 2: hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 2>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p); break;
-        case 3: hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 3>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p); break;
-        case 4: hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 4>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p); break;
-        default: hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, REPLAY, 0>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p); break;
+        case 1: launch_grad<ALGO, 1>(h, p, grid, e0, e1); break;
+        case 2: launch_grad<ALGO, 2>(h, p, grid, e0, e1); break;
+        case 3: launch_grad<ALGO, 3>(h, p, grid, e0, e1); break;
+        case 4: launch_grad<ALGO, 4>(h, p, grid, e0, e1); break;
+        default: launch_grad<ALGO, 0>(h, p, grid, e0, e1); break;
     }
 }
 
-void launch_batch(mi355rec_mf *h, const MfParams &p, bool replay) {
+void launch_batch(mi355rec_mf *h, const MfParams &p, bool timed) {
     const int grad_grid = div_up(p.n_in_batch, 4);
     const bool bpr = h->cfg.algorithm == MI355REC_MF_BPR;
-    if (bpr) {
-        if (replay) launch_grad_ki<MI355REC_MF_BPR, true>(h, p, grad_grid);
-        else launch_grad_ki<MI355REC_MF_BPR, false>(h, p, grad_grid);
-    } else {
-        if (replay) launch_grad_ki<MI355REC_MF_FUNK_SVD, true>(h, p, grad_grid);
-        else launch_grad_ki<MI355REC_MF_FUNK_SVD, false>(h, p, grad_grid);
+    if (bpr) launch_grad_ki<MI355REC_MF_BPR>(h, p, grad_grid, timed);
+    else launch_grad_ki<MI355REC_MF_FUNK_SVD>(h, p, grad_grid, timed);
+    const int slots = (bpr ? 3 : 2) * p.n_in_batch;
+    hipLaunchKernelGGL(mf_apply_kernel, dim3(div_up(slots, 4)), dim3(256), 0, h->stream, p);
+}
+
+void launch_sampler(mi355rec_mf *h, const MfParams &p) {
+    const int grid = div_up(p.samples_per_epoch, 256);
+    if (h->cfg.algorithm == MI355REC_MF_BPR) hipLaunchKernelGGL(mf_sample_kernel<MI355REC_MF_BPR>, dim3(grid), dim3(256), 0, h->stream, p);
+    else hipLaunchKernelGGL(mf_sample_kernel<MI355REC_MF_FUNK_SVD>, dim3(grid), dim3(256), 0, h->stream, p);
+}
+
+// One native epoch as plain launches (the first `timed` gradient launches carry per-dispatch events).
+void enqueue_epoch(mi355rec_mf *h, const MfParams &p, bool timed) {
+    launch_sampler(h, p);
+    const long long nb = batches_per_epoch(h);
+    for (long long b = 0; b < nb; ++b) launch_batch(h, p, timed);
+}
+
+// Capture one epoch into a graph (re-captured only if the stream base changed, i.e. after a replay call).
+constexpr long long MAX_GRAPH_BATCHES = 4096;
+void ensure_epoch_graph(mi355rec_mf *h, const MfParams &p) {
+    if (h->epoch_graph && h->graph_stream_base % batches_per_epoch(h) == p.stream_base % batches_per_epoch(h)) return;
+    if (h->epoch_graph) {
+        (void)hipGraphExecDestroy(h->epoch_graph);
+        h->epoch_graph = nullptr;
     }
-    const int max_touched = (bpr ? 3 : 2) * p.n_in_batch;
-    hipLaunchKernelGGL(mf_apply_kernel, dim3(div_up(max_touched, 4)), dim3(256), 0, h->stream, p);
+    hipGraph_t g = nullptr;
+    MI_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_epoch(h, p, false);
+    MI_HIP(hipStreamEndCapture(h->stream, &g));
+    MI_HIP(hipGraphInstantiate(&h->epoch_graph, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    h->graph_stream_base = p.stream_base;
 }
 
 void ensure_stream_capacity(mi355rec_mf *h, size_t n) {
     if (h->stream_capacity >= n) return;
+    if (h->epoch_graph) {   // the graph holds the old buffer addresses
+        (void)hipGraphExecDestroy(h->epoch_graph);
+        h->epoch_graph = nullptr;
+    }
     h->su.alloc(n);
     h->si.alloc(n);
     h->sj.alloc(n);
@@ -409,11 +457,18 @@ double bytes_per_sample(const mi355rec_mf *h) {
     return rows * 2.0 * 4.0 * (double)h->k;
 }
 
+void begin_call(mi355rec_mf *h) {
+    MI_HIP(hipMemsetAsync(h->loss_slots.ptr, 0, sizeof(double) * h->cfg.batch_size, h->stream));
+    h->dispatch_timers.reset();
+}
+
 void finish_call(mi355rec_mf *h, long long n_samples, long long n_batches) {
     MI_HIP(hipGetLastError());
+    h->host_loss.resize(h->cfg.batch_size);
+    h->loss_slots.download(h->host_loss.data(), h->cfg.batch_size, h->stream);
     MI_HIP(hipStreamSynchronize(h->stream));
-    MfState st{};
-    MI_HIP(hipMemcpy(&st, h->state.ptr, sizeof(MfState), hipMemcpyDeviceToHost));
+    double loss = 0;
+    for (double v : h->host_loss) loss += v;
     h->stats.call_ms = h->timer.elapsed_ms();
     h->stats.kernel_ms = h->dispatch_timers.total_ms();
     h->stats.n_timed = h->dispatch_timers.used;
@@ -421,7 +476,7 @@ void finish_call(mi355rec_mf *h, long long n_samples, long long n_batches) {
     h->stats.n_units = n_samples;
     h->stats.algorithmic_bytes = bytes_per_sample(h) * (double)n_samples;
     h->stats.algorithmic_flops = 0;
-    h->stats.loss = st.loss;
+    h->stats.loss = loss;
 }
 
 }  // namespace
@@ -478,6 +533,7 @@ extern "C" int mi355rec_mf_create(mi355rec_mf_t *out, const mi355rec_mf_config *
         }
         h->flag.alloc_zero((size_t)n_users + n_items, s);
         h->list.alloc((size_t)cfg->batch_size * 3);
+        h->loss_slots.alloc_zero((size_t)cfg->batch_size, s);
         h->state.alloc_zero(1, s);
         MI_HIP(hipStreamSynchronize(s));
         *out = h.release();
@@ -490,20 +546,25 @@ extern "C" int mi355rec_mf_run_epochs(mi355rec_mf_t h, int32_t n_epochs) {
         MI_REQUIRE(n_epochs >= 0, "n_epochs must be >= 0");
         ensure_device();
         const long long B = h->cfg.batch_size;
-        // number of mini-batches per epoch: .pyx:583 (BPR) / :289 (FunkSVD)
-        const long long per_epoch = (h->cfg.algorithm == MI355REC_MF_BPR ? (long long)h->n_users / B : (long long)h->nnz / B) + 1;
+        const long long per_epoch = batches_per_epoch(h);
         const long long n_batches = per_epoch * n_epochs;
-        h->record_period = per_epoch * B;
-        ensure_stream_capacity(h, (size_t)h->record_period);
+        ensure_stream_capacity(h, (size_t)(per_epoch * B));
         MfParams p{};
         fill_params(h, p);
-        MI_HIP(hipMemsetAsync(&h->state.ptr->loss, 0, sizeof(double), h->stream));
-        h->dispatch_timers.reset();
+        p.stream_batches = per_epoch;
+        begin_call(h);
+        // epochs whose gradient launches carry timing events run as plain launches, the rest replays the graph
+        const long long timed_epochs = h->max_timed > 0 ? std::min<long long>(n_epochs, (h->max_timed + per_epoch - 1) / per_epoch) : 0;
+        const bool use_graph = per_epoch <= MAX_GRAPH_BATCHES && n_epochs - timed_epochs > 0;
+        if (use_graph) ensure_epoch_graph(h, p);
         h->timer.start(h->stream);
-        for (long long b = 0; b < n_batches; ++b) launch_batch(h, p, false);
+        for (long long e = 0; e < n_epochs; ++e) {
+            if (e < timed_epochs || !use_graph) enqueue_epoch(h, p, e < timed_epochs);
+            else MI_HIP(hipGraphLaunch(h->epoch_graph, h->stream));
+        }
         h->timer.stop(h->stream);
         h->batches_done += n_batches;
-        h->last_call_samples = std::min<long long>(n_batches, per_epoch) * B;
+        h->last_call_samples = n_epochs > 0 ? per_epoch * B : 0;
         finish_call(h, n_batches * B, n_batches);
     });
 }
@@ -518,19 +579,18 @@ extern "C" int mi355rec_mf_run_samples(mi355rec_mf_t h, const int32_t *u, const 
         ensure_device();
         if (n == 0) return;
         const long long B = h->cfg.batch_size;
-        ensure_stream_capacity(h, (size_t)n);
+        ensure_stream_capacity(h, (size_t)std::max<long long>(n, batches_per_epoch(h) * B));
         hipStream_t s = h->stream;
         MI_HIP(hipMemcpyAsync(h->su.ptr, u, sizeof(int) * n, hipMemcpyHostToDevice, s));
         MI_HIP(hipMemcpyAsync(h->si.ptr, i, sizeof(int) * n, hipMemcpyHostToDevice, s));
         if (bpr) MI_HIP(hipMemcpyAsync(h->sj.ptr, j, sizeof(int) * n, hipMemcpyHostToDevice, s));
         else MI_HIP(hipMemcpyAsync(h->sr.ptr, rating, sizeof(float) * n, hipMemcpyHostToDevice, s));
-        h->record_period = 0;
         h->last_call_samples = 0;
         MfParams p{};
         fill_params(h, p);
-        MI_HIP(hipMemsetAsync(&h->state.ptr->loss, 0, sizeof(double), s));
         const long long n_batches = (n + B - 1) / B;
-        h->dispatch_timers.reset();
+        p.stream_batches = n_batches;
+        begin_call(h);
         h->timer.start(s);
         for (long long b = 0; b < n_batches; ++b) {
             p.n_in_batch = (int)std::min<long long>(B, n - b * B);
@@ -592,6 +652,7 @@ extern "C" int mi355rec_mf_get_stats(mi355rec_mf_t h, mi355rec_stats *stats) {
 extern "C" void mi355rec_mf_destroy(mi355rec_mf_t h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->epoch_graph) (void)hipGraphExecDestroy(h->epoch_graph);
     h->timer.destroy();
     h->dispatch_timers.destroy();
     if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -157,8 +157,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
     __shared__ uint32_t s_npos, s_nneg, s_ncand;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    constexpr int GROUPS = THREADS / G;
-    const int gid = tid / G, gl = tid % G;
+    const int gl = tid % G;
 
     for (;;) {
         if (tid == 0) {
@@ -180,16 +179,42 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         __syncthreads();
 
         // ---- computeItemSimilarities (.pyx:376-406): users of column c, then every item of each user ----
+        // A wavefront takes 64 users of the column at a time: lane l loads user l's id, weight and CSR row bounds
+        // (the only dependent loads, paid once per 64 users); the profiles are then streamed with the bounds
+        // broadcast from the owning lane, G lanes per profile, 4 independent loads in flight per lane.
         const int cbeg = p.csc_ptr[c], cend = p.csc_ptr[c + 1];
-        for (int q = cbeg + gid; q < cend; q += GROUPS) {
-            const int u = p.csc_idx[q];
-            float r = UNIT ? 1.f : p.csc_val[q];
-            if (p.row_w) r *= p.row_w[u];
-            const int rs = p.csr_ptr[u], re = p.csr_ptr[u + 1];
-            for (int t = rs + gl; t < re; t += G) {
-                const int j = p.csr_idx[t];
-                const float v = UNIT ? r : r * p.csr_val[t];
-                if (j != c) atomicAdd(&acc[j], v);
+        constexpr int WAVES = THREADS / 64, GPW = 64 / G;
+        const int wave = tid >> 6, sub = lane / G;
+        for (int base = cbeg + wave * 64; base < cend; base += WAVES * 64) {
+            const int q = base + lane;
+            const bool valid = q < cend;
+            const int u = valid ? p.csc_idx[q] : 0;
+            float r = valid ? (UNIT ? 1.f : p.csc_val[q]) : 0.f;
+            if (p.row_w && valid) r *= p.row_w[u];
+            const int rs = valid ? p.csr_ptr[u] : 0, re = valid ? p.csr_ptr[u + 1] : 0;
+            const int n_here = min(64, cend - base);
+            for (int m0 = 0; m0 < n_here; m0 += GPW) {
+                const int m = m0 + sub;
+                const int rs_m = __shfl(rs, m), re_m = __shfl(re, m);
+                const float r_m = __shfl(r, m);
+                for (int t = rs_m + gl; t < re_m; t += 4 * G) {
+                    const int t1 = t + G, t2 = t + 2 * G, t3 = t + 3 * G;
+                    const int j0 = p.csr_idx[t];
+                    const int j1 = t1 < re_m ? p.csr_idx[t1] : c;
+                    const int j2 = t2 < re_m ? p.csr_idx[t2] : c;
+                    const int j3 = t3 < re_m ? p.csr_idx[t3] : c;
+                    float v0 = r_m, v1 = r_m, v2 = r_m, v3 = r_m;
+                    if (!UNIT) {
+                        v0 *= p.csr_val[t];
+                        if (t1 < re_m) v1 *= p.csr_val[t1];
+                        if (t2 < re_m) v2 *= p.csr_val[t2];
+                        if (t3 < re_m) v3 *= p.csr_val[t3];
+                    }
+                    if (j0 != c) atomicAdd(&acc[j0], v0);      // the diagonal is never accumulated (.pyx:392)
+                    if (j1 != c) atomicAdd(&acc[j1], v1);
+                    if (j2 != c) atomicAdd(&acc[j2], v2);
+                    if (j3 != c) atomicAdd(&acc[j3], v3);
+                }
             }
         }
         __syncthreads();
