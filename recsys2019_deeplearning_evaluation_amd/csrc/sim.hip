@@ -29,8 +29,9 @@ struct SimParams {
     int topK, sortP;
     int kind, normalize;
     float shrink, tversky_alpha, tversky_beta;
-    const int *csr_ptr, *csr_idx;
-    const float *csr_val;
+    const int *csr_ptr;
+    const unsigned short *csr_idx16;   // column ids as uint16 (n_cols < 65536 on this path), padded by 8
+    const float *csr_val;              // padded by 8
     const int *csc_ptr, *csc_idx;
     const float *csc_val;
     const float *row_w;
@@ -180,49 +181,93 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
 
         // ---- computeItemSimilarities (.pyx:376-406): users of column c, then every item of each user ----
         // A wavefront takes 64 users of the column at a time: lane l loads user l's id, weight and CSR row bounds
-        // (the only dependent loads, paid once per 64 users); the profiles are then streamed with the bounds
-        // broadcast from the owning lane, G lanes per profile, 4 independent loads in flight per lane.
+        // (the only dependent loads, paid once per 64 users).  The profiles are then streamed with the bounds
+        // broadcast from the owning lane, G lanes per profile; every lane reads 16-byte chunks = 8 uint16 column
+        // ids (aligned; the first chunk may start before the row, the last may run past it: both masked), two
+        // chunks in flight.  UNIT data accumulates integer counts (ds_add_u32 runs ~3x faster than ds_add_f32 on
+        // gfx950 and is exact); otherwise float products.
         const int cbeg = p.csc_ptr[c], cend = p.csc_ptr[c + 1];
         constexpr int WAVES = THREADS / 64, GPW = 64 / G;
         const int wave = tid >> 6, sub = lane / G;
+        unsigned *acc_u = reinterpret_cast<unsigned *>(acc);
+        const uint4 *idx8 = reinterpret_cast<const uint4 *>(p.csr_idx16);
+        const float4 *val4 = reinterpret_cast<const float4 *>(p.csr_val);
         for (int base = cbeg + wave * 64; base < cend; base += WAVES * 64) {
             const int q = base + lane;
             const bool valid = q < cend;
             const int u = valid ? p.csc_idx[q] : 0;
             float r = valid ? (UNIT ? 1.f : p.csc_val[q]) : 0.f;
-            if (p.row_w && valid) r *= p.row_w[u];
+            if (!UNIT && p.row_w && valid) r *= p.row_w[u];
             const int rs = valid ? p.csr_ptr[u] : 0, re = valid ? p.csr_ptr[u + 1] : 0;
             const int n_here = min(64, cend - base);
-            for (int m0 = 0; m0 < n_here; m0 += GPW) {
-                const int m = m0 + sub;
-                const int rs_m = __shfl(rs, m), re_m = __shfl(re, m);
-                const float r_m = __shfl(r, m);
-                for (int t = rs_m + gl; t < re_m; t += 4 * G) {
-                    const int t1 = t + G, t2 = t + 2 * G, t3 = t + 3 * G;
-                    const int j0 = p.csr_idx[t];
-                    const int j1 = t1 < re_m ? p.csr_idx[t1] : c;
-                    const int j2 = t2 < re_m ? p.csr_idx[t2] : c;
-                    const int j3 = t3 < re_m ? p.csr_idx[t3] : c;
-                    float v0 = r_m, v1 = r_m, v2 = r_m, v3 = r_m;
-                    if (!UNIT) {
-                        v0 *= p.csr_val[t];
-                        if (t1 < re_m) v1 *= p.csr_val[t1];
-                        if (t2 < re_m) v2 *= p.csr_val[t2];
-                        if (t3 < re_m) v3 *= p.csr_val[t3];
+            // Flat, software-pipelined walk over the 16-byte chunks of this group's profiles: the load of chunk
+            // n+1 is issued before chunk n is accumulated.  Control flow is uniform inside a group; lanes whose
+            // entries fall outside [rs, re) add 0 to a private dummy word, so the inner loop has no branches.
+            int m = sub - GPW, t = 0, tend = 0, rs_m = 0, re_m = 0;
+            float r_m = 0.f;
+            bool have = true;
+            // Moves every group to its next chunk.  Executed by ALL 64 lanes with a wave-uniform trip count: the
+            // cross-lane reads (ds_bpermute) return 0 for inactive source lanes, so no lane may sit this out.
+            auto advance = [&]() {
+                if (have) t += 8 * G;
+                for (;;) {
+                    const bool need = have && t >= tend;             // this group wants its next user
+                    if (!__any(need)) break;
+                    const int m_next = m + GPW;
+                    const bool can = need && m_next < n_here;
+                    const int src = can ? m_next : lane;
+                    const int a = __shfl(rs, src), b = __shfl(re, src);
+                    const float cr = __shfl(r, src);
+                    if (need) {
+                        if (can) {
+                            m = m_next; rs_m = a; re_m = b; r_m = cr;
+                            t = a & ~7; tend = b;
+                        } else {
+                            have = false;
+                        }
                     }
-                    if (j0 != c) atomicAdd(&acc[j0], v0);      // the diagonal is never accumulated (.pyx:392)
-                    if (j1 != c) atomicAdd(&acc[j1], v1);
-                    if (j2 != c) atomicAdd(&acc[j2], v2);
-                    if (j3 != c) atomicAdd(&acc[j3], v3);
+                }
+            };
+            advance();
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (have) w = idx8[(t >> 3) + gl];
+            while (__any(have)) {
+                const bool c_have = have;
+                const int c_t = t + 8 * gl, c_rs = rs_m, c_re = re_m;
+                const float c_r = r_m;
+                const uint4 cw = w;
+                float vv[8];
+                if (!UNIT && c_have) {
+                    const float4 lo = val4[c_t >> 2], hi = val4[(c_t >> 2) + 1];
+                    vv[0] = lo.x; vv[1] = lo.y; vv[2] = lo.z; vv[3] = lo.w;
+                    vv[4] = hi.x; vv[5] = hi.y; vv[6] = hi.z; vv[7] = hi.w;
+                }
+                advance();
+                if (have) w = idx8[(t >> 3) + gl];
+                if (c_have) {
+                    const unsigned ww[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int tt = c_t + e;
+                        const bool ok = tt >= c_rs && tt < c_re;
+                        const unsigned j = (ww[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                        const unsigned at = ok ? j : (unsigned)lane;
+                        if (UNIT) atomicAdd(&acc_u[at], ok ? 1u : 0u);
+                        else atomicAdd(&acc[at], ok ? c_r * vv[e] : 0.f);
+                    }
                 }
             }
         }
+        // the diagonal was accumulated like any other cell: clear it (the reference never adds to it, .pyx:392)
+        __syncthreads();
+        if (tid == 0) acc[c] = 0.f;
+        __syncthreads();
         __syncthreads();
 
         // ---- normalisation (.pyx:473-504), in place; count signs for the selection ----
         uint32_t npos = 0, nneg = 0;
         for (int j = tid; j < p.n_cols; j += THREADS) {
-            float v = acc[j];
+            float v = UNIT ? (float)acc_u[j] : acc[j];
             if (v != 0.f) {
                 v = normalise(p, v, c, j);
                 acc[j] = v;
@@ -327,6 +372,11 @@ __global__ void row_center_kernel(const int *ptr, float *val, int n_rows) {
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
     const float mean = (float)(sum / (double)(e - s));
     for (int q = s + lane; q < e; q += 64) val[q] -= mean;
+}
+
+__global__ void narrow_idx_kernel(const int *idx, size_t nnz, unsigned short *out) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (unsigned short)idx[i];
 }
 
 __global__ void count_cols_kernel(const int *idx, size_t nnz, int *cnt) {
@@ -465,11 +515,13 @@ struct mi355rec_sim {
     StreamTimer timer;       // start/stop events carried by the column-kernel dispatch itself
     StreamTimer call_timer;  // events around the whole call (H2D of the schedule, kernel, D2H of the result)
     DeviceBuffer<int> csr_ptr, csr_idx, csc_ptr, csc_idx, order;
+    DeviceBuffer<unsigned short> csr_idx16;
     DeviceBuffer<float> csr_val, csc_val, row_w, norm, norm_alpha, norm_1ma;
     DeviceBuffer<unsigned> queue;
     DeviceBuffer<int> out_idx;
     DeviceBuffer<float> out_val;
     std::vector<long long> cost;   // host copy
+    std::vector<int> csc_ptr_host;
     std::vector<int> cost_order;   // all columns, most expensive first
     std::vector<int> range_order;  // host staging for the current call
     int group_lanes = 64;
@@ -482,7 +534,7 @@ namespace {
 
 template <int THREADS, int G>
 void launch_sim(mi355rec_sim *h, const SimParams &p, int grid, size_t lds) {
-    if (h->unit_values) {
+    if (h->unit_values && !h->row_w.ptr) {
         auto k = sim_column_kernel<THREADS, G, true>;
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipExtLaunchKernelGGL(k, dim3(grid), dim3(THREADS), (unsigned)lds, h->stream, h->timer.t0, h->timer.t1, 0, p);
@@ -540,7 +592,7 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     p.tversky_alpha = h->cfg.tversky_alpha;
     p.tversky_beta = h->cfg.tversky_beta;
     p.csr_ptr = h->csr_ptr.ptr;
-    p.csr_idx = h->csr_idx.ptr;
+    p.csr_idx16 = h->csr_idx16.ptr;
     p.csr_val = h->csr_val.ptr;
     p.csc_ptr = h->csc_ptr.ptr;
     p.csc_idx = h->csc_idx.ptr;
@@ -572,10 +624,11 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     h->stats.n_launches = 1;
     h->stats.n_timed = 1;
     h->stats.n_units = n_local;
-    // ALGORITHMIC bytes: every (user-of-column, item-of-user) pair is one index (+ one value
-    // unless the data is all-ones) read; every user of the column one index (+ value); plus the K results.
-    const double per_pair = h->unit_values ? 4.0 : 8.0;
-    h->stats.algorithmic_bytes = per_pair * (double)cost_sum + 8.0 * (double)n_local * (double)h->cfg.topK;
+    // ALGORITHMIC bytes, SURVEY.md section 8(d): per column c, its CSC column (8 B x n_c) + the CSR row of each of its users
+    // (8 B x L_u) + topK x 8 B of output, i.e. 8 * (nnz_range + cost_range) + 8 * n_local * topK.  (The kernel's own
+    // layout moves less -- uint16 ids, no values for all-ones data -- see DESIGN.md section 4.)
+    const double nnz_range = (double)(h->csc_ptr_host[end] - h->csc_ptr_host[start]);
+    h->stats.algorithmic_bytes = 8.0 * (nnz_range + (double)cost_sum) + 8.0 * (double)n_local * (double)h->cfg.topK;
     h->stats.algorithmic_flops = 0;
     h->last_start = start;
     h->last_end = end;
@@ -618,8 +671,12 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         hipStream_t s = h->stream;
         const size_t nnz = h->nnz;
         h->csr_ptr.upload(csr_indptr, (size_t)n_rows + 1, s);
-        h->csr_idx.upload(csr_indices, nnz, s);
-        h->csr_val.upload(csr_data, nnz, s);
+        // padding: the column kernel reads the profiles in aligned 16-byte chunks, a whole lane group at a time
+        h->csr_idx.alloc_zero(nnz + 520, s);
+        h->csr_val.alloc_zero(nnz + 520, s);
+        h->csr_idx16.alloc_zero(nnz + 520, s);
+        MI_HIP(hipMemcpyAsync(h->csr_idx.ptr, csr_indices, nnz * sizeof(int), hipMemcpyHostToDevice, s));
+        MI_HIP(hipMemcpyAsync(h->csr_val.ptr, csr_data, nnz * sizeof(float), hipMemcpyHostToDevice, s));
         if (row_weights) h->row_w.upload(row_weights, n_rows, s);
         const int eb = 256, eg = std::min<size_t>((nnz + eb - 1) / eb, 4096);
 
@@ -644,6 +701,7 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         pos_in.alloc(nnz);
         pos_out.alloc(nnz);
         key_out.alloc(nnz);
+        hipLaunchKernelGGL(narrow_idx_kernel, dim3(eg), dim3(eb), 0, s, h->csr_idx.ptr, nnz, h->csr_idx16.ptr);
         hipLaunchKernelGGL(count_cols_kernel, dim3(eg), dim3(eb), 0, s, h->csr_idx.ptr, nnz, cnt.ptr);
         hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, cnt.ptr, h->csc_ptr.ptr, cursor.ptr, n_cols);
         hipLaunchKernelGGL(expand_rows_kernel, dim3(div_up((int64_t)n_rows * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr, n_rows,
@@ -688,6 +746,8 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         not_unit.download(&nu, 1, s);
         h->cost.resize(n_cols);
         cost.download(h->cost.data(), n_cols, s);
+        h->csc_ptr_host.resize((size_t)n_cols + 1);
+        h->csc_ptr.download(h->csc_ptr_host.data(), (size_t)n_cols + 1, s);
         MI_HIP(hipStreamSynchronize(s));
         h->unit_values = (nu == 0);
 
@@ -701,7 +761,9 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         long long total_cost = 0;
         for (long long c : h->cost) total_cost += c;
         const double weighted_len = (double)total_cost / (double)nnz;
-        h->group_lanes = weighted_len >= 96 ? 64 : (weighted_len >= 40 ? 32 : 16);
+        // each lane covers 8 profile entries per load: G lanes span 8*G entries
+        h->group_lanes = weighted_len >= 1024 ? 64 : (weighted_len >= 320 ? 32 : 16);
+        if (getenv("MI355REC_SIM_G")) h->group_lanes = atoi(getenv("MI355REC_SIM_G"));
         *out = h.release();
     });
 }
