@@ -10,5 +10,7 @@ from .knn import ItemKNNCFRecommender, UserKNNCFRecommender  # noqa: F401
 from .matrix_factorization import (MatrixFactorization_MI355X_Epoch, MatrixFactorization_BPR_MI355X,  # noqa: F401
                                    MatrixFactorization_FunkSVD_MI355X)
 
-__all__ = ["Compute_Similarity", "Compute_Similarity_MI355X", "ItemKNNCFRecommender", "UserKNNCFRecommender",
+from .ials import IALS_MI355X_Epoch, IALSRecommender  # noqa: F401,E402
+
+__all__ = ["IALS_MI355X_Epoch", "IALSRecommender", "Compute_Similarity", "Compute_Similarity_MI355X", "ItemKNNCFRecommender", "UserKNNCFRecommender",
            "MatrixFactorization_MI355X_Epoch", "MatrixFactorization_BPR_MI355X", "MatrixFactorization_FunkSVD_MI355X"]

@@ -1,0 +1,100 @@
+"""Parity of the HIP IALS solve step (through the C ABI) against the CPU oracle / golden fixtures.
+float64 on both sides: tolerance 1e-8 relative (the only differences are summation order and Gauss-Jordan
+vs. LAPACK inverse)."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from oracle import oracle as O
+from recsys2019_deeplearning_evaluation_amd import IALS_MI355X_Epoch, IALSRecommender
+from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
+from _util import load_golden, rel_err, unpack_csr
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-8
+
+
+def test_golden_fixture(gpu):
+    z, cases = load_golden("ials")
+    X = unpack_csr(z, "X")
+    for n, case in enumerate(cases):
+        kw = case["kw"]
+        Cm = O.oracle_ials_confidence(X, kw["confidence_scaling"], kw["alpha"], kw.get("epsilon", 1.0))
+        dev = IALS_MI355X_Epoch(Cm, kw["num_factors"], kw["reg"], z["V0_%d" % n])
+        dev.run_epochs(case["epochs"])
+        U, V = dev.get_factors()
+        assert rel_err(U, z["U_%d" % n]) < RTOL
+        assert rel_err(V, z["V_%d" % n]) < RTOL
+        dev.close()
+
+
+@pytest.mark.parametrize("k", [1, 5, 32, 33, 64, 100, 160, 161, 200, 224])
+def test_factor_counts(gpu, k):
+    X = named_urm("ml1m", "real", scale=0.08)
+    Cm = O.oracle_ials_confidence(X, "linear", 2.0)
+    Cc = sps.csc_matrix(Cm)
+    rng = np.random.default_rng(k)
+    V0 = k ** -0.5 * rng.random((X.shape[1], k))
+    U = np.zeros((X.shape[0], k)); V = V0.copy()
+    O.oracle_ials_epoch(Cm, Cc, U, V, 1e-3)
+    dev = IALS_MI355X_Epoch(Cm, k, 1e-3, V0)
+    dev.run_epochs(1)
+    Ud, Vd = dev.get_factors()
+    assert rel_err(Ud, U) < RTOL and rel_err(Vd, V) < RTOL
+    # every solved row satisfies its normal equations (independent of the oracle)
+    VV = V0.T @ V0
+    for u in [0, 7, X.shape[0] - 1]:
+        s, e = Cm.indptr[u], Cm.indptr[u + 1]
+        Yi = V0[Cm.indices[s:e]]; c = Cm.data[s:e].astype(np.float64)
+        Bm = VV + Yi.T @ ((c - 1)[:, None] * Yi) + 1e-3 * np.eye(k)
+        assert np.abs(Bm @ Ud[u] - Yi.T @ c).max() < 1e-8 * max(1.0, np.abs(Yi.T @ c).max())
+    st = dev.stats()
+    assert st["n_units"] == X.shape[0] + X.shape[1] and st["algorithmic_flops"] > 0
+    dev.close()
+
+
+def test_small_regularisation_and_log_scaling(gpu):
+    X = named_urm("ml1m", "real", scale=0.1)
+    Cm = O.oracle_ials_confidence(X, "log", 5.0, 0.3)
+    Cc = sps.csc_matrix(Cm)
+    k = 48
+    V0 = k ** -0.5 * np.random.default_rng(1).random((X.shape[1], k))
+    U = np.zeros((X.shape[0], k)); V = V0.copy()
+    for _ in range(3):
+        O.oracle_ials_epoch(Cm, Cc, U, V, 1e-5)       # the hyper-parameter search goes down to reg = 1e-5
+    dev = IALS_MI355X_Epoch(Cm, k, 1e-5, V0)
+    dev.run_epochs(3)
+    Ud, Vd = dev.get_factors()
+    assert rel_err(Ud, U) < 1e-6 and rel_err(Vd, V) < 1e-6
+
+
+def test_cold_rows_are_left_alone_and_halves_compose(gpu):
+    X = named_urm("ml1m", "binary", scale=0.08).tolil()
+    X[3, :] = 0; X[:, 5] = 0
+    X = X.tocsr()
+    Cm = O.oracle_ials_confidence(X, "linear", 1.0)
+    k = 16
+    rng = np.random.default_rng(2)
+    V0 = rng.random((X.shape[1], k)); U0 = rng.random((X.shape[0], k))
+    a = IALS_MI355X_Epoch(Cm, k, 1e-2, V0, U0); a.run_epochs(1)
+    Ua, Va = a.get_factors()
+    np.testing.assert_array_equal(Ua[3], U0[3]); np.testing.assert_array_equal(Va[5], V0[5])
+    # the multi-GPU entry points: two user ranges + two item ranges == one epoch
+    b = IALS_MI355X_Epoch(Cm, k, 1e-2, V0, U0)
+    nu, ni = X.shape
+    b.user_half(0, nu // 2); b.user_half(nu // 2, nu); b.item_half(0, ni // 3); b.item_half(ni // 3, ni); b.synchronize()
+    Ub, Vb = b.get_factors()
+    assert rel_err(Ub, Ua) < 1e-12 and rel_err(Vb, Va) < 1e-12
+
+
+def test_recommender_surface(gpu):
+    X = named_urm("ml1m", "binary", scale=0.12)
+    np.random.seed(5)
+    rec = IALSRecommender(X, verbose=False)
+    rec.fit(epochs=3, num_factors=24, alpha=5.0, reg=1e-2)
+    assert rec.USER_factors.shape == (X.shape[0], 24)
+    scores = rec._compute_item_score(np.arange(50))
+    dense = X[:50].toarray() > 0
+    assert np.mean([scores[r][dense[r]].mean() > scores[r][~dense[r]].mean() for r in range(50)]) > 0.95
+    with pytest.raises(ValueError):
+        rec.fit(confidence_scaling="nope")
