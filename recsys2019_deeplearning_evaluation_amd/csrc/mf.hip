@@ -22,6 +22,7 @@
 // There is no dense contraction here, hence no MFMA; the path is bound by row gather/scatter bandwidth and,
 // at the reference's batch sizes (<= 1024), by the dependent-launch latency between mini-batches.
 #include "common.h"
+#include "sampling.cuh"
 
 #include <memory>
 
@@ -59,28 +60,6 @@ struct MfParams {
     long long samples_per_epoch;
     int n_in_batch;                      // samples in this launch's batch (<= batch_size; short only in replay)
 };
-
-__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-// draw number `d` of sample `sid`: stateless, so every lane of the wavefront computes the same value
-__device__ __forceinline__ unsigned draw32(unsigned long long seed, unsigned long long sid, unsigned d) {
-    return (unsigned)(mix64(seed ^ mix64(sid * 0xD1B54A32D192ED03ull + d)) >> 32);
-}
-__device__ __forceinline__ int bounded(unsigned r, int n) { return (int)(((unsigned long long)r * (unsigned)n) >> 32); }
-
-// is `item` absent from the sorted profile [row, row + n)?  (the reference scans linearly, .pyx:975-983)
-__device__ __forceinline__ bool profile_lacks(const int *row, int n, int item) {
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (row[mid] < item) lo = mid + 1; else hi = mid;
-    }
-    return lo == n || row[lo] != item;
-}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -10,6 +10,7 @@
 // select (bank-replicated histograms) followed by a bitonic sort of the K survivors.  The URM is read through
 // L2 / Infinity Cache; nothing but the K results per column is written to HBM.
 #include "common.h"
+#include "topk.cuh"
 
 #include <hipcub/hipcub.hpp>
 
@@ -19,10 +20,6 @@
 
 namespace mi355rec {
 namespace {
-
-constexpr uint32_t ZERO_KEY = 0x80000000u;
-constexpr int AUX_WORDS = 8192;  // 32 KiB: 256 bins x 32 bank replicas, later re-used as the candidate buffer
-constexpr int MAX_TOPK = 4096;   // AUX_WORDS * 4 B / 8 B per candidate
 
 struct SimParams {
     int n_rows, n_cols, n_cols_pad;
@@ -44,16 +41,6 @@ struct SimParams {
     float *out_dense;  // [n_local][n_cols] when topK == 0
 };
 
-// Order-preserving map float -> uint32 (larger float <=> larger key); +0.0 maps to ZERO_KEY.
-__device__ __forceinline__ uint32_t float_key(float v) {
-    uint32_t b = __float_as_uint(v);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float key_float(uint32_t k) {
-    uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
-    return __uint_as_float(b);
-}
-
 // Denominators of compute_similarity (.pyx:473-504); the +1e-6 is the reference's.
 __device__ __forceinline__ float normalise(const SimParams &p, float v, int c, int j) {
     if (p.normalize) {
@@ -66,84 +53,6 @@ __device__ __forceinline__ float normalise(const SimParams &p, float v, int c, i
         return v / (v + (p.norm[c] - v) * p.tversky_alpha + (p.norm[j] - v) * p.tversky_beta + p.shrink + 1e-6f);
     if (p.shrink != 0.f) return v / p.shrink;
     return v;
-}
-
-struct SelectScratch {
-    uint32_t wave_tot[4];
-    uint32_t digit, want, bin_count;
-};
-
-// Block-wide radix select: key of the `want`-th largest element (1-based) of
-//   { kf(j).key : j < n, kf(j).active }  U  { virt_key repeated virt_cnt times }.
-// On return every thread holds T (that key), need_eq (how many elements equal to T belong to the top `want`)
-// and eq_total (how many elements equal T, virtual ones included).
-template <int THREADS, class KeyFn>
-__device__ void block_select(KeyFn kf, int n, uint32_t want, uint32_t virt_key, uint32_t virt_cnt, uint32_t *hist,
-                             SelectScratch &sc, uint32_t &T, uint32_t &need_eq, uint32_t &eq_total) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t prefix = 0;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        for (int w = tid; w < AUX_WORDS; w += THREADS) hist[w] = 0;
-        __syncthreads();
-        for (int j = tid; j < n; j += THREADS) {
-            uint32_t key;
-            if (kf(j, key) && (pass == 0 || (key >> (shift + 8)) == prefix))
-                atomicAdd(&hist[((key >> shift) & 255u) * 32 + (lane & 31)], 1u);
-        }
-        __syncthreads();
-        uint32_t cnt = 0, suffix = 0;
-        if (tid < 256) {
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) cnt += hist[tid * 32 + ((r + tid) & 31)];
-            if (virt_cnt && (pass == 0 || (virt_key >> (shift + 8)) == prefix) && ((virt_key >> shift) & 255u) == (uint32_t)tid)
-                cnt += virt_cnt;
-            suffix = cnt;  // inclusive suffix sum inside the wave (towards higher bins)
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                uint32_t t = __shfl_down(suffix, off);
-                if (lane + off < 64) suffix += t;
-            }
-            if (lane == 0) sc.wave_tot[wave] = suffix;
-        }
-        __syncthreads();
-        if (tid < 256) {
-            for (int w = wave + 1; w < 4; ++w) suffix += sc.wave_tot[w];
-            const uint32_t above = suffix - cnt;
-            if (suffix >= want && above < want) {
-                sc.digit = tid;
-                sc.want = want - above;
-                sc.bin_count = cnt;
-            }
-        }
-        __syncthreads();
-        prefix = (prefix << 8) | sc.digit;
-        want = sc.want;
-        eq_total = sc.bin_count;
-        __syncthreads();
-    }
-    T = prefix;
-    need_eq = want;
-}
-
-template <int THREADS>
-__device__ void bitonic_sort_desc(uint64_t *a, int P) {
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < P; t += THREADS) {
-                int ixj = t ^ j;
-                if (ixj > t) {
-                    uint64_t x = a[t], y = a[ixj];
-                    bool desc = (t & k) == 0;
-                    if (desc ? (x < y) : (x > y)) {
-                        a[t] = y;
-                        a[ixj] = x;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
 }
 
 // THREADS: workgroup size; G: lanes that cooperate on one user profile (sub-wave group);
@@ -294,63 +203,11 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         __syncthreads();
         npos = s_npos;
         nneg = s_nneg;
-        const uint32_t nzero = (uint32_t)p.n_cols - npos - nneg;
-        const uint32_t K = (uint32_t)p.topK;
-
-        // ---- top-K: the K largest cells of the FULL column (zeros compete, then are dropped) ----
-        uint32_t T = ZERO_KEY, need_eq = 0, eq_total = 0;
-        const bool take_all_positive = npos <= K && (nneg == 0 || npos + nzero >= K);
-        auto value_key = [&](int j, uint32_t &key) {
-            float v = acc[j];
-            key = float_key(v);
-            return v != 0.f;
-        };
-        if (!take_all_positive) {
-            block_select<THREADS>(value_key, p.n_cols, K, ZERO_KEY, nzero, aux, sc, T, need_eq, eq_total);
-            if (T == ZERO_KEY) need_eq = 0;  // zeros are never emitted (.pyx:555)
-        }
-        uint32_t T2 = 0;  // tie-break on the index when more cells equal T than fit: lowest index wins
-        const bool partial_ties = need_eq > 0 && need_eq < eq_total;
-        if (partial_ties) {
-            uint32_t dummy_need, dummy_tot;
-            auto index_key = [&](int j, uint32_t &key) {
-                float v = acc[j];
-                key = ~(uint32_t)j;
-                return v != 0.f && float_key(v) == T;
-            };
-            block_select<THREADS>(index_key, p.n_cols, need_eq, 0u, 0u, aux, sc, T2, dummy_need, dummy_tot);
-        }
-        __syncthreads();
-        uint64_t *cand = reinterpret_cast<uint64_t *>(aux);
-        for (int j = tid; j < p.n_cols; j += THREADS) {
-            float v = acc[j];
-            if (v == 0.f) continue;
-            uint32_t key = float_key(v);
-            bool take = key > T || (need_eq > 0 && key == T && (!partial_ties || ~(uint32_t)j >= T2));
-            if (take) {
-                uint32_t slot_c = atomicAdd(&s_ncand, 1u);
-                if (slot_c < (uint32_t)p.sortP) cand[slot_c] = ((uint64_t)key << 32) | (uint32_t)(~(uint32_t)j);
-            }
-        }
-        __syncthreads();
-        const int ncand = min((int)s_ncand, p.topK);
-        for (int t = ncand + tid; t < p.sortP; t += THREADS) cand[t] = 0ull;
-        __syncthreads();
-        bitonic_sort_desc<THREADS>(cand, p.sortP);
-
-        // ---- emit (value descending; -1 padding), like the COO triples of .pyx:550-562 ----
+        // ---- top-K: the K largest cells of the FULL column (zeros compete, then are dropped), value-descending,
+        //      emitted like the COO triples of .pyx:550-562 with -1 padding ----
         const size_t base = (size_t)(c - p.start_col) * p.topK;
-        for (int t = tid; t < p.topK; t += THREADS) {
-            int idx = -1;
-            float val = 0.f;
-            if (t < ncand) {
-                uint64_t e = cand[t];
-                idx = (int)(~(uint32_t)(e & 0xFFFFFFFFull));
-                val = key_float((uint32_t)(e >> 32));
-            }
-            p.out_idx[base + t] = idx;
-            p.out_val[base + t] = val;
-        }
+        block_topk_emit<THREADS>(acc, p.n_cols, p.topK, p.sortP, npos, nneg, /*zeros_compete=*/true, aux, sc, &s_ncand,
+                                 p.out_idx + base, p.out_val + base);
         __syncthreads();
     }
 }
