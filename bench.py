@@ -143,8 +143,14 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")     # "gloo" + BENCH_SHARE_GPU=1: dry run of the N>1 path on one GPU
+        if os.environ.get("BENCH_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     import numpy as np
     from recsys2019_deeplearning_evaluation_amd import (Compute_Similarity_MI355X, MatrixFactorization_MI355X_Epoch, _native)
     from recsys2019_deeplearning_evaluation_amd.sharding import balanced_column_ranges, gather_slabs
@@ -157,6 +163,13 @@ def main():
         if dist is not None:
             torch.cuda.synchronize()
             dist.barrier()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     urm = load_urm(args.workload)
     n_users, n_items = urm.shape
@@ -174,10 +187,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     st = mf.stats()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
     total_samples = args.steps * per_epoch * world
     value = total_samples / elapsed
     avg_launch_s = (st["kernel_ms"] / max(1, st["n_timed"])) * 1e-3
@@ -214,11 +224,7 @@ def main():
                 f_idx, f_val = gather_slabs(d_idx, d_val, ranges, rank, TOPK, dist)
                 idx, val = f_idx.cpu().numpy(), f_val.cpu().numpy()
             barrier()
-            dt = time.perf_counter() - t1
-            if dist is not None:
-                t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt = float(t.item())
+            dt = max_over_ranks(time.perf_counter() - t1)
             best = dt if best is None else min(best, dt)
         sst = sim.stats()
         sim_gbps = sst["algorithmic_bytes"] / (sst["kernel_ms"] * 1e-3) / 1e9

@@ -35,24 +35,26 @@ def balanced_column_ranges(cost, n_parts):
 def gather_slabs(local_idx, local_val, ranges, rank, topK, dist, device=None):
     """All-gather the per-rank (n_local, topK) slabs into full (n_cols, topK) arrays on every rank.
 
-    local_idx / local_val: torch tensors (int32 / float32) on the communication device (GPU for nccl, CPU for
-    gloo) holding this rank's range.  Slabs are padded to the widest range so that one fixed-size
-    all_gather suffices."""
+    local_idx / local_val: torch tensors (int32 / float32) holding this rank's range (at least n_local rows).
+    Slabs are padded to the widest range so that one fixed-size all-gather per array suffices.  With the nccl
+    (= RCCL) backend the exchange happens between device buffers over xGMI; with gloo (CPU tests, or the
+    single-GPU dry run of bench.py) the slabs are staged through host memory."""
     import torch
     world = len(ranges)
     widest = max(e - s for s, e in ranges)
-    device = device if device is not None else local_idx.device
+    on_host = dist.get_backend() == "gloo"
+    device = torch.device("cpu") if on_host else (device if device is not None else local_idx.device)
     pad_idx = torch.full((widest, topK), -1, dtype=torch.int32, device=device)
     pad_val = torch.zeros((widest, topK), dtype=torch.float32, device=device)
     n_local = ranges[rank][1] - ranges[rank][0]
-    pad_idx[:n_local] = local_idx[:n_local]
-    pad_val[:n_local] = local_val[:n_local]
-    all_idx = torch.empty((world, widest, topK), dtype=torch.int32, device=device)
-    all_val = torch.empty((world, widest, topK), dtype=torch.float32, device=device)
-    dist.all_gather_into_tensor(all_idx, pad_idx)
-    dist.all_gather_into_tensor(all_val, pad_val)
-    full_idx = torch.cat([all_idx[r, :ranges[r][1] - ranges[r][0]] for r in range(world)], dim=0)
-    full_val = torch.cat([all_val[r, :ranges[r][1] - ranges[r][0]] for r in range(world)], dim=0)
+    pad_idx[:n_local] = local_idx[:n_local].to(device)
+    pad_val[:n_local] = local_val[:n_local].to(device)
+    all_idx = [torch.empty_like(pad_idx) for _ in range(world)]
+    all_val = [torch.empty_like(pad_val) for _ in range(world)]
+    dist.all_gather(all_idx, pad_idx)
+    dist.all_gather(all_val, pad_val)
+    full_idx = torch.cat([all_idx[r][:ranges[r][1] - ranges[r][0]] for r in range(world)], dim=0)
+    full_val = torch.cat([all_val[r][:ranges[r][1] - ranges[r][0]] for r in range(world)], dim=0)
     return full_idx, full_val
 
 

@@ -1,0 +1,137 @@
+"""Host-side logic that needs no GPU: recommender surface, slab assembly, column sharding, synthetic URMs."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from oracle import oracle as O
+from recsys2019_deeplearning_evaluation_amd import recommender_base as RB
+from recsys2019_deeplearning_evaluation_amd.sharding import balanced_column_ranges
+from recsys2019_deeplearning_evaluation_amd.similarity import slabs_to_csr
+from recsys2019_deeplearning_evaluation_amd.slim_bpr import rows_slabs_to_csr
+from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm, synthetic_urm
+from _util import csr_columns_as_slabs
+
+
+def test_slabs_to_csr_equals_reference_coo_assembly():
+    X = synthetic_urm(200, 80, 3000, 3, 40, seed=1, values="real")
+    orc = O.OracleSimilarity(X, topK=7, shrink=1)
+    idx, val = orc.build_slabs(0, 80)
+    W = slabs_to_csr(idx, val, 0, 80)
+    Wo = O.slabs_to_csr(idx, val, 0, 80)
+    assert sps.isspmatrix_csr(W) and W.dtype == np.float32 and abs(W - Wo).max() == 0
+    part = slabs_to_csr(idx[10:30], val[10:30], 10, 80)
+    assert abs(part - Wo.multiply(sps.csr_matrix(([1.0] * 20, (range(20), range(10, 30))), shape=(20, 80)).sum(axis=0) > 0)).max() < 1e-7
+    back_idx, back_val = csr_columns_as_slabs(W, 7)
+    np.testing.assert_array_equal(back_idx, idx)
+
+
+def test_rows_slabs_to_csr():
+    idx = np.array([[2, 0, -1], [-1, -1, -1], [1, -1, -1]], np.int32)
+    val = np.array([[0.5, 0.25, 0], [0, 0, 0], [-1.0, 0, 0]], np.float32)
+    W = rows_slabs_to_csr(idx, val, 3)
+    np.testing.assert_array_equal(W.toarray(), [[0.25, 0, 0.5], [0, 0, 0], [0, -1.0, 0]])
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_balanced_column_ranges(world):
+    rng = np.random.default_rng(0)
+    cost = (1e6 / np.arange(1, 2001) ** 0.8).astype(np.int64) + rng.integers(0, 50, 2000)     # Zipf-like skew
+    ranges = balanced_column_ranges(cost, world)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 2000 and len(ranges) == world
+    assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:])) and all(e > s for s, e in ranges)
+    loads = np.array([cost[s:e].sum() for s, e in ranges], dtype=float)
+    assert loads.max() <= 1.25 * loads.mean() + cost.max()
+    # equal-count ranges would be far worse on this skew
+    if world >= 4:
+        naive = np.array([c.sum() for c in np.array_split(cost, world)], dtype=float)
+        assert loads.max() < naive.max()
+
+
+def test_balanced_ranges_degenerate():
+    assert balanced_column_ranges([5, 5], 8) == [(0, 1), (1, 2)]
+    assert balanced_column_ranges([0, 0, 0, 0], 2) == [(0, 2), (2, 4)]
+    assert balanced_column_ranges(np.ones(10), 1) == [(0, 10)]
+
+
+def test_recommend_and_persistence(tmp_path):
+    X = synthetic_urm(50, 30, 400, 2, 20, seed=2, values="binary")
+
+    class Fixed(RB.BaseMatrixFactorizationRecommender):
+        RECOMMENDER_NAME = "Fixed"
+
+    rec = Fixed(X, verbose=False)
+    rng = np.random.default_rng(0)
+    rec.USER_factors = rng.normal(size=(50, 4)); rec.ITEM_factors = rng.normal(size=(30, 4))
+    ranked, scores = rec.recommend(np.arange(5), cutoff=6, return_scores=True)
+    for u in range(5):
+        seen = set(X[u].indices.tolist())
+        assert not seen & set(ranked[u]) and len(ranked[u]) == 6
+        s = rec.USER_factors[u] @ rec.ITEM_factors.T
+        s[list(seen)] = -np.inf
+        assert ranked[u] == np.argsort(-s)[:6].tolist()
+    single = rec.recommend(3, cutoff=4)
+    assert single == ranked[3][:4]
+    only = rec._compute_item_score(np.arange(2), items_to_compute=[1, 2])
+    assert np.isinf(only[:, 0]).all() and np.isfinite(only[:, 1:3]).all()
+    rec.set_items_to_ignore([0, 1])
+    assert not {0, 1} & set(rec.recommend(0, cutoff=10, remove_custom_items_flag=True))
+    rec.save_model(str(tmp_path) + "/", "m")
+    other = Fixed(X, verbose=False)
+    other.load_model(str(tmp_path) + "/", "m")
+    np.testing.assert_array_equal(other.USER_factors, rec.USER_factors)
+    assert other.use_bias is False
+
+
+def test_similarity_topk_helper_matches_reference_semantics():
+    rng = np.random.default_rng(1)
+    S = rng.normal(size=(12, 12)); S[rng.random((12, 12)) < 0.5] = 0
+    W = RB.similarityMatrixTopK(S, k=3)
+    for c in range(12):
+        col = S[:, c]; nz = np.flatnonzero(col)
+        want = nz[np.argsort(col[nz])[-3:]]
+        np.testing.assert_array_equal(np.sort(W[:, c].nonzero()[0]), np.sort(want))
+    assert abs(RB.similarityMatrixTopK(sps.csr_matrix(S), k=3) - W).max() < 1e-7
+
+
+def test_early_stopping_loop():
+    class Toy(RB.Incremental_Training_Early_Stopping):
+        verbose = False
+        RECOMMENDER_NAME = "toy"
+
+        def __init__(self):
+            self.epochs_run = 0; self.best = None
+
+        def _run_epoch(self, n):
+            self.epochs_run += 1
+
+        def _prepare_model_for_validation(self):
+            pass
+
+        def _update_best_model(self):
+            self.best = self.epochs_run
+
+    class Evaluator:
+        def __init__(self):
+            self.values = iter([0.1, 0.3, 0.2, 0.25, 0.1, 0.0])
+
+        def evaluateRecommender(self, rec):
+            return {10: {"MAP": next(self.values)}}, "str"
+
+    t = Toy()
+    t._train_with_early_stopping(7)
+    assert t.epochs_run == 7 and t.epochs_best == 6 and t.best == 7
+    t = Toy()
+    t._train_with_early_stopping(100, validation_every_n=2, stop_on_validation=True, validation_metric="MAP",
+                                 lower_validations_allowed=2, evaluator_object=Evaluator())
+    assert t.epochs_best == 4 and t.best == 4 and t.epochs_run == 8
+    with pytest.raises(AssertionError):
+        Toy()._train_with_early_stopping(5, evaluator_object=Evaluator())
+
+
+def test_synthetic_family_is_seeded_and_has_no_cold_rows():
+    a = named_urm("ml1m", "real", scale=0.1); b = named_urm("ml1m", "real", scale=0.1)
+    assert (a != b).nnz == 0 and a.has_sorted_indices
+    assert (np.diff(a.indptr) > 0).all() and (np.diff(a.tocsc().indptr) > 0).all()
+    assert len(np.unique(a.data)) > 1000 and (a.data != np.rint(a.data)).mean() > 0.99   # jittered ratings
+    c = named_urm("ml1m", "binary", scale=0.1)
+    assert (c.data == 1).all()
