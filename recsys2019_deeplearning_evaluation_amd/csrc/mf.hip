@@ -534,7 +534,8 @@ extern "C" int mi355rec_mf_run_epochs(mi355rec_mf_t h, int32_t n_epochs) {
         begin_call(h);
         // epochs whose gradient launches carry timing events run as plain launches, the rest replays the graph
         const long long timed_epochs = h->max_timed > 0 ? std::min<long long>(n_epochs, (h->max_timed + per_epoch - 1) / per_epoch) : 0;
-        const bool use_graph = per_epoch <= MAX_GRAPH_BATCHES && n_epochs - timed_epochs > 0;
+        // MI355REC_NO_GRAPH=1: plain launches only (rocprofv3 on ROCm 7.2 crashes while tracing graph replays)
+        const bool use_graph = per_epoch <= MAX_GRAPH_BATCHES && n_epochs - timed_epochs > 0 && !getenv("MI355REC_NO_GRAPH");
         if (use_graph) ensure_epoch_graph(h, p);
         h->timer.start(h->stream);
         for (long long e = 0; e < n_epochs; ++e) {
