@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sim", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each CPU baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other hot paths (FunkSVD, large-batch BPR, SLIM-BPR, IALS)")
     return ap.parse_args()
 
 
@@ -129,6 +130,57 @@ def cpu_baseline_sim(urm, costs, seconds):
     return {"value": est_full, "unit": "s", "cores": 1, "kind": kind,
             "sample": "columns [%d,%d) = %.2f %% of the build's work ran %.1f s (+ %.1f s constructor); full build extrapolated "
                       "by cost" % (start, end, 100 * frac, t_cols, t_init)}
+
+
+def other_paths(urm):
+    """The remaining rows of SURVEY.md section 8 on the same URM shape, one short run each (N = 1 only).  Throughputs come from
+    the handle's own stream events (call_ms); fractions are ALGORITHMIC work / time against the MI355X peaks."""
+    import numpy as np
+    from recsys2019_deeplearning_evaluation_amd import (IALS_MI355X_Epoch, MatrixFactorization_MI355X_Epoch,
+                                                        SLIM_BPR_MI355X_Epoch)
+    out = {}
+
+    def mf_run(tag, epochs, **kw):
+        m = MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, learning_rate=1e-3, init_std_dev=0.1, random_seed=7, **kw)
+        m.epochIteration_Cython(1)
+        m.epochIteration_Cython(epochs)
+        st = m.stats()
+        sec = st["call_ms"] * 1e-3
+        out[tag] = {"samples_per_s": st["n_units"] / sec, "algorithmic_GBps": st["algorithmic_bytes"] / sec / 1e9,
+                    "frac_of_hbm_peak": st["algorithmic_bytes"] / sec / 1e9 / HBM_PEAK_GBPS, "epochs": epochs, "seconds": sec}
+        m.close()
+
+    # the same BPR epoch at a batch size where a mini-batch fills the chip (the reference's search space stops at 1024)
+    mf_run("bpr_mf_k128_batch65536", 200, algorithm_name="MF_BPR", batch_size=65536, sgd_mode="sgd")
+    mf_run("bpr_mf_k128_batch1000_adagrad", 50, algorithm_name="MF_BPR", batch_size=BATCH, sgd_mode="adagrad")
+    mf_run("funk_svd_k128_batch1000_bias", 1, algorithm_name="FUNK_SVD", batch_size=BATCH, sgd_mode="sgd", use_bias=True,
+           negative_interactions_quota=0.0)
+    for symmetric in (False, True):
+        sl = SLIM_BPR_MI355X_Epoch(urm, symmetric=symmetric, sgd_mode="adagrad", learning_rate=1e-4, topK=TOPK, random_seed=7)
+        sl.epochIteration_Cython(1)
+        sl.epochIteration_Cython(2)
+        st = sl.stats()
+        sec = st["call_ms"] * 1e-3
+        t0 = time.perf_counter()
+        sl.get_S_slabs(TOPK)
+        out["slim_bpr_%s" % ("symmetric" if symmetric else "dense")] = {
+            "samples_per_s": st["n_units"] / sec, "algorithmic_GBps": st["algorithmic_bytes"] / sec / 1e9,
+            "launches_per_epoch": st["n_launches"] / 2, "seconds_per_epoch": sec / 2, "get_S_topk_s": time.perf_counter() - t0}
+        sl.close()
+    k = 200
+    conf = urm.copy()
+    conf.data = (1.0 + 1.0 * conf.data).astype(np.float32)
+    V0 = k ** -0.5 * np.random.default_rng(0).random((urm.shape[1], k))
+    ia = IALS_MI355X_Epoch(conf, k, 1e-3, V0)
+    ia.run_epochs(1)
+    st = ia.stats()
+    sec = st["call_ms"] * 1e-3
+    out["ials_k200"] = {"seconds_per_epoch": sec, "row_solves_per_s": st["n_units"] / sec,
+                        "algorithmic_fp64_TFLOPs": st["algorithmic_flops"] / sec / 1e12,
+                        "frac_of_fp64_vector_peak_78.6TF": st["algorithmic_flops"] / sec / 1e12 / 78.6,
+                        "row_kernel_ms": st["kernel_ms"]}
+    ia.close()
+    return out
 
 
 def main():
@@ -243,6 +295,11 @@ def main():
                       "batch_size": BATCH, "n_factors": K_FACTORS, "parallelism": "replicas x%d" % world},
            "roofline": roofline, "extra": extra}
 
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            out["extra"]["other_paths"] = other_paths(urm)
+        except Exception as exc:                       # the headline line must survive a failure in the side measurements
+            out["extra"]["other_paths_error"] = repr(exc)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline_bpr(urm, args.cpu_seconds)
         base["host_cpu_count"] = os.cpu_count()

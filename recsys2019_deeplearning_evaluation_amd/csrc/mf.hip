@@ -115,14 +115,14 @@ __global__ __launch_bounds__(256) void mf_sample_kernel(const MfParams p) {
 
 // KI = ceil(k / 64) rows-in-registers specialisation (1..4); KI == 0: any k, rows are re-read for the scatter.
 template <int ALGO, int KI>
-__global__ __launch_bounds__(256) void mf_grad_kernel(const MfParams p) {
+__global__ __launch_bounds__(256) void mf_grad_kernel(const MfParams p, const int batch_local) {
+    // batch_local = position of this mini-batch inside the stream buffer; it is a launch argument (baked into the
+    // graph node), so the sample triplet is the first load of the kernel, not the second
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);   // sample slot inside the batch
-    const long long batch = p.state->grad_batch;
-    if (blockIdx.x == 0 && threadIdx.x == 0) p.state->apply_batch = batch;   // consumed by the apply kernel that follows
     double my_loss = 0.0;
     if (w < p.n_in_batch) {
-        const long long slot = ((batch - p.stream_base) % p.stream_batches) * (long long)p.batch_size + w;
+        const long long slot = (long long)batch_local * p.batch_size + w;
         const int u = p.su[slot], i = p.si[slot];
         int j = -1;
         float rating = 0.f;
@@ -251,7 +251,7 @@ __device__ __forceinline__ float adapt(const MfParams &p, float g, float *c1, fl
 __global__ __launch_bounds__(256) void mf_apply_kernel(const MfParams p) {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long batch = p.state->apply_batch;
+    const long long batch = p.state->grad_batch;         // global mini-batch index (only Adam's beta^t needs its value)
     const float invB = 1.f / (float)p.batch_size;      // mean over batch_size, NOT over the row's count (.pyx:802)
     float pw1 = 1.f, pw2 = 1.f;
     if (p.sgd_mode == MI355REC_ADAM) {                  // beta^(t) with t = batch + 1 (.pyx:217-218, :646-649)
@@ -358,30 +358,30 @@ void fill_params(mi355rec_mf *h, MfParams &p) {
 }
 
 template <int ALGO, int KI>
-void launch_grad(mi355rec_mf *h, const MfParams &p, int grid, hipEvent_t e0, hipEvent_t e1) {
-    if (e0) hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, KI>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p);
-    else hipLaunchKernelGGL((mf_grad_kernel<ALGO, KI>), dim3(grid), dim3(256), 0, h->stream, p);   // capturable
+void launch_grad(mi355rec_mf *h, const MfParams &p, int grid, int batch_local, hipEvent_t e0, hipEvent_t e1) {
+    if (e0) hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, KI>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p, batch_local);
+    else hipLaunchKernelGGL((mf_grad_kernel<ALGO, KI>), dim3(grid), dim3(256), 0, h->stream, p, batch_local);   // capturable
 }
 
 template <int ALGO>
-void launch_grad_ki(mi355rec_mf *h, const MfParams &p, int grid, bool timed) {
+void launch_grad_ki(mi355rec_mf *h, const MfParams &p, int grid, int batch_local, bool timed) {
     const int ki = h->k <= 256 ? (h->k + 63) / 64 : 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) h->dispatch_timers.next(e0, e1, h->max_timed);
     switch (ki) {
-        case 1: launch_grad<ALGO, 1>(h, p, grid, e0, e1); break;
-        case 2: launch_grad<ALGO, 2>(h, p, grid, e0, e1); break;
-        case 3: launch_grad<ALGO, 3>(h, p, grid, e0, e1); break;
-        case 4: launch_grad<ALGO, 4>(h, p, grid, e0, e1); break;
-        default: launch_grad<ALGO, 0>(h, p, grid, e0, e1); break;
+        case 1: launch_grad<ALGO, 1>(h, p, grid, batch_local, e0, e1); break;
+        case 2: launch_grad<ALGO, 2>(h, p, grid, batch_local, e0, e1); break;
+        case 3: launch_grad<ALGO, 3>(h, p, grid, batch_local, e0, e1); break;
+        case 4: launch_grad<ALGO, 4>(h, p, grid, batch_local, e0, e1); break;
+        default: launch_grad<ALGO, 0>(h, p, grid, batch_local, e0, e1); break;
     }
 }
 
-void launch_batch(mi355rec_mf *h, const MfParams &p, bool timed) {
+void launch_batch(mi355rec_mf *h, const MfParams &p, int batch_local, bool timed) {
     const int grad_grid = div_up(p.n_in_batch, 4);
     const bool bpr = h->cfg.algorithm == MI355REC_MF_BPR;
-    if (bpr) launch_grad_ki<MI355REC_MF_BPR>(h, p, grad_grid, timed);
-    else launch_grad_ki<MI355REC_MF_FUNK_SVD>(h, p, grad_grid, timed);
+    if (bpr) launch_grad_ki<MI355REC_MF_BPR>(h, p, grad_grid, batch_local, timed);
+    else launch_grad_ki<MI355REC_MF_FUNK_SVD>(h, p, grad_grid, batch_local, timed);
     const int slots = (bpr ? 3 : 2) * p.n_in_batch;
     hipLaunchKernelGGL(mf_apply_kernel, dim3(div_up(slots, 4)), dim3(256), 0, h->stream, p);
 }
@@ -396,13 +396,13 @@ void launch_sampler(mi355rec_mf *h, const MfParams &p) {
 void enqueue_epoch(mi355rec_mf *h, const MfParams &p, bool timed) {
     launch_sampler(h, p);
     const long long nb = batches_per_epoch(h);
-    for (long long b = 0; b < nb; ++b) launch_batch(h, p, timed);
+    for (long long b = 0; b < nb; ++b) launch_batch(h, p, (int)b, timed);
 }
 
 // Capture one epoch into a graph (re-captured only if the stream base changed, i.e. after a replay call).
 constexpr long long MAX_GRAPH_BATCHES = 4096;
 void ensure_epoch_graph(mi355rec_mf *h, const MfParams &p) {
-    if (h->epoch_graph && h->graph_stream_base % batches_per_epoch(h) == p.stream_base % batches_per_epoch(h)) return;
+    if (h->epoch_graph) return;
     if (h->epoch_graph) {
         (void)hipGraphExecDestroy(h->epoch_graph);
         h->epoch_graph = nullptr;
@@ -574,7 +574,7 @@ extern "C" int mi355rec_mf_run_samples(mi355rec_mf_t h, const int32_t *u, const 
         h->timer.start(s);
         for (long long b = 0; b < n_batches; ++b) {
             p.n_in_batch = (int)std::min<long long>(B, n - b * B);
-            launch_batch(h, p, true);
+            launch_batch(h, p, (int)b, true);
         }
         h->timer.stop(s);
         h->batches_done += n_batches;
