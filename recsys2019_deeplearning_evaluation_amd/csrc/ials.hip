@@ -9,11 +9,11 @@
 // vector pipe -- on CDNA4 the FP64 matrix rate equals the FP64 vector rate, so MFMA buys nothing here.
 //   gram_kernel      G = Y^T Y, register tiles + double atomics (tiny: n * k^2).
 //   ials_row_kernel  one 1024-thread workgroup per row, rows pulled longest-profile-first from a queue.  The k x k
-//                    system lives entirely in registers: thread (ty, tx) of the 32 x 32 grid owns the cells
-//                    B[ty + 32a][tx + 32b].  (1) B = G + reg I; (2) rank-1 updates (c-1) y y^T with the profile's
-//                    factor rows staged through LDS 16 at a time; (3) Gauss-Jordan elimination in place (SPD: no
-//                    pivoting), pivot row / column / rhs broadcast through double-buffered LDS, one barrier per
-//                    step, finished column tiles skipped; the rhs rides along, so no triangular solves follow.
+//                    system lives entirely in registers, lower-triangular tiles only: thread (ty, tx) of the 32 x 32
+//                    grid owns B[ty + 32a][tx + 32b], a >= b.  (1) B = G + reg I; (2) rank-1 updates (c-1) y y^T with
+//                    the profile's factor rows staged through LDS 16 at a time; (3) in-place right-looking Cholesky
+//                    (SPD: no pivoting), pivot column and rhs broadcast through double-buffered LDS, one barrier per
+//                    step, forward substitution fused; (4) column-oriented back substitution, one barrier per step.
 #include "common.h"
 
 #include <algorithm>
@@ -80,17 +80,16 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *Y, int n, int k
         }
 }
 
-// Thread grid TY x 32 (TY = 32: 1024 threads, TY = 16: 512 threads).  Thread (ty, tx) owns the cells
-// B[ty + TY*a][tx + 32*b], a < KTA = ceil(k / TY), b < KTB = ceil(k / 32).  The 512-thread shape is used for
-// k > 160: 1024 threads leave 128 registers per lane, not enough for 49 doubles plus operands.
-template <int KTA, int KTB, int TY>
-__global__ __launch_bounds__(32 * TY) void ials_row_kernel(const IalsParams p) {
-    constexpr int THREADS = 32 * TY, KPAD = KTB * 32;
-    static_assert(KTA * TY >= KPAD || KTA * TY + TY > KPAD, "row tiling must cover the padded width");
+// 1024 threads as a 32 x 32 grid.  Thread (ty, tx) owns the cells B[ty + 32a][tx + 32b] of the LOWER-triangular
+// tiles a >= b only (the system is symmetric): KT(KT+1)/2 doubles per thread, 28 at k = 200 -- no spills at the
+// 128-register budget of a 16-wave workgroup.  KT = ceil(k / 32).
+template <int KT>
+__global__ __launch_bounds__(1024) void ials_row_kernel(const IalsParams p) {
+    constexpr int KPAD = KT * 32;
     __shared__ double ys[CHUNK][KPAD];        // staged factor rows of the profile
     __shared__ double wts[CHUNK];             // c - 1
     __shared__ double cfs[CHUNK];             // c
-    __shared__ double colb[2][KPAD + 32];
+    __shared__ double pub[2][KPAD];           // pivot column (factorisation) / pivot row (back substitution), double-buffered
     __shared__ double rhsb[2];
     __shared__ int s_row;
 
@@ -105,16 +104,16 @@ __global__ __launch_bounds__(32 * TY) void ials_row_kernel(const IalsParams p) {
         const int row = p.order[slot];
         const int beg = p.ptr[row], end = p.ptr[row + 1];
 
-        // (1) B = YtY + reg I                                    (IALSRecommender.py:199)
-        double B[KTA][KTB];
+        // (1) B = YtY + reg I                                    (IALSRecommender.py:199), lower tiles only
+        double B[KT][KT];
 #pragma unroll
-        for (int a = 0; a < KTA; ++a)
+        for (int a = 0; a < KT; ++a)
 #pragma unroll
-            for (int b = 0; b < KTB; ++b) {
-                const int r = ty + TY * a, c = tx + 32 * b;
+            for (int b = 0; b <= a; ++b) {
+                const int r = ty + 32 * a, c = tx + 32 * b;
                 double v = 0.0;
                 if (r < k && c < k) v = p.G[(size_t)r * k + c] + (r == c ? p.reg : 0.0);
-                else if (r == c) v = 1.0;                        // identity padding keeps the elimination well defined
+                else if (r == c) v = 1.0;                        // identity padding keeps the factorisation well defined
                 B[a][b] = v;
             }
         double rhs = 0.0;                                         // thread t < k carries (Y_I^T c)[t]  (:201)
@@ -123,7 +122,7 @@ __global__ __launch_bounds__(32 * TY) void ials_row_kernel(const IalsParams p) {
         for (int base = beg; base < end; base += CHUNK) {
             const int nr = min(CHUNK, end - base);
             __syncthreads();
-            for (int e = tid; e < CHUNK * KPAD; e += THREADS) {
+            for (int e = tid; e < CHUNK * KPAD; e += 1024) {
                 const int r = e / KPAD, f = e % KPAD;
                 double v = 0.0;
                 if (r < nr && f < k) v = p.Y[(size_t)p.idx[base + r] * k + f];
@@ -137,57 +136,80 @@ __global__ __launch_bounds__(32 * TY) void ials_row_kernel(const IalsParams p) {
             __syncthreads();
             for (int r = 0; r < nr; ++r) {
                 const double w = wts[r];
-                double yb[KTB];
+                double yb[KT];
 #pragma unroll
-                for (int b = 0; b < KTB; ++b) yb[b] = ys[r][tx + 32 * b];
+                for (int b = 0; b < KT; ++b) yb[b] = ys[r][tx + 32 * b];
 #pragma unroll
-                for (int a = 0; a < KTA; ++a) {      // row operand fetched per a: keeps the operand registers at KTB + 1
-                    const double ya = (ty + TY * a < KPAD ? ys[r][ty + TY * a] : 0.0) * w;
+                for (int a = 0; a < KT; ++a) {
+                    const double ya = ys[r][ty + 32 * a] * w;
 #pragma unroll
-                    for (int b = 0; b < KTB; ++b) B[a][b] += ya * yb[b];
+                    for (int b = 0; b <= a; ++b) B[a][b] += ya * yb[b];
                 }
             }
-            for (int t = tid; t < k; t += THREADS) {
+            if (tid < k) {
                 double s = 0.0;
-                for (int r = 0; r < nr; ++r) s += ys[r][t] * cfs[r];
+                for (int r = 0; r < nr; ++r) s += ys[r][tid] * cfs[r];
                 rhs += s;
             }
         }
 
-        // (3) Gauss-Jordan on [B | rhs]; afterwards rhs IS the solution  (reference: np.linalg.inv(B) . rhs, :201).
-        // The not-yet-eliminated block of an SPD matrix stays symmetric, so the pivot ROW to the right of the pivot
-        // equals the pivot COLUMN below it and is 0 to the left: only the column is published.  The loop over column
-        // tiles is unrolled at compile time, which keeps every register index static.
+        // (3) B = L L^T in place (right-looking Cholesky, one published column and one barrier per step), with the
+        // forward substitution L z = rhs fused in.  The tile loop is unrolled at compile time so that every register
+        // index is static.  (The reference forms inv(B) . rhs, :201; same solution.)
+        int step = 0;
 #pragma unroll
-        for (int JB = 0; JB < KTB; ++JB) {
+        for (int JB = 0; JB < KT; ++JB) {
 #pragma unroll 1
             for (int jl = 0; jl < 32; ++jl) {
                 const int j = JB * 32 + jl;
                 if (j >= k) break;
-                const int buf = j & 1;
-                if (tx == jl) {      // owners of column j publish B[:, j]
+                const int buf = (step++) & 1;
+                if (tx == jl) {      // owners of column j publish B[:, j] (rows of tiles a >= JB)
 #pragma unroll
-                    for (int a = 0; a < KTA; ++a) colb[buf][ty + TY * a] = B[a][JB];
+                    for (int a = JB; a < KT; ++a) pub[buf][ty + 32 * a] = B[a][JB];
                 }
                 if (tid == j) rhsb[buf] = rhs;
                 __syncthreads();
-                const double d = colb[buf][j];
-                const double inv = 1.0 / d;
-                const double rj = rhsb[buf] * inv;
-                double rb[KTB];
+                const double d = pub[buf][j];
+                const double inv = 1.0 / sqrt(d);               // 1 / L_jj
+                const double zj = rhsb[buf] * inv;
+                double lc[KT];
 #pragma unroll
-                for (int b = JB; b < KTB; ++b) {
+                for (int b = JB; b < KT; ++b) {
                     const int c = tx + 32 * b;
-                    rb[b] = (c > j ? colb[buf][c] : (c == j ? d : 0.0)) * inv;
+                    lc[b] = c > j ? pub[buf][c] * inv : 0.0;     // L[c][j]; columns <= j are not updated
                 }
 #pragma unroll
-                for (int a = 0; a < KTA; ++a) {
-                    const int r = ty + TY * a;
-                    const double ca = colb[buf][r];
+                for (int a = JB; a < KT; ++a) {
+                    const int r = ty + 32 * a;
+                    const double lr = r > j ? pub[buf][r] * inv : 0.0;   // L[r][j]
 #pragma unroll
-                    for (int b = JB; b < KTB; ++b) B[a][b] = r == j ? rb[b] : B[a][b] - ca * rb[b];
+                    for (int b = JB; b <= a; ++b) {
+                        double v = B[a][b] - lr * lc[b];
+                        if (b == JB && tx == jl) v = r > j ? lr : (r == j ? d * inv : B[a][b]);   // column j becomes L[:, j]
+                        B[a][b] = v;
+                    }
                 }
-                if (tid < k) rhs = tid == j ? rj : rhs - colb[buf][tid] * rj;
+                if (tid < k) rhs = tid == j ? zj : (tid > j ? rhs - pub[buf][tid] * inv * zj : rhs);
+            }
+        }
+        // (4) back substitution L^T x = z, column oriented: x_j = z_j / L_jj, then z_c -= L[j][c] x_j for c < j.
+        // Row j of L is held by the threads with ty == j % 32 in the tiles (JA, b <= JA).
+#pragma unroll
+        for (int JA = KT - 1; JA >= 0; --JA) {
+#pragma unroll 1
+            for (int jl = 31; jl >= 0; --jl) {
+                const int j = JA * 32 + jl;
+                if (j >= k) continue;
+                const int buf = (step++) & 1;
+                if (ty == jl) {
+#pragma unroll
+                    for (int b = 0; b <= JA; ++b) pub[buf][tx + 32 * b] = B[JA][b];
+                }
+                if (tid == j) rhsb[buf] = rhs;
+                __syncthreads();
+                const double xj = rhsb[buf] / pub[buf][j];
+                if (tid < k) rhs = tid == j ? xj : (tid < j ? rhs - pub[buf][tid] * xj : rhs);
             }
         }
         if (tid < k) p.X[(size_t)row * k + tid] = rhs;
@@ -287,20 +309,20 @@ void launch_gram(mi355rec_ials *h, const double *Y, int n) {
     }
 }
 
-template <int KTA, int KTB, int TY>
+template <int KT>
 void launch_rows_t(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1) {
-    hipExtLaunchKernelGGL((ials_row_kernel<KTA, KTB, TY>), dim3(grid), dim3(32 * TY), 0, h->stream, e0, e1, 0, p);
+    hipExtLaunchKernelGGL(ials_row_kernel<KT>, dim3(grid), dim3(1024), 0, h->stream, e0, e1, 0, p);
 }
 
 void launch_rows(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1) {
     switch ((h->k + 31) / 32) {
-        case 1: launch_rows_t<1, 1, 32>(h, p, grid, e0, e1); break;
-        case 2: launch_rows_t<2, 2, 32>(h, p, grid, e0, e1); break;
-        case 3: launch_rows_t<3, 3, 32>(h, p, grid, e0, e1); break;
-        case 4: launch_rows_t<4, 4, 32>(h, p, grid, e0, e1); break;
-        case 5: launch_rows_t<5, 5, 32>(h, p, grid, e0, e1); break;
-        case 6: launch_rows_t<12, 6, 16>(h, p, grid, e0, e1); break;
-        default: launch_rows_t<14, 7, 16>(h, p, grid, e0, e1); break;
+        case 1: launch_rows_t<1>(h, p, grid, e0, e1); break;
+        case 2: launch_rows_t<2>(h, p, grid, e0, e1); break;
+        case 3: launch_rows_t<3>(h, p, grid, e0, e1); break;
+        case 4: launch_rows_t<4>(h, p, grid, e0, e1); break;
+        case 5: launch_rows_t<5>(h, p, grid, e0, e1); break;
+        case 6: launch_rows_t<6>(h, p, grid, e0, e1); break;
+        default: launch_rows_t<7>(h, p, grid, e0, e1); break;
     }
 }
 
@@ -379,7 +401,7 @@ extern "C" int mi355rec_ials_create(mi355rec_ials_t *out, int32_t n_users, int32
         MI_REQUIRE(out && indptr && indices && confidence && V0, "NULL argument");
         MI_REQUIRE(n_users > 0 && n_items > 0, "empty URM");
         MI_REQUIRE(n_factors >= 1, "num_factors must be >= 1");
-        if (n_factors > 224)
+        if (n_factors > 224)   // 7 x 7 tiles of 32: 28 lower-triangular doubles per thread; the search space stops at 200
             fail(MI355REC_E_UNSUPPORTED, "num_factors = %d: the register-resident solver covers num_factors <= 224", n_factors);
         ensure_device();
         std::unique_ptr<mi355rec_ials> h(new mi355rec_ials());
