@@ -66,6 +66,21 @@ def load_urm(name):
     return urm
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the latest committed PMC collection (profiles/*_pmc_traffic.json, produced by
+    scripts/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes of this same workload; FETCH doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the counters itself; None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline_bpr(urm, seconds):
     """The reference's compiled Cython BPR epoch (oracle/_ref) on ONE host core; falls back to the C restatement."""
     import io
@@ -246,7 +261,7 @@ def main():
     bytes_per_launch = st["algorithmic_bytes"] / max(1, st["n_launches"])
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": "mf_grad_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic("mf_grad_kernel"),
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_launch_s * 1e6,
                 "timed_launches": st["n_timed"],
                 "whole_epoch_achieved_GBps": st["algorithmic_bytes"] / (st["call_ms"] * 1e-3) / 1e9}
