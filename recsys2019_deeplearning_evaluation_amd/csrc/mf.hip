@@ -31,7 +31,6 @@ namespace {
 
 struct MfState {           // lives in device memory so that launches carry no per-batch host arguments
     long long grad_batch;  // index (since create) of the batch the next grad kernel works on
-    long long apply_batch; // same for the next apply kernel
     long long epoch;       // index (since create) of the epoch the next sampling kernel draws
 };
 
@@ -55,8 +54,6 @@ struct MfParams {
     // sample stream: one epoch drawn by mf_sample_kernel (native) or the caller's stream (replay)
     int *su, *si, *sj;
     float *sr;
-    long long stream_base;               // batch index (since create) at which the stream buffer starts
-    long long stream_batches;            // number of mini-batches the stream buffer holds (it is read cyclically)
     long long samples_per_epoch;
     int n_in_batch;                      // samples in this launch's batch (<= batch_size; short only in replay)
 };
@@ -317,7 +314,6 @@ struct mi355rec_mf {
     DispatchTimers dispatch_timers;
     int max_timed = 0;
     hipGraphExec_t epoch_graph = nullptr;   // one native epoch: sample kernel + n_batches x (grad, apply)
-    long long graph_stream_base = -1;
     std::vector<double> host_loss;
 };
 
@@ -351,8 +347,6 @@ void fill_params(mi355rec_mf *h, MfParams &p) {
     p.c1_bu = h->c1_bu.ptr; p.c2_bu = h->c2_bu.ptr; p.c1_bi = h->c1_bi.ptr; p.c2_bi = h->c2_bi.ptr; p.c_mu = h->c_mu.ptr;
     p.flag = h->flag.ptr; p.list = h->list.ptr; p.loss_slots = h->loss_slots.ptr; p.state = h->state.ptr;
     p.su = h->su.ptr; p.si = h->si.ptr; p.sj = h->sj.ptr; p.sr = h->sr.ptr;
-    p.stream_base = h->batches_done;
-    p.stream_batches = 1;
     p.samples_per_epoch = batches_per_epoch(h) * (long long)c.batch_size;
     p.n_in_batch = c.batch_size;
 }
@@ -399,7 +393,7 @@ void enqueue_epoch(mi355rec_mf *h, const MfParams &p, bool timed) {
     for (long long b = 0; b < nb; ++b) launch_batch(h, p, (int)b, timed);
 }
 
-// Capture one epoch into a graph (re-captured only if the stream base changed, i.e. after a replay call).
+// Capture one epoch into a graph (once per handle; re-captured only if the stream buffers are re-allocated).
 constexpr long long MAX_GRAPH_BATCHES = 4096;
 void ensure_epoch_graph(mi355rec_mf *h, const MfParams &p) {
     if (h->epoch_graph) return;
@@ -413,7 +407,6 @@ void ensure_epoch_graph(mi355rec_mf *h, const MfParams &p) {
     MI_HIP(hipStreamEndCapture(h->stream, &g));
     MI_HIP(hipGraphInstantiate(&h->epoch_graph, g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
-    h->graph_stream_base = p.stream_base;
 }
 
 void ensure_stream_capacity(mi355rec_mf *h, size_t n) {
@@ -530,7 +523,6 @@ extern "C" int mi355rec_mf_run_epochs(mi355rec_mf_t h, int32_t n_epochs) {
         ensure_stream_capacity(h, (size_t)(per_epoch * B));
         MfParams p{};
         fill_params(h, p);
-        p.stream_batches = per_epoch;
         begin_call(h);
         // epochs whose gradient launches carry timing events run as plain launches, the rest replays the graph
         const long long timed_epochs = h->max_timed > 0 ? std::min<long long>(n_epochs, (h->max_timed + per_epoch - 1) / per_epoch) : 0;
@@ -569,7 +561,6 @@ extern "C" int mi355rec_mf_run_samples(mi355rec_mf_t h, const int32_t *u, const 
         MfParams p{};
         fill_params(h, p);
         const long long n_batches = (n + B - 1) / B;
-        p.stream_batches = n_batches;
         begin_call(h);
         h->timer.start(s);
         for (long long b = 0; b < n_batches; ++b) {

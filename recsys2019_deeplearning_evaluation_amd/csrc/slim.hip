@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void slim_sample_kernel(SlimParams p, int *su,
 
 // One SGD step (.pyx:243-317) by LANES cooperating lanes; `reduce` sums x over them.
 template <int LANES, class Reduce>
-__device__ __forceinline__ void slim_step(const SlimParams &p, int t, int lane, Reduce reduce, bool leader) {
+__device__ __forceinline__ void slim_step(const SlimParams &p, int t, int lane, Reduce reduce) {
     const int u = p.su[t], i = p.si[t], j = p.sj[t];
     const int rs = p.indptr[u], re = p.indptr[u + 1];
     float x = 0.f;
@@ -95,8 +95,7 @@ __device__ __forceinline__ void slim_step(const SlimParams &p, int t, int lane, 
         x += p.S[cell_at(p, i, s)] - p.S[cell_at(p, j, s)];
     }
     float gi = 0.f, gj = 0.f;
-    x = reduce(x, i, j, gi, gj, t);          // also turns x into the two per-item steps (leader updates the caches)
-    (void)leader;
+    x = reduce(x, i, j, gi, gj, t);          // also turns x into the two per-item steps (one lane updates the caches)
     for (int q = rs + lane; q < re; q += LANES) {
         const int s = p.indices[q];
         if (s != i) {
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(256) void slim_level_kernel(const SlimParams p, int
         gj = __shfl(b, 0);
         return x;
     };
-    slim_step<64>(p, t, lane, reduce, lane == 0);
+    slim_step<64>(p, t, lane, reduce);
 }
 
 // Ordered path (any store): one workgroup runs steps [0, n_steps) one after the other.
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(1024) void slim_ordered_kernel(const SlimParams p) 
             gj = s_g[1];
             return x;
         };
-        slim_step<1024>(p, t, tid, reduce, tid == 0);
+        slim_step<1024>(p, t, tid, reduce);
         __threadfence_block();       // the next step of this workgroup must read what this one wrote
         __syncthreads();
     }

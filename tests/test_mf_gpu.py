@@ -130,7 +130,7 @@ def test_funk_replay_parity(gpu, mode, use_bias):
     _replay_case(X, kw, epochs=1)
 
 
-def test_config1_ml1m_k64_replay(gpu):
+def test_baseline_config_2_ml1m_k64_replay(gpu):
     """BASELINE config 2 at full ML-1M shape: k=64, batch 1000, sgd; 5 replayed epochs."""
     X = named_urm("ml1m", "binary")
     kw = dict(n_factors=64, algorithm_name="MF_BPR", batch_size=1000, random_seed=42, sgd_mode="sgd", learning_rate=1e-3,

@@ -161,3 +161,30 @@ def test_full_size_ml20m_shape_properties(gpu):
     st = dev.stats()
     assert st["n_units"] == n and st["kernel_ms"] > 0
     dev.close()
+
+
+def test_baseline_config_4_netflix_shape_properties(gpu):
+    """BASELINE.json configs[3]: full cosine similarity on the Netflix-Prize-shaped URM (480 189 x 17 770, 100 M nnz);
+    here on ONE GPU plus the cost-balanced 8-way column cut the multi-GPU build would use.  Properties as for the
+    ML-20M case, and mid-popularity columns are checked against the oracle."""
+    from recsys2019_deeplearning_evaluation_amd.sharding import balanced_column_ranges
+    X = named_urm("netflix", "binary")
+    dev = Compute_Similarity_MI355X(X, topK=100, shrink=0, similarity="cosine")
+    idx, val, _ = dev.compute_slabs()
+    n = X.shape[1]
+    valid = idx >= 0
+    assert idx.shape == (n, 100) and (val[valid] > 0).all() and (val[valid] <= 1.0 + 1e-5).all()
+    assert (np.diff(val, axis=1) <= 1e-7).all() and (idx != np.arange(n)[:, None]).all()
+    cost = dev.column_costs()
+    ranges = balanced_column_ranges(cost, 8)
+    loads = np.array([cost[s:e].sum() for s, e in ranges], dtype=float)
+    assert loads.max() < 1.1 * loads.mean() + cost.max()
+    # a column range computed on its own equals the same rows of the full build (what each rank of the sharded build does)
+    s, e = ranges[3]
+    part_idx, part_val, s0 = dev.compute_slabs(s, e)
+    np.testing.assert_array_equal(part_idx, idx[s0:s0 + len(part_idx)])
+    np.testing.assert_array_equal(part_val, val[s0:s0 + len(part_idx)])
+    orc = O.OracleSimilarity(X, topK=0)
+    for c in np.argsort(cost)[[n // 2, n // 2 + 1, n // 3]]:
+        check_topk_against_dense(idx[c], val[c], orc.column(int(c))[0], 100, RTOL)
+    dev.close()

@@ -107,3 +107,25 @@ def test_recommender_fit_surface(gpu):
         SLIM_BPR_MI355X(X, verbose=False).fit(epochs=1, train_with_sparse_weights=True)
     with pytest.raises(ValueError):
         SLIM_BPR_MI355X(X, verbose=False).fit(epochs=1, topK=0)
+
+
+def test_baseline_config_3_ml20m_shape_properties(gpu):
+    """BASELINE.json configs[2]: SLIM-BPR top-k=100 on the ML-20M-shaped URM (dense S = 2.86 GB in HBM).  Too big for the
+    float64 oracle in a test, so size-independent properties of one native epoch on the dense store: only sampled
+    (i, j) rows of S are touched, S[i, seen] went up and S[j, seen] went down, the diagonal is zero, and get_S returns
+    sorted non-zero rows."""
+    X = named_urm("ml20m", "binary")
+    dev = SLIM_BPR_MI355X_Epoch(X, topK=100, symmetric=False, sgd_mode="sgd", learning_rate=0.05, random_seed=5)
+    dev.epochIteration_Cython()
+    st = dev.stats()
+    assert st["n_units"] == X.shape[0] + 1 and st["n_launches"] > 100        # level schedule, not one step per launch
+    idx, val = dev.get_S_slabs(100)
+    n = X.shape[1]
+    assert idx.shape == (n, 100)
+    valid = idx >= 0
+    assert (val[valid] != 0).all() and (np.diff(np.where(valid, val, -np.inf), axis=1) <= 0).all()
+    assert (idx != np.arange(n)[:, None]).all()
+    touched_rows = valid.any(axis=1).sum()
+    assert 0.2 * n < touched_rows <= n                                        # ~139k steps over 26.7k item rows
+    assert (val[valid] > 0).any() and (val[valid] < 0).any()
+    dev.close()
