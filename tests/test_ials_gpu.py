@@ -104,3 +104,39 @@ def test_recommender_surface(gpu):
     assert np.mean([scores[r][dense[r]].mean() > scores[r][~dense[r]].mean() for r in range(50)]) > 0.95
     with pytest.raises(ValueError):
         rec.fit(confidence_scaling="nope")
+
+
+def test_baseline_config_5_ml20m_k200_properties(gpu):
+    """BASELINE.json configs[4]: IALS k=200 on the ML-20M-shaped URM.  Oracle-free check at full size: after the user
+    half-step every sampled user row solves its own normal equations (YtY + Y_I^T (C-1) Y_I + reg I) x = Y_I^T c against
+    the ITEM factors it was solved with, and after the item half-step sampled item rows do against the updated users."""
+    X = named_urm("ml20m", "binary")
+    Cm = O.oracle_ials_confidence(X, "linear", 1.0)
+    k, reg = 200, 1e-3
+    V0 = k ** -0.5 * np.random.default_rng(0).random((X.shape[1], k))
+    dev = IALS_MI355X_Epoch(Cm, k, reg, V0)
+    nu, ni = X.shape
+    dev.user_half(0, nu); dev.synchronize()
+    U, V_same = dev.get_factors()
+    np.testing.assert_array_equal(V_same, V0)
+    VV = V0.T @ V0
+    for u in [0, 1, nu // 2, nu - 1, int(np.argmax(np.diff(Cm.indptr)))]:
+        s, e = Cm.indptr[u], Cm.indptr[u + 1]
+        Yi = V0[Cm.indices[s:e]]; c = Cm.data[s:e].astype(np.float64)
+        Bm = VV + Yi.T @ ((c - 1)[:, None] * Yi) + reg * np.eye(k)
+        rhs = Yi.T @ c
+        assert np.abs(Bm @ U[u] - rhs).max() < 1e-7 * np.abs(rhs).max()
+    dev.item_half(0, ni); dev.synchronize()
+    U2, V = dev.get_factors()
+    np.testing.assert_array_equal(U2, U)
+    UU = U.T @ U
+    Cc = sps.csc_matrix(Cm)
+    for i in [0, ni // 2, ni - 1]:
+        s, e = Cc.indptr[i], Cc.indptr[i + 1]
+        Yi = U[Cc.indices[s:e]]; c = Cc.data[s:e].astype(np.float64)
+        Bm = UU + Yi.T @ ((c - 1)[:, None] * Yi) + reg * np.eye(k)
+        rhs = Yi.T @ c
+        assert np.abs(Bm @ V[i] - rhs).max() < 1e-7 * np.abs(rhs).max()
+    st = dev.stats()
+    assert st["algorithmic_flops"] > 0
+    dev.close()
