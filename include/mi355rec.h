@@ -209,6 +209,29 @@ int mi355rec_ials_get_factors(mi355rec_ials_t h, double *U, double *V);
 int mi355rec_ials_get_stats(mi355rec_ials_t h, mi355rec_stats *stats);
 void mi355rec_ials_destroy(mi355rec_ials_t h);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Scoring + ranking of factor models  (Base/BaseMatrixFactorizationRecommender.py:38
+ * _compute_item_score and the filter/rank half of Base/BaseRecommender.py:131 recommend)
+ * ---------------------------------------------------------------------------------------------------- */
+
+typedef struct mi355rec_scorer *mi355rec_scorer_t;
+
+/* U (n_users x k), V (n_items x k) float32 row-major; biases only read when use_bias; the "seen" CSR is URM_train
+ * (sorted or not), used by remove_seen. */
+int mi355rec_scorer_create(mi355rec_scorer_t *out, int32_t n_users, int32_t n_items, int32_t n_factors,
+                           const float *U, const float *V, int32_t use_bias, const float *user_bias, const float *item_bias,
+                           float global_bias, const int32_t *seen_indptr, const int32_t *seen_indices);
+/* New factor values of the same shapes (after more training epochs). */
+int mi355rec_scorer_update(mi355rec_scorer_t h, const float *U, const float *V, const float *user_bias, const float *item_bias,
+                           float global_bias);
+/* For every user of the batch: scores = U[u] . V^T (+ biases); items with item_allowed[j] == 0 (nullable mask) and, when
+ * remove_seen, the user's seen items become -inf; ranked[(row) * cutoff ...] = the cutoff best items in descending score
+ * order, -1 padded where fewer finite scores exist.  scores (nullable, n x n_items) receives the filtered score matrix. */
+int mi355rec_scorer_recommend(mi355rec_scorer_t h, const int32_t *user_ids, int32_t n, int32_t cutoff, int32_t remove_seen,
+                              const uint8_t *item_allowed, int32_t *ranked, float *scores);
+int mi355rec_scorer_get_stats(mi355rec_scorer_t h, mi355rec_stats *stats);
+void mi355rec_scorer_destroy(mi355rec_scorer_t h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,11 @@ SIGNATURES = {
     "mi355rec_ials_get_factors": (C.c_int, [_vp, _vp, _vp]),
     "mi355rec_ials_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "mi355rec_ials_destroy": (None, [_vp]),
+    "mi355rec_scorer_create": (C.c_int, [C.POINTER(_vp), _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _f32, _vp, _vp]),
+    "mi355rec_scorer_update": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32]),
+    "mi355rec_scorer_recommend": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mi355rec_scorer_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "mi355rec_scorer_destroy": (None, [_vp]),
 }
 
 _lib = None

@@ -1,0 +1,256 @@
+// score.hip -- matrix-factorisation scoring and top-cutoff ranking on MI355X (gfx950)  [SURVEY.md section 8(f) rank 1].
+//
+// Replaces, for factor models, BaseMatrixFactorizationRecommender._compute_item_score
+// (Base/BaseMatrixFactorizationRecommender.py:38-70: scores = USER_factors[users] . ITEM_factors^T (+ biases)) and the
+// filtering + ranking half of BaseRecommender.recommend (Base/BaseRecommender.py:131-222: seen / excluded items -> -inf,
+// the `cutoff` best items per user in descending score order, -inf items dropped) -- the step the reference's
+// EvaluatorHoldout runs on every validation (Base/Evaluation/Evaluator.py:436).
+//
+//   score_gemm_kernel  the one GEMM-shaped op next to the hot path: a 32-user x 128-item tile per workgroup, four
+//                      wavefronts each driving v_mfma_f32_32x32x2_f32 (exact f32: bitwise an fmaf chain, at the f32 vector
+//                      rate) over K in LDS-staged chunks of 64; biases added in the epilogue.
+//   score_rank_kernel  one workgroup per user: the score row is pulled into LDS, seen / excluded items are set to -inf,
+//                      the same in-LDS radix-select + bitonic-sort top-K as the similarity build emits the ranking.
+#include "common.h"
+#include "topk.cuh"
+
+#include <algorithm>
+#include <memory>
+
+namespace mi355rec {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int KC = 64;              // K chunk staged in LDS
+constexpr int LD = KC + 1;          // odd leading dimension: conflict-free column reads
+
+struct ScoreParams {
+    int n_users, n_items, k, use_bias;
+    const float *U, *V, *bu, *bi;
+    float mu;
+    const int *users;               // user id of every row of the batch
+    int n_batch;
+    float *scores;                  // [n_batch][n_items]
+};
+
+__global__ __launch_bounds__(256) void score_gemm_kernel(const ScoreParams p) {
+    __shared__ float As[32][LD];
+    __shared__ float Bs[128][LD];
+    __shared__ int s_user[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.y * 32, col0 = blockIdx.x * 128;
+    if (tid < 32) s_user[tid] = row0 + tid < p.n_batch ? p.users[row0 + tid] : -1;
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.k; k0 += KC) {
+        __syncthreads();
+        for (int e = tid; e < 32 * KC; e += 256) {
+            const int r = e / KC, f = e % KC;
+            const int u = s_user[r];
+            As[r][f] = (u >= 0 && k0 + f < p.k) ? p.U[(size_t)u * p.k + k0 + f] : 0.f;
+        }
+        for (int e = tid; e < 128 * KC; e += 256) {
+            const int r = e / KC, f = e % KC;
+            const int item = col0 + r;
+            Bs[r][f] = (item < p.n_items && k0 + f < p.k) ? p.V[(size_t)item * p.k + k0 + f] : 0.f;
+        }
+        __syncthreads();
+        const int kk = min(KC, p.k - k0);
+        // A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]   (32x32x2 f32 operand maps)
+        const float *a_row = &As[lane & 31][lane >> 5];
+        const float *b_row = &Bs[wave * 32 + (lane & 31)][lane >> 5];
+        for (int s = 0; s < kk; s += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_row[s], b_row[s], acc, 0, 0, 0);
+    }
+    // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int item = col0 + wave * 32 + (lane & 31);
+    if (item >= p.n_items) return;
+    const float item_term = p.use_bias ? p.bi[item] + p.mu : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int u = s_user[r];
+        if (u < 0) continue;
+        float v = acc[reg] + item_term;
+        if (p.use_bias) v += p.bu[u];
+        p.scores[(size_t)(row0 + r) * p.n_items + item] = v;
+    }
+}
+
+struct RankParams {
+    int n_items, n_pad, cutoff, sortP, remove_seen;
+    const int *users, *seen_ptr, *seen_idx;
+    const unsigned char *allowed;   // nullable: 0 marks an excluded item (items_to_compute / top-pop / custom filters)
+    float *scores;
+    int *ranked;
+    int write_back;                 // store the filtered row (return_scores=True)
+};
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void score_rank_kernel(const RankParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *acc = smem;
+    uint32_t *aux = reinterpret_cast<uint32_t *>(smem + p.n_pad);
+    __shared__ SelectScratch sc;
+    __shared__ uint32_t s_ncand, s_nfinite;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.x;
+    float *row = p.scores + (size_t)b * p.n_items;
+    if (tid == 0) { s_ncand = 0; s_nfinite = 0; }
+    for (int j = tid; j < p.n_items; j += THREADS) {
+        float v = row[j];
+        if (p.allowed && !p.allowed[j]) v = -INFINITY;
+        acc[j] = v;
+    }
+    __syncthreads();
+    if (p.remove_seen) {            // _remove_seen_on_scores (BaseRecommender.py:115-123)
+        const int u = p.users[b];
+        for (int q = p.seen_ptr[u] + tid; q < p.seen_ptr[u + 1]; q += THREADS) acc[p.seen_idx[q]] = -INFINITY;
+        __syncthreads();
+    }
+    uint32_t nfin = 0;
+    for (int j = tid; j < p.n_items; j += THREADS) {
+        const float v = acc[j];
+        nfin += v > -INFINITY;
+        if (p.write_back) row[j] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nfin += __shfl_down(nfin, off);
+    if (lane == 0 && nfin) atomicAdd(&s_nfinite, nfin);
+    __syncthreads();
+    block_topk_emit<THREADS>(acc, p.n_items, p.cutoff, p.sortP, s_nfinite, 0u, TOPK_FINITE, aux, sc, &s_ncand,
+                             p.ranked + (size_t)b * p.cutoff, nullptr);
+}
+
+}  // namespace
+}  // namespace mi355rec
+
+using namespace mi355rec;
+
+struct mi355rec_scorer {
+    int n_users = 0, n_items = 0, k = 0, use_bias = 0;
+    float mu = 0.f;
+    hipStream_t stream = nullptr;
+    StreamTimer gemm_timer, call_timer;
+    DeviceBuffer<float> U, V, bu, bi, scores;
+    DeviceBuffer<int> seen_ptr, seen_idx, users, ranked;
+    DeviceBuffer<unsigned char> allowed;
+    mi355rec_stats stats{};
+};
+
+namespace {
+void upload_model(mi355rec_scorer *h, const float *U, const float *V, const float *bu, const float *bi, float mu) {
+    hipStream_t s = h->stream;
+    MI_HIP(hipMemcpyAsync(h->U.ptr, U, sizeof(float) * (size_t)h->n_users * h->k, hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(h->V.ptr, V, sizeof(float) * (size_t)h->n_items * h->k, hipMemcpyHostToDevice, s));
+    if (h->use_bias) {
+        MI_REQUIRE(bu && bi, "use_bias is set but the bias vectors are NULL");
+        MI_HIP(hipMemcpyAsync(h->bu.ptr, bu, sizeof(float) * h->n_users, hipMemcpyHostToDevice, s));
+        MI_HIP(hipMemcpyAsync(h->bi.ptr, bi, sizeof(float) * h->n_items, hipMemcpyHostToDevice, s));
+        h->mu = mu;
+    }
+    MI_HIP(hipStreamSynchronize(s));
+}
+}  // namespace
+
+extern "C" int mi355rec_scorer_create(mi355rec_scorer_t *out, int32_t n_users, int32_t n_items, int32_t n_factors,
+                                      const float *U, const float *V, int32_t use_bias, const float *user_bias,
+                                      const float *item_bias, float global_bias, const int32_t *seen_indptr,
+                                      const int32_t *seen_indices) {
+    return guarded([&] {
+        MI_REQUIRE(out && U && V && seen_indptr && seen_indices, "NULL argument");
+        MI_REQUIRE(n_users > 0 && n_items > 0 && n_factors > 0, "empty model");
+        ensure_device();
+        const size_t lds = ((size_t)((n_items + 3) & ~3)) * 4 + (size_t)AUX_WORDS * 4 + 2048;
+        if (lds > 160 * 1024)
+            fail(MI355REC_E_UNSUPPORTED, "n_items = %d: a score row does not fit the 160 KiB LDS of the ranking kernel", n_items);
+        std::unique_ptr<mi355rec_scorer> h(new mi355rec_scorer());
+        h->n_users = n_users; h->n_items = n_items; h->k = n_factors; h->use_bias = use_bias != 0;
+        MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->gemm_timer.init();
+        h->call_timer.init();
+        h->U.alloc((size_t)n_users * n_factors);
+        h->V.alloc((size_t)n_items * n_factors);
+        if (h->use_bias) { h->bu.alloc(n_users); h->bi.alloc(n_items); }
+        h->seen_ptr.upload(seen_indptr, (size_t)n_users + 1, h->stream);
+        h->seen_idx.upload(seen_indices, (size_t)seen_indptr[n_users], h->stream);
+        h->allowed.alloc(n_items);
+        upload_model(h.get(), U, V, user_bias, item_bias, global_bias);
+        *out = h.release();
+    });
+}
+
+extern "C" int mi355rec_scorer_update(mi355rec_scorer_t h, const float *U, const float *V, const float *user_bias,
+                                      const float *item_bias, float global_bias) {
+    return guarded([&] {
+        MI_REQUIRE(h && U && V, "NULL argument");
+        ensure_device();
+        upload_model(h, U, V, user_bias, item_bias, global_bias);
+    });
+}
+
+extern "C" int mi355rec_scorer_recommend(mi355rec_scorer_t h, const int32_t *user_ids, int32_t n, int32_t cutoff,
+                                         int32_t remove_seen, const uint8_t *item_allowed, int32_t *ranked, float *scores) {
+    return guarded([&] {
+        MI_REQUIRE(h && user_ids && ranked, "NULL argument");
+        MI_REQUIRE(n > 0, "empty user batch");
+        MI_REQUIRE(cutoff >= 1 && cutoff <= h->n_items, "cutoff must be in [1, n_items]");
+        if (cutoff > MAX_TOPK) fail(MI355REC_E_UNSUPPORTED, "cutoff = %d exceeds the in-LDS selection limit of %d", cutoff, MAX_TOPK);
+        for (int i = 0; i < n; ++i)
+            MI_REQUIRE(user_ids[i] >= 0 && user_ids[i] < h->n_users, "Cold users not allowed. Users in trained model are %d, "
+                       "requested prediction for user %d", h->n_users, user_ids[i]);
+        ensure_device();
+        hipStream_t s = h->stream;
+        if (h->users.count < (size_t)n) h->users.alloc(n);
+        if (h->ranked.count < (size_t)n * cutoff) h->ranked.alloc((size_t)n * cutoff);
+        if (h->scores.count < (size_t)n * h->n_items) h->scores.alloc((size_t)n * h->n_items);
+        MI_HIP(hipMemcpyAsync(h->users.ptr, user_ids, sizeof(int) * n, hipMemcpyHostToDevice, s));
+        if (item_allowed) MI_HIP(hipMemcpyAsync(h->allowed.ptr, item_allowed, h->n_items, hipMemcpyHostToDevice, s));
+        h->call_timer.start(s);
+        ScoreParams sp{};
+        sp.n_users = h->n_users; sp.n_items = h->n_items; sp.k = h->k; sp.use_bias = h->use_bias;
+        sp.U = h->U.ptr; sp.V = h->V.ptr; sp.bu = h->bu.ptr; sp.bi = h->bi.ptr; sp.mu = h->mu;
+        sp.users = h->users.ptr; sp.n_batch = n; sp.scores = h->scores.ptr;
+        hipExtLaunchKernelGGL(score_gemm_kernel, dim3(div_up(h->n_items, 128), div_up(n, 32)), dim3(256), 0, s, h->gemm_timer.t0,
+                              h->gemm_timer.t1, 0, sp);
+        RankParams rp{};
+        rp.n_items = h->n_items; rp.n_pad = (h->n_items + 3) & ~3; rp.cutoff = cutoff;
+        int P = 1;
+        while (P < std::max(2, cutoff)) P <<= 1;
+        rp.sortP = P; rp.remove_seen = remove_seen;
+        rp.users = h->users.ptr; rp.seen_ptr = h->seen_ptr.ptr; rp.seen_idx = h->seen_idx.ptr;
+        rp.allowed = item_allowed ? h->allowed.ptr : nullptr;
+        rp.scores = h->scores.ptr; rp.ranked = h->ranked.ptr; rp.write_back = scores != nullptr;
+        const size_t lds = (size_t)rp.n_pad * 4 + (size_t)AUX_WORDS * 4;
+        auto k = score_rank_kernel<1024>;
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3(n), dim3(1024), lds, s, rp);
+        MI_HIP(hipGetLastError());
+        h->call_timer.stop(s);
+        h->ranked.download(ranked, (size_t)n * cutoff, s);
+        if (scores) h->scores.download(scores, (size_t)n * h->n_items, s);
+        MI_HIP(hipStreamSynchronize(s));
+        h->stats = mi355rec_stats{};
+        h->stats.call_ms = h->call_timer.elapsed_ms();
+        h->stats.kernel_ms = h->gemm_timer.elapsed_ms();
+        h->stats.n_launches = 1;
+        h->stats.n_timed = 1;
+        h->stats.n_units = n;
+        h->stats.algorithmic_flops = 2.0 * (double)n * h->n_items * h->k;
+        h->stats.algorithmic_bytes = 4.0 * ((double)n * h->k + (double)h->n_items * h->k + (double)n * h->n_items);
+    });
+}
+
+extern "C" int mi355rec_scorer_get_stats(mi355rec_scorer_t h, mi355rec_stats *stats) {
+    return guarded([&] {
+        MI_REQUIRE(h && stats, "NULL argument");
+        *stats = h->stats;
+    });
+}
+
+extern "C" void mi355rec_scorer_destroy(mi355rec_scorer_t h) {
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->gemm_timer.destroy();
+    h->call_timer.destroy();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         // ---- top-K: the K largest cells of the FULL column (zeros compete, then are dropped), value-descending,
         //      emitted like the COO triples of .pyx:550-562 with -1 padding ----
         const size_t base = (size_t)(c - p.start_col) * p.topK;
-        block_topk_emit<THREADS>(acc, p.n_cols, p.topK, p.sortP, npos, nneg, /*zeros_compete=*/true, aux, sc, &s_ncand,
+        block_topk_emit<THREADS>(acc, p.n_cols, p.topK, p.sortP, npos, nneg, TOPK_ZEROS_COMPETE, aux, sc, &s_ncand,
                                  p.out_idx + base, p.out_val + base);
         __syncthreads();
     }

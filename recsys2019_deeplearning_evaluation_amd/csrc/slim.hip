@@ -196,7 +196,7 @@ __global__ __launch_bounds__(THREADS) void slim_topk_kernel(const SlimParams p, 
         __syncthreads();
         // symmetric store: Triangular_Matrix.get_scipy_csr ranks the FULL row (zeros compete, :1384-1404);
         // dense store: similarityMatrixTopK ranks the non-zero cells only (Base/Recommender_utils.py:100-104)
-        block_topk_emit<THREADS>(acc, p.n_items, topK, sortP, s_npos, s_nneg, p.symmetric != 0, aux, sc, &s_ncand,
+        block_topk_emit<THREADS>(acc, p.n_items, topK, sortP, s_npos, s_nneg, p.symmetric ? TOPK_ZEROS_COMPETE : TOPK_NONZERO, aux, sc, &s_ncand,
                                  out_idx + (size_t)r * topK, out_val + (size_t)r * topK);
         __syncthreads();
     }

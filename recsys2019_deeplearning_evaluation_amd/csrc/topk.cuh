@@ -103,32 +103,41 @@ __device__ void bitonic_sort_desc(uint64_t *a, int P) {
 }
 
 
+// Which cells take part in a top-K.
+//   TOPK_ZEROS_COMPETE : the K largest cells of the whole array are taken, zeros included, and zeros are then dropped
+//                        (Compute_Similarity_Cython.pyx:523-555, Triangular_Matrix.get_scipy_csr :1384-1404)
+//   TOPK_NONZERO       : only non-zero cells compete (similarityMatrixTopK, Base/Recommender_utils.py:100-104)
+//   TOPK_FINITE        : every cell except -inf competes and nothing is dropped (BaseRecommender.recommend :182-205,
+//                        where -inf marks excluded items)
+enum { TOPK_ZEROS_COMPETE = 0, TOPK_NONZERO = 1, TOPK_FINITE = 2 };
+
 // Top-K of the n floats in LDS array `acc` (K = topK <= sortP, sortP a power of two, sortP * 8 B <= AUX_WORDS * 4 B).
-//   npos / nneg     : number of strictly positive / negative cells (block-uniform, counted by the caller)
-//   zeros_compete   : true  -> the K largest cells of the whole array are taken, zeros included, and zeros are then
-//                              dropped (Compute_Similarity_Cython.pyx:523-555, Triangular_Matrix.get_scipy_csr :1384-1404);
-//                     false -> only non-zero cells compete (similarityMatrixTopK, Base/Recommender_utils.py:100-104)
+//   npos / nneg     : TOPK_ZEROS_COMPETE / TOPK_NONZERO: number of strictly positive / negative cells;
+//                     TOPK_FINITE: npos = number of cells > -inf, nneg = 0          (block-uniform, counted by the caller)
 //   *ncand          : shared counter, must be 0 on entry
-// Output: out_idx / out_val [topK], value-descending, ties broken towards the lower index, (-1, 0) padded.
+// Output: out_idx / out_val [topK] (out_val may be null), value-descending, ties broken towards the lower index,
+// (-1, 0) padded.
 template <int THREADS>
-__device__ void block_topk_emit(const float *acc, int n, int topK, int sortP, uint32_t npos, uint32_t nneg, bool zeros_compete,
+__device__ void block_topk_emit(const float *acc, int n, int topK, int sortP, uint32_t npos, uint32_t nneg, int mode,
                                 uint32_t *aux, SelectScratch &sc, uint32_t *ncand_shared, int *out_idx, float *out_val) {
     const int tid = threadIdx.x;
+    const bool zeros_compete = mode == TOPK_ZEROS_COMPETE;
     const uint32_t nzero = zeros_compete ? (uint32_t)n - npos - nneg : 0u;
     uint32_t K = (uint32_t)topK;
     if (!zeros_compete) K = min(K, npos + nneg);
     uint32_t T = ZERO_KEY, need_eq = 0, eq_total = 0;
     // all positives fit and no negative can displace a zero: nothing to select
     bool take_all = zeros_compete ? (npos <= K && (nneg == 0 || npos + nzero >= K)) : (npos + nneg <= K);
-    if (!zeros_compete && take_all) T = 0u;                      // every non-zero key is > 0
+    if (!zeros_compete && take_all) T = 0u;                      // every candidate key is > 0
+    auto candidate = [&](float v) { return mode == TOPK_FINITE ? v > -INFINITY : v != 0.f; };
     auto value_key = [&](int j, uint32_t &key) {
         const float v = acc[j];
         key = float_key(v);
-        return v != 0.f;
+        return candidate(v);
     };
     if (!take_all) {
         block_select<THREADS>(value_key, n, K, ZERO_KEY, nzero, aux, sc, T, need_eq, eq_total);
-        if (T == ZERO_KEY) need_eq = 0;                           // zeros are never emitted
+        if (zeros_compete && T == ZERO_KEY) need_eq = 0;          // zeros are never emitted
     }
     uint32_t T2 = 0;  // tie-break on the index when more cells equal T than fit: lowest index wins
     const bool partial_ties = need_eq > 0 && need_eq < eq_total;
@@ -137,7 +146,7 @@ __device__ void block_topk_emit(const float *acc, int n, int topK, int sortP, ui
         auto index_key = [&](int j, uint32_t &key) {
             const float v = acc[j];
             key = ~(uint32_t)j;
-            return v != 0.f && float_key(v) == T;
+            return candidate(v) && float_key(v) == T;
         };
         block_select<THREADS>(index_key, n, need_eq, 0u, 0u, aux, sc, T2, dummy_need, dummy_tot);
     }
@@ -145,7 +154,7 @@ __device__ void block_topk_emit(const float *acc, int n, int topK, int sortP, ui
     uint64_t *cand = reinterpret_cast<uint64_t *>(aux);
     for (int j = tid; j < n; j += THREADS) {
         const float v = acc[j];
-        if (v == 0.f) continue;
+        if (!candidate(v)) continue;
         const uint32_t key = float_key(v);
         const bool take = key > T || (need_eq > 0 && key == T && (!partial_ties || ~(uint32_t)j >= T2));
         if (take) {
@@ -167,7 +176,7 @@ __device__ void block_topk_emit(const float *acc, int n, int topK, int sortP, ui
             val = key_float((uint32_t)(e >> 32));
         }
         out_idx[t] = idx;
-        out_val[t] = val;
+        if (out_val) out_val[t] = val;
     }
 }
 

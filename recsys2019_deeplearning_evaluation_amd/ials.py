@@ -12,6 +12,7 @@ import numpy as np
 
 from . import _native as N
 from .recommender_base import (BaseMatrixFactorizationRecommender, Incremental_Training_Early_Stopping, check_matrix)
+from .scoring import GpuScoringMixin
 
 
 class IALS_MI355X_Epoch:
@@ -72,7 +73,7 @@ class IALS_MI355X_Epoch:
         return st.as_dict()
 
 
-class IALSRecommender(BaseMatrixFactorizationRecommender, Incremental_Training_Early_Stopping):
+class IALSRecommender(GpuScoringMixin, BaseMatrixFactorizationRecommender, Incremental_Training_Early_Stopping):
     """Drop-in for the reference IALSRecommender with _run_epoch on the GPU."""
     RECOMMENDER_NAME = "IALSRecommender"
     AVAILABLE_CONFIDENCE_SCALING = ["linear", "log"]

@@ -19,6 +19,7 @@ import numpy as np
 from . import _native as N
 from .recommender_base import (BaseMatrixFactorizationRecommender, Incremental_Training_Early_Stopping,
                                check_matrix)
+from .scoring import GpuScoringMixin
 
 
 class MatrixFactorization_MI355X_Epoch:
@@ -143,7 +144,7 @@ class MatrixFactorization_MI355X_Epoch:
         return np.array(self._download(True)[4][0])
 
 
-class _MatrixFactorization_MI355X(BaseMatrixFactorizationRecommender, Incremental_Training_Early_Stopping):
+class _MatrixFactorization_MI355X(GpuScoringMixin, BaseMatrixFactorizationRecommender, Incremental_Training_Early_Stopping):
     RECOMMENDER_NAME = "MatrixFactorization_MI355X_Recommender"
 
     def __init__(self, URM_train, verbose=True, algorithm_name="MF_BPR"):

@@ -1,0 +1,112 @@
+"""Device scoring + ranking for factor models.
+
+`MI355XScorer` keeps USER/ITEM factors (and biases) plus the "seen" CSR in HBM and answers the two questions the
+reference's evaluation loop asks on every validation (Base/Evaluation/Evaluator.py:436):
+  scores  = BaseMatrixFactorizationRecommender._compute_item_score   (BaseMatrixFactorizationRecommender.py:38-70)
+  ranking = the filter + top-cutoff half of BaseRecommender.recommend (BaseRecommender.py:131-222)
+`GpuScoringMixin` plugs it under `recommend()` of a BaseMatrixFactorizationRecommender without changing its signature;
+`_compute_item_score` itself is left untouched (host NumPy), so either path can be checked against the other.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class MI355XScorer:
+    def __init__(self, USER_factors, ITEM_factors, URM_seen, USER_bias=None, ITEM_bias=None, GLOBAL_bias=0.0):
+        U, V = N.as_f32(USER_factors), N.as_f32(ITEM_factors)
+        assert U.shape[1] == V.shape[1], "User and Item factors have inconsistent shape"
+        self.n_users, self.n_items, self.n_factors = U.shape[0], V.shape[0], U.shape[1]
+        self.use_bias = USER_bias is not None
+        seen = URM_seen.tocsr()
+        assert seen.shape == (self.n_users, self.n_items)
+        indptr, indices = N.as_i32(seen.indptr), N.as_i32(seen.indices)
+        bu = N.as_f32(USER_bias) if self.use_bias else None
+        bi = N.as_f32(ITEM_bias) if self.use_bias else None
+        self._lib = N.load()
+        self._h = C.c_void_p()
+        N.check(self._lib.mi355rec_scorer_create(C.byref(self._h), self.n_users, self.n_items, self.n_factors, N.ptr(U), N.ptr(V),
+                                                 int(self.use_bias), N.ptr(bu), N.ptr(bi), float(np.asarray(GLOBAL_bias)),
+                                                 N.ptr(indptr), N.ptr(indices)))
+
+    def update(self, USER_factors, ITEM_factors, USER_bias=None, ITEM_bias=None, GLOBAL_bias=0.0):
+        U, V = N.as_f32(USER_factors), N.as_f32(ITEM_factors)
+        assert U.shape == (self.n_users, self.n_factors) and V.shape == (self.n_items, self.n_factors)
+        bu = N.as_f32(USER_bias) if self.use_bias else None
+        bi = N.as_f32(ITEM_bias) if self.use_bias else None
+        N.check(self._lib.mi355rec_scorer_update(self._h, N.ptr(U), N.ptr(V), N.ptr(bu), N.ptr(bi), float(np.asarray(GLOBAL_bias))))
+
+    def recommend(self, user_id_array, cutoff, remove_seen=True, allowed_items=None, return_scores=False):
+        """ranked: int32 (n, cutoff) with -1 padding; scores: float32 (n, n_items) with -inf for filtered items."""
+        users = N.as_i32(np.atleast_1d(user_id_array))
+        cutoff = int(min(cutoff, self.n_items))
+        ranked = np.empty((len(users), cutoff), np.int32)
+        scores = np.empty((len(users), self.n_items), np.float32) if return_scores else None
+        mask = None if allowed_items is None else np.ascontiguousarray(allowed_items, dtype=np.uint8)
+        N.check(self._lib.mi355rec_scorer_recommend(self._h, N.ptr(users), len(users), cutoff, int(bool(remove_seen)),
+                                                    N.ptr(mask), N.ptr(ranked), N.ptr(scores)))
+        return ranked, scores
+
+    def stats(self):
+        st = N.Stats()
+        N.check(self._lib.mi355rec_scorer_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi355rec_scorer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GpuScoringMixin:
+    """recommend() of BaseRecommender (same signature, same return values) served by MI355XScorer.  The scorer is
+    (re)built lazily from the host attributes USER_factors / ITEM_factors[/biases], so it follows early-stopping's
+    _prepare_model_for_validation / best-model swaps automatically."""
+    _scorer = None
+    _scorer_key = None
+
+    def _get_scorer(self):
+        key = (id(self.USER_factors), id(self.ITEM_factors), bool(self.use_bias))
+        if self._scorer is None or self._scorer.use_bias != bool(self.use_bias):
+            if self._scorer is not None:
+                self._scorer.close()
+            bias = dict(USER_bias=self.USER_bias, ITEM_bias=self.ITEM_bias, GLOBAL_bias=self.GLOBAL_bias) if self.use_bias else {}
+            self._scorer = MI355XScorer(self.USER_factors, self.ITEM_factors, self.URM_train, **bias)
+        elif key != self._scorer_key:
+            bias = dict(USER_bias=self.USER_bias, ITEM_bias=self.ITEM_bias, GLOBAL_bias=self.GLOBAL_bias) if self.use_bias else {}
+            self._scorer.update(self.USER_factors, self.ITEM_factors, **bias)
+        self._scorer_key = key
+        return self._scorer
+
+    def recommend(self, user_id_array, cutoff=None, remove_seen_flag=True, items_to_compute=None, remove_top_pop_flag=False,
+                  remove_custom_items_flag=False, return_scores=False):
+        single_user = np.isscalar(user_id_array)
+        users = np.atleast_1d(user_id_array)
+        if cutoff is None:
+            cutoff = self.URM_train.shape[1] - 1
+        allowed = None
+        if items_to_compute is not None or remove_top_pop_flag or remove_custom_items_flag:
+            allowed = np.zeros(self.n_items, np.uint8) if items_to_compute is not None else np.ones(self.n_items, np.uint8)
+            if items_to_compute is not None:
+                allowed[np.asarray(items_to_compute)] = 1
+            if remove_top_pop_flag:
+                allowed[self.filterTopPop_ItemsID] = 0
+            if remove_custom_items_flag:
+                allowed[self.items_to_ignore_ID] = 0
+        scorer = self._get_scorer()
+        assert scorer.n_users > np.max(users), \
+            "{}: Cold users not allowed. Users in trained model are {}, requested prediction for users up to {}".format(
+                self.RECOMMENDER_NAME, scorer.n_users, np.max(users))
+        ranked, scores = scorer.recommend(users, cutoff, remove_seen_flag, allowed, return_scores)
+        ranking_list = [row[row >= 0].tolist() for row in ranked]
+        if single_user:
+            ranking_list = ranking_list[0]
+        return (ranking_list, scores) if return_scores else ranking_list

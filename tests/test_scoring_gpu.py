@@ -1,0 +1,99 @@
+"""Device scoring + ranking against the host formulas of the reference
+(BaseMatrixFactorizationRecommender._compute_item_score + BaseRecommender.recommend, re-provided in recommender_base)."""
+import numpy as np
+import pytest
+
+from recsys2019_deeplearning_evaluation_amd import MI355XScorer, MatrixFactorization_BPR_MI355X
+from recsys2019_deeplearning_evaluation_amd import recommender_base as RB
+from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_reference(X, U, V, users, bias=None, allowed=None, remove_seen=True):
+    scores = U[users].astype(np.float64) @ V.T.astype(np.float64)
+    if bias is not None:
+        bu, bi, mu = bias
+        scores = scores + bi + mu + bu[users][:, None]
+    if allowed is not None:
+        scores[:, ~allowed.astype(bool)] = -np.inf
+    if remove_seen:
+        for r, u in enumerate(users):
+            scores[r, X.indices[X.indptr[u]:X.indptr[u + 1]]] = -np.inf
+    return scores
+
+
+def _check_ranking(ranked_row, score_row, cutoff, tol):
+    got = ranked_row[ranked_row >= 0]
+    finite = np.isfinite(score_row)
+    k = min(cutoff, int(finite.sum()))
+    assert len(got) == k and len(set(got.tolist())) == k
+    if k == 0:
+        return
+    order = np.sort(score_row[finite])[::-1]
+    t = order[k - 1]
+    assert np.isfinite(score_row[got]).all()
+    assert (score_row[got] >= t - tol).all()                       # nothing clearly below the k-th score
+    assert np.isin(np.flatnonzero(score_row > t + tol), got).all()   # everything clearly above it is there
+    assert (np.diff(score_row[got]) <= tol).all()                  # descending
+
+
+@pytest.mark.parametrize("k", [1, 7, 64, 128, 200])
+@pytest.mark.parametrize("use_bias", [False, True])
+def test_scores_and_ranking_match_host(gpu, k, use_bias):
+    X = named_urm("ml1m", "binary", scale=0.3)
+    rng = np.random.default_rng(k)
+    U = rng.normal(0, 0.3, (X.shape[0], k)).astype(np.float32); V = rng.normal(0, 0.3, (X.shape[1], k)).astype(np.float32)
+    bias = (rng.normal(size=X.shape[0]).astype(np.float32), rng.normal(size=X.shape[1]).astype(np.float32), 0.7) if use_bias else None
+    sc = MI355XScorer(U, V, X, *(bias if bias else ()))
+    users = rng.choice(X.shape[0], 333, replace=False)
+    ranked, scores = sc.recommend(users, 25, remove_seen=True, return_scores=True)
+    want = _host_reference(X, U, V, users, bias)
+    scale = np.abs(want[np.isfinite(want)]).max()
+    assert (np.isfinite(scores) == np.isfinite(want)).all()
+    assert np.abs(scores[np.isfinite(want)] - want[np.isfinite(want)]).max() < 1e-5 * scale
+    for r in range(len(users)):
+        _check_ranking(ranked[r], want[r], 25, 1e-5 * scale)
+    st = sc.stats()
+    assert st["algorithmic_flops"] == 2.0 * len(users) * X.shape[1] * k
+    sc.close()
+
+
+def test_filters_cutoffs_and_edge_cases(gpu):
+    X = named_urm("ml1m", "binary", scale=0.2)
+    rng = np.random.default_rng(0)
+    U = rng.normal(size=(X.shape[0], 16)).astype(np.float32); V = rng.normal(size=(X.shape[1], 16)).astype(np.float32)
+    sc = MI355XScorer(U, V, X)
+    users = np.arange(40)
+    allowed = np.zeros(X.shape[1], np.uint8); allowed[rng.choice(X.shape[1], 30, replace=False)] = 1
+    for cutoff in (1, 30, 31, 200, X.shape[1]):
+        for remove_seen in (False, True):
+            ranked, _ = sc.recommend(users, cutoff, remove_seen=remove_seen, allowed_items=allowed)
+            want = _host_reference(X, U, V, users, None, allowed, remove_seen)
+            for r in range(len(users)):
+                _check_ranking(ranked[r], want[r], min(cutoff, X.shape[1]), 1e-5 * 10)
+    U2 = U * 2
+    sc.update(U2, V)
+    _, s2 = sc.recommend(users, 5, remove_seen=False, return_scores=True)
+    np.testing.assert_allclose(s2, (U2[users].astype(np.float64) @ V.T.astype(np.float64)), rtol=1e-5, atol=1e-4)
+    with pytest.raises(ValueError):
+        sc.recommend(np.array([X.shape[0]]), 5)
+    sc.close()
+
+
+def test_recommender_recommend_is_served_by_the_device_and_equals_the_host_path(gpu):
+    X = named_urm("ml1m", "binary", scale=0.15)
+    rec = MatrixFactorization_BPR_MI355X(X, verbose=False)
+    rec.fit(epochs=5, batch_size=200, num_factors=24, learning_rate=0.05, sgd_mode="adagrad", random_seed=3)
+    users = np.arange(60)
+    dev_lists, dev_scores = rec.recommend(users, cutoff=10, return_scores=True)
+    host_lists, host_scores = RB.BaseRecommender.recommend(rec, users, cutoff=10, return_scores=True)
+    assert rec._scorer is not None and rec._scorer.stats()["n_units"] == 60
+    fin = np.isfinite(host_scores)
+    assert (np.isfinite(dev_scores) == fin).all()
+    assert np.abs(dev_scores[fin] - host_scores[fin]).max() < 1e-5 * np.abs(host_scores[fin]).max()
+    agree = np.mean([a == b for a, b in zip(dev_lists, host_lists)])
+    assert agree > 0.9                                     # identical except where two scores are within float32 noise
+    assert rec.recommend(3, cutoff=4) == dev_lists[3][:4]
+    rec.set_items_to_ignore([0, 1, 2])
+    assert not {0, 1, 2} & set(rec.recommend(5, cutoff=20, remove_custom_items_flag=True))

@@ -123,7 +123,7 @@ def test_baseline_config_3_ml20m_shape_properties(gpu):
     n = X.shape[1]
     assert idx.shape == (n, 100)
     valid = idx >= 0
-    assert (val[valid] != 0).all() and (np.diff(np.where(valid, val, -np.inf), axis=1) <= 0).all()
+    assert (val[valid] != 0).all() and (np.diff(np.where(valid, val, -1e30), axis=1) <= 0).all()
     assert (idx != np.arange(n)[:, None]).all()
     touched_rows = valid.any(axis=1).sum()
     assert 0.2 * n < touched_rows <= n                                        # ~139k steps over 26.7k item rows
