@@ -182,6 +182,31 @@ def other_paths(urm):
             "samples_per_s": st["n_units"] / sec, "algorithmic_GBps": st["algorithmic_bytes"] / sec / 1e9,
             "launches_per_epoch": st["n_launches"] / 2, "seconds_per_epoch": sec / 2, "get_S_topk_s": time.perf_counter() - t0}
         sl.close()
+    # scoring + ranking of 1000 users (the Evaluator's block size, Base/Evaluation/Evaluator.py:406-408), k = 128
+    from recsys2019_deeplearning_evaluation_amd import MI355XScorer
+    rng = np.random.default_rng(0)
+    Uf = rng.normal(0, 0.1, (urm.shape[0], K_FACTORS)).astype(np.float32)
+    Vf = rng.normal(0, 0.1, (urm.shape[1], K_FACTORS)).astype(np.float32)
+    sc = MI355XScorer(Uf, Vf, urm)
+    users = rng.choice(urm.shape[0], 1000, replace=False).astype(np.int32)
+    sc.recommend(users, 20)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        sc.recommend(users, 20)
+    wall = (time.perf_counter() - t0) / 5
+    st = sc.stats()
+    t0 = time.perf_counter()                        # the reference's host path for the same block (NumPy, all host cores via BLAS)
+    host = Uf[users] @ Vf.T
+    for r, u in enumerate(users):
+        host[r, urm.indices[urm.indptr[u]:urm.indptr[u + 1]]] = -np.inf
+    part = (-host).argpartition(20, axis=1)[:, :20]
+    np.argsort(-host[np.arange(1000)[:, None], part], axis=1)
+    host_wall = time.perf_counter() - t0
+    out["mf_scoring_1000_users_cutoff20"] = {"users_per_s": 1000 / wall, "device_ms": st["call_ms"], "gemm_ms": st["kernel_ms"],
+                                             "gemm_f32_TFLOPs": st["algorithmic_flops"] / (st["kernel_ms"] * 1e-3) / 1e12,
+                                             "frac_of_f32_mfma_peak_157TF": st["algorithmic_flops"] / (st["kernel_ms"] * 1e-3) / 1e12 / 157.3,
+                                             "host_numpy_users_per_s": 1000 / host_wall}
+    sc.close()
     k = 200
     conf = urm.copy()
     conf.data = (1.0 + 1.0 * conf.data).astype(np.float32)
