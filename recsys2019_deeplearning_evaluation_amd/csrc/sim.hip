@@ -21,13 +21,19 @@
 namespace mi355rec {
 namespace {
 
+constexpr int MAX_TILE = 32256;   // cells of the LDS accumulator: 4 B * 32256 + 32 KiB selection scratch + statics <= 160 KiB
+
 struct SimParams {
     int n_rows, n_cols, n_cols_pad;
     int topK, sortP;
     int kind, normalize;
     float shrink, tversky_alpha, tversky_beta;
     const int *csr_ptr;
-    const unsigned short *csr_idx16;   // column ids as uint16 (n_cols < 65536 on this path), padded by 8
+    const unsigned short *csr_idx16;   // column ids relative to their tile base, as uint16 (tile width <= 32256)
+    int tile_w, n_tiles;               // accumulator tile width and count (1 when n_cols fits the LDS)
+    const int *row_tile_ptr;           // n_tiles > 1: [n_rows][n_tiles + 1] positions where a CSR row crosses tile bounds
+    int *cand_idx;                     // n_tiles > 1: per-workgroup scratch [n_tiles * topK] of per-tile candidates
+    float *cand_val;
     const float *csr_val;              // padded by 8
     const int *csc_ptr, *csc_idx;
     const float *csc_val;
@@ -70,16 +76,28 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
     const int gl = tid % G;
 
     for (;;) {
-        if (tid == 0) {
-            s_col = (int)atomicAdd(p.queue, 1u);
-            s_npos = 0;
-            s_nneg = 0;
-            s_ncand = 0;
-        }
+        if (tid == 0) s_col = (int)atomicAdd(p.queue, 1u);
         __syncthreads();
         const int slot = s_col;
         if (slot >= p.n_local) break;
         const int c = p.order[slot];
+        const int cbeg = p.csc_ptr[c], cend = p.csc_ptr[c + 1];
+        const size_t out_base = (size_t)(c - p.start_col) * p.topK;
+        int *wg_cand_idx = p.cand_idx + (size_t)blockIdx.x * p.n_tiles * p.topK;
+        float *wg_cand_val = p.cand_val + (size_t)blockIdx.x * p.n_tiles * p.topK;
+        long long total_nonzero = 0;
+
+        // Columns wider than the LDS accumulator are processed in tiles of tile_w neighbour ids: every CSR entry
+        // belongs to exactly one tile (ids are stored tile-relative and row_tile_ptr marks the crossings), so the
+        // tiles together read each profile once.  n_tiles == 1 is the common case.
+        for (int tile = 0; tile < p.n_tiles; ++tile) {
+        const int tile_base = tile * p.tile_w;
+        const int n_tile = min(p.tile_w, p.n_cols - tile_base);
+        if (tid == 0) {
+            s_npos = 0;
+            s_nneg = 0;
+            s_ncand = 0;
+        }
 
         // ---- clear this_item_weights (.pyx:365-370) ----
         {
@@ -95,7 +113,6 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         // ids (aligned; the first chunk may start before the row, the last may run past it: both masked), two
         // chunks in flight.  UNIT data accumulates integer counts (ds_add_u32 runs ~3x faster than ds_add_f32 on
         // gfx950 and is exact); otherwise float products.
-        const int cbeg = p.csc_ptr[c], cend = p.csc_ptr[c + 1];
         constexpr int WAVES = THREADS / 64, GPW = 64 / G;
         const int wave = tid >> 6, sub = lane / G;
         unsigned *acc_u = reinterpret_cast<unsigned *>(acc);
@@ -107,7 +124,17 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             const int u = valid ? p.csc_idx[q] : 0;
             float r = valid ? (UNIT ? 1.f : p.csc_val[q]) : 0.f;
             if (!UNIT && p.row_w && valid) r *= p.row_w[u];
-            const int rs = valid ? p.csr_ptr[u] : 0, re = valid ? p.csr_ptr[u + 1] : 0;
+            int rs = 0, re = 0;
+            if (valid) {
+                if (p.n_tiles == 1) {
+                    rs = p.csr_ptr[u];
+                    re = p.csr_ptr[u + 1];
+                } else {
+                    const int *tp = p.row_tile_ptr + (size_t)u * (p.n_tiles + 1) + tile;
+                    rs = tp[0];
+                    re = tp[1];
+                }
+            }
             const int n_here = min(64, cend - base);
             // Flat, software-pipelined walk over the 16-byte chunks of this group's profiles: the load of chunk
             // n+1 is issued before chunk n is accumulated.  Control flow is uniform inside a group; lanes whose
@@ -169,16 +196,15 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         }
         // the diagonal was accumulated like any other cell: clear it (the reference never adds to it, .pyx:392)
         __syncthreads();
-        if (tid == 0) acc[c] = 0.f;
-        __syncthreads();
+        if (tid == 0 && c >= tile_base && c < tile_base + n_tile) acc[c - tile_base] = 0.f;
         __syncthreads();
 
         // ---- normalisation (.pyx:473-504), in place; count signs for the selection ----
         uint32_t npos = 0, nneg = 0;
-        for (int j = tid; j < p.n_cols; j += THREADS) {
+        for (int j = tid; j < n_tile; j += THREADS) {
             float v = UNIT ? (float)acc_u[j] : acc[j];
             if (v != 0.f) {
-                v = normalise(p, v, c, j);
+                v = normalise(p, v, c, tile_base + j);
                 acc[j] = v;
                 npos += v > 0.f;
                 nneg += v < 0.f;
@@ -186,8 +212,8 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         }
         if (p.topK == 0) {  // dense output (.pyx:507-510)
             __syncthreads();
-            float *dst = p.out_dense + (size_t)(c - p.start_col) * p.n_cols;
-            for (int j = tid; j < p.n_cols; j += THREADS) dst[j] = acc[j];
+            float *dst = p.out_dense + (size_t)(c - p.start_col) * p.n_cols + tile_base;
+            for (int j = tid; j < n_tile; j += THREADS) dst[j] = acc[j];
             __syncthreads();
             continue;
         }
@@ -203,12 +229,48 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         __syncthreads();
         npos = s_npos;
         nneg = s_nneg;
-        // ---- top-K: the K largest cells of the FULL column (zeros compete, then are dropped), value-descending,
-        //      emitted like the COO triples of .pyx:550-562 with -1 padding ----
-        const size_t base = (size_t)(c - p.start_col) * p.topK;
-        block_topk_emit<THREADS>(acc, p.n_cols, p.topK, p.sortP, npos, nneg, TOPK_ZEROS_COMPETE, aux, sc, &s_ncand,
-                                 p.out_idx + base, p.out_val + base);
+        total_nonzero += npos + nneg;
+        if (p.n_tiles == 1) {
+            // ---- top-K: the K largest cells of the FULL column (zeros compete, then are dropped), value-descending,
+            //      emitted like the COO triples of .pyx:550-562 with -1 padding ----
+            block_topk_emit<THREADS>(acc, n_tile, p.topK, p.sortP, npos, nneg, TOPK_ZEROS_COMPETE, aux, sc, &s_ncand,
+                                     p.out_idx + out_base, p.out_val + out_base);
+        } else {
+            // the tile's K best non-zero cells go to the workgroup's scratch; zeros are accounted for in the merge
+            block_topk_emit<THREADS>(acc, n_tile, p.topK, p.sortP, npos, nneg, TOPK_NONZERO, aux, sc, &s_ncand,
+                                     wg_cand_idx + tile * p.topK, wg_cand_val + tile * p.topK, tile_base);
+        }
         __syncthreads();
+        }  // tiles
+
+        if (p.n_tiles > 1 && p.topK > 0) {
+            // ---- merge of the per-tile candidates: the K largest of the whole column, zeros competing ----
+            const int n_m = p.n_tiles * p.topK;
+            if (tid == 0) { s_npos = 0; s_nneg = 0; s_ncand = 0; }
+            __threadfence_block();
+            __syncthreads();
+            uint32_t npos = 0, nneg = 0;
+            for (int j = tid; j < n_m; j += THREADS) {
+                const float v = wg_cand_idx[j] >= 0 ? wg_cand_val[j] : 0.f;
+                acc[j] = v;
+                npos += v > 0.f;
+                nneg += v < 0.f;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                npos += __shfl_down(npos, off);
+                nneg += __shfl_down(nneg, off);
+            }
+            if (lane == 0) {
+                if (npos) atomicAdd(&s_npos, npos);
+                if (nneg) atomicAdd(&s_nneg, nneg);
+            }
+            __syncthreads();
+            block_topk_emit<THREADS>(acc, n_m, p.topK, p.sortP, s_npos, s_nneg, TOPK_ZEROS_COMPETE, aux, sc, &s_ncand,
+                                     p.out_idx + out_base, p.out_val + out_base, 0, wg_cand_idx,
+                                     (long long)p.n_cols - total_nonzero);
+            __syncthreads();
+        }
     }
 }
 
@@ -231,9 +293,23 @@ __global__ void row_center_kernel(const int *ptr, float *val, int n_rows) {
     for (int q = s + lane; q < e; q += 64) val[q] -= mean;
 }
 
-__global__ void narrow_idx_kernel(const int *idx, size_t nnz, unsigned short *out) {
+__global__ void narrow_idx_kernel(const int *idx, size_t nnz, int tile_w, unsigned short *out) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = (unsigned short)idx[i];
+        out[i] = (unsigned short)(idx[i] % tile_w);          // id relative to the base of its accumulator tile
+}
+
+// row_tile_ptr[u][t] = first position of CSR row u whose column id is >= t * tile_w (rows have sorted ids).
+__global__ void row_tile_ptr_kernel(const int *ptr, const int *idx, int n_rows, int tile_w, int n_tiles, int *out) {
+    const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (e >= (long long)n_rows * (n_tiles + 1)) return;
+    const int u = (int)(e / (n_tiles + 1)), t = (int)(e % (n_tiles + 1));
+    int lo = ptr[u], hi = ptr[u + 1];
+    const long long bound = (long long)t * tile_w;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (idx[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    out[e] = lo;
 }
 
 __global__ void count_cols_kernel(const int *idx, size_t nnz, int *cnt) {
@@ -373,6 +449,9 @@ struct mi355rec_sim {
     StreamTimer call_timer;  // events around the whole call (H2D of the schedule, kernel, D2H of the result)
     DeviceBuffer<int> csr_ptr, csr_idx, csc_ptr, csc_idx, order;
     DeviceBuffer<unsigned short> csr_idx16;
+    DeviceBuffer<int> row_tile_ptr, cand_idx;
+    DeviceBuffer<float> cand_val;
+    int tile_w = 0, n_tiles = 1;
     DeviceBuffer<float> csr_val, csc_val, row_w, norm, norm_alpha, norm_1ma;
     DeviceBuffer<unsigned> queue;
     DeviceBuffer<int> out_idx;
@@ -438,7 +517,10 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     SimParams p{};
     p.n_rows = h->n_rows;
     p.n_cols = h->n_cols;
-    p.n_cols_pad = (h->n_cols + 3) & ~3;
+    p.n_cols_pad = h->tile_w;          // length of the LDS accumulator
+    p.tile_w = h->tile_w;
+    p.n_tiles = h->n_tiles;
+    p.row_tile_ptr = h->row_tile_ptr.ptr;
     p.topK = h->cfg.topK;
     int P = 1;
     while (P < std::max(2, p.topK)) P <<= 1;
@@ -468,14 +550,24 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
 
     const size_t lds = (size_t)p.n_cols_pad * 4 + (size_t)AUX_WORDS * 4;
     const int cus = multiprocessor_count();
-    h->call_timer.start(h->stream);
-    if (lds > 72 * 1024) {
-        // one 16-wave workgroup per CU (the accumulator owns most of the 160 KiB LDS)
-        launch_sim_g<1024>(h, p, std::min(n_local, cus), lds);
-    } else {
-        int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (lds + 1024))));
-        launch_sim_g<512>(h, p, std::min(n_local, cus * per_cu), lds);
+    int threads = 1024, grid = std::min(n_local, cus);   // one 16-wave workgroup per CU when the accumulator owns the LDS
+    if (lds <= 72 * 1024) {
+        const int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (lds + 1024))));
+        threads = 512;
+        grid = std::min(n_local, cus * per_cu);
     }
+    if (h->n_tiles > 1 && p.topK > 0) {
+        const size_t need = (size_t)grid * h->n_tiles * p.topK;
+        if (h->cand_idx.count < need) {
+            h->cand_idx.alloc(need);
+            h->cand_val.alloc(need);
+        }
+    }
+    p.cand_idx = h->cand_idx.ptr;
+    p.cand_val = h->cand_val.ptr;
+    h->call_timer.start(h->stream);
+    if (threads == 1024) launch_sim_g<1024>(h, p, grid, lds);
+    else launch_sim_g<512>(h, p, grid, lds);
     h->call_timer.stop(h->stream);
 
     h->stats.n_launches = 1;
@@ -503,12 +595,6 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
                    "Cosine_Similarity: value for parameter 'mode' not recognized (%d)", cfg->similarity);
         MI_REQUIRE(cfg->topK >= 0, "topK must be >= 0");
         ensure_device();
-        const size_t lds_needed = ((size_t)((n_cols + 3) & ~3)) * 4 + (size_t)AUX_WORDS * 4 + 2048;
-        if (lds_needed > 160 * 1024)
-            fail(MI355REC_E_UNSUPPORTED,
-                 "n_cols = %d needs %zu B of LDS for the per-column accumulator (limit 160 KiB); the tiled "
-                 "accumulator variant is not available yet",
-                 n_cols, lds_needed);
         std::unique_ptr<mi355rec_sim> h(new mi355rec_sim());
         h->cfg = *cfg;
         h->cfg.topK = std::min(cfg->topK, n_cols);  // .pyx:146
@@ -520,6 +606,12 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         if (set_based) h->cfg.normalize = 0;  // .pyx:124-135
         h->n_rows = n_rows;
         h->n_cols = n_cols;
+        // accumulator tiling: the LDS holds MAX_TILE neighbour cells next to the 32 KiB selection scratch
+        h->tile_w = n_cols <= MAX_TILE ? ((n_cols + 3) & ~3) : MAX_TILE;
+        h->n_tiles = (n_cols + h->tile_w - 1) / h->tile_w;
+        if ((long long)h->n_tiles * h->cfg.topK > h->tile_w)
+            fail(MI355REC_E_UNSUPPORTED, "n_cols = %d with topK = %d: the per-tile candidates (%d x %d) do not fit the merge buffer",
+                 n_cols, h->cfg.topK, h->n_tiles, h->cfg.topK);
         h->nnz = (size_t)csr_indptr[n_rows];
         MI_REQUIRE(h->nnz > 0, "matrix has no stored values");
         MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -558,7 +650,12 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         pos_in.alloc(nnz);
         pos_out.alloc(nnz);
         key_out.alloc(nnz);
-        hipLaunchKernelGGL(narrow_idx_kernel, dim3(eg), dim3(eb), 0, s, h->csr_idx.ptr, nnz, h->csr_idx16.ptr);
+        hipLaunchKernelGGL(narrow_idx_kernel, dim3(eg), dim3(eb), 0, s, h->csr_idx.ptr, nnz, h->tile_w, h->csr_idx16.ptr);
+        if (h->n_tiles > 1) {
+            h->row_tile_ptr.alloc((size_t)n_rows * (h->n_tiles + 1));
+            hipLaunchKernelGGL(row_tile_ptr_kernel, dim3(div_up((int64_t)n_rows * (h->n_tiles + 1), 256)), dim3(256), 0, s,
+                               h->csr_ptr.ptr, h->csr_idx.ptr, n_rows, h->tile_w, h->n_tiles, h->row_tile_ptr.ptr);
+        }
         hipLaunchKernelGGL(count_cols_kernel, dim3(eg), dim3(eb), 0, s, h->csr_idx.ptr, nnz, cnt.ptr);
         hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, cnt.ptr, h->csc_ptr.ptr, cursor.ptr, n_cols);
         hipLaunchKernelGGL(expand_rows_kernel, dim3(div_up((int64_t)n_rows * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr, n_rows,

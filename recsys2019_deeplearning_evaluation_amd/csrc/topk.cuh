@@ -117,12 +117,16 @@ enum { TOPK_ZEROS_COMPETE = 0, TOPK_NONZERO = 1, TOPK_FINITE = 2 };
 //   *ncand          : shared counter, must be 0 on entry
 // Output: out_idx / out_val [topK] (out_val may be null), value-descending, ties broken towards the lower index,
 // (-1, 0) padded.
+//   idx_offset      : added to every emitted index (tiled callers: base of the tile)
+//   idx_map         : if non-null the emitted index is idx_map[local index] (merge of per-tile candidates)
+//   zero_count      : TOPK_ZEROS_COMPETE only: number of competing zeros; < 0 = n - npos - nneg
 template <int THREADS>
 __device__ void block_topk_emit(const float *acc, int n, int topK, int sortP, uint32_t npos, uint32_t nneg, int mode,
-                                uint32_t *aux, SelectScratch &sc, uint32_t *ncand_shared, int *out_idx, float *out_val) {
+                                uint32_t *aux, SelectScratch &sc, uint32_t *ncand_shared, int *out_idx, float *out_val,
+                                int idx_offset = 0, const int *idx_map = nullptr, long long zero_count = -1) {
     const int tid = threadIdx.x;
     const bool zeros_compete = mode == TOPK_ZEROS_COMPETE;
-    const uint32_t nzero = zeros_compete ? (uint32_t)n - npos - nneg : 0u;
+    const uint32_t nzero = zeros_compete ? (zero_count >= 0 ? (uint32_t)zero_count : (uint32_t)n - npos - nneg) : 0u;
     uint32_t K = (uint32_t)topK;
     if (!zeros_compete) K = min(K, npos + nneg);
     uint32_t T = ZERO_KEY, need_eq = 0, eq_total = 0;
@@ -173,6 +177,7 @@ __device__ void block_topk_emit(const float *acc, int n, int topK, int sortP, ui
         if (t < ncand) {
             const uint64_t e = cand[t];
             idx = (int)(~(uint32_t)(e & 0xFFFFFFFFull));
+            idx = idx_map ? idx_map[idx] : idx + idx_offset;
             val = key_float((uint32_t)(e >> 32));
         }
         out_idx[t] = idx;

@@ -42,8 +42,8 @@ class ItemKNNCFRecommender(_KNNCFMixin, BaseItemSimilarityMatrixRecommender):
 
 
 class UserKNNCFRecommender(_KNNCFMixin, BaseUserSimilarityMatrixRecommender):
-    """UserKNN recommender: the same build on URM.T (columns = users).  The per-column accumulator must fit
-    the CU's LDS, i.e. n_users <= ~32k on this path."""
+    """UserKNN recommender: the same build on URM.T (columns = users); user bases wider than the LDS accumulator
+    (32 256 cells) are handled by the kernel's accumulator tiling."""
     RECOMMENDER_NAME = "UserKNNCFRecommender"
 
     def __init__(self, URM_train, verbose=True):

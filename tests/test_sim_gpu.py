@@ -122,8 +122,8 @@ def test_edge_cases(gpu):
         dev.close()
     with pytest.raises(ValueError):
         Compute_Similarity_MI355X(X, row_weights=[1.0, 2.0])
-    with pytest.raises(NotImplementedError):
-        Compute_Similarity_MI355X(sps.random(4, 60000, 0.01, format="csr", dtype=np.float32, random_state=0))
+    with pytest.raises(NotImplementedError):      # 3 tiles x topK 4096 candidates exceed the merge buffer
+        Compute_Similarity_MI355X(sps.random(4, 90000, 0.01, format="csr", dtype=np.float32, random_state=0), topK=20000)
 
 
 def test_itemknn_recommender_end_to_end(gpu):
@@ -188,3 +188,44 @@ def test_baseline_config_4_netflix_shape_properties(gpu):
     for c in np.argsort(cost)[[n // 2, n // 2 + 1, n // 3]]:
         check_topk_against_dense(idx[c], val[c], orc.column(int(c))[0], 100, RTOL)
     dev.close()
+
+
+@pytest.mark.parametrize("values,similarity", [("real", "cosine"), ("binary", "jaccard"), ("real", "pearson")])
+def test_wide_matrices_use_accumulator_tiles(gpu, values, similarity):
+    """More columns than LDS cells (32 256): the accumulator is tiled over the neighbour ids and the per-tile top-K
+    candidates are merged.  70 000 columns = 3 tiles; every column is checked against the oracle."""
+    X = synthetic_urm(2500, 70000, 420000, 20, 600, seed=11, values=values, zipf_exponent=0.6)
+    dev = Compute_Similarity_MI355X(X, topK=40, shrink=2, similarity=similarity)
+    idx, val, _ = dev.compute_slabs()
+    orc = O.OracleSimilarity(X, topK=0, shrink=2, similarity=similarity)
+    for c in range(0, X.shape[1], 7):
+        check_topk_against_dense(idx[c], val[c], orc.column(c)[0], 40, RTOL)
+    # a column range and the dense variant go through the same tiles
+    part_idx, part_val, s0 = dev.compute_slabs(33000, 33100)
+    np.testing.assert_array_equal(part_idx, idx[33000:33100])
+    dev.close()
+    dense = Compute_Similarity_MI355X(X[:, :40000], topK=0, shrink=2, similarity=similarity)
+    W = dense.compute_similarity(start_col=32000, end_col=32300)
+    orc2 = O.OracleSimilarity(X[:, :40000], topK=0, shrink=2, similarity=similarity)
+    for c in (32000, 32255, 32256, 32299):
+        assert rel_err(W[:, c], orc2.column(c)[0]) < RTOL or np.abs(orc2.column(c)[0]).max() == 0
+    dense.close()
+
+
+def test_userknn_recommender_on_a_wide_user_base(gpu):
+    """UserKNN = the same build on URM.T: 40 000 users -> two accumulator tiles."""
+    from recsys2019_deeplearning_evaluation_amd import UserKNNCFRecommender
+    X = synthetic_urm(40000, 900, 500000, 5, 200, seed=12, values="binary")
+    rec = UserKNNCFRecommender(X, verbose=False)
+    rec.fit(topK=15, shrink=1, similarity="cosine")
+    assert rec.W_sparse.shape == (40000, 40000) and (np.diff(rec.W_sparse.tocsc().indptr) <= 15).all()
+    orc = O.OracleSimilarity(rec.URM_train.T.tocsr(), topK=0, shrink=1)
+    Wc = rec.W_sparse.tocsc()
+    for c in (0, 17, 32255, 32256, 39999):
+        col = np.zeros(40000, np.float32); col[Wc.indices[Wc.indptr[c]:Wc.indptr[c + 1]]] = Wc.data[Wc.indptr[c]:Wc.indptr[c + 1]]
+        want = orc.column(c)[0]
+        order = np.argsort(-col, kind="stable")[:15]
+        check_topk_against_dense(np.where(col[order] > 0, order, -1).astype(np.int32)[np.argsort(np.where(col[order] > 0, 0, 1), kind="stable")],
+                                 np.sort(col[order])[::-1], want, 15, RTOL)
+    scores = rec._compute_item_score(np.arange(5))
+    assert scores.shape == (5, 900)
