@@ -280,17 +280,24 @@ __global__ void fill_kernel(float *x, size_t n, float v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = v;
 }
 
+// Mean of the stored cells of every segment (CSR row or CSC column), summed SEQUENTIALLY in float32 in storage order:
+// that is what the reference's `dataMatrix.sum(axis=...)` does on a float32 matrix (SciPy csr_matvec against ones),
+// and mean-centred data is a difference of nearly equal numbers, so the summation order is visible in the result.
+__global__ void segment_mean_kernel(const int *ptr, const float *val, int n_segments, float *mean) {
+    const int sgm = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sgm >= n_segments) return;
+    const int s = ptr[sgm], e = ptr[sgm + 1];
+    float sum = 0.f;
+    for (int q = s; q < e; ++q) sum += val[q];
+    mean[sgm] = e > s ? (float)((double)sum / (double)(e - s)) : 0.f;
+}
+
 // applyAdjustedCosine (.pyx:275-310): subtract from every stored cell the mean of its row.
-__global__ void row_center_kernel(const int *ptr, float *val, int n_rows) {
+__global__ void row_center_kernel(const int *ptr, float *val, int n_rows, const float *mean) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= n_rows) return;
-    const int s = ptr[wave], e = ptr[wave + 1];
-    if (e == s) return;
-    double sum = 0.0;
-    for (int q = s + lane; q < e; q += 64) sum += (double)val[q];
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-    const float mean = (float)(sum / (double)(e - s));
-    for (int q = s + lane; q < e; q += 64) val[q] -= mean;
+    const float m = mean[wave];
+    for (int q = ptr[wave] + lane; q < ptr[wave + 1]; q += 64) val[q] -= m;
 }
 
 __global__ void narrow_idx_kernel(const int *idx, size_t nnz, int tile_w, unsigned short *out) {
@@ -631,9 +638,14 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
 
         // pre-processing of the stored values (.pyx:158-164)
         if (set_based) hipLaunchKernelGGL(fill_kernel, dim3(eg), dim3(eb), 0, s, h->csr_val.ptr, nnz, 1.0f);
-        if (cfg->similarity == MI355REC_SIM_ADJUSTED)
+        DeviceBuffer<float> row_mean;
+        if (cfg->similarity == MI355REC_SIM_ADJUSTED) {
+            row_mean.alloc((size_t)n_rows);
+            hipLaunchKernelGGL(segment_mean_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->csr_val.ptr,
+                               n_rows, row_mean.ptr);
             hipLaunchKernelGGL(row_center_kernel, dim3(div_up((int64_t)n_rows * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr,
-                               h->csr_val.ptr, n_rows);
+                               h->csr_val.ptr, n_rows, row_mean.ptr);
+        }
 
         // CSR -> CSC (.pyx:203-207), on the device: stable radix sort of the cell positions by column
         DeviceBuffer<int> cnt, cursor, row_of, pos_in, pos_out, key_out;
@@ -674,8 +686,8 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         const int cg = div_up((int64_t)n_cols * 64, 256);
         if (cfg->similarity == MI355REC_SIM_PEARSON) {
             mean.alloc((size_t)n_cols);
-            hipLaunchKernelGGL(column_stats_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_idx.ptr, h->csc_val.ptr,
-                               h->csr_ptr.ptr, n_cols, mean.ptr, (double *)nullptr, (long long *)nullptr);
+            hipLaunchKernelGGL(segment_mean_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_val.ptr, n_cols,
+                               mean.ptr);
             hipLaunchKernelGGL(col_center_kernel, dim3(eg), dim3(eb), 0, s, h->csr_idx.ptr, h->csr_val.ptr, nnz, mean.ptr);
             hipLaunchKernelGGL(col_center_csc_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_val.ptr, n_cols, mean.ptr);
         }
