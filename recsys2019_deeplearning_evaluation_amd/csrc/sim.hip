@@ -280,15 +280,40 @@ __global__ void fill_kernel(float *x, size_t n, float v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = v;
 }
 
-// Mean of the stored cells of every segment (CSR row or CSC column), summed SEQUENTIALLY in float32 in storage order:
-// that is what the reference's `dataMatrix.sum(axis=...)` does on a float32 matrix (SciPy csr_matvec against ones),
-// and mean-centred data is a difference of nearly equal numbers, so the summation order is visible in the result.
+// NumPy's float32 pairwise summation (numpy/_core/src/umath/loops_utils.h, FLOAT_pairwise_sum): < 8 elements
+// sequentially, <= 128 with eight running partial sums, above that split in halves (rounded to a multiple of 8).
+__device__ float numpy_pairwise_sum(const float *a, int n) {
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    if (n <= 128) {
+        float r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) {
+            r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+            r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+        }
+        float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return numpy_pairwise_sum(a, n2) + numpy_pairwise_sum(a + n2, n - n2);
+}
+
+// Mean of the stored cells of every segment (CSR row or CSC column).  Mean-centred data is a difference of nearly
+// equal numbers, so the float32 rounding of the SUM is visible in the result: the reference's
+// `dataMatrix.sum(axis=...)` on a float32 matrix is np.add.reduceat(data, indptr), i.e. first element + NumPy's
+// pairwise sum of the rest, in float32 -- reproduced bit for bit (checked against SciPy on the CPU).
 __global__ void segment_mean_kernel(const int *ptr, const float *val, int n_segments, float *mean) {
     const int sgm = blockIdx.x * blockDim.x + threadIdx.x;
     if (sgm >= n_segments) return;
     const int s = ptr[sgm], e = ptr[sgm + 1];
     float sum = 0.f;
-    for (int q = s; q < e; ++q) sum += val[q];
+    if (e > s) sum = e - s > 1 ? val[s] + numpy_pairwise_sum(val + s + 1, e - s - 1) : val[s];
     mean[sgm] = e > s ? (float)((double)sum / (double)(e - s)) : 0.f;
 }
 
