@@ -2,12 +2,13 @@
 
 Mirrors KNN/ItemKNNCFRecommender.py:17 (fit :31-54) and KNN/UserKNNCFRecommender.py:17 (fit :31-55): same fit()
 keywords, same W_sparse attribute, same scoring through the base classes.  Feature weighting (BM25 / TF-IDF,
-Base/IR_feature_weighting.py) is a pre-step outside the hot path and raises
-NotImplementedError here rather than silently running elsewhere.
+Base/IR_feature_weighting.py) is the reference's host-side NumPy pre-step (feature_weighting.py); the similarity
+build that follows runs on the device.
 """
 import numpy as np
 
 from .recommender_base import (BaseItemSimilarityMatrixRecommender, BaseUserSimilarityMatrixRecommender, check_matrix)
+from .feature_weighting import apply_feature_weighting
 from .similarity import Compute_Similarity
 
 
@@ -18,8 +19,6 @@ class _KNNCFMixin:
         if feature_weighting not in self.FEATURE_WEIGHTING_VALUES:
             raise ValueError("Value for 'feature_weighting' not recognized. Acceptable values are {}, provided was '{}'".format(
                 self.FEATURE_WEIGHTING_VALUES, feature_weighting))
-        if feature_weighting != "none":
-            raise NotImplementedError("feature_weighting='{}' is not on the MI355X hot path yet".format(feature_weighting))
 
 
 class ItemKNNCFRecommender(_KNNCFMixin, BaseItemSimilarityMatrixRecommender):
@@ -33,6 +32,7 @@ class ItemKNNCFRecommender(_KNNCFMixin, BaseItemSimilarityMatrixRecommender):
         self.topK = topK
         self.shrink = shrink
         self._check_weighting(feature_weighting)
+        self.URM_train = apply_feature_weighting(self.URM_train, feature_weighting, user_major=False)
         builder = Compute_Similarity(self.URM_train, shrink=shrink, topK=topK, normalize=normalize,
                                      similarity=similarity, **similarity_args)
         self.W_sparse = builder.compute_similarity()
@@ -53,6 +53,7 @@ class UserKNNCFRecommender(_KNNCFMixin, BaseUserSimilarityMatrixRecommender):
         self.topK = topK
         self.shrink = shrink
         self._check_weighting(feature_weighting)
+        self.URM_train = apply_feature_weighting(self.URM_train, feature_weighting, user_major=True)
         builder = Compute_Similarity(self.URM_train.T, shrink=shrink, topK=topK, normalize=normalize,
                                      similarity=similarity, **similarity_args)
         self.W_sparse = builder.compute_similarity()

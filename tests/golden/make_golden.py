@@ -140,6 +140,15 @@ def main():
         out["V_%d" % n] = rec.ITEM_factors
     out["cases"] = np.array(json.dumps(cases))
     np.savez_compressed(os.path.join(HERE, "ials.npz"), **out)
+    # ---------------- BM25 / TF-IDF pre-weighting (pure-Python reference) ----------------
+    bm25 = ref_loader.load_python_reference("Base.IR_feature_weighting", "okapi_BM_25")
+    tfidf = ref_loader.load_python_reference("Base.IR_feature_weighting", "TF_IDF")
+    Xw = small_urm(50, 35, 0.2, 16, real=True)
+    out = pack_csr("X", Xw)
+    out["bm25_T"] = bm25(Xw.astype(np.float32).T).T.toarray()
+    out["tfidf_T"] = tfidf(Xw.astype(np.float32).T).T.toarray()
+    out["cases"] = np.array(json.dumps([]))
+    np.savez_compressed(os.path.join(HERE, "feature_weighting.npz"), **out)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -135,3 +135,13 @@ def test_synthetic_family_is_seeded_and_has_no_cold_rows():
     assert len(np.unique(a.data)) > 1000 and (a.data != np.rint(a.data)).mean() > 0.99   # jittered ratings
     c = named_urm("ml1m", "binary", scale=0.1)
     assert (c.data == 1).all()
+
+
+def test_feature_weighting_matches_reference_fixture():
+    from _util import load_golden, unpack_csr
+    from recsys2019_deeplearning_evaluation_amd.feature_weighting import apply_feature_weighting
+    z, _ = load_golden("feature_weighting")
+    X = unpack_csr(z, "X")
+    np.testing.assert_allclose(apply_feature_weighting(X, "BM25", False).toarray(), z["bm25_T"].astype(np.float32), rtol=1e-6)
+    np.testing.assert_allclose(apply_feature_weighting(X, "TF-IDF", True).toarray(), z["tfidf_T"].astype(np.float32), rtol=1e-6)
+    assert apply_feature_weighting(X, "none", False) is X

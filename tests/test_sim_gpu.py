@@ -229,3 +229,15 @@ def test_userknn_recommender_on_a_wide_user_base(gpu):
                                  np.sort(col[order])[::-1], want, 15, RTOL)
     scores = rec._compute_item_score(np.arange(5))
     assert scores.shape == (5, 900)
+
+
+@pytest.mark.parametrize("weighting", ["BM25", "TF-IDF"])
+def test_itemknn_with_feature_weighting(gpu, weighting):
+    X = named_urm("ml1m", "real", scale=0.15)
+    rec = ItemKNNCFRecommender(X, verbose=False)
+    rec.fit(topK=20, shrink=5, similarity="cosine", feature_weighting=weighting)
+    assert abs(rec.URM_train - X).max() > 0                       # the recommender's URM is re-weighted, like the reference's
+    Wo = O.OracleSimilarity(rec.URM_train, topK=20, shrink=5).compute_similarity(exact_numpy_topk=True)
+    assert abs(rec.W_sparse - Wo).max() <= RTOL * abs(Wo).max()
+    with pytest.raises(ValueError):
+        ItemKNNCFRecommender(X, verbose=False).fit(feature_weighting="nope")
