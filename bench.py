@@ -272,7 +272,7 @@ def main():
                                           learning_rate=1e-3, sgd_mode="sgd", init_std_dev=0.1, random_seed=42 + rank)
     if args.warmup > 0:
         mf.epochIteration_Cython(args.warmup)
-    mf.set_profiling(min(4096, args.steps * (per_epoch // BATCH)))
+    mf.set_profiling(min(10 * (per_epoch // BATCH), args.steps * (per_epoch // BATCH)))   # the first 10 epochs carry per-dispatch events
     barrier()
     t0 = time.perf_counter()
     mf.epochIteration_Cython(args.steps)            # blocking: returns after the stream has drained

@@ -279,6 +279,13 @@ struct mi355rec_ials {
     mi355rec_stats stats{};
     double flops_acc = 0, bytes_acc = 0;
     long long rows_acc = 0, launches_acc = 0;
+
+    ~mi355rec_ials() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        call_timer.destroy();
+        dispatch_timers.destroy();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
 };
 
 namespace {
@@ -531,11 +538,4 @@ extern "C" int mi355rec_ials_get_stats(mi355rec_ials_t h, mi355rec_stats *stats)
     });
 }
 
-extern "C" void mi355rec_ials_destroy(mi355rec_ials_t h) {
-    if (!h) return;
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->call_timer.destroy();
-    h->dispatch_timers.destroy();
-    if (h->stream) (void)hipStreamDestroy(h->stream);
-    delete h;
-}
+extern "C" void mi355rec_ials_destroy(mi355rec_ials_t h) { delete h; }

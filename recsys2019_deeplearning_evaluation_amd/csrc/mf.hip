@@ -315,6 +315,14 @@ struct mi355rec_mf {
     int max_timed = 0;
     hipGraphExec_t epoch_graph = nullptr;   // one native epoch: sample kernel + n_batches x (grad, apply)
     std::vector<double> host_loss;
+
+    ~mi355rec_mf() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (epoch_graph) (void)hipGraphExecDestroy(epoch_graph);
+        timer.destroy();
+        dispatch_timers.destroy();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
 };
 
 namespace {
@@ -620,12 +628,4 @@ extern "C" int mi355rec_mf_get_stats(mi355rec_mf_t h, mi355rec_stats *stats) {
     });
 }
 
-extern "C" void mi355rec_mf_destroy(mi355rec_mf_t h) {
-    if (!h) return;
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->epoch_graph) (void)hipGraphExecDestroy(h->epoch_graph);
-    h->timer.destroy();
-    h->dispatch_timers.destroy();
-    if (h->stream) (void)hipStreamDestroy(h->stream);
-    delete h;
-}
+extern "C" void mi355rec_mf_destroy(mi355rec_mf_t h) { delete h; }

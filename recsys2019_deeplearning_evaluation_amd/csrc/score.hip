@@ -134,6 +134,13 @@ struct mi355rec_scorer {
     DeviceBuffer<int> seen_ptr, seen_idx, users, ranked;
     DeviceBuffer<unsigned char> allowed;
     mi355rec_stats stats{};
+
+    ~mi355rec_scorer() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        gemm_timer.destroy();
+        call_timer.destroy();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
 };
 
 namespace {
@@ -246,11 +253,4 @@ extern "C" int mi355rec_scorer_get_stats(mi355rec_scorer_t h, mi355rec_stats *st
     });
 }
 
-extern "C" void mi355rec_scorer_destroy(mi355rec_scorer_t h) {
-    if (!h) return;
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->gemm_timer.destroy();
-    h->call_timer.destroy();
-    if (h->stream) (void)hipStreamDestroy(h->stream);
-    delete h;
-}
+extern "C" void mi355rec_scorer_destroy(mi355rec_scorer_t h) { delete h; }

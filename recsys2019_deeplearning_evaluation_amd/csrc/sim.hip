@@ -496,6 +496,13 @@ struct mi355rec_sim {
     mi355rec_stats stats{};
     // last call
     int last_start = -1, last_end = -1;
+
+    ~mi355rec_sim() {   // also runs when mi355rec_sim_create fails half-way: nothing leaks
+        if (stream) (void)hipStreamSynchronize(stream);
+        timer.destroy();
+        call_timer.destroy();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
 };
 
 namespace {
@@ -840,11 +847,4 @@ extern "C" int mi355rec_sim_get_stats(mi355rec_sim_t h, mi355rec_stats *stats) {
     });
 }
 
-extern "C" void mi355rec_sim_destroy(mi355rec_sim_t h) {
-    if (!h) return;
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->timer.destroy();
-    h->call_timer.destroy();
-    if (h->stream) (void)hipStreamDestroy(h->stream);
-    delete h;
-}
+extern "C" void mi355rec_sim_destroy(mi355rec_sim_t h) { delete h; }

@@ -233,6 +233,13 @@ struct mi355rec_slim {
     std::vector<float> h_pw1, h_pw2;
     std::vector<double> h_loss;
     mi355rec_stats stats{};
+
+    ~mi355rec_slim() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        call_timer.destroy();
+        dispatch_timers.destroy();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
 };
 
 namespace {
@@ -479,11 +486,4 @@ extern "C" int mi355rec_slim_get_stats(mi355rec_slim_t h, mi355rec_stats *stats)
     });
 }
 
-extern "C" void mi355rec_slim_destroy(mi355rec_slim_t h) {
-    if (!h) return;
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->call_timer.destroy();
-    h->dispatch_timers.destroy();
-    if (h->stream) (void)hipStreamDestroy(h->stream);
-    delete h;
-}
+extern "C" void mi355rec_slim_destroy(mi355rec_slim_t h) { delete h; }
