@@ -30,7 +30,7 @@ namespace mi355rec {
 namespace {
 
 struct MfState {           // lives in device memory so that launches carry no per-batch host arguments
-    long long grad_batch;  // index (since create) of the batch the next grad kernel works on
+    long long grad_batch;  // number of gradient kernels run since create = 1-based index of the current mini-batch
     long long epoch;       // index (since create) of the epoch the next sampling kernel draws
 };
 
@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256) void mf_grad_kernel(const MfParams p, const in
     // graph node), so the sample triplet is the first load of the kernel, not the second
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);   // sample slot inside the batch
+    // count the mini-batches since create (Adam's beta^t): single writer here, read only by the apply kernel that follows
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.state->grad_batch += 1;
     double my_loss = 0.0;
     if (w < p.n_in_batch) {
         const long long slot = (long long)batch_local * p.batch_size + w;
@@ -248,20 +250,19 @@ __device__ __forceinline__ float adapt(const MfParams &p, float g, float *c1, fl
 __global__ __launch_bounds__(256) void mf_apply_kernel(const MfParams p) {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long batch = p.state->grad_batch;         // global mini-batch index (only Adam's beta^t needs its value)
     const float invB = 1.f / (float)p.batch_size;      // mean over batch_size, NOT over the row's count (.pyx:802)
     float pw1 = 1.f, pw2 = 1.f;
     if (p.sgd_mode == MI355REC_ADAM) {                  // beta^(t) with t = batch + 1 (.pyx:217-218, :646-649)
-        pw1 = (float)(1.0 - pow(p.beta_1_d, (double)(batch + 1)));
-        pw2 = (float)(1.0 - pow(p.beta_2_d, (double)(batch + 1)));
+        // the global mini-batch index lives in device memory (graph replays carry no host arguments); only Adam reads
+        // it, so the other optimisers keep this dependent load off their critical path
+        const long long t = p.state->grad_batch;        // advanced by the gradient kernel of this mini-batch: t = batch + 1
+        pw1 = (float)(1.0 - pow(p.beta_1_d, (double)t));
+        pw2 = (float)(1.0 - pow(p.beta_2_d, (double)t));
     }
-    if (w == 0 && lane == 0) {
-        if (p.use_bias) {
-            float g = adapt(p, p.acc_mu[0] * invB, p.c_mu, p.c_mu + 1, 0, pw1, pw2);
-            p.mu[0] += p.lr * g;
-            p.acc_mu[0] = 0.f;
-        }
-        p.state->grad_batch = batch + 1;
+    if (w == 0 && lane == 0 && p.use_bias) {
+        float g = adapt(p, p.acc_mu[0] * invB, p.c_mu, p.c_mu + 1, 0, pw1, pw2);
+        p.mu[0] += p.lr * g;
+        p.acc_mu[0] = 0.f;
     }
     const int per = p.algorithm_is_bpr ? 3 : 2;
     if (w >= per * p.n_in_batch) return;
