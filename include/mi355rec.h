@@ -232,6 +232,19 @@ int mi355rec_scorer_recommend(mi355rec_scorer_t h, const int32_t *user_ids, int3
 int mi355rec_scorer_get_stats(mi355rec_scorer_t h, mi355rec_stats *stats);
 void mi355rec_scorer_destroy(mi355rec_scorer_t h);
 
+/* Similarity models: scores[u] = A[u, :] . B, A (n_users x n_mid) and B (n_mid x n_items) CSR float32.
+ * ItemKNN / SLIM: A = URM_train, B = W_sparse (Base/BaseSimilarityMatrixRecommender.py:73-92);
+ * UserKNN: A = W_sparse, B = URM_train (:101-116).  Filtering and ranking as mi355rec_scorer_recommend. */
+typedef struct mi355rec_spscorer *mi355rec_spscorer_t;
+int mi355rec_spscorer_create(mi355rec_spscorer_t *out, int32_t n_users, int32_t n_mid, int32_t n_items,
+                             const int32_t *a_indptr, const int32_t *a_indices, const float *a_data,
+                             const int32_t *b_indptr, const int32_t *b_indices, const float *b_data,
+                             const int32_t *seen_indptr, const int32_t *seen_indices);
+int mi355rec_spscorer_recommend(mi355rec_spscorer_t h, const int32_t *user_ids, int32_t n, int32_t cutoff, int32_t remove_seen,
+                                const uint8_t *item_allowed, int32_t *ranked, float *scores);
+int mi355rec_spscorer_get_stats(mi355rec_spscorer_t h, mi355rec_stats *stats);
+void mi355rec_spscorer_destroy(mi355rec_spscorer_t h);
+
 #ifdef __cplusplus
 }
 #endif

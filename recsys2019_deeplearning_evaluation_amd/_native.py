@@ -101,6 +101,10 @@ SIGNATURES = {
     "mi355rec_scorer_recommend": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mi355rec_scorer_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "mi355rec_scorer_destroy": (None, [_vp]),
+    "mi355rec_spscorer_create": (C.c_int, [C.POINTER(_vp), _i32, _i32, _i32] + [_vp] * 8),
+    "mi355rec_spscorer_recommend": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mi355rec_spscorer_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "mi355rec_spscorer_destroy": (None, [_vp]),
 }
 
 _lib = None

@@ -254,3 +254,166 @@ extern "C" int mi355rec_scorer_get_stats(mi355rec_scorer_t h, mi355rec_stats *st
 }
 
 extern "C" void mi355rec_scorer_destroy(mi355rec_scorer_t h) { delete h; }
+
+// ------------------------------------------------------------------------------------------------------
+// Similarity-model scoring: scores[u] = A[u, :] . B with A and B sparse (CSR).
+//   ItemKNN / SLIM  (BaseItemSimilarityMatrixRecommender._compute_item_score, Base/BaseSimilarityMatrixRecommender.py:73-92):
+//                   A = URM_train, B = W_sparse                         -> user_profile . W
+//   UserKNN         (BaseUserSimilarityMatrixRecommender._compute_item_score, :101-116):  A = W_sparse, B = URM_train
+// One workgroup per user: the dense score row lives in LDS (it IS dense in the reference: .toarray()), every stored cell
+// of A[u] streams one row of B into it with LDS float atomics, then the same filter + top-cutoff as the factor models.
+// ------------------------------------------------------------------------------------------------------
+namespace mi355rec {
+namespace {
+
+struct SpScoreParams {
+    int n_out, n_pad, cutoff, sortP, remove_seen, write_back;
+    const int *a_ptr, *a_idx, *b_ptr, *b_idx;
+    const float *a_val, *b_val;
+    const int *users, *seen_ptr, *seen_idx;
+    const unsigned char *allowed;
+    float *scores;                  // [n_batch][n_out] when write_back
+    int *ranked;
+};
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void spscore_kernel(const SpScoreParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *acc = smem;
+    uint32_t *aux = reinterpret_cast<uint32_t *>(smem + p.n_pad);
+    __shared__ SelectScratch sc;
+    __shared__ uint32_t s_ncand, s_nfinite;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int WAVES = THREADS / 64;
+    const int b = blockIdx.x, u = p.users[b];
+    if (tid == 0) { s_ncand = 0; s_nfinite = 0; }
+    for (int j = tid; j < p.n_pad; j += THREADS) acc[j] = 0.f;
+    __syncthreads();
+    // one wavefront per stored cell of A[u]: its row of B is added, scaled, to the score row
+    for (int q = p.a_ptr[u] + wave; q < p.a_ptr[u + 1]; q += WAVES) {
+        const int m = p.a_idx[q];
+        const float w = p.a_val[q];
+        for (int t = p.b_ptr[m] + lane; t < p.b_ptr[m + 1]; t += 64) atomicAdd(&acc[p.b_idx[t]], w * p.b_val[t]);
+    }
+    __syncthreads();
+    if (p.allowed)
+        for (int j = tid; j < p.n_out; j += THREADS)
+            if (!p.allowed[j]) acc[j] = -INFINITY;
+    if (p.remove_seen)
+        for (int q = p.seen_ptr[u] + tid; q < p.seen_ptr[u + 1]; q += THREADS) acc[p.seen_idx[q]] = -INFINITY;
+    __syncthreads();
+    uint32_t nfin = 0;
+    float *row = p.scores + (size_t)b * p.n_out;
+    for (int j = tid; j < p.n_out; j += THREADS) {
+        const float v = acc[j];
+        nfin += v > -INFINITY;
+        if (p.write_back) row[j] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nfin += __shfl_down(nfin, off);
+    if (lane == 0 && nfin) atomicAdd(&s_nfinite, nfin);
+    __syncthreads();
+    block_topk_emit<THREADS>(acc, p.n_out, p.cutoff, p.sortP, s_nfinite, 0u, TOPK_FINITE, aux, sc, &s_ncand,
+                             p.ranked + (size_t)b * p.cutoff, nullptr);
+}
+
+}  // namespace
+}  // namespace mi355rec
+
+struct mi355rec_spscorer {
+    int n_users = 0, n_mid = 0, n_out = 0;
+    hipStream_t stream = nullptr;
+    StreamTimer timer;
+    DeviceBuffer<int> a_ptr, a_idx, b_ptr, b_idx, seen_ptr, seen_idx, users, ranked;
+    DeviceBuffer<float> a_val, b_val, scores;
+    DeviceBuffer<unsigned char> allowed;
+    mi355rec_stats stats{};
+    double nnz_a = 0, nnz_b = 0;
+
+    ~mi355rec_spscorer() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        timer.destroy();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" int mi355rec_spscorer_create(mi355rec_spscorer_t *out, int32_t n_users, int32_t n_mid, int32_t n_out,
+                                        const int32_t *a_indptr, const int32_t *a_indices, const float *a_data,
+                                        const int32_t *b_indptr, const int32_t *b_indices, const float *b_data,
+                                        const int32_t *seen_indptr, const int32_t *seen_indices) {
+    return guarded([&] {
+        MI_REQUIRE(out && a_indptr && a_indices && a_data && b_indptr && b_indices && b_data && seen_indptr && seen_indices, "NULL argument");
+        MI_REQUIRE(n_users > 0 && n_mid > 0 && n_out > 0, "empty model");
+        ensure_device();
+        const size_t lds = ((size_t)((n_out + 3) & ~3)) * 4 + (size_t)AUX_WORDS * 4 + 2048;
+        if (lds > 160 * 1024)
+            fail(MI355REC_E_UNSUPPORTED, "n_items = %d: a score row does not fit the 160 KiB LDS of the ranking kernel", n_out);
+        std::unique_ptr<mi355rec_spscorer> h(new mi355rec_spscorer());
+        h->n_users = n_users; h->n_mid = n_mid; h->n_out = n_out;
+        MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->timer.init();
+        hipStream_t s = h->stream;
+        const size_t na = (size_t)a_indptr[n_users], nb = (size_t)b_indptr[n_mid], ns = (size_t)seen_indptr[n_users];
+        h->a_ptr.upload(a_indptr, (size_t)n_users + 1, s);
+        h->a_idx.upload(a_indices, na, s);
+        h->a_val.upload(a_data, na, s);
+        h->b_ptr.upload(b_indptr, (size_t)n_mid + 1, s);
+        h->b_idx.upload(b_indices, nb, s);
+        h->b_val.upload(b_data, nb, s);
+        h->seen_ptr.upload(seen_indptr, (size_t)n_users + 1, s);
+        h->seen_idx.upload(seen_indices, ns, s);
+        h->allowed.alloc(n_out);
+        h->nnz_a = (double)na; h->nnz_b = (double)nb;
+        MI_HIP(hipStreamSynchronize(s));
+        *out = h.release();
+    });
+}
+
+extern "C" int mi355rec_spscorer_recommend(mi355rec_spscorer_t h, const int32_t *user_ids, int32_t n, int32_t cutoff,
+                                           int32_t remove_seen, const uint8_t *item_allowed, int32_t *ranked, float *scores) {
+    return guarded([&] {
+        MI_REQUIRE(h && user_ids && ranked, "NULL argument");
+        MI_REQUIRE(n > 0, "empty user batch");
+        MI_REQUIRE(cutoff >= 1 && cutoff <= h->n_out, "cutoff must be in [1, n_items]");
+        if (cutoff > MAX_TOPK) fail(MI355REC_E_UNSUPPORTED, "cutoff = %d exceeds the in-LDS selection limit of %d", cutoff, MAX_TOPK);
+        for (int i = 0; i < n; ++i) MI_REQUIRE(user_ids[i] >= 0 && user_ids[i] < h->n_users, "user id %d out of range", user_ids[i]);
+        ensure_device();
+        hipStream_t s = h->stream;
+        if (h->users.count < (size_t)n) h->users.alloc(n);
+        if (h->ranked.count < (size_t)n * cutoff) h->ranked.alloc((size_t)n * cutoff);
+        if (scores && h->scores.count < (size_t)n * h->n_out) h->scores.alloc((size_t)n * h->n_out);
+        MI_HIP(hipMemcpyAsync(h->users.ptr, user_ids, sizeof(int) * n, hipMemcpyHostToDevice, s));
+        if (item_allowed) MI_HIP(hipMemcpyAsync(h->allowed.ptr, item_allowed, h->n_out, hipMemcpyHostToDevice, s));
+        SpScoreParams p{};
+        p.n_out = h->n_out; p.n_pad = (h->n_out + 3) & ~3; p.cutoff = cutoff;
+        int P = 1;
+        while (P < std::max(2, cutoff)) P <<= 1;
+        p.sortP = P; p.remove_seen = remove_seen; p.write_back = scores != nullptr;
+        p.a_ptr = h->a_ptr.ptr; p.a_idx = h->a_idx.ptr; p.a_val = h->a_val.ptr;
+        p.b_ptr = h->b_ptr.ptr; p.b_idx = h->b_idx.ptr; p.b_val = h->b_val.ptr;
+        p.users = h->users.ptr; p.seen_ptr = h->seen_ptr.ptr; p.seen_idx = h->seen_idx.ptr;
+        p.allowed = item_allowed ? h->allowed.ptr : nullptr;
+        p.scores = h->scores.ptr; p.ranked = h->ranked.ptr;
+        const size_t lds = (size_t)p.n_pad * 4 + (size_t)AUX_WORDS * 4;
+        auto k = spscore_kernel<1024>;
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipExtLaunchKernelGGL(k, dim3(n), dim3(1024), (unsigned)lds, s, h->timer.t0, h->timer.t1, 0, p);
+        MI_HIP(hipGetLastError());
+        h->ranked.download(ranked, (size_t)n * cutoff, s);
+        if (scores) h->scores.download(scores, (size_t)n * h->n_out, s);
+        MI_HIP(hipStreamSynchronize(s));
+        h->stats = mi355rec_stats{};
+        h->stats.kernel_ms = h->stats.call_ms = h->timer.elapsed_ms();
+        h->stats.n_launches = h->stats.n_timed = 1;
+        h->stats.n_units = n;
+    });
+}
+
+extern "C" int mi355rec_spscorer_get_stats(mi355rec_spscorer_t h, mi355rec_stats *stats) {
+    return guarded([&] {
+        MI_REQUIRE(h && stats, "NULL argument");
+        *stats = h->stats;
+    });
+}
+
+extern "C" void mi355rec_spscorer_destroy(mi355rec_spscorer_t h) { delete h; }

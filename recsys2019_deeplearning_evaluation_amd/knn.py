@@ -9,6 +9,7 @@ import numpy as np
 
 from .recommender_base import (BaseItemSimilarityMatrixRecommender, BaseUserSimilarityMatrixRecommender, check_matrix)
 from .feature_weighting import apply_feature_weighting
+from .scoring import GpuSimilarityScoringMixin
 from .similarity import Compute_Similarity
 
 
@@ -21,7 +22,7 @@ class _KNNCFMixin:
                 self.FEATURE_WEIGHTING_VALUES, feature_weighting))
 
 
-class ItemKNNCFRecommender(_KNNCFMixin, BaseItemSimilarityMatrixRecommender):
+class ItemKNNCFRecommender(GpuSimilarityScoringMixin, _KNNCFMixin, BaseItemSimilarityMatrixRecommender):
     """ItemKNN recommender: W_sparse = top-K item-item similarity of the URM columns."""
     RECOMMENDER_NAME = "ItemKNNCFRecommender"
 
@@ -41,10 +42,11 @@ class ItemKNNCFRecommender(_KNNCFMixin, BaseItemSimilarityMatrixRecommender):
         builder.compute_similarity_object.close()
 
 
-class UserKNNCFRecommender(_KNNCFMixin, BaseUserSimilarityMatrixRecommender):
+class UserKNNCFRecommender(GpuSimilarityScoringMixin, _KNNCFMixin, BaseUserSimilarityMatrixRecommender):
     """UserKNN recommender: the same build on URM.T (columns = users); user bases wider than the LDS accumulator
     (32 256 cells) are handled by the kernel's accumulator tiling."""
     RECOMMENDER_NAME = "UserKNNCFRecommender"
+    _SCORER_USER_BASED = True
 
     def __init__(self, URM_train, verbose=True):
         super(UserKNNCFRecommender, self).__init__(URM_train, verbose=verbose)

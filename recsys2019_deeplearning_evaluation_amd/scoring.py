@@ -110,3 +110,84 @@ class GpuScoringMixin:
         if single_user:
             ranking_list = ranking_list[0]
         return (ranking_list, scores) if return_scores else ranking_list
+
+
+class MI355XSparseScorer:
+    """scores[u] = A[u, :] . B for sparse A, B (ItemKNN / SLIM: A = URM_train, B = W_sparse; UserKNN: A = W_sparse,
+    B = URM_train), filtered and ranked on the device like MI355XScorer."""
+
+    def __init__(self, A, B, URM_seen):
+        A, B, seen = A.tocsr(), B.tocsr(), URM_seen.tocsr()
+        assert A.shape[1] == B.shape[0] and seen.shape == (A.shape[0], B.shape[1])
+        self.n_users, self.n_items = A.shape[0], B.shape[1]
+        arrs = [N.as_i32(A.indptr), N.as_i32(A.indices), N.as_f32(A.data), N.as_i32(B.indptr), N.as_i32(B.indices),
+                N.as_f32(B.data), N.as_i32(seen.indptr), N.as_i32(seen.indices)]
+        self._lib = N.load()
+        self._h = C.c_void_p()
+        N.check(self._lib.mi355rec_spscorer_create(C.byref(self._h), A.shape[0], A.shape[1], B.shape[1], *[N.ptr(a) for a in arrs]))
+
+    def recommend(self, user_id_array, cutoff, remove_seen=True, allowed_items=None, return_scores=False):
+        users = N.as_i32(np.atleast_1d(user_id_array))
+        cutoff = int(min(cutoff, self.n_items))
+        ranked = np.empty((len(users), cutoff), np.int32)
+        scores = np.empty((len(users), self.n_items), np.float32) if return_scores else None
+        mask = None if allowed_items is None else np.ascontiguousarray(allowed_items, dtype=np.uint8)
+        N.check(self._lib.mi355rec_spscorer_recommend(self._h, N.ptr(users), len(users), cutoff, int(bool(remove_seen)),
+                                                      N.ptr(mask), N.ptr(ranked), N.ptr(scores)))
+        return ranked, scores
+
+    def stats(self):
+        st = N.Stats()
+        N.check(self._lib.mi355rec_spscorer_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi355rec_spscorer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GpuSimilarityScoringMixin:
+    """recommend() for BaseItemSimilarityMatrixRecommender / BaseUserSimilarityMatrixRecommender subclasses, served by
+    MI355XSparseScorer.  `_SCORER_USER_BASED` selects the operand order.  The scorer is rebuilt whenever W_sparse or
+    URM_train is replaced (fit, early-stopping validation)."""
+    _SCORER_USER_BASED = False
+    _sp_scorer = None
+    _sp_scorer_key = None
+
+    def _get_sparse_scorer(self):
+        key = (id(self.W_sparse), id(self.URM_train))
+        if self._sp_scorer is None or key != self._sp_scorer_key:
+            if self._sp_scorer is not None:
+                self._sp_scorer.close()
+            A, B = (self.W_sparse, self.URM_train) if self._SCORER_USER_BASED else (self.URM_train, self.W_sparse)
+            self._sp_scorer = MI355XSparseScorer(A, B, self.URM_train)
+            self._sp_scorer_key = key
+        return self._sp_scorer
+
+    def recommend(self, user_id_array, cutoff=None, remove_seen_flag=True, items_to_compute=None, remove_top_pop_flag=False,
+                  remove_custom_items_flag=False, return_scores=False):
+        single_user = np.isscalar(user_id_array)
+        users = np.atleast_1d(user_id_array)
+        if cutoff is None:
+            cutoff = self.URM_train.shape[1] - 1
+        allowed = None
+        if items_to_compute is not None or remove_top_pop_flag or remove_custom_items_flag:
+            allowed = np.zeros(self.n_items, np.uint8) if items_to_compute is not None else np.ones(self.n_items, np.uint8)
+            if items_to_compute is not None:
+                allowed[np.asarray(items_to_compute)] = 1
+            if remove_top_pop_flag:
+                allowed[self.filterTopPop_ItemsID] = 0
+            if remove_custom_items_flag:
+                allowed[self.items_to_ignore_ID] = 0
+        ranked, scores = self._get_sparse_scorer().recommend(users, cutoff, remove_seen_flag, allowed, return_scores)
+        ranking_list = [row[row >= 0].tolist() for row in ranked]
+        if single_user:
+            ranking_list = ranking_list[0]
+        return (ranking_list, scores) if return_scores else ranking_list

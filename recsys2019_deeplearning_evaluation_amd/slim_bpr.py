@@ -18,6 +18,7 @@ import scipy.sparse as sps
 from . import _native as N
 from .recommender_base import (BaseItemSimilarityMatrixRecommender, Incremental_Training_Early_Stopping, check_matrix,
                                similarityMatrixTopK)
+from .scoring import GpuSimilarityScoringMixin
 
 
 def rows_slabs_to_csr(nbr_idx, nbr_val, n):
@@ -107,7 +108,7 @@ class SLIM_BPR_MI355X_Epoch:
         return st.as_dict()
 
 
-class SLIM_BPR_MI355X(BaseItemSimilarityMatrixRecommender, Incremental_Training_Early_Stopping):
+class SLIM_BPR_MI355X(GpuSimilarityScoringMixin, BaseItemSimilarityMatrixRecommender, Incremental_Training_Early_Stopping):
     """Drop-in for SLIM_BPR_Cython."""
     RECOMMENDER_NAME = "SLIM_BPR_Recommender"
 

@@ -97,3 +97,26 @@ def test_recommender_recommend_is_served_by_the_device_and_equals_the_host_path(
     assert rec.recommend(3, cutoff=4) == dev_lists[3][:4]
     rec.set_items_to_ignore([0, 1, 2])
     assert not {0, 1, 2} & set(rec.recommend(5, cutoff=20, remove_custom_items_flag=True))
+
+
+@pytest.mark.parametrize("user_based", [False, True])
+def test_similarity_model_scoring_matches_host(gpu, user_based):
+    """ItemKNN / UserKNN recommend(): URM[u] . W (resp. W[u] . URM) + filter + rank on the device == the host path."""
+    from recsys2019_deeplearning_evaluation_amd import ItemKNNCFRecommender, UserKNNCFRecommender
+    X = named_urm("ml1m", "real", scale=0.2)
+    rec = (UserKNNCFRecommender if user_based else ItemKNNCFRecommender)(X, verbose=False)
+    rec.fit(topK=30, shrink=3, similarity="cosine")
+    users = np.arange(0, X.shape[0], 7)
+    dev_lists, dev_scores = rec.recommend(users, cutoff=15, return_scores=True)
+    host_lists, host_scores = RB.BaseRecommender.recommend(rec, users, cutoff=15, return_scores=True)
+    assert rec._sp_scorer is not None
+    fin = np.isfinite(host_scores)
+    assert (np.isfinite(dev_scores) == fin).all()
+    scale = np.abs(host_scores[fin]).max()
+    assert np.abs(dev_scores[fin] - host_scores[fin]).max() < 1e-5 * scale
+    for r in range(len(users)):
+        _check_ranking(np.array(dev_lists[r] + [-1] * (15 - len(dev_lists[r]))), host_scores[r].astype(np.float64), 15, 1e-5 * scale)
+    allowed_items = np.arange(0, X.shape[1], 3)
+    only = rec.recommend(users[:5], cutoff=10, items_to_compute=allowed_items)
+    assert all(set(l) <= set(allowed_items.tolist()) for l in only)
+    assert rec.recommend(int(users[2]), cutoff=5) == dev_lists[2][:5]
