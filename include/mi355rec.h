@@ -112,7 +112,7 @@ void mi355rec_sim_destroy(mi355rec_sim_t h);
  * get_USER_factors ... get_GLOBAL_bias :685-702)
  * ---------------------------------------------------------------------------------------------------- */
 
-enum { MI355REC_MF_BPR = 0, MI355REC_MF_FUNK_SVD = 1 };                       /* algorithm_name (.pyx:93) */
+enum { MI355REC_MF_BPR = 0, MI355REC_MF_FUNK_SVD = 1, MI355REC_MF_ASY_SVD = 2 };   /* algorithm_name (.pyx:93) */
 enum { MI355REC_SGD = 0, MI355REC_ADAGRAD = 1, MI355REC_RMSPROP = 2, MI355REC_ADAM = 3 };  /* sgd_mode (.pyx:92) */
 
 typedef struct {
@@ -132,8 +132,10 @@ typedef struct {
 
 typedef struct mi355rec_mf *mi355rec_mf_t;
 
-/* URM (n_users x n_items) as CSR with sorted indices.  U0 (n_users x k) and V0 (n_items x k) are the initial
- * factors, row-major float32 (the host draws them exactly like .pyx:174-175 does). */
+/* URM (n_users x n_items) as CSR with sorted indices.  U0 (n_users x k; n_ITEMS x k for ASY_SVD, whose "user" matrix is
+ * the second item-sized matrix Y, .pyx:163-166) and V0 (n_items x k) are the initial factors, row-major float32 (the host
+ * draws them exactly like .pyx:174-175 does).  ASY_SVD requires batch_size == 1 (.pyx:395) and runs its nnz + 1 steps per
+ * epoch strictly in order. */
 int mi355rec_mf_create(mi355rec_mf_t *out, const mi355rec_mf_config *cfg, int32_t n_users, int32_t n_items,
                        const int32_t *indptr, const int32_t *indices, const float *data,
                        const float *U0, const float *V0);

@@ -57,6 +57,10 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.orc_mf_create.restype = _p
         L.orc_mf_create.argtypes = [C.c_int32] * 4 + [_p] * 5 + [C.c_double] * 7 + [C.c_int32, C.c_int32] + [C.c_double] * 3
+        L.orc_mf_create_rows.restype = _p
+        L.orc_mf_create_rows.argtypes = [C.c_int32] * 5 + [_p] * 5 + [C.c_double] * 7 + [C.c_int32, C.c_int32] + [C.c_double] * 3
+        L.orc_mf_epoch_asy.argtypes = [_p]
+        L.orc_mf_replay_asy.argtypes = [_p, _p, _p, _p, C.c_int64]
         L.orc_mf_destroy.argtypes = [_p]
         L.orc_srand.argtypes = [C.c_uint]
         L.orc_rand.restype = C.c_int
@@ -104,7 +108,7 @@ def _sorted_csr(URM):
 # --------------------------------------------------------------------------------------------------
 
 class OracleMF:
-    """Restates MatrixFactorization_Cython_Epoch for algorithm_name in {"MF_BPR", "FUNK_SVD"}.
+    """Restates MatrixFactorization_Cython_Epoch for algorithm_name in {"MF_BPR", "FUNK_SVD", "ASY_SVD"}.
 
     Constructor arguments, defaults, RNG seeding order and factor initialisation follow
     MatrixFactorization_Cython_Epoch.pyx:95-188 (np.random.seed(seed); srand(seed); U then V from
@@ -118,8 +122,10 @@ class OracleMF:
                  sgd_mode="sgd", gamma=0.995, beta_1=0.9, beta_2=0.999):
         if sgd_mode not in SGD_MODES:
             raise ValueError("Value for 'sgd_mode' not recognized: %r" % (sgd_mode,))
-        if algorithm_name not in ("FUNK_SVD", "MF_BPR"):
+        if algorithm_name not in ("FUNK_SVD", "MF_BPR", "ASY_SVD"):
             raise ValueError("Value for 'algorithm_name' not recognized by the oracle: %r" % (algorithm_name,))
+        if algorithm_name == "ASY_SVD":
+            assert batch_size == 1, "Batch size other than 1 not supported for ASY_SVD"
         URM = _sorted_csr(URM_train)
         self.n_users, self.n_items = URM.shape
         self.n_factors = int(n_factors)
@@ -133,11 +139,13 @@ class OracleMF:
         if random_seed is not None:
             np.random.seed(seed=random_seed)
             L.orc_srand(C.c_uint(int(random_seed)))
-        U0 = np.random.normal(init_mean, init_std_dev, (self.n_users, self.n_factors)).astype(np.float64)
+        # AsySVD keeps TWO item-sized matrices (.pyx:163-166): "USER_factors" is then n_items x k
+        self.n_u_rows = self.n_items if algorithm_name == "ASY_SVD" else self.n_users
+        U0 = np.random.normal(init_mean, init_std_dev, (self.n_u_rows, self.n_factors)).astype(np.float64)
         V0 = np.random.normal(init_mean, init_std_dev, (self.n_items, self.n_factors)).astype(np.float64)
         self.initial_USER_factors = U0.copy()
         self.initial_ITEM_factors = V0.copy()
-        self._h = L.orc_mf_create(self.n_users, self.n_items, self.n_factors, self.batch_size,
+        self._h = L.orc_mf_create_rows(self.n_users, self.n_items, self.n_u_rows, self.n_factors, self.batch_size,
                                   _ptr(self._indptr), _ptr(self._indices), _ptr(self._data), _ptr(U0), _ptr(V0),
                                   learning_rate, user_reg, item_reg, bias_reg, positive_reg, negative_reg,
                                   negative_interactions_quota, int(self.use_bias), SGD_MODES[sgd_mode],
@@ -164,6 +172,8 @@ class OracleMF:
     def epochIteration_Cython(self):
         if self.algorithm_name == "MF_BPR":
             lib().orc_mf_epoch_bpr(self._h)
+        elif self.algorithm_name == "ASY_SVD":
+            lib().orc_mf_epoch_asy(self._h)
         else:
             lib().orc_mf_epoch_funk(self._h)
 
@@ -174,10 +184,11 @@ class OracleMF:
             lib().orc_mf_replay_bpr(self._h, _ptr(u), _ptr(i), _ptr(j), len(u))
         else:
             rating = np.ascontiguousarray(rating, np.float64)
-            lib().orc_mf_replay_funk(self._h, _ptr(u), _ptr(i), _ptr(rating), len(u))
+            fn = lib().orc_mf_replay_asy if self.algorithm_name == "ASY_SVD" else lib().orc_mf_replay_funk
+            fn(self._h, _ptr(u), _ptr(i), _ptr(rating), len(u))
 
     def _get(self):
-        U = np.empty((self.n_users, self.n_factors)); V = np.empty((self.n_items, self.n_factors))
+        U = np.empty((self.n_u_rows, self.n_factors)); V = np.empty((self.n_items, self.n_factors))
         bu = np.empty(self.n_users); bi = np.empty(self.n_items); mu = C.c_double(0.0)
         lib().orc_mf_get(self._h, _ptr(U), _ptr(V), _ptr(bu), _ptr(bi), C.byref(mu))
         return U, V, bu, bi, mu.value

@@ -18,7 +18,7 @@ E_INVALID, E_HIP, E_NO_DEVICE, E_UNSUPPORTED, E_NUMERIC = -1, -2, -3, -4, -5
 SIMILARITY_CODES = {"cosine": 0, "adjusted": 1, "asymmetric": 2, "pearson": 3, "jaccard": 4, "tanimoto": 4,
                     "dice": 5, "tversky": 6}
 SGD_MODE_CODES = {"sgd": 0, "adagrad": 1, "rmsprop": 2, "adam": 3}
-ALGORITHM_CODES = {"MF_BPR": 0, "FUNK_SVD": 1}
+ALGORITHM_CODES = {"MF_BPR": 0, "FUNK_SVD": 1, "ASY_SVD": 2}
 
 
 class NativeLibraryError(RuntimeError):

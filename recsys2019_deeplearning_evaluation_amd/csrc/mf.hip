@@ -32,12 +32,14 @@ namespace {
 struct MfState {           // lives in device memory so that launches carry no per-batch host arguments
     long long grad_batch;  // number of gradient kernels run since create = 1-based index of the current mini-batch
     long long epoch;       // index (since create) of the epoch the next sampling kernel draws
+    double beta_1_power, beta_2_power;   // AsySVD: Adam's running products (advanced once per step, .pyx:536-539)
+    double asy_loss;
 };
 
 struct MfParams {
     int n_users, n_items, k, batch_size;
     int use_bias, sgd_mode, sample_negatives, algorithm_is_bpr;
-    float lr, user_reg, bias_reg, positive_reg, negative_reg, quota;
+    float lr, user_reg, item_reg, bias_reg, positive_reg, negative_reg, quota;
     float gamma, beta_1, beta_2, one_m_gamma, one_m_beta_1, one_m_beta_2;   // 1 - x formed in double on the host
     double beta_1_d, beta_2_d;
     unsigned long long seed;
@@ -292,6 +294,109 @@ __global__ __launch_bounds__(256) void mf_apply_kernel(const MfParams p) {
     }
 }
 
+// AsySVD (.pyx:393-541): batch_size is 1 and every step rewrites all the Y rows of the sampled user's profile, which
+// nearly every other profile shares -- the steps are executed strictly in order by ONE 1024-thread workgroup (16
+// wavefronts across the profile rows, lanes across the factors).  p.U is the n_items x k matrix Y ("USER_factors" in the
+// reference), p.V the item factors X.
+constexpr int ASY_KMAX = 256;
+__global__ __launch_bounds__(1024) void mf_asy_kernel(const MfParams p, const long long first, const int count) {
+    __shared__ float s_part[16][ASY_KMAX];
+    __shared__ float s_acc[ASY_KMAX], s_xi[ASY_KMAX];
+    __shared__ float s_err, s_pw1, s_pw2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = p.k;
+    double b1p = 0.0, b2p = 0.0, loss = 0.0;
+    if (tid == 0) {
+        b1p = p.state->beta_1_power;
+        b2p = p.state->beta_2_power;
+        loss = p.state->asy_loss;
+    }
+    for (int s = 0; s < count; ++s) {
+        const long long t = first + s;
+        const int u = p.su[t], i = p.si[t];
+        const float rating = p.sr[t];
+        const int rs = p.indptr[u], re = p.indptr[u + 1];
+        float *X = p.V + (size_t)i * k;
+        for (int f = tid; f < k; f += 1024) s_xi[f] = X[f];
+        // user vector: sum of the Y rows of the profile / sqrt(profile length)   (.pyx:424-441)
+        float part[ASY_KMAX / 64];
+#pragma unroll
+        for (int c = 0; c < ASY_KMAX / 64; ++c) part[c] = 0.f;
+        for (int q = rs + wave; q < re; q += 16) {
+            const float *Y = p.U + (size_t)p.indices[q] * k;
+#pragma unroll
+            for (int c = 0; c < ASY_KMAX / 64; ++c) {
+                const int f = lane + 64 * c;
+                if (f < k) part[c] += Y[f];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < ASY_KMAX / 64; ++c) {
+            const int f = lane + 64 * c;
+            if (f < k) s_part[wave][f] = part[c];
+        }
+        __syncthreads();
+        if (tid < k) {
+            float a = 0.f;
+            for (int w = 0; w < 16; ++w) a += s_part[w][tid];
+            s_acc[tid] = a / sqrtf((float)(re - rs));
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float dot = 0.f;
+            for (int f = lane; f < k; f += 64) dot += s_acc[f] * s_xi[f];
+            dot = wave_sum(dot);
+            if (lane == 0) {
+                float pred = dot;
+                if (p.use_bias) pred += p.mu[0] + p.bu[u] + p.bi[i];
+                const float err = rating - pred;
+                loss += (double)err * err;
+                const float pw1 = (float)(1.0 - b1p), pw2 = (float)(1.0 - b2p);
+                if (p.use_bias) {       // global, item, user bias -- in that order (.pyx:458-490)
+                    float g = adapt(p, err - p.bias_reg * p.mu[0], p.c_mu, p.c_mu + 1, 0, pw1, pw2);
+                    p.mu[0] += p.lr * g;
+                    g = adapt(p, err - p.bias_reg * p.bi[i], p.c1_bi, p.c2_bi, (size_t)i, pw1, pw2);
+                    p.bi[i] += p.lr * g;
+                    g = adapt(p, err - p.bias_reg * p.bu[u], p.c1_bu, p.c2_bu, (size_t)u, pw1, pw2);
+                    p.bu[u] += p.lr * g;
+                }
+                s_err = err;
+                s_pw1 = pw1;
+                s_pw2 = pw2;
+                if (p.sgd_mode == MI355REC_ADAM) {
+                    b1p *= p.beta_1_d;
+                    b2p *= p.beta_2_d;
+                }
+            }
+        }
+        __syncthreads();
+        const float err = s_err, pw1 = s_pw1, pw2 = s_pw2;
+        // every Y row of the profile moves against the OLD X[i]   (.pyx:493-511)
+        for (int q = rs + wave; q < re; q += 16) {
+            const size_t row = (size_t)p.indices[q];
+            float *Y = p.U + row * k;
+            for (int f = lane; f < k; f += 64) {
+                const float w = Y[f];
+                const float g = adapt(p, err * s_xi[f] - p.user_reg * w, p.c1U, p.c2U, row * k + f, pw1, pw2);
+                Y[f] = w + p.lr * g;
+            }
+        }
+        // X[i] moves against the user vector formed BEFORE the Y update   (.pyx:514-531)
+        if (tid < k) {
+            const float h = s_xi[tid];
+            const float g = adapt(p, err * s_acc[tid] - p.item_reg * h, p.c1V, p.c2V, (size_t)i * k + tid, pw1, pw2);
+            X[tid] = h + p.lr * g;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) {
+        p.state->beta_1_power = b1p;
+        p.state->beta_2_power = b2p;
+        p.state->asy_loss = loss;
+    }
+}
+
 }  // namespace
 }  // namespace mi355rec
 
@@ -300,6 +405,7 @@ using namespace mi355rec;
 struct mi355rec_mf {
     mi355rec_mf_config cfg{};
     int n_users = 0, n_items = 0, k = 0;
+    int n_u_rows = 0;                 // rows of U: n_users, or n_items for AsySVD
     size_t nnz = 0;
     hipStream_t stream = nullptr;
     StreamTimer timer;
@@ -331,17 +437,18 @@ namespace {
 long long batches_per_epoch(const mi355rec_mf *h) {
     // .pyx:583 (BPR: n_users / B + 1) and :289 (FunkSVD: nnz / B + 1)
     const long long B = h->cfg.batch_size;
+    // ASY_SVD: nnz / 1 + 1 single-sample steps (.pyx:397)
     return (h->cfg.algorithm == MI355REC_MF_BPR ? (long long)h->n_users / B : (long long)h->nnz / B) + 1;
 }
 
 void fill_params(mi355rec_mf *h, MfParams &p) {
     const auto &c = h->cfg;
     p.n_users = h->n_users; p.n_items = h->n_items; p.k = h->k; p.batch_size = c.batch_size;
-    p.use_bias = c.use_bias && c.algorithm == MI355REC_MF_FUNK_SVD;
+    p.use_bias = c.use_bias && c.algorithm != MI355REC_MF_BPR;
     p.sgd_mode = c.sgd_mode;
     p.algorithm_is_bpr = c.algorithm == MI355REC_MF_BPR;
     p.sample_negatives = c.negative_interactions_quota != 0.0;
-    p.lr = (float)c.learning_rate; p.user_reg = (float)c.user_reg; p.bias_reg = (float)c.bias_reg;
+    p.lr = (float)c.learning_rate; p.user_reg = (float)c.user_reg; p.item_reg = (float)c.item_reg; p.bias_reg = (float)c.bias_reg;
     p.positive_reg = (float)c.positive_reg; p.negative_reg = (float)c.negative_reg;
     p.quota = (float)c.negative_interactions_quota;
     p.gamma = (float)c.gamma; p.beta_1 = (float)c.beta_1; p.beta_2 = (float)c.beta_2;
@@ -396,8 +503,24 @@ void launch_sampler(mi355rec_mf *h, const MfParams &p) {
 }
 
 // One native epoch as plain launches (the first `timed` gradient launches carry per-dispatch events).
+constexpr int ASY_CHUNK = 1 << 16;   // steps per launch of the ordered AsySVD kernel (keeps single launches short)
+
+void enqueue_asy_steps(mi355rec_mf *h, const MfParams &p, long long n_steps, bool timed) {
+    for (long long first = 0; first < n_steps; first += ASY_CHUNK) {
+        const int count = (int)std::min<long long>(ASY_CHUNK, n_steps - first);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed) h->dispatch_timers.next(e0, e1, h->max_timed);
+        if (e0) hipExtLaunchKernelGGL(mf_asy_kernel, dim3(1), dim3(1024), 0, h->stream, e0, e1, 0, p, first, count);
+        else hipLaunchKernelGGL(mf_asy_kernel, dim3(1), dim3(1024), 0, h->stream, p, first, count);
+    }
+}
+
 void enqueue_epoch(mi355rec_mf *h, const MfParams &p, bool timed) {
     launch_sampler(h, p);
+    if (h->cfg.algorithm == MI355REC_MF_ASY_SVD) {
+        enqueue_asy_steps(h, p, p.samples_per_epoch, timed);
+        return;
+    }
     const long long nb = batches_per_epoch(h);
     for (long long b = 0; b < nb; ++b) launch_batch(h, p, (int)b, timed);
 }
@@ -434,12 +557,13 @@ void ensure_stream_capacity(mi355rec_mf *h, size_t n) {
 double bytes_per_sample(const mi355rec_mf *h) {
     // ALGORITHMIC lower bound of DESIGN.md section 4: every row a sample touches is read once and written once
     // (3 rows for BPR, 2 for FunkSVD), fp32.
-    const double rows = h->cfg.algorithm == MI355REC_MF_BPR ? 3.0 : 2.0;
+    const double rows = h->cfg.algorithm == MI355REC_MF_BPR ? 3.0 : 2.0;   // (AsySVD: its profile-sized term is added per call)
     return rows * 2.0 * 4.0 * (double)h->k;
 }
 
 void begin_call(mi355rec_mf *h) {
     MI_HIP(hipMemsetAsync(h->loss_slots.ptr, 0, sizeof(double) * h->cfg.batch_size, h->stream));
+    MI_HIP(hipMemsetAsync(&h->state.ptr->asy_loss, 0, sizeof(double), h->stream));
     h->dispatch_timers.reset();
 }
 
@@ -450,6 +574,11 @@ void finish_call(mi355rec_mf *h, long long n_samples, long long n_batches) {
     MI_HIP(hipStreamSynchronize(h->stream));
     double loss = 0;
     for (double v : h->host_loss) loss += v;
+    if (h->cfg.algorithm == MI355REC_MF_ASY_SVD) {
+        MfState st{};
+        MI_HIP(hipMemcpy(&st, h->state.ptr, sizeof(MfState), hipMemcpyDeviceToHost));
+        loss = st.asy_loss;
+    }
     h->stats.call_ms = h->timer.elapsed_ms();
     h->stats.kernel_ms = h->dispatch_timers.total_ms();
     h->stats.n_timed = h->dispatch_timers.used;
@@ -468,8 +597,12 @@ extern "C" int mi355rec_mf_create(mi355rec_mf_t *out, const mi355rec_mf_config *
     return guarded([&] {
         MI_REQUIRE(out && cfg && indptr && indices && data && U0 && V0, "NULL argument");
         MI_REQUIRE(n_users > 0 && n_items > 0, "empty URM");
-        MI_REQUIRE(cfg->algorithm == MI355REC_MF_BPR || cfg->algorithm == MI355REC_MF_FUNK_SVD,
+        MI_REQUIRE(cfg->algorithm >= MI355REC_MF_BPR && cfg->algorithm <= MI355REC_MF_ASY_SVD,
                    "Value for 'algorithm_name' not recognized (%d)", cfg->algorithm);
+        const bool asy = cfg->algorithm == MI355REC_MF_ASY_SVD;
+        MI_REQUIRE(!asy || cfg->batch_size == 1, "Batch size other than 1 not supported for ASY_SVD");
+        if (asy && cfg->n_factors > ASY_KMAX)
+            fail(MI355REC_E_UNSUPPORTED, "ASY_SVD: n_factors = %d exceeds %d", cfg->n_factors, ASY_KMAX);
         MI_REQUIRE(cfg->sgd_mode >= MI355REC_SGD && cfg->sgd_mode <= MI355REC_ADAM, "Value for 'sgd_mode' not recognized (%d)",
                    cfg->sgd_mode);
         MI_REQUIRE(cfg->n_factors >= 1, "n_factors must be >= 1");
@@ -480,12 +613,13 @@ extern "C" int mi355rec_mf_create(mi355rec_mf_t *out, const mi355rec_mf_config *
         h->n_users = n_users;
         h->n_items = n_items;
         h->k = cfg->n_factors;
+        h->n_u_rows = asy ? n_items : n_users;
         h->nnz = (size_t)indptr[n_users];
         MI_REQUIRE(h->nnz > 0, "URM has no interactions");
         MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->timer.init();
         hipStream_t s = h->stream;
-        const size_t nu = (size_t)n_users * h->k, ni = (size_t)n_items * h->k;
+        const size_t nu = (size_t)h->n_u_rows * h->k, ni = (size_t)n_items * h->k;
         h->indptr.upload(indptr, (size_t)n_users + 1, s);
         h->indices.upload(indices, h->nnz, s);
         h->data.upload(data, h->nnz, s);
@@ -516,6 +650,12 @@ extern "C" int mi355rec_mf_create(mi355rec_mf_t *out, const mi355rec_mf_config *
         h->list.alloc((size_t)cfg->batch_size * 3);
         h->loss_slots.alloc_zero((size_t)cfg->batch_size, s);
         h->state.alloc_zero(1, s);
+        {   // Adam's running beta powers start at beta^1 (.pyx:217-218)
+            MfState init{};
+            init.beta_1_power = cfg->beta_1;
+            init.beta_2_power = cfg->beta_2;
+            MI_HIP(hipMemcpyAsync(h->state.ptr, &init, sizeof(MfState), hipMemcpyHostToDevice, s));
+        }
         MI_HIP(hipStreamSynchronize(s));
         *out = h.release();
     });
@@ -536,7 +676,8 @@ extern "C" int mi355rec_mf_run_epochs(mi355rec_mf_t h, int32_t n_epochs) {
         // epochs whose gradient launches carry timing events run as plain launches, the rest replays the graph
         const long long timed_epochs = h->max_timed > 0 ? std::min<long long>(n_epochs, (h->max_timed + per_epoch - 1) / per_epoch) : 0;
         // MI355REC_NO_GRAPH=1: plain launches only (rocprofv3 on ROCm 7.2 crashes while tracing graph replays)
-        const bool use_graph = per_epoch <= MAX_GRAPH_BATCHES && n_epochs - timed_epochs > 0 && !getenv("MI355REC_NO_GRAPH");
+        const bool use_graph = per_epoch <= MAX_GRAPH_BATCHES && n_epochs - timed_epochs > 0 && !getenv("MI355REC_NO_GRAPH") &&
+                               h->cfg.algorithm != MI355REC_MF_ASY_SVD;
         if (use_graph) ensure_epoch_graph(h, p);
         h->timer.start(h->stream);
         for (long long e = 0; e < n_epochs; ++e) {
@@ -555,7 +696,7 @@ extern "C" int mi355rec_mf_run_samples(mi355rec_mf_t h, const int32_t *u, const 
     return guarded([&] {
         MI_REQUIRE(h && u && i, "NULL argument");
         const bool bpr = h->cfg.algorithm == MI355REC_MF_BPR;
-        MI_REQUIRE(bpr ? j != nullptr : rating != nullptr, "%s", bpr ? "BPR replay needs the negative items" : "FunkSVD replay needs the ratings");
+        MI_REQUIRE(bpr ? j != nullptr : rating != nullptr, "%s", bpr ? "BPR replay needs the negative items" : "FunkSVD / AsySVD replay needs the ratings");
         MI_REQUIRE(n >= 0, "n must be >= 0");
         ensure_device();
         if (n == 0) return;
@@ -572,6 +713,13 @@ extern "C" int mi355rec_mf_run_samples(mi355rec_mf_t h, const int32_t *u, const 
         const long long n_batches = (n + B - 1) / B;
         begin_call(h);
         h->timer.start(s);
+        if (h->cfg.algorithm == MI355REC_MF_ASY_SVD) {
+            enqueue_asy_steps(h, p, n, true);
+            h->timer.stop(s);
+            h->batches_done += n;
+            finish_call(h, n, (n + ASY_CHUNK - 1) / ASY_CHUNK);
+            return;
+        }
         for (long long b = 0; b < n_batches; ++b) {
             p.n_in_batch = (int)std::min<long long>(B, n - b * B);
             launch_batch(h, p, (int)b, true);
@@ -587,7 +735,7 @@ extern "C" int mi355rec_mf_get_factors(mi355rec_mf_t h, float *U, float *V, floa
         MI_REQUIRE(h, "NULL handle");
         ensure_device();
         hipStream_t s = h->stream;
-        if (U) h->U.download(U, (size_t)h->n_users * h->k, s);
+        if (U) h->U.download(U, (size_t)h->n_u_rows * h->k, s);
         if (V) h->V.download(V, (size_t)h->n_items * h->k, s);
         if (bu) h->bu.download(bu, h->n_users, s);
         if (bi) h->bi.download(bi, h->n_items, s);
@@ -607,7 +755,7 @@ extern "C" int mi355rec_mf_get_last_samples(mi355rec_mf_t h, int32_t *u, int32_t
         if (u) h->su.download(u, m, s);
         if (i) h->si.download(i, m, s);
         if (j && h->cfg.algorithm == MI355REC_MF_BPR) h->sj.download(j, m, s);
-        if (rating && h->cfg.algorithm == MI355REC_MF_FUNK_SVD) h->sr.download(rating, m, s);
+        if (rating && h->cfg.algorithm != MI355REC_MF_BPR) h->sr.download(rating, m, s);
         MI_HIP(hipStreamSynchronize(s));
     });
 }

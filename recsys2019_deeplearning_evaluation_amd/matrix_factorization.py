@@ -9,7 +9,7 @@ The epoch object keeps the reference constructor's argument names / defaults / V
 initialised on the host exactly as the reference does (np.random.seed(seed); normal(init_mean, init_std_dev)
 for U then V, .pyx:142-175) and live in HBM as float32 afterwards.  Sampling happens on the device
 (counter-based RNG seeded by random_seed); `replay_samples` runs the identical arithmetic on a given sample
-stream (parity mode).  AsySVD ("ASY_SVD") is not on the device path yet and raises NotImplementedError.
+stream (parity mode).  AsySVD ("ASY_SVD", batch_size 1) runs its steps strictly in order on one workgroup.
 """
 import ctypes as C
 import sys
@@ -38,7 +38,7 @@ class MatrixFactorization_MI355X_Epoch:
             raise ValueError("Value for 'algorithm_name' not recognized. Acceptable values are {}, provided was '{}'".format(
                 self.ALGORITHM_NAME_VALUES, algorithm_name))
         if algorithm_name == "ASY_SVD":
-            raise NotImplementedError("ASY_SVD is not on the MI355X device path yet")
+            assert batch_size == 1, "Batch size other than 1 not supported for ASY_SVD"
         URM_train = check_matrix(URM_train, "csr")
         URM_train = URM_train.sorted_indices()
         self.n_users, self.n_items = URM_train.shape
@@ -49,14 +49,16 @@ class MatrixFactorization_MI355X_Epoch:
         self.verbose = verbose
         if random_seed is not None:
             np.random.seed(seed=random_seed)
-        # same draw order as .pyx:174-175; an explicit initial model (parity tests) overrides the draw
-        U0 = np.random.normal(init_mean, init_std_dev, (self.n_users, self.n_factors))
+        # same draw order as .pyx:174-175; an explicit initial model (parity tests) overrides the draw.  AsySVD keeps two
+        # item-sized matrices (.pyx:163-166): its "USER_factors" is the n_items x k matrix Y
+        self.n_user_rows = self.n_items if algorithm_name == "ASY_SVD" else self.n_users
+        U0 = np.random.normal(init_mean, init_std_dev, (self.n_user_rows, self.n_factors))
         V0 = np.random.normal(init_mean, init_std_dev, (self.n_items, self.n_factors))
         if initial_USER_factors is not None:
             U0 = np.asarray(initial_USER_factors)
         if initial_ITEM_factors is not None:
             V0 = np.asarray(initial_ITEM_factors)
-        assert U0.shape == (self.n_users, self.n_factors) and V0.shape == (self.n_items, self.n_factors)
+        assert U0.shape == (self.n_user_rows, self.n_factors) and V0.shape == (self.n_items, self.n_factors)
         seed = int(random_seed) if random_seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
         cfg = N.MFConfig(N.ALGORITHM_CODES[algorithm_name], self.n_factors, self.batch_size, int(self.use_bias),
                          N.SGD_MODE_CODES[sgd_mode], learning_rate, user_reg, item_reg, bias_reg, positive_reg,
@@ -116,7 +118,7 @@ class MatrixFactorization_MI355X_Epoch:
 
     # ---- model read-back (fresh host copies, float32) ----
     def _download(self, want_bias):
-        U = np.empty((self.n_users, self.n_factors), np.float32)
+        U = np.empty((self.n_user_rows, self.n_factors), np.float32)
         V = np.empty((self.n_items, self.n_factors), np.float32)
         bu = bi = mu = None
         if want_bias:
@@ -169,7 +171,7 @@ class _MatrixFactorization_MI355X(GpuScoringMixin, BaseMatrixFactorizationRecomm
         common = dict(algorithm_name=self.algorithm_name, n_factors=num_factors, learning_rate=learning_rate,
                       sgd_mode=sgd_mode, user_reg=user_reg, batch_size=batch_size, use_bias=use_bias,
                       init_mean=init_mean, init_std_dev=init_std_dev, verbose=self.verbose, random_seed=random_seed)
-        if self.algorithm_name == "FUNK_SVD":
+        if self.algorithm_name in ("FUNK_SVD", "ASY_SVD"):
             # as in the reference wrapper (.py:63-77) positive_reg is NOT forwarded, so items end up unregularised
             self.epoch_kernel = MatrixFactorization_MI355X_Epoch(
                 self.URM_train, item_reg=item_reg, bias_reg=bias_reg,
@@ -236,3 +238,38 @@ class MatrixFactorization_FunkSVD_MI355X(_MatrixFactorization_MI355X):
 
     def fit(self, **key_args):
         super(MatrixFactorization_FunkSVD_MI355X, self).fit(**key_args)
+
+
+class MatrixFactorization_AsySVD_MI355X(_MatrixFactorization_MI355X):
+    """Drop-in for MatrixFactorization_AsySVD_Cython (MatrixFactorization_Cython.py:219): two item-sized factor matrices;
+    a user's factors are the sum of the Y rows of its profile divided by sqrt(profile length)."""
+    RECOMMENDER_NAME = "MatrixFactorization_AsySVD_MI355X_Recommender"
+
+    def __init__(self, *pos_args, **key_args):
+        super(MatrixFactorization_AsySVD_MI355X, self).__init__(*pos_args, algorithm_name="ASY_SVD", **key_args)
+
+    def fit(self, **key_args):
+        if key_args.get("batch_size", 1) > 1:
+            print("{}: batch_size not supported for this recommender, setting to default value 1.".format(self.RECOMMENDER_NAME))
+        key_args["batch_size"] = 1
+        super(MatrixFactorization_AsySVD_MI355X, self).fit(**key_args)
+
+    def _prepare_model_for_validation(self):
+        self.ITEM_factors_Y, self.ITEM_factors = self.epoch_kernel.get_factors()
+        self.USER_factors = self._estimate_user_factors(self.ITEM_factors_Y)
+        if self.use_bias:
+            self.USER_bias = self.epoch_kernel.get_USER_bias()
+            self.ITEM_bias = self.epoch_kernel.get_ITEM_bias()
+            self.GLOBAL_bias = self.epoch_kernel.get_GLOBAL_bias()
+
+    def _update_best_model(self):
+        super(MatrixFactorization_AsySVD_MI355X, self)._update_best_model()
+        self.ITEM_factors_Y_best = self.ITEM_factors_Y.copy()
+
+    def _estimate_user_factors(self, ITEM_factors_Y):
+        # MatrixFactorization_Cython.py:281-304: URM . Y, every row divided by sqrt(profile length)
+        length_sqrt = np.sqrt(np.ediff1d(self.URM_train.indptr))
+        USER_factors = self.URM_train.dot(ITEM_factors_Y)
+        warm = length_sqrt > 0
+        USER_factors[warm] /= length_sqrt[warm][:, None]
+        return USER_factors

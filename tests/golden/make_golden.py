@@ -92,6 +92,12 @@ def main():
                           negative_interactions_quota=0.3)))
     cases.append(dict(matrix="Xr", epochs=2, kw=dict(n_factors=5, algorithm_name="FUNK_SVD", batch_size=1, random_seed=7,
                       sgd_mode="sgd", learning_rate=0.02, use_bias=False, negative_interactions_quota=0.0)))
+    for mode in ["sgd", "adagrad", "rmsprop", "adam"]:      # AsySVD: batch_size 1, two item-sized matrices
+        cases.append(dict(matrix="Xr", epochs=2, kw=dict(n_factors=7, algorithm_name="ASY_SVD", batch_size=1, random_seed=303,
+                          sgd_mode=mode, learning_rate=0.01, user_reg=0.01, item_reg=0.02, bias_reg=0.03, use_bias=True,
+                          negative_interactions_quota=0.3)))
+    cases.append(dict(matrix="Xr", epochs=1, kw=dict(n_factors=70, algorithm_name="ASY_SVD", batch_size=1, random_seed=304,
+                      sgd_mode="sgd", learning_rate=0.005, use_bias=False, negative_interactions_quota=0.0)))
     for n, case in enumerate(cases):
         Xc = Xb if case["matrix"] == "Xb" else Xr
         m = MF(Xc, **case["kw"])

@@ -95,7 +95,7 @@ def test_golden_fixture_replay(gpu):
         u, i, j, r = orc.recorded()
         dev = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=orc.initial_USER_factors,
                                                initial_ITEM_factors=orc.initial_ITEM_factors, **kw)
-        dev.replay_samples(u, i, neg_item=j, rating=r) if kw["algorithm_name"] == "MF_BPR" else dev.replay_samples(u, i, rating=r)
+        dev.replay_samples(u, i, neg_item=j) if kw["algorithm_name"] == "MF_BPR" else dev.replay_samples(u, i, rating=r)
         mode = kw["sgd_mode"]
         assert_factor_parity(dev.get_USER_factors(), z["U_%d" % n], mode, "U")
         assert_factor_parity(dev.get_ITEM_factors(), z["V_%d" % n], mode, "V")
@@ -236,3 +236,48 @@ def test_full_size_ml20m_k128_properties(gpu):
     assert np.abs(dB - 2 * dA).max() <= 1e-4 * np.abs(dB).max()
     st = a.stats()
     assert st["n_units"] == 1000
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("k", [5, 64, 130])
+def test_asysvd_replay_parity(gpu, mode, k):
+    """AsySVD (MatrixFactorization_Cython_Epoch.pyx:393-541): nnz + 1 strictly ordered single-sample steps."""
+    X = named_urm("ml1m", "real", scale=0.05)                 # 302 x 185, ~3 k interactions per epoch
+    kw = dict(n_factors=k, algorithm_name="ASY_SVD", batch_size=1, random_seed=17, sgd_mode=mode, learning_rate=0.005,
+              user_reg=0.01, item_reg=0.02, bias_reg=0.02, use_bias=True, negative_interactions_quota=0.4)
+    orc = O.OracleMF(X, **kw)
+    orc.record_samples(10 ** 6)
+    orc.epochIteration_Cython(); orc.epochIteration_Cython()
+    u, i, _, r = orc.recorded()
+    dev = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=orc.initial_USER_factors,
+                                           initial_ITEM_factors=orc.initial_ITEM_factors, **kw)
+    assert dev.get_USER_factors().shape == (X.shape[1], k)       # the "user" matrix is item-sized
+    dev.replay_samples(u, i, rating=r)
+    assert_factor_parity(dev.get_USER_factors(), orc.get_USER_factors(), mode, "Y")
+    assert_factor_parity(dev.get_ITEM_factors(), orc.get_ITEM_factors(), mode, "X")
+    assert_factor_parity(dev.get_ITEM_bias(), orc.get_ITEM_bias(), mode, "bi")
+    assert dev.stats()["n_units"] == len(u) == 2 * (X.nnz + 1)
+    dev.close()
+
+
+def test_asysvd_native_epoch_and_recommender(gpu):
+    from recsys2019_deeplearning_evaluation_amd import MatrixFactorization_AsySVD_MI355X
+    X = named_urm("ml1m", "real", scale=0.05)
+    kw = dict(n_factors=12, algorithm_name="ASY_SVD", batch_size=1, random_seed=4, sgd_mode="sgd", learning_rate=0.005,
+              negative_interactions_quota=0.0)
+    orc = O.OracleMF(X, **kw)
+    dev = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=orc.initial_USER_factors,
+                                           initial_ITEM_factors=orc.initial_ITEM_factors, **kw)
+    dev.epochIteration_Cython()
+    u, i, r = dev.last_epoch_samples()
+    assert len(u) == X.nnz + 1
+    np.testing.assert_array_equal(X.toarray()[u, i], r)           # quota 0 => every sample is a stored interaction
+    orc.replay(u, i, rating=r.astype(np.float64))
+    assert rel_err(dev.get_USER_factors(), orc.get_USER_factors()) < RTOL
+    assert rel_err(dev.get_ITEM_factors(), orc.get_ITEM_factors()) < RTOL
+    rec = MatrixFactorization_AsySVD_MI355X(X, verbose=False)
+    rec.fit(epochs=2, num_factors=8, learning_rate=0.005, use_bias=True, random_seed=1, batch_size=64)
+    assert rec.ITEM_factors_Y.shape == (X.shape[1], 8) and rec.USER_factors.shape == (X.shape[0], 8)
+    assert len(rec.recommend(3, cutoff=5)) == 5
+    with pytest.raises(AssertionError):
+        MatrixFactorization_MI355X_Epoch(X, n_factors=4, algorithm_name="ASY_SVD", batch_size=2)
