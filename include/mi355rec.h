@@ -80,6 +80,9 @@ typedef struct {
     int32_t normalize;
     int32_t similarity;      /* MI355REC_SIM_* */
     float   asymmetric_alpha, tversky_alpha, tversky_beta;   /* `cdef float` in the reference (.pyx:65) */
+    int32_t unit_column_side;   /* 1: the value of (row u, column c) on the COLUMN side of the product is taken as 1, i.e.
+                                 * out(c, j) = sum over the rows u storing c of data[u, j] -- the boolean-transpose product of
+                                 * the graph recommenders (GraphBased/P3alphaRecommender.py:69-104); 0: the plain self-product */
 } mi355rec_sim_config;
 
 typedef struct mi355rec_sim *mi355rec_sim_t;

@@ -36,7 +36,8 @@ class Stats(C.Structure):
 
 class SimConfig(C.Structure):
     _fields_ = [("topK", C.c_int32), ("shrink", C.c_int32), ("normalize", C.c_int32), ("similarity", C.c_int32),
-                ("asymmetric_alpha", C.c_float), ("tversky_alpha", C.c_float), ("tversky_beta", C.c_float)]
+                ("asymmetric_alpha", C.c_float), ("tversky_alpha", C.c_float), ("tversky_beta", C.c_float),
+                ("unit_column_side", C.c_int32)]
 
 
 class MFConfig(C.Structure):

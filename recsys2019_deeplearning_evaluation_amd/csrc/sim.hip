@@ -26,7 +26,7 @@ constexpr int MAX_TILE = 32256;   // cells of the LDS accumulator: 4 B * 32256 +
 struct SimParams {
     int n_rows, n_cols, n_cols_pad;
     int topK, sortP;
-    int kind, normalize;
+    int kind, normalize, unit_col;
     float shrink, tversky_alpha, tversky_beta;
     const int *csr_ptr;
     const unsigned short *csr_idx16;   // column ids relative to their tile base, as uint16 (tile width <= 32256)
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             const int q = base + lane;
             const bool valid = q < cend;
             const int u = valid ? p.csc_idx[q] : 0;
-            float r = valid ? (UNIT ? 1.f : p.csc_val[q]) : 0.f;
+            float r = valid ? ((UNIT || p.unit_col) ? 1.f : p.csc_val[q]) : 0.f;
             if (!UNIT && p.row_w && valid) r *= p.row_w[u];
             int rs = 0, re = 0;
             if (valid) {
@@ -566,6 +566,7 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     p.sortP = P;
     p.kind = h->cfg.similarity;
     p.normalize = h->cfg.normalize;
+    p.unit_col = h->cfg.unit_column_side;
     p.shrink = (float)h->cfg.shrink;
     p.tversky_alpha = h->cfg.tversky_alpha;
     p.tversky_beta = h->cfg.tversky_beta;

@@ -35,7 +35,7 @@ class Compute_Similarity_MI355X:
     SIMILARITY_VALUES = ("cosine", "pearson", "adjusted", "asymmetric", "jaccard", "tanimoto", "dice", "tversky")
 
     def __init__(self, dataMatrix, topK=100, shrink=0, normalize=True, asymmetric_alpha=0.5, tversky_alpha=1.0,
-                 tversky_beta=1.0, similarity="cosine", row_weights=None):
+                 tversky_beta=1.0, similarity="cosine", row_weights=None, unit_column_side=False):
         if similarity not in self.SIMILARITY_VALUES:
             raise ValueError("Cosine_Similarity: value for parameter 'mode' not recognized."
                              " Allowed values are: 'cosine', 'pearson', 'adjusted', 'asymmetric', 'jaccard', 'tanimoto',"
@@ -52,7 +52,7 @@ class Compute_Similarity_MI355X:
         indptr, indices, data = N.as_i32(csr.indptr), N.as_i32(csr.indices), N.as_f32(csr.data)
         rw = None if row_weights is None else N.as_f32(row_weights)
         cfg = N.SimConfig(self.TopK, int(shrink), int(bool(normalize)), N.SIMILARITY_CODES[similarity],
-                          float(asymmetric_alpha), float(tversky_alpha), float(tversky_beta))
+                          float(asymmetric_alpha), float(tversky_alpha), float(tversky_beta), int(bool(unit_column_side)))
         self._lib = N.load()
         self._h = C.c_void_p()
         N.check(self._lib.mi355rec_sim_create(C.byref(self._h), C.byref(cfg), self.n_rows, self.n_columns,

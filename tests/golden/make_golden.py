@@ -155,6 +155,21 @@ def main():
     out["tfidf_T"] = tfidf(Xw.astype(np.float32).T).T.toarray()
     out["cases"] = np.array(json.dumps([]))
     np.savez_compressed(os.path.join(HERE, "feature_weighting.npz"), **out)
+    # ---------------- P3alpha / RP3beta (pure-Python reference) ----------------
+    P3 = ref_loader.load_python_reference("GraphBased.P3alphaRecommender", "P3alphaRecommender")
+    RP3 = ref_loader.load_python_reference("GraphBased.RP3betaRecommender", "RP3betaRecommender")
+    Xg = small_urm(70, 45, 0.18, 17, real=True)
+    out = pack_csr("X", Xg)
+    cases = [dict(cls="P3", kw=dict(topK=8, alpha=1.0, normalize_similarity=False)),
+             dict(cls="P3", kw=dict(topK=8, alpha=0.7, normalize_similarity=True, min_rating=2, implicit=True)),
+             dict(cls="RP3", kw=dict(topK=8, alpha=1.0, beta=0.6, normalize_similarity=True)),
+             dict(cls="RP3", kw=dict(topK=6, alpha=1.3, beta=0.3, normalize_similarity=False))]
+    for n, case in enumerate(cases):
+        rec = quiet(lambda: (P3 if case["cls"] == "P3" else RP3)(Xg.copy(), verbose=False))
+        quiet(lambda: rec.fit(**case["kw"]))
+        out["W_%d" % n] = rec.W_sparse.toarray().astype(np.float64)
+    out["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(HERE, "graph_based.npz"), **out)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
