@@ -47,6 +47,7 @@ class _RandomWalkRecommender(GpuSimilarityScoringMixin, BaseItemSimilarityMatrix
         row_factor = np.zeros(n_items)
         row_factor[item_count != 0] = np.power(1.0 / item_count[item_count != 0], alpha)
         W = rows_slabs_to_csr(idx, (val * row_factor[:, None]).astype(np.float32), n_items)
+        self.W_rowwise = W                  # per-row top-K of the walk, before normalisation / the column-wise cut
         if normalize_similarity:
             norm = np.asarray(abs(W).sum(axis=1)).ravel()
             inv = np.divide(1.0, norm, out=np.zeros_like(norm), where=norm != 0)

@@ -161,7 +161,7 @@ def main():
     Xg = small_urm(70, 45, 0.18, 17, real=True)
     out = pack_csr("X", Xg)
     cases = [dict(cls="P3", kw=dict(topK=8, alpha=1.0, normalize_similarity=False)),
-             dict(cls="P3", kw=dict(topK=8, alpha=0.7, normalize_similarity=True, min_rating=2, implicit=True)),
+             dict(cls="P3", kw=dict(topK=8, alpha=0.7, normalize_similarity=True, min_rating=2, implicit=False)),
              dict(cls="RP3", kw=dict(topK=8, alpha=1.0, beta=0.6, normalize_similarity=True)),
              dict(cls="RP3", kw=dict(topK=6, alpha=1.3, beta=0.3, normalize_similarity=False))]
     for n, case in enumerate(cases):
