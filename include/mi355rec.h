@@ -105,6 +105,9 @@ int mi355rec_sim_compute_dense(mi355rec_sim_t h, int32_t start_col, int32_t end_
 /* cost(c) = sum over users of column c of their profile length: the work of one column; used to cut
  * cost-balanced column ranges for multi-GPU sharding. */
 int mi355rec_sim_column_costs(mi355rec_sim_t h, int64_t *cost /* n_cols */);
+/* Schedule of the last compute call: work items queued, columns that were split over several workgroups, and the
+ * number of parts they were split into (diagnostics; a heavy column is accumulated by several workgroups). */
+int mi355rec_sim_schedule_info(mi355rec_sim_t h, int32_t *n_items, int32_t *n_split_columns, int32_t *n_parts);
 int mi355rec_sim_sync(mi355rec_sim_t h);
 int mi355rec_sim_get_stats(mi355rec_sim_t h, mi355rec_stats *stats);
 void mi355rec_sim_destroy(mi355rec_sim_t h);

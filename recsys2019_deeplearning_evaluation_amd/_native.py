@@ -70,6 +70,7 @@ SIGNATURES = {
     "mi355rec_sim_compute_device": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355rec_sim_compute_dense": (C.c_int, [_vp, _i32, _i32, _vp, _i64]),
     "mi355rec_sim_column_costs": (C.c_int, [_vp, _vp]),
+    "mi355rec_sim_schedule_info": (C.c_int, [_vp, _vp, _vp, _vp]),
     "mi355rec_sim_sync": (C.c_int, [_vp]),
     "mi355rec_sim_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "mi355rec_sim_destroy": (None, [_vp]),

@@ -39,24 +39,25 @@ struct SimParams {
     const float *csc_val;
     const float *row_w;
     const float *norm, *norm_alpha, *norm_1ma;
-    const int *order;  // columns of this call, most expensive first
-    int n_local, start_col;
+    const int4 *items;  // work items of this call, most expensive first: {column, part, n_parts, first part slot}
+    int n_items, start_col;
+    uint32_t *part_buf;     // [part slots][n_cols_pad] partial accumulators of split columns
+    unsigned *part_count;   // arrival counters, indexed by the first part slot of a split column
+    unsigned long long *phase_ticks;   // diagnostics (MI355REC_SIM_PHASES=1): 100 MHz ticks per phase, summed over workgroups
     unsigned *queue;
     int *out_idx;
     float *out_val;
     float *out_dense;  // [n_local][n_cols] when topK == 0
 };
 
-// Denominators of compute_similarity (.pyx:473-504); the +1e-6 is the reference's.
-__device__ __forceinline__ float normalise(const SimParams &p, float v, int c, int j) {
-    if (p.normalize) {
-        float den = (p.kind == MI355REC_SIM_ASYMMETRIC) ? p.norm_alpha[c] * p.norm_1ma[j] : p.norm[c] * p.norm[j];
-        return v / (den + p.shrink + 1e-6f);
-    }
-    if (p.kind == MI355REC_SIM_JACCARD) return v / (p.norm[c] + p.norm[j] - v + p.shrink + 1e-6f);
-    if (p.kind == MI355REC_SIM_DICE) return v / (p.norm[c] + p.norm[j] + p.shrink + 1e-6f);
+// Denominators of compute_similarity (.pyx:473-504); the +1e-6 is the reference's.  norm_c / norm_j are the column
+// norms of the two items (asymmetric cosine: norm^(2 alpha) of c and norm^(2 (1 - alpha)) of j).
+__device__ __forceinline__ float normalise(const SimParams &p, float v, float norm_c, float norm_j) {
+    if (p.normalize) return v / (norm_c * norm_j + p.shrink + 1e-6f);
+    if (p.kind == MI355REC_SIM_JACCARD) return v / (norm_c + norm_j - v + p.shrink + 1e-6f);
+    if (p.kind == MI355REC_SIM_DICE) return v / (norm_c + norm_j + p.shrink + 1e-6f);
     if (p.kind == MI355REC_SIM_TVERSKY)
-        return v / (v + (p.norm[c] - v) * p.tversky_alpha + (p.norm[j] - v) * p.tversky_beta + p.shrink + 1e-6f);
+        return v / (v + (norm_c - v) * p.tversky_alpha + (norm_j - v) * p.tversky_beta + p.shrink + 1e-6f);
     if (p.shrink != 0.f) return v / p.shrink;
     return v;
 }
@@ -69,19 +70,33 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
     float *acc = smem;
     uint32_t *aux = reinterpret_cast<uint32_t *>(smem + p.n_cols_pad);
     __shared__ SelectScratch sc;
-    __shared__ int s_col;
-    __shared__ uint32_t s_npos, s_nneg, s_ncand;
+    __shared__ int s_col, s_last;
+    __shared__ uint32_t s_npos, s_nneg, s_ncand, s_kmin, s_kmax;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int gl = tid % G;
 
+    unsigned long long t_prev = p.phase_ticks ? wall_clock64() : 0ull;
+    auto mark = [&](int phase) {
+        if (p.phase_ticks && tid == 0) {
+            const unsigned long long now = wall_clock64();
+            atomicAdd(&p.phase_ticks[phase], now - t_prev);
+            t_prev = now;
+        }
+    };
     for (;;) {
         if (tid == 0) s_col = (int)atomicAdd(p.queue, 1u);
         __syncthreads();
         const int slot = s_col;
-        if (slot >= p.n_local) break;
-        const int c = p.order[slot];
-        const int cbeg = p.csc_ptr[c], cend = p.csc_ptr[c + 1];
+        if (slot >= p.n_items) break;
+        const int4 item = p.items[slot];
+        const int c = item.x;
+        int cbeg = p.csc_ptr[c], cend = p.csc_ptr[c + 1];
+        if (item.z > 1) {   // a heavy column split over several workgroups: this one walks users [cbeg, cend) of it
+            const int per = (((cend - cbeg + item.z - 1) / item.z) + 63) & ~63;
+            cbeg = min(cend, cbeg + item.y * per);
+            cend = min(cend, cbeg + per);
+        }
         const size_t out_base = (size_t)(c - p.start_col) * p.topK;
         int *wg_cand_idx = p.cand_idx + (size_t)blockIdx.x * p.n_tiles * p.topK;
         float *wg_cand_val = p.cand_val + (size_t)blockIdx.x * p.n_tiles * p.topK;
@@ -97,6 +112,8 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             s_npos = 0;
             s_nneg = 0;
             s_ncand = 0;
+            s_kmin = 0xFFFFFFFFu;
+            s_kmax = 0u;
         }
 
         // ---- clear this_item_weights (.pyx:365-370) ----
@@ -105,27 +122,38 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) a4[w] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
+        mark(0);
 
         // ---- computeItemSimilarities (.pyx:376-406): users of column c, then every item of each user ----
-        // A wavefront takes 64 users of the column at a time: lane l loads user l's id, weight and CSR row bounds
-        // (the only dependent loads, paid once per 64 users).  The profiles are then streamed with the bounds
-        // broadcast from the owning lane, G lanes per profile; every lane reads 16-byte chunks = 8 uint16 column
-        // ids (aligned; the first chunk may start before the row, the last may run past it: both masked), two
-        // chunks in flight.  UNIT data accumulates integer counts (ds_add_u32 runs ~3x faster than ds_add_f32 on
-        // gfx950 and is exact); otherwise float products.
+        // The column's users are dealt to the wavefronts in equal contiguous runs (a column with few users -- the long
+        // tail: most columns have far fewer than WAVES x 64 of them -- still keeps every wavefront busy).  A wavefront
+        // takes 64 of its users per round: lane l loads user l's id, weight and CSR bounds (the only dependent loads)
+        // into a wavefront-private table in the selection scratch.  Its GPW lane groups then walk the table
+        // round-robin, streaming each profile in aligned 16-byte chunks (8 uint16 column ids per lane; the first chunk
+        // may start before the row and the last may run past it: both masked).
+        // The stream is latency-bound (one workgroup per CU = 16 wavefronts, each load ~1 us away), so every group
+        // runs a fetch cursor DEPTH chunks ahead of its consume cursor: DEPTH loads per lane in flight, issued
+        // unconditionally (finished groups re-read a hot line) so that the wait counters are static and the consume
+        // side only ever waits for the oldest chunk.
+        // UNIT data accumulates integer counts (ds_add_u32 runs ~3x faster than ds_add_f32 on gfx950 and is exact);
+        // otherwise float products.
         constexpr int WAVES = THREADS / 64, GPW = 64 / G;
+        constexpr int DEPTH = UNIT ? 4 : 2;
         const int wave = tid >> 6, sub = lane / G;
         unsigned *acc_u = reinterpret_cast<unsigned *>(acc);
         const uint4 *idx8 = reinterpret_cast<const uint4 *>(p.csr_idx16);
         const float4 *val4 = reinterpret_cast<const float4 *>(p.csr_val);
-        for (int base = cbeg + wave * 64; base < cend; base += WAVES * 64) {
-            const int q = base + lane;
-            const bool valid = q < cend;
-            const int u = valid ? p.csc_idx[q] : 0;
-            float r = valid ? ((UNIT || p.unit_col) ? 1.f : p.csc_val[q]) : 0.f;
-            if (!UNIT && p.row_w && valid) r *= p.row_w[u];
-            int rs = 0, re = 0;
-            if (valid) {
+        int *tab = reinterpret_cast<int *>(aux) + wave * 192;       // [64] x {rs, re, weight}
+        const int per_wave = (cend - cbeg + WAVES - 1) / WAVES;
+        const int wbeg = min(cend, cbeg + wave * per_wave), wend = min(cend, wbeg + per_wave);
+        for (int base = wbeg; base < wend; base += 64) {
+            const int n_here = min(64, wend - base);
+            if (lane < n_here) {
+                const int q = base + lane;
+                const int u = p.csc_idx[q];
+                float r = (UNIT || p.unit_col) ? 1.f : p.csc_val[q];
+                if (!UNIT && p.row_w) r *= p.row_w[u];
+                int rs, re;
                 if (p.n_tiles == 1) {
                     rs = p.csr_ptr[u];
                     re = p.csr_ptr[u + 1];
@@ -134,80 +162,157 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                     rs = tp[0];
                     re = tp[1];
                 }
+                tab[lane * 3] = rs;
+                tab[lane * 3 + 1] = re;
+                tab[lane * 3 + 2] = __float_as_int(r);
             }
-            const int n_here = min(64, cend - base);
-            // Flat, software-pipelined walk over the 16-byte chunks of this group's profiles: the load of chunk
-            // n+1 is issued before chunk n is accumulated.  Control flow is uniform inside a group; lanes whose
-            // entries fall outside [rs, re) add 0 to a private dummy word, so the inner loop has no branches.
-            int m = sub - GPW, t = 0, tend = 0, rs_m = 0, re_m = 0;
-            float r_m = 0.f;
-            bool have = true;
-            // Moves every group to its next chunk.  Executed by ALL 64 lanes with a wave-uniform trip count: the
-            // cross-lane reads (ds_bpermute) return 0 for inactive source lanes, so no lane may sit this out.
-            auto advance = [&]() {
-                if (have) t += 8 * G;
-                for (;;) {
-                    const bool need = have && t >= tend;             // this group wants its next user
-                    if (!__any(need)) break;
-                    const int m_next = m + GPW;
-                    const bool can = need && m_next < n_here;
-                    const int src = can ? m_next : lane;
-                    const int a = __shfl(rs, src), b = __shfl(re, src);
-                    const float cr = __shfl(r, src);
-                    if (need) {
-                        if (can) {
-                            m = m_next; rs_m = a; re_m = b; r_m = cr;
-                            t = a & ~7; tend = b;
-                        } else {
-                            have = false;
-                        }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // fetch cursor of this lane group
+            int m = sub - GPW, f_t = 0, f_end = 0, f_rs = 0, f_re = 0;
+            float f_r = 0.f;
+            bool f_have = true;
+            auto next_user = [&]() {        // moves the fetch cursor to the group's next non-empty profile
+                do {
+                    m += GPW;
+                    f_have = m < n_here;
+                    if (f_have) {
+                        f_rs = tab[m * 3];
+                        f_re = tab[m * 3 + 1];
+                        f_r = __int_as_float(tab[m * 3 + 2]);
+                        f_t = f_rs & ~7;
+                        f_end = f_re;
+                    }
+                } while (f_have && f_t >= f_end);     // empty segments exist only with accumulator tiles
+            };
+            next_user();
+            uint4 ids[DEPTH];
+            float4 vlo[DEPTH], vhi[DEPTH];
+            int c_t[DEPTH], c_rs[DEPTH], c_re[DEPTH];
+            float c_r[DEPTH];
+            int pending = 0;
+            auto fetch = [&](int d) {
+                const int at = f_have ? f_t + 8 * gl : 8 * gl;       // finished groups: a valid, cache-hot address
+                c_t[d] = at;
+                c_rs[d] = f_have ? f_rs : 0;
+                c_re[d] = f_have ? f_re : 0;
+                c_r[d] = f_r;
+                ids[d] = idx8[at >> 3];
+                if (!UNIT) {
+                    vlo[d] = val4[at >> 2];
+                    vhi[d] = val4[(at >> 2) + 1];
+                }
+                if (f_have) {
+                    ++pending;
+                    f_t += 8 * G;
+                    if (f_t >= f_end) next_user();
+                }
+            };
+            auto consume = [&](int d) {
+                if (c_re[d] > c_rs[d]) --pending;
+                const unsigned ww[4] = {ids[d].x, ids[d].y, ids[d].z, ids[d].w};
+                const float vv[8] = {vlo[d].x, vlo[d].y, vlo[d].z, vlo[d].w, vhi[d].x, vhi[d].y, vhi[d].z, vhi[d].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int tt = c_t[d] + e;
+                    const unsigned j = (ww[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                    if (tt >= c_rs[d] && tt < c_re[d]) {
+                        if (UNIT) atomicAdd(&acc_u[j], 1u);
+                        else atomicAdd(&acc[j], c_r[d] * vv[e]);
                     }
                 }
             };
-            advance();
-            uint4 w = make_uint4(0, 0, 0, 0);
-            if (have) w = idx8[(t >> 3) + gl];
-            while (__any(have)) {
-                const bool c_have = have;
-                const int c_t = t + 8 * gl, c_rs = rs_m, c_re = re_m;
-                const float c_r = r_m;
-                const uint4 cw = w;
-                float vv[8];
-                if (!UNIT && c_have) {
-                    const float4 lo = val4[c_t >> 2], hi = val4[(c_t >> 2) + 1];
-                    vv[0] = lo.x; vv[1] = lo.y; vv[2] = lo.z; vv[3] = lo.w;
-                    vv[4] = hi.x; vv[5] = hi.y; vv[6] = hi.z; vv[7] = hi.w;
-                }
-                advance();
-                if (have) w = idx8[(t >> 3) + gl];
-                if (c_have) {
-                    const unsigned ww[4] = {cw.x, cw.y, cw.z, cw.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int tt = c_t + e;
-                        const bool ok = tt >= c_rs && tt < c_re;
-                        const unsigned j = (ww[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-                        const unsigned at = ok ? j : (unsigned)lane;
-                        if (UNIT) atomicAdd(&acc_u[at], ok ? 1u : 0u);
-                        else atomicAdd(&acc[at], ok ? c_r * vv[e] : 0.f);
-                    }
+            for (int d = 0; d < DEPTH; ++d) fetch(d);
+            while (pending > 0) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    consume(d);
+                    fetch(d);
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // the table is rewritten by the next round
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        mark(1);
+        if (item.z > 1) {
+            // Split column: publish this part's accumulator; the workgroup that arrives last adds the parts up (in
+            // part order, so the float result does not depend on arrival order) and carries on with the column.
+            // Nobody waits for anybody.
+            {
+                uint4 *dst = reinterpret_cast<uint4 *>(p.part_buf + (size_t)(item.w + item.y) * p.n_cols_pad);
+                const uint4 *src = reinterpret_cast<const uint4 *>(acc);
+                for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) dst[w] = src[w];
+            }
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) s_last = atomicAdd(&p.part_count[item.w], 1u) == (unsigned)(item.z - 1);
+            __syncthreads();
+            if (!s_last) continue;
+            __threadfence();
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.part_buf + (size_t)item.w * p.n_cols_pad);
+            const size_t stride4 = (size_t)p.n_cols_pad / 4;
+            for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) {
+                uint4 a = src[w];
+                for (int q = 1; q < item.z; ++q) {
+                    const uint4 b = src[q * stride4 + w];
+                    if (UNIT) {
+                        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                    } else {
+                        a.x = __float_as_uint(__uint_as_float(a.x) + __uint_as_float(b.x));
+                        a.y = __float_as_uint(__uint_as_float(a.y) + __uint_as_float(b.y));
+                        a.z = __float_as_uint(__uint_as_float(a.z) + __uint_as_float(b.z));
+                        a.w = __float_as_uint(__uint_as_float(a.w) + __uint_as_float(b.w));
+                    }
+                }
+                reinterpret_cast<uint4 *>(acc)[w] = a;
+            }
+            __syncthreads();
+            mark(2);
         }
         // the diagonal was accumulated like any other cell: clear it (the reference never adds to it, .pyx:392)
-        __syncthreads();
         if (tid == 0 && c >= tile_base && c < tile_base + n_tile) acc[c - tile_base] = 0.f;
         __syncthreads();
 
         // ---- normalisation (.pyx:473-504), in place; count signs for the selection ----
-        uint32_t npos = 0, nneg = 0;
-        for (int j = tid; j < n_tile; j += THREADS) {
-            float v = UNIT ? (float)acc_u[j] : acc[j];
-            if (v != 0.f) {
-                v = normalise(p, v, c, tile_base + j);
-                acc[j] = v;
-                npos += v > 0.f;
-                nneg += v < 0.f;
+        uint32_t npos = 0, nneg = 0, kmin = 0xFFFFFFFFu, kmax = 0u;   // key range of the positive cells
+        {
+            const bool asym = p.normalize && p.kind == MI355REC_SIM_ASYMMETRIC;
+            const float norm_c = asym ? p.norm_alpha[c] : p.norm[c];
+            const float4 *nj4 = reinterpret_cast<const float4 *>((asym ? p.norm_1ma : p.norm) + tile_base);
+            float4 *a4 = reinterpret_cast<float4 *>(acc);
+            // four cells per thread and step (the norm arrays are padded to a multiple of 4; cells beyond n_tile are 0)
+            for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) {
+                float4 q = a4[w];
+                if (UNIT) {
+                    const uint4 qu = *reinterpret_cast<const uint4 *>(&q);
+                    if ((qu.x | qu.y | qu.z | qu.w) == 0u) continue;
+                    q = make_float4((float)qu.x, (float)qu.y, (float)qu.z, (float)qu.w);
+                } else if (q.x == 0.f && q.y == 0.f && q.z == 0.f && q.w == 0.f) {
+                    continue;
+                }
+                const float4 nj = nj4[w];
+                float vv[4] = {q.x, q.y, q.z, q.w};
+                const float nn[4] = {nj.x, nj.y, nj.z, nj.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = vv[e];
+                    if (v != 0.f) {
+                        v = normalise(p, v, norm_c, nn[e]);
+                        npos += v > 0.f;
+                        nneg += v < 0.f;
+                        if (v > 0.f) {
+                            const uint32_t key = float_key(v);
+                            kmin = min(kmin, key);
+                            kmax = max(kmax, key);
+                        }
+                    }
+                    vv[e] = v;
+                }
+                a4[w] = make_float4(vv[0], vv[1], vv[2], vv[3]);
             }
         }
         if (p.topK == 0) {  // dense output (.pyx:507-510)
@@ -221,26 +326,34 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         for (int off = 32; off > 0; off >>= 1) {
             npos += __shfl_down(npos, off);
             nneg += __shfl_down(nneg, off);
+            kmin = min(kmin, (uint32_t)__shfl_down(kmin, off));
+            kmax = max(kmax, (uint32_t)__shfl_down(kmax, off));
         }
         if (lane == 0) {
-            if (npos) atomicAdd(&s_npos, npos);
+            if (npos) {
+                atomicAdd(&s_npos, npos);
+                atomicMin(&s_kmin, kmin);
+                atomicMax(&s_kmax, kmax);
+            }
             if (nneg) atomicAdd(&s_nneg, nneg);
         }
         __syncthreads();
         npos = s_npos;
         nneg = s_nneg;
         total_nonzero += npos + nneg;
+        mark(3);
         if (p.n_tiles == 1) {
             // ---- top-K: the K largest cells of the FULL column (zeros compete, then are dropped), value-descending,
             //      emitted like the COO triples of .pyx:550-562 with -1 padding ----
             block_topk_emit<THREADS>(acc, n_tile, p.topK, p.sortP, npos, nneg, TOPK_ZEROS_COMPETE, aux, sc, &s_ncand,
-                                     p.out_idx + out_base, p.out_val + out_base);
+                                     p.out_idx + out_base, p.out_val + out_base, 0, nullptr, -1, s_kmin, s_kmax);
         } else {
             // the tile's K best non-zero cells go to the workgroup's scratch; zeros are accounted for in the merge
             block_topk_emit<THREADS>(acc, n_tile, p.topK, p.sortP, npos, nneg, TOPK_NONZERO, aux, sc, &s_ncand,
                                      wg_cand_idx + tile * p.topK, wg_cand_val + tile * p.topK, tile_base);
         }
         __syncthreads();
+        mark(4);
         }  // tiles
 
         if (p.n_tiles > 1 && p.topK > 0) {
@@ -479,7 +592,13 @@ struct mi355rec_sim {
     hipStream_t stream = nullptr;
     StreamTimer timer;       // start/stop events carried by the column-kernel dispatch itself
     StreamTimer call_timer;  // events around the whole call (H2D of the schedule, kernel, D2H of the result)
-    DeviceBuffer<int> csr_ptr, csr_idx, csc_ptr, csc_idx, order;
+    DeviceBuffer<int> csr_ptr, csr_idx, csc_ptr, csc_idx;
+    DeviceBuffer<int4> items;
+    DeviceBuffer<uint32_t> part_buf;
+    DeviceBuffer<unsigned> part_count;
+    DeviceBuffer<unsigned long long> phase_ticks;
+    std::vector<int4> items_host;   // host staging for the current call
+    int n_split_columns = 0, n_part_items = 0;
     DeviceBuffer<unsigned short> csr_idx16;
     DeviceBuffer<int> row_tile_ptr, cand_idx;
     DeviceBuffer<float> cand_val;
@@ -491,7 +610,6 @@ struct mi355rec_sim {
     std::vector<long long> cost;   // host copy
     std::vector<int> csc_ptr_host;
     std::vector<int> cost_order;   // all columns, most expensive first
-    std::vector<int> range_order;  // host staging for the current call
     int group_lanes = 64;
     mi355rec_stats stats{};
     // last call
@@ -524,6 +642,7 @@ void launch_sim(mi355rec_sim *h, const SimParams &p, int grid, size_t lds) {
 template <int THREADS>
 void launch_sim_g(mi355rec_sim *h, const SimParams &p, int grid, size_t lds) {
     switch (h->group_lanes) {
+        case 8: launch_sim<THREADS, 8>(h, p, grid, lds); break;
         case 16: launch_sim<THREADS, 16>(h, p, grid, lds); break;
         case 32: launch_sim<THREADS, 32>(h, p, grid, lds); break;
         default: launch_sim<THREADS, 64>(h, p, grid, lds); break;
@@ -542,16 +661,64 @@ void clamp_range(const mi355rec_sim *h, int32_t &s, int32_t &e) {
 // Runs the column kernel for [start,end) leaving results in d_idx/d_val (or d_dense when topK == 0).
 void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, float *d_dense) {
     const int n_local = end - start;
-    h->range_order.clear();
-    h->range_order.reserve(n_local);
+    const size_t lds = (size_t)h->tile_w * 4 + (size_t)AUX_WORDS * 4;
+    const int cus = multiprocessor_count();
+    int threads = 1024, max_grid = cus;   // one 16-wave workgroup per CU when the accumulator owns the LDS
+    if (lds <= 72 * 1024) {
+        const int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (lds + 1024))));
+        threads = 512;
+        max_grid = cus * per_cu;
+    }
+
+    // ---- schedule: work items, most expensive first (LPT).  A column whose cost exceeds 1/6 of a workgroup's fair
+    //      share is split into parts (contiguous runs of its users) that different workgroups accumulate; otherwise
+    //      the head items bound the build as soon as the range is spread over many CUs (at ML-20M shape the top
+    //      column is 0.49 of a CU's share on one GPU, 3.9 on eight).  Not combined with accumulator tiling.
     long long cost_sum = 0;
-    for (int c : h->cost_order)
-        if (c >= start && c < end) {
-            h->range_order.push_back(c);
-            cost_sum += h->cost[c];
+    for (int c = start; c < end; ++c) cost_sum += h->cost[c];
+    int min_part_users = 2 * threads;
+    if (getenv("MI355REC_SIM_MIN_PART_USERS")) min_part_users = std::max(64, atoi(getenv("MI355REC_SIM_MIN_PART_USERS")));
+    const long long limit = std::max<long long>(1, cost_sum / ((long long)max_grid * 6));
+    h->items_host.clear();
+    h->items_host.reserve((size_t)n_local + 8 * (size_t)max_grid);
+    std::vector<std::pair<long long, int>> keyed;   // (item cost, index into items_host)
+    keyed.reserve(h->items_host.capacity());
+    int part_slots = 0, n_split = 0;
+    for (int c : h->cost_order) {
+        if (c < start || c >= end) continue;
+        const int n_c = h->csc_ptr_host[c + 1] - h->csc_ptr_host[c];
+        long long parts = 1;
+        if (h->n_tiles == 1 && h->cost[c] > limit)
+            parts = std::max<long long>(1, std::min<long long>({(h->cost[c] + limit - 1) / limit, (long long)n_c / min_part_users, 64ll}));
+        if (parts > 1) {
+            for (int q = 0; q < (int)parts; ++q) {
+                keyed.emplace_back(h->cost[c] / parts, (int)h->items_host.size());
+                h->items_host.push_back(make_int4(c, q, (int)parts, part_slots));
+            }
+            part_slots += (int)parts;
+            ++n_split;
+        } else {
+            keyed.emplace_back(h->cost[c], (int)h->items_host.size());
+            h->items_host.push_back(make_int4(c, 0, 1, 0));
         }
-    MI_HIP(hipMemcpyAsync(h->order.ptr, h->range_order.data(), sizeof(int) * n_local, hipMemcpyHostToDevice, h->stream));
+    }
+    if (n_split) {
+        std::stable_sort(keyed.begin(), keyed.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+        std::vector<int4> sorted(keyed.size());
+        for (size_t i = 0; i < keyed.size(); ++i) sorted[i] = h->items_host[keyed[i].second];
+        h->items_host.swap(sorted);
+    }
+    const int n_items = (int)h->items_host.size();
+    h->n_split_columns = n_split;
+    h->n_part_items = part_slots;
+    if (h->items.count < (size_t)n_items) h->items.alloc((size_t)n_items + 1024);
+    MI_HIP(hipMemcpyAsync(h->items.ptr, h->items_host.data(), sizeof(int4) * n_items, hipMemcpyHostToDevice, h->stream));
     MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(unsigned), h->stream));
+    if (part_slots) {
+        if (h->part_buf.count < (size_t)part_slots * h->tile_w) h->part_buf.alloc((size_t)part_slots * h->tile_w);
+        if (h->part_count.count < (size_t)part_slots) h->part_count.alloc((size_t)part_slots);
+        MI_HIP(hipMemsetAsync(h->part_count.ptr, 0, sizeof(unsigned) * part_slots, h->stream));
+    }
 
     SimParams p{};
     p.n_rows = h->n_rows;
@@ -580,22 +747,22 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     p.norm = h->norm.ptr;
     p.norm_alpha = h->norm_alpha.ptr;
     p.norm_1ma = h->norm_1ma.ptr;
-    p.order = h->order.ptr;
-    p.n_local = n_local;
+    p.items = h->items.ptr;
+    p.n_items = n_items;
+    p.part_buf = h->part_buf.ptr;
+    p.part_count = h->part_count.ptr;
+    if (getenv("MI355REC_SIM_PHASES")) {
+        if (!h->phase_ticks.ptr) h->phase_ticks.alloc(8);
+        MI_HIP(hipMemsetAsync(h->phase_ticks.ptr, 0, 8 * sizeof(unsigned long long), h->stream));
+        p.phase_ticks = h->phase_ticks.ptr;
+    }
     p.start_col = start;
     p.queue = h->queue.ptr;
     p.out_idx = d_idx;
     p.out_val = d_val;
     p.out_dense = d_dense;
 
-    const size_t lds = (size_t)p.n_cols_pad * 4 + (size_t)AUX_WORDS * 4;
-    const int cus = multiprocessor_count();
-    int threads = 1024, grid = std::min(n_local, cus);   // one 16-wave workgroup per CU when the accumulator owns the LDS
-    if (lds <= 72 * 1024) {
-        const int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (lds + 1024))));
-        threads = 512;
-        grid = std::min(n_local, cus * per_cu);
-    }
+    const int grid = std::min(n_items, max_grid);
     if (h->n_tiles > 1 && p.topK > 0) {
         const size_t need = (size_t)grid * h->n_tiles * p.topK;
         if (h->cand_idx.count < need) {
@@ -728,11 +895,11 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         cost.alloc((size_t)n_cols);
         hipLaunchKernelGGL(column_stats_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_idx.ptr, h->csc_val.ptr,
                            h->csr_ptr.ptr, n_cols, (float *)nullptr, sumsq.ptr, cost.ptr);
-        h->norm.alloc((size_t)n_cols);
+        h->norm.alloc_zero((size_t)n_cols + 4, s);
         const bool asym = cfg->similarity == MI355REC_SIM_ASYMMETRIC;
         if (asym) {
-            h->norm_alpha.alloc((size_t)n_cols);
-            h->norm_1ma.alloc((size_t)n_cols);
+            h->norm_alpha.alloc_zero((size_t)n_cols + 4, s);
+            h->norm_1ma.alloc_zero((size_t)n_cols + 4, s);
         }
         hipLaunchKernelGGL(norms_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, s, sumsq.ptr, n_cols, (int)set_based,
                            (int)asym, cfg->asymmetric_alpha, h->norm.ptr, h->norm_alpha.ptr, h->norm_1ma.ptr);
@@ -754,7 +921,6 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         std::iota(h->cost_order.begin(), h->cost_order.end(), 0);
         std::stable_sort(h->cost_order.begin(), h->cost_order.end(),
                          [&](int a, int b) { return h->cost[a] > h->cost[b]; });
-        h->order.alloc((size_t)n_cols);
         h->queue.alloc(1);
         // lanes per user profile: sized to the profile length seen from an item (cost-weighted mean)
         long long total_cost = 0;
@@ -794,6 +960,13 @@ extern "C" int mi355rec_sim_compute(mi355rec_sim_t h, int32_t start_col, int32_t
         h->out_val.download(nbr_val, n, h->stream);
         MI_HIP(hipStreamSynchronize(h->stream));
         h->stats.kernel_ms = h->timer.elapsed_ms(), h->stats.call_ms = h->call_timer.elapsed_ms();
+        if (h->phase_ticks.ptr && getenv("MI355REC_SIM_PHASES")) {
+            unsigned long long t[8];
+            h->phase_ticks.download(t, 8, h->stream);
+            MI_HIP(hipStreamSynchronize(h->stream));
+            fprintf(stderr, "[mi355rec sim phases, workgroup-ms] fetch+clear %.2f  accumulate %.2f  split-merge %.2f  normalise %.2f  topk %.2f  (kernel %.3f ms)\n",
+                    t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, h->stats.kernel_ms);
+        }
     });
 }
 
@@ -830,6 +1003,15 @@ extern "C" int mi355rec_sim_column_costs(mi355rec_sim_t h, int64_t *cost) {
     return guarded([&] {
         MI_REQUIRE(h && cost, "NULL argument");
         for (int c = 0; c < h->n_cols; ++c) cost[c] = h->cost[c];
+    });
+}
+
+extern "C" int mi355rec_sim_schedule_info(mi355rec_sim_t h, int32_t *n_items, int32_t *n_split_columns, int32_t *n_parts) {
+    return guarded([&] {
+        MI_REQUIRE(h && n_items && n_split_columns && n_parts, "NULL argument");
+        *n_items = (int32_t)h->items_host.size();
+        *n_split_columns = h->n_split_columns;
+        *n_parts = h->n_part_items;
     });
 }
 

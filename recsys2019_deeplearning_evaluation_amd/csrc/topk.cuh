@@ -1,7 +1,7 @@
 // topk.cuh -- block-wide top-K selection in LDS, shared by the similarity build (per-column top-K,
 // Compute_Similarity_Cython.pyx:523-562) and SLIM-BPR's get_S (per-row top-K, SLIM_BPR_Cython_Epoch.pyx:343-391).
-// 4-pass radix select on an order-preserving uint32 key with bank-replicated histograms, then a bitonic sort of
-// the survivors.  gfx950 only.
+// Radix select on an order-preserving uint32 key (bank-replicated histograms, digit windows placed where the keys
+// differ, early exit to a small candidate superset), then a counting rank of the survivors.  gfx950 only.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -26,33 +26,55 @@ __device__ __forceinline__ float key_float(uint32_t k) {
 
 struct SelectScratch {
     uint32_t wave_tot[4];
-    uint32_t digit, want, bin_count;
+    uint32_t digit, want, bin_count, out_count;
 };
 
 // Block-wide radix select: key of the `want`-th largest element (1-based) of
 //   { kf(j).key : j < n, kf(j).active }  U  { virt_key repeated virt_cnt times }.
-// On return every thread holds T (that key), need_eq (how many elements equal to T belong to the top `want`)
-// and eq_total (how many elements equal T, virtual ones included).
+// [key_lo, key_hi] must contain every key that can belong to the top `want`, and every active key outside it must lie
+// BELOW key_lo (such keys are simply not counted).  The bits the two bounds share are skipped, so the 8-bit digit
+// windows start where the keys actually differ (similarity values of one column share sign and leading exponent bits:
+// a window over bits 31..24 would put nearly every cell in two or three bins).
+// Early exit: as soon as (elements above the current bin) + (elements in it) <= cap, the function returns true with
+// T = the lowest key of that bin: { key >= T } is a superset of the answer of at most cap elements, which the caller
+// sorts.  Otherwise all bits are resolved and it returns false with T = the exact key, need_eq = how many elements
+// equal to T belong to the top `want`, eq_total = how many elements equal T (virtual ones included).
+// `vals` (LDS, readable up to the next multiple of 4) is scanned four cells per thread and step; kf(j, v, key) maps
+// cell j with value v to its key and says whether it takes part.
 template <int THREADS, class KeyFn>
-__device__ void block_select(KeyFn kf, int n, uint32_t want, uint32_t virt_key, uint32_t virt_cnt, uint32_t *hist,
-                             SelectScratch &sc, uint32_t &T, uint32_t &need_eq, uint32_t &eq_total) {
+__device__ bool block_select(KeyFn kf, const float *vals, int n, uint32_t want, uint32_t virt_key, uint32_t virt_cnt, uint32_t *hist,
+                             SelectScratch &sc, uint32_t key_lo, uint32_t key_hi, uint32_t cap, uint32_t &T,
+                             uint32_t &need_eq, uint32_t &eq_total) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t prefix = 0;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        for (int w = tid; w < AUX_WORDS; w += THREADS) hist[w] = 0;
-        __syncthreads();
-        for (int j = tid; j < n; j += THREADS) {
-            uint32_t key;
-            if (kf(j, key) && (pass == 0 || (key >> (shift + 8)) == prefix))
-                atomicAdd(&hist[((key >> shift) & 255u) * 32 + (lane & 31)], 1u);
+    const uint32_t want0 = want;
+    int remaining = max(1, 32 - (int)__clz(key_lo ^ key_hi));          // __clz(0) == 32
+    uint32_t prefix = (uint32_t)((uint64_t)key_hi >> remaining);
+    for (int w = tid; w < AUX_WORDS; w += THREADS) hist[w] = 0;
+    __syncthreads();
+    while (remaining > 0) {
+        const int width = min(8, remaining), shift = remaining - width;
+        const uint32_t mask = (1u << width) - 1u;
+        for (int w = tid; w < (n + 3) / 4; w += THREADS) {
+            const float4 q = reinterpret_cast<const float4 *>(vals)[w];
+            const float vv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 4 * w + e;
+                uint32_t key;
+                if (j < n && kf(j, vv[e], key) && (uint32_t)((uint64_t)key >> remaining) == prefix)
+                    atomicAdd(&hist[((key >> shift) & mask) * 32 + (lane & 31)], 1u);
+            }
         }
         __syncthreads();
         uint32_t cnt = 0, suffix = 0;
         if (tid < 256) {
 #pragma unroll 8
-            for (int r = 0; r < 32; ++r) cnt += hist[tid * 32 + ((r + tid) & 31)];
-            if (virt_cnt && (pass == 0 || (virt_key >> (shift + 8)) == prefix) && ((virt_key >> shift) & 255u) == (uint32_t)tid)
+            for (int r = 0; r < 32; ++r) {
+                const int at = tid * 32 + ((r + tid) & 31);
+                cnt += hist[at];
+                hist[at] = 0;                                           // ready for the next pass
+            }
+            if (virt_cnt && (uint32_t)((uint64_t)virt_key >> remaining) == prefix && ((virt_key >> shift) & mask) == (uint32_t)tid)
                 cnt += virt_cnt;
             suffix = cnt;  // inclusive suffix sum inside the wave (towards higher bins)
 #pragma unroll
@@ -73,13 +95,19 @@ __device__ void block_select(KeyFn kf, int n, uint32_t want, uint32_t virt_key, 
             }
         }
         __syncthreads();
-        prefix = (prefix << 8) | sc.digit;
+        prefix = (prefix << width) | sc.digit;
         want = sc.want;
         eq_total = sc.bin_count;
+        remaining = shift;
         __syncthreads();
+        if (remaining > 0 && (want0 - want) + eq_total <= cap) {
+            T = prefix << remaining;
+            return true;
+        }
     }
     T = prefix;
     need_eq = want;
+    return false;
 }
 
 template <int THREADS>
@@ -111,7 +139,7 @@ __device__ void bitonic_sort_desc(uint64_t *a, int P) {
 //                        where -inf marks excluded items)
 enum { TOPK_ZEROS_COMPETE = 0, TOPK_NONZERO = 1, TOPK_FINITE = 2 };
 
-// Top-K of the n floats in LDS array `acc` (K = topK <= sortP, sortP a power of two, sortP * 8 B <= AUX_WORDS * 4 B).
+// Top-K of the n floats in LDS array `acc` (K = topK <= MAX_TOPK).
 //   npos / nneg     : TOPK_ZEROS_COMPETE / TOPK_NONZERO: number of strictly positive / negative cells;
 //                     TOPK_FINITE: npos = number of cells > -inf, nneg = 0          (block-uniform, counted by the caller)
 //   *ncand          : shared counter, must be 0 on entry
@@ -120,69 +148,132 @@ enum { TOPK_ZEROS_COMPETE = 0, TOPK_NONZERO = 1, TOPK_FINITE = 2 };
 //   idx_offset      : added to every emitted index (tiled callers: base of the tile)
 //   idx_map         : if non-null the emitted index is idx_map[local index] (merge of per-tile candidates)
 //   zero_count      : TOPK_ZEROS_COMPETE only: number of competing zeros; < 0 = n - npos - nneg
+//   key_lo / key_hi : float_key range of the cells that can reach the top K (see block_select); for
+//                     TOPK_ZEROS_COMPETE it is the range of the POSITIVE cells and is used when npos >= topK.
+// Method: radix select with early exit to a superset of <= cap candidates, which are ranked by counting (every
+// candidate counts the candidates above it: keys carry the index, so ranks are a permutation) -- or by a bitonic sort
+// when there are more than 1024 of them -- and written straight to their output slot.
 template <int THREADS>
 __device__ void block_topk_emit(const float *acc, int n, int topK, int sortP, uint32_t npos, uint32_t nneg, int mode,
                                 uint32_t *aux, SelectScratch &sc, uint32_t *ncand_shared, int *out_idx, float *out_val,
-                                int idx_offset = 0, const int *idx_map = nullptr, long long zero_count = -1) {
-    const int tid = threadIdx.x;
+                                int idx_offset = 0, const int *idx_map = nullptr, long long zero_count = -1,
+                                uint32_t key_lo = 0u, uint32_t key_hi = 0xFFFFFFFFu) {
+    const int tid = threadIdx.x, lane = tid & 63;
     const bool zeros_compete = mode == TOPK_ZEROS_COMPETE;
     const uint32_t nzero = zeros_compete ? (zero_count >= 0 ? (uint32_t)zero_count : (uint32_t)n - npos - nneg) : 0u;
     uint32_t K = (uint32_t)topK;
     if (!zeros_compete) K = min(K, npos + nneg);
+    if (zeros_compete && npos < K) {   // zeros / negatives take part: full key range
+        key_lo = 0u;
+        key_hi = 0xFFFFFFFFu;
+    }
+    const uint32_t cap = (uint32_t)min(AUX_WORDS / 2, max(256, 2 * topK));
     uint32_t T = ZERO_KEY, need_eq = 0, eq_total = 0;
+    if (tid == 0) sc.out_count = 0;
     // all positives fit and no negative can displace a zero: nothing to select
     bool take_all = zeros_compete ? (npos <= K && (nneg == 0 || npos + nzero >= K)) : (npos + nneg <= K);
     if (!zeros_compete && take_all) T = 0u;                      // every candidate key is > 0
     auto candidate = [&](float v) { return mode == TOPK_FINITE ? v > -INFINITY : v != 0.f; };
-    auto value_key = [&](int j, uint32_t &key) {
-        const float v = acc[j];
+    auto value_key = [&](int, float v, uint32_t &key) {
         key = float_key(v);
         return candidate(v);
     };
-    if (!take_all) {
-        block_select<THREADS>(value_key, n, K, ZERO_KEY, nzero, aux, sc, T, need_eq, eq_total);
-        if (zeros_compete && T == ZERO_KEY) need_eq = 0;          // zeros are never emitted
+    bool superset = false;
+    if (!take_all && zeros_compete && npos >= K && npos <= cap) {
+        superset = true;                                         // few enough positives: rank them all
+        T = max(key_lo, ZERO_KEY + 1u);                          // positives only
+    } else if (!take_all) {
+        superset = block_select<THREADS>(value_key, acc, n, K, ZERO_KEY, nzero, aux, sc, key_lo, key_hi, cap, T, need_eq, eq_total);
+        if (!superset && zeros_compete && T == ZERO_KEY) need_eq = 0;          // zeros are never emitted
     }
     uint32_t T2 = 0;  // tie-break on the index when more cells equal T than fit: lowest index wins
-    const bool partial_ties = need_eq > 0 && need_eq < eq_total;
+    const bool partial_ties = !superset && need_eq > 0 && need_eq < eq_total;
     if (partial_ties) {
         uint32_t dummy_need, dummy_tot;
-        auto index_key = [&](int j, uint32_t &key) {
-            const float v = acc[j];
+        auto index_key = [&](int j, float v, uint32_t &key) {
             key = ~(uint32_t)j;
             return candidate(v) && float_key(v) == T;
         };
-        block_select<THREADS>(index_key, n, need_eq, 0u, 0u, aux, sc, T2, dummy_need, dummy_tot);
+        block_select<THREADS>(index_key, acc, n, need_eq, 0u, 0u, aux, sc, 0u, 0xFFFFFFFFu, 0u, T2, dummy_need, dummy_tot);
     }
     __syncthreads();
+    // ---- candidates -> aux as (key << 32 | ~index); slots are handed out per wavefront (one LDS atomic per wave) ----
     uint64_t *cand = reinterpret_cast<uint64_t *>(aux);
-    for (int j = tid; j < n; j += THREADS) {
-        const float v = acc[j];
-        if (!candidate(v)) continue;
-        const uint32_t key = float_key(v);
-        const bool take = key > T || (need_eq > 0 && key == T && (!partial_ties || ~(uint32_t)j >= T2));
-        if (take) {
-            const uint32_t slot_c = atomicAdd(ncand_shared, 1u);
-            if (slot_c < (uint32_t)sortP) cand[slot_c] = ((uint64_t)key << 32) | (uint32_t)(~(uint32_t)j);
+    constexpr int CAND_MAX = AUX_WORDS / 2;
+    for (int w0 = 0; w0 < (n + 3) / 4; w0 += THREADS) {
+        const int w = w0 + tid;
+        float vv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (4 * w < n) {
+            const float4 q = reinterpret_cast<const float4 *>(acc)[w];
+            vv[0] = q.x; vv[1] = q.y; vv[2] = q.z; vv[3] = q.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * w + e;
+            const float v = vv[e];
+            const uint32_t key = float_key(v);
+            const bool take = j < n && candidate(v) &&
+                              (superset ? key >= T : (key > T || (need_eq > 0 && key == T && (!partial_ties || ~(uint32_t)j >= T2))));
+            const unsigned long long m = __ballot(take);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(ncand_shared, (uint32_t)__popcll(m));
+                base = __shfl(base, leader);
+                if (take) {
+                    const uint32_t slot_c = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (slot_c < (uint32_t)CAND_MAX) cand[slot_c] = ((uint64_t)key << 32) | (uint32_t)(~(uint32_t)j);
+                }
+            }
         }
     }
     __syncthreads();
-    const int ncand = min((int)*ncand_shared, topK);
-    for (int t = ncand + tid; t < sortP; t += THREADS) cand[t] = 0ull;
-    __syncthreads();
-    bitonic_sort_desc<THREADS>(cand, sortP);
-    for (int t = tid; t < topK; t += THREADS) {
-        int idx = -1;
-        float val = 0.f;
-        if (t < ncand) {
-            const uint64_t e = cand[t];
-            idx = (int)(~(uint32_t)(e & 0xFFFFFFFFull));
+    const int ncand = min((int)*ncand_shared, CAND_MAX);
+    // rank r (0 = largest) is emitted when it falls inside the top K of [positives, the competing zeros, negatives]
+    auto emit = [&](uint64_t e, int r) {
+        const uint32_t key = (uint32_t)(e >> 32);
+        const bool ok = (uint32_t)r + ((zeros_compete && key < ZERO_KEY) ? nzero : 0u) < K;
+        if (ok) {
+            int idx = (int)(~(uint32_t)(e & 0xFFFFFFFFull));
             idx = idx_map ? idx_map[idx] : idx + idx_offset;
-            val = key_float((uint32_t)(e >> 32));
+            out_idx[r] = idx;
+            if (out_val) out_val[r] = key_float(key);
         }
-        out_idx[t] = idx;
-        if (out_val) out_val[t] = val;
+        return ok;
+    };
+    uint32_t emitted = 0;
+    if (ncand <= 1024) {
+        // counting rank: G lanes share one candidate (G a power of two <= 64, G * ncand <= THREADS when possible)
+        int G = 1;
+        while (G < 64 && 2 * G * ncand <= THREADS) G <<= 1;
+        const int per_round = THREADS / G, part = tid & (G - 1);
+        for (int c0 = 0; c0 < ncand; c0 += per_round) {
+            const int c = c0 + tid / G;
+            const bool live = c < ncand;
+            const uint64_t mine = live ? cand[c] : 0ull;
+            int r = 0;
+            if (live)
+                for (int i = part; i < ncand; i += G) r += cand[i] > mine;
+            for (int off = 1; off < G; off <<= 1) r += __shfl_xor(r, off);
+            if (live && part == 0) emitted += emit(mine, r);
+        }
+    } else {
+        int P = 2048;
+        while (P < ncand) P <<= 1;
+        for (int t = ncand + tid; t < P; t += THREADS) cand[t] = 0ull;
+        __syncthreads();
+        bitonic_sort_desc<THREADS>(cand, P);
+        for (int t = tid; t < min(ncand, topK); t += THREADS) emitted += emit(cand[t], t);
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) emitted += __shfl_down(emitted, off);
+    if (lane == 0 && emitted) atomicAdd(&sc.out_count, emitted);
+    __syncthreads();
+    for (int t = (int)sc.out_count + tid; t < topK; t += THREADS) {
+        out_idx[t] = -1;
+        if (out_val) out_val[t] = 0.f;
+    }
+    __syncthreads();   // sc and aux may be re-used by the caller's next column
 }
 
 }  // namespace mi355rec

@@ -100,6 +100,12 @@ class Compute_Similarity_MI355X:
         N.check(self._lib.mi355rec_sim_column_costs(self._h, N.ptr(cost)))
         return cost
 
+    def schedule_info(self):
+        """(work items, split columns, parts) of the last compute call."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        N.check(self._lib.mi355rec_sim_schedule_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def stats(self):
         st = N.Stats()
         N.check(self._lib.mi355rec_sim_get_stats(self._h, C.byref(st)))

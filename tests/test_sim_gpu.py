@@ -241,3 +241,49 @@ def test_itemknn_with_feature_weighting(gpu, weighting):
     assert abs(rec.W_sparse - Wo).max() <= RTOL * abs(Wo).max()
     with pytest.raises(ValueError):
         ItemKNNCFRecommender(X, verbose=False).fit(feature_weighting="nope")
+
+
+@pytest.mark.parametrize("values,similarity", [("binary", "cosine"), ("real", "cosine"), ("real", "adjusted"), ("binary", "tversky")])
+def test_heavy_columns_split_over_workgroups(gpu, values, similarity, monkeypatch):
+    """Columns above 1/6 of a workgroup's fair share are accumulated by several workgroups (parts of the column's
+    users) and summed by the last one to arrive: same result as the oracle, and -- integer counts -- bit-identical to
+    the unsplit build on all-ones data."""
+    X = named_urm("ml1m", values, scale=0.25)
+    kw = dict(topK=50, shrink=3, normalize=True, similarity=similarity)
+    monkeypatch.setenv("MI355REC_SIM_MIN_PART_USERS", "1000000")
+    plain = Compute_Similarity_MI355X(X, **kw)
+    idx0, val0, _ = plain.compute_slabs()
+    assert plain.schedule_info()[1] == 0
+    monkeypatch.setenv("MI355REC_SIM_MIN_PART_USERS", "64")
+    split = Compute_Similarity_MI355X(X, **kw)
+    idx1, val1, _ = split.compute_slabs()
+    n_items, n_split, n_parts = split.schedule_info()
+    assert n_split > 10 and n_parts >= 2 * n_split and n_items == X.shape[1] - n_split + n_parts
+    if values == "binary":
+        assert (idx0 == idx1).all() and (val0 == val1).all()
+    orc = O.OracleSimilarity(X, **dict(kw, topK=0))
+    for c in range(X.shape[1]):
+        check_topk_against_dense(idx1[c], val1[c], orc.column(c)[0], 50, RTOL)
+    # column ranges and the dense (topK = 0) output go through the same split schedule
+    s, e = 3, X.shape[1] // 5
+    idx2, val2, _ = split.compute_slabs(s, e)
+    assert split.schedule_info()[1] > 0
+    assert (idx2 == idx1[s:e]).all() and np.allclose(val2, val1[s:e], rtol=1e-6, atol=0)
+    dense = Compute_Similarity_MI355X(X, **dict(kw, topK=0))
+    W = dense.compute_similarity(0, 40)
+    assert dense.schedule_info()[1] > 0
+    for c in range(0, 40, 7):
+        assert rel_err(W[:, c], orc.column(c)[0]) < RTOL
+    for o in (plain, split, dense):
+        o.close()
+
+
+def test_split_schedule_is_the_default_at_full_ml1m_size(gpu):
+    X = named_urm("ml1m", "binary")
+    dev = Compute_Similarity_MI355X(X, topK=100, shrink=0, normalize=True, similarity="cosine")
+    idx, val, _ = dev.compute_slabs()
+    assert dev.schedule_info()[1] > 0
+    orc = O.OracleSimilarity(X, topK=0, shrink=0, normalize=True, similarity="cosine")
+    for c in range(0, X.shape[1], 37):
+        check_topk_against_dense(idx[c], val[c], orc.column(c)[0], 100, RTOL)
+    dev.close()
