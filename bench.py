@@ -245,7 +245,7 @@ def main():
             dist.init_process_group(backend)
     import numpy as np
     from recsys2019_deeplearning_evaluation_amd import (Compute_Similarity_MI355X, MatrixFactorization_MI355X_Epoch, _native)
-    from recsys2019_deeplearning_evaluation_amd.sharding import balanced_column_ranges, gather_slabs
+    from recsys2019_deeplearning_evaluation_amd.sharding import similarity_column_ranges, gather_slabs
     _native.load()
     if _native.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
@@ -298,7 +298,7 @@ def main():
     if not args.no_sim:
         sim = Compute_Similarity_MI355X(urm, topK=TOPK, shrink=0, normalize=True, similarity="cosine")
         costs = sim.column_costs()
-        ranges = balanced_column_ranges(costs, world)
+        ranges = similarity_column_ranges(sim, world)
         s, e = ranges[rank]
         best = None
         for rep in range(3):

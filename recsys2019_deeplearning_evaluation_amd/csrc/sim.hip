@@ -185,7 +185,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                         f_t = f_rs & ~7;
                         f_end = f_re;
                     }
-                } while (f_have && f_t >= f_end);     // empty segments exist only with accumulator tiles
+                } while (f_have && f_rs >= f_re);     // empty segments exist only with accumulator tiles
             };
             next_user();
             uint4 ids[DEPTH];
@@ -247,12 +247,22 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                 const uint4 *src = reinterpret_cast<const uint4 *>(acc);
                 for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) dst[w] = src[w];
             }
-            __threadfence();
+            // Every wavefront waits until its own stores have reached the L2; after the barrier ONE thread makes them
+            // visible device-wide (agent-scope release: L2 write-back) and counts the arrival; the last arriver
+            // acquires (invalidates this CU's L1 / stale L2 lines) on behalf of the whole workgroup.  A fence per
+            // thread costs ~50 us per part on gfx950 (16 wavefronts x write-back + invalidate).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) s_last = atomicAdd(&p.part_count[item.w], 1u) == (unsigned)(item.z - 1);
+            if (tid == 0) {
+                __threadfence();
+                s_last = atomicAdd(&p.part_count[item.w], 1u) == (unsigned)(item.z - 1);
+                if (s_last) __threadfence();
+            }
             __syncthreads();
-            if (!s_last) continue;
-            __threadfence();
+            if (!s_last) {
+                mark(2);
+                continue;
+            }
             const uint4 *src = reinterpret_cast<const uint4 *>(p.part_buf + (size_t)item.w * p.n_cols_pad);
             const size_t stride4 = (size_t)p.n_cols_pad / 4;
             for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) {
@@ -670,15 +680,15 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
         max_grid = cus * per_cu;
     }
 
-    // ---- schedule: work items, most expensive first (LPT).  A column whose cost exceeds 1/6 of a workgroup's fair
+    // ---- schedule: work items, most expensive first (LPT).  A column whose cost exceeds 1/2 of a workgroup's fair
     //      share is split into parts (contiguous runs of its users) that different workgroups accumulate; otherwise
     //      the head items bound the build as soon as the range is spread over many CUs (at ML-20M shape the top
     //      column is 0.49 of a CU's share on one GPU, 3.9 on eight).  Not combined with accumulator tiling.
     long long cost_sum = 0;
     for (int c = start; c < end; ++c) cost_sum += h->cost[c];
-    int min_part_users = 2 * threads;
+    int min_part_users = 4 * threads;
     if (getenv("MI355REC_SIM_MIN_PART_USERS")) min_part_users = std::max(64, atoi(getenv("MI355REC_SIM_MIN_PART_USERS")));
-    const long long limit = std::max<long long>(1, cost_sum / ((long long)max_grid * 6));
+    const long long limit = std::max<long long>(1, cost_sum / ((long long)max_grid * 2));
     h->items_host.clear();
     h->items_host.reserve((size_t)n_local + 8 * (size_t)max_grid);
     std::vector<std::pair<long long, int>> keyed;   // (item cost, index into items_host)
