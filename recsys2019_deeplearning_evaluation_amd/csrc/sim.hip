@@ -21,20 +21,27 @@
 namespace mi355rec {
 namespace {
 
-constexpr int MAX_TILE = 32256;   // cells of the LDS accumulator: 4 B * 32256 + 32 KiB selection scratch + statics <= 160 KiB
+constexpr int MAX_TILE = 32256;      // uint32 count cells of the LDS accumulator: 4 B * (32256 + 4) + 32 KiB selection scratch + statics <= 160 KiB
+constexpr int MAX_TILE_F64 = 16128;  // float64 cells (real-valued data): 8 B * (16128 + 4) + 32 KiB
+constexpr int F64_CELLS_PER_THREAD = 16;   // >= MAX_TILE_F64 / 1024 (and the 512-thread launches have <= 5116 cells)
 
 struct SimParams {
-    int n_rows, n_cols, n_cols_pad;
+    int n_rows, n_cols, n_cols_pad;    // n_cols_pad: neighbour cells of the LDS accumulator (tile width, multiple of 4)
+    int acc_cells;                     // n_cols_pad + 4 spare cells that absorb the padding entries of the profiles
+    int acc_words;                     // 32-bit words of the accumulator: acc_cells (uint32 counts) or 2 * acc_cells (float64)
     int topK, sortP;
     int kind, normalize, unit_col;
     float shrink, tversky_alpha, tversky_beta;
     const int *csr_ptr;
-    const unsigned short *csr_idx16;   // column ids relative to their tile base, as uint16 (tile width <= 32256)
+    // Profile stream: every (row, accumulator tile) segment of the CSR matrix, padded to a multiple of 8 entries so
+    // that a 16-byte chunk is either entirely inside a segment or entirely outside (no per-entry bounds checks in the
+    // hot loop).  Ids are uint16 relative to the tile base; padding entries carry the id of a spare cell and value 0.
+    const int *seg_ptr;                // [n_rows * n_tiles + 1], multiples of 8
+    const unsigned short *seg_idx16;
+    const float *seg_val;
     int tile_w, n_tiles;               // accumulator tile width and count (1 when n_cols fits the LDS)
-    const int *row_tile_ptr;           // n_tiles > 1: [n_rows][n_tiles + 1] positions where a CSR row crosses tile bounds
     int *cand_idx;                     // n_tiles > 1: per-workgroup scratch [n_tiles * topK] of per-tile candidates
     float *cand_val;
-    const float *csr_val;              // padded by 8
     const int *csc_ptr, *csc_idx;
     const float *csc_val;
     const float *row_w;
@@ -68,7 +75,7 @@ template <int THREADS, int G, bool UNIT>
 __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *acc = smem;
-    uint32_t *aux = reinterpret_cast<uint32_t *>(smem + p.n_cols_pad);
+    uint32_t *aux = reinterpret_cast<uint32_t *>(smem + p.acc_words);
     __shared__ SelectScratch sc;
     __shared__ int s_col, s_last;
     __shared__ uint32_t s_npos, s_nneg, s_ncand, s_kmin, s_kmax;
@@ -133,14 +140,9 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         };
         auto load_bounds = [&](bool valid, int u, float cv, int &rs, int &re, float &r) {
             if (valid) {
-                if (p.n_tiles == 1) {
-                    rs = p.csr_ptr[u];
-                    re = p.csr_ptr[u + 1];
-                } else {
-                    const int *tp = p.row_tile_ptr + (size_t)u * (p.n_tiles + 1) + tile;
-                    rs = tp[0];
-                    re = tp[1];
-                }
+                const int *sp = p.seg_ptr + ((size_t)u * p.n_tiles + tile);
+                rs = sp[0];
+                re = sp[1];
                 r = cv;
                 if (!UNIT && p.row_w) r *= p.row_w[u];
             }
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         // ---- clear this_item_weights (.pyx:365-370) ----
         {
             float4 *a4 = reinterpret_cast<float4 *>(acc);
-            for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) a4[w] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int w = tid; w < p.acc_words / 4; w += THREADS) a4[w] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         load_bounds(wbeg + lane < wend, u_first, cv_first, t_rs, t_re, t_r);
         __syncthreads();
@@ -162,18 +164,23 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         // ---- computeItemSimilarities (.pyx:376-406): users of column c, then every item of each user ----
         // A wavefront takes 64 of its users per round: lane l puts user l's CSR bounds and weight into a
         // wavefront-private table in the selection scratch.  Its GPW lane groups then walk the table round-robin,
-        // streaming each profile in aligned 16-byte chunks (8 uint16 column ids per lane; the first chunk may start
-        // before the row and the last may run past it: both masked).
-        // The stream is latency-bound (one workgroup per CU = 16 wavefronts, each load ~1 us away), so every group
+        // streaming each profile segment in 16-byte chunks (8 uint16 column ids per lane).  Segments are padded to whole
+        // chunks, so a lane's chunk is valid or not as a whole: the accumulation is 8 x (extract id, ds_add) with
+        // nothing else -- on the 16-lane SIMDs of CDNA every wave64 VALU instruction costs 4 issue cycles, and the
+        // per-entry bounds checks of an unpadded layout made this loop VALU-issue-bound (3.7 of 5.8 ms at ML-20M shape).
+        // The stream is also latency-bound (one workgroup per CU = 16 wavefronts, each load ~1 us away), so every group
         // runs a fetch cursor DEPTH chunks ahead of its consume cursor: DEPTH loads per lane in flight, issued
         // unconditionally (finished groups re-read a hot line) so that the wait counters are static and the consume
         // side only ever waits for the oldest chunk.
-        // UNIT data accumulates integer counts (ds_add_u32 runs ~3x faster than ds_add_f32 on gfx950 and is exact);
-        // otherwise float products.
+        // UNIT data accumulates integer counts with ds_add_u32; real-valued data accumulates float64 products with
+        // ds_add_f64 -- like the reference, whose accumulator is a double array.  (Measured on gfx950, random cells, per
+        // CU and ns: ds_add_u32 21.6 lane-adds, ds_add_u64 13.2, ds_add_f64 7.2, ds_add_f32 0.8 -- the float32 LDS
+        // atomic is 27x slower than the integer one and 9x slower than the float64 one.)
         constexpr int DEPTH = UNIT ? 4 : 2;
         unsigned *acc_u = reinterpret_cast<unsigned *>(acc);
-        const uint4 *idx8 = reinterpret_cast<const uint4 *>(p.csr_idx16);
-        const float4 *val4 = reinterpret_cast<const float4 *>(p.csr_val);
+        double *acc_d = reinterpret_cast<double *>(acc);
+        const uint4 *idx8 = reinterpret_cast<const uint4 *>(p.seg_idx16);
+        const float4 *val4 = reinterpret_cast<const float4 *>(p.seg_val);
         int *tab = reinterpret_cast<int *>(aux) + wave * 192;       // [64] x {rs, re, weight}
         for (int base = wbeg; base < wend; base += 64) {
             const int n_here = min(64, wend - base);
@@ -189,32 +196,29 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             // fetch cursor of this lane group
-            int m = sub - GPW, f_t = 0, f_end = 0, f_rs = 0, f_re = 0;
+            int m = sub - GPW, f_t = 0, f_re = 0;
             float f_r = 0.f;
             bool f_have = true;
-            auto next_user = [&]() {        // moves the fetch cursor to the group's next non-empty profile
+            auto next_user = [&]() {        // moves the fetch cursor to the group's next non-empty segment
                 do {
                     m += GPW;
                     f_have = m < n_here;
                     if (f_have) {
-                        f_rs = tab[m * 3];
+                        f_t = tab[m * 3];
                         f_re = tab[m * 3 + 1];
                         f_r = __int_as_float(tab[m * 3 + 2]);
-                        f_t = f_rs & ~7;
-                        f_end = f_re;
                     }
-                } while (f_have && f_rs >= f_re);     // empty segments exist only with accumulator tiles
+                } while (f_have && f_t >= f_re);      // empty segments exist only with accumulator tiles
             };
             next_user();
             uint4 ids[DEPTH];
             float4 vlo[DEPTH], vhi[DEPTH];
-            int c_t[DEPTH], c_rs[DEPTH], c_re[DEPTH];
+            int c_t[DEPTH], c_re[DEPTH];      // chunk position of the lane; end of the group's segment (0: no chunk)
             float c_r[DEPTH];
             int pending = 0;
             auto fetch = [&](int d) {
                 const int at = f_have ? f_t + 8 * gl : 8 * gl;       // finished groups: a valid, cache-hot address
                 c_t[d] = at;
-                c_rs[d] = f_have ? f_rs : 0;
                 c_re[d] = f_have ? f_re : 0;
                 c_r[d] = f_r;
                 ids[d] = idx8[at >> 3];
@@ -225,22 +229,22 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                 if (f_have) {
                     ++pending;
                     f_t += 8 * G;
-                    if (f_t >= f_end) next_user();
+                    if (f_t >= f_re) next_user();
                 }
             };
             // (An interleaved lane <-> entry mapping -- neighbouring lanes on neighbouring profile entries, hoping for
             // neighbouring LDS banks -- was measured 11 % slower than 8 consecutive entries per lane.)
             auto consume = [&](int d) {
-                if (c_re[d] > c_rs[d]) --pending;
-                const unsigned ww[4] = {ids[d].x, ids[d].y, ids[d].z, ids[d].w};
-                const float vv[8] = {vlo[d].x, vlo[d].y, vlo[d].z, vlo[d].w, vhi[d].x, vhi[d].y, vhi[d].z, vhi[d].w};
+                if (c_re[d] > 0) --pending;
+                if (c_t[d] < c_re[d]) {
+                    const unsigned ww[4] = {ids[d].x, ids[d].y, ids[d].z, ids[d].w};
+                    const float vv[8] = {vlo[d].x, vlo[d].y, vlo[d].z, vlo[d].w, vhi[d].x, vhi[d].y, vhi[d].z, vhi[d].w};
+                    const double rd = (double)c_r[d];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int tt = c_t[d] + e;
-                    const unsigned j = (ww[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-                    if (tt >= c_rs[d] && tt < c_re[d]) {
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned j = (e & 1) ? (ww[e >> 1] >> 16) : (ww[e >> 1] & 0xFFFFu);
                         if (UNIT) atomicAdd(&acc_u[j], 1u);
-                        else atomicAdd(&acc[j], c_r[d] * vv[e]);
+                        else atomicAdd(&acc_d[j], rd * (double)vv[e]);
                     }
                 }
             };
@@ -259,13 +263,14 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         __syncthreads();
         mark(1);
         if (item.z > 1) {
+            const int pub_words = UNIT ? p.n_cols_pad : 2 * p.n_cols_pad;
             // Split column: publish this part's accumulator; the workgroup that arrives last adds the parts up (in
             // part order, so the float result does not depend on arrival order) and carries on with the column.
             // Nobody waits for anybody.
             {
-                uint4 *dst = reinterpret_cast<uint4 *>(p.part_buf + (size_t)(item.w + item.y) * p.n_cols_pad);
+                uint4 *dst = reinterpret_cast<uint4 *>(p.part_buf + (size_t)(item.w + item.y) * pub_words);   // spare cells are not published
                 const uint4 *src = reinterpret_cast<const uint4 *>(acc);
-                for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) dst[w] = src[w];
+                for (int w = tid; w < pub_words / 4; w += THREADS) dst[w] = src[w];
             }
             // Every wavefront waits until its own stores have reached the L2; after the barrier ONE thread makes them
             // visible device-wide (agent-scope release: L2 write-back) and counts the arrival; the last arriver
@@ -283,19 +288,19 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                 mark(2);
                 continue;
             }
-            const uint4 *src = reinterpret_cast<const uint4 *>(p.part_buf + (size_t)item.w * p.n_cols_pad);
-            const size_t stride4 = (size_t)p.n_cols_pad / 4;
-            for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.part_buf + (size_t)item.w * pub_words);
+            const size_t stride4 = (size_t)pub_words / 4;
+            for (int w = tid; w < pub_words / 4; w += THREADS) {
                 uint4 a = src[w];
                 for (int q = 1; q < item.z; ++q) {
                     const uint4 b = src[q * stride4 + w];
                     if (UNIT) {
                         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-                    } else {
-                        a.x = __float_as_uint(__uint_as_float(a.x) + __uint_as_float(b.x));
-                        a.y = __float_as_uint(__uint_as_float(a.y) + __uint_as_float(b.y));
-                        a.z = __float_as_uint(__uint_as_float(a.z) + __uint_as_float(b.z));
-                        a.w = __float_as_uint(__uint_as_float(a.w) + __uint_as_float(b.w));
+                    } else {   // two float64 cells
+                        const double a0 = __hiloint2double((int)a.y, (int)a.x) + __hiloint2double((int)b.y, (int)b.x);
+                        const double a1 = __hiloint2double((int)a.w, (int)a.z) + __hiloint2double((int)b.w, (int)b.z);
+                        a = make_uint4((unsigned)__double2loint(a0), (unsigned)__double2hiint(a0), (unsigned)__double2loint(a1),
+                                       (unsigned)__double2hiint(a1));
                     }
                 }
                 reinterpret_cast<uint4 *>(acc)[w] = a;
@@ -304,7 +309,10 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             mark(2);
         }
         // the diagonal was accumulated like any other cell: clear it (the reference never adds to it, .pyx:392)
-        if (tid == 0 && c >= tile_base && c < tile_base + n_tile) acc[c - tile_base] = 0.f;
+        if (tid == 0 && c >= tile_base && c < tile_base + n_tile) {
+            if (UNIT) acc[c - tile_base] = 0.f;
+            else acc_d[c - tile_base] = 0.0;
+        }
         __syncthreads();
 
         // ---- normalisation (.pyx:473-504), in place; count signs for the selection ----
@@ -312,37 +320,58 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         {
             const bool asym = p.normalize && p.kind == MI355REC_SIM_ASYMMETRIC;
             const float norm_c = asym ? p.norm_alpha[c] : p.norm[c];
-            const float4 *nj4 = reinterpret_cast<const float4 *>((asym ? p.norm_1ma : p.norm) + tile_base);
-            float4 *a4 = reinterpret_cast<float4 *>(acc);
-            // four cells per thread and step (the norm arrays are padded to a multiple of 4; cells beyond n_tile are 0)
-            for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) {
-                float4 q = a4[w];
-                if (UNIT) {
-                    const uint4 qu = *reinterpret_cast<const uint4 *>(&q);
-                    if ((qu.x | qu.y | qu.z | qu.w) == 0u) continue;
-                    q = make_float4((float)qu.x, (float)qu.y, (float)qu.z, (float)qu.w);
-                } else if (q.x == 0.f && q.y == 0.f && q.z == 0.f && q.w == 0.f) {
-                    continue;
+            const float *nj = (asym ? p.norm_1ma : p.norm) + tile_base;
+            auto account = [&](float v) {
+                npos += v > 0.f;
+                nneg += v < 0.f;
+                if (v > 0.f) {
+                    const uint32_t key = float_key(v);
+                    kmin = min(kmin, key);
+                    kmax = max(kmax, key);
                 }
-                const float4 nj = nj4[w];
-                float vv[4] = {q.x, q.y, q.z, q.w};
-                const float nn[4] = {nj.x, nj.y, nj.z, nj.w};
+            };
+            if (UNIT) {
+                const float4 *nj4 = reinterpret_cast<const float4 *>(nj);
+                float4 *a4 = reinterpret_cast<float4 *>(acc);
+                // four cells per thread and step (the norm arrays are padded to a multiple of 4; cells beyond n_tile are 0)
+                for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) {
+                    const uint4 qu = reinterpret_cast<const uint4 *>(acc)[w];
+                    if ((qu.x | qu.y | qu.z | qu.w) == 0u) continue;
+                    const float4 n4 = nj4[w];
+                    float vv[4] = {(float)qu.x, (float)qu.y, (float)qu.z, (float)qu.w};
+                    const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = vv[e];
-                    if (v != 0.f) {
-                        v = normalise(p, v, norm_c, nn[e]);
-                        npos += v > 0.f;
-                        nneg += v < 0.f;
-                        if (v > 0.f) {
-                            const uint32_t key = float_key(v);
-                            kmin = min(kmin, key);
-                            kmax = max(kmax, key);
+                    for (int e = 0; e < 4; ++e) {
+                        if (vv[e] != 0.f) {
+                            vv[e] = normalise(p, vv[e], norm_c, nn[e]);
+                            account(vv[e]);
                         }
                     }
-                    vv[e] = v;
+                    a4[w] = make_float4(vv[0], vv[1], vv[2], vv[3]);
                 }
-                a4[w] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            } else {
+                // float64 sums -> normalised float32 values in the first half of the same LDS bytes: every thread reads
+                // all of its cells into registers before anyone writes
+                float reg[F64_CELLS_PER_THREAD];
+#pragma unroll
+                for (int k = 0; k < F64_CELLS_PER_THREAD; ++k) {
+                    const int j = tid + k * THREADS;
+                    float v = 0.f;
+                    if (j < n_tile) {
+                        v = (float)acc_d[j];
+                        if (v != 0.f) {
+                            v = normalise(p, v, norm_c, nj[j]);
+                            account(v);
+                        }
+                    }
+                    reg[k] = v;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < F64_CELLS_PER_THREAD; ++k) {
+                    const int j = tid + k * THREADS;
+                    if (j < p.n_cols_pad) acc[j] = reg[k];
+                }
             }
         }
         if (p.topK == 0) {  // dense output (.pyx:507-510)
@@ -468,9 +497,44 @@ __global__ void row_center_kernel(const int *ptr, float *val, int n_rows, const 
     for (int q = ptr[wave] + lane; q < ptr[wave + 1]; q += 64) val[q] -= m;
 }
 
-__global__ void narrow_idx_kernel(const int *idx, size_t nnz, int tile_w, unsigned short *out) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = (unsigned short)(idx[i] % tile_w);          // id relative to the base of its accumulator tile
+// Padded length (multiple of 8 entries) of every (row, accumulator tile) segment; slot n_seg gets 0 so that the
+// exclusive scan over n_seg + 1 slots ends with the total.
+__global__ void seg_len_kernel(const int *csr_ptr, const int *row_tile_ptr, int n_rows, int n_tiles, int *len_pad) {
+    const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long n_seg = (long long)n_rows * n_tiles;
+    if (k > n_seg) return;
+    int len = 0;
+    if (k < n_seg) {
+        const int u = (int)(k / n_tiles), t = (int)(k % n_tiles);
+        if (n_tiles == 1) len = csr_ptr[u + 1] - csr_ptr[u];
+        else len = row_tile_ptr[(size_t)u * (n_tiles + 1) + t + 1] - row_tile_ptr[(size_t)u * (n_tiles + 1) + t];
+    }
+    len_pad[k] = (len + 7) & ~7;
+}
+
+// The profile stream of the column kernel (one wavefront per segment): ids relative to the tile base as uint16,
+// values as they are after pre-processing; padding entries point at the 4 spare accumulator cells and carry 0.
+__global__ void seg_fill_kernel(const int *csr_ptr, const int *row_tile_ptr, const int *csr_idx, const float *csr_val,
+                                const int *seg_ptr, int n_rows, int n_tiles, int tile_w, unsigned short *seg_idx16,
+                                float *seg_val) {
+    const long long k = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (k >= (long long)n_rows * n_tiles) return;
+    const int u = (int)(k / n_tiles), t = (int)(k % n_tiles);
+    int a, b;
+    if (n_tiles == 1) {
+        a = csr_ptr[u];
+        b = csr_ptr[u + 1];
+    } else {
+        a = row_tile_ptr[(size_t)u * (n_tiles + 1) + t];
+        b = row_tile_ptr[(size_t)u * (n_tiles + 1) + t + 1];
+    }
+    const int dst = seg_ptr[k], padded = seg_ptr[k + 1] - dst, len = b - a;
+    for (int q = lane; q < padded; q += 64) {
+        const bool real = q < len;
+        seg_idx16[dst + q] = (unsigned short)(real ? csr_idx[a + q] - t * tile_w : tile_w + (q & 3));
+        seg_val[dst + q] = real ? csr_val[a + q] : 0.f;
+    }
 }
 
 // row_tile_ptr[u][t] = first position of CSR row u whose column id is >= t * tile_w (rows have sorted ids).
@@ -629,7 +693,9 @@ struct mi355rec_sim {
     DeviceBuffer<unsigned long long> phase_ticks;
     std::vector<int4> items_host;   // host staging for the current call
     int n_split_columns = 0, n_part_items = 0;
-    DeviceBuffer<unsigned short> csr_idx16;
+    DeviceBuffer<unsigned short> seg_idx16;
+    DeviceBuffer<int> seg_ptr;
+    DeviceBuffer<float> seg_val;
     DeviceBuffer<int> row_tile_ptr, cand_idx;
     DeviceBuffer<float> cand_val;
     int tile_w = 0, n_tiles = 1;
@@ -691,7 +757,9 @@ void clamp_range(const mi355rec_sim *h, int32_t &s, int32_t &e) {
 // Runs the column kernel for [start,end) leaving results in d_idx/d_val (or d_dense when topK == 0).
 void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, float *d_dense) {
     const int n_local = end - start;
-    const size_t lds = (size_t)h->tile_w * 4 + (size_t)AUX_WORDS * 4;
+    const bool unit_kernel = h->unit_values && !h->row_w.ptr;
+    const int acc_words = (h->tile_w + 4) * (unit_kernel ? 1 : 2);
+    const size_t lds = (size_t)acc_words * 4 + (size_t)AUX_WORDS * 4;
     const int cus = multiprocessor_count();
     int threads = 1024, max_grid = cus;   // one 16-wave workgroup per CU when the accumulator owns the LDS
     if (lds <= 72 * 1024) {
@@ -745,7 +813,8 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     MI_HIP(hipMemcpyAsync(h->items.ptr, h->items_host.data(), sizeof(int4) * n_items, hipMemcpyHostToDevice, h->stream));
     MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(unsigned), h->stream));
     if (part_slots) {
-        if (h->part_buf.count < (size_t)part_slots * h->tile_w) h->part_buf.alloc((size_t)part_slots * h->tile_w);
+        const size_t pub_words = (size_t)h->tile_w * (unit_kernel ? 1 : 2);
+        if (h->part_buf.count < (size_t)part_slots * pub_words) h->part_buf.alloc((size_t)part_slots * pub_words);
         if (h->part_count.count < (size_t)part_slots) h->part_count.alloc((size_t)part_slots);
         MI_HIP(hipMemsetAsync(h->part_count.ptr, 0, sizeof(unsigned) * part_slots, h->stream));
     }
@@ -753,10 +822,11 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     SimParams p{};
     p.n_rows = h->n_rows;
     p.n_cols = h->n_cols;
-    p.n_cols_pad = h->tile_w;          // length of the LDS accumulator
+    p.n_cols_pad = h->tile_w;          // neighbour cells of the LDS accumulator
+    p.acc_cells = h->tile_w + 4;
+    p.acc_words = acc_words;
     p.tile_w = h->tile_w;
     p.n_tiles = h->n_tiles;
-    p.row_tile_ptr = h->row_tile_ptr.ptr;
     p.topK = h->cfg.topK;
     int P = 1;
     while (P < std::max(2, p.topK)) P <<= 1;
@@ -768,8 +838,9 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     p.tversky_alpha = h->cfg.tversky_alpha;
     p.tversky_beta = h->cfg.tversky_beta;
     p.csr_ptr = h->csr_ptr.ptr;
-    p.csr_idx16 = h->csr_idx16.ptr;
-    p.csr_val = h->csr_val.ptr;
+    p.seg_ptr = h->seg_ptr.ptr;
+    p.seg_idx16 = h->seg_idx16.ptr;
+    p.seg_val = h->seg_val.ptr;
     p.csc_ptr = h->csc_ptr.ptr;
     p.csc_idx = h->csc_idx.ptr;
     p.csc_val = h->csc_val.ptr;
@@ -843,12 +914,6 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         if (set_based) h->cfg.normalize = 0;  // .pyx:124-135
         h->n_rows = n_rows;
         h->n_cols = n_cols;
-        // accumulator tiling: the LDS holds MAX_TILE neighbour cells next to the 32 KiB selection scratch
-        h->tile_w = n_cols <= MAX_TILE ? ((n_cols + 3) & ~3) : MAX_TILE;
-        h->n_tiles = (n_cols + h->tile_w - 1) / h->tile_w;
-        if ((long long)h->n_tiles * h->cfg.topK > h->tile_w)
-            fail(MI355REC_E_UNSUPPORTED, "n_cols = %d with topK = %d: the per-tile candidates (%d x %d) do not fit the merge buffer",
-                 n_cols, h->cfg.topK, h->n_tiles, h->cfg.topK);
         h->nnz = (size_t)csr_indptr[n_rows];
         MI_REQUIRE(h->nnz > 0, "matrix has no stored values");
         MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -860,7 +925,6 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         // padding: the column kernel reads the profiles in aligned 16-byte chunks, a whole lane group at a time
         h->csr_idx.alloc_zero(nnz + 520, s);
         h->csr_val.alloc_zero(nnz + 520, s);
-        h->csr_idx16.alloc_zero(nnz + 520, s);
         MI_HIP(hipMemcpyAsync(h->csr_idx.ptr, csr_indices, nnz * sizeof(int), hipMemcpyHostToDevice, s));
         MI_HIP(hipMemcpyAsync(h->csr_val.ptr, csr_data, nnz * sizeof(float), hipMemcpyHostToDevice, s));
         if (row_weights) h->row_w.upload(row_weights, n_rows, s);
@@ -868,6 +932,27 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
 
         // pre-processing of the stored values (.pyx:158-164)
         if (set_based) hipLaunchKernelGGL(fill_kernel, dim3(eg), dim3(eb), 0, s, h->csr_val.ptr, nnz, 1.0f);
+        // All-ones data (implicit URMs, every set-based similarity) takes the integer-count kernel, which never reads
+        // the value arrays; mean-centred data never qualifies.
+        h->unit_values = set_based;
+        if (!set_based && cfg->similarity != MI355REC_SIM_ADJUSTED && cfg->similarity != MI355REC_SIM_PEARSON) {
+            DeviceBuffer<int> not_unit;
+            not_unit.alloc_zero(1, s);
+            hipLaunchKernelGGL(minmax_kernel, dim3(eg), dim3(eb), 0, s, h->csr_val.ptr, nnz, not_unit.ptr);
+            MI_HIP(hipGetLastError());
+            int nu = 1;
+            not_unit.download(&nu, 1, s);
+            MI_HIP(hipStreamSynchronize(s));
+            h->unit_values = (nu == 0);
+        }
+        // accumulator tiling: the LDS holds MAX_TILE count cells (MAX_TILE_F64 float64 cells for real-valued data or row
+        // weights) next to the 32 KiB selection scratch
+        const int max_tile = (h->unit_values && !row_weights) ? MAX_TILE : MAX_TILE_F64;
+        h->tile_w = n_cols <= max_tile ? ((n_cols + 3) & ~3) : max_tile;
+        h->n_tiles = (n_cols + h->tile_w - 1) / h->tile_w;
+        if ((long long)h->n_tiles * h->cfg.topK > h->tile_w)
+            fail(MI355REC_E_UNSUPPORTED, "n_cols = %d with topK = %d: the per-tile candidates (%d x %d) do not fit the merge buffer",
+                 n_cols, h->cfg.topK, h->n_tiles, h->cfg.topK);
         DeviceBuffer<float> row_mean;
         if (cfg->similarity == MI355REC_SIM_ADJUSTED) {
             row_mean.alloc((size_t)n_rows);
@@ -892,7 +977,6 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         pos_in.alloc(nnz);
         pos_out.alloc(nnz);
         key_out.alloc(nnz);
-        hipLaunchKernelGGL(narrow_idx_kernel, dim3(eg), dim3(eb), 0, s, h->csr_idx.ptr, nnz, h->tile_w, h->csr_idx16.ptr);
         if (h->n_tiles > 1) {
             h->row_tile_ptr.alloc((size_t)n_rows * (h->n_tiles + 1));
             hipLaunchKernelGGL(row_tile_ptr_kernel, dim3(div_up((int64_t)n_rows * (h->n_tiles + 1), 256)), dim3(256), 0, s,
@@ -921,6 +1005,29 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
             hipLaunchKernelGGL(col_center_kernel, dim3(eg), dim3(eb), 0, s, h->csr_idx.ptr, h->csr_val.ptr, nnz, mean.ptr);
             hipLaunchKernelGGL(col_center_csc_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_val.ptr, n_cols, mean.ptr);
         }
+        // the profile stream: (row, tile) segments padded to whole 16-byte chunks, from the pre-processed values
+        {
+            const long long n_seg = (long long)n_rows * h->n_tiles;
+            DeviceBuffer<int> len_pad;
+            DeviceBuffer<char> scan_tmp;
+            len_pad.alloc((size_t)n_seg + 1);
+            h->seg_ptr.alloc((size_t)n_seg + 1);
+            hipLaunchKernelGGL(seg_len_kernel, dim3(div_up(n_seg + 1, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->row_tile_ptr.ptr,
+                               n_rows, h->n_tiles, len_pad.ptr);
+            size_t scan_bytes = 0;
+            MI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, (int)(n_seg + 1), s));
+            scan_tmp.alloc(scan_bytes);
+            MI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp.ptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, (int)(n_seg + 1), s));
+            const size_t seg_cap = nnz + 7 * (size_t)n_seg + 520;     // every segment grows by at most 7 entries
+            MI_REQUIRE(seg_cap < (size_t)INT32_MAX, "matrix too large for 32-bit segment offsets");
+            h->seg_idx16.alloc_zero(seg_cap, s);
+            h->seg_val.alloc_zero(seg_cap, s);
+            hipLaunchKernelGGL(seg_fill_kernel, dim3(div_up(n_seg * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->row_tile_ptr.ptr,
+                               h->csr_idx.ptr, h->csr_val.ptr, h->seg_ptr.ptr, n_rows, h->n_tiles, h->tile_w, h->seg_idx16.ptr,
+                               h->seg_val.ptr);
+            MI_HIP(hipGetLastError());
+            MI_HIP(hipStreamSynchronize(s));      // the temporaries above go out of scope
+        }
         sumsq.alloc((size_t)n_cols);
         cost.alloc((size_t)n_cols);
         hipLaunchKernelGGL(column_stats_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_idx.ptr, h->csc_val.ptr,
@@ -933,19 +1040,12 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         }
         hipLaunchKernelGGL(norms_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, s, sumsq.ptr, n_cols, (int)set_based,
                            (int)asym, cfg->asymmetric_alpha, h->norm.ptr, h->norm_alpha.ptr, h->norm_1ma.ptr);
-        // all-ones data -> value arrays never read by the hot kernel
-        DeviceBuffer<int> not_unit;
-        not_unit.alloc_zero(1, s);
-        hipLaunchKernelGGL(minmax_kernel, dim3(eg), dim3(eb), 0, s, h->csr_val.ptr, nnz, not_unit.ptr);
         MI_HIP(hipGetLastError());
-        int nu = 1;
-        not_unit.download(&nu, 1, s);
         h->cost.resize(n_cols);
         cost.download(h->cost.data(), n_cols, s);
         h->csc_ptr_host.resize((size_t)n_cols + 1);
         h->csc_ptr.download(h->csc_ptr_host.data(), (size_t)n_cols + 1, s);
         MI_HIP(hipStreamSynchronize(s));
-        h->unit_values = (nu == 0);
 
         h->cost_order.resize(n_cols);
         std::iota(h->cost_order.begin(), h->cost_order.end(), 0);
@@ -958,6 +1058,8 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         const double weighted_len = (double)total_cost / (double)nnz;
         // each lane covers 8 profile entries per load: G lanes span 8*G entries
         h->group_lanes = weighted_len >= 1024 ? 64 : (weighted_len >= 320 ? 32 : 16);
+        // the float64 kernel has half the loads in flight per lane (DEPTH 2): narrower groups keep more profiles going
+        if (!(h->unit_values && !row_weights)) h->group_lanes = weighted_len >= 2048 ? 64 : (weighted_len >= 640 ? 32 : 16);
         if (getenv("MI355REC_SIM_G")) h->group_lanes = atoi(getenv("MI355REC_SIM_G"));
         *out = h.release();
     });
