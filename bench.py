@@ -320,9 +320,17 @@ def main():
             best = dt if best is None else min(best, dt)
         sst = sim.stats()
         sim_gbps = sst["algorithmic_bytes"] / (sst["kernel_ms"] * 1e-3) / 1e9
+        # what actually bounds the column kernel: LDS atomic adds, one per co-occurrence pair (ds_add_u32: 21.6 lane-adds
+        # per CU and ns measured on MI355X with random cells, scratch/micro/lds_atomics.hip; 256 CUs), and the bytes its
+        # own layout streams (uint16 ids, no values for all-ones data)
+        pairs = float(np.asarray(costs[s:e], dtype=np.float64).sum())
+        pair_rate = pairs / (sst["kernel_ms"] * 1e-3)
+        extra.update({"itemknn_pairs_this_rank": pairs, "itemknn_pairs_per_s": pair_rate,
+                      "itemknn_frac_of_lds_atomic_peak": pair_rate / (21.6e9 * 256),
+                      "itemknn_stream_GBps_this_rank": 2.0 * pairs / (sst["kernel_ms"] * 1e-3) / 1e9})
         extra.update({"itemknn_cosine_build_s": best, "itemknn_topK": TOPK,
                       "itemknn_kernel_ms_this_rank": sst["kernel_ms"], "itemknn_columns_this_rank": int(e - s),
-                      "itemknn_algorithmic_GBps_this_rank": sim_gbps, "itemknn_frac_of_hbm_peak": sim_gbps / HBM_PEAK_GBPS,
+                      "itemknn_algorithmic_GBps_this_rank": sim_gbps, "itemknn_algorithmic_over_hbm_peak": sim_gbps / HBM_PEAK_GBPS,
                       "itemknn_nnz_out": int((idx >= 0).sum())})
         sim.close()
 
