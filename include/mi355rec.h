@@ -71,7 +71,15 @@ enum {                       /* `similarity=` strings of Compute_Similarity_Cyth
     MI355REC_SIM_PEARSON    = 3,
     MI355REC_SIM_JACCARD    = 4,   /* == "tanimoto" */
     MI355REC_SIM_DICE       = 5,
-    MI355REC_SIM_TVERSKY    = 6
+    MI355REC_SIM_TVERSKY    = 6,
+    MI355REC_SIM_EUCLIDEAN  = 7    /* Base/Similarity/Compute_Similarity_Euclidean.py:16 (reached through the dispatcher,
+                                    * Compute_Similarity.py:59-62): 1 / (f(distance) + shrink + 1e-9), float32 arithmetic */
+};
+
+enum {                       /* `similarity_from_distance_mode=` of Compute_Similarity_Euclidean (:46-57, :189-196) */
+    MI355REC_EUCLID_LIN = 0, /* f(d) = d         */
+    MI355REC_EUCLID_LOG = 1, /* f(d) = log(d+1)  */
+    MI355REC_EUCLID_EXP = 2  /* f(d) = exp(d)    */
 };
 
 typedef struct {
@@ -83,6 +91,9 @@ typedef struct {
     int32_t unit_column_side;   /* 1: the value of (row u, column c) on the COLUMN side of the product is taken as 1, i.e.
                                  * out(c, j) = sum over the rows u storing c of data[u, j] -- the boolean-transpose product of
                                  * the graph recommenders (GraphBased/P3alphaRecommender.py:69-104); 0: the plain self-product */
+    int32_t normalize_avg_row;  /* MI355REC_SIM_EUCLIDEAN only: squared distance divided by n_rows (Euclidean.py:181-182);
+                                 * `normalize` then means squared distance / (|a| |b|) (:178-179) */
+    int32_t euclidean_mode;     /* MI355REC_EUCLID_* */
 } mi355rec_sim_config;
 
 typedef struct mi355rec_sim *mi355rec_sim_t;

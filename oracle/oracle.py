@@ -428,6 +428,69 @@ class OracleSimilarity:
         return idx, val
 
 
+class OracleSimilarityEuclidean:
+    """Restates Compute_Similarity_Euclidean (Base/Similarity/Compute_Similarity_Euclidean.py:13; compute_similarity
+    :87-248) in NumPy, in the dtype of the input like the reference (float32 for a URM): squared distances from the
+    Gram matrix (:167-172), optional division by the product of the norms (:178-179) and by n_rows (:181-182), square
+    root (:184), the three distance -> similarity maps (:186-196), zero diagonal (:202), top-K of the whole column with
+    zeros dropped (:213-224).  row_weights are not restated (the reference's use of them only runs on square inputs,
+    :174-175).  `dense()` returns every column; `compute_similarity()` the csr_matrix the reference returns."""
+
+    MODES = ("lin", "log", "exp")
+
+    def __init__(self, dataMatrix, topK=100, shrink=0, normalize=False, normalize_avg_row=False,
+                 similarity_from_distance_mode="lin"):
+        if similarity_from_distance_mode not in self.MODES:
+            raise ValueError("Compute_Similarity_Euclidean: value for parameter 'mode' not recognized.")
+        self.X = dataMatrix.copy()      # the caller's sparse format: float32 summation order depends on it (:44)
+        self.n_rows, self.n_columns = self.X.shape
+        self.TopK = min(int(topK), self.n_columns)
+        self.shrink, self.normalize, self.normalize_avg_row = shrink, bool(normalize), bool(normalize_avg_row)
+        self.mode = similarity_from_distance_mode
+        self.sq = np.asarray(self.X.power(2).sum(axis=0)).ravel()          # item_distance_initial (:112)
+        self.rt = np.sqrt(self.sq)                                         # sumOfSquared (:113)
+
+    def columns(self, start, end):
+        """Similarity columns [start, end) as an (n_columns, end - start) array of the input dtype."""
+        block = self.X[:, start:end].toarray()
+        gram = np.asarray(self.X.T.dot(block))                             # (:156)
+        out = np.empty_like(gram)
+        for k, c in enumerate(range(start, end)):
+            d2 = self.sq.copy()
+            d2 += self.sq[c]
+            d2 -= 2 * gram[:, k]
+            d2[c] = 0.0
+            if self.normalize:
+                d2 /= self.rt[c] * self.rt
+            if self.normalize_avg_row:
+                d2 /= self.n_rows
+            with np.errstate(invalid="ignore"):
+                d = np.sqrt(d2)
+            if self.mode == "exp":
+                sim = 1 / (np.exp(d) + self.shrink + 1e-9)
+            elif self.mode == "lin":
+                sim = 1 / (d + self.shrink + 1e-9)
+            else:
+                sim = 1 / (np.log(d + 1) + self.shrink + 1e-9)
+            sim[c] = 0.0
+            out[:, k] = sim
+        return out
+
+    def dense(self):
+        return self.columns(0, self.n_columns)
+
+    def compute_similarity(self):
+        W = self.dense()
+        rows, cols, vals = [], [], []
+        for c in range(self.n_columns):
+            w = W[:, c]
+            part = (-w).argpartition(self.TopK - 1)[0:self.TopK]
+            top = part[np.argsort(-w[part])]
+            top = top[w[top] != 0.0]
+            rows.extend(top); cols.extend([c] * len(top)); vals.extend(w[top])
+        return sps.csr_matrix((vals, (rows, cols)), shape=(self.n_columns, self.n_columns), dtype=np.float32)
+
+
 def slabs_to_csr(idx, val, start_col, n_columns):
     """(n_local, topK) neighbour/value slabs (-1 padded) -> csr_matrix with column = source item (.pyx:603-605)."""
     keep = idx >= 0

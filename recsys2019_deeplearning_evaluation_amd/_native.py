@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_HERE, "libmi355rec.so")
 E_INVALID, E_HIP, E_NO_DEVICE, E_UNSUPPORTED, E_NUMERIC = -1, -2, -3, -4, -5
 
 SIMILARITY_CODES = {"cosine": 0, "adjusted": 1, "asymmetric": 2, "pearson": 3, "jaccard": 4, "tanimoto": 4,
-                    "dice": 5, "tversky": 6}
+                    "dice": 5, "tversky": 6, "euclidean": 7}
+EUCLIDEAN_MODE_CODES = {"lin": 0, "log": 1, "exp": 2}
 SGD_MODE_CODES = {"sgd": 0, "adagrad": 1, "rmsprop": 2, "adam": 3}
 ALGORITHM_CODES = {"MF_BPR": 0, "FUNK_SVD": 1, "ASY_SVD": 2}
 
@@ -37,7 +38,7 @@ class Stats(C.Structure):
 class SimConfig(C.Structure):
     _fields_ = [("topK", C.c_int32), ("shrink", C.c_int32), ("normalize", C.c_int32), ("similarity", C.c_int32),
                 ("asymmetric_alpha", C.c_float), ("tversky_alpha", C.c_float), ("tversky_beta", C.c_float),
-                ("unit_column_side", C.c_int32)]
+                ("unit_column_side", C.c_int32), ("normalize_avg_row", C.c_int32), ("euclidean_mode", C.c_int32)]
 
 
 class MFConfig(C.Structure):

@@ -31,6 +31,7 @@ struct SimParams {
     int acc_words;                     // 32-bit words of the accumulator: acc_cells (uint32 counts) or 2 * acc_cells (float64)
     int topK, sortP;
     int kind, normalize, unit_col;
+    int avg_row, euclid_mode;          // MI355REC_SIM_EUCLIDEAN
     float shrink, tversky_alpha, tversky_beta;
     const int *csr_ptr;
     // Profile stream: every (row, accumulator tile) segment of the CSR matrix, padded to a multiple of 8 entries so
@@ -67,6 +68,21 @@ __device__ __forceinline__ float normalise(const SimParams &p, float v, float no
         return v / (v + (norm_c - v) * p.tversky_alpha + (norm_j - v) * p.tversky_beta + p.shrink + 1e-6f);
     if (p.shrink != 0.f) return v / p.shrink;
     return v;
+}
+
+// Compute_Similarity_Euclidean.compute_similarity (Euclidean.py:167-203), one cell: the reference works in float32
+// NumPy arithmetic (the dtype of the URM), one operation per statement -- restated with explicitly rounded float32
+// operations so that no multiply-add is contracted.  sq_* = sum of squares of the column, rt_* = its square root.
+// Deviation: a squared distance that rounds below zero is clamped to 0 (the reference takes sqrt of it and emits nan).
+__device__ __forceinline__ float euclidean_cell(const SimParams &p, float dot, float sq_c, float sq_j, float rt_c, float rt_j) {
+    float d2 = __fsub_rn(__fadd_rn(sq_j, sq_c), __fmul_rn(2.f, dot));          // (a-b)^2 = a^2 + b^2 - 2ab   (:167-172)
+    if (p.normalize) d2 = __fdiv_rn(d2, __fmul_rn(rt_c, rt_j));                // :178-179
+    if (p.avg_row) d2 = __fdiv_rn(d2, (float)p.n_rows);                        // :181-182
+    const float d = __fsqrt_rn(fmaxf(d2, 0.f));                                // :184
+    float f = d;                                                               // "lin" :189-190
+    if (p.euclid_mode == MI355REC_EUCLID_EXP) f = expf(d);                     // :186-187
+    else if (p.euclid_mode == MI355REC_EUCLID_LOG) f = logf(__fadd_rn(d, 1.f));  // :192-193
+    return __fdiv_rn(1.f, __fadd_rn(__fadd_rn(f, p.shrink), 1e-9f));
 }
 
 // THREADS: workgroup size; G: lanes that cooperate on one user profile (sub-wave group);
@@ -319,8 +335,11 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         uint32_t npos = 0, nneg = 0, kmin = 0xFFFFFFFFu, kmax = 0u;   // key range of the positive cells
         {
             const bool asym = p.normalize && p.kind == MI355REC_SIM_ASYMMETRIC;
+            const bool euclid = p.kind == MI355REC_SIM_EUCLIDEAN;      // every cell but the diagonal gets a value
             const float norm_c = asym ? p.norm_alpha[c] : p.norm[c];
+            const float sq_c = euclid ? p.norm_alpha[c] : 0.f;         // euclidean: norm_alpha holds the sums of squares
             const float *nj = (asym ? p.norm_1ma : p.norm) + tile_base;
+            const float *sqj = p.norm_alpha + tile_base;
             auto account = [&](float v) {
                 npos += v > 0.f;
                 nneg += v < 0.f;
@@ -336,15 +355,26 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                 // four cells per thread and step (the norm arrays are padded to a multiple of 4; cells beyond n_tile are 0)
                 for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) {
                     const uint4 qu = reinterpret_cast<const uint4 *>(acc)[w];
-                    if ((qu.x | qu.y | qu.z | qu.w) == 0u) continue;
+                    if (!euclid && (qu.x | qu.y | qu.z | qu.w) == 0u) continue;
                     const float4 n4 = nj4[w];
                     float vv[4] = {(float)qu.x, (float)qu.y, (float)qu.z, (float)qu.w};
                     const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+                    if (euclid) {
+                        const float4 s4 = reinterpret_cast<const float4 *>(sqj)[w];
+                        const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (vv[e] != 0.f) {
-                            vv[e] = normalise(p, vv[e], norm_c, nn[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            const int j = 4 * w + e;
+                            vv[e] = (j < n_tile && tile_base + j != c) ? euclidean_cell(p, vv[e], sq_c, ss[e], norm_c, nn[e]) : 0.f;
                             account(vv[e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (vv[e] != 0.f) {
+                                vv[e] = normalise(p, vv[e], norm_c, nn[e]);
+                                account(vv[e]);
+                            }
                         }
                     }
                     a4[w] = make_float4(vv[0], vv[1], vv[2], vv[3]);
@@ -359,7 +389,10 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                     float v = 0.f;
                     if (j < n_tile) {
                         v = (float)acc_d[j];
-                        if (v != 0.f) {
+                        if (euclid) {
+                            v = tile_base + j != c ? euclidean_cell(p, v, sq_c, sqj[j], norm_c, nj[j]) : 0.f;
+                            account(v);
+                        } else if (v != 0.f) {
                             v = normalise(p, v, norm_c, nj[j]);
                             account(v);
                         }
@@ -640,11 +673,16 @@ __global__ void col_center_csc_kernel(const int *csc_ptr, float *csc_val, int n_
 }
 
 // sumOfSquared -> norms (.pyx:169-177)
-__global__ void norms_kernel(const double *sumsq, int n_cols, int set_based, int asymmetric, float alpha, float *norm,
-                             float *norm_alpha, float *norm_1ma) {
+__global__ void norms_kernel(const double *sumsq, int n_cols, int set_based, int asymmetric, int euclidean, float alpha,
+                             float *norm, float *norm_alpha, float *norm_1ma) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cols) return;
     double s = sumsq[c];
+    if (euclidean) {   // float32 like the reference: item_distance_initial and its square root (Euclidean.py:112-113)
+        norm_alpha[c] = (float)s;
+        norm[c] = __fsqrt_rn((float)s);
+        return;
+    }
     if (!set_based) s = sqrt(s);
     norm[c] = (float)s;
     if (asymmetric) {
@@ -834,6 +872,8 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     p.kind = h->cfg.similarity;
     p.normalize = h->cfg.normalize;
     p.unit_col = h->cfg.unit_column_side;
+    p.avg_row = h->cfg.normalize_avg_row;
+    p.euclid_mode = h->cfg.euclidean_mode;
     p.shrink = (float)h->cfg.shrink;
     p.tversky_alpha = h->cfg.tversky_alpha;
     p.tversky_beta = h->cfg.tversky_beta;
@@ -899,8 +939,15 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
     return guarded([&] {
         MI_REQUIRE(out && cfg && csr_indptr && csr_indices && csr_data, "NULL argument");
         MI_REQUIRE(n_rows > 0 && n_cols > 0, "empty matrix (%d x %d)", n_rows, n_cols);
-        MI_REQUIRE(cfg->similarity >= MI355REC_SIM_COSINE && cfg->similarity <= MI355REC_SIM_TVERSKY,
+        MI_REQUIRE(cfg->similarity >= MI355REC_SIM_COSINE && cfg->similarity <= MI355REC_SIM_EUCLIDEAN,
                    "Cosine_Similarity: value for parameter 'mode' not recognized (%d)", cfg->similarity);
+        const bool euclid = cfg->similarity == MI355REC_SIM_EUCLIDEAN;
+        if (euclid) {
+            MI_REQUIRE(cfg->euclidean_mode >= MI355REC_EUCLID_LIN && cfg->euclidean_mode <= MI355REC_EUCLID_EXP,
+                       "Compute_Similarity_Euclidean: value for parameter 'mode' not recognized (%d)", cfg->euclidean_mode);
+            // the reference multiplies the length-n_cols distance vector by the length-n_rows weights (Euclidean.py:174-175)
+            if (row_weights) fail(MI355REC_E_UNSUPPORTED, "Compute_Similarity_Euclidean: row_weights are not supported");
+        }
         MI_REQUIRE(cfg->topK >= 0, "topK must be >= 0");
         ensure_device();
         std::unique_ptr<mi355rec_sim> h(new mi355rec_sim());
@@ -1034,12 +1081,13 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
                            h->csr_ptr.ptr, n_cols, (float *)nullptr, sumsq.ptr, cost.ptr);
         h->norm.alloc_zero((size_t)n_cols + 4, s);
         const bool asym = cfg->similarity == MI355REC_SIM_ASYMMETRIC;
+        if (euclid) h->norm_alpha.alloc_zero((size_t)n_cols + 4, s);     // sums of squares
         if (asym) {
             h->norm_alpha.alloc_zero((size_t)n_cols + 4, s);
             h->norm_1ma.alloc_zero((size_t)n_cols + 4, s);
         }
         hipLaunchKernelGGL(norms_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, s, sumsq.ptr, n_cols, (int)set_based,
-                           (int)asym, cfg->asymmetric_alpha, h->norm.ptr, h->norm_alpha.ptr, h->norm_1ma.ptr);
+                           (int)asym, (int)euclid, cfg->asymmetric_alpha, h->norm.ptr, h->norm_alpha.ptr, h->norm_1ma.ptr);
         MI_HIP(hipGetLastError());
         h->cost.resize(n_cols);
         cost.download(h->cost.data(), n_cols, s);

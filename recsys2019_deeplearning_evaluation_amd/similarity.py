@@ -35,8 +35,9 @@ class Compute_Similarity_MI355X:
     SIMILARITY_VALUES = ("cosine", "pearson", "adjusted", "asymmetric", "jaccard", "tanimoto", "dice", "tversky")
 
     def __init__(self, dataMatrix, topK=100, shrink=0, normalize=True, asymmetric_alpha=0.5, tversky_alpha=1.0,
-                 tversky_beta=1.0, similarity="cosine", row_weights=None, unit_column_side=False):
-        if similarity not in self.SIMILARITY_VALUES:
+                 tversky_beta=1.0, similarity="cosine", row_weights=None, unit_column_side=False,
+                 normalize_avg_row=False, similarity_from_distance_mode="lin"):
+        if similarity not in self.SIMILARITY_VALUES and similarity != "euclidean":
             raise ValueError("Cosine_Similarity: value for parameter 'mode' not recognized."
                              " Allowed values are: 'cosine', 'pearson', 'adjusted', 'asymmetric', 'jaccard', 'tanimoto',"
                              "dice, tversky. Passed value was '{}'".format(similarity))
@@ -52,7 +53,8 @@ class Compute_Similarity_MI355X:
         indptr, indices, data = N.as_i32(csr.indptr), N.as_i32(csr.indices), N.as_f32(csr.data)
         rw = None if row_weights is None else N.as_f32(row_weights)
         cfg = N.SimConfig(self.TopK, int(shrink), int(bool(normalize)), N.SIMILARITY_CODES[similarity],
-                          float(asymmetric_alpha), float(tversky_alpha), float(tversky_beta), int(bool(unit_column_side)))
+                          float(asymmetric_alpha), float(tversky_alpha), float(tversky_beta), int(bool(unit_column_side)),
+                          int(bool(normalize_avg_row)), N.EUCLIDEAN_MODE_CODES.get(similarity_from_distance_mode, -1))
         self._lib = N.load()
         self._h = C.c_void_p()
         N.check(self._lib.mi355rec_sim_create(C.byref(self._h), C.byref(cfg), self.n_rows, self.n_columns,
@@ -123,19 +125,39 @@ class Compute_Similarity_MI355X:
         return slabs_to_csr(idx, val, s, self.n_columns)
 
 
+class Compute_Similarity_Euclidean_MI355X(Compute_Similarity_MI355X):
+    """Drop-in for Compute_Similarity_Euclidean (Base/Similarity/Compute_Similarity_Euclidean.py:13): same constructor
+    keywords and defaults (normalize=False!), same `compute_similarity(start_col, end_col)` and csr_matrix float32
+    result.  similarity = 1 / (f(distance) + shrink + 1e-9) with f = identity / log(1 + .) / exp for "lin" / "log" / "exp",
+    every pair of columns has one (no co-occurrence needed), the diagonal is 0.  `row_weights` raise NotImplementedError:
+    the reference multiplies the length-n_cols distance vector by the length-n_rows weights (:174-175), which only
+    runs on square inputs."""
+
+    def __init__(self, dataMatrix, topK=100, shrink=0, normalize=False, normalize_avg_row=False,
+                 similarity_from_distance_mode="lin", row_weights=None, **args):
+        if similarity_from_distance_mode not in N.EUCLIDEAN_MODE_CODES:
+            raise ValueError("Compute_Similarity_Euclidean: value for parameter 'mode' not recognized."
+                             " Allowed values are: 'exp', 'lin', 'log'."
+                             " Passed value was '{}'".format(similarity_from_distance_mode))
+        if row_weights is not None and dataMatrix.shape[0] != len(row_weights):
+            raise ValueError("Compute_Similarity_Euclidean: provided row_weights and dataMatrix have different number of rows."
+                             "row_weights has {} rows, dataMatrix has {}.".format(len(row_weights), dataMatrix.shape[0]))
+        super().__init__(dataMatrix, topK=topK, shrink=shrink, normalize=normalize, similarity="euclidean",
+                         row_weights=row_weights, normalize_avg_row=normalize_avg_row,
+                         similarity_from_distance_mode=similarity_from_distance_mode)
+
+
 class Compute_Similarity:
     """Dispatcher with the reference's signature (Compute_Similarity.py:32).  `use_implementation` accepts
     "mi355x" (also chosen by the reference's default "density" rule and by "cython"): on this path every
-    implementation name resolves to the device kernels; "python" and similarity="euclidean" are outside the
-    hot path and raise NotImplementedError instead of silently running on the CPU."""
+    implementation name resolves to the device kernels, similarity="euclidean" goes to the Euclidean front-end as in
+    the reference (:59-62); "python" raises NotImplementedError instead of silently running on the CPU."""
 
     def __init__(self, dataMatrix, use_implementation="density", similarity=None, **args):
         assert np.all(np.isfinite(dataMatrix.data)), \
             "Compute_Similarity: Data matrix contains {} non finite values".format(
                 np.sum(np.logical_not(np.isfinite(dataMatrix.data))))
-        if similarity == "euclidean":
-            raise NotImplementedError("Compute_Similarity: 'euclidean' is not on the MI355X hot path")
-        assert not (dataMatrix.shape[0] == 1 and dataMatrix.nnz == dataMatrix.shape[1]), \
+        assert similarity == "euclidean" or not (dataMatrix.shape[0] == 1 and dataMatrix.nnz == dataMatrix.shape[1]), \
             "Compute_Similarity: data has only 1 feature (shape: {}) with dense values," \
             " vector and set based similarities are not defined on 1-dimensional dense data," \
             " use Euclidean similarity instead.".format(dataMatrix.shape)
@@ -147,7 +169,11 @@ class Compute_Similarity:
             raise ValueError("Compute_Similarity: value for argument 'use_implementation' not recognized")
         if isinstance(dataMatrix, np.ndarray):
             dataMatrix = sps.csr_matrix(dataMatrix)
-        self.compute_similarity_object = Compute_Similarity_MI355X(dataMatrix, **args)
+        if similarity == "euclidean":
+            args.pop("similarity", None)
+            self.compute_similarity_object = Compute_Similarity_Euclidean_MI355X(dataMatrix, **args)
+        else:
+            self.compute_similarity_object = Compute_Similarity_MI355X(dataMatrix, **args)
 
     def compute_similarity(self, **args):
         return self.compute_similarity_object.compute_similarity(**args)

@@ -170,6 +170,23 @@ def main():
         out["W_%d" % n] = rec.W_sparse.toarray().astype(np.float64)
     out["cases"] = np.array(json.dumps(cases))
     np.savez_compressed(os.path.join(HERE, "graph_based.npz"), **out)
+    # ---------------- Euclidean similarity (pure-Python reference) ----------------
+    EUC = ref_loader.load_python_reference("Base.Similarity.Compute_Similarity_Euclidean", "Compute_Similarity_Euclidean")
+    Xe = small_urm(60, 40, 0.2, 18, real=True)
+    Xe.data = np.round(Xe.data)          # integer ratings: the reference's float32 sums are exact, parity is 1e-6
+    out = pack_csr("X", Xe)
+    Xj = small_urm(60, 40, 0.2, 19, real=True)     # jittered ratings: float32 cancellation noise in the reference
+    out.update(pack_csr("Xj", Xj))
+    cases = []
+    for mode in ("lin", "log", "exp"):
+        for normalize, avg_row, shrink in ((False, False, 0), (True, False, 2), (False, True, 0), (True, True, 5)):
+            cases.append(dict(similarity_from_distance_mode=mode, normalize=normalize, normalize_avg_row=avg_row, shrink=shrink))
+    for n, kw in enumerate(cases):
+        out["dense_%d" % n] = quiet(lambda: EUC(Xe, topK=Xe.shape[1], **kw).compute_similarity()).toarray().astype(np.float32)
+        out["top_%d" % n] = quiet(lambda: EUC(Xe, topK=6, **kw).compute_similarity()).toarray().astype(np.float32)
+    out["densej_0"] = quiet(lambda: EUC(Xj, topK=Xj.shape[1], **cases[0]).compute_similarity()).toarray().astype(np.float32)
+    out["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(HERE, "euclidean.npz"), **out)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -85,3 +85,19 @@ def test_ials_oracle_matches_reference_outputs():
             O.oracle_ials_epoch(Cm, Cc, U, V, kw["reg"])
         np.testing.assert_allclose(U, z["U_%d" % n], rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(V, z["V_%d" % n], rtol=1e-10, atol=1e-12)
+
+
+def test_euclidean_oracle_is_bit_exact_with_reference_outputs():
+    """Same NumPy float32 operations in the same order: the restatement reproduces the reference's dense columns and
+    its top-K csr_matrix exactly (integer ratings and jittered ones alike)."""
+    z, cases = load_golden("euclidean")
+    X = unpack_csr(z, "X")
+    for n, kw in enumerate(cases):
+        orc = O.OracleSimilarityEuclidean(X, topK=X.shape[1], **kw)
+        assert np.array_equal(orc.dense().astype(np.float32), z["dense_%d" % n]), kw
+        top = O.OracleSimilarityEuclidean(X, topK=6, **kw).compute_similarity().toarray()
+        assert np.array_equal(top, z["top_%d" % n]), kw
+    Xj = unpack_csr(z, "Xj")
+    assert np.array_equal(O.OracleSimilarityEuclidean(Xj, topK=Xj.shape[1], **cases[0]).dense().astype(np.float32), z["densej_0"])
+    with pytest.raises(ValueError):
+        O.OracleSimilarityEuclidean(X, similarity_from_distance_mode="sqrt")

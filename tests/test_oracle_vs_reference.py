@@ -112,3 +112,13 @@ def test_baseline_config_1_itemknn_cosine_ml1m_shape(ref):
     Wb = orc.compute_similarity()                       # C top-K (tie-free input => same as NumPy's)
     assert Wa.shape == (3706, 3706) and Wa.nnz == Wb.nnz == 3706 * 100
     assert abs(Wa - Wb).max() == 0
+
+
+@pytest.mark.parametrize("mode", ["lin", "log", "exp"])
+def test_euclidean_bit_exact(ref, mode):
+    EUC = ref_loader.load_python_reference("Base.Similarity.Compute_Similarity_Euclidean", "Compute_Similarity_Euclidean")
+    X = synthetic_urm(150, 90, 2500, seed=5, values="real")
+    for kw in (dict(normalize=False, normalize_avg_row=False, shrink=0), dict(normalize=True, normalize_avg_row=True, shrink=3)):
+        want = _quiet(lambda: EUC(X, topK=10, similarity_from_distance_mode=mode, **kw).compute_similarity()).toarray()
+        got = O.OracleSimilarityEuclidean(X, topK=10, similarity_from_distance_mode=mode, **kw).compute_similarity().toarray()
+        assert np.array_equal(got, want)
