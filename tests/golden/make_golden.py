@@ -170,6 +170,19 @@ def main():
         out["W_%d" % n] = rec.W_sparse.toarray().astype(np.float64)
     out["cases"] = np.array(json.dumps(cases))
     np.savez_compressed(os.path.join(HERE, "graph_based.npz"), **out)
+    # ---------------- EASE_R (pure-Python reference over the compiled similarity) ----------------
+    EASE = ref_loader.load_python_reference("EASE_R.EASE_R_Recommender", "EASE_R_Recommender")
+    Xs = small_urm(70, 45, 0.18, 21, real=True)
+    out = pack_csr("X", Xs)
+    cases = [dict(topK=None, l2_norm=50.0, normalize_matrix=False), dict(topK=7, l2_norm=10.0, normalize_matrix=True),
+             dict(topK=None, l2_norm=1e3, normalize_matrix=True)]
+    for n, kw in enumerate(cases):
+        rec = quiet(lambda: EASE(Xs.copy()))
+        quiet(lambda: rec.fit(verbose=False, **kw))
+        W = rec.W_sparse
+        out["W_%d" % n] = (W.toarray() if sps.issparse(W) else np.asarray(W)).astype(np.float32)
+    out["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(HERE, "ease_r.npz"), **out)
     # ---------------- Euclidean similarity (pure-Python reference) ----------------
     EUC = ref_loader.load_python_reference("Base.Similarity.Compute_Similarity_Euclidean", "Compute_Similarity_Euclidean")
     Xe = small_urm(60, 40, 0.2, 18, real=True)
