@@ -321,7 +321,7 @@ def main():
         sst = sim.stats()
         sim_gbps = sst["algorithmic_bytes"] / (sst["kernel_ms"] * 1e-3) / 1e9
         # what actually bounds the column kernel: LDS atomic adds, one per co-occurrence pair (ds_add_u32: 21.6 lane-adds
-        # per CU and ns measured on MI355X with random cells, scratch/micro/lds_atomics.hip; 256 CUs), and the bytes its
+        # per CU and ns measured on MI355X with random cells, scripts/micro/lds_atomics.hip; 256 CUs), and the bytes its
         # own layout streams (uint16 ids, no values for all-ones data)
         pairs = float(np.asarray(costs[s:e], dtype=np.float64).sum())
         pair_rate = pairs / (sst["kernel_ms"] * 1e-3)
