@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void score_gemm_kernel(const ScoreParams p) {
 }
 
 struct RankParams {
-    int n_items, n_pad, cutoff, sortP, remove_seen;
+    int n_items, n_pad, cutoff, remove_seen;
     const int *users, *seen_ptr, *seen_idx;
     const unsigned char *allowed;   // nullable: 0 marks an excluded item (items_to_compute / top-pop / custom filters)
     float *scores;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(THREADS) void score_rank_kernel(const RankParams p)
     for (int off = 32; off > 0; off >>= 1) nfin += __shfl_down(nfin, off);
     if (lane == 0 && nfin) atomicAdd(&s_nfinite, nfin);
     __syncthreads();
-    block_topk_emit<THREADS>(acc, p.n_items, p.cutoff, p.sortP, s_nfinite, 0u, TOPK_FINITE, aux, sc, &s_ncand,
+    block_topk_emit<THREADS>(acc, p.n_items, p.cutoff, s_nfinite, 0u, TOPK_FINITE, aux, sc, &s_ncand,
                              p.ranked + (size_t)b * p.cutoff, nullptr);
 }
 
@@ -220,9 +220,7 @@ extern "C" int mi355rec_scorer_recommend(mi355rec_scorer_t h, const int32_t *use
                               h->gemm_timer.t1, 0, sp);
         RankParams rp{};
         rp.n_items = h->n_items; rp.n_pad = (h->n_items + 3) & ~3; rp.cutoff = cutoff;
-        int P = 1;
-        while (P < std::max(2, cutoff)) P <<= 1;
-        rp.sortP = P; rp.remove_seen = remove_seen;
+        rp.remove_seen = remove_seen;
         rp.users = h->users.ptr; rp.seen_ptr = h->seen_ptr.ptr; rp.seen_idx = h->seen_idx.ptr;
         rp.allowed = item_allowed ? h->allowed.ptr : nullptr;
         rp.scores = h->scores.ptr; rp.ranked = h->ranked.ptr; rp.write_back = scores != nullptr;
@@ -267,7 +265,7 @@ namespace mi355rec {
 namespace {
 
 struct SpScoreParams {
-    int n_out, n_pad, cutoff, sortP, remove_seen, write_back;
+    int n_out, n_pad, cutoff, remove_seen, write_back;
     const int *a_ptr, *a_idx, *b_ptr, *b_idx;
     const float *a_val, *b_val;
     const int *users, *seen_ptr, *seen_idx;
@@ -313,7 +311,7 @@ __global__ __launch_bounds__(THREADS) void spscore_kernel(const SpScoreParams p)
     for (int off = 32; off > 0; off >>= 1) nfin += __shfl_down(nfin, off);
     if (lane == 0 && nfin) atomicAdd(&s_nfinite, nfin);
     __syncthreads();
-    block_topk_emit<THREADS>(acc, p.n_out, p.cutoff, p.sortP, s_nfinite, 0u, TOPK_FINITE, aux, sc, &s_ncand,
+    block_topk_emit<THREADS>(acc, p.n_out, p.cutoff, s_nfinite, 0u, TOPK_FINITE, aux, sc, &s_ncand,
                              p.ranked + (size_t)b * p.cutoff, nullptr);
 }
 
@@ -386,9 +384,7 @@ extern "C" int mi355rec_spscorer_recommend(mi355rec_spscorer_t h, const int32_t 
         if (item_allowed) MI_HIP(hipMemcpyAsync(h->allowed.ptr, item_allowed, h->n_out, hipMemcpyHostToDevice, s));
         SpScoreParams p{};
         p.n_out = h->n_out; p.n_pad = (h->n_out + 3) & ~3; p.cutoff = cutoff;
-        int P = 1;
-        while (P < std::max(2, cutoff)) P <<= 1;
-        p.sortP = P; p.remove_seen = remove_seen; p.write_back = scores != nullptr;
+        p.remove_seen = remove_seen; p.write_back = scores != nullptr;
         p.a_ptr = h->a_ptr.ptr; p.a_idx = h->a_idx.ptr; p.a_val = h->a_val.ptr;
         p.b_ptr = h->b_ptr.ptr; p.b_idx = h->b_idx.ptr; p.b_val = h->b_val.ptr;
         p.users = h->users.ptr; p.seen_ptr = h->seen_ptr.ptr; p.seen_idx = h->seen_idx.ptr;

@@ -4,11 +4,15 @@
 // column norms, CSR+CSC views), computeItemSimilarities :325-406 (the hot loop), compute_similarity :411-607
 // (normalisation :473-504, per-column top-K :523-562).
 //
-// Design: one persistent workgroup per CU pulls columns from a cost-ordered queue;
-// the per-column accumulator `this_item_weights` lives in LDS (4 B x n_cols), the co-occurrence products are
-// accumulated with LDS float atomics, normalised in place and reduced to the top-K by an in-LDS 4-pass radix
-// select (bank-replicated histograms) followed by a bitonic sort of the K survivors.  The URM is read through
-// L2 / Infinity Cache; nothing but the K results per column is written to HBM.
+// Also serves Compute_Similarity_Euclidean.py (euclidean_cell below), the boolean-transpose products of P3alpha / RP3beta
+// (unit_column_side) and the Gram step of EASE_R (dense output).
+//
+// Design: one persistent workgroup per CU pulls work items (columns, or parts of heavy
+// columns) from a cost-ordered queue; the per-column accumulator `this_item_weights` lives in LDS (uint32 counts for
+// all-ones data, float64 sums otherwise), the co-occurrence products are accumulated with LDS atomics from a padded
+// uint16 profile stream, normalised in place and reduced to the top-K by an in-LDS radix select with early exit
+// (bank-replicated histograms) and a counting rank of the survivors.  The URM is read through L2 / Infinity Cache;
+// nothing but the K results per column (and the partial accumulators of split columns) is written to HBM.
 #include "common.h"
 #include "topk.cuh"
 
@@ -29,7 +33,7 @@ struct SimParams {
     int n_rows, n_cols, n_cols_pad;    // n_cols_pad: neighbour cells of the LDS accumulator (tile width, multiple of 4)
     int acc_cells;                     // n_cols_pad + 4 spare cells that absorb the padding entries of the profiles
     int acc_words;                     // 32-bit words of the accumulator: acc_cells (uint32 counts) or 2 * acc_cells (float64)
-    int topK, sortP;
+    int topK;
     int kind, normalize, unit_col;
     int avg_row, euclid_mode;          // MI355REC_SIM_EUCLIDEAN
     float shrink, tversky_alpha, tversky_beta;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         long long total_nonzero = 0;
 
         // Columns wider than the LDS accumulator are processed in tiles of tile_w neighbour ids: every CSR entry
-        // belongs to exactly one tile (ids are stored tile-relative and row_tile_ptr marks the crossings), so the
+        // belongs to exactly one (row, tile) segment of the profile stream (ids are stored tile-relative), so the
         // tiles together read each profile once.  n_tiles == 1 is the common case.
         for (int tile = 0; tile < p.n_tiles; ++tile) {
         const int tile_base = tile * p.tile_w;
@@ -437,11 +441,11 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         if (p.n_tiles == 1) {
             // ---- top-K: the K largest cells of the FULL column (zeros compete, then are dropped), value-descending,
             //      emitted like the COO triples of .pyx:550-562 with -1 padding ----
-            block_topk_emit<THREADS>(acc, n_tile, p.topK, p.sortP, npos, nneg, TOPK_ZEROS_COMPETE, aux, sc, &s_ncand,
+            block_topk_emit<THREADS>(acc, n_tile, p.topK, npos, nneg, TOPK_ZEROS_COMPETE, aux, sc, &s_ncand,
                                      p.out_idx + out_base, p.out_val + out_base, 0, nullptr, -1, s_kmin, s_kmax);
         } else {
             // the tile's K best non-zero cells go to the workgroup's scratch; zeros are accounted for in the merge
-            block_topk_emit<THREADS>(acc, n_tile, p.topK, p.sortP, npos, nneg, TOPK_NONZERO, aux, sc, &s_ncand,
+            block_topk_emit<THREADS>(acc, n_tile, p.topK, npos, nneg, TOPK_NONZERO, aux, sc, &s_ncand,
                                      wg_cand_idx + tile * p.topK, wg_cand_val + tile * p.topK, tile_base);
         }
         __syncthreads();
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                 if (nneg) atomicAdd(&s_nneg, nneg);
             }
             __syncthreads();
-            block_topk_emit<THREADS>(acc, n_m, p.topK, p.sortP, s_npos, s_nneg, TOPK_ZEROS_COMPETE, aux, sc, &s_ncand,
+            block_topk_emit<THREADS>(acc, n_m, p.topK, s_npos, s_nneg, TOPK_ZEROS_COMPETE, aux, sc, &s_ncand,
                                      p.out_idx + out_base, p.out_val + out_base, 0, wg_cand_idx,
                                      (long long)p.n_cols - total_nonzero);
             __syncthreads();
@@ -866,9 +870,6 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     p.tile_w = h->tile_w;
     p.n_tiles = h->n_tiles;
     p.topK = h->cfg.topK;
-    int P = 1;
-    while (P < std::max(2, p.topK)) P <<= 1;
-    p.sortP = P;
     p.kind = h->cfg.similarity;
     p.normalize = h->cfg.normalize;
     p.unit_col = h->cfg.unit_column_side;

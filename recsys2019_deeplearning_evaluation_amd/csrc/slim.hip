@@ -166,7 +166,7 @@ __global__ __launch_bounds__(1024) void slim_ordered_kernel(const SlimParams p) 
 
 // get_S (.pyx:343-391): row r of S with the diagonal zeroed (symmetric store mirrored), then the per-row top-K.
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void slim_topk_kernel(const SlimParams p, int topK, int sortP, int n_pad, int *out_idx,
+__global__ __launch_bounds__(THREADS) void slim_topk_kernel(const SlimParams p, int topK, int n_pad, int *out_idx,
                                                             float *out_val) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *acc = smem;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(THREADS) void slim_topk_kernel(const SlimParams p, 
         __syncthreads();
         // symmetric store: Triangular_Matrix.get_scipy_csr ranks the FULL row (zeros compete, :1384-1404);
         // dense store: similarityMatrixTopK ranks the non-zero cells only (Base/Recommender_utils.py:100-104)
-        block_topk_emit<THREADS>(acc, p.n_items, topK, sortP, s_npos, s_nneg, p.symmetric ? TOPK_ZEROS_COMPETE : TOPK_NONZERO, aux, sc, &s_ncand,
+        block_topk_emit<THREADS>(acc, p.n_items, topK, s_npos, s_nneg, p.symmetric ? TOPK_ZEROS_COMPETE : TOPK_NONZERO, aux, sc, &s_ncand,
                                  out_idx + (size_t)r * topK, out_val + (size_t)r * topK);
         __syncthreads();
     }
@@ -442,8 +442,6 @@ extern "C" int mi355rec_slim_get_S_topk(mi355rec_slim_t h, int32_t topK, int32_t
         const size_t lds = (size_t)n_pad * 4 + (size_t)AUX_WORDS * 4;
         if (lds + 2048 > 160 * 1024)
             fail(MI355REC_E_UNSUPPORTED, "n_items = %d: a row of S does not fit the 160 KiB LDS for the top-K selection", h->n_items);
-        int P = 1;
-        while (P < std::max(2, topK)) P <<= 1;
         DeviceBuffer<int> d_idx;
         DeviceBuffer<float> d_val;
         const size_t n_out = (size_t)h->n_items * topK;
@@ -454,7 +452,7 @@ extern "C" int mi355rec_slim_get_S_topk(mi355rec_slim_t h, int32_t topK, int32_t
         auto k = slim_topk_kernel<1024>;
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds + 2048))));
-        hipLaunchKernelGGL(k, dim3(std::min(h->n_items, multiprocessor_count() * per_cu)), dim3(1024), lds, h->stream, p, topK, P,
+        hipLaunchKernelGGL(k, dim3(std::min(h->n_items, multiprocessor_count() * per_cu)), dim3(1024), lds, h->stream, p, topK,
                            n_pad, d_idx.ptr, d_val.ptr);
         MI_HIP(hipGetLastError());
         d_idx.download(nbr_idx, n_out, h->stream);

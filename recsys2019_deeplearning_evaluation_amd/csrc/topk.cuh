@@ -154,7 +154,7 @@ enum { TOPK_ZEROS_COMPETE = 0, TOPK_NONZERO = 1, TOPK_FINITE = 2 };
 // candidate counts the candidates above it: keys carry the index, so ranks are a permutation) -- or by a bitonic sort
 // when there are more than 1024 of them -- and written straight to their output slot.
 template <int THREADS>
-__device__ void block_topk_emit(const float *acc, int n, int topK, int sortP, uint32_t npos, uint32_t nneg, int mode,
+__device__ void block_topk_emit(const float *acc, int n, int topK, uint32_t npos, uint32_t nneg, int mode,
                                 uint32_t *aux, SelectScratch &sc, uint32_t *ncand_shared, int *out_idx, float *out_val,
                                 int idx_offset = 0, const int *idx_map = nullptr, long long zero_count = -1,
                                 uint32_t key_lo = 0u, uint32_t key_hi = 0xFFFFFFFFu) {

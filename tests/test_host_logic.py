@@ -145,3 +145,26 @@ def test_feature_weighting_matches_reference_fixture():
     np.testing.assert_allclose(apply_feature_weighting(X, "BM25", False).toarray(), z["bm25_T"].astype(np.float32), rtol=1e-6)
     np.testing.assert_allclose(apply_feature_weighting(X, "TF-IDF", True).toarray(), z["tfidf_T"].astype(np.float32), rtol=1e-6)
     assert apply_feature_weighting(X, "none", False) is X
+
+
+def test_similarity_column_ranges_add_the_fixed_per_column_part():
+    """Shard ranges for the similarity build balance pairs + a fixed per-column cost: with a head-heavy catalogue the
+    pure pair count would give the tail rank nearly all the columns (and all of their clearing / ranking work)."""
+    from recsys2019_deeplearning_evaluation_amd.sharding import FIXED_PAIRS_PER_CELL, similarity_column_ranges
+
+    class Stub:
+        n_columns = 1000
+
+        def column_costs(self):
+            c = np.full(1000, 10, dtype=np.int64)
+            c[:10] = 1_000_000
+            return c
+
+    plain = balanced_column_ranges(Stub().column_costs(), 2)
+    fixed = similarity_column_ranges(Stub(), 2)
+    assert plain[0][1] <= 6                                   # half of the pairs = five head columns
+    per_col = FIXED_PAIRS_PER_CELL * 1000
+    est = lambda r: sum(Stub().column_costs()[r[0]:r[1]]) + per_col * (r[1] - r[0])
+    assert abs(est(fixed[0]) - est(fixed[1])) <= 1_000_000 + per_col      # within one head column
+    assert fixed[0][1] > plain[0][1]
+    assert fixed[0][0] == 0 and fixed[-1][1] == 1000 and fixed[0][1] == fixed[1][0]
