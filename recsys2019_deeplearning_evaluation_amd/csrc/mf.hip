@@ -46,7 +46,8 @@ struct MfParams {
     const int *indptr, *indices;
     const float *data;
     float *U, *V, *accU, *accV;
-    float *bu, *bi, *mu, *acc_bu, *acc_bi, *acc_mu;
+    float *bu, *bi, *mu, *acc_bu, *acc_bi;
+    float *mu_slots;   // FunkSVD with bias: the global-bias gradient terms of a mini-batch, one partial sum per workgroup
     float *c1U, *c2U, *c1V, *c2V;        // optimiser state: c1 = cache / first moment, c2 = second moment
     float *c1_bu, *c2_bu, *c1_bi, *c2_bi, *c_mu;  // c_mu[0] = cache/m1, c_mu[1] = m2
     int *flag;                           // [n_users + n_items]
@@ -119,6 +120,8 @@ __global__ __launch_bounds__(256) void mf_grad_kernel(const MfParams p, const in
     // graph node), so the sample triplet is the first load of the kernel, not the second
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);   // sample slot inside the batch
+    __shared__ float s_mu[4];
+    float mu_term = 0.f;
     // count the mini-batches since create (Adam's beta^t): single writer here, read only by the apply kernel that follows
     if (blockIdx.x == 0 && threadIdx.x == 0) p.state->grad_batch += 1;
     double my_loss = 0.0;
@@ -197,7 +200,9 @@ __global__ __launch_bounds__(256) void mf_grad_kernel(const MfParams p, const in
             const float err = rating - pred;
             my_loss = (double)err * err;
             if (p.use_bias && lane == 0) {   // .pyx:329-336
-                atomicAdd(p.acc_mu, err - p.bias_reg * p.mu[0]);
+                // the global bias has ONE accumulator: a thousand same-address atomics serialise at ~12 ns each (12 of
+                // the 22 us of a mini-batch); the terms are summed per workgroup below and by the apply kernel instead
+                mu_term = err - p.bias_reg * p.mu[0];
                 atomicAdd(&p.acc_bi[i], err - p.bias_reg * p.bi[i]);
                 atomicAdd(&p.acc_bu[u], err - p.bias_reg * p.bu[u]);
             }
@@ -221,6 +226,11 @@ __global__ __launch_bounds__(256) void mf_grad_kernel(const MfParams p, const in
         }
     }
     if (lane == 0 && w < p.n_in_batch) p.loss_slots[w] += my_loss;   // slot w is private to this wavefront
+    if (ALGO != MI355REC_MF_BPR && p.use_bias) {
+        if (lane == 0) s_mu[threadIdx.x >> 6] = mu_term;
+        __syncthreads();
+        if (threadIdx.x == 0) p.mu_slots[blockIdx.x] = (s_mu[0] + s_mu[1]) + (s_mu[2] + s_mu[3]);
+    }
 }
 
 // adaptive_gradient (.pyx:835-873) on one cell; pw1/pw2 = 1 - beta^t
@@ -261,10 +271,14 @@ __global__ __launch_bounds__(256) void mf_apply_kernel(const MfParams p) {
         pw1 = (float)(1.0 - pow(p.beta_1_d, (double)t));
         pw2 = (float)(1.0 - pow(p.beta_2_d, (double)t));
     }
-    if (w == 0 && lane == 0 && p.use_bias) {
-        float g = adapt(p, p.acc_mu[0] * invB, p.c_mu, p.c_mu + 1, 0, pw1, pw2);
-        p.mu[0] += p.lr * g;
-        p.acc_mu[0] = 0.f;
+    if (w == 0 && p.use_bias) {                         // global bias: sum of the gradient kernel's per-workgroup partials
+        float acc_mu = 0.f;
+        for (int q = lane; q < (p.n_in_batch + 3) / 4; q += 64) acc_mu += p.mu_slots[q];
+        acc_mu = wave_sum(acc_mu);
+        if (lane == 0) {
+            float g = adapt(p, acc_mu * invB, p.c_mu, p.c_mu + 1, 0, pw1, pw2);
+            p.mu[0] += p.lr * g;
+        }
     }
     const int per = p.algorithm_is_bpr ? 3 : 2;
     if (w >= per * p.n_in_batch) return;
@@ -410,7 +424,7 @@ struct mi355rec_mf {
     hipStream_t stream = nullptr;
     StreamTimer timer;
     DeviceBuffer<int> indptr, indices, flag, list, su, si, sj;
-    DeviceBuffer<float> data, U, V, accU, accV, bu, bi, mu, acc_bu, acc_bi, acc_mu;
+    DeviceBuffer<float> data, U, V, accU, accV, bu, bi, mu, acc_bu, acc_bi, mu_slots;
     DeviceBuffer<float> c1U, c2U, c1V, c2V, c1_bu, c2_bu, c1_bi, c2_bi, c_mu, sr;
     DeviceBuffer<double> loss_slots;
     DeviceBuffer<MfState> state;
@@ -458,7 +472,7 @@ void fill_params(mi355rec_mf *h, MfParams &p) {
     p.indptr = h->indptr.ptr; p.indices = h->indices.ptr; p.data = h->data.ptr;
     p.U = h->U.ptr; p.V = h->V.ptr; p.accU = h->accU.ptr; p.accV = h->accV.ptr;
     p.bu = h->bu.ptr; p.bi = h->bi.ptr; p.mu = h->mu.ptr;
-    p.acc_bu = h->acc_bu.ptr; p.acc_bi = h->acc_bi.ptr; p.acc_mu = h->acc_mu.ptr;
+    p.acc_bu = h->acc_bu.ptr; p.acc_bi = h->acc_bi.ptr; p.mu_slots = h->mu_slots.ptr;
     p.c1U = h->c1U.ptr; p.c2U = h->c2U.ptr; p.c1V = h->c1V.ptr; p.c2V = h->c2V.ptr;
     p.c1_bu = h->c1_bu.ptr; p.c2_bu = h->c2_bu.ptr; p.c1_bi = h->c1_bi.ptr; p.c2_bi = h->c2_bi.ptr; p.c_mu = h->c_mu.ptr;
     p.flag = h->flag.ptr; p.list = h->list.ptr; p.loss_slots = h->loss_slots.ptr; p.state = h->state.ptr;
@@ -632,7 +646,7 @@ extern "C" int mi355rec_mf_create(mi355rec_mf_t *out, const mi355rec_mf_config *
         h->mu.alloc_zero(1, s);
         h->acc_bu.alloc_zero(n_users, s);
         h->acc_bi.alloc_zero(n_items, s);
-        h->acc_mu.alloc_zero(1, s);
+        h->mu_slots.alloc_zero((size_t)(cfg->batch_size + 3) / 4 + 1, s);
         if (cfg->sgd_mode != MI355REC_SGD) {
             h->c1U.alloc_zero(nu, s);
             h->c1V.alloc_zero(ni, s);
