@@ -134,6 +134,36 @@ __global__ __launch_bounds__(256) void slim_level_kernel(const SlimParams p, int
     slim_step<64>(p, t, lane, reduce);
 }
 
+// Level-parallel path, one WORKGROUP per step: a level lasts as long as its longest profile, and a single wavefront
+// walks a 2000-item profile in 2 x 32 dependent gather rounds (~1 us each); THREADS lanes do it in a few.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void slim_level_wg_kernel(const SlimParams p, int first, int count) {
+    __shared__ float s_part[THREADS / 64];
+    __shared__ float s_g[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= count) return;
+    const int t = p.order[first + blockIdx.x];
+    auto reduce = [&](float x, int i, int j, float &gi, float &gj, int step) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if (lane == 0) s_part[wave] = x;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+            for (int w = 0; w < THREADS / 64; ++w) tot += s_part[w];
+            const float g = 1.f / (1.f + __expf(tot));
+            s_g[0] = slim_adapt(p, g, i, p.pw1[step], p.pw2[step]);     // item i first, then j, as .pyx:267-268
+            s_g[1] = slim_adapt(p, g, j, p.pw1[step], p.pw2[step]);
+            atomicAdd(&p.loss_slots[step & (LOSS_SLOTS - 1)], (double)tot * tot);   // steps of one level may share a slot
+        }
+        __syncthreads();
+        gi = s_g[0];
+        gj = s_g[1];
+        return x;
+    };
+    slim_step<THREADS>(p, t, tid, reduce);
+}
+
 // Ordered path (any store): one workgroup runs steps [0, n_steps) one after the other.
 __global__ __launch_bounds__(1024) void slim_ordered_kernel(const SlimParams p) {
     __shared__ float s_part[16];
@@ -311,14 +341,19 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile) {
         std::vector<int> cursor(h->h_level_ptr.begin(), h->h_level_ptr.end());
         for (int t = 0; t < n; ++t) h->h_order[cursor[level[t]]++] = t;     // stable: stream order inside a level
         MI_HIP(hipMemcpyAsync(h->order.ptr, h->h_order.data(), sizeof(int) * n, hipMemcpyHostToDevice, s));
+        const bool wave_levels = getenv("MI355REC_SLIM_WAVE_LEVELS") != nullptr;
         for (int l = 1; l <= n_levels; ++l) {
             const int first = h->h_level_ptr[l], count = h->h_level_ptr[l + 1] - first;
             if (count == 0) continue;
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (h->dispatch_timers.next(e0, e1, 512))
-                hipExtLaunchKernelGGL(slim_level_kernel, dim3(div_up(count, 4)), dim3(256), 0, s, e0, e1, 0, p, first, count);
-            else
-                hipLaunchKernelGGL(slim_level_kernel, dim3(div_up(count, 4)), dim3(256), 0, s, p, first, count);
+            const bool timed = h->dispatch_timers.next(e0, e1, 512);
+            if (wave_levels) {       // MI355REC_SLIM_WAVE_LEVELS=1: the one-wavefront-per-step kernel (comparison / diagnostics)
+                if (timed) hipExtLaunchKernelGGL(slim_level_kernel, dim3(div_up(count, 4)), dim3(256), 0, s, e0, e1, 0, p, first, count);
+                else hipLaunchKernelGGL(slim_level_kernel, dim3(div_up(count, 4)), dim3(256), 0, s, p, first, count);
+            } else {
+                if (timed) hipExtLaunchKernelGGL(slim_level_wg_kernel<512>, dim3(count), dim3(512), 0, s, e0, e1, 0, p, first, count);
+                else hipLaunchKernelGGL(slim_level_wg_kernel<512>, dim3(count), dim3(512), 0, s, p, first, count);
+            }
             h->stats.n_launches += 1;
         }
     }
