@@ -111,6 +111,12 @@ int mi355rec_sim_compute(mi355rec_sim_t h, int32_t start_col, int32_t end_col, i
 /* Same, results left in device memory (for the RCCL gather of the column-sharded build); asynchronous on
  * the handle's stream -- call mi355rec_sim_sync before another stream/library reads the buffers. */
 int mi355rec_sim_compute_device(mi355rec_sim_t h, int32_t start_col, int32_t end_col, int32_t *d_nbr_idx, float *d_nbr_val);
+/* Same columns, assembled on the device into the CSR matrix the reference returns (.pyx:603-605): row = neighbour,
+ * column = source item, column indices ascending inside a row.  indptr: n_cols + 1; indices / data: capacity
+ * (end_col - start_col) * topK, the first *nnz entries are written.  (The host-side COO -> CSR conversion of 2.7 M cells
+ * takes ~200 ms in SciPy -- more than ten times the whole device build at ML-20M shape.) */
+int mi355rec_sim_compute_csr(mi355rec_sim_t h, int32_t start_col, int32_t end_col, int32_t *indptr, int32_t *indices,
+                             float *data, int64_t *nnz);
 /* topK == 0 variant (.pyx:507-510): W[j * ld + (c - start_col)] = similarity(j, c); W is host, row-major, ld >= end_col-start_col. */
 int mi355rec_sim_compute_dense(mi355rec_sim_t h, int32_t start_col, int32_t end_col, float *W, int64_t ld);
 /* cost(c) = sum over users of column c of their profile length: the work of one column; used to cut

@@ -70,6 +70,7 @@ SIGNATURES = {
     "mi355rec_sim_compute": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355rec_sim_compute_device": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355rec_sim_compute_dense": (C.c_int, [_vp, _i32, _i32, _vp, _i64]),
+    "mi355rec_sim_compute_csr": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "mi355rec_sim_column_costs": (C.c_int, [_vp, _vp]),
     "mi355rec_sim_schedule_info": (C.c_int, [_vp, _vp, _vp, _vp]),
     "mi355rec_sim_sync": (C.c_int, [_vp]),

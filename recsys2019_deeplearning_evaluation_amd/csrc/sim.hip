@@ -686,6 +686,27 @@ __global__ void minmax_kernel(const float *val, size_t nnz, int *not_unit) {
     if (bad) atomicOr(not_unit, 1);
 }
 
+// CSR assembly of the result (.pyx:603-605: row = neighbour, column = source item) -- sort keys: the neighbour id of
+// every slab entry, padding entries (-1) mapped past the last row so that they sort to the end.
+__global__ void csr_keys_kernel(const int *slab_idx, size_t n, int n_cols, int *key, int *pos) {
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int r = slab_idx[e];
+        key[e] = r >= 0 ? r : n_cols;
+        pos[e] = (int)e;
+    }
+}
+
+// After the stable sort by neighbour id: entry t of the CSR arrays comes from slab position pos[t]; its column is the
+// slab row (source item).  Positions ascend inside a row, hence so do the columns: indices come out sorted.
+__global__ void csr_gather_kernel(const int *pos, const float *slab_val, size_t n, int topK, int start_col, int *indices,
+                                  float *data) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const int e = pos[t];
+        indices[t] = start_col + e / topK;
+        data[t] = slab_val[e];
+    }
+}
+
 // [n_local][n_cols] -> [n_cols][n_local] (32x32 tiles through LDS)
 __global__ void transpose_kernel(const float *in, float *out, int rows, int cols) {
     __shared__ float tile[32][33];
@@ -717,6 +738,9 @@ struct mi355rec_sim {
     DeviceBuffer<uint32_t> part_buf;
     DeviceBuffer<unsigned> part_count;
     DeviceBuffer<unsigned long long> phase_ticks;
+    DeviceBuffer<int> csr_key, csr_key_sorted, csr_pos, csr_pos_sorted, csr_indptr, csr_indices;   // mi355rec_sim_compute_csr
+    DeviceBuffer<float> csr_data;
+    DeviceBuffer<char> csr_sort_tmp;
     std::vector<int4> items_host;   // host staging for the current call
     int n_split_columns = 0, n_part_items = 0;
     DeviceBuffer<unsigned short> seg_idx16;
@@ -1129,6 +1153,53 @@ extern "C" int mi355rec_sim_compute(mi355rec_sim_t h, int32_t start_col, int32_t
             fprintf(stderr, "[mi355rec sim phases, workgroup-ms] fetch+clear %.2f  accumulate %.2f  split-merge %.2f  normalise %.2f  topk %.2f  (kernel %.3f ms)\n",
                     t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, h->stats.kernel_ms);
         }
+    });
+}
+
+extern "C" int mi355rec_sim_compute_csr(mi355rec_sim_t h, int32_t start_col, int32_t end_col, int32_t *indptr, int32_t *indices,
+                                        float *data, int64_t *nnz_out) {
+    return guarded([&] {
+        MI_REQUIRE(h && indptr && indices && data && nnz_out, "NULL argument");
+        MI_REQUIRE(h->cfg.topK > 0, "topK == 0: use mi355rec_sim_compute_dense");
+        ensure_device();
+        clamp_range(h, start_col, end_col);
+        const size_t n = (size_t)(end_col - start_col) * h->cfg.topK;
+        MI_REQUIRE(n < (size_t)INT32_MAX, "result too large for 32-bit CSR offsets");
+        if (h->out_idx.count < n) {
+            h->out_idx.alloc(n);
+            h->out_val.alloc(n);
+        }
+        if (h->csr_key.count < n) {
+            h->csr_key.alloc(n); h->csr_key_sorted.alloc(n); h->csr_pos.alloc(n); h->csr_pos_sorted.alloc(n);
+            h->csr_indices.alloc(n); h->csr_data.alloc(n);
+        }
+        if (!h->csr_indptr.ptr) h->csr_indptr.alloc((size_t)h->n_cols + 1);
+        hipStream_t s = h->stream;
+        run_columns(h, start_col, end_col, h->out_idx.ptr, h->out_val.ptr, nullptr);
+        const int eb = 256, eg = (int)std::min<size_t>((n + eb - 1) / eb, 4096);
+        hipLaunchKernelGGL(csr_keys_kernel, dim3(eg), dim3(eb), 0, s, h->out_idx.ptr, n, h->n_cols, h->csr_key.ptr, h->csr_pos.ptr);
+        int key_bits = 1;
+        while ((1ll << key_bits) < (long long)h->n_cols + 1) ++key_bits;
+        size_t tmp_bytes = 0;
+        MI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->csr_key.ptr, h->csr_key_sorted.ptr, h->csr_pos.ptr,
+                                                  h->csr_pos_sorted.ptr, (int)n, 0, key_bits, s));
+        if (h->csr_sort_tmp.count < tmp_bytes) h->csr_sort_tmp.alloc(tmp_bytes);
+        MI_HIP(hipcub::DeviceRadixSort::SortPairs(h->csr_sort_tmp.ptr, tmp_bytes, h->csr_key.ptr, h->csr_key_sorted.ptr,
+                                                  h->csr_pos.ptr, h->csr_pos_sorted.ptr, (int)n, 0, key_bits, s));
+        // indptr[r] = first sorted position whose key is >= r; indptr[n_cols] = number of real entries (padding sorts last)
+        hipLaunchKernelGGL(csc_ptr_kernel, dim3(div_up(h->n_cols + 1, 256)), dim3(256), 0, s, h->csr_key_sorted.ptr, n, h->n_cols,
+                           h->csr_indptr.ptr);
+        hipLaunchKernelGGL(csr_gather_kernel, dim3(eg), dim3(eb), 0, s, h->csr_pos_sorted.ptr, h->out_val.ptr, n, h->cfg.topK,
+                           start_col, h->csr_indices.ptr, h->csr_data.ptr);
+        MI_HIP(hipGetLastError());
+        h->csr_indptr.download(indptr, (size_t)h->n_cols + 1, s);
+        MI_HIP(hipStreamSynchronize(s));
+        const size_t nnz = (size_t)indptr[h->n_cols];
+        *nnz_out = (int64_t)nnz;
+        h->csr_indices.download(indices, nnz, s);
+        h->csr_data.download(data, nnz, s);
+        MI_HIP(hipStreamSynchronize(s));
+        h->stats.kernel_ms = h->timer.elapsed_ms(), h->stats.call_ms = h->call_timer.elapsed_ms();
     });
 }
 

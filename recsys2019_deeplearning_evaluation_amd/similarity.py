@@ -121,8 +121,17 @@ class Compute_Similarity_MI355X:
             N.check(self._lib.mi355rec_sim_compute_dense(self._h, s, e, N.ptr(slab), e - s))
             W[:, s:e] = slab
             return W
-        idx, val, s = self.compute_slabs(start_col, end_col)
-        return slabs_to_csr(idx, val, s, self.n_columns)
+        # CSR assembled on the device: SciPy's COO/CSC -> CSR conversion of the result would cost more than the build
+        s, e = self._range(start_col, end_col)
+        cap = (e - s) * self.TopK
+        indptr = np.empty(self.n_columns + 1, dtype=np.int32)
+        indices = np.empty(cap, dtype=np.int32)
+        data = np.empty(cap, dtype=np.float32)
+        nnz = C.c_int64()
+        N.check(self._lib.mi355rec_sim_compute_csr(self._h, s, e, N.ptr(indptr), N.ptr(indices), N.ptr(data), C.byref(nnz)))
+        W = sps.csr_matrix((data[:nnz.value], indices[:nnz.value], indptr), shape=(self.n_columns, self.n_columns))
+        W.has_sorted_indices = True
+        return W
 
 
 class Compute_Similarity_Euclidean_MI355X(Compute_Similarity_MI355X):

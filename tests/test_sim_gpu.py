@@ -356,3 +356,23 @@ def test_euclidean_errors_and_knn_recommender(gpu):
     W = rec.W_sparse.toarray()
     assert ((W != 0).sum(axis=0) == 15).all()
     assert np.abs(W[W != 0] - want[W != 0]).max() < RTOL * np.abs(want).max()
+
+
+def test_csr_assembled_on_the_device_equals_the_host_assembly(gpu):
+    """compute_similarity() returns the CSR matrix built on the device (sort by neighbour id); it must be the very
+    matrix the COO assembly of the slabs gives (Compute_Similarity_Cython.pyx:603-605), sorted indices included."""
+    from recsys2019_deeplearning_evaluation_amd.similarity import slabs_to_csr
+    cases = [(named_urm("ml1m", "real", scale=0.2), dict(topK=30, shrink=2, similarity="cosine"), None),
+             (named_urm("ml1m", "binary", scale=0.2), dict(topK=7, shrink=0, similarity="jaccard"), (11, 301)),
+             (synthetic_urm(300, 40000, 90000, seed=4, values="binary"), dict(topK=20, shrink=0, similarity="cosine"), None)]
+    for X, kw, rng in cases:
+        dev = Compute_Similarity_MI355X(X, **kw)
+        args = () if rng is None else rng
+        W = dev.compute_similarity(*args)
+        idx, val, s = dev.compute_slabs(*args)
+        want = slabs_to_csr(idx, val, s, X.shape[1])
+        want.sort_indices()
+        assert W.shape == want.shape and W.nnz == want.nnz and W.dtype == np.float32
+        assert np.array_equal(W.indptr, want.indptr) and np.array_equal(W.indices, want.indices)
+        assert np.array_equal(W.data, want.data)
+        dev.close()
