@@ -38,24 +38,33 @@ def check_matrix(X, format="csc", dtype=np.float32):
 
 
 def similarityMatrixTopK(item_weights, k=100, verbose=False):
-    """Keep, column by column, the k largest non-zero cells (Recommender_utils.py:55). Returns CSC float32."""
+    """Keep, column by column, the k largest non-zero cells (Recommender_utils.py:55). Returns CSC float32.
+
+    Vectorised: columns that already hold at most k non-zero cells are kept as they are (the usual case after a
+    per-row top-K), only the others are ranked; a dense input is ranked with one argpartition along the rows."""
     n = item_weights.shape[1]
     assert item_weights.shape[0] == n, "selectTopK: ItemWeights is not a square matrix"
     k = min(k, n)
-    dense = isinstance(item_weights, np.ndarray)
-    W = item_weights if dense else check_matrix(item_weights, "csc", dtype=np.float32)
-    data, rows, indptr = [], [], [0]
-    for c in range(n):
-        if dense:
-            col, ridx = W[:, c], np.arange(n, dtype=np.int32)
+    if isinstance(item_weights, np.ndarray):
+        W = np.asarray(item_weights, dtype=np.float32)
+        if k < n:
+            ranked = np.where(W != 0, -W, np.inf)                   # zero cells do not compete (:100-104)
+            top = np.argpartition(ranked, k - 1, axis=0)[:k]        # (k, n) row ids of the k largest non-zero cells per column
         else:
-            col, ridx = W.data[W.indptr[c]:W.indptr[c + 1]], W.indices[W.indptr[c]:W.indptr[c + 1]]
-        keep = col != 0
-        col, ridx = col[keep], ridx[keep]
-        top = np.argsort(col)[-k:]
-        data.append(col[top]); rows.append(ridx[top]); indptr.append(indptr[-1] + len(top))
-    return sps.csc_matrix((np.concatenate(data) if data else [], np.concatenate(rows) if rows else [], indptr),
-                          shape=(n, n), dtype=np.float32)
+            top = np.broadcast_to(np.arange(n)[:, None], (n, n))
+        vals = np.take_along_axis(W, top, axis=0)
+        keep = vals != 0
+        cols = np.broadcast_to(np.arange(n)[None, :], top.shape)
+        return sps.csc_matrix((vals[keep], (top[keep], cols[keep])), shape=(n, n), dtype=np.float32)
+    W = check_matrix(item_weights, "csc", dtype=np.float32).copy()
+    W.eliminate_zeros()
+    counts = np.diff(W.indptr)
+    keep = np.ones(W.nnz, dtype=bool)
+    for c in np.flatnonzero(counts > k):
+        a, b = W.indptr[c], W.indptr[c + 1]
+        keep[a + np.argsort(W.data[a:b], kind="stable")[:b - a - k]] = False
+    indptr = np.concatenate([[0], np.cumsum(np.minimum(counts, k))])
+    return sps.csc_matrix((W.data[keep], W.indices[keep], indptr), shape=(n, n), dtype=np.float32)
 
 
 class BaseRecommender(object):
