@@ -186,3 +186,16 @@ def test_similarity_matrix_topk_equals_the_column_loop(n, density, k):
         want[top, c] = D[top, c]
     assert np.array_equal(similarityMatrixTopK(A, k).toarray(), want)
     assert np.array_equal(similarityMatrixTopK(D, k).toarray(), want)
+
+
+def test_similarity_matrix_topk_reference_unit_tests():
+    """The two cases of the reference's own Base/Recommender_utils_Test.py:18-50, on this package's similarityMatrixTopK."""
+    from recsys2019_deeplearning_evaluation_amd.recommender_base import similarityMatrixTopK
+    rng = np.random.RandomState(0)
+    dense_input = rng.random_sample((100, 100))
+    dense_output = similarityMatrixTopK(dense_input, k=20)
+    assert (dense_output.toarray() != 0).sum() == 20 * 100                   # DenseToDense (:18-31)
+    dense_input = rng.random_sample((20, 20))
+    on_dense = similarityMatrixTopK(dense_input, k=5).toarray()
+    on_sparse = similarityMatrixTopK(sps.csc_matrix(dense_input), k=5).toarray()
+    assert np.allclose(on_dense, on_sparse)                                   # sparseToSparse (:34-50)

@@ -122,3 +122,20 @@ def test_euclidean_bit_exact(ref, mode):
         want = _quiet(lambda: EUC(X, topK=10, similarity_from_distance_mode=mode, **kw).compute_similarity()).toarray()
         got = O.OracleSimilarityEuclidean(X, topK=10, similarity_from_distance_mode=mode, **kw).compute_similarity().toarray()
         assert np.array_equal(got, want)
+
+
+def test_package_similarity_matrix_topk_equals_the_reference_function():
+    ref_topk = ref_loader.load_python_reference("Base.Recommender_utils", "similarityMatrixTopK")
+    if ref_topk is None:
+        pytest.skip("reference tree not available")
+    from recsys2019_deeplearning_evaluation_amd.recommender_base import similarityMatrixTopK
+    rng = np.random.default_rng(2)
+    A = sps.random(70, 70, 0.4, random_state=np.random.RandomState(2), format="csr", dtype=np.float32)
+    A.data = rng.standard_normal(A.nnz).astype(np.float32)
+    for k in (1, 6, 70):
+        want = _quiet(lambda: ref_topk(A.copy(), k=k, verbose=False)).toarray()
+        assert np.array_equal(similarityMatrixTopK(A, k).toarray(), want)
+        want_d = _quiet(lambda: ref_topk(A.toarray(), k=k, verbose=False))
+        want_d = want_d.toarray() if sps.issparse(want_d) else np.asarray(want_d)
+        got_d = similarityMatrixTopK(A.toarray(), k).toarray()
+        assert np.array_equal(got_d, want_d)        # same rule on dense input: non-zero cells only (Recommender_utils.py:104-108)
