@@ -137,6 +137,7 @@ void mi355rec_sim_destroy(mi355rec_sim_t h);
 
 enum { MI355REC_MF_BPR = 0, MI355REC_MF_FUNK_SVD = 1, MI355REC_MF_ASY_SVD = 2 };   /* algorithm_name (.pyx:93) */
 enum { MI355REC_SGD = 0, MI355REC_ADAGRAD = 1, MI355REC_RMSPROP = 2, MI355REC_ADAM = 3 };  /* sgd_mode (.pyx:92) */
+enum { MI355REC_F32 = 0, MI355REC_F64 = 1 };
 
 typedef struct {
     int32_t algorithm;       /* MI355REC_MF_* */
@@ -151,17 +152,22 @@ typedef struct {
     double  negative_interactions_quota;
     double  gamma, beta_1, beta_2;
     uint64_t random_seed;    /* seeds the on-device counter-based sampler */
+    int32_t precision;       /* MI355REC_F32 / MI355REC_F64: storage AND arithmetic type of factors, biases and optimiser
+                              * moments on the device, and the element type of U0 / V0.  The reference computes in double
+                              * (.pyx:55-66); float32 holds the 1e-5 bar for plain sgd, the adaptive optimisers divide
+                              * every gradient component by sqrt(running g^2) + 1e-8 and need float64 state for it. */
+    int32_t reserved;
 } mi355rec_mf_config;
 
 typedef struct mi355rec_mf *mi355rec_mf_t;
 
 /* URM (n_users x n_items) as CSR with sorted indices.  U0 (n_users x k; n_ITEMS x k for ASY_SVD, whose "user" matrix is
- * the second item-sized matrix Y, .pyx:163-166) and V0 (n_items x k) are the initial factors, row-major float32 (the host
- * draws them exactly like .pyx:174-175 does).  ASY_SVD requires batch_size == 1 (.pyx:395) and runs its nnz + 1 steps per
+ * the second item-sized matrix Y, .pyx:163-166) and V0 (n_items x k) are the initial factors, row-major, float32 or float64
+ * as cfg->precision says (the host draws them exactly like .pyx:174-175 does).  ASY_SVD requires batch_size == 1 (.pyx:395) and runs its nnz + 1 steps per
  * epoch strictly in order. */
 int mi355rec_mf_create(mi355rec_mf_t *out, const mi355rec_mf_config *cfg, int32_t n_users, int32_t n_items,
                        const int32_t *indptr, const int32_t *indices, const float *data,
-                       const float *U0, const float *V0);
+                       const void *U0, const void *V0);
 /* n_epochs x epochIteration_Cython(): each epoch is n_users/B+1 (BPR, .pyx:583) or nnz/B+1 (FunkSVD, :289)
  * mini-batches of B samples drawn ON THE DEVICE. */
 int mi355rec_mf_run_epochs(mi355rec_mf_t h, int32_t n_epochs);
@@ -175,7 +181,7 @@ int mi355rec_mf_get_factors(mi355rec_mf_t h, float *U, float *V, float *bu, floa
 /* Copy the (u, i, j|rating) stream drawn by the LAST mi355rec_mf_run_epochs call (at most cap entries);
  * returns the number of samples of that call in *n. */
 int mi355rec_mf_get_last_samples(mi355rec_mf_t h, int32_t *u, int32_t *i, int32_t *j, float *rating, int64_t cap, int64_t *n);
-/* Time (at most) the first max_timed_launches gradient-kernel launches of every subsequent call with per-dispatch
+/* Time (at most) the first max_timed_launches mini-batch kernel launches of every subsequent call with per-dispatch
  * events; 0 (default) disables it. */
 int mi355rec_mf_set_profiling(mi355rec_mf_t h, int32_t max_timed_launches);
 int mi355rec_mf_get_stats(mi355rec_mf_t h, mi355rec_stats *stats);

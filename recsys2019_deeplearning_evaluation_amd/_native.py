@@ -20,6 +20,7 @@ SIMILARITY_CODES = {"cosine": 0, "adjusted": 1, "asymmetric": 2, "pearson": 3, "
 EUCLIDEAN_MODE_CODES = {"lin": 0, "log": 1, "exp": 2}
 SGD_MODE_CODES = {"sgd": 0, "adagrad": 1, "rmsprop": 2, "adam": 3}
 ALGORITHM_CODES = {"MF_BPR": 0, "FUNK_SVD": 1, "ASY_SVD": 2}
+PRECISION_CODES = {"fp32": 0, "fp64": 1}
 
 
 class NativeLibraryError(RuntimeError):
@@ -48,7 +49,7 @@ class MFConfig(C.Structure):
                 ("positive_reg", C.c_double), ("negative_reg", C.c_double),
                 ("negative_interactions_quota", C.c_double),
                 ("gamma", C.c_double), ("beta_1", C.c_double), ("beta_2", C.c_double),
-                ("random_seed", C.c_uint64)]
+                ("random_seed", C.c_uint64), ("precision", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SlimConfig(C.Structure):
@@ -179,3 +180,7 @@ def as_i32(a):
 
 def as_f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

@@ -1,80 +1,189 @@
-// mf.hip -- BPR-MF and FunkSVD mini-batch SGD epochs on MI355X (gfx950).
+// mf.hip -- BPR-MF, FunkSVD and AsySVD mini-batch SGD epochs on MI355X (gfx950).
 //
 // Replaces MatrixFactorization/Cython/MatrixFactorization_Cython_Epoch.pyx (reference):
 //   epochIteration_Cython_BPR_SGD :580-649, epochIteration_Cython_FUNK_SVD_SGD :286-361,
 //   sampleBPR_Cython :940-985, sampleMSE_Cython :878-935, _add_*_sample_in_minibatch :737-766,
-//   _apply_minibatch_updates_to_latent_factors :770-829, adaptive_gradient :835-873.
+//   _apply_minibatch_updates_to_latent_factors :770-829, adaptive_gradient :835-873, ASY_SVD :393-541.
 //
-// Design.  The reference's mini-batch semantics make the B samples of a batch independent:
-// every gradient is taken against start-of-batch factors, summed per row, and the sum is applied once.
-// That maps to one sampling kernel per epoch and two kernels per mini-batch:
-//   mf_sample_kernel one thread per sample of the epoch: counter-based RNG, user / positive draw, negative by
-//                    rejection against the sorted CSR row (binary search); sampling does not depend on the
-//                    factors, so it is taken off the per-batch critical path;
-//   mf_grad_kernel   one 64-lane wavefront per sample: row gather, wavefront-shuffle dot product, gradient rows
-//                    scattered into the fp32 accumulators with device-scope float atomics; the first toucher of
-//                    a row (flag exchange, the reference's flag arrays) files it in the sample's own slot of the
-//                    batch's touched list -- no shared counter, no same-address atomics;
-//   mf_apply_kernel  one wavefront per list slot: mean over batch_size, optimiser step, += lr * step,
-//                    accumulator and flag reset.
-// A whole epoch (1 + 2*n_batches launches) is captured once into a hipGraph and replayed: all per-batch state
-// (batch index -> RNG counter, Adam's beta^t) lives in device memory, so the launches carry no host arguments.
-// There is no dense contraction here, hence no MFMA; the path is bound by row gather/scatter bandwidth and,
-// at the reference's batch sizes (<= 1024), by the dependent-launch latency between mini-batches.
+// Design.  The reference's mini-batch rule -- every gradient of a batch is taken against the
+// start-of-batch factors, the gradients of a row are summed, the sum is applied once -- has two consequences:
+//   (1) the samples of a batch are independent, and
+//   (2) the sample stream does not depend on the factors, so everything about WHO touches WHICH row WHEN is known
+//       before the first mini-batch runs.
+// Round 1 used (1) only: a scatter kernel (float atomics into accumulators, first-toucher flags) and an apply kernel per
+// mini-batch, i.e. two dependent launches and five dependent memory round trips per batch (10.2 us per batch of 1000).
+// This version uses (2) as well and turns the batch into ONE gather kernel with no atomics, no flags and no
+// accumulators:
+//   mf_sample_kernel   one thread per sample of the epoch (counter-based RNG, binary-search rejection);
+//   schedule           the epoch's (row, batch) incidences are radix-sorted (hipCUB) into TASKS: one task per row touched
+//                      in a batch, holding the list of that batch's samples which touch the row.  Because every
+//                      row's tasks are ordered by batch, the VERSION of a row each sample must read is static: factor
+//                      rows live in two buffers, version v of a row in buffer (v & 1); a task reads version v of
+//                      every row it needs and writes version v + 1 of its own row into the other buffer, which no
+//                      reader of the same batch looks at.  Parities are baked into the sample records;
+//   mf_batch_kernel    one wavefront per task: for each sample of the list, gather the 3 (BPR) / 2 (FunkSVD) rows at
+//                      their parities, x_uij by DPP / v_permlane swap reduction inside a LPR-lane group (16-byte
+//                      loads; a 64-lane wavefront works on 64/LPR samples at a time), own-row gradient summed in
+//                      registers in sample order (deterministic), then mean over batch_size, optimiser, += lr * step,
+//                      one store of the new row version.
+// One dependent launch and three dependent memory round trips per mini-batch (task header -> rows -> store); 12 row
+// transfers per sample instead of 18.  The arithmetic type is the storage type: float32 for plain sgd (north_star),
+// float64 factors + moments for adagrad / rmsprop / adam, whose per-component normalisation amplifies float32 rounding
+// to O(lr); outputs are float32 either way.
+// There is no dense contraction here, hence no MFMA.
 #include "common.h"
 #include "sampling.cuh"
+
+#include <hipcub/hipcub.hpp>
 
 #include <memory>
 
 namespace mi355rec {
 namespace {
 
-struct MfState {           // lives in device memory so that launches carry no per-batch host arguments
-    long long grad_batch;  // number of gradient kernels run since create = 1-based index of the current mini-batch
+struct MfState {           // lives in device memory so that graph replays carry no per-epoch host arguments
+    long long batch_base;  // mini-batches executed before the stream now in the buffers (Adam's t, global-bias ring)
     long long epoch;       // index (since create) of the epoch the next sampling kernel draws
     double beta_1_power, beta_2_power;   // AsySVD: Adam's running products (advanced once per step, .pyx:536-539)
     double asy_loss;
 };
 
+struct TaskHeader {        // 32 bytes, one per (row, mini-batch) incidence
+    int entry;             // user row u, or n_users + item
+    int meta;              // bit 31: buffer holding the row's current version; bits 0..27: number of samples
+    int start;             // first record of the list (recs[], sorted order)
+    int pad;
+    int4 rec0;             // the first record itself: single-sample tasks (most of them) need no second load
+};
+constexpr int LEN_MASK = 0x0fffffff;
+typedef int int8v __attribute__((ext_vector_type(8)));
+// record .w: bits 0-1 role of the task's row in this sample (0 user, 1 item / positive item, 2 negative item),
+//            bit 2 / 3 / 4: buffer of the sample's user / item / negative-item row
+constexpr int ROLE_U = 0, ROLE_I = 1;   // 2: negative item
+
+template <class T> struct MuState { T mu, c1, c2, pad; };
+
+template <class T>
 struct MfParams {
     int n_users, n_items, k, batch_size;
-    int use_bias, sgd_mode, sample_negatives, algorithm_is_bpr;
-    float lr, user_reg, item_reg, bias_reg, positive_reg, negative_reg, quota;
-    float gamma, beta_1, beta_2, one_m_gamma, one_m_beta_1, one_m_beta_2;   // 1 - x formed in double on the host
+    int use_bias, sgd_mode, sample_negatives, tasks_per_batch;
+    T lr, user_reg, item_reg, bias_reg, positive_reg, negative_reg, inv_batch;
+    T gamma, beta_1, beta_2, one_m_gamma, one_m_beta_1, one_m_beta_2;
+    float quota;
     double beta_1_d, beta_2_d;
     unsigned long long seed;
     const int *indptr, *indices;
     const float *data;
-    float *U, *V, *accU, *accV;
-    float *bu, *bi, *mu, *acc_bu, *acc_bi;
-    float *mu_slots;   // FunkSVD with bias: the global-bias gradient terms of a mini-batch, one partial sum per workgroup
-    float *c1U, *c2U, *c1V, *c2V;        // optimiser state: c1 = cache / first moment, c2 = second moment
-    float *c1_bu, *c2_bu, *c1_bi, *c2_bi, *c_mu;  // c_mu[0] = cache/m1, c_mu[1] = m2
-    int *flag;                           // [n_users + n_items]
-    int *list;                           // touched-row slots of the batch: 3 (BPR) / 2 (FunkSVD) per sample, -1 = not first toucher
-    double *loss_slots;                  // [batch_size] per-sample-slot running loss (summed on the host)
+    T *U0, *U1, *V0, *V1;                // two buffers per factor matrix: version v of a row lives in buffer v & 1
+    T *bu0, *bu1, *bi0, *bi1;
+    T *c1U, *c2U, *c1V, *c2V;            // optimiser state (one copy: only the row's own task touches it)
+    T *c1_bu, *c2_bu, *c1_bi, *c2_bi;
+    MuState<T> *mu_state;                // [3] ring: global bias after batch b - 1, written by batch b        (FunkSVD)
+    T *mu_acc;                           // [3][16] ring: batch b's global-bias gradient terms, spread over 16 addresses
+    T *asy_mu, *asy_c_mu;                // AsySVD: global bias and its optimiser state, updated in place
+    unsigned char *par;                  // [n_u_rows + n_items] buffer of every row's current version at stream start
+    double *loss_slots;                  // [tasks_per_batch * 4] per (wavefront, group) running loss
     MfState *state;
     // sample stream: one epoch drawn by mf_sample_kernel (native) or the caller's stream (replay)
     int *su, *si, *sj;
     float *sr;
     long long samples_per_epoch;
-    int n_in_batch;                      // samples in this launch's batch (<= batch_size; short only in replay)
+    // schedule
+    const TaskHeader *tasks;
+    const int4 *recs;
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+// ---- wavefront reductions without LDS traffic ----------------------------------------------------------------------
+// row_ror:n rotates inside each row of 16 lanes; v_permlane16_swap / v_permlane32_swap (gfx950) exchange rows / halves.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ float swap16_sum(float v) {   // lane l gets v[l] + v[l ^ 16] (same operand order in both rows)
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float swap32_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ double swap16_sum(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    const double a = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[0] << 32) | (unsigned)lo[0]);
+    const double c = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[1] << 32) | (unsigned)lo[1]);
+    return a + c;
+}
+__device__ __forceinline__ double swap32_sum(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    const double a = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[0] << 32) | (unsigned)lo[0]);
+    const double c = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[1] << 32) | (unsigned)lo[1]);
+    return a + c;
+}
+// sum over aligned groups of LPR lanes, every lane of the group gets the (bitwise identical) result
+template <int LPR, class T> __device__ __forceinline__ T group_sum(T v) {
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    v += dpp_mov<0x122>(v);   // row_ror:2
+    v += dpp_mov<0x121>(v);   // row_ror:1
+    if (LPR >= 32) v = swap16_sum(v);
+    if (LPR >= 64) v = swap32_sum(v);
     return v;
 }
+// sum ACROSS the 64 / LPR groups (lane l of every group gets the total of the lanes l of all groups)
+template <int LPR, class T> __device__ __forceinline__ T cross_group_sum(T v) {
+    if (LPR <= 16) v = swap16_sum(v);
+    if (LPR <= 32) v = swap32_sum(v);
+    return v;
+}
+template <class T> __device__ __forceinline__ T wave_sum(T v) { return group_sum<64>(v); }
 
-// _add_*_sample_in_minibatch (.pyx:737-766): the first toucher of a row owns its apply
-__device__ __forceinline__ void touch(const MfParams &p, int entry, int slot) {
-    p.list[slot] = atomicExch(&p.flag[entry], 1) == 0 ? entry : -1;
+__device__ __forceinline__ float sigmoid_of_minus(float x) { return 1.f / (1.f + __expf(x)); }   // .pyx:619
+__device__ __forceinline__ double sigmoid_of_minus(double x) { return 1.0 / (1.0 + exp(x)); }
+__device__ __forceinline__ float root(float x) { return sqrtf(x); }
+__device__ __forceinline__ double root(double x) { return sqrt(x); }
+
+// adaptive_gradient (.pyx:835-873) on one cell whose state is passed by reference; pw1/pw2 = 1 - beta^t
+template <class T, class P>
+__device__ __forceinline__ T adapt_cell(const P &p, T g, T &c1, T &c2, T pw1, T pw2) {
+    switch (p.sgd_mode) {
+        case MI355REC_ADAGRAD:
+            c1 = c1 + g * g;
+            return g / (root(c1) + (T)1e-8);
+        case MI355REC_RMSPROP:
+            c1 = c1 * p.gamma + p.one_m_gamma * (g * g);
+            return g / (root(c1) + (T)1e-8);
+        case MI355REC_ADAM: {
+            c1 = c1 * p.beta_1 + p.one_m_beta_1 * g;
+            c2 = c2 * p.beta_2 + p.one_m_beta_2 * (g * g);
+            return (c1 / pw1) / (root(c2 / pw2) + (T)1e-8);
+        }
+        default:
+            return g;
+    }
+}
+// the same on a cell in memory
+template <class T, class P>
+__device__ __forceinline__ T adapt(const P &p, T g, T *c1, T *c2, size_t at, T pw1, T pw2) {
+    if (p.sgd_mode == MI355REC_SGD) return g;
+    T a = c1[at], b = p.sgd_mode == MI355REC_ADAM ? c2[at] : (T)0;
+    const T step = adapt_cell(p, g, a, b, pw1, pw2);
+    c1[at] = a;
+    if (p.sgd_mode == MI355REC_ADAM) c2[at] = b;
+    return step;
 }
 
 // One thread per sample of one epoch (sampleBPR_Cython .pyx:940-985 / sampleMSE_Cython :878-935).
-template <int ALGO>
-__global__ __launch_bounds__(256) void mf_sample_kernel(const MfParams p) {
+template <int ALGO, class T>
+__global__ __launch_bounds__(256) void mf_sample_kernel(const MfParams<T> p) {
     const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const long long epoch = p.state->epoch;
     if (t < p.samples_per_epoch) {
@@ -113,212 +222,491 @@ __global__ __launch_bounds__(256) void mf_sample_kernel(const MfParams p) {
     if (t == 0) p.state->epoch = epoch + 1;
 }
 
-// KI = ceil(k / 64) rows-in-registers specialisation (1..4); KI == 0: any k, rows are re-read for the scatter.
-template <int ALGO, int KI>
-__global__ __launch_bounds__(256) void mf_grad_kernel(const MfParams p, const int batch_local) {
-    // batch_local = position of this mini-batch inside the stream buffer; it is a launch argument (baked into the
-    // graph node), so the sample triplet is the first load of the kernel, not the second
+// ---- schedule: (row, mini-batch) incidences -> tasks ----------------------------------------------------------------
+struct SchedParams {
+    long long n_samples;
+    int per;                 // incidences per sample: 3 (BPR) / 2 (FunkSVD)
+    int n_users, batch_size, batch_bits, tasks_per_batch;
+    const int *su, *si, *sj;
+    const float *sr;
+    unsigned long long *keys;      // unsorted keys: entry << batch_bits | batch
+    int *slots;                    // unsorted values: sample * per + role
+    const unsigned long long *keys_sorted;
+    const int *slots_sorted;
+    int *head;                     // 1 where a new (row, batch) run starts
+    const int *head_scan;          // inclusive scan of head
+    int *task_at;                  // for run heads: index of the task header
+    unsigned char *spar;           // per incidence: buffer of the row's version this sample reads
+    unsigned char *par;            // per row: buffer of the current version (advanced by the last task of the row)
+    int *batch_count;
+    TaskHeader *tasks;
+    int4 *recs;
+};
+
+__global__ __launch_bounds__(256) void mf_keys_kernel(const SchedParams s) {
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (t >= s.n_samples) return;
+    const unsigned long long batch = (unsigned long long)(t / s.batch_size);
+    const long long q = t * s.per;
+    s.keys[q] = ((unsigned long long)s.su[t] << s.batch_bits) | batch;
+    s.slots[q] = (int)q;
+    s.keys[q + 1] = ((unsigned long long)(s.n_users + s.si[t]) << s.batch_bits) | batch;
+    s.slots[q + 1] = (int)q + 1;
+    if (s.per == 3) {
+        s.keys[q + 2] = ((unsigned long long)(s.n_users + s.sj[t]) << s.batch_bits) | batch;
+        s.slots[q + 2] = (int)q + 2;
+    }
+}
+
+__global__ __launch_bounds__(256) void mf_heads_kernel(const SchedParams s) {
+    const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (q >= s.n_samples * s.per) return;
+    s.head[q] = q == 0 || s.keys_sorted[q] != s.keys_sorted[q - 1];
+}
+
+// One thread per run head: version parity of the row at this batch, a place in the batch's task array, the header.
+__global__ __launch_bounds__(256) void mf_tasks_kernel(const SchedParams s) {
+    const long long n = s.n_samples * s.per;
+    const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (q >= n || !s.head[q]) return;
+    const unsigned long long key = s.keys_sorted[q];
+    const int entry = (int)(key >> s.batch_bits);
+    const int batch = (int)(key & ((1ull << s.batch_bits) - 1));
+    long long end = q + 1;
+    while (end < n && !s.head[end]) ++end;
+    // rank of this batch among the batches of the stream that touch the row = number of run heads since the row's first
+    const unsigned long long first_key = (unsigned long long)entry << s.batch_bits;
+    long long lo = 0, hi = q;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (s.keys_sorted[mid] < first_key) lo = mid + 1; else hi = mid;
+    }
+    const int rank = s.head_scan[q] - s.head_scan[lo];
+    const int parity = (s.par[entry] + rank) & 1;
+    const int at = batch * s.tasks_per_batch + atomicAdd(&s.batch_count[batch], 1);
+    s.task_at[q] = at;
+    TaskHeader h;
+    h.entry = entry;
+    h.meta = (int)(end - q) | (parity << 31);
+    h.start = (int)q;
+    h.pad = 0;
+    s.tasks[at].entry = h.entry;
+    s.tasks[at].meta = h.meta;
+    s.tasks[at].start = h.start;
+    s.tasks[at].pad = 0;
+    for (long long r = q; r < end; ++r) s.spar[s.slots_sorted[r]] = (unsigned char)parity;
+}
+
+// One thread per incidence (sorted order): the sample record with the parities of all its rows.
+__global__ __launch_bounds__(256) void mf_recs_kernel(const SchedParams s) {
+    const long long n = s.n_samples * s.per;
+    const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const int slot = s.slots_sorted[q];
+    const int sample = slot / s.per, role = slot - sample * s.per;
+    const long long base = (long long)sample * s.per;
+    int4 rec;
+    rec.x = s.su[sample];
+    rec.y = s.si[sample];
+    rec.z = s.per == 3 ? s.sj[sample] : __float_as_int(s.sr[sample]);
+    rec.w = role | (s.spar[base] << 2) | (s.spar[base + 1] << 3) | (s.per == 3 ? s.spar[base + 2] << 4 : 0);
+    s.recs[q] = rec;
+    if (s.head[q]) {
+        s.tasks[s.task_at[q]].rec0 = rec;
+        // last task of this row in the stream: the next stream starts from the other buffer
+        const int entry = (int)(s.keys_sorted[q] >> s.batch_bits);
+        long long end = q + 1;
+        while (end < n && !s.head[end]) ++end;
+        if (end == n || (int)(s.keys_sorted[end] >> s.batch_bits) != entry) s.par[entry] = s.spar[slot] ^ 1;
+    }
+}
+
+template <class T>
+__global__ void mf_stream_end_kernel(const MfParams<T> p, const long long n_batches) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) p.state->batch_base += n_batches;
+}
+
+// ---- the mini-batch --------------------------------------------------------------------------------------------------
+template <class T, int VEC> struct alignas(sizeof(T) * VEC) Chunk { T v[VEC]; };
+
+// Loads are issued unconditionally from clamped (always valid) addresses and masked afterwards: no branch sits between
+// two loads, so the compiler batches them under one wait.
+template <class T, int VEC>
+__device__ __forceinline__ Chunk<T, VEC> load_chunk(const T *row, int chunk, bool ok) {
+    Chunk<T, VEC> r = *reinterpret_cast<const Chunk<T, VEC> *>(row + (size_t)(ok ? chunk : 0) * VEC);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) r.v[e] = ok ? r.v[e] : (T)0;
+    return r;
+}
+
+// Adam's 1 - beta^t for the 1-based mini-batch index t
+template <class T, class P> __device__ __forceinline__ void adam_powers(const P &p, long long t, T &pw1, T &pw2) {
+    pw1 = (T)1;
+    pw2 = (T)1;
+    if (p.sgd_mode == MI355REC_ADAM) {
+        pw1 = (T)(1.0 - pow(p.beta_1_d, (double)t));
+        pw2 = (T)(1.0 - pow(p.beta_2_d, (double)t));
+    }
+}
+
+// Global bias as the batch `gb` must see it (FunkSVD with bias): the value after batch gb - 2 plus batch gb - 1's step,
+// computed identically by every wavefront from the ring; wavefront 0 files the result for the next batch.
+template <class T>
+__device__ __forceinline__ T global_bias_at(const MfParams<T> &p, long long gb, bool writer, int lane) {
+    const int prev = (int)((gb + 2) % 3), cur = (int)(gb % 3), nxt = (int)((gb + 1) % 3);
+    MuState<T> st = p.mu_state[prev];
+    T part = lane < 16 ? p.mu_acc[prev * 16 + lane] : (T)0;
+    part += dpp_mov<0x128>(part);
+    part += dpp_mov<0x124>(part);
+    part += dpp_mov<0x122>(part);
+    part += dpp_mov<0x121>(part);
+    const T sum = __shfl(part, 0);
+    if (gb > 0) {
+        T pw1, pw2;
+        adam_powers(p, gb, pw1, pw2);           // the step belongs to batch gb - 1, whose 1-based index is gb
+        const T step = adapt_cell(p, sum * p.inv_batch, st.c1, st.c2, pw1, pw2);
+        st.mu += p.lr * step;
+    }
+    if (writer) {
+        if (lane == 0) p.mu_state[cur] = st;
+        if (lane < 16) p.mu_acc[nxt * 16 + lane] = (T)0;
+    }
+    return st.mu;
+}
+
+// the three rows of one sample, KI chunks of VEC elements per lane
+template <class T, int VEC, int KI, bool BPR> struct Rows {
+    Chunk<T, VEC> A[KI], B[KI], C[BPR ? KI : 1];
+    T bu, bi;
+};
+
+template <class T, int VEC, int LPR, int KI, bool BPR>
+__device__ __forceinline__ Rows<T, VEC, KI, BPR> load_rows(const MfParams<T> &p, const int4 rec, int li, const bool (&cok)[KI],
+                                                           bool bias) {
+    Rows<T, VEC, KI, BPR> r;
+    const int k = p.k;
+    const T *Wu = ((rec.w >> 2) & 1 ? p.U1 : p.U0) + (size_t)rec.x * k;
+    const T *Hi = ((rec.w >> 3) & 1 ? p.V1 : p.V0) + (size_t)rec.y * k;
+    const T *Hj = ((rec.w >> 4) & 1 ? p.V1 : p.V0) + (size_t)(BPR ? rec.z : 0) * k;
+#pragma unroll
+    for (int c = 0; c < KI; ++c) {
+        r.A[c] = load_chunk<T, VEC>(Wu, c * LPR + li, cok[c]);
+        r.B[c] = load_chunk<T, VEC>(Hi, c * LPR + li, cok[c]);
+        if (BPR) r.C[c] = load_chunk<T, VEC>(Hj, c * LPR + li, cok[c]);
+    }
+    r.bu = (T)0;
+    r.bi = (T)0;
+    if (bias) {                                   // wave-uniform
+        r.bu = ((rec.w >> 2) & 1 ? p.bu1 : p.bu0)[rec.x];
+        r.bi = ((rec.w >> 3) & 1 ? p.bi1 : p.bi0)[rec.y];
+    }
+    return r;
+}
+
+// KI chunks of VEC elements per lane, LPR lanes per row (64 / LPR samples of a task's list in flight per wavefront).
+template <int ALGO, class T, int VEC, int LPR, int KI>
+__global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, const int batch_local) {
+    constexpr int G = 64 / LPR;
+    constexpr bool BPR = ALGO == MI355REC_MF_BPR;
+    using Ch = Chunk<T, VEC>;
+    using R = Rows<T, VEC, KI, BPR>;
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);   // sample slot inside the batch
-    __shared__ float s_mu[4];
-    float mu_term = 0.f;
-    // count the mini-batches since create (Adam's beta^t): single writer here, read only by the apply kernel that follows
-    if (blockIdx.x == 0 && threadIdx.x == 0) p.state->grad_batch += 1;
-    double my_loss = 0.0;
-    if (w < p.n_in_batch) {
-        const long long slot = (long long)batch_local * p.batch_size + w;
-        const int u = p.su[slot], i = p.si[slot];
-        int j = -1;
-        float rating = 0.f;
-        if (ALGO == MI355REC_MF_BPR) j = p.sj[slot]; else rating = p.sr[slot];
-        if (lane == 0) {
-            constexpr int PER = ALGO == MI355REC_MF_BPR ? 3 : 2;
-            touch(p, p.n_users + i, PER * w);
-            if (ALGO == MI355REC_MF_BPR) touch(p, p.n_users + j, PER * w + 1);
-            touch(p, u, PER * w + PER - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    // every wave-uniform input is requested before the first one is waited for (scalar loads, one wait)
+    // (unused task slots of a batch are zero: a header with no samples means there is nothing to do)
+    // (the grid is rounded up to whole workgroups: wavefronts past the batch's last slot re-read that slot and idle)
+    const TaskHeader *hp = p.tasks + ((size_t)batch_local * p.tasks_per_batch + min(wv, p.tasks_per_batch - 1));
+    const int8v hd = *reinterpret_cast<const int8v *>(hp);      // one 32-byte scalar load: header and first record
+    // (the kernel arguments the row gathers need are requested now, next to the header, rather than in a second scalar
+    // round trip after the header has arrived; the statement sits after the load because a side effect before it would
+    // stop the compiler from using the scalar cache for the header)
+    const bool bias = !BPR && p.use_bias;
+    long long gb = batch_local;                                  // global mini-batch index: only Adam and the global bias need it
+    if (bias || p.sgd_mode == MI355REC_ADAM) gb += p.state->batch_base;
+    asm volatile("" ::"s"(p.k), "s"(p.U0), "s"(p.U1), "s"(p.V0), "s"(p.V1), "s"(p.recs));
+    const int4 h0 = make_int4(hd[0], hd[1], hd[2], hd[3]), h1 = make_int4(hd[4], hd[5], hd[6], hd[7]);
+    const bool active = (h0.y & LEN_MASK) != 0 && wv < p.tasks_per_batch;
+    __shared__ T s_mu[4];
+    T mu_term = (T)0;
+    T mu_eff = (T)0;
+    if (bias) mu_eff = global_bias_at(p, gb, wv == 0, lane);
+    if (active) {
+        const int entry = h0.x, len = h0.y & LEN_MASK, own_par = (unsigned)h0.y >> 31, start = h0.z;
+        const int g = lane / LPR, li = lane % LPR;
+        const int k = p.k, chunks = k / VEC;
+        bool cok[KI];
+#pragma unroll
+        for (int c = 0; c < KI; ++c) cok[c] = c * LPR + li < chunks;
+        const int iters = (len + G - 1) / G;
+        // software pipeline: records two list positions ahead of the arithmetic, rows one ahead.  Positions past the
+        // end of the list are clamped to the last record (valid addresses) and contribute nothing.
+        int4 rec = h1;
+        if (G > 1 && len > 1) {                    // single-sample tasks (most of them) go straight from the header to the rows
+            const int4 r = p.recs[start + min(g, len - 1)];
+            if (g != 0) rec = r;
         }
-        const int k = p.k;
-        const float *Wu = p.U + (size_t)u * k, *Hi = p.V + (size_t)i * k;
-        float *aU = p.accU + (size_t)u * k, *aI = p.accV + (size_t)i * k;
-        if (ALGO == MI355REC_MF_BPR) {
-            const float *Hj = p.V + (size_t)j * k;
-            float *aJ = p.accV + (size_t)j * k;
-            float wu[KI ? KI : 1], hi[KI ? KI : 1], hj[KI ? KI : 1];
-            float x = 0.f;
-            if (KI) {
+        int4 rec_n = rec;
+        if (iters > 1) rec_n = p.recs[start + min(g + G, len - 1)];
+        R rows = load_rows<T, VEC, LPR, KI, BPR>(p, rec, li, cok, bias);
+        T pw1, pw2;
+        adam_powers(p, gb + 1, pw1, pw2);
+
+        Ch acc[KI], own[KI];
 #pragma unroll
-                for (int t = 0; t < KI; ++t) {
-                    const int f = lane + 64 * t;
-                    const bool ok = f < k;
-                    wu[t] = ok ? Wu[f] : 0.f;
-                    hi[t] = ok ? Hi[f] : 0.f;
-                    hj[t] = ok ? Hj[f] : 0.f;
-                    x += wu[t] * (hi[t] - hj[t]);
-                }
-            } else {
-                for (int f = lane; f < k; f += 64) x += Wu[f] * (Hi[f] - Hj[f]);
-            }
-            x = wave_sum(x);
-            const float s = 1.f / (1.f + __expf(x));          // gradient of log(sigm(-x_uij)), .pyx:619
-            my_loss = (double)x * x;
-            if (KI) {
+        for (int c = 0; c < KI; ++c)
 #pragma unroll
-                for (int t = 0; t < KI; ++t) {
-                    const int f = lane + 64 * t;
-                    if (f < k) {
-                        atomicAdd(&aU[f], s * (hi[t] - hj[t]) - p.user_reg * wu[t]);
-                        atomicAdd(&aI[f], s * wu[t] - p.positive_reg * hi[t]);
-                        atomicAdd(&aJ[f], -s * wu[t] - p.negative_reg * hj[t]);
+            for (int e = 0; e < VEC; ++e) { acc[c].v[e] = (T)0; own[c].v[e] = (T)0; }
+        T bias_acc = (T)0, own_bias = (T)0;
+        double loss = 0.0;
+
+        for (int it = 0; it < iters; ++it) {
+            const int idx = it * G + g;
+            const bool valid = idx < len;
+            // issue the next position's loads before this position's arithmetic (wave-uniform conditions)
+            int4 rec_nn = rec_n;
+            if (it + 2 < iters) rec_nn = p.recs[start + min(idx + 2 * G, len - 1)];
+            R rows_n = rows;
+            if (it + 1 < iters) rows_n = load_rows<T, VEC, LPR, KI, BPR>(p, rec_n, li, cok, bias);
+
+            const int role = rec.w & 3;
+            T dot = (T)0;
+#pragma unroll
+            for (int c = 0; c < KI; ++c)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    dot += BPR ? rows.A[c].v[e] * (rows.B[c].v[e] - rows.C[c].v[e]) : rows.A[c].v[e] * rows.B[c].v[e];
+            dot = group_sum<LPR>(dot);
+            if (BPR) {
+                const T x = dot;
+                const T sg = sigmoid_of_minus(x);
+                if (valid && role == ROLE_U && li == 0) loss += (double)x * (double)x;
+#pragma unroll
+                for (int c = 0; c < KI; ++c)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const T a = rows.A[c].v[e], b = rows.B[c].v[e], cc = rows.C[c].v[e];
+                        const T gU = sg * (b - cc) - p.user_reg * a;        // .pyx:626-639
+                        const T gI = sg * a - p.positive_reg * b;
+                        const T gJ = sg * (-a) - p.negative_reg * cc;
+                        const T gr = role == ROLE_U ? gU : (role == ROLE_I ? gI : gJ);
+                        acc[c].v[e] += valid ? gr : (T)0;
+                        if (it == 0) own[c].v[e] = role == ROLE_U ? a : (role == ROLE_I ? b : cc);
                     }
-                }
             } else {
-                for (int f = lane; f < k; f += 64) {
-                    const float a = Wu[f], b = Hi[f], c = Hj[f];
-                    atomicAdd(&aU[f], s * (b - c) - p.user_reg * a);
-                    atomicAdd(&aI[f], s * a - p.positive_reg * b);
-                    atomicAdd(&aJ[f], -s * a - p.negative_reg * c);
+                T pred = dot;
+                if (bias) pred += mu_eff + rows.bu + rows.bi;
+                const T err = (T)__int_as_float(rec.z) - pred;
+                if (valid && role == ROLE_U) {
+                    if (li == 0) loss += (double)err * (double)err;
+                    if (bias) mu_term += err - p.bias_reg * mu_eff;            // .pyx:329-336
                 }
-            }
-        } else {
-            float wu[KI ? KI : 1], hi[KI ? KI : 1];
-            float dot = 0.f;
-            if (KI) {
+                if (bias && valid) bias_acc += err - p.bias_reg * (role == ROLE_U ? rows.bu : rows.bi);
+                if (it == 0) own_bias = role == ROLE_U ? rows.bu : rows.bi;
 #pragma unroll
-                for (int t = 0; t < KI; ++t) {
-                    const int f = lane + 64 * t;
-                    const bool ok = f < k;
-                    wu[t] = ok ? Wu[f] : 0.f;
-                    hi[t] = ok ? Hi[f] : 0.f;
-                    dot += wu[t] * hi[t];
-                }
-            } else {
-                for (int f = lane; f < k; f += 64) dot += Wu[f] * Hi[f];
-            }
-            dot = wave_sum(dot);
-            float pred = dot;
-            if (p.use_bias) pred += p.mu[0] + p.bu[u] + p.bi[i];
-            const float err = rating - pred;
-            my_loss = (double)err * err;
-            if (p.use_bias && lane == 0) {   // .pyx:329-336
-                // the global bias has ONE accumulator: a thousand same-address atomics serialise at ~12 ns each (12 of
-                // the 22 us of a mini-batch); the terms are summed per workgroup below and by the apply kernel instead
-                mu_term = err - p.bias_reg * p.mu[0];
-                atomicAdd(&p.acc_bi[i], err - p.bias_reg * p.bi[i]);
-                atomicAdd(&p.acc_bu[u], err - p.bias_reg * p.bu[u]);
-            }
-            // NB the item gradient is regularised with positive_reg (sic, .pyx:346), never item_reg
-            if (KI) {
+                for (int c = 0; c < KI; ++c)
 #pragma unroll
-                for (int t = 0; t < KI; ++t) {
-                    const int f = lane + 64 * t;
-                    if (f < k) {
-                        atomicAdd(&aI[f], err * wu[t] - p.positive_reg * hi[t]);
-                        atomicAdd(&aU[f], err * hi[t] - p.user_reg * wu[t]);
+                    for (int e = 0; e < VEC; ++e) {
+                        const T a = rows.A[c].v[e], b = rows.B[c].v[e];
+                        // NB the item gradient is regularised with positive_reg (sic, .pyx:346), never item_reg
+                        const T gU = err * b - p.user_reg * a;
+                        const T gI = err * a - p.positive_reg * b;
+                        const T gr = role == ROLE_U ? gU : gI;
+                        acc[c].v[e] += valid ? gr : (T)0;
+                        if (it == 0) own[c].v[e] = role == ROLE_U ? a : b;
                     }
+            }
+            rec = rec_n;
+            rec_n = rec_nn;
+            rows = rows_n;
+        }
+        // totals over the groups, in a fixed order
+        if (G > 1) {
+#pragma unroll
+            for (int c = 0; c < KI; ++c)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[c].v[e] = cross_group_sum<LPR>(acc[c].v[e]);
+            if (bias) bias_acc = cross_group_sum<LPR>(bias_acc);
+        }
+        if (bias) {   // every lane of a group carries the group's terms: one lane per group counts
+            mu_term = li == 0 ? mu_term : (T)0;
+            mu_term = wave_sum(mu_term);
+        }
+        if (li == 0 && loss != 0.0) p.loss_slots[wv * 4 + g] += loss;      // (wavefront, group) slots are private
+        // _apply_minibatch_updates_to_latent_factors (.pyx:770-829): mean over batch_size (NOT over the row's count)
+        if (g == 0) {
+            const bool is_item = entry >= p.n_users;
+            const int row = is_item ? entry - p.n_users : entry;
+            T *Wn = (is_item ? (own_par ? p.V0 : p.V1) : (own_par ? p.U0 : p.U1)) + (size_t)row * k;
+            T *c1 = (is_item ? p.c1V : p.c1U) + (size_t)row * k, *c2 = (is_item ? p.c2V : p.c2U) + (size_t)row * k;
+#pragma unroll
+            for (int c = 0; c < KI; ++c) {
+                if (!cok[c]) continue;
+                const size_t at = (size_t)(c * LPR + li) * VEC;
+                Ch m1, m2, out;
+                if (p.sgd_mode != MI355REC_SGD) m1 = *reinterpret_cast<const Ch *>(c1 + at);
+                if (p.sgd_mode == MI355REC_ADAM) m2 = *reinterpret_cast<const Ch *>(c2 + at);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const T gm = acc[c].v[e] * p.inv_batch;
+                    const T step = adapt_cell(p, gm, m1.v[e], m2.v[e], pw1, pw2);
+                    out.v[e] = own[c].v[e] + p.lr * step;
                 }
-            } else {
-                for (int f = lane; f < k; f += 64) {
-                    const float a = Wu[f], b = Hi[f];
-                    atomicAdd(&aI[f], err * a - p.positive_reg * b);
-                    atomicAdd(&aU[f], err * b - p.user_reg * a);
-                }
+                *reinterpret_cast<Ch *>(Wn + at) = out;
+                if (p.sgd_mode != MI355REC_SGD) *reinterpret_cast<Ch *>(c1 + at) = m1;
+                if (p.sgd_mode == MI355REC_ADAM) *reinterpret_cast<Ch *>(c2 + at) = m2;
+            }
+            if (bias && li == 0) {
+                T *bn = is_item ? (own_par ? p.bi0 : p.bi1) : (own_par ? p.bu0 : p.bu1);
+                T *b1 = is_item ? p.c1_bi : p.c1_bu, *b2 = is_item ? p.c2_bi : p.c2_bu;
+                const T step = adapt(p, bias_acc * p.inv_batch, b1, b2, (size_t)row, pw1, pw2);
+                bn[row] = own_bias + p.lr * step;
             }
         }
     }
-    if (lane == 0 && w < p.n_in_batch) p.loss_slots[w] += my_loss;   // slot w is private to this wavefront
-    if (ALGO != MI355REC_MF_BPR && p.use_bias) {
+    if (bias) {   // the batch's global-bias terms: per workgroup through LDS, then one atomic on one of 16 addresses
         if (lane == 0) s_mu[threadIdx.x >> 6] = mu_term;
         __syncthreads();
-        if (threadIdx.x == 0) p.mu_slots[blockIdx.x] = (s_mu[0] + s_mu[1]) + (s_mu[2] + s_mu[3]);
+        if (threadIdx.x == 0) {
+            const T sum = (s_mu[0] + s_mu[1]) + (s_mu[2] + s_mu[3]);
+            if (sum != (T)0) atomicAdd(&p.mu_acc[(int)(gb % 3) * 16 + (blockIdx.x & 15)], sum);
+        }
     }
 }
 
-// adaptive_gradient (.pyx:835-873) on one cell; pw1/pw2 = 1 - beta^t
-__device__ __forceinline__ float adapt(const MfParams &p, float g, float *c1, float *c2, size_t at, float pw1, float pw2) {
-    switch (p.sgd_mode) {
-        case MI355REC_ADAGRAD: {
-            float c = c1[at] + g * g;
-            c1[at] = c;
-            return g / (sqrtf(c) + 1e-8f);
-        }
-        case MI355REC_RMSPROP: {
-            float c = c1[at] * p.gamma + p.one_m_gamma * (g * g);
-            c1[at] = c;
-            return g / (sqrtf(c) + 1e-8f);
-        }
-        case MI355REC_ADAM: {
-            float m1 = c1[at] * p.beta_1 + p.one_m_beta_1 * g;
-            float m2 = c2[at] * p.beta_2 + p.one_m_beta_2 * (g * g);
-            c1[at] = m1;
-            c2[at] = m2;
-            return (m1 / pw1) / (sqrtf(m2 / pw2) + 1e-8f);
-        }
-        default:
-            return g;
-    }
-}
-
-// _apply_minibatch_updates_to_latent_factors (.pyx:770-829): one wavefront per touched row.
-__global__ __launch_bounds__(256) void mf_apply_kernel(const MfParams p) {
+// Any k (odd k, k > 64 lanes x 2 chunks): one task per wavefront, one sample at a time, rows re-read for the update.
+template <int ALGO, class T>
+__global__ __launch_bounds__(256) void mf_batch_generic_kernel(const MfParams<T> p, const int batch_local) {
+    constexpr bool BPR = ALGO == MI355REC_MF_BPR;
+    constexpr int KMAX_REG = 8;    // k <= 512 keeps the own-row gradient in registers, larger k is rejected at create
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const float invB = 1.f / (float)p.batch_size;      // mean over batch_size, NOT over the row's count (.pyx:802)
-    float pw1 = 1.f, pw2 = 1.f;
-    if (p.sgd_mode == MI355REC_ADAM) {                  // beta^(t) with t = batch + 1 (.pyx:217-218, :646-649)
-        // the global mini-batch index lives in device memory (graph replays carry no host arguments); only Adam reads
-        // it, so the other optimisers keep this dependent load off their critical path
-        const long long t = p.state->grad_batch;        // advanced by the gradient kernel of this mini-batch: t = batch + 1
-        pw1 = (float)(1.0 - pow(p.beta_1_d, (double)t));
-        pw2 = (float)(1.0 - pow(p.beta_2_d, (double)t));
-    }
-    if (w == 0 && p.use_bias) {                         // global bias: sum of the gradient kernel's per-workgroup partials
-        float acc_mu = 0.f;
-        for (int q = lane; q < (p.n_in_batch + 3) / 4; q += 64) acc_mu += p.mu_slots[q];
-        acc_mu = wave_sum(acc_mu);
-        if (lane == 0) {
-            float g = adapt(p, acc_mu * invB, p.c_mu, p.c_mu + 1, 0, pw1, pw2);
-            p.mu[0] += p.lr * g;
+    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const TaskHeader *hp = p.tasks + ((size_t)batch_local * p.tasks_per_batch + min(wv, p.tasks_per_batch - 1));
+    const int4 h0 = *reinterpret_cast<const int4 *>(hp);
+    const bool active = (h0.y & LEN_MASK) != 0 && wv < p.tasks_per_batch;
+    const bool bias = !BPR && p.use_bias;
+    __shared__ T s_mu[4];
+    T mu_term = (T)0;
+    if (active || bias) {
+        const long long gb = p.state->batch_base + batch_local;
+        T mu_eff = (T)0;
+        if (bias) mu_eff = global_bias_at(p, gb, wv == 0, lane);
+        if (active) {
+            const int entry = h0.x, len = h0.y & LEN_MASK, own_par = (unsigned)h0.y >> 31, start = h0.z;
+            const int k = p.k;
+            T pw1, pw2;
+            adam_powers(p, gb + 1, pw1, pw2);
+            T acc[KMAX_REG];
+#pragma unroll
+            for (int c = 0; c < KMAX_REG; ++c) acc[c] = (T)0;
+            T bias_acc = (T)0;
+            double loss = 0.0;
+            for (int idx = 0; idx < len; ++idx) {
+                const int4 rec = idx == 0 ? hp->rec0 : p.recs[start + idx];
+                const int role = rec.w & 3;
+                const T *Wu = ((rec.w >> 2) & 1 ? p.U1 : p.U0) + (size_t)rec.x * k;
+                const T *Hi = ((rec.w >> 3) & 1 ? p.V1 : p.V0) + (size_t)rec.y * k;
+                const T *Hj = ((rec.w >> 4) & 1 ? p.V1 : p.V0) + (size_t)(BPR ? rec.z : 0) * k;
+                T dot = (T)0;
+                for (int f = lane; f < k; f += 64) dot += BPR ? Wu[f] * (Hi[f] - Hj[f]) : Wu[f] * Hi[f];
+                dot = wave_sum(dot);
+                if (BPR) {
+                    const T sg = sigmoid_of_minus(dot);
+                    if (role == ROLE_U) loss += (double)dot * (double)dot;
+#pragma unroll
+                    for (int c = 0; c < KMAX_REG; ++c) {
+                        const int f = lane + 64 * c;
+                        if (f < k) {
+                            const T a = Wu[f], b = Hi[f], cc = Hj[f];
+                            acc[c] += role == ROLE_U ? sg * (b - cc) - p.user_reg * a
+                                                     : (role == ROLE_I ? sg * a - p.positive_reg * b : sg * (-a) - p.negative_reg * cc);
+                        }
+                    }
+                } else {
+                    T bu_v = (T)0, bi_v = (T)0;
+                    if (bias) {
+                        bu_v = ((rec.w >> 2) & 1 ? p.bu1 : p.bu0)[rec.x];
+                        bi_v = ((rec.w >> 3) & 1 ? p.bi1 : p.bi0)[rec.y];
+                    }
+                    const T err = __int_as_float(rec.z) - (dot + (bias ? mu_eff + bu_v + bi_v : (T)0));
+                    if (role == ROLE_U) {
+                        loss += (double)err * (double)err;
+                        if (bias) mu_term += err - p.bias_reg * mu_eff;
+                    }
+                    if (bias) bias_acc += err - p.bias_reg * (role == ROLE_U ? bu_v : bi_v);
+#pragma unroll
+                    for (int c = 0; c < KMAX_REG; ++c) {
+                        const int f = lane + 64 * c;
+                        if (f < k) {
+                            const T a = Wu[f], b = Hi[f];
+                            acc[c] += role == ROLE_U ? err * b - p.user_reg * a : err * a - p.positive_reg * b;
+                        }
+                    }
+                }
+            }
+            if (lane == 0 && loss != 0.0) p.loss_slots[wv * 4] += loss;
+            const bool is_item = entry >= p.n_users;
+            const int row = is_item ? entry - p.n_users : entry;
+            const T *Wo = (is_item ? (own_par ? p.V1 : p.V0) : (own_par ? p.U1 : p.U0)) + (size_t)row * k;
+            T *Wn = (is_item ? (own_par ? p.V0 : p.V1) : (own_par ? p.U0 : p.U1)) + (size_t)row * k;
+            T *c1 = is_item ? p.c1V : p.c1U, *c2 = is_item ? p.c2V : p.c2U;
+#pragma unroll
+            for (int c = 0; c < KMAX_REG; ++c) {
+                const int f = lane + 64 * c;
+                if (f < k) {
+                    const T step = adapt(p, acc[c] * p.inv_batch, c1, c2, (size_t)row * k + f, pw1, pw2);
+                    Wn[f] = Wo[f] + p.lr * step;
+                }
+            }
+            if (bias && lane == 0) {
+                const T *bo = is_item ? (own_par ? p.bi1 : p.bi0) : (own_par ? p.bu1 : p.bu0);
+                T *bn = is_item ? (own_par ? p.bi0 : p.bi1) : (own_par ? p.bu0 : p.bu1);
+                T *b1 = is_item ? p.c1_bi : p.c1_bu, *b2 = is_item ? p.c2_bi : p.c2_bu;
+                const T step = adapt(p, bias_acc * p.inv_batch, b1, b2, (size_t)row, pw1, pw2);
+                bn[row] = bo[row] + p.lr * step;
+            }
+            mu_term = lane == 0 ? mu_term : (T)0;     // every lane computed the same terms
         }
     }
-    const int per = p.algorithm_is_bpr ? 3 : 2;
-    if (w >= per * p.n_in_batch) return;
-    const int entry = p.list[w];
-    if (entry < 0) return;                              // this sample was not the first toucher of that row
-    const bool is_item = entry >= p.n_users;
-    const int row = is_item ? entry - p.n_users : entry;
-    const int k = p.k;
-    float *W = (is_item ? p.V : p.U) + (size_t)row * k;
-    float *A = (is_item ? p.accV : p.accU) + (size_t)row * k;
-    float *c1 = is_item ? p.c1V : p.c1U, *c2 = is_item ? p.c2V : p.c2U;
-    for (int f = lane; f < k; f += 64) {
-        float g = A[f] * invB;
-        g = adapt(p, g, c1, c2, (size_t)row * k + f, pw1, pw2);
-        W[f] += p.lr * g;
-        A[f] = 0.f;
-    }
-    if (lane == 0) {
-        if (p.use_bias) {
-            float *b = is_item ? p.bi : p.bu, *ab = is_item ? p.acc_bi : p.acc_bu;
-            float *b1 = is_item ? p.c1_bi : p.c1_bu, *b2 = is_item ? p.c2_bi : p.c2_bu;
-            float g = adapt(p, ab[row] * invB, b1, b2, (size_t)row, pw1, pw2);
-            b[row] += p.lr * g;
-            ab[row] = 0.f;
+    if (bias) {
+        if (lane == 0) s_mu[threadIdx.x >> 6] = mu_term;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const T sum = (s_mu[0] + s_mu[1]) + (s_mu[2] + s_mu[3]);
+            const long long gb = p.state->batch_base + batch_local;
+            if (sum != (T)0) atomicAdd(&p.mu_acc[(int)(gb % 3) * 16 + (blockIdx.x & 15)], sum);
         }
-        p.flag[entry] = 0;
     }
+}
+
+// Current version of every row as float32 (the getters of .pyx:685-702), and the global bias after the last batch.
+template <class T>
+__global__ __launch_bounds__(256) void mf_gather_rows_kernel(const T *b0, const T *b1, const unsigned char *par, long long n_rows,
+                                                             int k, float *out) {
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (t >= n_rows * k) return;
+    const long long row = t / k;
+    out[t] = (float)(par[row] ? b1[t] : b0[t]);
+}
+template <class T>
+__global__ void mf_final_mu_kernel(const MfParams<T> p, float *out) {
+    const int lane = threadIdx.x & 63;
+    const T mu = global_bias_at(p, p.state->batch_base, false, lane);
+    if (threadIdx.x == 0) out[0] = (float)mu;
 }
 
 // AsySVD (.pyx:393-541): batch_size is 1 and every step rewrites all the Y rows of the sampled user's profile, which
 // nearly every other profile shares -- the steps are executed strictly in order by ONE 1024-thread workgroup (16
-// wavefronts across the profile rows, lanes across the factors).  p.U is the n_items x k matrix Y ("USER_factors" in the
-// reference), p.V the item factors X.
+// wavefronts across the profile rows, lanes across the factors).  p.U0 is the n_items x k matrix Y ("USER_factors" in
+// the reference), p.V0 the item factors X; nothing is double-buffered here.
 constexpr int ASY_KMAX = 256;
-__global__ __launch_bounds__(1024) void mf_asy_kernel(const MfParams p, const long long first, const int count) {
-    __shared__ float s_part[16][ASY_KMAX];
-    __shared__ float s_acc[ASY_KMAX], s_xi[ASY_KMAX];
-    __shared__ float s_err, s_pw1, s_pw2;
+template <class T>
+__global__ __launch_bounds__(1024) void mf_asy_kernel(const MfParams<T> p, const long long first, const int count) {
+    __shared__ T s_part[16][ASY_KMAX];
+    __shared__ T s_acc[ASY_KMAX], s_xi[ASY_KMAX];
+    __shared__ T s_err, s_pw1, s_pw2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = p.k;
+    T *const Ymat = p.U0, *const Xmat = p.V0, *const bu = p.bu0, *const bi = p.bi0;
     double b1p = 0.0, b2p = 0.0, loss = 0.0;
     if (tid == 0) {
         b1p = p.state->beta_1_power;
@@ -328,16 +716,16 @@ __global__ __launch_bounds__(1024) void mf_asy_kernel(const MfParams p, const lo
     for (int s = 0; s < count; ++s) {
         const long long t = first + s;
         const int u = p.su[t], i = p.si[t];
-        const float rating = p.sr[t];
+        const T rating = (T)p.sr[t];
         const int rs = p.indptr[u], re = p.indptr[u + 1];
-        float *X = p.V + (size_t)i * k;
+        T *X = Xmat + (size_t)i * k;
         for (int f = tid; f < k; f += 1024) s_xi[f] = X[f];
         // user vector: sum of the Y rows of the profile / sqrt(profile length)   (.pyx:424-441)
-        float part[ASY_KMAX / 64];
+        T part[ASY_KMAX / 64];
 #pragma unroll
-        for (int c = 0; c < ASY_KMAX / 64; ++c) part[c] = 0.f;
+        for (int c = 0; c < ASY_KMAX / 64; ++c) part[c] = (T)0;
         for (int q = rs + wave; q < re; q += 16) {
-            const float *Y = p.U + (size_t)p.indices[q] * k;
+            const T *Y = Ymat + (size_t)p.indices[q] * k;
 #pragma unroll
             for (int c = 0; c < ASY_KMAX / 64; ++c) {
                 const int f = lane + 64 * c;
@@ -351,28 +739,28 @@ __global__ __launch_bounds__(1024) void mf_asy_kernel(const MfParams p, const lo
         }
         __syncthreads();
         if (tid < k) {
-            float a = 0.f;
+            T a = (T)0;
             for (int w = 0; w < 16; ++w) a += s_part[w][tid];
-            s_acc[tid] = a / sqrtf((float)(re - rs));
+            s_acc[tid] = a / root((T)(re - rs));
         }
         __syncthreads();
         if (wave == 0) {
-            float dot = 0.f;
+            T dot = (T)0;
             for (int f = lane; f < k; f += 64) dot += s_acc[f] * s_xi[f];
             dot = wave_sum(dot);
             if (lane == 0) {
-                float pred = dot;
-                if (p.use_bias) pred += p.mu[0] + p.bu[u] + p.bi[i];
-                const float err = rating - pred;
-                loss += (double)err * err;
-                const float pw1 = (float)(1.0 - b1p), pw2 = (float)(1.0 - b2p);
+                T pred = dot;
+                if (p.use_bias) pred += p.asy_mu[0] + bu[u] + bi[i];
+                const T err = rating - pred;
+                loss += (double)err * (double)err;
+                const T pw1 = (T)(1.0 - b1p), pw2 = (T)(1.0 - b2p);
                 if (p.use_bias) {       // global, item, user bias -- in that order (.pyx:458-490)
-                    float g = adapt(p, err - p.bias_reg * p.mu[0], p.c_mu, p.c_mu + 1, 0, pw1, pw2);
-                    p.mu[0] += p.lr * g;
-                    g = adapt(p, err - p.bias_reg * p.bi[i], p.c1_bi, p.c2_bi, (size_t)i, pw1, pw2);
-                    p.bi[i] += p.lr * g;
-                    g = adapt(p, err - p.bias_reg * p.bu[u], p.c1_bu, p.c2_bu, (size_t)u, pw1, pw2);
-                    p.bu[u] += p.lr * g;
+                    T g = adapt(p, err - p.bias_reg * p.asy_mu[0], p.asy_c_mu, p.asy_c_mu + 1, 0, pw1, pw2);
+                    p.asy_mu[0] += p.lr * g;
+                    g = adapt(p, err - p.bias_reg * bi[i], p.c1_bi, p.c2_bi, (size_t)i, pw1, pw2);
+                    bi[i] += p.lr * g;
+                    g = adapt(p, err - p.bias_reg * bu[u], p.c1_bu, p.c2_bu, (size_t)u, pw1, pw2);
+                    bu[u] += p.lr * g;
                 }
                 s_err = err;
                 s_pw1 = pw1;
@@ -384,21 +772,21 @@ __global__ __launch_bounds__(1024) void mf_asy_kernel(const MfParams p, const lo
             }
         }
         __syncthreads();
-        const float err = s_err, pw1 = s_pw1, pw2 = s_pw2;
+        const T err = s_err, pw1 = s_pw1, pw2 = s_pw2;
         // every Y row of the profile moves against the OLD X[i]   (.pyx:493-511)
         for (int q = rs + wave; q < re; q += 16) {
             const size_t row = (size_t)p.indices[q];
-            float *Y = p.U + row * k;
+            T *Y = Ymat + row * k;
             for (int f = lane; f < k; f += 64) {
-                const float w = Y[f];
-                const float g = adapt(p, err * s_xi[f] - p.user_reg * w, p.c1U, p.c2U, row * k + f, pw1, pw2);
+                const T w = Y[f];
+                const T g = adapt(p, err * s_xi[f] - p.user_reg * w, p.c1U, p.c2U, row * k + f, pw1, pw2);
                 Y[f] = w + p.lr * g;
             }
         }
         // X[i] moves against the user vector formed BEFORE the Y update   (.pyx:514-531)
         if (tid < k) {
-            const float h = s_xi[tid];
-            const float g = adapt(p, err * s_acc[tid] - p.item_reg * h, p.c1V, p.c2V, (size_t)i * k + tid, pw1, pw2);
+            const T h = s_xi[tid];
+            const T g = adapt(p, err * s_acc[tid] - p.item_reg * h, p.c1V, p.c2V, (size_t)i * k + tid, pw1, pw2);
             X[tid] = h + p.lr * g;
         }
         __threadfence_block();
@@ -420,21 +808,34 @@ struct mi355rec_mf {
     mi355rec_mf_config cfg{};
     int n_users = 0, n_items = 0, k = 0;
     int n_u_rows = 0;                 // rows of U: n_users, or n_items for AsySVD
+    bool f64 = false;                 // storage / arithmetic type of factors and moments
     size_t nnz = 0;
     hipStream_t stream = nullptr;
     StreamTimer timer;
-    DeviceBuffer<int> indptr, indices, flag, list, su, si, sj;
-    DeviceBuffer<float> data, U, V, accU, accV, bu, bi, mu, acc_bu, acc_bi, mu_slots;
-    DeviceBuffer<float> c1U, c2U, c1V, c2V, c1_bu, c2_bu, c1_bi, c2_bi, c_mu, sr;
+    DeviceBuffer<int> indptr, indices, su, si, sj;
+    DeviceBuffer<float> data, sr, stage;
+    // T-typed arrays (float or double by `f64`), held as bytes
+    DeviceBuffer<unsigned char> U[2], V[2], bu[2], bi[2], c1U, c2U, c1V, c2V, c1_bu, c2_bu, c1_bi, c2_bi;
+    DeviceBuffer<unsigned char> mu_state, mu_acc, asy_mu, asy_c_mu;
+    DeviceBuffer<unsigned char> par;
     DeviceBuffer<double> loss_slots;
     DeviceBuffer<MfState> state;
+    // schedule
+    DeviceBuffer<unsigned long long> keys, keys_sorted;
+    DeviceBuffer<int> slots, slots_sorted, head, head_scan, task_at, batch_count;
+    DeviceBuffer<unsigned char> spar, cub_tmp;
+    DeviceBuffer<TaskHeader> tasks;
+    DeviceBuffer<int4> recs;
+    size_t cub_tmp_bytes = 0;
+    size_t stream_capacity = 0;      // samples
+    long long batch_capacity = 0;    // mini-batches the task arrays can hold
     long long batches_done = 0;      // batches executed since create (device state mirrors this)
     long long last_call_samples = 0; // samples in the stream buffer after the last native call
-    size_t stream_capacity = 0;
     mi355rec_stats stats{};
     DispatchTimers dispatch_timers;
     int max_timed = 0;
-    hipGraphExec_t epoch_graph = nullptr;   // one native epoch: sample kernel + n_batches x (grad, apply)
+    hipGraphExec_t epoch_graph = nullptr;   // one native epoch: sampler, schedule, n_batches mini-batch kernels
+    bool graph_failed = false;
     std::vector<double> host_loss;
 
     ~mi355rec_mf() {
@@ -448,124 +849,215 @@ struct mi355rec_mf {
 
 namespace {
 
+int bits_for(unsigned long long n_values) {   // bits needed for values 0 .. n_values - 1 (at least 1)
+    int b = 1;
+    while (b < 63 && (1ull << b) < n_values) ++b;
+    return b;
+}
+
+int per_sample(const mi355rec_mf *h) { return h->cfg.algorithm == MI355REC_MF_BPR ? 3 : 2; }
+
 long long batches_per_epoch(const mi355rec_mf *h) {
-    // .pyx:583 (BPR: n_users / B + 1) and :289 (FunkSVD: nnz / B + 1)
+    // .pyx:583 (BPR: n_users / B + 1) and :289 (FunkSVD: nnz / B + 1); ASY_SVD: nnz / 1 + 1 single-sample steps (.pyx:397)
     const long long B = h->cfg.batch_size;
-    // ASY_SVD: nnz / 1 + 1 single-sample steps (.pyx:397)
     return (h->cfg.algorithm == MI355REC_MF_BPR ? (long long)h->n_users / B : (long long)h->nnz / B) + 1;
 }
 
-void fill_params(mi355rec_mf *h, MfParams &p) {
+template <class T> T *as(const DeviceBuffer<unsigned char> &b) { return reinterpret_cast<T *>(b.ptr); }
+
+template <class T>
+void fill_params(mi355rec_mf *h, MfParams<T> &p) {
     const auto &c = h->cfg;
     p.n_users = h->n_users; p.n_items = h->n_items; p.k = h->k; p.batch_size = c.batch_size;
     p.use_bias = c.use_bias && c.algorithm != MI355REC_MF_BPR;
     p.sgd_mode = c.sgd_mode;
-    p.algorithm_is_bpr = c.algorithm == MI355REC_MF_BPR;
     p.sample_negatives = c.negative_interactions_quota != 0.0;
-    p.lr = (float)c.learning_rate; p.user_reg = (float)c.user_reg; p.item_reg = (float)c.item_reg; p.bias_reg = (float)c.bias_reg;
-    p.positive_reg = (float)c.positive_reg; p.negative_reg = (float)c.negative_reg;
+    p.tasks_per_batch = per_sample(h) * c.batch_size;
+    p.lr = (T)c.learning_rate; p.user_reg = (T)c.user_reg; p.item_reg = (T)c.item_reg; p.bias_reg = (T)c.bias_reg;
+    p.positive_reg = (T)c.positive_reg; p.negative_reg = (T)c.negative_reg;
+    p.inv_batch = (T)1 / (T)c.batch_size;
     p.quota = (float)c.negative_interactions_quota;
-    p.gamma = (float)c.gamma; p.beta_1 = (float)c.beta_1; p.beta_2 = (float)c.beta_2;
-    p.one_m_gamma = (float)(1.0 - c.gamma); p.one_m_beta_1 = (float)(1.0 - c.beta_1); p.one_m_beta_2 = (float)(1.0 - c.beta_2);
+    p.gamma = (T)c.gamma; p.beta_1 = (T)c.beta_1; p.beta_2 = (T)c.beta_2;
+    p.one_m_gamma = (T)(1.0 - c.gamma); p.one_m_beta_1 = (T)(1.0 - c.beta_1); p.one_m_beta_2 = (T)(1.0 - c.beta_2);
     p.beta_1_d = c.beta_1; p.beta_2_d = c.beta_2;
     p.seed = c.random_seed;
     p.indptr = h->indptr.ptr; p.indices = h->indices.ptr; p.data = h->data.ptr;
-    p.U = h->U.ptr; p.V = h->V.ptr; p.accU = h->accU.ptr; p.accV = h->accV.ptr;
-    p.bu = h->bu.ptr; p.bi = h->bi.ptr; p.mu = h->mu.ptr;
-    p.acc_bu = h->acc_bu.ptr; p.acc_bi = h->acc_bi.ptr; p.mu_slots = h->mu_slots.ptr;
-    p.c1U = h->c1U.ptr; p.c2U = h->c2U.ptr; p.c1V = h->c1V.ptr; p.c2V = h->c2V.ptr;
-    p.c1_bu = h->c1_bu.ptr; p.c2_bu = h->c2_bu.ptr; p.c1_bi = h->c1_bi.ptr; p.c2_bi = h->c2_bi.ptr; p.c_mu = h->c_mu.ptr;
-    p.flag = h->flag.ptr; p.list = h->list.ptr; p.loss_slots = h->loss_slots.ptr; p.state = h->state.ptr;
+    p.U0 = as<T>(h->U[0]); p.U1 = as<T>(h->U[1]); p.V0 = as<T>(h->V[0]); p.V1 = as<T>(h->V[1]);
+    p.bu0 = as<T>(h->bu[0]); p.bu1 = as<T>(h->bu[1]); p.bi0 = as<T>(h->bi[0]); p.bi1 = as<T>(h->bi[1]);
+    p.c1U = as<T>(h->c1U); p.c2U = as<T>(h->c2U); p.c1V = as<T>(h->c1V); p.c2V = as<T>(h->c2V);
+    p.c1_bu = as<T>(h->c1_bu); p.c2_bu = as<T>(h->c2_bu); p.c1_bi = as<T>(h->c1_bi); p.c2_bi = as<T>(h->c2_bi);
+    p.mu_state = reinterpret_cast<MuState<T> *>(h->mu_state.ptr);
+    p.mu_acc = as<T>(h->mu_acc);
+    p.asy_mu = as<T>(h->asy_mu); p.asy_c_mu = as<T>(h->asy_c_mu);
+    p.par = h->par.ptr;
+    p.loss_slots = h->loss_slots.ptr; p.state = h->state.ptr;
     p.su = h->su.ptr; p.si = h->si.ptr; p.sj = h->sj.ptr; p.sr = h->sr.ptr;
     p.samples_per_epoch = batches_per_epoch(h) * (long long)c.batch_size;
-    p.n_in_batch = c.batch_size;
+    p.tasks = h->tasks.ptr; p.recs = h->recs.ptr;
 }
 
-template <int ALGO, int KI>
-void launch_grad(mi355rec_mf *h, const MfParams &p, int grid, int batch_local, hipEvent_t e0, hipEvent_t e1) {
-    if (e0) hipExtLaunchKernelGGL((mf_grad_kernel<ALGO, KI>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p, batch_local);
-    else hipLaunchKernelGGL((mf_grad_kernel<ALGO, KI>), dim3(grid), dim3(256), 0, h->stream, p, batch_local);   // capturable
+// ---- kernel selection -------------------------------------------------------------------------------------------------
+template <int ALGO, class T, int VEC, int LPR, int KI>
+void launch_batch_as(mi355rec_mf *h, const MfParams<T> &p, int grid, int batch_local, hipEvent_t e0, hipEvent_t e1) {
+    if (e0) hipExtLaunchKernelGGL((mf_batch_kernel<ALGO, T, VEC, LPR, KI>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p, batch_local);
+    else hipLaunchKernelGGL((mf_batch_kernel<ALGO, T, VEC, LPR, KI>), dim3(grid), dim3(256), 0, h->stream, p, batch_local);   // capturable
 }
 
-template <int ALGO>
-void launch_grad_ki(mi355rec_mf *h, const MfParams &p, int grid, int batch_local, bool timed) {
-    const int ki = h->k <= 256 ? (h->k + 63) / 64 : 0;
+template <int ALGO, class T>
+void launch_batch(mi355rec_mf *h, const MfParams<T> &p, int batch_local, bool timed) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int grid = div_up(p.tasks_per_batch, 4);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) h->dispatch_timers.next(e0, e1, h->max_timed);
-    switch (ki) {
-        case 1: launch_grad<ALGO, 1>(h, p, grid, batch_local, e0, e1); break;
-        case 2: launch_grad<ALGO, 2>(h, p, grid, batch_local, e0, e1); break;
-        case 3: launch_grad<ALGO, 3>(h, p, grid, batch_local, e0, e1); break;
-        case 4: launch_grad<ALGO, 4>(h, p, grid, batch_local, e0, e1); break;
-        default: launch_grad<ALGO, 0>(h, p, grid, batch_local, e0, e1); break;
-    }
+    const int k = h->k, chunks = k / VEC;
+    if (k % VEC == 0 && chunks <= 16) launch_batch_as<ALGO, T, VEC, 16, 1>(h, p, grid, batch_local, e0, e1);
+    else if (k % VEC == 0 && chunks <= 32) launch_batch_as<ALGO, T, VEC, 32, 1>(h, p, grid, batch_local, e0, e1);
+    else if (k % VEC == 0 && chunks <= 64) launch_batch_as<ALGO, T, VEC, 64, 1>(h, p, grid, batch_local, e0, e1);
+    else if (k % VEC == 0 && chunks <= 128) launch_batch_as<ALGO, T, VEC, 64, 2>(h, p, grid, batch_local, e0, e1);
+    else if (e0) hipExtLaunchKernelGGL((mf_batch_generic_kernel<ALGO, T>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p, batch_local);
+    else hipLaunchKernelGGL((mf_batch_generic_kernel<ALGO, T>), dim3(grid), dim3(256), 0, h->stream, p, batch_local);
 }
 
-void launch_batch(mi355rec_mf *h, const MfParams &p, int batch_local, bool timed) {
-    const int grad_grid = div_up(p.n_in_batch, 4);
-    const bool bpr = h->cfg.algorithm == MI355REC_MF_BPR;
-    if (bpr) launch_grad_ki<MI355REC_MF_BPR>(h, p, grad_grid, batch_local, timed);
-    else launch_grad_ki<MI355REC_MF_FUNK_SVD>(h, p, grad_grid, batch_local, timed);
-    const int slots = (bpr ? 3 : 2) * p.n_in_batch;
-    hipLaunchKernelGGL(mf_apply_kernel, dim3(div_up(slots, 4)), dim3(256), 0, h->stream, p);
-}
-
-void launch_sampler(mi355rec_mf *h, const MfParams &p) {
+template <class T>
+void launch_sampler(mi355rec_mf *h, const MfParams<T> &p) {
     const int grid = div_up(p.samples_per_epoch, 256);
-    if (h->cfg.algorithm == MI355REC_MF_BPR) hipLaunchKernelGGL(mf_sample_kernel<MI355REC_MF_BPR>, dim3(grid), dim3(256), 0, h->stream, p);
-    else hipLaunchKernelGGL(mf_sample_kernel<MI355REC_MF_FUNK_SVD>, dim3(grid), dim3(256), 0, h->stream, p);
+    if (h->cfg.algorithm == MI355REC_MF_BPR) hipLaunchKernelGGL((mf_sample_kernel<MI355REC_MF_BPR, T>), dim3(grid), dim3(256), 0, h->stream, p);
+    else hipLaunchKernelGGL((mf_sample_kernel<MI355REC_MF_FUNK_SVD, T>), dim3(grid), dim3(256), 0, h->stream, p);
 }
 
-// One native epoch as plain launches (the first `timed` gradient launches carry per-dispatch events).
+// Stream buffers -> tasks (all on the handle's stream, no host synchronisation: capturable).
+void enqueue_schedule(mi355rec_mf *h, long long n_samples, long long n_batches) {
+    hipStream_t s = h->stream;
+    const int per = per_sample(h);
+    const long long n = n_samples * per;
+    SchedParams sp{};
+    sp.n_samples = n_samples;
+    sp.per = per;
+    sp.n_users = h->n_users;
+    sp.batch_size = h->cfg.batch_size;
+    sp.batch_bits = bits_for((unsigned long long)n_batches);
+    sp.tasks_per_batch = per * h->cfg.batch_size;
+    sp.su = h->su.ptr; sp.si = h->si.ptr; sp.sj = h->sj.ptr; sp.sr = h->sr.ptr;
+    sp.keys = h->keys.ptr; sp.slots = h->slots.ptr;
+    sp.keys_sorted = h->keys_sorted.ptr; sp.slots_sorted = h->slots_sorted.ptr;
+    sp.head = h->head.ptr; sp.head_scan = h->head_scan.ptr; sp.task_at = h->task_at.ptr;
+    sp.spar = h->spar.ptr; sp.par = h->par.ptr; sp.batch_count = h->batch_count.ptr;
+    sp.tasks = h->tasks.ptr; sp.recs = h->recs.ptr;
+    const int end_bit = sp.batch_bits + bits_for((unsigned long long)h->n_users + h->n_items);
+    MI_REQUIRE(end_bit <= 64, "sample stream too long for the schedule keys");
+    MI_HIP(hipMemsetAsync(h->batch_count.ptr, 0, sizeof(int) * (size_t)n_batches, s));
+    MI_HIP(hipMemsetAsync(h->tasks.ptr, 0, sizeof(TaskHeader) * (size_t)n_batches * sp.tasks_per_batch, s));
+    hipLaunchKernelGGL(mf_keys_kernel, dim3(div_up(n_samples, 256)), dim3(256), 0, s, sp);
+    size_t bytes = h->cub_tmp_bytes;
+    MI_HIP(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->slots.ptr,
+                                              h->slots_sorted.ptr, (int)n, 0, end_bit, s));
+    hipLaunchKernelGGL(mf_heads_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, sp);
+    bytes = h->cub_tmp_bytes;
+    MI_HIP(hipcub::DeviceScan::InclusiveSum(h->cub_tmp.ptr, bytes, h->head.ptr, h->head_scan.ptr, (int)n, s));
+    hipLaunchKernelGGL(mf_tasks_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, sp);
+    hipLaunchKernelGGL(mf_recs_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, sp);
+}
+
+template <class T>
+void enqueue_batches(mi355rec_mf *h, const MfParams<T> &p, long long n_batches, bool timed) {
+    const bool bpr = h->cfg.algorithm == MI355REC_MF_BPR;
+    for (long long b = 0; b < n_batches; ++b) {
+        if (bpr) launch_batch<MI355REC_MF_BPR, T>(h, p, (int)b, timed);
+        else launch_batch<MI355REC_MF_FUNK_SVD, T>(h, p, (int)b, timed);
+    }
+    hipLaunchKernelGGL(mf_stream_end_kernel<T>, dim3(1), dim3(64), 0, h->stream, p, n_batches);
+}
+
 constexpr int ASY_CHUNK = 1 << 16;   // steps per launch of the ordered AsySVD kernel (keeps single launches short)
 
-void enqueue_asy_steps(mi355rec_mf *h, const MfParams &p, long long n_steps, bool timed) {
+template <class T>
+void enqueue_asy_steps(mi355rec_mf *h, const MfParams<T> &p, long long n_steps, bool timed) {
     for (long long first = 0; first < n_steps; first += ASY_CHUNK) {
         const int count = (int)std::min<long long>(ASY_CHUNK, n_steps - first);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timed) h->dispatch_timers.next(e0, e1, h->max_timed);
-        if (e0) hipExtLaunchKernelGGL(mf_asy_kernel, dim3(1), dim3(1024), 0, h->stream, e0, e1, 0, p, first, count);
-        else hipLaunchKernelGGL(mf_asy_kernel, dim3(1), dim3(1024), 0, h->stream, p, first, count);
+        if (e0) hipExtLaunchKernelGGL(mf_asy_kernel<T>, dim3(1), dim3(1024), 0, h->stream, e0, e1, 0, p, first, count);
+        else hipLaunchKernelGGL(mf_asy_kernel<T>, dim3(1), dim3(1024), 0, h->stream, p, first, count);
     }
 }
 
-void enqueue_epoch(mi355rec_mf *h, const MfParams &p, bool timed) {
+// One native epoch as plain launches (the first `max_timed` mini-batch launches carry per-dispatch events when `timed`).
+template <class T>
+void enqueue_epoch(mi355rec_mf *h, const MfParams<T> &p, bool timed) {
     launch_sampler(h, p);
     if (h->cfg.algorithm == MI355REC_MF_ASY_SVD) {
         enqueue_asy_steps(h, p, p.samples_per_epoch, timed);
         return;
     }
     const long long nb = batches_per_epoch(h);
-    for (long long b = 0; b < nb; ++b) launch_batch(h, p, (int)b, timed);
+    enqueue_schedule(h, p.samples_per_epoch, nb);
+    enqueue_batches(h, p, nb, timed);
 }
 
 // Capture one epoch into a graph (once per handle; re-captured only if the stream buffers are re-allocated).
 constexpr long long MAX_GRAPH_BATCHES = 4096;
-void ensure_epoch_graph(mi355rec_mf *h, const MfParams &p) {
-    if (h->epoch_graph) return;
-    if (h->epoch_graph) {
-        (void)hipGraphExecDestroy(h->epoch_graph);
-        h->epoch_graph = nullptr;
-    }
+template <class T>
+void ensure_epoch_graph(mi355rec_mf *h, const MfParams<T> &p) {
+    if (h->epoch_graph || h->graph_failed) return;
     hipGraph_t g = nullptr;
-    MI_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    enqueue_epoch(h, p, false);
-    MI_HIP(hipStreamEndCapture(h->stream, &g));
-    MI_HIP(hipGraphInstantiate(&h->epoch_graph, g, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(g);
+    hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+        try {
+            enqueue_epoch(h, p, false);
+        } catch (...) {
+            (void)hipStreamEndCapture(h->stream, &g);
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            h->graph_failed = true;
+            return;
+        }
+        e = hipStreamEndCapture(h->stream, &g);
+    }
+    if (e == hipSuccess) e = hipGraphInstantiate(&h->epoch_graph, g, nullptr, nullptr, 0);
+    if (g) (void)hipGraphDestroy(g);
+    if (e != hipSuccess) {       // plain launches remain correct, only slower: remember and go on
+        (void)hipGetLastError();
+        h->epoch_graph = nullptr;
+        h->graph_failed = true;
+    }
 }
 
-void ensure_stream_capacity(mi355rec_mf *h, size_t n) {
-    if (h->stream_capacity >= n) return;
-    if (h->epoch_graph) {   // the graph holds the old buffer addresses
-        (void)hipGraphExecDestroy(h->epoch_graph);
-        h->epoch_graph = nullptr;
+void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batches) {
+    const bool asy = h->cfg.algorithm == MI355REC_MF_ASY_SVD;
+    if (h->stream_capacity < n_samples) {
+        if (h->epoch_graph) {   // the graph holds the old buffer addresses
+            (void)hipGraphExecDestroy(h->epoch_graph);
+            h->epoch_graph = nullptr;
+        }
+        h->su.alloc(n_samples);
+        h->si.alloc(n_samples);
+        h->sj.alloc(n_samples);
+        h->sr.alloc(n_samples);
+        h->stream_capacity = n_samples;
+        if (!asy) {
+            const size_t n = n_samples * (size_t)per_sample(h);
+            MI_REQUIRE(n < (1ull << 31), "sample stream too long (%zu incidences)", n);
+            h->keys.alloc(n); h->keys_sorted.alloc(n);
+            h->slots.alloc(n); h->slots_sorted.alloc(n);
+            h->head.alloc(n); h->head_scan.alloc(n); h->task_at.alloc(n);
+            h->spar.alloc(n); h->recs.alloc(n);
+            size_t sort_bytes = 0, scan_bytes = 0;
+            MI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, h->keys.ptr, h->keys_sorted.ptr, h->slots.ptr,
+                                                      h->slots_sorted.ptr, (int)n, 0, 64, h->stream));
+            MI_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, h->head.ptr, h->head_scan.ptr, (int)n, h->stream));
+            h->cub_tmp_bytes = std::max(sort_bytes, scan_bytes) + 256;
+            h->cub_tmp.alloc(h->cub_tmp_bytes);
+        }
     }
-    h->su.alloc(n);
-    h->si.alloc(n);
-    h->sj.alloc(n);
-    h->sr.alloc(n);
-    h->stream_capacity = n;
+    if (!asy && h->batch_capacity < n_batches) {
+        if (h->epoch_graph) {
+            (void)hipGraphExecDestroy(h->epoch_graph);
+            h->epoch_graph = nullptr;
+        }
+        h->batch_count.alloc((size_t)n_batches);
+        h->tasks.alloc((size_t)n_batches * per_sample(h) * h->cfg.batch_size);
+        h->batch_capacity = n_batches;
+    }
 }
 
 double bytes_per_sample(const mi355rec_mf *h) {
@@ -576,15 +1068,15 @@ double bytes_per_sample(const mi355rec_mf *h) {
 }
 
 void begin_call(mi355rec_mf *h) {
-    MI_HIP(hipMemsetAsync(h->loss_slots.ptr, 0, sizeof(double) * h->cfg.batch_size, h->stream));
+    MI_HIP(hipMemsetAsync(h->loss_slots.ptr, 0, sizeof(double) * h->loss_slots.count, h->stream));
     MI_HIP(hipMemsetAsync(&h->state.ptr->asy_loss, 0, sizeof(double), h->stream));
     h->dispatch_timers.reset();
 }
 
-void finish_call(mi355rec_mf *h, long long n_samples, long long n_batches) {
+void finish_call(mi355rec_mf *h, long long n_samples, long long n_launches) {
     MI_HIP(hipGetLastError());
-    h->host_loss.resize(h->cfg.batch_size);
-    h->loss_slots.download(h->host_loss.data(), h->cfg.batch_size, h->stream);
+    h->host_loss.resize(h->loss_slots.count);
+    h->loss_slots.download(h->host_loss.data(), h->loss_slots.count, h->stream);
     MI_HIP(hipStreamSynchronize(h->stream));
     double loss = 0;
     for (double v : h->host_loss) loss += v;
@@ -596,18 +1088,132 @@ void finish_call(mi355rec_mf *h, long long n_samples, long long n_batches) {
     h->stats.call_ms = h->timer.elapsed_ms();
     h->stats.kernel_ms = h->dispatch_timers.total_ms();
     h->stats.n_timed = h->dispatch_timers.used;
-    h->stats.n_launches = n_batches;            // launches of the dominant (gradient) kernel
+    h->stats.n_launches = n_launches;           // launches of the dominant (mini-batch) kernel
     h->stats.n_units = n_samples;
     h->stats.algorithmic_bytes = bytes_per_sample(h) * (double)n_samples;
     h->stats.algorithmic_flops = 0;
     h->stats.loss = loss;
 }
 
+template <class T>
+void create_typed(mi355rec_mf *h, const void *U0, const void *V0) {
+    hipStream_t s = h->stream;
+    const auto &cfg = h->cfg;
+    const size_t nu = (size_t)h->n_u_rows * h->k, ni = (size_t)h->n_items * h->k, ts = sizeof(T);
+    for (int b = 0; b < 2; ++b) {
+        h->U[b].upload(static_cast<const unsigned char *>(U0), nu * ts, s);
+        h->V[b].upload(static_cast<const unsigned char *>(V0), ni * ts, s);
+        h->bu[b].alloc_zero((size_t)h->n_users * ts, s);
+        h->bi[b].alloc_zero((size_t)h->n_items * ts, s);
+    }
+    if (cfg.sgd_mode != MI355REC_SGD) {
+        h->c1U.alloc_zero(nu * ts, s);
+        h->c1V.alloc_zero(ni * ts, s);
+        h->c1_bu.alloc_zero((size_t)h->n_users * ts, s);
+        h->c1_bi.alloc_zero((size_t)h->n_items * ts, s);
+        if (cfg.sgd_mode == MI355REC_ADAM) {
+            h->c2U.alloc_zero(nu * ts, s);
+            h->c2V.alloc_zero(ni * ts, s);
+            h->c2_bu.alloc_zero((size_t)h->n_users * ts, s);
+            h->c2_bi.alloc_zero((size_t)h->n_items * ts, s);
+        }
+    }
+    h->mu_state.alloc_zero(3 * sizeof(MuState<T>), s);
+    h->mu_acc.alloc_zero(3 * 16 * ts, s);
+    h->asy_mu.alloc_zero(ts, s);
+    h->asy_c_mu.alloc_zero(2 * ts, s);
+}
+
+template <class T>
+void run_epochs_typed(mi355rec_mf *h, int n_epochs) {
+    const long long B = h->cfg.batch_size;
+    const long long per_epoch = batches_per_epoch(h);
+    const bool asy = h->cfg.algorithm == MI355REC_MF_ASY_SVD;
+    ensure_stream_capacity(h, (size_t)(per_epoch * B), per_epoch);
+    MfParams<T> p{};
+    fill_params(h, p);
+    begin_call(h);
+    // epochs whose mini-batch launches carry timing events run as plain launches, the rest replays the graph
+    const long long timed_epochs = h->max_timed > 0 ? std::min<long long>(n_epochs, (h->max_timed + per_epoch - 1) / per_epoch) : 0;
+    // MI355REC_NO_GRAPH=1: plain launches only (rocprofv3 on ROCm 7.2 crashes while tracing graph replays)
+    bool use_graph = per_epoch <= MAX_GRAPH_BATCHES && n_epochs - timed_epochs > 0 && !getenv("MI355REC_NO_GRAPH") && !asy;
+    if (use_graph) {
+        ensure_epoch_graph(h, p);
+        use_graph = h->epoch_graph != nullptr;
+    }
+    h->timer.start(h->stream);
+    for (long long e = 0; e < n_epochs; ++e) {
+        if (e < timed_epochs || !use_graph) enqueue_epoch(h, p, e < timed_epochs);
+        else MI_HIP(hipGraphLaunch(h->epoch_graph, h->stream));
+    }
+    h->timer.stop(h->stream);
+    h->batches_done += per_epoch * n_epochs;
+    h->last_call_samples = n_epochs > 0 ? per_epoch * B : 0;
+    finish_call(h, per_epoch * n_epochs * B, asy ? n_epochs * ((per_epoch + ASY_CHUNK - 1) / ASY_CHUNK) : per_epoch * n_epochs);
+}
+
+template <class T>
+void run_samples_typed(mi355rec_mf *h, int64_t n) {
+    const long long B = h->cfg.batch_size;
+    MfParams<T> p{};
+    fill_params(h, p);
+    const long long n_batches = (n + B - 1) / B;
+    begin_call(h);
+    h->timer.start(h->stream);
+    if (h->cfg.algorithm == MI355REC_MF_ASY_SVD) {
+        enqueue_asy_steps(h, p, n, true);
+        h->timer.stop(h->stream);
+        h->batches_done += n;
+        finish_call(h, n, (n + ASY_CHUNK - 1) / ASY_CHUNK);
+        return;
+    }
+    enqueue_schedule(h, n, n_batches);
+    enqueue_batches(h, p, n_batches, true);
+    h->timer.stop(h->stream);
+    h->batches_done += n_batches;
+    finish_call(h, n, n_batches);
+}
+
+template <class T>
+void get_factors_typed(mi355rec_mf *h, float *U, float *V, float *bu, float *bi, float *mu) {
+    hipStream_t s = h->stream;
+    MfParams<T> p{};
+    fill_params(h, p);
+    const size_t nu = (size_t)h->n_u_rows * h->k, ni = (size_t)h->n_items * h->k;
+    const size_t need = std::max(std::max(nu, ni), (size_t)std::max(h->n_users, h->n_items));
+    if (h->stage.count < need) h->stage.alloc(need);
+    // rows of U are entries [0, n_u_rows) of `par` for BPR / FunkSVD; AsySVD never flips a buffer (par stays 0)
+    const unsigned char *par_u = h->par.ptr, *par_v = h->par.ptr + h->n_users;
+    auto gather = [&](const T *b0, const T *b1, const unsigned char *par, size_t rows, int k, float *host) {
+        hipLaunchKernelGGL(mf_gather_rows_kernel<T>, dim3(div_up((long long)rows * k, 256)), dim3(256), 0, s, b0, b1, par,
+                           (long long)rows, k, h->stage.ptr);
+        h->stage.download(host, rows * k, s);
+        MI_HIP(hipStreamSynchronize(s));
+    };
+    const bool asy = h->cfg.algorithm == MI355REC_MF_ASY_SVD;
+    if (U) gather(p.U0, p.U1, asy ? par_v : par_u, h->n_u_rows, h->k, U);   // AsySVD: item-sized, par is all zero anyway
+    if (V) gather(p.V0, p.V1, par_v, h->n_items, h->k, V);
+    if (bu) gather(p.bu0, p.bu1, par_u, h->n_users, 1, bu);
+    if (bi) gather(p.bi0, p.bi1, par_v, h->n_items, 1, bi);
+    if (mu) {
+        if (asy) {
+            T v;
+            MI_HIP(hipMemcpyAsync(&v, p.asy_mu, sizeof(T), hipMemcpyDeviceToHost, s));
+            MI_HIP(hipStreamSynchronize(s));
+            *mu = (float)v;
+        } else {
+            hipLaunchKernelGGL(mf_final_mu_kernel<T>, dim3(1), dim3(64), 0, s, p, h->stage.ptr);
+            h->stage.download(mu, 1, s);
+            MI_HIP(hipStreamSynchronize(s));
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mi355rec_mf_create(mi355rec_mf_t *out, const mi355rec_mf_config *cfg, int32_t n_users, int32_t n_items,
-                                  const int32_t *indptr, const int32_t *indices, const float *data, const float *U0,
-                                  const float *V0) {
+                                  const int32_t *indptr, const int32_t *indices, const float *data, const void *U0,
+                                  const void *V0) {
     return guarded([&] {
         MI_REQUIRE(out && cfg && indptr && indices && data && U0 && V0, "NULL argument");
         MI_REQUIRE(n_users > 0 && n_items > 0, "empty URM");
@@ -620,7 +1226,9 @@ extern "C" int mi355rec_mf_create(mi355rec_mf_t *out, const mi355rec_mf_config *
         MI_REQUIRE(cfg->sgd_mode >= MI355REC_SGD && cfg->sgd_mode <= MI355REC_ADAM, "Value for 'sgd_mode' not recognized (%d)",
                    cfg->sgd_mode);
         MI_REQUIRE(cfg->n_factors >= 1, "n_factors must be >= 1");
+        if (cfg->n_factors > 512) fail(MI355REC_E_UNSUPPORTED, "n_factors = %d exceeds 512", cfg->n_factors);
         MI_REQUIRE(cfg->batch_size >= 1, "batch_size must be >= 1");
+        MI_REQUIRE(cfg->precision == MI355REC_F32 || cfg->precision == MI355REC_F64, "precision must be MI355REC_F32 or MI355REC_F64");
         ensure_device();
         std::unique_ptr<mi355rec_mf> h(new mi355rec_mf());
         h->cfg = *cfg;
@@ -628,41 +1236,18 @@ extern "C" int mi355rec_mf_create(mi355rec_mf_t *out, const mi355rec_mf_config *
         h->n_items = n_items;
         h->k = cfg->n_factors;
         h->n_u_rows = asy ? n_items : n_users;
+        h->f64 = cfg->precision == MI355REC_F64;
         h->nnz = (size_t)indptr[n_users];
         MI_REQUIRE(h->nnz > 0, "URM has no interactions");
         MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->timer.init();
         hipStream_t s = h->stream;
-        const size_t nu = (size_t)h->n_u_rows * h->k, ni = (size_t)n_items * h->k;
         h->indptr.upload(indptr, (size_t)n_users + 1, s);
         h->indices.upload(indices, h->nnz, s);
         h->data.upload(data, h->nnz, s);
-        h->U.upload(U0, nu, s);
-        h->V.upload(V0, ni, s);
-        h->accU.alloc_zero(nu, s);
-        h->accV.alloc_zero(ni, s);
-        h->bu.alloc_zero(n_users, s);
-        h->bi.alloc_zero(n_items, s);
-        h->mu.alloc_zero(1, s);
-        h->acc_bu.alloc_zero(n_users, s);
-        h->acc_bi.alloc_zero(n_items, s);
-        h->mu_slots.alloc_zero((size_t)(cfg->batch_size + 3) / 4 + 1, s);
-        if (cfg->sgd_mode != MI355REC_SGD) {
-            h->c1U.alloc_zero(nu, s);
-            h->c1V.alloc_zero(ni, s);
-            h->c1_bu.alloc_zero(n_users, s);
-            h->c1_bi.alloc_zero(n_items, s);
-            h->c_mu.alloc_zero(2, s);
-            if (cfg->sgd_mode == MI355REC_ADAM) {
-                h->c2U.alloc_zero(nu, s);
-                h->c2V.alloc_zero(ni, s);
-                h->c2_bu.alloc_zero(n_users, s);
-                h->c2_bi.alloc_zero(n_items, s);
-            }
-        }
-        h->flag.alloc_zero((size_t)n_users + n_items, s);
-        h->list.alloc((size_t)cfg->batch_size * 3);
-        h->loss_slots.alloc_zero((size_t)cfg->batch_size, s);
+        if (h->f64) create_typed<double>(h.get(), U0, V0); else create_typed<float>(h.get(), U0, V0);
+        h->par.alloc_zero((size_t)n_users + n_items, s);
+        h->loss_slots.alloc_zero((size_t)per_sample(h.get()) * cfg->batch_size * 4, s);
         h->state.alloc_zero(1, s);
         {   // Adam's running beta powers start at beta^1 (.pyx:217-218)
             MfState init{};
@@ -680,28 +1265,7 @@ extern "C" int mi355rec_mf_run_epochs(mi355rec_mf_t h, int32_t n_epochs) {
         MI_REQUIRE(h, "NULL handle");
         MI_REQUIRE(n_epochs >= 0, "n_epochs must be >= 0");
         ensure_device();
-        const long long B = h->cfg.batch_size;
-        const long long per_epoch = batches_per_epoch(h);
-        const long long n_batches = per_epoch * n_epochs;
-        ensure_stream_capacity(h, (size_t)(per_epoch * B));
-        MfParams p{};
-        fill_params(h, p);
-        begin_call(h);
-        // epochs whose gradient launches carry timing events run as plain launches, the rest replays the graph
-        const long long timed_epochs = h->max_timed > 0 ? std::min<long long>(n_epochs, (h->max_timed + per_epoch - 1) / per_epoch) : 0;
-        // MI355REC_NO_GRAPH=1: plain launches only (rocprofv3 on ROCm 7.2 crashes while tracing graph replays)
-        const bool use_graph = per_epoch <= MAX_GRAPH_BATCHES && n_epochs - timed_epochs > 0 && !getenv("MI355REC_NO_GRAPH") &&
-                               h->cfg.algorithm != MI355REC_MF_ASY_SVD;
-        if (use_graph) ensure_epoch_graph(h, p);
-        h->timer.start(h->stream);
-        for (long long e = 0; e < n_epochs; ++e) {
-            if (e < timed_epochs || !use_graph) enqueue_epoch(h, p, e < timed_epochs);
-            else MI_HIP(hipGraphLaunch(h->epoch_graph, h->stream));
-        }
-        h->timer.stop(h->stream);
-        h->batches_done += n_batches;
-        h->last_call_samples = n_epochs > 0 ? per_epoch * B : 0;
-        finish_call(h, n_batches * B, n_batches);
+        if (h->f64) run_epochs_typed<double>(h, n_epochs); else run_epochs_typed<float>(h, n_epochs);
     });
 }
 
@@ -715,32 +1279,15 @@ extern "C" int mi355rec_mf_run_samples(mi355rec_mf_t h, const int32_t *u, const 
         ensure_device();
         if (n == 0) return;
         const long long B = h->cfg.batch_size;
-        ensure_stream_capacity(h, (size_t)std::max<long long>(n, batches_per_epoch(h) * B));
+        const long long per_epoch = batches_per_epoch(h);
+        ensure_stream_capacity(h, (size_t)std::max<long long>(n, per_epoch * B), std::max<long long>((n + B - 1) / B, per_epoch));
         hipStream_t s = h->stream;
         MI_HIP(hipMemcpyAsync(h->su.ptr, u, sizeof(int) * n, hipMemcpyHostToDevice, s));
         MI_HIP(hipMemcpyAsync(h->si.ptr, i, sizeof(int) * n, hipMemcpyHostToDevice, s));
         if (bpr) MI_HIP(hipMemcpyAsync(h->sj.ptr, j, sizeof(int) * n, hipMemcpyHostToDevice, s));
         else MI_HIP(hipMemcpyAsync(h->sr.ptr, rating, sizeof(float) * n, hipMemcpyHostToDevice, s));
         h->last_call_samples = 0;
-        MfParams p{};
-        fill_params(h, p);
-        const long long n_batches = (n + B - 1) / B;
-        begin_call(h);
-        h->timer.start(s);
-        if (h->cfg.algorithm == MI355REC_MF_ASY_SVD) {
-            enqueue_asy_steps(h, p, n, true);
-            h->timer.stop(s);
-            h->batches_done += n;
-            finish_call(h, n, (n + ASY_CHUNK - 1) / ASY_CHUNK);
-            return;
-        }
-        for (long long b = 0; b < n_batches; ++b) {
-            p.n_in_batch = (int)std::min<long long>(B, n - b * B);
-            launch_batch(h, p, (int)b, true);
-        }
-        h->timer.stop(s);
-        h->batches_done += n_batches;
-        finish_call(h, n, n_batches);
+        if (h->f64) run_samples_typed<double>(h, n); else run_samples_typed<float>(h, n);
     });
 }
 
@@ -748,13 +1295,7 @@ extern "C" int mi355rec_mf_get_factors(mi355rec_mf_t h, float *U, float *V, floa
     return guarded([&] {
         MI_REQUIRE(h, "NULL handle");
         ensure_device();
-        hipStream_t s = h->stream;
-        if (U) h->U.download(U, (size_t)h->n_u_rows * h->k, s);
-        if (V) h->V.download(V, (size_t)h->n_items * h->k, s);
-        if (bu) h->bu.download(bu, h->n_users, s);
-        if (bi) h->bi.download(bi, h->n_items, s);
-        if (mu) h->mu.download(mu, 1, s);
-        MI_HIP(hipStreamSynchronize(s));
+        if (h->f64) get_factors_typed<double>(h, U, V, bu, bi, mu); else get_factors_typed<float>(h, U, V, bu, bi, mu);
     });
 }
 

@@ -7,7 +7,9 @@ Mirrors
   MatrixFactorization_BPR_Cython        :171      MatrixFactorization_FunkSVD_Cython  :192
 The epoch object keeps the reference constructor's argument names / defaults / ValueErrors; factors are
 initialised on the host exactly as the reference does (np.random.seed(seed); normal(init_mean, init_std_dev)
-for U then V, .pyx:142-175) and live in HBM as float32 afterwards.  Sampling happens on the device
+for U then V, .pyx:142-175).  On the device factors and optimiser moments are float32 for plain sgd and float64 for
+adagrad / rmsprop / adam (`precision="auto"`; the reference computes in double and the adaptive normalisation amplifies
+float32 rounding); the getters return float32 either way.  Sampling happens on the device
 (counter-based RNG seeded by random_seed); `replay_samples` runs the identical arithmetic on a given sample
 stream (parity mode).  AsySVD ("ASY_SVD", batch_size 1) runs its steps strictly in order on one workgroup.
 """
@@ -30,7 +32,7 @@ class MatrixFactorization_MI355X_Epoch:
                  learning_rate=1e-3, use_bias=False, user_reg=0.0, item_reg=0.0, bias_reg=0.0, positive_reg=0.0,
                  negative_reg=0.0, verbose=False, random_seed=None, init_mean=0.0, init_std_dev=0.1,
                  sgd_mode="sgd", gamma=0.995, beta_1=0.9, beta_2=0.999,
-                 initial_USER_factors=None, initial_ITEM_factors=None):
+                 initial_USER_factors=None, initial_ITEM_factors=None, precision="auto"):
         if sgd_mode not in self.SGD_MODE_VALUES:
             raise ValueError("Value for 'sgd_mode' not recognized. Acceptable values are {}, provided was '{}'".format(
                 self.SGD_MODE_VALUES, sgd_mode))
@@ -39,6 +41,12 @@ class MatrixFactorization_MI355X_Epoch:
                 self.ALGORITHM_NAME_VALUES, algorithm_name))
         if algorithm_name == "ASY_SVD":
             assert batch_size == 1, "Batch size other than 1 not supported for ASY_SVD"
+        if precision == "auto":
+            precision = "fp32" if sgd_mode == "sgd" else "fp64"
+        if precision not in N.PRECISION_CODES:
+            raise ValueError("Value for 'precision' not recognized. Acceptable values are {}, provided was '{}'".format(
+                ["auto"] + list(N.PRECISION_CODES), precision))
+        self.precision = precision
         URM_train = check_matrix(URM_train, "csr")
         URM_train = URM_train.sorted_indices()
         self.n_users, self.n_items = URM_train.shape
@@ -62,9 +70,10 @@ class MatrixFactorization_MI355X_Epoch:
         seed = int(random_seed) if random_seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
         cfg = N.MFConfig(N.ALGORITHM_CODES[algorithm_name], self.n_factors, self.batch_size, int(self.use_bias),
                          N.SGD_MODE_CODES[sgd_mode], learning_rate, user_reg, item_reg, bias_reg, positive_reg,
-                         negative_reg, negative_interactions_quota, gamma, beta_1, beta_2, seed & (2 ** 64 - 1))
+                         negative_reg, negative_interactions_quota, gamma, beta_1, beta_2, seed & (2 ** 64 - 1),
+                         N.PRECISION_CODES[precision], 0)
         indptr, indices, data = N.as_i32(URM_train.indptr), N.as_i32(URM_train.indices), N.as_f32(URM_train.data)
-        U0, V0 = N.as_f32(U0), N.as_f32(V0)
+        U0, V0 = (N.as_f64(U0), N.as_f64(V0)) if precision == "fp64" else (N.as_f32(U0), N.as_f32(V0))
         self._lib = N.load()
         self._h = C.c_void_p()
         N.check(self._lib.mi355rec_mf_create(C.byref(self._h), C.byref(cfg), self.n_users, self.n_items,

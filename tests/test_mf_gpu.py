@@ -17,30 +17,16 @@ from _util import load_golden, rel_err, unpack_csr
 pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 MODES = ["sgd", "adagrad", "rmsprop", "adam"]
-# Tolerances, relative to max|factor| (north_star: 1e-5 on float32 factor matrices).
-#  - sgd: max-norm 1e-5, strictly.
-#  - adagrad / rmsprop / adam divide every gradient component by (sqrt(running g^2) + 1e-8).  A component whose
-#    mini-batch gradient nearly cancels has a large RELATIVE float32 error, and the normalisation turns it into an
-#    O(lr) absolute error on that cell; over epochs the float32 storage rounding of the factors (6e-8) is amplified the
-#    same way.  This is a property of float32 factors (which north_star prescribes), not of the kernels: a NumPy
-#    emulation doing ALL arithmetic in float64 and only STORING the factors as float32 gives, on the rmsprop case
-#    below, median 3e-8 / 99th percentile 6e-6 / max 3e-3 against the float64 oracle (adagrad 7e-9 / 6e-8 / 1.5e-5),
-#    and 2e-15 once the storage is float64 too.  For these optimisers the DISTRIBUTION of the error is
-#    checked (median, 99th percentile, outlier fraction, hard cap), plus a tight 99.9th-percentile bound after the first
-#    mini-batch, where only the cancellation effect exists.
-ADAPTIVE = ("adagrad", "rmsprop", "adam")
+# Tolerance: 1e-5 relative to max|factor| on the float32 outputs (north_star), for EVERY optimiser.  Plain sgd keeps
+# float32 factors on the device.  adagrad / rmsprop / adam divide every gradient component by (sqrt(running g^2) + 1e-8):
+# a component whose mini-batch gradient nearly cancels turns float32 rounding into an O(lr) error, so for these modes the
+# device keeps factors, biases and moments in float64 (precision="auto"), exactly like the reference's `double` arrays.
 
 
 def assert_factor_parity(dev, ref, mode, what):
     dev = np.asarray(dev, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
     err = np.abs(dev - ref) / max(np.abs(ref).max(), 1e-30)
-    if mode not in ADAPTIVE:
-        assert err.max() < RTOL, (what, mode, err.max())
-        return
-    assert np.median(err) < 1e-6, (what, mode, np.median(err))
-    assert np.quantile(err, 0.99) < 5e-4, (what, mode, np.quantile(err, 0.99))
-    assert (err > 1e-3).mean() < 2e-3, (what, mode, (err > 1e-3).mean())
-    assert err.max() < 0.1, (what, mode, err.max())
+    assert err.max() < RTOL, (what, mode, err.max())
 
 
 def _replay_case(X, kw, epochs):
@@ -66,19 +52,6 @@ def _replay_case(X, kw, epochs):
     assert st["n_units"] == len(u)
     assert abs(st["loss"] - orc.cumulative_loss()) <= 1e-3 * max(1.0, orc.cumulative_loss()) or epochs > 1
     dev.close()
-    if mode in ADAPTIVE:      # first mini-batch only: no accumulated amplification yet (see the note on tolerances above)
-        B = kw["batch_size"]
-        one = O.OracleMF(X, **kw)
-        first = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=one.initial_USER_factors,
-                                                 initial_ITEM_factors=one.initial_ITEM_factors, **kw)
-        if kw["algorithm_name"] == "MF_BPR":
-            one.replay(u[:B], i[:B], j=j[:B]); first.replay_samples(u[:B], i[:B], neg_item=j[:B])
-        else:
-            one.replay(u[:B], i[:B], rating=r[:B]); first.replay_samples(u[:B], i[:B], rating=r[:B])
-        for got, want in ((first.get_USER_factors(), one.get_USER_factors()), (first.get_ITEM_factors(), one.get_ITEM_factors())):
-            err = np.abs(got - want) / np.abs(want).max()
-            assert np.quantile(err, 0.999) < RTOL and err.max() < 1e-2, (np.quantile(err, 0.999), err.max())
-        first.close()
     return dev
 
 
@@ -211,6 +184,100 @@ def test_recommender_fit_surface(gpu):
     f = MatrixFactorization_FunkSVD_MI355X(named_urm("ml1m", "real", scale=0.1), verbose=False)
     f.fit(epochs=2, batch_size=500, num_factors=8, learning_rate=0.01, use_bias=True, random_seed=2)
     assert f.USER_bias.shape == (f.n_users,) and np.isfinite(f.ITEM_factors).all()
+
+
+def test_headline_ml20m_k128_replay_vs_oracle(gpu):
+    """BASELINE headline config, exactly: 138 493 x 26 744, k=128, batch 1000, sgd.  One full reference epoch (139 mini-batches,
+    glibc rand() stream of the oracle) replayed on the device; then two more NATIVE epochs (graph replay, device sampler) whose
+    streams are replayed through the oracle."""
+    X = named_urm("ml20m", "binary")
+    kw = dict(n_factors=128, algorithm_name="MF_BPR", batch_size=1000, random_seed=42, sgd_mode="sgd", learning_rate=0.05)
+    orc = O.OracleMF(X, **kw)
+    orc.record_samples(10 ** 6)
+    orc.epochIteration_Cython()
+    u, i, j, _ = orc.recorded()
+    assert len(u) == 139000
+    dev = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=orc.initial_USER_factors,
+                                           initial_ITEM_factors=orc.initial_ITEM_factors, **kw)
+    dev.replay_samples(u, i, neg_item=j)
+    assert_factor_parity(dev.get_USER_factors(), orc.get_USER_factors(), "sgd", "U")
+    assert_factor_parity(dev.get_ITEM_factors(), orc.get_ITEM_factors(), "sgd", "V")
+    for _ in range(2):
+        dev.epochIteration_Cython()
+        du, di, dj = dev.last_epoch_samples()
+        orc.replay(du, di, j=dj)
+    assert_factor_parity(dev.get_USER_factors(), orc.get_USER_factors(), "sgd", "U")
+    assert_factor_parity(dev.get_ITEM_factors(), orc.get_ITEM_factors(), "sgd", "V")
+    dev.close()
+
+
+@pytest.mark.parametrize("mode", ["sgd", "adam"])
+def test_funksvd_ml20m_k128_replay_vs_oracle(gpu, mode):
+    """FunkSVD at the ML-20M shape, k=128, batch 1000, biases on: the first 300 mini-batches of a reference epoch."""
+    X = named_urm("ml20m", "real")
+    kw = dict(n_factors=128, algorithm_name="FUNK_SVD", batch_size=1000, random_seed=7, sgd_mode=mode, learning_rate=0.005,
+              user_reg=0.01, item_reg=0.01, bias_reg=0.01, use_bias=True, negative_interactions_quota=0.3)
+    orc = O.OracleMF(X, **kw)
+    n = 300 * 1000
+    rng = np.random.default_rng(5)
+    # a valid FunkSVD stream without running the 20 M-sample reference epoch: stored positives and zero-rated other items
+    rows = np.repeat(np.arange(X.shape[0]), np.diff(X.indptr))
+    pick = rng.integers(0, X.nnz, n)
+    u = rows[pick].astype(np.int32); i = X.indices[pick].astype(np.int32); r = X.data[pick].astype(np.float64)
+    neg = rng.random(n) < 0.3
+    i[neg] = rng.integers(0, X.shape[1], neg.sum()); r[neg] = 0.0
+    orc.replay(u, i, rating=r)
+    dev = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=orc.initial_USER_factors,
+                                           initial_ITEM_factors=orc.initial_ITEM_factors, **kw)
+    dev.replay_samples(u[:100000], i[:100000], rating=r[:100000])      # two calls: state carries over
+    dev.replay_samples(u[100000:], i[100000:], rating=r[100000:])
+    assert_factor_parity(dev.get_USER_factors(), orc.get_USER_factors(), mode, "U")
+    assert_factor_parity(dev.get_ITEM_factors(), orc.get_ITEM_factors(), mode, "V")
+    assert_factor_parity(dev.get_USER_bias(), orc.get_USER_bias(), mode, "bu")
+    assert_factor_parity(dev.get_ITEM_bias(), orc.get_ITEM_bias(), mode, "bi")
+    assert abs(float(dev.get_GLOBAL_bias()) - float(orc.get_GLOBAL_bias())) < 1e-5 * max(1.0, abs(float(orc.get_GLOBAL_bias())))
+    dev.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_native_graph_epochs_equal_oracle(gpu, mode):
+    """Several native epochs in ONE call (hipGraph replays): row versions, Adam's t and the global-bias ring carry over."""
+    X = named_urm("ml1m", "real", scale=0.2)
+    kw = dict(n_factors=40, algorithm_name="FUNK_SVD", batch_size=128, random_seed=3, sgd_mode=mode, learning_rate=0.01,
+              user_reg=0.01, bias_reg=0.01, use_bias=True, negative_interactions_quota=0.25)
+    orc = O.OracleMF(X, **kw)
+    a = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=orc.initial_USER_factors,
+                                         initial_ITEM_factors=orc.initial_ITEM_factors, **kw)
+    b = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=orc.initial_USER_factors,
+                                         initial_ITEM_factors=orc.initial_ITEM_factors, **kw)
+    a.epochIteration_Cython(3)                       # one call, three epochs
+    for _ in range(3):                               # three calls: the same streams (same seed, same epoch counter)
+        b.epochIteration_Cython()
+        u, i, r = b.last_epoch_samples()
+        orc.replay(u, i, rating=r.astype(np.float64))
+    for dev in (a, b):
+        assert_factor_parity(dev.get_USER_factors(), orc.get_USER_factors(), mode, "U")
+        assert_factor_parity(dev.get_ITEM_factors(), orc.get_ITEM_factors(), mode, "V")
+        assert_factor_parity(dev.get_ITEM_bias(), orc.get_ITEM_bias(), mode, "bi")
+        assert abs(float(dev.get_GLOBAL_bias()) - float(orc.get_GLOBAL_bias())) < 1e-5 * max(1.0, abs(float(orc.get_GLOBAL_bias())))
+    np.testing.assert_array_equal(a.get_ITEM_factors(), b.get_ITEM_factors())      # the device path is deterministic
+
+
+def test_fp32_state_is_available_for_adaptive_modes(gpu):
+    """precision="fp32" keeps float32 factors and moments for the adaptive optimisers (half the memory); it then only
+    tracks the float64 reference statistically -- this is the round-1 behaviour, kept as an option, not the default."""
+    X = named_urm("ml1m", "binary", scale=0.2)
+    kw = dict(n_factors=64, algorithm_name="MF_BPR", batch_size=100, random_seed=11, sgd_mode="adagrad", learning_rate=0.05)
+    orc = O.OracleMF(X, **kw)
+    orc.record_samples(10 ** 6); orc.epochIteration_Cython()
+    u, i, j, _ = orc.recorded()
+    dev = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=orc.initial_USER_factors,
+                                           initial_ITEM_factors=orc.initial_ITEM_factors, precision="fp32", **kw)
+    dev.replay_samples(u, i, neg_item=j)
+    err = np.abs(dev.get_ITEM_factors() - orc.get_ITEM_factors()) / np.abs(orc.get_ITEM_factors()).max()
+    assert np.median(err) < 1e-6 and err.max() < 0.1
+    with pytest.raises(ValueError):
+        MatrixFactorization_MI355X_Epoch(X, precision="fp16", **kw)
 
 
 def test_full_size_ml20m_k128_properties(gpu):
