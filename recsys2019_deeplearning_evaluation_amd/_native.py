@@ -83,6 +83,7 @@ SIGNATURES = {
     "mi355rec_mf_get_factors": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mi355rec_mf_get_last_samples": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     "mi355rec_mf_set_profiling": (C.c_int, [_vp, _i32]),
+    "mi355rec_mf_get_phase_ticks": (C.c_int, [_vp, _vp, _i64, C.POINTER(_i64)]),
     "mi355rec_mf_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "mi355rec_mf_destroy": (None, [_vp]),
     "mi355rec_slim_create": (C.c_int, [C.POINTER(_vp), C.POINTER(SlimConfig), _i32, _i32, _vp, _vp]),

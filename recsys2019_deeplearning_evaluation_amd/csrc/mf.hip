@@ -91,6 +91,7 @@ struct MfParams {
     // schedule
     const TaskHeader *tasks;
     const int4 *recs;
+    unsigned long long *ticks;           // optional [tasks_per_batch][8] shader-clock stamps of the last mini-batch (MI355REC_MF_TICKS=1)
 };
 
 // ---- wavefront reductions without LDS traffic ----------------------------------------------------------------------
@@ -145,6 +146,12 @@ template <int LPR, class T> __device__ __forceinline__ T cross_group_sum(T v) {
     return v;
 }
 template <class T> __device__ __forceinline__ T wave_sum(T v) { return group_sum<64>(v); }
+
+__device__ __forceinline__ unsigned long long stamp() {   // shader clock; not reordered against memory operations
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
 
 __device__ __forceinline__ float sigmoid_of_minus(float x) { return 1.f / (1.f + __expf(x)); }   // .pyx:619
 __device__ __forceinline__ double sigmoid_of_minus(double x) { return 1.0 / (1.0 + exp(x)); }
@@ -321,6 +328,167 @@ __global__ __launch_bounds__(256) void mf_recs_kernel(const SchedParams s) {
     }
 }
 
+// ---- fast schedule: one workgroup per mini-batch sorts its incidences in LDS -----------------------------------------------
+// The general path above radix-sorts the whole stream (hipCUB picks a merge sort at this size: 120 us for the 417 k incidences
+// of a BPR epoch at ML-20M shape, plus 270 us for the task kernel's dependent searches) -- two thirds of the time of the 139
+// mini-batches it prepares.  When a mini-batch fits LDS and the stream has at most 256 mini-batches the same tasks come out of
+// three short kernels: (1) per mini-batch, a bitonic sort of (row, slot) keys in LDS, run lengths, task slots (lists longer
+// than two rounds of one wavefront get the 4 wavefronts of a workgroup: 4 aligned headers), and one bit per (row, mini-batch) in a global bitmap;
+// (2) per incidence, the version parity of each of the sample's rows = parity at stream start + number of earlier
+// mini-batches with the row's bit set; (3) per row, the parity after the stream, bitmap cleared for the next one.
+constexpr int META_WIDE = 1 << 30;        // header.meta: bits 0-27 list length, 28-29 quarter, 30 wide, 31 buffer of the own row
+constexpr int SCHED_THREADS = 1024;
+constexpr int FAST_MAX_BATCHES = 256, FAST_MAX_SLOTS = 8192;
+
+struct FastSchedParams {
+    long long n_samples;
+    int per, n_users, n_entries, batch_size, tasks_per_batch, slot_bits, np, words, group;
+    const int *su, *si, *sj;
+    const float *sr;
+    unsigned *touched;            // [n_entries][words]: bit b of row x = mini-batch b of this stream touches x
+    unsigned char *par;           // [n_entries]: buffer of every row's current version at stream start
+    int *sorted_slot;             // [n_batches][tasks_per_batch]: batch-local incidence ids in (row, id) order
+    int *qtask;                   // per sorted position: batch-local slot of its task's (first) header | wide << 30
+    TaskHeader *tasks;
+    int4 *recs;
+};
+
+__global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const FastSchedParams s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned sched_lds[];
+    unsigned *K = sched_lds;                                   // [np] keys: row << slot_bits | incidence
+    int *hpos = reinterpret_cast<int *>(sched_lds + s.np);     // [np + 1] first sorted position of every run
+    int *tpos = hpos + s.np + 1;                               // [np] header slot of every task
+    typedef hipcub::BlockScan<int, SCHED_THREADS> Scan;
+    __shared__ typename Scan::TempStorage scan_tmp;
+    const int tid = threadIdx.x, b = blockIdx.x, np = s.np, sb = s.slot_bits;
+    const long long first = (long long)b * s.batch_size;
+    const int n_in = (int)min((long long)s.batch_size, s.n_samples - first);
+    const int m = n_in * s.per;
+    for (int q = tid; q < np; q += SCHED_THREADS) {
+        unsigned key = 0xFFFFFFFFu;
+        if (q < m) {
+            const int smp = q / s.per, role = q - smp * s.per;
+            const long long t = first + smp;
+            const int entry = role == 0 ? s.su[t] : s.n_users + (role == 1 ? s.si[t] : s.sj[t]);
+            key = ((unsigned)entry << sb) | (unsigned)q;
+        }
+        K[q] = key;
+    }
+    __syncthreads();
+    for (int size = 2; size <= np; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < np / 2; t += SCHED_THREADS) {
+                const int lo = ((t / stride) * 2 * stride) + (t % stride), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned a = K[lo], c = K[hi];
+                if ((a > c) == up) { K[lo] = c; K[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // run heads -> hpos[]
+    const int C = np / SCHED_THREADS;
+    int cnt = 0;
+    for (int c = 0; c < C; ++c) {
+        const int q = tid * C + c;
+        cnt += q < m && (q == 0 || (K[q] >> sb) != (K[q - 1] >> sb));
+    }
+    int off = 0, total = 0;
+    Scan(scan_tmp).ExclusiveSum(cnt, off, total);
+    for (int c = 0; c < C; ++c) {
+        const int q = tid * C + c;
+        if (q < m && (q == 0 || (K[q] >> sb) != (K[q - 1] >> sb))) hpos[off++] = q;
+    }
+    if (tid == 0) hpos[total] = m;
+    __syncthreads();
+    // header slots: wide tasks first (4 aligned slots each), then the others; both in row order
+    const int CT = (total + SCHED_THREADS - 1) / SCHED_THREADS;
+    const int t_lo = min(tid * CT, total), t_hi = min(t_lo + CT, total);
+    int wcnt = 0;
+    const int wide_min = 2 * s.group;               // longer than two rounds of one wavefront: split over a workgroup
+    for (int t = t_lo; t < t_hi; ++t) wcnt += hpos[t + 1] - hpos[t] > wide_min;
+    int woff = 0, n_wide = 0;
+    Scan(scan_tmp).ExclusiveSum(wcnt, woff, n_wide);
+    TaskHeader *out = s.tasks + (size_t)b * s.tasks_per_batch;
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int start = hpos[t], len = hpos[t + 1] - start;
+        const bool wide = len > wide_min;
+        const int slot = wide ? 4 * woff : 4 * n_wide + (t - woff);
+        woff += wide;
+        tpos[t] = slot | (wide ? META_WIDE : 0);
+        const int entry = (int)(K[start] >> sb);
+        for (int part = 0; part < (wide ? 4 : 1); ++part) {
+            *reinterpret_cast<int4 *>(out + slot + part) =
+                make_int4(entry, len | (wide ? META_WIDE | (part << 28) : 0), b * s.tasks_per_batch + start, 0);
+            out[slot + part].rec0 = make_int4(0, 0, 0, 0);     // (a short wide list leaves its last quarters without a record)
+        }
+        atomicOr(&s.touched[(size_t)entry * s.words + (b >> 5)], 1u << (b & 31));
+    }
+    const int used = 4 * n_wide + (total - n_wide);
+    for (int slot = used + tid; slot < s.tasks_per_batch; slot += SCHED_THREADS)
+        *reinterpret_cast<int4 *>(out + slot) = make_int4(0, 0, 0, 0);          // no samples: the slot's wavefront idles
+    __syncthreads();
+    for (int q = tid; q < m; q += SCHED_THREADS) {
+        int lo = 0, hi = total;                       // last run starting at or before q
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (hpos[mid] <= q) lo = mid; else hi = mid;
+        }
+        s.sorted_slot[(size_t)b * s.tasks_per_batch + q] = (int)(K[q] & ((1u << sb) - 1));
+        s.qtask[(size_t)b * s.tasks_per_batch + q] = tpos[lo];
+    }
+}
+
+__device__ __forceinline__ int version_parity(const FastSchedParams &s, int entry, int b) {
+    const unsigned *w = s.touched + (size_t)entry * s.words;
+    int cnt = 0;
+    for (int k = 0; k < (b >> 5); ++k) cnt += __popc(w[k]);
+    cnt += __popc(w[b >> 5] & ((1u << (b & 31)) - 1u));
+    return (s.par[entry] + cnt) & 1;
+}
+
+__global__ __launch_bounds__(256) void mf_sched_emit_kernel(const FastSchedParams s) {
+    const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    const long long first = (long long)b * s.batch_size;
+    const int n_in = (int)min((long long)s.batch_size, s.n_samples - first);
+    if (q >= n_in * s.per) return;
+    const size_t at = (size_t)b * s.tasks_per_batch + q;
+    const int slot = s.sorted_slot[at];
+    const int smp = slot / s.per, role = slot - smp * s.per;
+    const long long t = first + smp;
+    const int u = s.su[t], i = s.si[t], j = s.per == 3 ? s.sj[t] : 0;
+    const int pu = version_parity(s, u, b), pi = version_parity(s, s.n_users + i, b);
+    const int pj = s.per == 3 ? version_parity(s, s.n_users + j, b) : 0;
+    const int4 rec = make_int4(u, i, s.per == 3 ? j : __float_as_int(s.sr[t]), role | (pu << 2) | (pi << 3) | (pj << 4));
+    s.recs[at] = rec;
+    const int tp = s.qtask[at];
+    TaskHeader *hd = s.tasks + (size_t)b * s.tasks_per_batch + (tp & (META_WIDE - 1));
+    const int off = (int)(at - (size_t)hd->start);
+    const int own = role == 0 ? pu : (role == 1 ? pi : pj);
+    int part = -1;
+    if (tp & META_WIDE) {           // quarter k of a wide list starts at position k * group
+        if (off % s.group == 0 && off / s.group < 4) part = off / s.group;      // (quarters past the end of the list stay empty)
+    } else if (off == 0) {
+        part = 0;
+    }
+    if (part >= 0) {
+        hd[part].rec0 = rec;
+        hd[part].meta |= own << 31;
+    }
+}
+
+__global__ __launch_bounds__(256) void mf_sched_finish_kernel(const FastSchedParams s) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= s.n_entries) return;
+    unsigned *w = s.touched + (size_t)x * s.words;
+    int cnt = 0;
+    for (int k = 0; k < s.words; ++k) {
+        const unsigned v = w[k];
+        if (v) { cnt += __popc(v); w[k] = 0; }
+    }
+    if (cnt & 1) s.par[x] ^= 1;
+}
+
 template <class T>
 __global__ void mf_stream_end_kernel(const MfParams<T> p, const long long n_batches) {
     if (threadIdx.x == 0 && blockIdx.x == 0) p.state->batch_base += n_batches;
@@ -412,6 +580,7 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
     using R = Rows<T, VEC, KI, BPR>;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const unsigned long long tk0 = p.ticks ? stamp() : 0ull;
     // every wave-uniform input is requested before the first one is waited for (scalar loads, one wait)
     // (unused task slots of a batch are zero: a header with no samples means there is nothing to do)
     // (the grid is rounded up to whole workgroups: wavefronts past the batch's last slot re-read that slot and idle)
@@ -427,26 +596,35 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
     const int4 h0 = make_int4(hd[0], hd[1], hd[2], hd[3]), h1 = make_int4(hd[4], hd[5], hd[6], hd[7]);
     const bool active = (h0.y & LEN_MASK) != 0 && wv < p.tasks_per_batch;
     __shared__ T s_mu[4];
+    __shared__ T s_wide[4][LPR * KI * VEC];
+    __shared__ T s_wide_bias[4];
     T mu_term = (T)0;
     T mu_eff = (T)0;
+    unsigned long long tk1 = 0, tk2 = 0, tk3 = 0;
+    if (p.ticks) tk1 = stamp();          // header has arrived (its value decided `active`)
     if (bias) mu_eff = global_bias_at(p, gb, wv == 0, lane);
     if (active) {
         const int entry = h0.x, len = h0.y & LEN_MASK, own_par = (unsigned)h0.y >> 31, start = h0.z;
+        // a wide task (list longer than two rounds of a wavefront) owns the 4 wavefronts of this workgroup: quarter `part` takes list
+        // positions part * G + g, then every 4 * G; h1 is the record at part * G
+        const bool wide = (h0.y & META_WIDE) != 0;
+        const int part = (h0.y >> 28) & 3;
+        const int base = wide ? part * G : 0, step = wide ? 4 * G : G;
         const int g = lane / LPR, li = lane % LPR;
         const int k = p.k, chunks = k / VEC;
         bool cok[KI];
 #pragma unroll
         for (int c = 0; c < KI; ++c) cok[c] = c * LPR + li < chunks;
-        const int iters = (len + G - 1) / G;
+        const int iters = len > base ? (len - base + step - 1) / step : 0;      // (a short wide list leaves late quarters empty)
         // software pipeline: records two list positions ahead of the arithmetic, rows one ahead.  Positions past the
         // end of the list are clamped to the last record (valid addresses) and contribute nothing.
         int4 rec = h1;
         if (G > 1 && len > 1) {                    // single-sample tasks (most of them) go straight from the header to the rows
-            const int4 r = p.recs[start + min(g, len - 1)];
+            const int4 r = p.recs[start + min(base + g, len - 1)];
             if (g != 0) rec = r;
         }
         int4 rec_n = rec;
-        if (iters > 1) rec_n = p.recs[start + min(g + G, len - 1)];
+        if (iters > 1) rec_n = p.recs[start + min(base + step + g, len - 1)];
         R rows = load_rows<T, VEC, LPR, KI, BPR>(p, rec, li, cok, bias);
         T pw1, pw2;
         adam_powers(p, gb + 1, pw1, pw2);
@@ -460,11 +638,11 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
         double loss = 0.0;
 
         for (int it = 0; it < iters; ++it) {
-            const int idx = it * G + g;
+            const int idx = base + it * step + g;
             const bool valid = idx < len;
             // issue the next position's loads before this position's arithmetic (wave-uniform conditions)
             int4 rec_nn = rec_n;
-            if (it + 2 < iters) rec_nn = p.recs[start + min(idx + 2 * G, len - 1)];
+            if (it + 2 < iters) rec_nn = p.recs[start + min(idx + 2 * step, len - 1)];
             R rows_n = rows;
             if (it + 1 < iters) rows_n = load_rows<T, VEC, LPR, KI, BPR>(p, rec_n, li, cok, bias);
 
@@ -476,6 +654,10 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
                 for (int e = 0; e < VEC; ++e)
                     dot += BPR ? rows.A[c].v[e] * (rows.B[c].v[e] - rows.C[c].v[e]) : rows.A[c].v[e] * rows.B[c].v[e];
             dot = group_sum<LPR>(dot);
+            if (p.ticks && it == 0) {
+                asm volatile("" ::"v"(dot));
+                tk2 = stamp();           // first rows have arrived
+            }
             if (BPR) {
                 const T x = dot;
                 const T sg = sigmoid_of_minus(x);
@@ -531,9 +713,32 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
             mu_term = li == 0 ? mu_term : (T)0;
             mu_term = wave_sum(mu_term);
         }
-        if (li == 0 && loss != 0.0) p.loss_slots[wv * 4 + g] += loss;      // (wavefront, group) slots are private
+        // (wavefront, group) slots are private; an atomic without return value instead of load + add + store keeps a
+        // dependent memory round trip out of the tail of the wavefront
+        if (li == 0 && loss != 0.0) atomicAdd(&p.loss_slots[wv * 4 + g], loss);
+        if (p.ticks) tk3 = stamp();      // list done
+        if (wide) {                      // the four quarters meet in LDS and are summed in quarter order by the first
+            if (g == 0) {
+#pragma unroll
+                for (int c = 0; c < KI; ++c)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) s_wide[part][(c * VEC + e) * LPR + li] = acc[c].v[e];
+                if (li == 0) s_wide_bias[part] = bias_acc;
+            }
+            __syncthreads();
+            if (part == 0 && g == 0) {
+#pragma unroll
+                for (int c = 0; c < KI; ++c)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const int at = (c * VEC + e) * LPR + li;
+                        acc[c].v[e] = ((s_wide[0][at] + s_wide[1][at]) + s_wide[2][at]) + s_wide[3][at];
+                    }
+                bias_acc = ((s_wide_bias[0] + s_wide_bias[1]) + s_wide_bias[2]) + s_wide_bias[3];
+            }
+        }
         // _apply_minibatch_updates_to_latent_factors (.pyx:770-829): mean over batch_size (NOT over the row's count)
-        if (g == 0) {
+        if (g == 0 && (!wide || part == 0)) {
             const bool is_item = entry >= p.n_users;
             const int row = is_item ? entry - p.n_users : entry;
             T *Wn = (is_item ? (own_par ? p.V0 : p.V1) : (own_par ? p.U0 : p.U1)) + (size_t)row * k;
@@ -570,6 +775,11 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
             const T sum = (s_mu[0] + s_mu[1]) + (s_mu[2] + s_mu[3]);
             if (sum != (T)0) atomicAdd(&p.mu_acc[(int)(gb % 3) * 16 + (blockIdx.x & 15)], sum);
         }
+    }
+    if (p.ticks && lane == 0 && wv < p.tasks_per_batch) {
+        unsigned long long *o = p.ticks + (size_t)wv * 8;
+        o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = stamp(); o[5] = (unsigned long long)(h0.y & LEN_MASK);
+        o[6] = blockIdx.x; o[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // XCC_ID
     }
 }
 
@@ -825,6 +1035,10 @@ struct mi355rec_mf {
     DeviceBuffer<int> slots, slots_sorted, head, head_scan, task_at, batch_count;
     DeviceBuffer<unsigned char> spar, cub_tmp;
     DeviceBuffer<TaskHeader> tasks;
+    DeviceBuffer<unsigned> touched;         // fast schedule: (row, mini-batch) bitmap
+    DeviceBuffer<int> sorted_slot, qtask;
+    bool fast_schedule = false;
+    DeviceBuffer<unsigned long long> ticks;
     DeviceBuffer<int4> recs;
     size_t cub_tmp_bytes = 0;
     size_t stream_capacity = 0;      // samples
@@ -894,6 +1108,7 @@ void fill_params(mi355rec_mf *h, MfParams<T> &p) {
     p.su = h->su.ptr; p.si = h->si.ptr; p.sj = h->sj.ptr; p.sr = h->sr.ptr;
     p.samples_per_epoch = batches_per_epoch(h) * (long long)c.batch_size;
     p.tasks = h->tasks.ptr; p.recs = h->recs.ptr;
+    p.ticks = h->ticks.ptr;
 }
 
 // ---- kernel selection -------------------------------------------------------------------------------------------------
@@ -925,8 +1140,62 @@ void launch_sampler(mi355rec_mf *h, const MfParams<T> &p) {
     else hipLaunchKernelGGL((mf_sample_kernel<MI355REC_MF_FUNK_SVD, T>), dim3(grid), dim3(256), 0, h->stream, p);
 }
 
+int pow2_at_least(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// samples of a task's list a wavefront of the mini-batch kernel works on at a time (must mirror launch_batch)
+int samples_in_flight(const mi355rec_mf *h) {
+    const int vec = h->f64 ? 2 : 4, k = h->k;
+    if (k % vec != 0 || k / vec > 128) return 1;
+    const int chunks = k / vec;
+    return chunks <= 16 ? 4 : (chunks <= 32 ? 2 : 1);
+}
+
+bool fast_schedule_fits(const mi355rec_mf *h, long long n_batches) {
+    const int tpb = per_sample(h) * h->cfg.batch_size;
+    return !getenv("MI355REC_MF_GENERAL_SCHEDULE") && n_batches <= FAST_MAX_BATCHES && tpb <= FAST_MAX_SLOTS &&
+           bits_for((unsigned long long)h->n_users + h->n_items) + bits_for((unsigned long long)std::max(tpb, SCHED_THREADS)) <= 31 &&
+           (h->k % (h->f64 ? 2 : 4) == 0 && h->k / (h->f64 ? 2 : 4) <= 128);    // the any-k kernel does not split wide lists
+}
+
+void enqueue_fast_schedule(mi355rec_mf *h, long long n_samples, long long n_batches) {
+    hipStream_t s = h->stream;
+    FastSchedParams f{};
+    f.n_samples = n_samples;
+    f.per = per_sample(h);
+    f.n_users = h->n_users;
+    f.n_entries = h->n_users + h->n_items;
+    f.batch_size = h->cfg.batch_size;
+    f.tasks_per_batch = f.per * h->cfg.batch_size;
+    f.np = std::max(SCHED_THREADS, pow2_at_least(f.tasks_per_batch));
+    f.slot_bits = bits_for((unsigned long long)f.np);
+    f.words = FAST_MAX_BATCHES / 32;
+    f.group = samples_in_flight(h);
+    f.su = h->su.ptr; f.si = h->si.ptr; f.sj = h->sj.ptr; f.sr = h->sr.ptr;
+    f.touched = h->touched.ptr; f.par = h->par.ptr;
+    f.sorted_slot = h->sorted_slot.ptr; f.qtask = h->qtask.ptr;
+    f.tasks = h->tasks.ptr; f.recs = h->recs.ptr;
+    const size_t lds = sizeof(unsigned) * (3 * (size_t)f.np + 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mf_sched_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(unsigned) * (3 * (size_t)FAST_MAX_SLOTS + 1))));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(mf_sched_sort_kernel, dim3((unsigned)n_batches), dim3(SCHED_THREADS), lds, s, f);
+    hipLaunchKernelGGL(mf_sched_emit_kernel, dim3(div_up(f.tasks_per_batch, 256), (unsigned)n_batches), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(mf_sched_finish_kernel, dim3(div_up(f.n_entries, 256)), dim3(256), 0, s, f);
+}
+
 // Stream buffers -> tasks (all on the handle's stream, no host synchronisation: capturable).
 void enqueue_schedule(mi355rec_mf *h, long long n_samples, long long n_batches) {
+    if (h->fast_schedule && fast_schedule_fits(h, n_batches)) {
+        enqueue_fast_schedule(h, n_samples, n_batches);
+        return;
+    }
     hipStream_t s = h->stream;
     const int per = per_sample(h);
     const long long n = n_samples * per;
@@ -1040,7 +1309,7 @@ void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batche
             h->keys.alloc(n); h->keys_sorted.alloc(n);
             h->slots.alloc(n); h->slots_sorted.alloc(n);
             h->head.alloc(n); h->head_scan.alloc(n); h->task_at.alloc(n);
-            h->spar.alloc(n); h->recs.alloc(n);
+            h->spar.alloc(n);
             size_t sort_bytes = 0, scan_bytes = 0;
             MI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, h->keys.ptr, h->keys_sorted.ptr, h->slots.ptr,
                                                       h->slots_sorted.ptr, (int)n, 0, 64, h->stream));
@@ -1054,8 +1323,17 @@ void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batche
             (void)hipGraphExecDestroy(h->epoch_graph);
             h->epoch_graph = nullptr;
         }
+        const size_t tpb = (size_t)per_sample(h) * h->cfg.batch_size;
         h->batch_count.alloc((size_t)n_batches);
-        h->tasks.alloc((size_t)n_batches * per_sample(h) * h->cfg.batch_size);
+        h->tasks.alloc((size_t)(n_batches + 1) * tpb);
+        MI_HIP(hipMemsetAsync(h->tasks.ptr, 0, sizeof(TaskHeader) * (size_t)(n_batches + 1) * tpb, h->stream));
+        h->recs.alloc((size_t)n_batches * tpb);          // records of batch b start at b * tpb in both schedule paths
+        h->fast_schedule = fast_schedule_fits(h, 1);
+        if (h->fast_schedule) {
+            h->sorted_slot.alloc((size_t)n_batches * tpb);
+            h->qtask.alloc((size_t)n_batches * tpb);
+            if (!h->touched.ptr) h->touched.alloc_zero(((size_t)h->n_users + h->n_items) * (FAST_MAX_BATCHES / 32), h->stream);
+        }
         h->batch_capacity = n_batches;
     }
 }
@@ -1247,6 +1525,7 @@ extern "C" int mi355rec_mf_create(mi355rec_mf_t *out, const mi355rec_mf_config *
         h->data.upload(data, h->nnz, s);
         if (h->f64) create_typed<double>(h.get(), U0, V0); else create_typed<float>(h.get(), U0, V0);
         h->par.alloc_zero((size_t)n_users + n_items, s);
+        if (getenv("MI355REC_MF_TICKS")) h->ticks.alloc_zero((size_t)per_sample(h.get()) * cfg->batch_size * 8, s);
         h->loss_slots.alloc_zero((size_t)per_sample(h.get()) * cfg->batch_size * 4, s);
         h->state.alloc_zero(1, s);
         {   // Adam's running beta powers start at beta^1 (.pyx:217-218)
@@ -1322,6 +1601,18 @@ extern "C" int mi355rec_mf_set_profiling(mi355rec_mf_t h, int32_t max_timed_laun
         ensure_device();
         h->max_timed = max_timed_launches;
         h->dispatch_timers.reserve(max_timed_launches);
+    });
+}
+
+extern "C" int mi355rec_mf_get_phase_ticks(mi355rec_mf_t h, uint64_t *out, int64_t cap, int64_t *n) {
+    return guarded([&] {
+        MI_REQUIRE(h && n, "NULL argument");
+        ensure_device();
+        *n = (int64_t)h->ticks.count;
+        if (out && cap > 0) {
+            MI_HIP(hipStreamSynchronize(h->stream));
+            MI_HIP(hipMemcpy(out, h->ticks.ptr, sizeof(uint64_t) * std::min<size_t>((size_t)cap, h->ticks.count), hipMemcpyDeviceToHost));
+        }
     });
 }
 

@@ -260,7 +260,27 @@ def test_native_graph_epochs_equal_oracle(gpu, mode):
         assert_factor_parity(dev.get_ITEM_factors(), orc.get_ITEM_factors(), mode, "V")
         assert_factor_parity(dev.get_ITEM_bias(), orc.get_ITEM_bias(), mode, "bi")
         assert abs(float(dev.get_GLOBAL_bias()) - float(orc.get_GLOBAL_bias())) < 1e-5 * max(1.0, abs(float(orc.get_GLOBAL_bias())))
-    np.testing.assert_array_equal(a.get_ITEM_factors(), b.get_ITEM_factors())      # the device path is deterministic
+
+
+@pytest.mark.parametrize("algorithm", ["MF_BPR", "FUNK_SVD"])
+def test_schedule_paths_agree(gpu, algorithm, monkeypatch):
+    """The in-LDS schedule (with wide tasks for long lists) and the general radix-sort schedule build the same tasks."""
+    X = named_urm("ml1m", "real", scale=0.3)
+    kw = dict(n_factors=64, algorithm_name=algorithm, batch_size=1500, random_seed=8, sgd_mode="sgd", learning_rate=0.02,
+              user_reg=0.01, positive_reg=0.01, negative_reg=0.02, use_bias=algorithm == "FUNK_SVD", bias_reg=0.01)
+    out = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("MI355REC_MF_GENERAL_SCHEDULE", "1")
+        dev = MatrixFactorization_MI355X_Epoch(X, **kw)
+        dev.epochIteration_Cython(3)
+        out.append((dev.get_USER_factors(), dev.get_ITEM_factors(), dev.last_epoch_samples()))
+        dev.close()
+    np.testing.assert_array_equal(out[0][2][0], out[1][2][0])
+    for a, b in zip(out[0][:2], out[1][:2]):
+        assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max()
+    counts = np.bincount(out[0][2][1][:1500])
+    assert counts.max() > 8, "the case must contain a list long enough to be split over a workgroup (more than 2 rounds of 4)"
 
 
 def test_fp32_state_is_available_for_adaptive_modes(gpu):
