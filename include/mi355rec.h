@@ -202,6 +202,9 @@ typedef struct {
     double  learning_rate, li_reg, lj_reg;
     double  gamma, beta_1, beta_2;
     uint64_t random_seed;
+    int32_t precision;       /* MI355REC_F32 / MI355REC_F64: type of S and of the per-item optimiser cells on the device (the reference
+                              * is double throughout; float32 holds 1e-5 for plain sgd, the adaptive optimisers need float64) */
+    int32_t reserved;
 } mi355rec_slim_config;
 
 typedef struct mi355rec_slim *mi355rec_slim_t;
@@ -212,6 +215,8 @@ int mi355rec_slim_create(mi355rec_slim_t *out, const mi355rec_slim_config *cfg, 
  * strictly ordered samples per epoch, drawn on the device and executed in stream order. */
 int mi355rec_slim_run_epochs(mi355rec_slim_t h, int32_t n_epochs);
 int mi355rec_slim_run_samples(mi355rec_slim_t h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t n);
+/* The (u, i, j) stream of the LAST epoch drawn on the device (at most cap entries; *n = its length, 0 before the first epoch). */
+int mi355rec_slim_get_last_samples(mi355rec_slim_t h, int32_t *u, int32_t *i, int32_t *j, int64_t cap, int64_t *n);
 /* get_S: diagonal zeroed, per-ROW top-K (.pyx:343-391): nbr_idx/nbr_val[(row) * topK ...], descending,
  * (-1, 0) padded, zeros never emitted. */
 int mi355rec_slim_get_S_topk(mi355rec_slim_t h, int32_t topK, int32_t *nbr_idx, float *nbr_val);

@@ -5,76 +5,106 @@
 // adaptive_gradient :398-436, get_S :343-391.  The wrapper hard-codes batch_size = 1
 // (SLIM_BPR/Cython/SLIM_BPR_Cython.py:140), so an epoch is n_users + 1 STRICTLY ORDERED SGD steps.
 //
-// Design.  S is a dense fp32 n_items x n_items matrix in HBM (2.86 GB at ML-20M shape; the
-// symmetric store uses the lower triangle of the same array).  The sample stream of an epoch does not depend on
-// S and is drawn up front by one kernel.  Exact sequential semantics are kept in two ways:
-//   dense (asymmetric) store  step t touches only rows i_t and j_t of S and the two per-item optimiser cells, so
-//                             steps with disjoint {i, j} commute.  The host level-schedules the epoch (level(t) =
-//                             1 + max level of the previous step on row i_t / j_t) and every level runs as one
-//                             launch, one 64-lane wavefront per step;
-//   symmetric store           cell (r, c) aliases (c, r): conflicts are per cell, and almost every step touches a
-//                             popular row through its profile.  This round the epoch runs as ONE persistent
-//                             workgroup executing the steps in order, 1024 lanes across the profile.
-// Both are gather/scatter of 4-byte cells (2 L_u reads + 2 L_u writes per step): HBM/L2-latency bound, no MFMA.
+// Design.  S is a dense n_items x n_items matrix in HBM (the symmetric store uses the lower triangle
+// of the same array); float32 for plain sgd, float64 (like the reference) for adagrad / rmsprop / adam.  The sample stream
+// does not depend on S, so WHICH earlier step a step has to wait for is known before the first step runs:
+//   dense store       step t owns rows i_t and j_t (and the optimiser cells of items i_t, j_t).  Per item, steps take
+//                     numbered tickets in stream order (a device sort of the 2n (item, step) pairs gives every step its two
+//                     ticket numbers);
+//   symmetric store   cell (r, c) aliases (c, r), so ownership is per CELL: the cells every step touches are sorted by
+//                     (cell, step) and each one is handed the step that touched it last (`pred`).
+// Round 1 turned the row dependencies into ~1250 host-scheduled level launches per epoch (dense, 10.6 us per level) and ran
+// the symmetric store on ONE workgroup.  Here ONE persistent kernel executes the whole stream as a dataflow graph: workgroups
+// pull steps from an in-order queue; a step waits until its two tickets come up (and, symmetric, until the last writer of
+// each of its cells is done), does its 2 L_u gathers, the two per-item optimiser steps, its 2 L_u scattered writes, drains
+// them, and passes the tickets on.  Cells are only ever accessed with agent-scope atomic loads / write-through stores
+// (L2 / MALL coherent across XCDs); waiting is a relaxed poll of ONE word per lane.  Because the queue is in order, a
+// waiting step only ever waits for steps that are already running: no deadlock, whatever the residency.
+// Exact sequential semantics; the critical path is the chain of steps on the most popular item, not launches.
+// 4-byte gathers / scatters, no dense contraction: no MFMA.
 #include "common.h"
 #include "sampling.cuh"
 #include "topk.cuh"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <memory>
-#include <numeric>
 
 namespace mi355rec {
 namespace {
 
+constexpr int LOSS_SLOTS = 1024;
+constexpr int FLOW_THREADS = 256;
+constexpr int FLOW_REGS = 4;                          // profile entries per thread whose cells stay in registers between the passes
+constexpr unsigned NO_CELL = 0xFFFFFFFFu;             // (the diagonal is read but never written: it orders nothing)
+constexpr long long SPIN_LIMIT_TICKS = 2000000000ll;  // 20 s of the 100 MHz wall clock: a stuck hand-off aborts instead of hanging
+
+template <class T>
 struct SlimParams {
     int n_users, n_items, symmetric, sgd_mode;
-    float lr, li_reg, lj_reg, gamma, beta_1, beta_2, one_m_gamma, one_m_beta_1, one_m_beta_2;
+    T lr, li_reg, lj_reg, gamma, beta_1, beta_2, one_m_gamma, one_m_beta_1, one_m_beta_2;
+    double beta_1_d, beta_2_d;
     unsigned long long seed;
     const int *indptr, *indices;
-    float *S;
-    float *c1, *c2;                 // per-ITEM optimiser scalars (.pyx:177-181): cache / first moment, second moment
+    T *S;
+    T *c1, *c2;                     // per-ITEM optimiser scalars (.pyx:177-181): cache / first moment, second moment
     const int *su, *si, *sj;        // sample stream of the call
-    const float *pw1, *pw2;         // 1 - beta^t for every step of the stream (running product formed on the host in double)
-    const int *order;               // level schedule: step ids grouped by level
+    const int *seq;                 // [2 n_steps] ticket numbers of step t on item i_t (2t) and item j_t (2t + 1)
+    const long long *cellptr;       // symmetric: first cell slot of every step (2 per profile entry: row i, row j)
+    const int *pred;                // symmetric: per cell slot, the step that touched the cell last (-1: nobody in this call)
+    int *ticket;                    // [n_items] steps of this call completed on the item
+    int *done;                      // symmetric: [n_steps]
+    int *queue;                     // [0] next step, [1] abort flag
     double *loss_slots;             // [LOSS_SLOTS]
     long long epoch;                // RNG counter base
-    int n_steps;
+    long long steps_before;         // steps executed before this call (Adam's beta^t, .pyx:313-317)
+    int n_steps, use_tickets;
 };
-constexpr int LOSS_SLOTS = 1024;
 
-__device__ __forceinline__ size_t cell_at(const SlimParams &p, int r, int c) {
+template <class T> __device__ __forceinline__ T aload(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void astore(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <class P> __device__ __forceinline__ size_t cell_at(const P &p, int r, int c) {
     // Triangular_Matrix.get_value/add_value (.pyx:1290-1330): in symmetric mode (r, c) with c > r lives at (c, r)
     if (p.symmetric && c > r) { const int t = r; r = c; c = t; }
     return (size_t)r * p.n_items + c;
 }
 
-// per-ITEM adaptive step (.pyx:398-436); pw1 / pw2 = 1 - beta^t of this step
-__device__ __forceinline__ float slim_adapt(const SlimParams &p, float g, int item, float pw1, float pw2) {
+__device__ __forceinline__ float root(float x) { return sqrtf(x); }
+__device__ __forceinline__ double root(double x) { return sqrt(x); }
+__device__ __forceinline__ float sigmoid_of_minus(float x) { return 1.f / (1.f + __expf(x)); }
+__device__ __forceinline__ double sigmoid_of_minus(double x) { return 1.0 / (1.0 + exp(x)); }
+
+// per-ITEM adaptive step (.pyx:398-436); pw1 / pw2 = 1 - beta^t of this step.  The cells travel between workgroups with the
+// item's ticket, hence the agent-scope accesses.
+template <class T>
+__device__ __forceinline__ T slim_adapt(const SlimParams<T> &p, T g, int item, T pw1, T pw2) {
     switch (p.sgd_mode) {
         case MI355REC_ADAGRAD: {
-            const float c = p.c1[item] + g * g;
-            p.c1[item] = c;
-            return g / (sqrtf(c) + 1e-8f);
+            const T c = aload(&p.c1[item]) + g * g;
+            astore(&p.c1[item], c);
+            return g / (root(c) + (T)1e-8);
         }
         case MI355REC_RMSPROP: {
-            const float c = p.c1[item] * p.gamma + p.one_m_gamma * (g * g);
-            p.c1[item] = c;
-            return g / (sqrtf(c) + 1e-8f);
+            const T c = aload(&p.c1[item]) * p.gamma + p.one_m_gamma * (g * g);
+            astore(&p.c1[item], c);
+            return g / (root(c) + (T)1e-8);
         }
         case MI355REC_ADAM: {
-            const float m1 = p.c1[item] * p.beta_1 + p.one_m_beta_1 * g;
-            const float m2 = p.c2[item] * p.beta_2 + p.one_m_beta_2 * (g * g);
-            p.c1[item] = m1;
-            p.c2[item] = m2;
-            return (m1 / pw1) / (sqrtf(m2 / pw2) + 1e-8f);
+            const T m1 = aload(&p.c1[item]) * p.beta_1 + p.one_m_beta_1 * g;
+            const T m2 = aload(&p.c2[item]) * p.beta_2 + p.one_m_beta_2 * (g * g);
+            astore(&p.c1[item], m1);
+            astore(&p.c2[item], m2);
+            return (m1 / pw1) / (root(m2 / pw2) + (T)1e-8);
         }
         default:
             return g;
     }
 }
 
-__global__ __launch_bounds__(256) void slim_sample_kernel(SlimParams p, int *su, int *si, int *sj) {
+template <class T>
+__global__ __launch_bounds__(256) void slim_sample_kernel(SlimParams<T> p, int *su, int *si, int *sj) {
     const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (t >= p.n_steps) return;
     int u, i, j;
@@ -84,119 +114,271 @@ __global__ __launch_bounds__(256) void slim_sample_kernel(SlimParams p, int *su,
     sj[t] = j;
 }
 
-// One SGD step (.pyx:243-317) by LANES cooperating lanes; `reduce` sums x over them.
-template <int LANES, class Reduce>
-__device__ __forceinline__ void slim_step(const SlimParams &p, int t, int lane, Reduce reduce) {
-    const int u = p.su[t], i = p.si[t], j = p.sj[t];
-    const int rs = p.indptr[u], re = p.indptr[u + 1];
-    float x = 0.f;
-    for (int q = rs + lane; q < re; q += LANES) {
-        const int s = p.indices[q];
-        x += p.S[cell_at(p, i, s)] - p.S[cell_at(p, j, s)];
-    }
-    float gi = 0.f, gj = 0.f;
-    x = reduce(x, i, j, gi, gj, t);          // also turns x into the two per-item steps (one lane updates the caches)
-    for (int q = rs + lane; q < re; q += LANES) {
-        const int s = p.indices[q];
-        if (s != i) {
-            float *c = &p.S[cell_at(p, i, s)];
-            const float v = *c;
-            *c = v + p.lr * (gi - p.li_reg * v);
-        }
-        if (s != j) {
-            float *c = &p.S[cell_at(p, j, s)];
-            const float v = *c;
-            *c = v - p.lr * (gj - p.lj_reg * v);
-        }
-    }
+// ---- dependencies of the stream ---------------------------------------------------------------------------------------
+struct DepParams {
+    int n_steps, n_items;
+    const int *indptr, *indices, *su, *si, *sj;
+    unsigned long long *keys;       // item pass: item << 32 | step;  cell pass: cell << 32 | step
+    int *vals;                      // item pass: 2 step + role;      cell pass: cell slot
+    const unsigned long long *keys_sorted;
+    const int *vals_sorted;
+    int *seq;
+    int *len2;                      // 2 L_u per step
+    const long long *cellptr;
+    int *pred;
+    long long n_cells;
+};
+
+__global__ __launch_bounds__(256) void slim_item_keys_kernel(const DepParams d) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= d.n_steps) return;
+    d.keys[2 * t] = ((unsigned long long)d.si[t] << 32) | (unsigned)t;
+    d.vals[2 * t] = 2 * t;
+    d.keys[2 * t + 1] = ((unsigned long long)d.sj[t] << 32) | (unsigned)t;
+    d.vals[2 * t + 1] = 2 * t + 1;
+    d.len2[t] = 2 * (d.indptr[d.su[t] + 1] - d.indptr[d.su[t]]);
 }
 
-// Level-parallel path (dense store): one wavefront per step of the level.
-__global__ __launch_bounds__(256) void slim_level_kernel(const SlimParams p, int first, int count) {
+// ticket number = how many earlier steps of the stream touch the same item = position inside the item's run
+__global__ __launch_bounds__(256) void slim_seq_kernel(const DepParams d) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= 2 * d.n_steps) return;
+    const unsigned long long first_key = d.keys_sorted[q] & 0xFFFFFFFF00000000ull;
+    int lo = 0, hi = q;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (d.keys_sorted[mid] < first_key) lo = mid + 1; else hi = mid;
+    }
+    d.seq[d.vals_sorted[q]] = q - lo;
+}
+
+// symmetric store: one wavefront per step lists the canonical cells of its two rows
+__global__ __launch_bounds__(256) void slim_cell_keys_kernel(const DepParams d) {
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= count) return;
-    const int t = p.order[first + w];
-    auto reduce = [&](float x, int i, int j, float &gi, float &gj, int step) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        const float g = 1.f / (1.f + __expf(x));
-        float a = 0.f, b = 0.f;
-        if (lane == 0) {
-            a = slim_adapt(p, g, i, p.pw1[step], p.pw2[step]);     // item i first, then j, as .pyx:267-268
-            b = slim_adapt(p, g, j, p.pw1[step], p.pw2[step]);
-            atomicAdd(&p.loss_slots[step & (LOSS_SLOTS - 1)], (double)x * x);   // steps of one level may share a slot
-        }
-        gi = __shfl(a, 0);
-        gj = __shfl(b, 0);
-        return x;
-    };
-    slim_step<64>(p, t, lane, reduce);
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= d.n_steps) return;
+    const int u = d.su[t], i = d.si[t], j = d.sj[t];
+    const int rs = d.indptr[u], L = d.indptr[u + 1] - rs;
+    const long long cp = d.cellptr[t];
+    for (int idx = lane; idx < L; idx += 64) {
+        const int s = d.indices[rs + idx];
+        const unsigned ci = s == i ? NO_CELL : (unsigned)((size_t)max(i, s) * d.n_items + min(i, s));
+        const unsigned cj = s == j ? NO_CELL : (unsigned)((size_t)max(j, s) * d.n_items + min(j, s));
+        d.keys[cp + 2 * idx] = ((unsigned long long)ci << 32) | (unsigned)t;
+        d.vals[cp + 2 * idx] = (int)(cp + 2 * idx);
+        d.keys[cp + 2 * idx + 1] = ((unsigned long long)cj << 32) | (unsigned)t;
+        d.vals[cp + 2 * idx + 1] = (int)(cp + 2 * idx + 1);
+    }
 }
 
-// Level-parallel path, one WORKGROUP per step: a level lasts as long as its longest profile, and a single wavefront
-// walks a 2000-item profile in 2 x 32 dependent gather rounds (~1 us each); THREADS lanes do it in a few.
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void slim_level_wg_kernel(const SlimParams p, int first, int count) {
-    __shared__ float s_part[THREADS / 64];
-    __shared__ float s_g[2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if ((int)blockIdx.x >= count) return;
-    const int t = p.order[first + blockIdx.x];
-    auto reduce = [&](float x, int i, int j, float &gi, float &gj, int step) {
+__global__ __launch_bounds__(256) void slim_pred_kernel(const DepParams d) {
+    const long long q = blockIdx.x * 256ll + threadIdx.x;
+    if (q >= d.n_cells) return;
+    const unsigned long long key = d.keys_sorted[q];
+    const unsigned cell = (unsigned)(key >> 32);
+    int pred = -1;
+    if (q > 0 && cell != NO_CELL) {
+        const unsigned long long before = d.keys_sorted[q - 1];
+        if ((unsigned)(before >> 32) == cell) pred = (int)(before & 0xFFFFFFFFull);
+    }
+    d.pred[d.vals_sorted[q]] = pred;
+}
+
+// ---- the stream ---------------------------------------------------------------------------------------------------------
+// relaxed poll of one word; a hand-off that does not arrive within SPIN_LIMIT_TICKS raises the abort flag (everybody stops
+// waiting, the call fails) instead of hanging the device
+template <class T>
+__device__ __forceinline__ void wait_for(const SlimParams<T> &p, const int *word, int want, bool exact) {
+    unsigned polls = 0;
+    long long t0 = 0;
+    for (;;) {
+        const int v = aload(word);
+        if (exact ? v == want : v != 0) return;
+        __builtin_amdgcn_s_sleep(2);
+        if ((++polls & 255u) == 0) {
+            if (aload(&p.queue[1])) return;
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > SPIN_LIMIT_TICKS) { astore(&p.queue[1], 1); return; }
+        }
+    }
+}
+
+template <class T>
+__device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <class T, bool SYM>
+__global__ __launch_bounds__(FLOW_THREADS) void slim_flow_kernel(const SlimParams<T> p) {
+    __shared__ int s_t;
+    __shared__ T s_part[FLOW_THREADS / 64];
+    __shared__ T s_g[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (;;) {
+        if (tid == 0) s_t = atomicAdd(&p.queue[0], 1);         // in-order queue: everything this step can wait for is already running
+        __syncthreads();
+        const int t = s_t;
+        if (t >= p.n_steps) break;
+        const int u = p.su[t], i = p.si[t], j = p.sj[t];
+        const int rs = p.indptr[u], L = p.indptr[u + 1] - rs;
+        const long long cp = SYM ? p.cellptr[t] : 0;
+        // profile entries and (symmetric) the last writers of their cells do not depend on anybody: fetch them before waiting
+        int sv[FLOW_REGS], pa[FLOW_REGS], pb[FLOW_REGS];
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) {
+            const int idx = tid + r * FLOW_THREADS;
+            sv[r] = idx < L ? p.indices[rs + idx] : 0;
+            pa[r] = SYM && idx < L ? p.pred[cp + 2 * idx] : -1;
+            pb[r] = SYM && idx < L ? p.pred[cp + 2 * idx + 1] : -1;
+        }
+        if (p.use_tickets) {
+            if (tid < 2) wait_for(p, &p.ticket[tid ? j : i], p.seq[2 * t + tid], true);
+            __syncthreads();
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        // x_uij over the profile (.pyx:243-260)
+        T x = (T)0;
+        T va[FLOW_REGS], vb[FLOW_REGS];
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) {
+            const int idx = tid + r * FLOW_THREADS;
+            va[r] = (T)0;
+            vb[r] = (T)0;
+            if (idx < L) {
+                if (SYM) {
+                    if (pa[r] >= 0) wait_for(p, &p.done[pa[r]], 1, false);
+                    if (pb[r] >= 0) wait_for(p, &p.done[pb[r]], 1, false);
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                }
+                va[r] = aload(&p.S[cell_at(p, i, sv[r])]);
+                vb[r] = aload(&p.S[cell_at(p, j, sv[r])]);
+                x += va[r] - vb[r];
+            }
+        }
+        for (int idx = tid + FLOW_REGS * FLOW_THREADS; idx < L; idx += FLOW_THREADS) {    // profiles longer than 1024
+            const int s = p.indices[rs + idx];
+            if (SYM) {
+                const int a = p.pred[cp + 2 * idx], b = p.pred[cp + 2 * idx + 1];
+                if (a >= 0) wait_for(p, &p.done[a], 1, false);
+                if (b >= 0) wait_for(p, &p.done[b], 1, false);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            }
+            x += aload(&p.S[cell_at(p, i, s)]) - aload(&p.S[cell_at(p, j, s)]);
+        }
+        x = wave_sum(x);
         if (lane == 0) s_part[wave] = x;
         __syncthreads();
         if (tid == 0) {
-            float tot = 0.f;
-            for (int w = 0; w < THREADS / 64; ++w) tot += s_part[w];
-            const float g = 1.f / (1.f + __expf(tot));
-            s_g[0] = slim_adapt(p, g, i, p.pw1[step], p.pw2[step]);     // item i first, then j, as .pyx:267-268
-            s_g[1] = slim_adapt(p, g, j, p.pw1[step], p.pw2[step]);
-            atomicAdd(&p.loss_slots[step & (LOSS_SLOTS - 1)], (double)tot * tot);   // steps of one level may share a slot
+            T tot = (T)0;
+#pragma unroll
+            for (int w = 0; w < FLOW_THREADS / 64; ++w) tot += s_part[w];
+            const T g = sigmoid_of_minus(tot);                         // .pyx:263
+            T pw1 = (T)1, pw2 = (T)1;
+            if (p.sgd_mode == MI355REC_ADAM) {
+                const double tt = (double)(p.steps_before + t + 1);
+                pw1 = (T)(1.0 - pow(p.beta_1_d, tt));
+                pw2 = (T)(1.0 - pow(p.beta_2_d, tt));
+            }
+            s_g[0] = slim_adapt(p, g, i, pw1, pw2);                    // item i first, then j, as .pyx:267-268
+            s_g[1] = slim_adapt(p, g, j, pw1, pw2);
+            atomicAdd(&p.loss_slots[t & (LOSS_SLOTS - 1)], (double)tot * (double)tot);
         }
         __syncthreads();
-        gi = s_g[0];
-        gj = s_g[1];
-        return x;
-    };
-    slim_step<THREADS>(p, t, tid, reduce);
+        const T gi = s_g[0], gj = s_g[1];
+        // the two rows move (.pyx:271-309); write-through stores
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) {
+            const int idx = tid + r * FLOW_THREADS;
+            if (idx < L) {
+                const int s = sv[r];
+                if (s != i) astore(&p.S[cell_at(p, i, s)], va[r] + p.lr * (gi - p.li_reg * va[r]));
+                if (s != j) astore(&p.S[cell_at(p, j, s)], vb[r] - p.lr * (gj - p.lj_reg * vb[r]));
+            }
+        }
+        for (int idx = tid + FLOW_REGS * FLOW_THREADS; idx < L; idx += FLOW_THREADS) {
+            const int s = p.indices[rs + idx];
+            if (s != i) {
+                T *c = &p.S[cell_at(p, i, s)];
+                const T v = aload(c);
+                astore(c, v + p.lr * (gi - p.li_reg * v));
+            }
+            if (s != j) {
+                T *c = &p.S[cell_at(p, j, s)];
+                const T v = aload(c);
+                astore(c, v - p.lr * (gj - p.lj_reg * v));
+            }
+        }
+        // publish: every storing wavefront drains its write-through stores, then ONE lane passes the tickets on
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (p.use_tickets) {
+                astore(&p.ticket[i], p.seq[2 * t] + 1);
+                astore(&p.ticket[j], p.seq[2 * t + 1] + 1);
+            }
+            if (SYM) astore(&p.done[t], 1);
+        }
+    }
 }
 
-// Ordered path (any store): one workgroup runs steps [0, n_steps) one after the other.
-__global__ __launch_bounds__(1024) void slim_ordered_kernel(const SlimParams p) {
-    __shared__ float s_part[16];
-    __shared__ float s_g[2];
+// Fallback (symmetric store with more than 65 535 items: cell ids no longer fit the 32-bit sort key): one workgroup runs
+// the steps one after the other.
+template <class T>
+__global__ __launch_bounds__(1024) void slim_ordered_kernel(const SlimParams<T> p) {
+    __shared__ T s_part[16];
+    __shared__ T s_g[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int t = 0; t < p.n_steps; ++t) {
-        auto reduce = [&](float x, int i, int j, float &gi, float &gj, int step) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-            if (lane == 0) s_part[wave] = x;
-            __syncthreads();
-            if (tid == 0) {
-                float tot = 0.f;
-                for (int w = 0; w < 16; ++w) tot += s_part[w];
-                const float g = 1.f / (1.f + __expf(tot));
-                s_g[0] = slim_adapt(p, g, i, p.pw1[step], p.pw2[step]);
-                s_g[1] = slim_adapt(p, g, j, p.pw1[step], p.pw2[step]);
-                p.loss_slots[step & (LOSS_SLOTS - 1)] += (double)tot * tot;
+        const int u = p.su[t], i = p.si[t], j = p.sj[t];
+        const int rs = p.indptr[u], re = p.indptr[u + 1];
+        T x = (T)0;
+        for (int q = rs + tid; q < re; q += 1024) {
+            const int s = p.indices[q];
+            x += p.S[cell_at(p, i, s)] - p.S[cell_at(p, j, s)];
+        }
+        x = wave_sum(x);
+        if (lane == 0) s_part[wave] = x;
+        __syncthreads();
+        if (tid == 0) {
+            T tot = (T)0;
+            for (int w = 0; w < 16; ++w) tot += s_part[w];
+            const T g = sigmoid_of_minus(tot);
+            T pw1 = (T)1, pw2 = (T)1;
+            if (p.sgd_mode == MI355REC_ADAM) {
+                const double tt = (double)(p.steps_before + t + 1);
+                pw1 = (T)(1.0 - pow(p.beta_1_d, tt));
+                pw2 = (T)(1.0 - pow(p.beta_2_d, tt));
             }
-            __syncthreads();
-            gi = s_g[0];
-            gj = s_g[1];
-            return x;
-        };
-        slim_step<1024>(p, t, tid, reduce);
+            s_g[0] = slim_adapt(p, g, i, pw1, pw2);
+            s_g[1] = slim_adapt(p, g, j, pw1, pw2);
+            p.loss_slots[t & (LOSS_SLOTS - 1)] += (double)tot * (double)tot;
+        }
+        __syncthreads();
+        const T gi = s_g[0], gj = s_g[1];
+        for (int q = rs + tid; q < re; q += 1024) {
+            const int s = p.indices[q];
+            if (s != i) {
+                T *c = &p.S[cell_at(p, i, s)];
+                const T v = *c;
+                *c = v + p.lr * (gi - p.li_reg * v);
+            }
+            if (s != j) {
+                T *c = &p.S[cell_at(p, j, s)];
+                const T v = *c;
+                *c = v - p.lr * (gj - p.lj_reg * v);
+            }
+        }
         __threadfence_block();       // the next step of this workgroup must read what this one wrote
         __syncthreads();
     }
 }
 
 // get_S (.pyx:343-391): row r of S with the diagonal zeroed (symmetric store mirrored), then the per-row top-K.
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void slim_topk_kernel(const SlimParams p, int topK, int n_pad, int *out_idx,
+template <class T, int THREADS>
+__global__ __launch_bounds__(THREADS) void slim_topk_kernel(const SlimParams<T> p, int topK, int n_pad, int *out_idx,
                                                             float *out_val) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *acc = smem;
@@ -209,7 +391,7 @@ __global__ __launch_bounds__(THREADS) void slim_topk_kernel(const SlimParams p, 
         __syncthreads();
         uint32_t npos = 0, nneg = 0;
         for (int c = tid; c < p.n_items; c += THREADS) {
-            const float v = c == r ? 0.f : p.S[cell_at(p, r, c)];
+            const float v = c == r ? 0.f : (float)p.S[cell_at(p, r, c)];
             acc[c] = v;
             npos += v > 0.f;
             nneg += v < 0.f;
@@ -232,11 +414,12 @@ __global__ __launch_bounds__(THREADS) void slim_topk_kernel(const SlimParams p, 
     }
 }
 
-__global__ void slim_dense_kernel(const SlimParams p, float *out) {
+template <class T>
+__global__ void slim_dense_kernel(const SlimParams<T> p, float *out) {
     const size_t n = (size_t)p.n_items;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n * n; e += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(e / n), c = (int)(e % n);
-        out[e] = r == c ? 0.f : p.S[cell_at(p, r, c)];
+        out[e] = r == c ? 0.f : (float)p.S[cell_at(p, r, c)];
     }
 }
 
@@ -248,19 +431,18 @@ using namespace mi355rec;
 struct mi355rec_slim {
     mi355rec_slim_config cfg{};
     int n_users = 0, n_items = 0;
+    bool f64 = false;
     size_t nnz = 0;
     hipStream_t stream = nullptr;
     StreamTimer call_timer;
     DispatchTimers dispatch_timers;
-    DeviceBuffer<int> indptr, indices, su, si, sj, order;
-    DeviceBuffer<float> S, c1, c2, pw1, pw2;
+    DeviceBuffer<int> indptr, indices, su, si, sj, seq, len2, ticket, done, queue, vals, vals_sorted, pred;
+    DeviceBuffer<long long> cellptr;
+    DeviceBuffer<unsigned long long> keys, keys_sorted;
+    DeviceBuffer<unsigned char> S, c1, c2, cub_tmp;     // S, c1, c2: float or double by `f64`
     DeviceBuffer<double> loss_slots;
-    size_t stream_capacity = 0;
+    size_t stream_capacity = 0, cell_capacity = 0;
     long long steps_done = 0, epochs_done = 0;
-    double beta_1_power = 0, beta_2_power = 0;       // running products, like the reference's beta_*_power_t
-    std::vector<int> h_u, h_i, h_j, h_order, h_level_ptr, last_level;
-    std::vector<int> indptr_host;
-    std::vector<float> h_pw1, h_pw2;
     std::vector<double> h_loss;
     mi355rec_stats stats{};
 
@@ -274,90 +456,121 @@ struct mi355rec_slim {
 
 namespace {
 
-void fill_params(mi355rec_slim *h, SlimParams &p) {
+template <class T>
+void fill_params(mi355rec_slim *h, SlimParams<T> &p) {
     const auto &c = h->cfg;
     p.n_users = h->n_users; p.n_items = h->n_items; p.symmetric = c.symmetric; p.sgd_mode = c.sgd_mode;
-    p.lr = (float)c.learning_rate; p.li_reg = (float)c.li_reg; p.lj_reg = (float)c.lj_reg;
-    p.gamma = (float)c.gamma; p.beta_1 = (float)c.beta_1; p.beta_2 = (float)c.beta_2;
-    p.one_m_gamma = (float)(1.0 - c.gamma); p.one_m_beta_1 = (float)(1.0 - c.beta_1); p.one_m_beta_2 = (float)(1.0 - c.beta_2);
+    p.lr = (T)c.learning_rate; p.li_reg = (T)c.li_reg; p.lj_reg = (T)c.lj_reg;
+    p.gamma = (T)c.gamma; p.beta_1 = (T)c.beta_1; p.beta_2 = (T)c.beta_2;
+    p.one_m_gamma = (T)(1.0 - c.gamma); p.one_m_beta_1 = (T)(1.0 - c.beta_1); p.one_m_beta_2 = (T)(1.0 - c.beta_2);
+    p.beta_1_d = c.beta_1; p.beta_2_d = c.beta_2;
     p.seed = c.random_seed;
     p.indptr = h->indptr.ptr; p.indices = h->indices.ptr;
-    p.S = h->S.ptr; p.c1 = h->c1.ptr; p.c2 = h->c2.ptr;
+    p.S = reinterpret_cast<T *>(h->S.ptr); p.c1 = reinterpret_cast<T *>(h->c1.ptr); p.c2 = reinterpret_cast<T *>(h->c2.ptr);
     p.su = h->su.ptr; p.si = h->si.ptr; p.sj = h->sj.ptr;
-    p.pw1 = h->pw1.ptr; p.pw2 = h->pw2.ptr;
-    p.order = h->order.ptr;
+    p.seq = h->seq.ptr; p.cellptr = h->cellptr.ptr; p.pred = h->pred.ptr;
+    p.ticket = h->ticket.ptr; p.done = h->done.ptr; p.queue = h->queue.ptr;
     p.loss_slots = h->loss_slots.ptr;
     p.epoch = h->epochs_done;
+    p.steps_before = h->steps_done;
     p.n_steps = 0;
+    p.use_tickets = 1;
+}
+
+bool flow_supported(const mi355rec_slim *h) {
+    return !(h->cfg.symmetric && h->n_items > 65535) && !getenv("MI355REC_SLIM_ORDERED");
 }
 
 void ensure_capacity(mi355rec_slim *h, size_t n) {
     if (h->stream_capacity >= n) return;
-    h->su.alloc(n); h->si.alloc(n); h->sj.alloc(n); h->order.alloc(n);
-    h->pw1.alloc(n); h->pw2.alloc(n);
+    h->su.alloc(n); h->si.alloc(n); h->sj.alloc(n);
+    h->seq.alloc(2 * n); h->len2.alloc(n + 1); h->done.alloc(n); h->cellptr.alloc(n + 1);
     h->stream_capacity = n;
 }
 
-// Runs the steps currently in su/si/sj (n of them) exactly in order; host copies of the stream are in h_u/h_i/h_j.
+void ensure_sort_capacity(mi355rec_slim *h, size_t n) {
+    if (h->cell_capacity >= n) return;
+    h->keys.alloc(n); h->keys_sorted.alloc(n); h->vals.alloc(n); h->vals_sorted.alloc(n); h->pred.alloc(n);
+    size_t sort_bytes = 0, scan_bytes = 0;
+    MI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr, h->vals_sorted.ptr,
+                                              (int)n, 0, 64, h->stream));
+    MI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, h->len2.ptr, h->cellptr.ptr, (int)h->stream_capacity + 1, h->stream));
+    h->cub_tmp.alloc(std::max(sort_bytes, scan_bytes) + 256);
+    h->cell_capacity = n;
+}
+
+int bits_for(unsigned long long n_values) {
+    int b = 1;
+    while (b < 63 && (1ull << b) < n_values) ++b;
+    return b;
+}
+
+// Runs the n steps currently in su/si/sj exactly in stream order.
+template <class T>
 void run_stream(mi355rec_slim *h, int n, double &sum_profile) {
     hipStream_t s = h->stream;
-    // Adam's bias corrections: the reference multiplies beta_power by beta after every sample (.pyx:313-317)
-    h->h_pw1.resize(n); h->h_pw2.resize(n);
-    for (int t = 0; t < n; ++t) {
-        h->h_pw1[t] = (float)(1.0 - h->beta_1_power);
-        h->h_pw2[t] = (float)(1.0 - h->beta_2_power);
-        if (h->cfg.sgd_mode == MI355REC_ADAM) {
-            h->beta_1_power *= h->cfg.beta_1;
-            h->beta_2_power *= h->cfg.beta_2;
-        }
-    }
-    MI_HIP(hipMemcpyAsync(h->pw1.ptr, h->h_pw1.data(), sizeof(float) * n, hipMemcpyHostToDevice, s));
-    MI_HIP(hipMemcpyAsync(h->pw2.ptr, h->h_pw2.data(), sizeof(float) * n, hipMemcpyHostToDevice, s));
-    SlimParams p{};
+    SlimParams<T> p{};
     fill_params(h, p);
     p.n_steps = n;
-    for (int t = 0; t < n; ++t) sum_profile += h->indptr_host[h->h_u[t] + 1] - h->indptr_host[h->h_u[t]];
-    if (h->cfg.symmetric) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool sym = h->cfg.symmetric != 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!flow_supported(h)) {
         h->dispatch_timers.next(e0, e1, 1 << 30);
-        hipExtLaunchKernelGGL(slim_ordered_kernel, dim3(1), dim3(1024), 0, s, e0, e1, 0, p);
+        hipExtLaunchKernelGGL(slim_ordered_kernel<T>, dim3(1), dim3(1024), 0, s, e0, e1, 0, p);
         h->stats.n_launches += 1;
-    } else {
-        // level schedule: a step may run once the previous steps on its two rows are done
-        h->last_level.assign(h->n_items, 0);
-        std::vector<int> level(n);
-        int n_levels = 0;
-        for (int t = 0; t < n; ++t) {
-            const int l = 1 + std::max(h->last_level[h->h_i[t]], h->last_level[h->h_j[t]]);
-            level[t] = l;
-            h->last_level[h->h_i[t]] = l;
-            h->last_level[h->h_j[t]] = l;
-            n_levels = std::max(n_levels, l);
-        }
-        h->h_level_ptr.assign(n_levels + 2, 0);
-        for (int t = 0; t < n; ++t) h->h_level_ptr[level[t] + 1]++;
-        for (int l = 1; l <= n_levels + 1; ++l) h->h_level_ptr[l] += h->h_level_ptr[l - 1];
-        h->h_order.resize(n);
-        std::vector<int> cursor(h->h_level_ptr.begin(), h->h_level_ptr.end());
-        for (int t = 0; t < n; ++t) h->h_order[cursor[level[t]]++] = t;     // stable: stream order inside a level
-        MI_HIP(hipMemcpyAsync(h->order.ptr, h->h_order.data(), sizeof(int) * n, hipMemcpyHostToDevice, s));
-        const bool wave_levels = getenv("MI355REC_SLIM_WAVE_LEVELS") != nullptr;
-        for (int l = 1; l <= n_levels; ++l) {
-            const int first = h->h_level_ptr[l], count = h->h_level_ptr[l + 1] - first;
-            if (count == 0) continue;
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            const bool timed = h->dispatch_timers.next(e0, e1, 512);
-            if (wave_levels) {       // MI355REC_SLIM_WAVE_LEVELS=1: the one-wavefront-per-step kernel (comparison / diagnostics)
-                if (timed) hipExtLaunchKernelGGL(slim_level_kernel, dim3(div_up(count, 4)), dim3(256), 0, s, e0, e1, 0, p, first, count);
-                else hipLaunchKernelGGL(slim_level_kernel, dim3(div_up(count, 4)), dim3(256), 0, s, p, first, count);
-            } else {
-                if (timed) hipExtLaunchKernelGGL(slim_level_wg_kernel<512>, dim3(count), dim3(512), 0, s, e0, e1, 0, p, first, count);
-                else hipLaunchKernelGGL(slim_level_wg_kernel<512>, dim3(count), dim3(512), 0, s, p, first, count);
-            }
-            h->stats.n_launches += 1;
-        }
+        MI_HIP(hipGetLastError());
+        h->steps_done += n;
+        return;
     }
+    // ticket numbers: sort the 2n (item, step) pairs, position inside the item's run
+    ensure_sort_capacity(h, std::max<size_t>(2 * (size_t)n, 1024));
+    DepParams d{};
+    d.n_steps = n; d.n_items = h->n_items;
+    d.indptr = h->indptr.ptr; d.indices = h->indices.ptr; d.su = h->su.ptr; d.si = h->si.ptr; d.sj = h->sj.ptr;
+    d.keys = h->keys.ptr; d.vals = h->vals.ptr; d.keys_sorted = h->keys_sorted.ptr; d.vals_sorted = h->vals_sorted.ptr;
+    d.seq = h->seq.ptr; d.len2 = h->len2.ptr; d.cellptr = h->cellptr.ptr; d.pred = h->pred.ptr;
+    hipLaunchKernelGGL(slim_item_keys_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d);
+    size_t bytes = h->cub_tmp.count;
+    MI_HIP(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr, h->vals_sorted.ptr,
+                                              2 * n, 0, 32 + bits_for((unsigned long long)h->n_items), s));
+    hipLaunchKernelGGL(slim_seq_kernel, dim3(div_up(2 * n, 256)), dim3(256), 0, s, d);
+    // profile lengths -> cell slots (also the algorithmic byte count of the call)
+    MI_HIP(hipMemsetAsync(h->len2.ptr + n, 0, sizeof(int), s));
+    bytes = h->cub_tmp.count;
+    MI_HIP(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp.ptr, bytes, h->len2.ptr, h->cellptr.ptr, n + 1, s));
+    long long n_cells = 0;
+    MI_HIP(hipMemcpyAsync(&n_cells, h->cellptr.ptr + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    sum_profile += 0.5 * (double)n_cells;
+    if (sym) {
+        MI_REQUIRE(n_cells < (1ll << 31), "stream too long for the cell sort (%lld cells)", n_cells);
+        ensure_sort_capacity(h, (size_t)std::max<long long>(n_cells, 1024));
+        d.keys = h->keys.ptr; d.vals = h->vals.ptr; d.keys_sorted = h->keys_sorted.ptr; d.vals_sorted = h->vals_sorted.ptr;
+        d.pred = h->pred.ptr;
+        d.n_cells = n_cells;
+        hipLaunchKernelGGL(slim_cell_keys_kernel, dim3(div_up(n, 4)), dim3(256), 0, s, d);
+        bytes = h->cub_tmp.count;
+        MI_HIP(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr,
+                                                  h->vals_sorted.ptr, (int)n_cells, 0, 64, s));
+        hipLaunchKernelGGL(slim_pred_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, s, d);
+        fill_params(h, p);          // (the sort buffers may have been re-allocated)
+        p.n_steps = n;
+        MI_HIP(hipMemsetAsync(h->done.ptr, 0, sizeof(int) * (size_t)n, s));
+    }
+    // the symmetric store orders steps per cell; item tickets are then only needed for the per-item optimiser cells
+    p.use_tickets = !sym || h->cfg.sgd_mode != MI355REC_SGD;
+    MI_HIP(hipMemsetAsync(h->ticket.ptr, 0, sizeof(int) * (size_t)h->n_items, s));
+    MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(int) * 2, s));
+    const int grid = std::min(n, multiprocessor_count() * 4);
+    h->dispatch_timers.next(e0, e1, 1 << 30);
+    if (sym) hipExtLaunchKernelGGL((slim_flow_kernel<T, true>), dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p);
+    else hipExtLaunchKernelGGL((slim_flow_kernel<T, false>), dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p);
+    h->stats.n_launches += 1;
     MI_HIP(hipGetLastError());
+    int flags[2] = {0, 0};
+    MI_HIP(hipMemcpyAsync(flags, h->queue.ptr, sizeof(flags), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    if (flags[1]) fail(MI355REC_E_HIP, "SLIM-BPR: a hand-off between steps did not arrive (dataflow kernel aborted)");
     h->steps_done += n;
 }
 
@@ -384,6 +597,60 @@ void end_call(mi355rec_slim *h, long long n_steps, double sum_profile) {
     h->stats.loss = loss;
 }
 
+template <class T>
+void run_epochs_typed(mi355rec_slim *h, int n_epochs) {
+    const int n = h->n_users + 1;                            // totalNumberOfBatch with batch_size 1 (.pyx:215)
+    ensure_capacity(h, (size_t)n);
+    begin_call(h);
+    double sum_profile = 0;
+    for (int e = 0; e < n_epochs; ++e) {
+        SlimParams<T> p{};
+        fill_params(h, p);
+        p.n_steps = n;
+        hipLaunchKernelGGL(slim_sample_kernel<T>, dim3(div_up(n, 256)), dim3(256), 0, h->stream, p, h->su.ptr, h->si.ptr, h->sj.ptr);
+        run_stream<T>(h, n, sum_profile);
+        h->epochs_done += 1;
+    }
+    end_call(h, (long long)n * n_epochs, sum_profile);
+}
+
+template <class T>
+void get_topk_typed(mi355rec_slim *h, int topK, int *nbr_idx, float *nbr_val) {
+    const int n_pad = (h->n_items + 3) & ~3;
+    const size_t lds = (size_t)n_pad * 4 + (size_t)AUX_WORDS * 4;
+    if (lds + 2048 > 160 * 1024)
+        fail(MI355REC_E_UNSUPPORTED, "n_items = %d: a row of S does not fit the 160 KiB LDS for the top-K selection", h->n_items);
+    DeviceBuffer<int> d_idx;
+    DeviceBuffer<float> d_val;
+    const size_t n_out = (size_t)h->n_items * topK;
+    d_idx.alloc(n_out);
+    d_val.alloc(n_out);
+    SlimParams<T> p{};
+    fill_params(h, p);
+    auto k = slim_topk_kernel<T, 1024>;
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds + 2048))));
+    hipLaunchKernelGGL(k, dim3(std::min(h->n_items, multiprocessor_count() * per_cu)), dim3(1024), lds, h->stream, p, topK,
+                       n_pad, d_idx.ptr, d_val.ptr);
+    MI_HIP(hipGetLastError());
+    d_idx.download(nbr_idx, n_out, h->stream);
+    d_val.download(nbr_val, n_out, h->stream);
+    MI_HIP(hipStreamSynchronize(h->stream));
+}
+
+template <class T>
+void get_dense_typed(mi355rec_slim *h, float *S) {
+    const size_t n2 = (size_t)h->n_items * h->n_items;
+    DeviceBuffer<float> out;
+    out.alloc(n2);
+    SlimParams<T> p{};
+    fill_params(h, p);
+    hipLaunchKernelGGL(slim_dense_kernel<T>, dim3((unsigned)std::min<size_t>((n2 + 255) / 256, 8192)), dim3(256), 0, h->stream, p, out.ptr);
+    MI_HIP(hipGetLastError());
+    out.download(S, n2, h->stream);
+    MI_HIP(hipStreamSynchronize(h->stream));
+}
+
 }  // namespace
 
 extern "C" int mi355rec_slim_create(mi355rec_slim_t *out, const mi355rec_slim_config *cfg, int32_t n_users, int32_t n_items,
@@ -393,26 +660,28 @@ extern "C" int mi355rec_slim_create(mi355rec_slim_t *out, const mi355rec_slim_co
         MI_REQUIRE(n_users > 0 && n_items > 0, "empty URM");
         MI_REQUIRE(cfg->sgd_mode >= MI355REC_SGD && cfg->sgd_mode <= MI355REC_ADAM, "Value for 'sgd_mode' not recognized (%d)",
                    cfg->sgd_mode);
+        MI_REQUIRE(cfg->precision == MI355REC_F32 || cfg->precision == MI355REC_F64, "precision must be MI355REC_F32 or MI355REC_F64");
         ensure_device();
         std::unique_ptr<mi355rec_slim> h(new mi355rec_slim());
         h->cfg = *cfg;
         h->n_users = n_users;
         h->n_items = n_items;
+        h->f64 = cfg->precision == MI355REC_F64;
         h->nnz = (size_t)indptr[n_users];
         MI_REQUIRE(h->nnz > 0, "URM has no interactions");
         MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->call_timer.init();
-        h->dispatch_timers.reserve(512);
+        h->dispatch_timers.reserve(64);
         hipStream_t s = h->stream;
+        const size_t ts = h->f64 ? sizeof(double) : sizeof(float);
         h->indptr.upload(indptr, (size_t)n_users + 1, s);
         h->indices.upload(indices, h->nnz, s);
-        h->indptr_host.assign(indptr, indptr + n_users + 1);
-        h->S.alloc_zero((size_t)n_items * n_items, s);          // .pyx:129 / :1237-1254
-        h->c1.alloc_zero((size_t)n_items, s);
-        h->c2.alloc_zero((size_t)n_items, s);
+        h->S.alloc_zero((size_t)n_items * n_items * ts, s);          // .pyx:129 / :1237-1254
+        h->c1.alloc_zero((size_t)n_items * ts, s);
+        h->c2.alloc_zero((size_t)n_items * ts, s);
+        h->ticket.alloc_zero((size_t)n_items, s);
+        h->queue.alloc_zero(2, s);
         h->loss_slots.alloc_zero(LOSS_SLOTS, s);
-        h->beta_1_power = cfg->beta_1;                           // starts at beta^1 (.pyx:163-164)
-        h->beta_2_power = cfg->beta_2;
         MI_HIP(hipStreamSynchronize(s));
         *out = h.release();
     });
@@ -423,24 +692,7 @@ extern "C" int mi355rec_slim_run_epochs(mi355rec_slim_t h, int32_t n_epochs) {
         MI_REQUIRE(h, "NULL handle");
         MI_REQUIRE(n_epochs >= 0, "n_epochs must be >= 0");
         ensure_device();
-        const int n = h->n_users + 1;                            // totalNumberOfBatch with batch_size 1 (.pyx:215)
-        ensure_capacity(h, (size_t)n);
-        begin_call(h);
-        double sum_profile = 0;
-        for (int e = 0; e < n_epochs; ++e) {
-            SlimParams p{};
-            fill_params(h, p);
-            p.n_steps = n;
-            hipLaunchKernelGGL(slim_sample_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, p, h->su.ptr, h->si.ptr, h->sj.ptr);
-            h->h_u.resize(n); h->h_i.resize(n); h->h_j.resize(n);
-            h->su.download(h->h_u.data(), n, h->stream);
-            h->si.download(h->h_i.data(), n, h->stream);
-            h->sj.download(h->h_j.data(), n, h->stream);
-            MI_HIP(hipStreamSynchronize(h->stream));
-            run_stream(h, n, sum_profile);
-            h->epochs_done += 1;
-        }
-        end_call(h, (long long)n * n_epochs, sum_profile);
+        if (h->f64) run_epochs_typed<double>(h, n_epochs); else run_epochs_typed<float>(h, n_epochs);
     });
 }
 
@@ -452,17 +704,30 @@ extern "C" int mi355rec_slim_run_samples(mi355rec_slim_t h, const int32_t *u, co
         if (n == 0) return;
         ensure_capacity(h, (size_t)n);
         hipStream_t s = h->stream;
-        MI_HIP(hipMemcpyAsync(h->su.ptr, u, sizeof(int) * n, hipMemcpyHostToDevice, s));
-        MI_HIP(hipMemcpyAsync(h->si.ptr, i, sizeof(int) * n, hipMemcpyHostToDevice, s));
-        MI_HIP(hipMemcpyAsync(h->sj.ptr, j, sizeof(int) * n, hipMemcpyHostToDevice, s));
-        h->h_u.assign(u, u + n); h->h_i.assign(i, i + n); h->h_j.assign(j, j + n);
         for (int64_t t = 0; t < n; ++t)
             MI_REQUIRE(u[t] >= 0 && u[t] < h->n_users && i[t] >= 0 && i[t] < h->n_items && j[t] >= 0 && j[t] < h->n_items,
                        "sample %lld out of range", (long long)t);
+        MI_HIP(hipMemcpyAsync(h->su.ptr, u, sizeof(int) * n, hipMemcpyHostToDevice, s));
+        MI_HIP(hipMemcpyAsync(h->si.ptr, i, sizeof(int) * n, hipMemcpyHostToDevice, s));
+        MI_HIP(hipMemcpyAsync(h->sj.ptr, j, sizeof(int) * n, hipMemcpyHostToDevice, s));
         begin_call(h);
         double sum_profile = 0;
-        run_stream(h, (int)n, sum_profile);
+        if (h->f64) run_stream<double>(h, (int)n, sum_profile); else run_stream<float>(h, (int)n, sum_profile);
         end_call(h, n, sum_profile);
+    });
+}
+
+extern "C" int mi355rec_slim_get_last_samples(mi355rec_slim_t h, int32_t *u, int32_t *i, int32_t *j, int64_t cap, int64_t *n) {
+    return guarded([&] {
+        MI_REQUIRE(h && n, "NULL argument");
+        ensure_device();
+        const int64_t have = h->epochs_done > 0 ? h->n_users + 1 : 0;
+        *n = have;
+        const size_t m = (size_t)std::min<int64_t>(cap, have);
+        if (u) h->su.download(u, m, h->stream);
+        if (i) h->si.download(i, m, h->stream);
+        if (j) h->sj.download(j, m, h->stream);
+        MI_HIP(hipStreamSynchronize(h->stream));
     });
 }
 
@@ -473,26 +738,7 @@ extern "C" int mi355rec_slim_get_S_topk(mi355rec_slim_t h, int32_t topK, int32_t
         ensure_device();
         topK = std::min(topK, h->n_items);
         if (topK > MAX_TOPK) fail(MI355REC_E_UNSUPPORTED, "topK = %d exceeds the in-LDS selection limit of %d", topK, MAX_TOPK);
-        const int n_pad = (h->n_items + 3) & ~3;
-        const size_t lds = (size_t)n_pad * 4 + (size_t)AUX_WORDS * 4;
-        if (lds + 2048 > 160 * 1024)
-            fail(MI355REC_E_UNSUPPORTED, "n_items = %d: a row of S does not fit the 160 KiB LDS for the top-K selection", h->n_items);
-        DeviceBuffer<int> d_idx;
-        DeviceBuffer<float> d_val;
-        const size_t n_out = (size_t)h->n_items * topK;
-        d_idx.alloc(n_out);
-        d_val.alloc(n_out);
-        SlimParams p{};
-        fill_params(h, p);
-        auto k = slim_topk_kernel<1024>;
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds + 2048))));
-        hipLaunchKernelGGL(k, dim3(std::min(h->n_items, multiprocessor_count() * per_cu)), dim3(1024), lds, h->stream, p, topK,
-                           n_pad, d_idx.ptr, d_val.ptr);
-        MI_HIP(hipGetLastError());
-        d_idx.download(nbr_idx, n_out, h->stream);
-        d_val.download(nbr_val, n_out, h->stream);
-        MI_HIP(hipStreamSynchronize(h->stream));
+        if (h->f64) get_topk_typed<double>(h, topK, nbr_idx, nbr_val); else get_topk_typed<float>(h, topK, nbr_idx, nbr_val);
     });
 }
 
@@ -500,15 +746,7 @@ extern "C" int mi355rec_slim_get_S_dense(mi355rec_slim_t h, float *S) {
     return guarded([&] {
         MI_REQUIRE(h && S, "NULL argument");
         ensure_device();
-        const size_t n2 = (size_t)h->n_items * h->n_items;
-        DeviceBuffer<float> out;
-        out.alloc(n2);
-        SlimParams p{};
-        fill_params(h, p);
-        hipLaunchKernelGGL(slim_dense_kernel, dim3((unsigned)std::min<size_t>((n2 + 255) / 256, 8192)), dim3(256), 0, h->stream, p, out.ptr);
-        MI_HIP(hipGetLastError());
-        out.download(S, n2, h->stream);
-        MI_HIP(hipStreamSynchronize(h->stream));
+        if (h->f64) get_dense_typed<double>(h, S); else get_dense_typed<float>(h, S);
     });
 }
 

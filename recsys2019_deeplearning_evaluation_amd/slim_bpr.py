@@ -31,7 +31,7 @@ def rows_slabs_to_csr(nbr_idx, nbr_val, n):
 class SLIM_BPR_MI355X_Epoch:
     def __init__(self, URM_mask, train_with_sparse_weights=False, final_model_sparse_weights=True, learning_rate=0.01,
                  li_reg=0.0, lj_reg=0.0, batch_size=1, topK=150, symmetric=True, verbose=False, random_seed=None,
-                 sgd_mode="adam", gamma=0.995, beta_1=0.9, beta_2=0.999):
+                 sgd_mode="adam", gamma=0.995, beta_1=0.9, beta_2=0.999, precision="auto"):
         if sgd_mode not in N.SGD_MODE_CODES:
             raise ValueError("Value for 'sgd_mode' not recognized. Acceptable values are {}, provided was '{}'".format(
                 list(N.SGD_MODE_CODES), sgd_mode))
@@ -39,6 +39,12 @@ class SLIM_BPR_MI355X_Epoch:
             raise NotImplementedError("SLIM_BPR: the sparse-tree training store is not on the MI355X device path")
         if batch_size != 1:
             raise NotImplementedError("SLIM_BPR: the reference wrapper always trains with batch_size=1; so does the device path")
+        if precision == "auto":         # float64 S and optimiser cells for the adaptive modes (the reference is double throughout)
+            precision = "fp32" if sgd_mode == "sgd" else "fp64"
+        if precision not in N.PRECISION_CODES:
+            raise ValueError("Value for 'precision' not recognized. Acceptable values are {}, provided was '{}'".format(
+                ["auto"] + list(N.PRECISION_CODES), precision))
+        self.precision = precision
         URM_mask = check_matrix(URM_mask, "csr")
         URM_mask = URM_mask.sorted_indices()
         self.n_users, self.n_items = URM_mask.shape
@@ -48,7 +54,7 @@ class SLIM_BPR_MI355X_Epoch:
         self.verbose = verbose
         seed = int(random_seed) if random_seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
         cfg = N.SlimConfig(int(self.symmetric), N.SGD_MODE_CODES[sgd_mode], learning_rate, li_reg, lj_reg, gamma, beta_1,
-                           beta_2, seed & (2 ** 64 - 1))
+                           beta_2, seed & (2 ** 64 - 1), N.PRECISION_CODES[precision], 0)
         indptr, indices = N.as_i32(URM_mask.indptr), N.as_i32(URM_mask.indices)
         self._lib = N.load()
         self._h = C.c_void_p()
@@ -79,6 +85,14 @@ class SLIM_BPR_MI355X_Epoch:
     def replay_samples(self, user, pos_item, neg_item):
         u, i, j = N.as_i32(user), N.as_i32(pos_item), N.as_i32(neg_item)
         N.check(self._lib.mi355rec_slim_run_samples(self._h, N.ptr(u), N.ptr(i), N.ptr(j), len(u)))
+
+    def last_epoch_samples(self):
+        """(user, pos_item, neg_item) drawn on the device during the last native epoch."""
+        n = C.c_int64(0)
+        N.check(self._lib.mi355rec_slim_get_last_samples(self._h, None, None, None, 0, C.byref(n)))
+        u = np.empty(n.value, np.int32); i = np.empty(n.value, np.int32); j = np.empty(n.value, np.int32)
+        N.check(self._lib.mi355rec_slim_get_last_samples(self._h, N.ptr(u), N.ptr(i), N.ptr(j), n.value, C.byref(n)))
+        return u, i, j
 
     def get_S_dense(self):
         S = np.empty((self.n_items, self.n_items), np.float32)
