@@ -421,6 +421,22 @@ class OracleSimilarity:
         idx, val = self.build_slabs(s, e)
         return slabs_to_csr(idx, val, s, n)
 
+    def compute_similarity_full_column_rule(self, start_col=None, end_col=None):
+        """The top-K rule of the reference's SECOND implementation, Compute_Similarity_Python.compute_similarity
+        (Base/Similarity/Compute_Similarity_Python.py:346-355): `(-column).argpartition(TopK-1)[0:TopK]` over the FULL column
+        -- zeros (untouched cells, the zeroed diagonal) compete with negative similarities -- then exact zeros are dropped.
+        Ties (NumPy introselect artefacts in the reference) go to the lower index here."""
+        s, e = self._range(start_col, end_col)
+        n = self.n_columns
+        vals, rows, cols = [], [], []
+        k = min(self.TopK, n)
+        for c in range(s, e):
+            w = self.column(c)[0]
+            order = np.lexsort((np.arange(n), -w))[:k]
+            order = order[w[order] != 0.0]
+            vals.extend(w[order]); rows.extend(order); cols.extend([c] * len(order))
+        return sps.csr_matrix((vals, (rows, cols)), shape=(n, n), dtype=np.float32)
+
     def build_slabs(self, start_col, end_col):
         ncol = end_col - start_col
         idx = np.empty((ncol, self.TopK), np.int32); val = np.empty((ncol, self.TopK), np.float32)

@@ -79,6 +79,23 @@ def main():
     out["cases"] = np.array(json.dumps(cases))
     np.savez_compressed(os.path.join(HERE, "similarity.npz"), **out)
 
+    # ---------------- top-K selection rule: Compute_Similarity_Python (pure-Python reference) vs the Cython class ----------------
+    # adjusted / pearson produce negative similarities.  Compute_Similarity_Python takes the K largest cells of the FULL column
+    # (zeros compete, then are dropped, Compute_Similarity_Python.py:346-355); the Cython class partitions a zero-padded array
+    # of the touched cells (.pyx:523-545), which picks padding entries (stale ids) as soon as fewer than K touched cells are
+    # non-negative.  Both outputs are stored, on tie-free data, so the tests can state exactly where they differ.
+    PYSIM = ref_loader.load_python_reference("Base.Similarity.Compute_Similarity_Python", "Compute_Similarity_Python")
+    Xk = small_urm(120, 45, 0.1, 23, real=True)
+    out = pack_csr("X", Xk)
+    cases = [dict(topK=12, shrink=2, normalize=True, similarity=sim) for sim in ("cosine", "adjusted", "pearson", "asymmetric")]
+    cases += [dict(topK=5, shrink=0, normalize=True, similarity="adjusted"), dict(topK=40, shrink=0, normalize=False, similarity="pearson")]
+    for n, kw in enumerate(cases):
+        out["python_%d" % n] = quiet(lambda: PYSIM(Xk, **kw).compute_similarity()).toarray().astype(np.float32)
+        out["cython_%d" % n] = quiet(lambda: SIM(Xk, **kw).compute_similarity()).toarray().astype(np.float32)
+        out["dense_%d" % n] = np.asarray(quiet(lambda: SIM(Xk, **dict(kw, topK=0)).compute_similarity()), dtype=np.float64)
+    out["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(HERE, "similarity_topk_rules.npz"), **out)
+
     # ---------------- BPR-MF / FunkSVD ----------------
     Xb = small_urm(70, 50, 0.15, 12, real=False)
     Xr = small_urm(70, 50, 0.15, 13, real=True)

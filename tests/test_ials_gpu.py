@@ -26,6 +26,14 @@ def test_golden_fixture(gpu):
         assert rel_err(U, z["U_%d" % n]) < RTOL
         assert rel_err(V, z["V_%d" % n]) < RTOL
         dev.close()
+        # the same case END TO END through the package's recommender: its own confidence scaling (ials.py) and its own draw of
+        # the initial item factors (same NumPy stream position as the reference's _init_factors, IALSRecommender.py:204-210)
+        from recsys2019_deeplearning_evaluation_amd import IALSRecommender
+        np.random.seed(404 + n)
+        rec = IALSRecommender(X, verbose=False)
+        rec.fit(epochs=case["epochs"], **kw)
+        assert rel_err(rec.USER_factors, z["U_%d" % n]) < RTOL
+        assert rel_err(rec.ITEM_factors, z["V_%d" % n]) < RTOL
 
 
 @pytest.mark.parametrize("k", [1, 5, 32, 33, 64, 100, 160, 161, 200, 224])

@@ -30,6 +30,42 @@ def test_similarity_oracle_c_topk_is_inside_reference_tie_class():
             np.testing.assert_allclose(np.sort(top[:, c]), np.sort(ref[:, c]), rtol=0, atol=0)
 
 
+def test_topk_rule_python_reference_vs_cython_reference():
+    """Where the reference's two implementations disagree, and which one this package follows.
+
+    Fixture: Compute_Similarity_Python and Compute_Similarity_Cython outputs on tie-free data whose adjusted / pearson
+    similarities are partly negative.  Statements checked, column by column:
+      1. the oracle's full-column rule (zeros compete, then are dropped) == Compute_Similarity_Python, indices AND values;
+      2. the Cython class equals it whenever at least min(K, touched) touched cells are positive (always, on non-negative data);
+      3. otherwise the Cython class has picked zero-padding entries of its partition array and read stale neighbour ids
+         (Compute_Similarity_Cython.pyx:523-545): its column then contains duplicates summed by the COO->CSR conversion or
+         extra negative cells -- it is NOT the K largest cells of the column.  The device follows rule 1."""
+    z, cases = load_golden("similarity_topk_rules")
+    X = unpack_csr(z, "X")
+    n = X.shape[1]
+    differing = 0
+    for k, kw in enumerate(cases):
+        py, cy, dense = z["python_%d" % k], z["cython_%d" % k], z["dense_%d" % k]
+        mine = O.OracleSimilarity(X, **kw).compute_similarity_full_column_rule().toarray()
+        assert ((mine != 0) == (py != 0)).all(), kw                                   # 1: same neighbours ...
+        atol = 1e-6 * np.abs(py).max()      # (the Python class works in float32, the Cython class and the oracle in float64)
+        np.testing.assert_allclose(mine, py, rtol=1e-6, atol=atol)                    #    ... same values
+        for c in range(n):
+            col = dense[:, c]
+            n_pos, n_touched = int((col > 0).sum()), int((col != 0).sum())
+            same = np.allclose(py[:, c], cy[:, c], rtol=1e-6, atol=atol)
+            if n_pos >= min(kw["topK"], n_touched):
+                assert same, (kw, c)                                                  # 2
+            elif not same:
+                differing += 1
+                support = np.flatnonzero(cy[:, c])
+                doubled = ~np.isclose(cy[support, c], dense[support, c], rtol=1e-5)   # duplicates summed by scipy
+                assert doubled.any() or (cy[:, c] < 0).any(), (kw, c)                 # 3
+        if kw["similarity"] in ("cosine", "asymmetric"):
+            np.testing.assert_allclose(py, cy, rtol=1e-6, atol=atol)                  # non-negative data: identical
+    assert differing >= 10            # the fixture really exercises the difference
+
+
 def test_mf_oracle_is_bit_exact_with_reference_outputs():
     z, cases = load_golden("matrix_factorization")
     mats = {"Xb": unpack_csr(z, "Xb"), "Xr": unpack_csr(z, "Xr")}
