@@ -11,8 +11,14 @@
 //                      rate) over K in LDS-staged chunks of 64; biases added in the epilogue.
 //   score_rank_kernel  one workgroup per user: the score row is pulled into LDS, seen / excluded items are set to -inf,
 //                      the same in-LDS radix-select + bitonic-sort top-K as the similarity build emits the ranking.
+//   wide ranking       catalogues whose score row does not fit LDS (> ~32 k items) and cutoffs above the in-LDS selection limit
+//                      (the reference's default cutoff=None ranks ALL items): rows stay in HBM, a filter kernel writes -inf,
+//                      one segmented radix sort (hipCUB, stable: ties keep the lower item id, like the in-LDS path) orders every
+//                      row, the first `cutoff` finite entries are the ranking.
 #include "common.h"
 #include "topk.cuh"
+
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <memory>
@@ -120,12 +126,81 @@ __global__ __launch_bounds__(THREADS) void score_rank_kernel(const RankParams p)
                              p.ranked + (size_t)b * p.cutoff, nullptr);
 }
 
+// ---- wide ranking: rows in HBM -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wide_filter_kernel(float *scores, int *ids, int n_items, const int *users, const int *seen_ptr,
+                                                          const int *seen_idx, const unsigned char *allowed, int remove_seen) {
+    const int b = blockIdx.y;
+    float *row = scores + (size_t)b * n_items;
+    int *id_row = ids + (size_t)b * n_items;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n_items; j += gridDim.x * 256) {
+        if (allowed && !allowed[j]) row[j] = -INFINITY;
+        id_row[j] = j;
+    }
+    if (remove_seen && blockIdx.x == 0) {      // a -inf store racing with the `allowed` -inf store of another block is the same value
+        const int u = users[b];
+        for (int q = seen_ptr[u] + threadIdx.x; q < seen_ptr[u + 1]; q += 256) row[seen_idx[q]] = -INFINITY;
+    }
+}
+
+__global__ __launch_bounds__(256) void wide_emit_kernel(const float *sorted_scores, const int *sorted_ids, int n_items, int cutoff,
+                                                        int *ranked) {
+    const int b = blockIdx.y;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < cutoff; r += gridDim.x * 256) {
+        const size_t at = (size_t)b * n_items + r;
+        ranked[(size_t)b * cutoff + r] = sorted_scores[at] > -INFINITY ? sorted_ids[at] : -1;
+    }
+}
+
+struct WideRanker {
+    DeviceBuffer<int> ids_in, ids_out, offsets;
+    DeviceBuffer<float> keys_out;
+    DeviceBuffer<unsigned char> tmp;
+    size_t capacity = 0;
+    int offsets_n = 0, offsets_items = 0;
+
+    // scores: [n][n_items] in HBM (unfiltered); ranked: [n][cutoff] on the device
+    void rank(hipStream_t s, float *scores, int n, int n_items, int cutoff, const int *users, const int *seen_ptr, const int *seen_idx,
+              const unsigned char *allowed, int remove_seen, int *ranked) {
+        const size_t total = (size_t)n * n_items;
+        if (total >= (1ull << 31)) fail(MI355REC_E_UNSUPPORTED, "user block of %d x %d scores exceeds the segmented sort (2^31 cells): use smaller blocks", n, n_items);
+        if (capacity < total) {
+            ids_in.alloc(total); ids_out.alloc(total); keys_out.alloc(total);
+            capacity = total;
+        }
+        if (offsets_n < n || offsets_items != n_items) {
+            std::vector<int> host((size_t)n + 1);
+            for (int b = 0; b <= n; ++b) host[b] = (int)((size_t)b * n_items);
+            offsets.alloc((size_t)n + 1);
+            MI_HIP(hipMemcpyAsync(offsets.ptr, host.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
+            MI_HIP(hipStreamSynchronize(s));
+            offsets_n = n; offsets_items = n_items;
+        }
+        hipLaunchKernelGGL(wide_filter_kernel, dim3(std::min(div_up(n_items, 256), 64), n), dim3(256), 0, s, scores, ids_in.ptr, n_items,
+                           users, seen_ptr, seen_idx, allowed, remove_seen);
+        size_t bytes = 0;
+        MI_HIP(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(nullptr, bytes, scores, keys_out.ptr, ids_in.ptr, ids_out.ptr, (int)total,
+                                                                     n, offsets.ptr, offsets.ptr + 1, 0, 32, s));
+        if (tmp.count < bytes) tmp.alloc(bytes + 256);
+        bytes = tmp.count;
+        MI_HIP(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(tmp.ptr, bytes, scores, keys_out.ptr, ids_in.ptr, ids_out.ptr, (int)total,
+                                                                     n, offsets.ptr, offsets.ptr + 1, 0, 32, s));
+        hipLaunchKernelGGL(wide_emit_kernel, dim3(std::min(div_up(cutoff, 256), 64), n), dim3(256), 0, s, keys_out.ptr, ids_out.ptr, n_items,
+                           cutoff, ranked);
+    }
+};
+
+bool fits_lds_rank(int n_items, int cutoff) {
+    const size_t lds = ((size_t)((n_items + 3) & ~3)) * 4 + (size_t)AUX_WORDS * 4 + 2048;
+    return lds <= 160 * 1024 && cutoff <= MAX_TOPK;
+}
+
 }  // namespace
 }  // namespace mi355rec
 
 using namespace mi355rec;
 
 struct mi355rec_scorer {
+    WideRanker wide;
     int n_users = 0, n_items = 0, k = 0, use_bias = 0;
     float mu = 0.f;
     hipStream_t stream = nullptr;
@@ -166,9 +241,6 @@ extern "C" int mi355rec_scorer_create(mi355rec_scorer_t *out, int32_t n_users, i
         MI_REQUIRE(out && U && V && seen_indptr && seen_indices, "NULL argument");
         MI_REQUIRE(n_users > 0 && n_items > 0 && n_factors > 0, "empty model");
         ensure_device();
-        const size_t lds = ((size_t)((n_items + 3) & ~3)) * 4 + (size_t)AUX_WORDS * 4 + 2048;
-        if (lds > 160 * 1024)
-            fail(MI355REC_E_UNSUPPORTED, "n_items = %d: a score row does not fit the 160 KiB LDS of the ranking kernel", n_items);
         std::unique_ptr<mi355rec_scorer> h(new mi355rec_scorer());
         h->n_users = n_users; h->n_items = n_items; h->k = n_factors; h->use_bias = use_bias != 0;
         MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -200,7 +272,6 @@ extern "C" int mi355rec_scorer_recommend(mi355rec_scorer_t h, const int32_t *use
         MI_REQUIRE(h && user_ids && ranked, "NULL argument");
         MI_REQUIRE(n > 0, "empty user batch");
         MI_REQUIRE(cutoff >= 1 && cutoff <= h->n_items, "cutoff must be in [1, n_items]");
-        if (cutoff > MAX_TOPK) fail(MI355REC_E_UNSUPPORTED, "cutoff = %d exceeds the in-LDS selection limit of %d", cutoff, MAX_TOPK);
         for (int i = 0; i < n; ++i)
             MI_REQUIRE(user_ids[i] >= 0 && user_ids[i] < h->n_users, "Cold users not allowed. Users in trained model are %d, "
                        "requested prediction for user %d", h->n_users, user_ids[i]);
@@ -218,16 +289,21 @@ extern "C" int mi355rec_scorer_recommend(mi355rec_scorer_t h, const int32_t *use
         sp.users = h->users.ptr; sp.n_batch = n; sp.scores = h->scores.ptr;
         hipExtLaunchKernelGGL(score_gemm_kernel, dim3(div_up(h->n_items, 128), div_up(n, 32)), dim3(256), 0, s, h->gemm_timer.t0,
                               h->gemm_timer.t1, 0, sp);
-        RankParams rp{};
-        rp.n_items = h->n_items; rp.n_pad = (h->n_items + 3) & ~3; rp.cutoff = cutoff;
-        rp.remove_seen = remove_seen;
-        rp.users = h->users.ptr; rp.seen_ptr = h->seen_ptr.ptr; rp.seen_idx = h->seen_idx.ptr;
-        rp.allowed = item_allowed ? h->allowed.ptr : nullptr;
-        rp.scores = h->scores.ptr; rp.ranked = h->ranked.ptr; rp.write_back = scores != nullptr;
-        const size_t lds = (size_t)rp.n_pad * 4 + (size_t)AUX_WORDS * 4;
-        auto k = score_rank_kernel<1024>;
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3(n), dim3(1024), lds, s, rp);
+        if (fits_lds_rank(h->n_items, cutoff)) {
+            RankParams rp{};
+            rp.n_items = h->n_items; rp.n_pad = (h->n_items + 3) & ~3; rp.cutoff = cutoff;
+            rp.remove_seen = remove_seen;
+            rp.users = h->users.ptr; rp.seen_ptr = h->seen_ptr.ptr; rp.seen_idx = h->seen_idx.ptr;
+            rp.allowed = item_allowed ? h->allowed.ptr : nullptr;
+            rp.scores = h->scores.ptr; rp.ranked = h->ranked.ptr; rp.write_back = scores != nullptr;
+            const size_t lds = (size_t)rp.n_pad * 4 + (size_t)AUX_WORDS * 4;
+            auto k = score_rank_kernel<1024>;
+            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k, dim3(n), dim3(1024), lds, s, rp);
+        } else {
+            h->wide.rank(s, h->scores.ptr, n, h->n_items, cutoff, h->users.ptr, h->seen_ptr.ptr, h->seen_idx.ptr,
+                         item_allowed ? h->allowed.ptr : nullptr, remove_seen, h->ranked.ptr);
+        }
         MI_HIP(hipGetLastError());
         h->call_timer.stop(s);
         h->ranked.download(ranked, (size_t)n * cutoff, s);
@@ -315,10 +391,23 @@ __global__ __launch_bounds__(THREADS) void spscore_kernel(const SpScoreParams p)
                              p.ranked + (size_t)b * p.cutoff, nullptr);
 }
 
+// the same accumulation with the score row in HBM (rows that do not fit LDS): global float atomics
+__global__ __launch_bounds__(1024) void spscore_wide_kernel(const SpScoreParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x, u = p.users[b];
+    float *row = p.scores + (size_t)b * p.n_out;
+    for (int q = p.a_ptr[u] + wave; q < p.a_ptr[u + 1]; q += 16) {
+        const int m = p.a_idx[q];
+        const float w = p.a_val[q];
+        for (int t = p.b_ptr[m] + lane; t < p.b_ptr[m + 1]; t += 64) atomicAdd(&row[p.b_idx[t]], w * p.b_val[t]);
+    }
+}
+
 }  // namespace
 }  // namespace mi355rec
 
 struct mi355rec_spscorer {
+    WideRanker wide;
     int n_users = 0, n_mid = 0, n_out = 0;
     hipStream_t stream = nullptr;
     StreamTimer timer;
@@ -343,9 +432,6 @@ extern "C" int mi355rec_spscorer_create(mi355rec_spscorer_t *out, int32_t n_user
         MI_REQUIRE(out && a_indptr && a_indices && a_data && b_indptr && b_indices && b_data && seen_indptr && seen_indices, "NULL argument");
         MI_REQUIRE(n_users > 0 && n_mid > 0 && n_out > 0, "empty model");
         ensure_device();
-        const size_t lds = ((size_t)((n_out + 3) & ~3)) * 4 + (size_t)AUX_WORDS * 4 + 2048;
-        if (lds > 160 * 1024)
-            fail(MI355REC_E_UNSUPPORTED, "n_items = %d: a score row does not fit the 160 KiB LDS of the ranking kernel", n_out);
         std::unique_ptr<mi355rec_spscorer> h(new mi355rec_spscorer());
         h->n_users = n_users; h->n_mid = n_mid; h->n_out = n_out;
         MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -373,13 +459,13 @@ extern "C" int mi355rec_spscorer_recommend(mi355rec_spscorer_t h, const int32_t 
         MI_REQUIRE(h && user_ids && ranked, "NULL argument");
         MI_REQUIRE(n > 0, "empty user batch");
         MI_REQUIRE(cutoff >= 1 && cutoff <= h->n_out, "cutoff must be in [1, n_items]");
-        if (cutoff > MAX_TOPK) fail(MI355REC_E_UNSUPPORTED, "cutoff = %d exceeds the in-LDS selection limit of %d", cutoff, MAX_TOPK);
         for (int i = 0; i < n; ++i) MI_REQUIRE(user_ids[i] >= 0 && user_ids[i] < h->n_users, "user id %d out of range", user_ids[i]);
         ensure_device();
         hipStream_t s = h->stream;
         if (h->users.count < (size_t)n) h->users.alloc(n);
         if (h->ranked.count < (size_t)n * cutoff) h->ranked.alloc((size_t)n * cutoff);
-        if (scores && h->scores.count < (size_t)n * h->n_out) h->scores.alloc((size_t)n * h->n_out);
+        const bool in_lds = fits_lds_rank(h->n_out, cutoff);
+        if ((scores || !in_lds) && h->scores.count < (size_t)n * h->n_out) h->scores.alloc((size_t)n * h->n_out);
         MI_HIP(hipMemcpyAsync(h->users.ptr, user_ids, sizeof(int) * n, hipMemcpyHostToDevice, s));
         if (item_allowed) MI_HIP(hipMemcpyAsync(h->allowed.ptr, item_allowed, h->n_out, hipMemcpyHostToDevice, s));
         SpScoreParams p{};
@@ -390,10 +476,17 @@ extern "C" int mi355rec_spscorer_recommend(mi355rec_spscorer_t h, const int32_t 
         p.users = h->users.ptr; p.seen_ptr = h->seen_ptr.ptr; p.seen_idx = h->seen_idx.ptr;
         p.allowed = item_allowed ? h->allowed.ptr : nullptr;
         p.scores = h->scores.ptr; p.ranked = h->ranked.ptr;
-        const size_t lds = (size_t)p.n_pad * 4 + (size_t)AUX_WORDS * 4;
-        auto k = spscore_kernel<1024>;
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipExtLaunchKernelGGL(k, dim3(n), dim3(1024), (unsigned)lds, s, h->timer.t0, h->timer.t1, 0, p);
+        if (in_lds) {
+            const size_t lds = (size_t)p.n_pad * 4 + (size_t)AUX_WORDS * 4;
+            auto k = spscore_kernel<1024>;
+            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipExtLaunchKernelGGL(k, dim3(n), dim3(1024), (unsigned)lds, s, h->timer.t0, h->timer.t1, 0, p);
+        } else {
+            MI_HIP(hipMemsetAsync(h->scores.ptr, 0, sizeof(float) * (size_t)n * h->n_out, s));
+            hipExtLaunchKernelGGL(spscore_wide_kernel, dim3(n), dim3(1024), 0, s, h->timer.t0, h->timer.t1, 0, p);
+            h->wide.rank(s, h->scores.ptr, n, h->n_out, cutoff, h->users.ptr, h->seen_ptr.ptr, h->seen_idx.ptr, p.allowed, remove_seen,
+                         h->ranked.ptr);
+        }
         MI_HIP(hipGetLastError());
         h->ranked.download(ranked, (size_t)n * cutoff, s);
         if (scores) h->scores.download(scores, (size_t)n * h->n_out, s);

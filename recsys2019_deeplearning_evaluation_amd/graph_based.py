@@ -16,7 +16,7 @@ from .similarity import Compute_Similarity_MI355X
 from .slim_bpr import rows_slabs_to_csr
 
 
-class _RandomWalkRecommender(GpuSimilarityScoringMixin, BaseItemSimilarityMatrixRecommender):
+class _RandomWalkLogic:
 
     def _fit_walk(self, topK, alpha, beta, min_rating, implicit, normalize_similarity):
         if min_rating > 0:
@@ -57,7 +57,7 @@ class _RandomWalkRecommender(GpuSimilarityScoringMixin, BaseItemSimilarityMatrix
         self.W_sparse = check_matrix(W, format="csr")
 
 
-class P3alphaRecommender(_RandomWalkRecommender):
+class _P3alphaLogic(_RandomWalkLogic):
     """Drop-in for GraphBased/P3alphaRecommender.py:19."""
     RECOMMENDER_NAME = "P3alphaRecommender"
 
@@ -67,7 +67,7 @@ class P3alphaRecommender(_RandomWalkRecommender):
         self._fit_walk(topK, alpha, None, min_rating, implicit, normalize_similarity)
 
 
-class RP3betaRecommender(_RandomWalkRecommender):
+class _RP3betaLogic(_RandomWalkLogic):
     """Drop-in for GraphBased/RP3betaRecommender.py:16."""
     RECOMMENDER_NAME = "RP3betaRecommender"
 
@@ -75,3 +75,11 @@ class RP3betaRecommender(_RandomWalkRecommender):
         self.alpha, self.beta, self.min_rating, self.topK, self.implicit = alpha, beta, min_rating, topK, implicit
         self.normalize_similarity = normalize_similarity
         self._fit_walk(topK, alpha, beta, min_rating, implicit, normalize_similarity)
+
+
+class P3alphaRecommender(_P3alphaLogic, GpuSimilarityScoringMixin, BaseItemSimilarityMatrixRecommender):
+    pass
+
+
+class RP3betaRecommender(_RP3betaLogic, GpuSimilarityScoringMixin, BaseItemSimilarityMatrixRecommender):
+    pass

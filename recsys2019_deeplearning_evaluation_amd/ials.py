@@ -73,8 +73,8 @@ class IALS_MI355X_Epoch:
         return st.as_dict()
 
 
-class IALSRecommender(GpuScoringMixin, BaseMatrixFactorizationRecommender, Incremental_Training_Early_Stopping):
-    """Drop-in for the reference IALSRecommender with _run_epoch on the GPU."""
+class _IALSLogic:
+    """Drop-in for the reference IALSRecommender with _run_epoch on the GPU (a mixin without bases, see matrix_factorization.py)."""
     RECOMMENDER_NAME = "IALSRecommender"
     AVAILABLE_CONFIDENCE_SCALING = ["linear", "log"]
 
@@ -115,3 +115,7 @@ class IALSRecommender(GpuScoringMixin, BaseMatrixFactorizationRecommender, Incre
 
     def _run_epoch(self, num_epoch):
         self.epoch_kernel.run_epochs(1)
+
+
+class IALSRecommender(_IALSLogic, GpuScoringMixin, BaseMatrixFactorizationRecommender, Incremental_Training_Early_Stopping):
+    pass

@@ -22,12 +22,12 @@ class _KNNCFMixin:
                 self.FEATURE_WEIGHTING_VALUES, feature_weighting))
 
 
-class ItemKNNCFRecommender(GpuSimilarityScoringMixin, _KNNCFMixin, BaseItemSimilarityMatrixRecommender):
+class _ItemKNNLogic(_KNNCFMixin):
     """ItemKNN recommender: W_sparse = top-K item-item similarity of the URM columns."""
     RECOMMENDER_NAME = "ItemKNNCFRecommender"
 
     def __init__(self, URM_train, verbose=True):
-        super(ItemKNNCFRecommender, self).__init__(URM_train, verbose=verbose)
+        super(_ItemKNNLogic, self).__init__(URM_train, verbose=verbose)
 
     def fit(self, topK=50, shrink=100, similarity="cosine", normalize=True, feature_weighting="none", **similarity_args):
         self.topK = topK
@@ -42,14 +42,14 @@ class ItemKNNCFRecommender(GpuSimilarityScoringMixin, _KNNCFMixin, BaseItemSimil
         builder.compute_similarity_object.close()
 
 
-class UserKNNCFRecommender(GpuSimilarityScoringMixin, _KNNCFMixin, BaseUserSimilarityMatrixRecommender):
+class _UserKNNLogic(_KNNCFMixin):
     """UserKNN recommender: the same build on URM.T (columns = users); user bases wider than the LDS accumulator
     (32 256 cells) are handled by the kernel's accumulator tiling."""
     RECOMMENDER_NAME = "UserKNNCFRecommender"
     _SCORER_USER_BASED = True
 
     def __init__(self, URM_train, verbose=True):
-        super(UserKNNCFRecommender, self).__init__(URM_train, verbose=verbose)
+        super(_UserKNNLogic, self).__init__(URM_train, verbose=verbose)
 
     def fit(self, topK=50, shrink=100, similarity="cosine", normalize=True, feature_weighting="none", **similarity_args):
         self.topK = topK
@@ -61,3 +61,11 @@ class UserKNNCFRecommender(GpuSimilarityScoringMixin, _KNNCFMixin, BaseUserSimil
         self.W_sparse = builder.compute_similarity()
         self.W_sparse = check_matrix(self.W_sparse, format="csr")
         builder.compute_similarity_object.close()
+
+
+class ItemKNNCFRecommender(_ItemKNNLogic, GpuSimilarityScoringMixin, BaseItemSimilarityMatrixRecommender):
+    pass
+
+
+class UserKNNCFRecommender(_UserKNNLogic, GpuSimilarityScoringMixin, BaseUserSimilarityMatrixRecommender):
+    pass

@@ -155,11 +155,14 @@ class MatrixFactorization_MI355X_Epoch:
         return np.array(self._download(True)[4][0])
 
 
-class _MatrixFactorization_MI355X(GpuScoringMixin, BaseMatrixFactorizationRecommender, Incremental_Training_Early_Stopping):
+class _MatrixFactorizationLogic:
+    """fit() / early-stopping hooks of MatrixFactorization_Cython.py:20-170 over the device epoch object.  A mixin without
+    bases: composed below with this package's re-provided recommender bases, and by reference_binding.bind() with the
+    reference's own Base classes."""
     RECOMMENDER_NAME = "MatrixFactorization_MI355X_Recommender"
 
     def __init__(self, URM_train, verbose=True, algorithm_name="MF_BPR"):
-        super(_MatrixFactorization_MI355X, self).__init__(URM_train, verbose=verbose)
+        super(_MatrixFactorizationLogic, self).__init__(URM_train, verbose=verbose)
         self.n_users, self.n_items = self.URM_train.shape
         self.normalize = False
         self.algorithm_name = algorithm_name
@@ -225,43 +228,43 @@ class _MatrixFactorization_MI355X(GpuScoringMixin, BaseMatrixFactorizationRecomm
         self.epoch_kernel.epochIteration_Cython()
 
 
-class MatrixFactorization_BPR_MI355X(_MatrixFactorization_MI355X):
+class _BPRLogic(_MatrixFactorizationLogic):
     """Drop-in for MatrixFactorization_BPR_Cython (forces use_bias=False, negative_interactions_quota=0)."""
     RECOMMENDER_NAME = "MatrixFactorization_BPR_MI355X_Recommender"
 
     def __init__(self, *pos_args, **key_args):
-        super(MatrixFactorization_BPR_MI355X, self).__init__(*pos_args, algorithm_name="MF_BPR", **key_args)
+        super(_BPRLogic, self).__init__(*pos_args, algorithm_name="MF_BPR", **key_args)
 
     def fit(self, **key_args):
         key_args["use_bias"] = False
         key_args["negative_interactions_quota"] = 0.0
-        super(MatrixFactorization_BPR_MI355X, self).fit(**key_args)
+        super(_BPRLogic, self).fit(**key_args)
 
 
-class MatrixFactorization_FunkSVD_MI355X(_MatrixFactorization_MI355X):
+class _FunkSVDLogic(_MatrixFactorizationLogic):
     """Drop-in for MatrixFactorization_FunkSVD_Cython."""
     RECOMMENDER_NAME = "MatrixFactorization_FunkSVD_MI355X_Recommender"
 
     def __init__(self, *pos_args, **key_args):
-        super(MatrixFactorization_FunkSVD_MI355X, self).__init__(*pos_args, algorithm_name="FUNK_SVD", **key_args)
+        super(_FunkSVDLogic, self).__init__(*pos_args, algorithm_name="FUNK_SVD", **key_args)
 
     def fit(self, **key_args):
-        super(MatrixFactorization_FunkSVD_MI355X, self).fit(**key_args)
+        super(_FunkSVDLogic, self).fit(**key_args)
 
 
-class MatrixFactorization_AsySVD_MI355X(_MatrixFactorization_MI355X):
+class _AsySVDLogic(_MatrixFactorizationLogic):
     """Drop-in for MatrixFactorization_AsySVD_Cython (MatrixFactorization_Cython.py:219): two item-sized factor matrices;
     a user's factors are the sum of the Y rows of its profile divided by sqrt(profile length)."""
     RECOMMENDER_NAME = "MatrixFactorization_AsySVD_MI355X_Recommender"
 
     def __init__(self, *pos_args, **key_args):
-        super(MatrixFactorization_AsySVD_MI355X, self).__init__(*pos_args, algorithm_name="ASY_SVD", **key_args)
+        super(_AsySVDLogic, self).__init__(*pos_args, algorithm_name="ASY_SVD", **key_args)
 
     def fit(self, **key_args):
         if key_args.get("batch_size", 1) > 1:
             print("{}: batch_size not supported for this recommender, setting to default value 1.".format(self.RECOMMENDER_NAME))
         key_args["batch_size"] = 1
-        super(MatrixFactorization_AsySVD_MI355X, self).fit(**key_args)
+        super(_AsySVDLogic, self).fit(**key_args)
 
     def _prepare_model_for_validation(self):
         self.ITEM_factors_Y, self.ITEM_factors = self.epoch_kernel.get_factors()
@@ -272,8 +275,17 @@ class MatrixFactorization_AsySVD_MI355X(_MatrixFactorization_MI355X):
             self.GLOBAL_bias = self.epoch_kernel.get_GLOBAL_bias()
 
     def _update_best_model(self):
-        super(MatrixFactorization_AsySVD_MI355X, self)._update_best_model()
+        super(_AsySVDLogic, self)._update_best_model()
         self.ITEM_factors_Y_best = self.ITEM_factors_Y.copy()
+
+    def set_URM_train(self, URM_train_new, estimate_item_similarity_for_cold_users=False, **kwargs):
+        """MatrixFactorization_Cython.py:257-278: the user factors of AsySVD are a function of the URM, so a new URM (the
+        evaluator's cold-user scenarios) re-estimates them from the learned Y."""
+        super(_AsySVDLogic, self).set_URM_train(URM_train_new, **kwargs)
+        if estimate_item_similarity_for_cold_users:           # (sic: the reference's keyword; it re-estimates USER_factors)
+            self._print("Estimating USER_factors for cold users...")
+            self.USER_factors = self._estimate_user_factors(self.ITEM_factors_Y_best)
+            self._print("Estimating USER_factors for cold users... done!")
 
     def _estimate_user_factors(self, ITEM_factors_Y):
         # MatrixFactorization_Cython.py:281-304: URM . Y, every row divided by sqrt(profile length)
@@ -282,3 +294,18 @@ class MatrixFactorization_AsySVD_MI355X(_MatrixFactorization_MI355X):
         warm = length_sqrt > 0
         USER_factors[warm] /= length_sqrt[warm][:, None]
         return USER_factors
+
+
+_BASES = (GpuScoringMixin, BaseMatrixFactorizationRecommender, Incremental_Training_Early_Stopping)
+
+
+class MatrixFactorization_BPR_MI355X(_BPRLogic, *_BASES):
+    pass
+
+
+class MatrixFactorization_FunkSVD_MI355X(_FunkSVDLogic, *_BASES):
+    pass
+
+
+class MatrixFactorization_AsySVD_MI355X(_AsySVDLogic, *_BASES):
+    pass

@@ -15,6 +15,7 @@ return_scores=True), rec.get_URM_train(), rec.set_items_to_ignore / reset_items_
 here -- so these classes drop into the reference evaluator unchanged.  When used *inside* the reference tree a
 maintainer can equally mix the kernel front-ends into the reference's own base classes.
 """
+import io
 import json
 import os
 import time
@@ -155,23 +156,32 @@ class BaseRecommender(object):
             ranking_list = ranking_list[0]
         return (ranking_list, scores) if return_scores else ranking_list
 
-    # ---- persistence: a zip of .npy / .npz / .json members, one per attribute (same idea as Base/DataIO.py:102) ----
+    # ---- persistence: the file layout of the reference's DataIO (Base/DataIO.py:102-186), so that models saved here load
+    # with `DataIO.load_data` / the reference's `load_model` and vice versa: a zip with one member per attribute (.npy for
+    # arrays, .npz for sparse matrices, .json for the rest) plus ".DataIO_attribute_to_file_name.json" mapping attribute -> member
+    _DATAIO_INDEX = ".DataIO_attribute_to_file_name"
+
     def _save_dict(self, folder_path, file_name, data):
         if file_name is None:
             file_name = self.RECOMMENDER_NAME
         os.makedirs(folder_path, exist_ok=True)
         path = os.path.join(folder_path, file_name + ("" if file_name.endswith(".zip") else ".zip"))
         self._print("Saving model in file '{}'".format(path))
+        index = {}
         with zipfile.ZipFile(path, "w", compression=zipfile.ZIP_DEFLATED) as z:
             for name, value in data.items():
                 if sps.issparse(value):
-                    with z.open(name + ".npz", "w") as f:
+                    index[name] = name + ".npz"
+                    with z.open(index[name], "w") as f:
                         sps.save_npz(f, value)
                 elif isinstance(value, np.ndarray):
-                    with z.open(name + ".npy", "w") as f:
+                    index[name] = name + ".npy"
+                    with z.open(index[name], "w") as f:
                         np.save(f, value, allow_pickle=False)
                 else:
-                    z.writestr(name + ".json", json.dumps(value if not isinstance(value, np.generic) else value.item()))
+                    index[name] = name + ".json"
+                    z.writestr(index[name], json.dumps(value if not isinstance(value, np.generic) else value.item()))
+            z.writestr(self._DATAIO_INDEX + ".json", json.dumps(index))
         self._print("Saving complete")
 
     def save_model(self, folder_path, file_name=None):
@@ -183,13 +193,19 @@ class BaseRecommender(object):
         path = os.path.join(folder_path, file_name + ("" if file_name.endswith(".zip") else ".zip"))
         self._print("Loading model from file '{}'".format(path))
         with zipfile.ZipFile(path) as z:
-            for member in z.namelist():
-                name, ext = os.path.splitext(member)
+            names = z.namelist()
+            index_member = next((m for m in (self._DATAIO_INDEX + ".json", "__DataIO_attribute_to_file_name.json") if m in names), None)
+            if index_member is not None:
+                index = json.loads(z.read(index_member).decode())
+            else:       # (files written by round-1 builds of this package carry no index)
+                index = {os.path.splitext(m)[0]: m for m in names}
+            for name, member in index.items():
+                ext = os.path.splitext(member)[1]
                 with z.open(member) as f:
                     if ext == ".npz":
-                        value = sps.load_npz(f)
+                        value = sps.load_npz(io.BytesIO(f.read()))
                     elif ext == ".npy":
-                        value = np.load(f, allow_pickle=False)
+                        value = np.load(io.BytesIO(f.read()), allow_pickle=False)
                     else:
                         value = json.loads(f.read().decode())
                 setattr(self, name, value)

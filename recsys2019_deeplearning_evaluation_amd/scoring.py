@@ -66,24 +66,45 @@ class MI355XScorer:
             pass
 
 
+def _fingerprint(array):
+    """Cheap content signature of a host array (256 strided elements + shape): an optimiser step moves practically every
+    cell of a factor matrix, so in-place edits of an object the cache already holds are noticed without hashing it all."""
+    a = np.asarray(array).ravel()
+    if a.size == 0:
+        return (0,)
+    step = max(1, a.size // 256)
+    return (np.asarray(array).shape, a[::step][:256].tobytes(), a[-1].tobytes())
+
+
 class GpuScoringMixin:
     """recommend() of BaseRecommender (same signature, same return values) served by MI355XScorer.  The scorer is
-    (re)built lazily from the host attributes USER_factors / ITEM_factors[/biases], so it follows early-stopping's
-    _prepare_model_for_validation / best-model swaps automatically."""
+    (re)built lazily from the host attributes USER_factors / ITEM_factors[/biases] and URM_train, so it follows
+    early-stopping's _prepare_model_for_validation / best-model swaps and set_URM_train automatically.  The cache holds
+    STRONG references to the objects it was built from and compares by identity (an id() of a freed object can be reused
+    by its successor) plus a content fingerprint (in-place edits)."""
     _scorer = None
-    _scorer_key = None
+    _scorer_src = None
+
+    def _scorer_sources(self):
+        src = [self.USER_factors, self.ITEM_factors]
+        if self.use_bias:
+            src += [self.USER_bias, self.ITEM_bias, np.asarray(self.GLOBAL_bias)]
+        return src
 
     def _get_scorer(self):
-        key = (id(self.USER_factors), id(self.ITEM_factors), bool(self.use_bias))
-        if self._scorer is None or self._scorer.use_bias != bool(self.use_bias):
+        src = self._scorer_sources()
+        prints = [_fingerprint(a) for a in src]
+        bias = dict(USER_bias=self.USER_bias, ITEM_bias=self.ITEM_bias, GLOBAL_bias=self.GLOBAL_bias) if self.use_bias else {}
+        old = self._scorer_src
+        rebuild = (self._scorer is None or self._scorer.use_bias != bool(self.use_bias) or old["urm"] is not self.URM_train
+                   or self._scorer.n_factors != np.asarray(self.USER_factors).shape[1])
+        if rebuild:
             if self._scorer is not None:
                 self._scorer.close()
-            bias = dict(USER_bias=self.USER_bias, ITEM_bias=self.ITEM_bias, GLOBAL_bias=self.GLOBAL_bias) if self.use_bias else {}
-            self._scorer = MI355XScorer(self.USER_factors, self.ITEM_factors, self.URM_train, **bias)
-        elif key != self._scorer_key:
-            bias = dict(USER_bias=self.USER_bias, ITEM_bias=self.ITEM_bias, GLOBAL_bias=self.GLOBAL_bias) if self.use_bias else {}
+            self._scorer = MI355XScorer(self.USER_factors, self.ITEM_factors, self.URM_train, **bias)    # uploads the seen CSR too
+        elif len(old["src"]) != len(src) or any(a is not b for a, b in zip(old["src"], src)) or old["prints"] != prints:
             self._scorer.update(self.USER_factors, self.ITEM_factors, **bias)
-        self._scorer_key = key
+        self._scorer_src = {"src": src, "prints": prints, "urm": self.URM_train}
         return self._scorer
 
     def recommend(self, user_id_array, cutoff=None, remove_seen_flag=True, items_to_compute=None, remove_top_pop_flag=False,
@@ -159,16 +180,20 @@ class GpuSimilarityScoringMixin:
     URM_train is replaced (fit, early-stopping validation)."""
     _SCORER_USER_BASED = False
     _sp_scorer = None
-    _sp_scorer_key = None
+    _sp_scorer_src = None
 
     def _get_sparse_scorer(self):
-        key = (id(self.W_sparse), id(self.URM_train))
-        if self._sp_scorer is None or key != self._sp_scorer_key:
+        # strong references + identity (SLIM's get_S_incremental_and_set_W assigns W_sparse twice per validation: the address of
+        # the first, freed matrix can be handed to its successor, so an id() key would score with stale weights)
+        W = self.W_sparse
+        print_now = (W.shape, W.nnz, _fingerprint(W.data), _fingerprint(W.indices)) if hasattr(W, "nnz") else _fingerprint(W)
+        old = self._sp_scorer_src
+        if self._sp_scorer is None or old["W"] is not W or old["urm"] is not self.URM_train or old["print"] != print_now:
             if self._sp_scorer is not None:
                 self._sp_scorer.close()
             A, B = (self.W_sparse, self.URM_train) if self._SCORER_USER_BASED else (self.URM_train, self.W_sparse)
             self._sp_scorer = MI355XSparseScorer(A, B, self.URM_train)
-            self._sp_scorer_key = key
+            self._sp_scorer_src = {"W": W, "urm": self.URM_train, "print": print_now}
         return self._sp_scorer
 
     def recommend(self, user_id_array, cutoff=None, remove_seen_flag=True, items_to_compute=None, remove_top_pop_flag=False,

@@ -135,12 +135,15 @@ def allgather_rows(T, ranges, rank, dist):
     torch.cuda.synchronize()
 
 
-def sharded_ials_epoch(epoch_object, dist, rank, world, user_ranges=None, item_ranges=None):
+def sharded_ials_epoch(epoch_object, dist, rank, world, user_ranges, item_ranges):
     """One IALS epoch with the row solves of each half-step split over the ranks (IALS_MI355X_Epoch on every rank,
-    identical state).  Ranges default to cost-balanced cuts by profile length."""
+    identical state).  `user_ranges` / `item_ranges`: one (start, end) per rank, e.g. from ials_row_ranges() (cost-balanced
+    cuts of the confidence matrix); they are required because the epoch object does not keep the host CSR."""
     if world == 1:
         epoch_object.run_epochs(1)
         return
+    assert user_ranges is not None and item_ranges is not None and len(user_ranges) == world == len(item_ranges), \
+        "sharded_ials_epoch: one user range and one item range per rank are required (see ials_row_ranges)"
     n_users, n_items, k = epoch_object.n_users, epoch_object.n_items, epoch_object.num_factors
     dU, dV = epoch_object.device_factor_pointers()
     U = device_tensor(dU, (n_users, k))

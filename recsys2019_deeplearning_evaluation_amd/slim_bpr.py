@@ -122,12 +122,12 @@ class SLIM_BPR_MI355X_Epoch:
         return st.as_dict()
 
 
-class SLIM_BPR_MI355X(GpuSimilarityScoringMixin, BaseItemSimilarityMatrixRecommender, Incremental_Training_Early_Stopping):
+class _SLIMLogic:
     """Drop-in for SLIM_BPR_Cython."""
     RECOMMENDER_NAME = "SLIM_BPR_Recommender"
 
     def __init__(self, URM_train, verbose=True, free_mem_threshold=0.5):
-        super(SLIM_BPR_MI355X, self).__init__(URM_train, verbose=verbose)
+        super(_SLIMLogic, self).__init__(URM_train, verbose=verbose)
         assert 0.0 <= free_mem_threshold <= 1.0, \
             "SLIM_BPR_Recommender: free_mem_threshold must be between 0.0 and 1.0, provided was '{}'".format(free_mem_threshold)
         self.n_users, self.n_items = self.URM_train.shape
@@ -181,3 +181,7 @@ class SLIM_BPR_MI355X(GpuSimilarityScoringMixin, BaseItemSimilarityMatrixRecomme
         self.S_incremental = self.epoch_kernel.get_S()
         self.W_sparse = similarityMatrixTopK(self.S_incremental, k=self.topK) if self.topK else self.S_incremental
         self.W_sparse = check_matrix(self.W_sparse, format="csr")
+
+
+class SLIM_BPR_MI355X(_SLIMLogic, GpuSimilarityScoringMixin, BaseItemSimilarityMatrixRecommender, Incremental_Training_Early_Stopping):
+    pass

@@ -120,3 +120,75 @@ def test_similarity_model_scoring_matches_host(gpu, user_based):
     only = rec.recommend(users[:5], cutoff=10, items_to_compute=allowed_items)
     assert all(set(l) <= set(allowed_items.tolist()) for l in only)
     assert rec.recommend(int(users[2]), cutoff=5) == dev_lists[2][:5]
+
+
+def test_large_catalogues_and_full_rankings_stay_on_the_device(gpu):
+    """Score rows that do not fit LDS (> ~32 k items) and the reference's default cutoff=None (rank ALL items): rows stay in
+    HBM and are ordered by one segmented radix sort; same results as the host path, no NotImplementedError."""
+    from recsys2019_deeplearning_evaluation_amd import MI355XSparseScorer
+    from recsys2019_deeplearning_evaluation_amd.synthetic import synthetic_urm
+    import scipy.sparse as sps
+    X = synthetic_urm(400, 40000, 30000, 5, 300, seed=2, values="binary")
+    rng = np.random.default_rng(1)
+    U = rng.normal(size=(X.shape[0], 32)).astype(np.float32); V = rng.normal(size=(X.shape[1], 32)).astype(np.float32)
+    sc = MI355XScorer(U, V, X)
+    users = rng.choice(X.shape[0], 50, replace=False)
+    want = _host_reference(X, U, V, users)
+    scale = np.abs(want[np.isfinite(want)]).max()
+    for cutoff in (10, 5000, X.shape[1] - 1):                    # in-LDS selection impossible in all three cases (40 000 items)
+        ranked, scores = sc.recommend(users, cutoff, remove_seen=True, return_scores=True)
+        assert np.abs(scores[np.isfinite(want)] - want[np.isfinite(want)]).max() < 1e-5 * scale
+        for r in range(0, len(users), 7):
+            _check_ranking(ranked[r], want[r], cutoff, 1e-5 * scale)
+    sc.close()
+    # a small catalogue with a cutoff above the in-LDS selection limit (the Evaluator never asks for it, recommend(user) does)
+    Xs = named_urm("ml1m", "binary", scale=0.3)
+    Us = rng.normal(size=(Xs.shape[0], 8)).astype(np.float32); Vs = rng.normal(size=(Xs.shape[1], 8)).astype(np.float32)
+    rec = RB.BaseMatrixFactorizationRecommender(Xs, verbose=False)
+    rec.USER_factors, rec.ITEM_factors = Us, Vs
+    from recsys2019_deeplearning_evaluation_amd import GpuScoringMixin
+    dev = type("R", (GpuScoringMixin, RB.BaseMatrixFactorizationRecommender), {})(Xs, verbose=False)
+    dev.USER_factors, dev.ITEM_factors = Us, Vs
+    assert dev.recommend(5) == rec.recommend(5)                   # cutoff=None: the full ranking, identical lists
+    # sparse (similarity-model) scorer on a wide catalogue
+    W = sps.random(X.shape[1], X.shape[1], 2e-4, format="csr", random_state=5, dtype=np.float32)
+    sp = MI355XSparseScorer(X, W, X)
+    ranked, scores = sp.recommend(users, 20, remove_seen=True, return_scores=True)
+    host = X[users].dot(W).toarray().astype(np.float64)
+    for r, u in enumerate(users):
+        host[r, X.indices[X.indptr[u]:X.indptr[u + 1]]] = -np.inf
+    fin = np.isfinite(host)
+    assert (np.isfinite(scores) == fin).all() and np.abs(scores[fin] - host[fin]).max() < 1e-5 * max(np.abs(host[fin]).max(), 1e-30)
+    for r in range(0, len(users), 5):
+        _check_ranking(ranked[r], host[r], 20, 1e-5 * max(np.abs(host[fin]).max(), 1e-30))
+    sp.close()
+
+
+def test_scorer_cache_follows_the_model_and_the_urm(gpu):
+    """The lazily built device scorer must notice a new URM_train (seen items), replaced AND in-place edited factors, and a
+    W_sparse whose predecessor's address has been recycled."""
+    from recsys2019_deeplearning_evaluation_amd import GpuScoringMixin, GpuSimilarityScoringMixin
+    import scipy.sparse as sps
+    X = named_urm("ml1m", "binary", scale=0.15)
+    rng = np.random.default_rng(3)
+    MF = type("MF", (GpuScoringMixin, RB.BaseMatrixFactorizationRecommender), {})
+    rec = MF(X, verbose=False)
+    rec.USER_factors = rng.normal(size=(X.shape[0], 8)).astype(np.float32); rec.ITEM_factors = rng.normal(size=(X.shape[1], 8)).astype(np.float32)
+    users = np.arange(30)
+    host = lambda: RB.BaseRecommender.recommend(rec, users, cutoff=10)
+    assert rec.recommend(users, cutoff=10) == host()
+    rec.ITEM_factors *= -1.0                                      # in place: same object
+    assert rec.recommend(users, cutoff=10) == host()
+    rec.USER_factors = rec.USER_factors[::-1].copy()              # replaced
+    assert rec.recommend(users, cutoff=10) == host()
+    X2 = X.copy().tolil(); X2[:30, :] = 0; X2 = X2.tocsr()        # cold-start view: nothing is "seen" any more for these users
+    rec.set_URM_train(X2)
+    assert rec.recommend(users, cutoff=10) == host()
+    KNN = type("KNN", (GpuSimilarityScoringMixin, RB.BaseItemSimilarityMatrixRecommender), {})
+    knn = KNN(X, verbose=False)
+    for seed in range(4):                                         # a fresh matrix each time; old ones are freed in between
+        knn.W_sparse = sps.random(X.shape[1], X.shape[1], 0.03, format="csr", random_state=seed, dtype=np.float32)
+        dev_lists, dev_scores = knn.recommend(users, cutoff=10, return_scores=True)
+        _, host_scores = RB.BaseRecommender.recommend(knn, users, cutoff=10, return_scores=True)
+        fin = np.isfinite(host_scores)
+        assert np.abs(dev_scores[fin] - host_scores[fin]).max() < 1e-5 * max(1e-30, np.abs(host_scores[fin]).max())
