@@ -34,6 +34,14 @@ extern "C" {
 #define MI355REC_E_NUMERIC      -5   /* non-finite value / not positive definite */
 
 const char *mi355rec_last_error(void);
+
+/* Raw device buffers of the calling process's device, for callers that keep results on the GPU and exchange them between
+ * GPUs themselves (sharding.py: RCCL all-gather of similarity slabs through ctypes, no PyTorch).  to_device: 1 = host -> device,
+ * 0 = device -> host; both copies are blocking. */
+int mi355rec_device_malloc(void **out, uint64_t bytes);
+int mi355rec_device_free(void *p);
+int mi355rec_device_memcpy(void *dst, const void *src, uint64_t bytes, int to_device);
+int mi355rec_device_synchronize(void);
 /* Number of visible HIP devices (0 and MI355REC_OK when none). */
 int mi355rec_device_count(int *count);
 /* Select the device used by handles created afterwards in this process (one process per GPU: LOCAL_RANK). */

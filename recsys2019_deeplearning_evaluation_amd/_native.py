@@ -68,6 +68,10 @@ SIGNATURES = {
     "mi355rec_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mi355rec_set_device": (C.c_int, [C.c_int]),
     "mi355rec_device_name": (C.c_int, [C.c_char_p, C.c_int]),
+    "mi355rec_device_malloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),
+    "mi355rec_device_free": (C.c_int, [_vp]),
+    "mi355rec_device_memcpy": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int]),
+    "mi355rec_device_synchronize": (C.c_int, []),
     "mi355rec_sim_create": (C.c_int, [C.POINTER(_vp), C.POINTER(SimConfig), _i32, _i32, _vp, _vp, _vp, _vp]),
     "mi355rec_sim_compute": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355rec_sim_compute_device": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
@@ -187,3 +191,31 @@ def as_f32(a):
 
 def as_f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class DeviceArray:
+    """A raw device allocation of the calling process's GPU (int32 words), released with the object."""
+
+    def __init__(self, n_words):
+        self.n_words = int(n_words)
+        self.ptr = C.c_void_p()
+        check(load().mi355rec_device_malloc(C.byref(self.ptr), 4 * self.n_words))
+
+    def address(self, word_offset=0):
+        return (self.ptr.value or 0) + 4 * int(word_offset)
+
+    def to_host(self, out=None):
+        out = np.empty(self.n_words, np.int32) if out is None else out
+        check(load().mi355rec_device_memcpy(ptr(out), self.ptr, 4 * self.n_words, 0))
+        return out
+
+    def close(self):
+        if getattr(self, "ptr", None) is not None and self.ptr.value:
+            load().mi355rec_device_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -75,3 +75,34 @@ extern "C" int mi355rec_device_name(char *buf, int buf_len) {
         snprintf(buf, buf_len, "%s", prop.gcnArchName);
     });
 }
+
+// ---- raw device buffers for callers that exchange results between GPUs without PyTorch (sharding.py over RCCL through ctypes)
+extern "C" int mi355rec_device_malloc(void **out, uint64_t bytes) {
+    return guarded([&] {
+        MI_REQUIRE(out != nullptr, "out is NULL");
+        ensure_device();
+        *out = nullptr;
+        if (bytes) MI_HIP(hipMalloc(out, (size_t)bytes));
+    });
+}
+
+extern "C" int mi355rec_device_free(void *p) {
+    return guarded([&] {
+        if (p) MI_HIP(hipFree(p));
+    });
+}
+
+extern "C" int mi355rec_device_memcpy(void *dst, const void *src, uint64_t bytes, int to_device) {
+    return guarded([&] {
+        MI_REQUIRE(dst && src, "NULL argument");
+        ensure_device();
+        MI_HIP(hipMemcpy(dst, src, (size_t)bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+    });
+}
+
+extern "C" int mi355rec_device_synchronize(void) {
+    return guarded([&] {
+        ensure_device();
+        MI_HIP(hipDeviceSynchronize());
+    });
+}

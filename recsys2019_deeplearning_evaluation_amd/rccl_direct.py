@@ -1,0 +1,116 @@
+"""RCCL through ctypes: the collective of the sharded similarity build without PyTorch.
+
+One process per GPU.  Rank 0 creates the `ncclUniqueId` and hands it to the other ranks over a plain TCP socket
+(MASTER_ADDR : MASTER_PORT + 1 by default -- the launcher's own store keeps MASTER_PORT); every rank then calls
+`ncclCommInitRank`.  `all_gather` runs on the null stream and returns after the device has finished (the callers are
+blocking library calls anyway).  Only the three entry points the build needs are bound.
+"""
+import ctypes as C
+import os
+import socket
+import time
+
+from . import _native as N
+
+NCCL_UNIQUE_ID_BYTES = 128
+NCCL_INT32 = 2          # ncclDataType_t: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3, ncclInt64 4, ncclUint64 5, ncclFloat16 6, ...
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * NCCL_UNIQUE_ID_BYTES)]
+
+
+def _load_rccl():
+    last = None
+    for name in (os.environ.get("MI355REC_RCCL_LIBRARY"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"):
+        if not name:
+            continue
+        try:
+            lib = C.CDLL(name)
+            break
+        except OSError as exc:
+            last = exc
+    else:
+        raise N.NativeLibraryError("librccl not found: %s" % last)
+    lib.ncclGetUniqueId.restype = C.c_int
+    lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+    lib.ncclCommInitRank.restype = C.c_int
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+    lib.ncclAllGather.restype = C.c_int
+    lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ncclCommDestroy.restype = C.c_int
+    lib.ncclCommDestroy.argtypes = [C.c_void_p]
+    lib.ncclGetErrorString.restype = C.c_char_p
+    lib.ncclGetErrorString.argtypes = [C.c_int]
+    return lib
+
+
+def exchange_unique_id(payload, rank, world, address, port, timeout=120.0):
+    """Rank 0 serves `payload` (bytes) to the world - 1 other ranks; they return what they received."""
+    if world == 1:
+        return payload
+    if rank == 0:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((address, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _ = srv.accept()
+                with conn:
+                    conn.sendall(payload)
+        return payload
+    deadline = time.time() + timeout
+    while True:
+        try:
+            with socket.create_connection((address, port), timeout=5.0) as conn:
+                chunks, need = [], len(payload) if payload else NCCL_UNIQUE_ID_BYTES
+                while need > 0:
+                    part = conn.recv(need)
+                    if not part:
+                        raise ConnectionError("peer closed the connection early")
+                    chunks.append(part)
+                    need -= len(part)
+                return b"".join(chunks)
+        except (ConnectionRefusedError, socket.timeout, ConnectionError):
+            if time.time() > deadline:
+                raise
+            time.sleep(0.05)
+
+
+class RcclCommunicator:
+    def __init__(self, rank=None, world=None, address=None, port=None):
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        address = address or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + 1)
+        self._lib = _load_rccl()
+        N.check(N.load().mi355rec_device_synchronize())          # binds this process to its device (set_device) first
+        uid = _UniqueId()
+        if self.rank == 0:
+            self._check(self._lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        raw = exchange_unique_id(bytes(uid.internal) if self.rank == 0 else b"", self.rank, self.world, address, port)
+        C.memmove(C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
+        self._comm = C.c_void_p()
+        self._check(self._lib.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise N.NativeLibraryError("%s failed: %s" % (what, self._lib.ncclGetErrorString(rc).decode()))
+
+    def all_gather_words(self, send_address, recv_address, n_words):
+        """recv[r * n_words : (r + 1) * n_words] = rank r's send[0 : n_words] (int32 words), on every rank.  Blocking."""
+        self._check(self._lib.ncclAllGather(C.c_void_p(send_address), C.c_void_p(recv_address), n_words, NCCL_INT32, self._comm, None),
+                    "ncclAllGather")
+        N.check(N.load().mi355rec_device_synchronize())
+
+    def close(self):
+        if getattr(self, "_comm", None) is not None and self._comm.value:
+            self._lib.ncclCommDestroy(self._comm)
+            self._comm = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

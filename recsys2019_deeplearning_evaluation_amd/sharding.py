@@ -1,4 +1,4 @@
-"""Multi-GPU sharding of the similarity build (one process per GPU, torch.distributed; backend "nccl" is RCCL).
+"""Multi-GPU sharding of the similarity build (one process per GPU; RCCL through torch.distributed or directly through ctypes).
 
 The path shards along the seam the reference already has and never uses: `compute_similarity(start_col,
 end_col)` (Compute_Similarity_Cython.pyx:411,447-451).  Every output column depends only on the read-only
@@ -70,27 +70,82 @@ def gather_slabs(local_idx, local_val, ranges, rank, topK, dist, device=None):
     return full_idx, full_val
 
 
-def sharded_similarity_build(similarity_object, dist=None, rank=0, world=1):
+class ShardedSimilarityBuild:
+    """The column-sharded build as a reusable object: ranges, the rank's slab and the gathered result are allocated ONCE.
+
+    Device layout: every rank owns one contiguous slab `[2][widest][topK]` of 4-byte words -- neighbour ids, then the
+    similarity values (float32 bits) -- which the column kernel fills directly (its two output pointers are the two halves).
+    The exchange is ONE all-gather of that slab into `[world][2][widest][topK]`; the result stays on the device of every
+    rank.  `build()` returns when the full result is resident on this rank's device -- the same definition at world == 1 (no
+    exchange) -- and `download()` copies it to the host, which only a caller that needs NumPy arrays pays.
+    Buffers belong to libmi355rec.so (raw device allocations); the transport is either
+      `comm`: an rccl_direct.RcclCommunicator (RCCL through ctypes, no PyTorch in the process), or
+      `dist`: torch.distributed ("nccl" = RCCL: device to device over xGMI; "gloo": staged through host memory, CPU-side tests)."""
+
+    def __init__(self, similarity_object, dist=None, rank=0, world=1, comm=None):
+        from ._native import DeviceArray
+        self.sim, self.dist, self.comm, self.rank, self.world = similarity_object, dist, comm, rank, world
+        assert world == 1 or (dist is None) != (comm is None), "exactly one transport: torch.distributed (dist) or RcclCommunicator (comm)"
+        self.topK, self.n = similarity_object.TopK, similarity_object.n_columns
+        self.ranges = similarity_column_ranges(similarity_object, world) if world > 1 else [(0, self.n)]
+        self.widest = max(e - s for s, e in self.ranges)
+        self.slab_words = 2 * self.widest * self.topK
+        self.local = DeviceArray(self.slab_words)
+        self.gathered = DeviceArray(world * self.slab_words) if world > 1 else self.local
+        self._host = np.empty(world * self.slab_words, np.int32)
+        if dist is not None and world > 1:
+            self.t_local = device_tensor(self.local.address(), (self.slab_words,), "<i4")
+            self.t_all = device_tensor(self.gathered.address(), (world * self.slab_words,), "<i4")
+            self.on_host = dist.get_backend() == "gloo"
+
+    def build(self):
+        """Kernel on this rank's range (+ the exchange); afterwards the gathered slabs are valid on this device.  Blocking."""
+        s, e = self.ranges[self.rank]
+        self.sim.compute_slabs_device(s if s > 0 else None, e if e < self.n else None, self.local.address(),
+                                      self.local.address(self.widest * self.topK))
+        self.sim.synchronize()
+        if self.world == 1:
+            return
+        if self.comm is not None:
+            self.comm.all_gather_words(self.local.address(), self.gathered.address(), self.slab_words)
+            return
+        import torch
+        if self.on_host:            # gloo: CPU-side tests / the single-GPU dry run of bench.py
+            mine = self.t_local.cpu()
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine)
+            self.t_all.copy_(torch.cat(parts))
+        else:
+            self.dist.all_gather_into_tensor(self.t_all, self.t_local)
+        torch.cuda.synchronize()
+
+    def download(self):
+        """(idx, val) NumPy arrays for ALL columns."""
+        host = self.gathered.to_host(self._host).reshape(self.world, 2, self.widest, self.topK)
+        idx = np.concatenate([host[r, 0, :e - s] for r, (s, e) in enumerate(self.ranges)], axis=0)
+        val = np.concatenate([host[r, 1, :e - s] for r, (s, e) in enumerate(self.ranges)], axis=0).view(np.float32)
+        return idx, val
+
+    def exchange_bytes_per_rank(self):
+        return 0 if self.world == 1 else 4 * self.slab_words
+
+    def close(self):
+        self.local.close()
+        if self.gathered is not self.local:
+            self.gathered.close()
+
+
+def sharded_similarity_build(similarity_object, dist=None, rank=0, world=1, comm=None):
     """Column-sharded build with a Compute_Similarity_MI355X object: returns (idx, val) numpy arrays for ALL
     columns on every rank.  With world == 1 this is the plain single-GPU build."""
-    topK = similarity_object.TopK
-    n = similarity_object.n_columns
     if world == 1:
         idx, val, _ = similarity_object.compute_slabs()
         return idx, val
-    import torch
-    ranges = similarity_column_ranges(similarity_object, world)
-    s, e = ranges[rank]
-    device = torch.device("cuda", torch.cuda.current_device())
-    widest = max(b - a for a, b in ranges)
-    d_idx = torch.empty((widest, topK), dtype=torch.int32, device=device)
-    d_val = torch.empty((widest, topK), dtype=torch.float32, device=device)
-    torch.cuda.synchronize()
-    # the kernels run on the handle's own stream: results are written straight into the torch tensors
-    _run_range(similarity_object, s, e, n, d_idx, d_val)
-    similarity_object.synchronize()
-    full_idx, full_val = gather_slabs(d_idx, d_val, ranges, rank, topK, dist, device)
-    return full_idx.cpu().numpy(), full_val.cpu().numpy()
+    job = ShardedSimilarityBuild(similarity_object, dist, rank, world, comm)
+    job.build()
+    out = job.download()
+    job.close()
+    return out
 
 
 def _run_range(similarity_object, s, e, n, d_idx, d_val):

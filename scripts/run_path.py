@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""One short invocation of ONE hot path at the ML-20M shape, for rocprofv3 (scripts/pmc_round.sh).  Usage: run_path.py <path>"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MI355REC_NO_GRAPH", "1")       # rocprofv3 (ROCm 7.2) crashes while tracing hipGraph replays
+import numpy as np  # noqa: E402
+
+from bench import load_urm, K_FACTORS, BATCH, TOPK  # noqa: E402
+from recsys2019_deeplearning_evaluation_amd import (Compute_Similarity_MI355X, IALS_MI355X_Epoch, MatrixFactorization_MI355X_Epoch,  # noqa: E402
+                                                    MI355XScorer, SLIM_BPR_MI355X_Epoch)
+
+path = sys.argv[1]
+urm = load_urm("ml20m")
+if path == "mf":
+    m = MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, algorithm_name="MF_BPR", batch_size=BATCH, learning_rate=1e-3, sgd_mode="sgd", random_seed=1)
+    m.epochIteration_Cython(2)
+elif path == "funk":
+    m = MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, algorithm_name="FUNK_SVD", batch_size=BATCH, learning_rate=1e-3, sgd_mode="sgd", use_bias=True, random_seed=1)
+    u = np.random.default_rng(0).integers(0, urm.shape[0], 200 * BATCH).astype(np.int32)
+    i = urm.indices[urm.indptr[u]]
+    m.replay_samples(u, i, rating=np.ones(len(u), np.float32))
+elif path == "sim":
+    s = Compute_Similarity_MI355X(urm, topK=TOPK, shrink=0, normalize=True, similarity="cosine")
+    s.compute_slabs()
+elif path in ("slim_dense", "slim_symmetric"):
+    s = SLIM_BPR_MI355X_Epoch(urm, symmetric=path == "slim_symmetric", sgd_mode="adagrad", learning_rate=1e-4, topK=TOPK, random_seed=7)
+    s.epochIteration_Cython(1)
+elif path == "ials":
+    conf = urm.copy(); conf.data = (1.0 + conf.data).astype(np.float32)
+    k = 200
+    ia = IALS_MI355X_Epoch(conf, k, 1e-3, k ** -0.5 * np.random.default_rng(0).random((urm.shape[1], k)))
+    ia.run_epochs(1)
+elif path == "score":
+    rng = np.random.default_rng(0)
+    sc = MI355XScorer(rng.normal(0, 0.1, (urm.shape[0], K_FACTORS)).astype(np.float32), rng.normal(0, 0.1, (urm.shape[1], K_FACTORS)).astype(np.float32), urm)
+    sc.recommend(rng.choice(urm.shape[0], 1000, replace=False).astype(np.int32), 20)
+else:
+    raise SystemExit("unknown path " + path)
+print("done", path)

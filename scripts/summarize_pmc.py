@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Condenses a scripts/pmc_round.sh output directory into summary.txt (stdout) and pmc_traffic.json."""
+import csv
+import datetime
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+OURS = ("mf_", "sim_", "slim_", "ials_", "gram_", "score_", "spscore", "wide_", "segment_")
+
+
+def short(name):
+    name = name.replace("mi355rec::(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0][:70]
+
+
+def find(sub, pattern):
+    hits = glob.glob(os.path.join(root, sub, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+traffic = {}
+for path in ("mf", "funk", "sim", "slim_dense", "slim_symmetric", "ials", "score"):
+    print("=" * 30, path, "=" * 30)
+    stats = find(path + "/trace", "*kernel_stats.csv")
+    durations = {}
+    if stats:
+        print("%-72s %7s %14s %12s %6s" % ("kernel (rocprofv3 --kernel-trace --stats)", "calls", "total_ns", "avg_ns", "%"))
+        for r in list(csv.DictReader(open(stats)))[:8]:
+            k = short(r["Name"])
+            durations[k] = float(r["AverageNs"])
+            print("%-72s %7s %14s %12.1f %6.2f" % (k, r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), float(r["Percentage"])))
+    per = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    for sub in ("fetch", "write", "sq"):
+        f = find(path + "/" + sub, "*counter_collection.csv")
+        if not f:
+            continue
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if not k.startswith(OURS):
+                continue
+            c = per[k][r["Counter_Name"]]
+            c[0] += 1
+            c[1] += float(r["Counter_Value"])
+    for k, counters in sorted(per.items(), key=lambda kv: -sum(v[1] for v in kv[1].values())):
+        line = "  pmc %-60s" % k
+        for name, (n, total) in sorted(counters.items()):
+            line += "  %s %.4g/launch (%d launches)" % (name, total / max(n, 1), n)
+        print(line)
+        f_kib = counters.get("FETCH_SIZE", [0, 0.0]); w_kib = counters.get("WRITE_SIZE", [0, 0.0])
+        if f_kib[0] or w_kib[0]:
+            fetch = 2.0 * 1024.0 * f_kib[1] / max(f_kib[0], 1)       # KiB -> B; x2: gfx950 counts 128-B requests as 64 B (MI355X_MICROARCH.md)
+            write = 1024.0 * w_kib[1] / max(w_kib[0], 1)
+            traffic[k] = {"fetch_bytes_per_launch_x2_corrected": fetch, "write_bytes_per_launch": write,
+                          "hbm_bytes_per_launch": fetch + write, "avg_ns": durations.get(k)}
+doc = {"collected": datetime.date.today().isoformat(), "workload": "ML-20M-shaped synthetic URM, scripts/run_path.py <path>",
+       "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B); WRITE_SIZE uncalibrated; memory-side "
+               "counters include Infinity-Cache hits", "kernels": traffic}
+json.dump(doc, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
+print("\nwrote", os.path.join(root, "pmc_traffic.json"))
