@@ -5,15 +5,13 @@
 //      x = inv(YtY + Y_I^T (C_I - 1) Y_I + reg I) . (Y_I^T c_I).
 //
 // Design.  This is the one dense contraction on the hot path; it is done in float64 like the
-// reference (the systems are ill-conditioned for small `reg`, fp32 cannot meet the 1e-5 parity bar), on the FP64
-// vector pipe -- on CDNA4 the FP64 matrix rate equals the FP64 vector rate, so MFMA buys nothing here.
+// reference (the systems are ill-conditioned for small `reg`, fp32 cannot meet the 1e-5 parity bar), on the FP64 MATRIX pipe
+// (v_mfma_f64_16x16x4_f64; on CDNA4 its peak equals the FP64 vector peak, 78.6 TFLOP/s, but one instruction carries 512
+// multiply-adds and needs 2 LDS operand reads, against 14 reads per 28 multiply-adds on the vector pipe).
 //   gram_kernel      G = Y^T Y, register tiles + double atomics (tiny: n * k^2).
-//   ials_row_kernel  one 1024-thread workgroup per row, rows pulled longest-profile-first from a queue.  The k x k
-//                    system lives entirely in registers, lower-triangular tiles only: thread (ty, tx) of the 32 x 32
-//                    grid owns B[ty + 32a][tx + 32b], a >= b.  (1) B = G + reg I; (2) rank-1 updates (c-1) y y^T with
-//                    the profile's factor rows staged through LDS 16 at a time; (3) in-place right-looking Cholesky
-//                    (SPD: no pivoting), pivot column and rhs broadcast through double-buffered LDS, one barrier per
-//                    step, forward substitution fused; (4) column-oriented back substitution, one barrier per step.
+//   ials_row_kernel  one 512-thread workgroup per row, rows pulled longest-profile-first from a queue; see the comment above
+//                    the kernel: augmented system in 16 x 16 register tiles, Gramian and trailing updates as MFMAs, blocked
+//                    Cholesky with an in-register diagonal-tile factorisation, back substitution through the tile inverses.
 #include "common.h"
 
 #include <algorithm>
@@ -36,7 +34,14 @@ struct IalsParams {
     const int *order;          // rows of this call, longest profile first
     int n_local;
     unsigned *queue;
+    unsigned long long *phases;   // optional (MI355REC_IALS_PHASES=1): shader-clock totals of {base, Gramian, Cholesky, back substitution}, rows
 };
+
+__device__ __forceinline__ unsigned long long ials_stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
 
 // G += Y[rows]^T Y[rows]; 256 threads as a 16 x 16 grid, thread owns G[ty + 16a][tx + 16b].
 template <int KT16>
@@ -80,140 +85,339 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *Y, int n, int k
         }
 }
 
-// 1024 threads as a 32 x 32 grid.  Thread (ty, tx) owns the cells B[ty + 32a][tx + 32b] of the LOWER-triangular
-// tiles a >= b only (the system is symmetric): KT(KT+1)/2 doubles per thread, 28 at k = 200 -- no spills at the
-// 128-register budget of a 16-wave workgroup.  KT = ceil(k / 32).
-template <int KT>
-__global__ __launch_bounds__(1024) void ials_row_kernel(const IalsParams p) {
-    constexpr int KPAD = KT * 32;
-    __shared__ double ys[CHUNK][KPAD];        // staged factor rows of the profile
-    __shared__ double wts[CHUNK];             // c - 1
-    __shared__ double cfs[CHUNK];             // c
-    __shared__ double pub[2][KPAD];           // pivot column (factorisation) / pivot row (back substitution), double-buffered
-    __shared__ double rhsb[2];
-    __shared__ int s_row;
+// ---- the row solver ---------------------------------------------------------------------------------------------------------
+// One 512-thread workgroup (8 wavefronts) per row.  The augmented system
+//        [ B    rhs ]      B = YtY + Y_I^T (C_I - 1) Y_I + reg I,  rhs = Y_I^T c_I
+//        [ rhs^T  * ]
+// lives in REGISTERS as 16 x 16 tiles of its lower triangle in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane l,
+// element i holds row 4 i + l / 16, column l % 16; checked on the device, scripts/micro/mfma_f64.hip); tile t belongs to
+// wavefront t % 8 (up to 15 tiles = 120 VGPRs per wavefront at k = 224).  Row k of the augmented matrix carries rhs, so its Cholesky row IS the forward substitution.
+//   (1) tiles = G + reg I;
+//   (2) Gramian: profile rows staged through LDS 16 at a time, every tile takes one MFMA per 4 profile rows
+//       (A operand (c - 1) y, B operand y; the rhs row takes c instead of (c - 1) y) -- the FP64 matrix pipe, 2 LDS reads per
+//       512 multiply-adds instead of 14 per 28;
+//   (3) blocked right-looking Cholesky, 16-column panels: panel tiles -> LDS; the diagonal tile is factored by 16 lanes of one
+//       wavefront (a row each, rows broadcast with v_readlane: no barriers inside); triangular solve of the panel, one lane per
+//       row; trailing update tile -= X_I X_J^T on the matrix pipe.  4 barriers per panel (52 at k = 200) instead of one per
+//       column twice over (400);
+//   (4) back substitution by tile rows: x_I from the diagonal tile (16 lanes), then every tile (I, J < I) subtracts its
+//       L^T x_I from segment J.
+// Round 1 kept 32 x 32 register tiles on the FP64 vector pipe with one barrier per column: VALU-issue bound in the
+// factorisation (2240 cycles per column: 28 multiply-adds among ~180 instructions on 16 wavefronts) and staging-latency bound
+// in the Gramian (1440 cycles per profile row); measured 832 k cycles per user row at ML-20M shape, k = 200.
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int TP = 17;                   // padded row length of a 16 x 16 tile staged in LDS (conflict-free operand reads)
+constexpr int MAX_KT = 15, MAX_NT = MAX_KT * (MAX_KT + 1) / 2;
+constexpr int ROW_THREADS = 512, ROW_WAVES = ROW_THREADS / 64;   // 2 wavefronts per SIMD: 256 VGPRs for the tiles of a wavefront
+constexpr double AUG_DIAG = 1e200;       // diagonal of the rhs row: keeps the last pivot positive, never used
 
-    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
-    const int k = p.k;
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)b, src_lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double swap_sum16(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[0] << 32) | (unsigned)lo[0]) +
+           __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[1] << 32) | (unsigned)lo[1]);
+}
+__device__ __forceinline__ double swap_sum32(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[0] << 32) | (unsigned)lo[0]) +
+           __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[1] << 32) | (unsigned)lo[1]);
+}
+
+// doubles of dynamic LDS the kernel needs for k factors
+static inline size_t ials_lds_doubles(int k) {
+    const int KT = (k + 1 + 15) / 16, KP = KT * 16;
+    return (size_t)std::max(2 * CHUNK * KP, KT * 16 * TP) + (size_t)KT * 16 * TP + (size_t)KT * 16 + 3 * (size_t)KP;   // staging | panel, Linv, z / x / acc
+}
+
+// 1 / sqrt(d) in full double precision from v_rsq_f64 and two Newton steps (the IEEE sqrt + divide sequences are ~50
+// instructions on the critical path of every pivot)
+__device__ __forceinline__ double fast_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * (1.5 - 0.5 * d * y * y);
+    y = y * (1.5 - 0.5 * d * y * y);
+    return y;
+}
+
+// The 16 x 16 diagonal tile of a panel (row-major in LDS, TP doubles per row) -> its Cholesky factor in place (upper part
+// cleared) and the inverse of that factor in `inv_tile`.  One wavefront, no barriers inside.
+__device__ __forceinline__ void factor_and_invert_diagonal_tile(double *P, double *inv_tile, int lane) {
+    const int r = lane & 15;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = P[r * TP + c];
+    double my_inv = 0.0;
+    // right-looking, all in registers: lane r holds row r; the pivot and the scaled column travel between lanes as v_readlane
+    // broadcasts (no LDS round trip on the dependent chain: 128 cycles per column when they did)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double d = lane_bcast(a[j], j);
+        const double inv = fast_rsqrt(d);
+        const double lj = r > j ? a[j] * inv : (r == j ? d * inv : 0.0);     // L[r][j]
+        a[j] = lj;
+        if (r == j) my_inv = inv;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) a[c] -= lj * lane_bcast(lj, c);      // only cells with c <= r are ever used
+    }
+    // the inverse, lane c computes column c: x starts as e_c; once x_m is final every later entry loses L[rr][m] x_m
+    double x[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) x[rr] = r == rr ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        x[m] *= lane_bcast(my_inv, m);
+#pragma unroll
+        for (int rr = m + 1; rr < 16; ++rr) x[rr] -= lane_bcast(a[m], rr) * x[m];
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            P[r * TP + c] = c <= r ? a[c] : 0.0;                               // L_JJ, upper part cleared
+            inv_tile[c * TP + r] = x[c];                                       // inverse[c][column r]
+        }
+    }
+}
+
+// The tile coordinates of a wavefront never change, so the compiler hoists every per-tile address computation (4 global
+// addresses + 8 LDS addresses per tile) out of the row loop and then spills them: ~150 live address registers at 13 tiles.
+// Passing the lane coordinates through an empty asm at the start of each phase keeps those computations where they are used.
+__device__ __forceinline__ int not_invariant(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams p) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ short s_tI[MAX_NT], s_tJ[MAX_NT];
+    __shared__ int s_row;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, cl = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k = p.k, KT = (k + 1 + 15) / 16, KP = KT * 16, NT = KT * (KT + 1) / 2;
+    double *const ya = lds;                                         // [CHUNK][KP]   A side: (c - 1) y, c in column k
+    double *const yb = ya + CHUNK * KP;                             // [CHUNK][KP]   B side: y
+    double *const P = lds;                                          // [KT][16][TP]  panel tiles (aliases the staging area)
+    double *const Linv = lds + max(2 * CHUNK * KP, KT * 16 * TP);   // [KT][16][TP]  inverses of the factored diagonal tiles
+    double *const zv = Linv + KT * 16 * TP + KT * 16;               // [KP] forward-substituted rhs
+    double *const xv = zv + KP;                                     // [KP] solution
+    double *const acc = xv + KP;                                    // [KP] sum of L[I][J]^T x_I over the tile rows already solved
+
+    for (int t = tid; t < NT; t += ROW_THREADS) {                   // tile t = I (I + 1) / 2 + J of the lower triangle
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        s_tI[t] = (short)I;
+        s_tJ[t] = (short)(t - I * (I + 1) / 2);
+    }
+    __syncthreads();
+    int tIs[SLOTS], tJs[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int t = wave + ROW_WAVES * s;
+        tIs[s] = t < NT ? __builtin_amdgcn_readfirstlane((int)s_tI[t]) : -1;
+        tJs[s] = t < NT ? __builtin_amdgcn_readfirstlane((int)s_tJ[t]) : -1;
+    }
+    const int Ik = k >> 4, rk = k & 15;                             // tile row and local row of the rhs row
+    // staging roles: wavefront w fetches profile rows 2 w and 2 w + 1 of a chunk, lanes across the factors (4 x 64 >= 224 + 1)
+    constexpr int SPL = 4;
 
     for (;;) {
+        __syncthreads();
         if (tid == 0) s_row = (int)atomicAdd(p.queue, 1u);
         __syncthreads();
         const int slot = s_row;
         if (slot >= p.n_local) break;
         const int row = p.order[slot];
         const int beg = p.ptr[row], end = p.ptr[row + 1];
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (p.phases && tid == 0) t0 = ials_stamp();
 
-        // (1) B = YtY + reg I                                    (IALSRecommender.py:199), lower tiles only
-        double B[KT][KT];
+        // (2a) the first chunk of profile rows is requested before anything else; item ids and confidences run one chunk
+        // further ahead than the factor rows they address (two dependent global round trips otherwise)
+        double pre[2][SPL];
+        double pre_c[2], next_c[2];
+        int next_item[2];
+        auto fetch_ids = [&](int base) {
 #pragma unroll
-        for (int a = 0; a < KT; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) {
-                const int r = ty + 32 * a, c = tx + 32 * b;
-                double v = 0.0;
-                if (r < k && c < k) v = p.G[(size_t)r * k + c] + (r == c ? p.reg : 0.0);
-                else if (r == c) v = 1.0;                        // identity padding keeps the factorisation well defined
-                B[a][b] = v;
+            for (int h = 0; h < 2; ++h) {
+                const int r = base + 2 * wave + h;
+                next_item[h] = r < end ? p.idx[r] : -1;
+                next_c[h] = r < end ? (double)p.conf[r] : 0.0;
             }
-        double rhs = 0.0;                                         // thread t < k carries (Y_I^T c)[t]  (:201)
+        };
+        auto fetch_rows = [&]() {                                    // rows of the ids fetched last
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool ok = next_item[h] >= 0;
+                pre_c[h] = next_c[h];
+                const double *src = p.Y + (size_t)(ok ? next_item[h] : 0) * k;
+#pragma unroll
+                for (int q = 0; q < SPL; ++q) {
+                    const int f = lane + 64 * q;
+                    pre[h][q] = ok && f < k ? src[f] : 0.0;
+                }
+            }
+        };
+        fetch_ids(beg);
+        fetch_rows();
+        fetch_ids(beg + CHUNK);
 
-        // (2) A = Y_I^T ((c - 1) o Y_I), rhs = Y_I^T c           (:197, :201)
+        // (1) B = YtY + reg I                                      (IALSRecommender.py:199)
+        d4 C[SLOTS];
+        {
+        const int g = not_invariant(lane >> 4), cl = not_invariant(lane & 15);
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double v = 0.0;
+                if (tIs[s] >= 0) {
+                    const int r = 16 * tIs[s] + 4 * i + g, c = 16 * tJs[s] + cl;
+                    if (r < k && c < k) v = p.G[(size_t)r * k + c] + (r == c ? p.reg : 0.0);
+                    else if (r == c) v = r == k ? AUG_DIAG : 1.0;   // identity padding keeps the factorisation well defined
+                }
+                C[s][i] = v;
+            }
+            if ((s & 3) == 3) asm volatile("" ::: "memory");         // four tiles' loads in flight at a time: bounded registers
+        }
+        }
+        if (p.phases && tid == 0) { asm volatile("" ::"v"(C[0][0])); t1 = ials_stamp(); }
+
+        // (2) A = Y_I^T ((c - 1) o Y_I), rhs = Y_I^T c             (:197, :201): the matrix pipe works on chunk n while the
+        // loads of chunk n + 1 are in flight
         for (int base = beg; base < end; base += CHUNK) {
             const int nr = min(CHUNK, end - base);
-            __syncthreads();
-            for (int e = tid; e < CHUNK * KPAD; e += 1024) {
-                const int r = e / KPAD, f = e % KPAD;
-                double v = 0.0;
-                if (r < nr && f < k) v = p.Y[(size_t)p.idx[base + r] * k + f];
-                ys[r][f] = v;
-            }
-            if (tid < CHUNK) {
-                const double c = tid < nr ? (double)p.conf[base + tid] : 1.0;
-                cfs[tid] = tid < nr ? c : 0.0;
-                wts[tid] = c - 1.0;
-            }
-            __syncthreads();
-            for (int r = 0; r < nr; ++r) {
-                const double w = wts[r];
-                double yb[KT];
+            __syncthreads();                                         // the previous chunk has been consumed
 #pragma unroll
-                for (int b = 0; b < KT; ++b) yb[b] = ys[r][tx + 32 * b];
+            for (int h = 0; h < 2; ++h) {
+                const int r = 2 * wave + h;
+                const double c = pre_c[h];
 #pragma unroll
-                for (int a = 0; a < KT; ++a) {
-                    const double ya = ys[r][ty + 32 * a] * w;
-#pragma unroll
-                    for (int b = 0; b <= a; ++b) B[a][b] += ya * yb[b];
-                }
-            }
-            if (tid < k) {
-                double s = 0.0;
-                for (int r = 0; r < nr; ++r) s += ys[r][tid] * cfs[r];
-                rhs += s;
-            }
-        }
-
-        // (3) B = L L^T in place (right-looking Cholesky, one published column and one barrier per step), with the
-        // forward substitution L z = rhs fused in.  The tile loop is unrolled at compile time so that every register
-        // index is static.  (The reference forms inv(B) . rhs, :201; same solution.)
-        int step = 0;
-#pragma unroll
-        for (int JB = 0; JB < KT; ++JB) {
-#pragma unroll 1
-            for (int jl = 0; jl < 32; ++jl) {
-                const int j = JB * 32 + jl;
-                if (j >= k) break;
-                const int buf = (step++) & 1;
-                if (tx == jl) {      // owners of column j publish B[:, j] (rows of tiles a >= JB)
-#pragma unroll
-                    for (int a = JB; a < KT; ++a) pub[buf][ty + 32 * a] = B[a][JB];
-                }
-                if (tid == j) rhsb[buf] = rhs;
-                __syncthreads();
-                const double d = pub[buf][j];
-                const double inv = 1.0 / sqrt(d);               // 1 / L_jj
-                const double zj = rhsb[buf] * inv;
-                double lc[KT];
-#pragma unroll
-                for (int b = JB; b < KT; ++b) {
-                    const int c = tx + 32 * b;
-                    lc[b] = c > j ? pub[buf][c] * inv : 0.0;     // L[c][j]; columns <= j are not updated
-                }
-#pragma unroll
-                for (int a = JB; a < KT; ++a) {
-                    const int r = ty + 32 * a;
-                    const double lr = r > j ? pub[buf][r] * inv : 0.0;   // L[r][j]
-#pragma unroll
-                    for (int b = JB; b <= a; ++b) {
-                        double v = B[a][b] - lr * lc[b];
-                        if (b == JB && tx == jl) v = r > j ? lr : (r == j ? d * inv : B[a][b]);   // column j becomes L[:, j]
-                        B[a][b] = v;
+                for (int q = 0; q < SPL; ++q) {
+                    const int f = lane + 64 * q;
+                    if (f < KP) {
+                        const double y = pre[h][q];
+                        ya[r * KP + f] = f == k ? c : y * (c - 1.0);     // (y is 0 beyond k and for rows past the profile)
+                        yb[r * KP + f] = y;
                     }
                 }
-                if (tid < k) rhs = tid == j ? zj : (tid > j ? rhs - pub[buf][tid] * inv * zj : rhs);
             }
-        }
-        // (4) back substitution L^T x = z, column oriented: x_j = z_j / L_jj, then z_c -= L[j][c] x_j for c < j.
-        // Row j of L is held by the threads with ty == j % 32 in the tiles (JA, b <= JA).
+            if (base + CHUNK < end) {
+                fetch_rows();
+                fetch_ids(base + 2 * CHUNK);
+            }
+            __syncthreads();
+            const int groups = (nr + 3) >> 2;
+            const int g = not_invariant(lane >> 4), cl = not_invariant(lane & 15);
+            // all operand reads of a group of 4 profile rows first, then the MFMAs (no branch between them: a wavefront with
+            // fewer tiles than slots runs its spare slot on tile (0, 0) and never looks at the result) -- otherwise every MFMA
+            // waits for its own two LDS reads (117 instead of 32 cycles per MFMA, measured)
+            for (int q = 0; q < groups; ++q) {
+                const double *ar = ya + (4 * q + g) * KP + cl, *br = yb + (4 * q + g) * KP + cl;
+                double av[SLOTS], bv[SLOTS];
 #pragma unroll
-        for (int JA = KT - 1; JA >= 0; --JA) {
-#pragma unroll 1
-            for (int jl = 31; jl >= 0; --jl) {
-                const int j = JA * 32 + jl;
-                if (j >= k) continue;
-                const int buf = (step++) & 1;
-                if (ty == jl) {
-#pragma unroll
-                    for (int b = 0; b <= JA; ++b) pub[buf][tx + 32 * b] = B[JA][b];
+                for (int s = 0; s < SLOTS; ++s) {
+                    av[s] = ar[16 * max(tIs[s], 0)];
+                    bv[s] = br[16 * max(tJs[s], 0)];
                 }
-                if (tid == j) rhsb[buf] = rhs;
-                __syncthreads();
-                const double xj = rhsb[buf] / pub[buf][j];
-                if (tid < k) rhs = tid == j ? xj : (tid < j ? rhs - pub[buf][tid] * xj : rhs);
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) C[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], C[s], 0, 0, 0);
             }
         }
-        if (tid < k) p.X[(size_t)row * k + tid] = rhs;
+        if (p.phases && tid == 0) { asm volatile("" ::"v"(C[0][0])); t2 = ials_stamp(); }
+
+        // (3) blocked Cholesky of the augmented matrix, panel J = columns 16 J .. 16 J + 15
+        for (int J = 0; J < KT; ++J) {
+            const int g = not_invariant(lane >> 4), cl = not_invariant(lane & 15);
+            __syncthreads();                                         // (the staging area / the previous panel is no longer read)
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+                if (tJs[s] == J) {
+                    double *tile = P + (tIs[s] - J) * 16 * TP;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tile[(4 * i + g) * TP + cl] = C[s][i];
+                }
+            __syncthreads();
+            if (wave == 0) factor_and_invert_diagonal_tile(P, Linv + J * 16 * TP, lane);
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                if (tJs[s] == J && tIs[s] > J) {                     // X = T L_JJ^-T on the matrix pipe: the owner's registers ARE the result
+                    double *tile = P + (tIs[s] - J) * 16 * TP;
+                    const double *li = Linv + J * 16 * TP;
+                    d4 X = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) X = __builtin_amdgcn_mfma_f64_16x16x4f64(tile[cl * TP + 4 * q + g], li[cl * TP + 4 * q + g], X, 0, 0, 0);
+                    C[s] = X;
+                    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // (the tile is rewritten below: its operand reads must have issued)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tile[(4 * i + g) * TP + cl] = X[i];
+                } else if (tJs[s] == J) {                            // the diagonal tile: L_JJ
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) C[s][i] = P[(4 * i + g) * TP + cl];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+                if (tJs[s] > J) {                                    // trailing update: tile -= X_I X_J'^T
+                    const double *xa = P + ((tIs[s] - J) * 16 + cl) * TP, *xb = P + ((tJs[s] - J) * 16 + cl) * TP;
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { av[q] = -xa[4 * q + g]; bv[q] = xb[4 * q + g]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) C[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], C[s], 0, 0, 0);
+                }
+        }
+        if (p.phases && tid == 0) { asm volatile("" ::"v"(C[0][0])); t3 = ials_stamp(); }
+
+        // (4) back substitution L^T x = z; z is row k of L (the forward substitution came with the factorisation)
         __syncthreads();
+        for (int f = tid; f < KP; f += ROW_THREADS) { xv[f] = 0.0; acc[f] = 0.0; zv[f] = 0.0; }
+        __syncthreads();
+        const int g = not_invariant(lane >> 4), cl = not_invariant(lane & 15);
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (tIs[s] == Ik && g == (rk & 3)) zv[16 * tJs[s] + cl] = C[s][rk >> 2];
+        __syncthreads();
+        for (int I = KT - 1; I >= 0; --I) {
+            if (wave == 0) {                                         // x_I = L_II^-T (z_I - acc_I): lane c < 16 takes entry c
+                const int c = lane & 15;
+                double t = zv[16 * I + c] - acc[16 * I + c];
+                if (16 * I + c >= k) t = 0.0;                        // the rhs row and the padding are not unknowns
+                double x = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) x += Linv[(I * 16 + m) * TP + c] * lane_bcast(t, m);   // (L^-T)[c][m] = Linv[m][c]
+                if (16 * I + c >= k) x = 0.0;
+                if (lane < 16) xv[16 * I + c] = x;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+                if (tIs[s] == I && tJs[s] < I) {                     // segment J loses L[I][J]^T x_I
+                    double part = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) part += C[s][i] * xv[16 * I + 4 * i + g];
+                    part = swap_sum32(swap_sum16(part));
+                    if (g == 0) atomicAdd(&acc[16 * tJs[s] + cl], part);
+                }
+            __syncthreads();
+        }
+        if (tid < k) p.X[(size_t)row * k + tid] = xv[tid];
+        if (p.phases && tid == 0) {
+            const unsigned long long t4 = ials_stamp();
+            atomicAdd(&p.phases[0], t1 - t0);
+            atomicAdd(&p.phases[1], t2 - t1);
+            atomicAdd(&p.phases[2], t3 - t2);
+            atomicAdd(&p.phases[3], t4 - t3);
+            atomicAdd(&p.phases[4], 1ull);
+        }
     }
 }
 
@@ -273,6 +477,7 @@ struct mi355rec_ials {
     DeviceBuffer<float> u_conf, i_conf;
     DeviceBuffer<double> U, V, G;
     DeviceBuffer<unsigned> queue;
+    DeviceBuffer<unsigned long long> phases;
     std::vector<int> user_order, item_order;     // longest profile first
     std::vector<int> u_ptr_host, i_ptr_host;
     std::vector<int> staging;
@@ -316,20 +521,26 @@ void launch_gram(mi355rec_ials *h, const double *Y, int n) {
     }
 }
 
-template <int KT>
+template <int SLOTS>
 void launch_rows_t(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1) {
-    hipExtLaunchKernelGGL(ials_row_kernel<KT>, dim3(grid), dim3(1024), 0, h->stream, e0, e1, 0, p);
+    const size_t lds = sizeof(double) * ials_lds_doubles(h->k);
+    auto kern = ials_row_kernel<SLOTS>;
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(ROW_THREADS), (unsigned)lds, h->stream, e0, e1, 0, p);
 }
 
 void launch_rows(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1) {
-    switch ((h->k + 31) / 32) {
+    const int KT = (h->k + 1 + 15) / 16, NT = KT * (KT + 1) / 2;
+    switch ((NT + ROW_WAVES - 1) / ROW_WAVES) {          // lower-triangle tiles per wavefront
         case 1: launch_rows_t<1>(h, p, grid, e0, e1); break;
         case 2: launch_rows_t<2>(h, p, grid, e0, e1); break;
-        case 3: launch_rows_t<3>(h, p, grid, e0, e1); break;
-        case 4: launch_rows_t<4>(h, p, grid, e0, e1); break;
-        case 5: launch_rows_t<5>(h, p, grid, e0, e1); break;
-        case 6: launch_rows_t<6>(h, p, grid, e0, e1); break;
-        default: launch_rows_t<7>(h, p, grid, e0, e1); break;
+        case 3: case 4: launch_rows_t<4>(h, p, grid, e0, e1); break;
+        case 5: case 6: launch_rows_t<6>(h, p, grid, e0, e1); break;
+        case 7: case 8: launch_rows_t<8>(h, p, grid, e0, e1); break;
+        case 9: case 10: launch_rows_t<10>(h, p, grid, e0, e1); break;
+        case 11: case 12: launch_rows_t<12>(h, p, grid, e0, e1); break;
+        case 13: launch_rows_t<13>(h, p, grid, e0, e1); break;
+        default: launch_rows_t<15>(h, p, grid, e0, e1); break;
     }
 }
 
@@ -363,11 +574,20 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
     p.order = h->order.ptr;
     p.n_local = n_local;
     p.queue = h->queue.ptr;
+    p.phases = h->phases.ptr;
     const int grid = std::min(n_local, multiprocessor_count());
     hipEvent_t e0 = nullptr, e1 = nullptr;
     h->dispatch_timers.next(e0, e1, 1 << 30);
     launch_rows(h, p, grid, e0, e1);
     MI_HIP(hipGetLastError());
+    if (h->phases.ptr) {
+        unsigned long long ph[5];
+        MI_HIP(hipMemcpyAsync(ph, h->phases.ptr, sizeof(ph), hipMemcpyDeviceToHost, h->stream));
+        MI_HIP(hipStreamSynchronize(h->stream));
+        fprintf(stderr, "[ials phases] %s half: %llu rows; shader cycles per row: base %.0f, Gramian %.0f, Cholesky %.0f, back-substitution %.0f\n",
+                users ? "user" : "item", ph[4], (double)ph[0] / ph[4], (double)ph[1] / ph[4], (double)ph[2] / ph[4], (double)ph[3] / ph[4]);
+        MI_HIP(hipMemsetAsync(h->phases.ptr, 0, sizeof(ph), h->stream));
+    }
     // ALGORITHMIC work, SURVEY.md section 8(d): Gramian 2 * nnz * k^2 flop per pass (+ the k x k base Gramian 2 n k^2),
     // solve k^3/3 + 2 k^2 per row; bytes: gathered factor rows + confidences + the solved rows.
     const double k = h->k;
@@ -408,7 +628,7 @@ extern "C" int mi355rec_ials_create(mi355rec_ials_t *out, int32_t n_users, int32
         MI_REQUIRE(out && indptr && indices && confidence && V0, "NULL argument");
         MI_REQUIRE(n_users > 0 && n_items > 0, "empty URM");
         MI_REQUIRE(n_factors >= 1, "num_factors must be >= 1");
-        if (n_factors > 224)   // 7 x 7 tiles of 32: 28 lower-triangular doubles per thread; the search space stops at 200
+        if (n_factors > 224)   // 15 x 15 tiles of 16 (the rhs row included): 8 tiles per wavefront; the search space stops at 200
             fail(MI355REC_E_UNSUPPORTED, "num_factors = %d: the register-resident solver covers num_factors <= 224", n_factors);
         ensure_device();
         std::unique_ptr<mi355rec_ials> h(new mi355rec_ials());
@@ -445,6 +665,7 @@ extern "C" int mi355rec_ials_create(mi355rec_ials_t *out, int32_t n_users, int32
         h->G.alloc((size_t)h->k * h->k);
         h->order.alloc((size_t)std::max(n_users, n_items));
         h->queue.alloc(1);
+        if (getenv("MI355REC_IALS_PHASES")) h->phases.alloc_zero(5, s);
         h->u_ptr_host.assign(indptr, indptr + n_users + 1);
         h->i_ptr_host.resize((size_t)n_items + 1);
         h->i_ptr.download(h->i_ptr_host.data(), (size_t)n_items + 1, s);
