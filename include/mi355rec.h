@@ -212,6 +212,12 @@ typedef struct {
     uint64_t random_seed;
     int32_t precision;       /* MI355REC_F32 / MI355REC_F64: type of S and of the per-item optimiser cells on the device (the reference
                               * is double throughout; float32 holds 1e-5 for plain sgd, the adaptive optimisers need float64) */
+    int32_t train_with_sparse_weights;   /* 1: the semantics of the Sparse_Matrix_Tree_CSR store (.pyx:582-1030) on the dense
+                              * device array: a cell "has a node" once it has been written; rebalance_tree(TopK) (.pyx:320-324,
+                              * 785-805) keeps the TopK largest nodes per row after every (n_steps / 5)-th step of an epoch, get_S
+                              * selects once more and keeps the selection (.pyx:381-382, 740-780).  Forces symmetric = 0
+                              * (.pyx:112-113) and needs MI355REC_F64 */
+    int32_t topK;            /* sparse store only: the TopK of the selections; 0 = the reference's `topK = False` (no selection) */
     int32_t reserved;
 } mi355rec_slim_config;
 
@@ -228,6 +234,10 @@ int mi355rec_slim_get_last_samples(mi355rec_slim_t h, int32_t *u, int32_t *i, in
 /* get_S: diagonal zeroed, per-ROW top-K (.pyx:343-391): nbr_idx/nbr_val[(row) * topK ...], descending,
  * (-1, 0) padded, zeros never emitted. */
 int mi355rec_slim_get_S_topk(mi355rec_slim_t h, int32_t topK, int32_t *nbr_idx, float *nbr_val);
+/* get_S of the sparse store with topK > 0 (.pyx:343-352, 381-382): the diagonal becomes a node holding zero, every row keeps
+ * its TopK largest nodes (the model changes, as in the reference), and the surviving NON-ZERO nodes of row r are listed in
+ * column order in nbr_idx/nbr_val[r * topK ...], (-1, 0) padded (from_linked_list_to_python_list :862-875). */
+int mi355rec_slim_get_S_sparse(mi355rec_slim_t h, int32_t *nbr_idx, float *nbr_val);
 /* Dense S (n_items x n_items, row-major, diagonal zeroed, symmetric mode mirrored). */
 int mi355rec_slim_get_S_dense(mi355rec_slim_t h, float *S);
 int mi355rec_slim_get_stats(mi355rec_slim_t h, mi355rec_stats *stats);

@@ -84,6 +84,10 @@ def lib():
         L.orc_slim_epoch.argtypes = [_p]
         L.orc_slim_replay.argtypes = [_p, _p, _p, _p, C.c_int64]
         L.orc_slim_get_S.argtypes = [_p, _p]
+        L.orc_slim_set_sparse.argtypes = [_p, C.c_int32]
+        L.orc_slim_sparse_get_S.restype = C.c_int64
+        L.orc_slim_sparse_get_S.argtypes = [_p, _p]
+        L.orc_slim_sparse_cells.argtypes = [_p, _p, _p]
         L.orc_sim_column.restype = C.c_int32
         L.orc_sim_column.argtypes = ([C.c_int32, C.c_int32] + [_p] * 7 + [C.c_int32] * 3 + [_p] * 3
                                      + [C.c_double] * 2 + [_p] * 3)
@@ -217,20 +221,21 @@ class OracleMF:
 # --------------------------------------------------------------------------------------------------
 
 class OracleSLIM:
-    """Restates SLIM_BPR_Cython_Epoch (dense and symmetric-triangular stores; batch_size is 1 as the wrapper
-    hard-codes, SLIM_BPR/Cython/SLIM_BPR_Cython.py:140).  Sparse-tree training mode is not restated."""
+    """Restates SLIM_BPR_Cython_Epoch (dense, symmetric-triangular and sparse-tree stores; batch_size is 1 as the wrapper
+    hard-codes, SLIM_BPR/Cython/SLIM_BPR_Cython.py:140).  The sparse-tree store (train_with_sparse_weights=True,
+    Sparse_Matrix_Tree_CSR .pyx:582-1030) is restated as the dense array plus a node-exists map: per-row top-K selection at
+    the rebalance points of the epoch (.pyx:320-324) and inside get_S (.pyx:381-382), which mutates the model."""
 
     def __init__(self, URM_mask, train_with_sparse_weights=False, final_model_sparse_weights=True,
                  learning_rate=0.01, li_reg=0.0, lj_reg=0.0, batch_size=1, topK=150, symmetric=True,
                  verbose=False, random_seed=None, sgd_mode="adam", gamma=0.995, beta_1=0.9, beta_2=0.999):
-        if train_with_sparse_weights:
-            raise NotImplementedError("oracle restates the dense and symmetric stores only")
         if sgd_mode not in SGD_MODES:
             raise ValueError("Value for 'sgd_mode' not recognized: %r" % (sgd_mode,))
         URM = _sorted_csr(URM_mask)
         self.n_users, self.n_items = URM.shape
         self.topK = topK
-        self.symmetric = bool(symmetric)
+        self.sparse = bool(train_with_sparse_weights)
+        self.symmetric = bool(symmetric) and not self.sparse                 # .pyx:112-113
         self.final_model_sparse_weights = final_model_sparse_weights
         self._indptr = np.ascontiguousarray(URM.indptr, dtype=np.int32)
         self._indices = np.ascontiguousarray(URM.indices, dtype=np.int32)
@@ -240,6 +245,8 @@ class OracleSLIM:
         self._h = L.orc_slim_create(self.n_users, self.n_items, _ptr(self._indptr), _ptr(self._indices),
                                     int(self.symmetric), SGD_MODES[sgd_mode], learning_rate, li_reg, lj_reg,
                                     gamma, beta_1, beta_2)
+        if self.sparse:
+            L.orc_slim_set_sparse(self._h, int(topK) if topK else 0)
         self._rec = None
 
     def __del__(self):
@@ -270,6 +277,13 @@ class OracleSLIM:
 
     def get_S(self):
         """get_S (.pyx:343-391): diagonal zeroed, then per-ROW top-K -> CSR (or the dense array)."""
+        if self.sparse:                       # the tree's non-zero nodes in column order; the selection is kept in the model
+            counts = np.zeros(self.n_items, np.int32)
+            total = lib().orc_slim_sparse_get_S(self._h, _ptr(counts))
+            cols = np.zeros(total, np.int32); data = np.zeros(total, np.float64)
+            lib().orc_slim_sparse_cells(self._h, _ptr(cols), _ptr(data))
+            indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+            return sps.csr_matrix((data, cols, indptr), shape=(self.n_items, self.n_items))
         S = self.get_S_dense()
         if not self.final_model_sparse_weights and not self.symmetric:
             return S

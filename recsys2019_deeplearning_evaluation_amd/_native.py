@@ -56,7 +56,7 @@ class SlimConfig(C.Structure):
     _fields_ = [("symmetric", C.c_int32), ("sgd_mode", C.c_int32), ("learning_rate", C.c_double),
                 ("li_reg", C.c_double), ("lj_reg", C.c_double),
                 ("gamma", C.c_double), ("beta_1", C.c_double), ("beta_2", C.c_double), ("random_seed", C.c_uint64),
-                ("precision", C.c_int32), ("reserved", C.c_int32)]
+                ("precision", C.c_int32), ("train_with_sparse_weights", C.c_int32), ("topK", C.c_int32), ("reserved", C.c_int32)]
 
 
 _vp = C.c_void_p
@@ -96,6 +96,7 @@ SIGNATURES = {
     "mi355rec_slim_run_samples": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
     "mi355rec_slim_get_last_samples": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     "mi355rec_slim_get_S_topk": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "mi355rec_slim_get_S_sparse": (C.c_int, [_vp, _vp, _vp]),
     "mi355rec_slim_get_S_dense": (C.c_int, [_vp, _vp]),
     "mi355rec_slim_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "mi355rec_slim_destroy": (None, [_vp]),

@@ -423,6 +423,238 @@ __global__ void slim_dense_kernel(const SlimParams<T> p, float *out) {
     }
 }
 
+// ---- the sparse-tree store's semantics on the dense array (Sparse_Matrix_Tree_CSR, .pyx:582-1030) --------------------------
+// A cell "has a node" once add_value has written it.  Cells without a node hold the bit pattern of -0.0: it reads as zero,
+// any update a + lr * g of a step turns it into an ordinary value, and no arithmetic of the epoch produces it again (an
+// update that is exactly -0.0 would; that needs a gradient that underflowed to zero).
+constexpr unsigned long long NO_NODE = 0x8000000000000000ull;
+constexpr int PRUNE_THREADS = 256;
+
+__global__ __launch_bounds__(256) void slim_no_nodes_kernel(unsigned long long *S, size_t n_cells) {
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n_cells; e += (size_t)gridDim.x * blockDim.x) S[e] = NO_NODE;
+}
+
+// unsigned key in the order of the doubles
+__device__ __forceinline__ unsigned long long order_key(unsigned long long bits) {
+    return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
+}
+
+// topK_selection_from_list on every row (.pyx:957-1030), as rebalance_tree(TopK) :785-805 and get_scipy_csr(TopK) :740-780 apply
+// it: a row with fewer than TopK nodes is left alone, otherwise the TopK largest values stay; among equal values the HIGHER
+// columns stay (glibc's qsort is a stable merge sort and compare_struct_on_data :553-568 never answers "equal", so ties keep
+// their column order and the last TopK of the sorted array are taken).  Dropped nodes are freed: no node, value zero.
+//
+// One workgroup per row.  The row is streamed once to count its nodes (most of the work: n_items^2 * 8 bytes per call, HBM
+// bound).  A row that has to be cut is read again (from L2) and its nodes are packed, in column order, into LDS, where an
+// 8-bit radix select finds the TopK-th value; rows with more than PRUNE_CAP nodes run the same select over the row itself.
+// The select stops as soon as the bucket holding the TopK-th value is wanted whole.
+constexpr int PRUNE_CAP = 2048;
+
+struct PruneShared {
+    unsigned hist[256];
+    unsigned wave_count[PRUNE_THREADS / 64];
+    unsigned keep, bucket;
+    unsigned long long prefix;
+    unsigned long long keys[PRUNE_CAP];
+    int cols[PRUNE_CAP];
+};
+
+// the row itself as the select's source: position = column
+struct RowSource {
+    unsigned long long *row;
+    int n;
+    __device__ __forceinline__ int size() const { return n; }
+    __device__ __forceinline__ bool key(int at, unsigned long long &k) const {
+        const unsigned long long b = row[at];
+        k = order_key(b);
+        return b != NO_NODE;
+    }
+    __device__ __forceinline__ void drop(int at) const { row[at] = NO_NODE; }
+};
+// the packed nodes in LDS (column order)
+struct PackedSource {
+    unsigned long long *row;
+    const unsigned long long *keys;
+    const int *cols;
+    int len;
+    __device__ __forceinline__ int size() const { return len; }
+    __device__ __forceinline__ bool key(int at, unsigned long long &k) const { k = keys[at]; return true; }
+    __device__ __forceinline__ void drop(int at) const { row[cols[at]] = NO_NODE; }
+};
+
+template <class Src>
+__device__ __forceinline__ void select_and_drop(const Src src, const int topK, PruneShared &sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int size = src.size();
+    // radix select, most significant byte first: after a pass the wanted value's leading bytes are `prefix`, `keep` of the
+    // keys that share them stay (all keys above them stay anyway)
+    unsigned keep = (unsigned)topK, bucket = 0;
+    unsigned long long prefix = 0;
+    int shift = 64;
+    while (shift > 0) {
+        shift -= 8;
+        sh.hist[tid] = 0;                                           // (PRUNE_THREADS == 256)
+        __syncthreads();
+        for (int at = tid; at < size; at += PRUNE_THREADS) {
+            unsigned long long k;
+            if (!src.key(at, k)) continue;
+            if (shift == 56 || (k >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(unsigned)(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) {                                            // lane l owns digits 4l .. 4l+3; suffix sums from the top digit down
+            const unsigned h0 = sh.hist[4 * lane], h1 = sh.hist[4 * lane + 1], h2 = sh.hist[4 * lane + 2], h3 = sh.hist[4 * lane + 3];
+            const unsigned own = h0 + h1 + h2 + h3;
+            unsigned incl = own;                                    // sum over lanes >= this one
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned v = __shfl_down(incl, off);
+                if (lane + off < 64) incl += v;
+            }
+            const unsigned long long reach = __ballot(incl >= keep);
+            const int owner = 63 - __builtin_clzll(reach);          // the highest lane whose suffix reaches `keep`
+            if (lane == owner) {
+                unsigned above = incl - own;                        // keys in higher digits
+                int d = 3;
+                unsigned hd = h3;
+                if (above + hd < keep) { above += hd; d = 2; hd = h2; }
+                if (d == 2 && above + hd < keep) { above += hd; d = 1; hd = h1; }
+                if (d == 1 && above + hd < keep) { above += hd; d = 0; hd = h0; }
+                sh.prefix = (prefix << 8) | (unsigned long long)(4 * lane + d);
+                sh.keep = keep - above;
+                sh.bucket = hd;
+            }
+        }
+        __syncthreads();
+        prefix = sh.prefix;
+        keep = sh.keep;
+        bucket = sh.bucket;
+        if (bucket == keep) break;                                  // the whole bucket stays: nothing left to split
+    }
+    // keys whose leading bytes are below `prefix` go; of the `bucket` keys equal to it the `keep` highest columns stay
+    const unsigned drop_ties = bucket - keep;                       // > 0 only after all 8 passes: equal VALUES
+    unsigned ties_before = 0;                                       // ties in lower columns (only tracked when some must go)
+    for (int at0 = 0; at0 < size; at0 += PRUNE_THREADS) {
+        const int at = at0 + tid;
+        bool tie = false, drop = false;
+        if (at < size) {
+            unsigned long long k;
+            if (src.key(at, k)) {
+                k >>= shift;
+                drop = k < prefix;
+                tie = k == prefix;
+            }
+        }
+        if (drop_ties) {
+            const unsigned long long m = __ballot(tie);
+            __syncthreads();
+            if (lane == 0) sh.wave_count[wave] = (unsigned)__builtin_popcountll(m);
+            __syncthreads();
+            unsigned before = ties_before, total = 0;
+#pragma unroll
+            for (int w = 0; w < PRUNE_THREADS / 64; ++w) {
+                if (w < wave) before += sh.wave_count[w];
+                total += sh.wave_count[w];
+            }
+            before += (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (tie && before < drop_ties) drop = true;             // the first (lowest-column) `drop_ties` ties go
+            ties_before += total;
+        }
+        if (drop) src.drop(at);
+    }
+    __syncthreads();
+}
+
+// with_diag: get_S gives the diagonal a node holding zero first (.pyx:350-351).
+__global__ __launch_bounds__(PRUNE_THREADS) void slim_prune_kernel(unsigned long long *S, int n, int topK, int with_diag) {
+    __shared__ PruneShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // every wavefront owns one contiguous quarter of the row (whole 64-column groups)
+    const int seg = ((n + PRUNE_THREADS - 1) / PRUNE_THREADS) * 64;
+    const int c_begin = min(wave * seg, n), c_end = min(c_begin + seg, n);
+    for (int r = blockIdx.x; r < n; r += gridDim.x) {
+        unsigned long long *row = S + (size_t)r * n;
+        if (with_diag && tid == 0) row[r] = 0ull;               // a node holding +0.0
+        __syncthreads();
+        unsigned mine = 0;
+        int c = c_begin + lane;
+        for (; c + 192 < c_end; c += 256) {                     // four independent loads in flight per lane
+            const unsigned long long b0 = row[c], b1 = row[c + 64], b2 = row[c + 128], b3 = row[c + 192];
+            mine += (b0 != NO_NODE) + (b1 != NO_NODE) + (b2 != NO_NODE) + (b3 != NO_NODE);
+        }
+        for (; c < c_end; c += 64) mine += row[c] != NO_NODE;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+        if (lane == 0) sh.wave_count[wave] = mine;
+        __syncthreads();
+        unsigned len = 0, base = 0;
+#pragma unroll
+        for (int w = 0; w < PRUNE_THREADS / 64; ++w) {
+            if (w < wave) base += sh.wave_count[w];
+            len += sh.wave_count[w];
+        }
+        __syncthreads();
+        if (topK <= 0 || len <= (unsigned)topK) continue;        // (len == TopK: the selection keeps everything)
+        if (len <= (unsigned)PRUNE_CAP) {
+            // pack (key, column) in column order: wavefront w writes from `base`, lanes by ballot rank
+            for (int c0 = c_begin; c0 < c_end; c0 += 64) {
+                const int cc = c0 + lane;
+                const unsigned long long b = cc < c_end ? row[cc] : NO_NODE;
+                const bool node = b != NO_NODE;
+                const unsigned long long m = __ballot(node);
+                if (node) {
+                    const unsigned at = base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    sh.keys[at] = order_key(b);
+                    sh.cols[at] = cc;
+                }
+                base += (unsigned)__builtin_popcountll(m);
+            }
+            __syncthreads();
+            select_and_drop(PackedSource{row, sh.keys, sh.cols, (int)len}, topK, sh);
+        } else {
+            select_and_drop(RowSource{row, n}, topK, sh);
+        }
+    }
+}
+
+// from_linked_list_to_python_list (.pyx:862-875) for every row after the selection: the non-zero nodes in column order.
+__global__ __launch_bounds__(PRUNE_THREADS) void slim_list_kernel(const unsigned long long *S, int n, int width, int *out_idx, float *out_val) {
+    __shared__ unsigned s_wave[PRUNE_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int r = blockIdx.x; r < n; r += gridDim.x) {
+        const unsigned long long *row = S + (size_t)r * n;
+        unsigned at = 0;
+        for (int c0 = 0; c0 < n; c0 += PRUNE_THREADS) {
+            const int c = c0 + tid;
+            double v = 0.0;
+            if (c < n) {
+                const unsigned long long b = row[c];
+                if (b != NO_NODE) v = __longlong_as_double((long long)b);
+            }
+            const bool listed = v != 0.0;
+            const unsigned long long m = __ballot(listed);
+            if (lane == 0) s_wave[wave] = (unsigned)__builtin_popcountll(m);
+            __syncthreads();
+            unsigned pos = at, total = 0;
+#pragma unroll
+            for (int w = 0; w < PRUNE_THREADS / 64; ++w) {
+                if (w < wave) pos += s_wave[w];
+                total += s_wave[w];
+            }
+            pos += (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (listed && pos < (unsigned)width) {
+                out_idx[(size_t)r * width + pos] = c;
+                out_val[(size_t)r * width + pos] = (float)v;
+            }
+            at += total;
+            __syncthreads();
+        }
+        for (unsigned q = min(at, (unsigned)width) + tid; q < (unsigned)width; q += PRUNE_THREADS) {
+            out_idx[(size_t)r * width + q] = -1;
+            out_val[(size_t)r * width + q] = 0.f;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace mi355rec
 
@@ -505,12 +737,13 @@ int bits_for(unsigned long long n_values) {
     return b;
 }
 
-// Runs the n steps currently in su/si/sj exactly in stream order.
+// Runs n steps of su/si/sj, starting at step `first`, exactly in stream order.
 template <class T>
-void run_stream(mi355rec_slim *h, int n, double &sum_profile) {
+void run_stream(mi355rec_slim *h, int n, double &sum_profile, int first = 0) {
     hipStream_t s = h->stream;
     SlimParams<T> p{};
     fill_params(h, p);
+    p.su += first; p.si += first; p.sj += first;
     p.n_steps = n;
     const bool sym = h->cfg.symmetric != 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -526,7 +759,7 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile) {
     ensure_sort_capacity(h, std::max<size_t>(2 * (size_t)n, 1024));
     DepParams d{};
     d.n_steps = n; d.n_items = h->n_items;
-    d.indptr = h->indptr.ptr; d.indices = h->indices.ptr; d.su = h->su.ptr; d.si = h->si.ptr; d.sj = h->sj.ptr;
+    d.indptr = h->indptr.ptr; d.indices = h->indices.ptr; d.su = h->su.ptr + first; d.si = h->si.ptr + first; d.sj = h->sj.ptr + first;
     d.keys = h->keys.ptr; d.vals = h->vals.ptr; d.keys_sorted = h->keys_sorted.ptr; d.vals_sorted = h->vals_sorted.ptr;
     d.seq = h->seq.ptr; d.len2 = h->len2.ptr; d.cellptr = h->cellptr.ptr; d.pred = h->pred.ptr;
     hipLaunchKernelGGL(slim_item_keys_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d);
@@ -554,6 +787,7 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile) {
                                                   h->vals_sorted.ptr, (int)n_cells, 0, 64, s));
         hipLaunchKernelGGL(slim_pred_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, s, d);
         fill_params(h, p);          // (the sort buffers may have been re-allocated)
+        p.su += first; p.si += first; p.sj += first;
         p.n_steps = n;
         MI_HIP(hipMemsetAsync(h->done.ptr, 0, sizeof(int) * (size_t)n, s));
     }
@@ -572,6 +806,36 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile) {
     MI_HIP(hipStreamSynchronize(s));
     if (flags[1]) fail(MI355REC_E_HIP, "SLIM-BPR: a hand-off between steps did not arrive (dataflow kernel aborted)");
     h->steps_done += n;
+}
+
+void prune_rows(mi355rec_slim *h, int with_diag) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    h->dispatch_timers.next(e0, e1, 1 << 30);
+    hipExtLaunchKernelGGL(slim_prune_kernel, dim3(std::min(h->n_items, multiprocessor_count() * 8)), dim3(PRUNE_THREADS), 0, h->stream,
+                          e0, e1, 0, reinterpret_cast<unsigned long long *>(h->S.ptr), h->n_items, h->cfg.topK, with_diag);
+    h->stats.n_launches += 1;
+    MI_HIP(hipGetLastError());
+}
+
+// One epoch of n steps on whichever store the handle has.  Sparse store: the stream is cut after every step whose index is a
+// positive multiple of n / 5 -- `numCurrentBatch % (totalNumberOfBatch/5) == 0 and numCurrentBatch != 0` with C integer
+// division (.pyx:320-324; the module sets cdivision) -- and the rows are pruned there.
+template <class T>
+void run_epoch_stream(mi355rec_slim *h, int n, double &sum_profile) {
+    if (!h->cfg.train_with_sparse_weights || n < 5) {
+        run_stream<T>(h, n, sum_profile);
+        return;
+    }
+    const int every = n / 5;
+    int first = 0;
+    while (first < n) {
+        // steps first .. cut (inclusive) run, then the rows are pruned if `cut` is a rebalance point
+        const int cut = std::max(1, (first + every - 1) / every) * every;      // next multiple of `every` at or after `first`, never step 0
+        const int last = std::min(cut, n - 1);
+        run_stream<T>(h, last - first + 1, sum_profile, first);
+        if (cut <= n - 1) prune_rows(h, 0);
+        first = last + 1;
+    }
 }
 
 void begin_call(mi355rec_slim *h) {
@@ -608,7 +872,7 @@ void run_epochs_typed(mi355rec_slim *h, int n_epochs) {
         fill_params(h, p);
         p.n_steps = n;
         hipLaunchKernelGGL(slim_sample_kernel<T>, dim3(div_up(n, 256)), dim3(256), 0, h->stream, p, h->su.ptr, h->si.ptr, h->sj.ptr);
-        run_stream<T>(h, n, sum_profile);
+        run_epoch_stream<T>(h, n, sum_profile);
         h->epochs_done += 1;
     }
     end_call(h, (long long)n * n_epochs, sum_profile);
@@ -664,6 +928,11 @@ extern "C" int mi355rec_slim_create(mi355rec_slim_t *out, const mi355rec_slim_co
         ensure_device();
         std::unique_ptr<mi355rec_slim> h(new mi355rec_slim());
         h->cfg = *cfg;
+        if (cfg->train_with_sparse_weights) {
+            MI_REQUIRE(cfg->precision == MI355REC_F64, "train_with_sparse_weights needs precision MI355REC_F64 (the selections compare values)");
+            MI_REQUIRE(cfg->topK >= 0, "topK must be >= 0 (0 = False)");
+            h->cfg.symmetric = 0;                                // .pyx:112-113
+        }
         h->n_users = n_users;
         h->n_items = n_items;
         h->f64 = cfg->precision == MI355REC_F64;
@@ -677,6 +946,9 @@ extern "C" int mi355rec_slim_create(mi355rec_slim_t *out, const mi355rec_slim_co
         h->indptr.upload(indptr, (size_t)n_users + 1, s);
         h->indices.upload(indices, h->nnz, s);
         h->S.alloc_zero((size_t)n_items * n_items * ts, s);          // .pyx:129 / :1237-1254
+        if (h->cfg.train_with_sparse_weights)                        // .pyx:124: an empty tree per row
+            hipLaunchKernelGGL(slim_no_nodes_kernel, dim3(multiprocessor_count() * 8), dim3(256), 0, s,
+                               reinterpret_cast<unsigned long long *>(h->S.ptr), (size_t)n_items * n_items);
         h->c1.alloc_zero((size_t)n_items * ts, s);
         h->c2.alloc_zero((size_t)n_items * ts, s);
         h->ticket.alloc_zero((size_t)n_items, s);
@@ -712,7 +984,8 @@ extern "C" int mi355rec_slim_run_samples(mi355rec_slim_t h, const int32_t *u, co
         MI_HIP(hipMemcpyAsync(h->sj.ptr, j, sizeof(int) * n, hipMemcpyHostToDevice, s));
         begin_call(h);
         double sum_profile = 0;
-        if (h->f64) run_stream<double>(h, (int)n, sum_profile); else run_stream<float>(h, (int)n, sum_profile);
+        // (the n samples are ONE epoch of n steps: that is what the sparse store's rebalance rule counts against)
+        if (h->f64) run_epoch_stream<double>(h, (int)n, sum_profile); else run_epoch_stream<float>(h, (int)n, sum_profile);
         end_call(h, n, sum_profile);
     });
 }
@@ -739,6 +1012,28 @@ extern "C" int mi355rec_slim_get_S_topk(mi355rec_slim_t h, int32_t topK, int32_t
         topK = std::min(topK, h->n_items);
         if (topK > MAX_TOPK) fail(MI355REC_E_UNSUPPORTED, "topK = %d exceeds the in-LDS selection limit of %d", topK, MAX_TOPK);
         if (h->f64) get_topk_typed<double>(h, topK, nbr_idx, nbr_val); else get_topk_typed<float>(h, topK, nbr_idx, nbr_val);
+    });
+}
+
+extern "C" int mi355rec_slim_get_S_sparse(mi355rec_slim_t h, int32_t *nbr_idx, float *nbr_val) {
+    return guarded([&] {
+        MI_REQUIRE(h && nbr_idx && nbr_val, "NULL argument");
+        MI_REQUIRE(h->cfg.train_with_sparse_weights && h->cfg.topK >= 1, "handle was not created with train_with_sparse_weights and topK >= 1");
+        ensure_device();
+        const int width = h->cfg.topK;
+        const size_t n_out = (size_t)h->n_items * width;
+        DeviceBuffer<int> d_idx;
+        DeviceBuffer<float> d_val;
+        d_idx.alloc(n_out);
+        d_val.alloc(n_out);
+        h->dispatch_timers.reset();
+        prune_rows(h, 1);
+        hipLaunchKernelGGL(slim_list_kernel, dim3(std::min(h->n_items, multiprocessor_count() * 8)), dim3(PRUNE_THREADS), 0, h->stream,
+                           reinterpret_cast<const unsigned long long *>(h->S.ptr), h->n_items, width, d_idx.ptr, d_val.ptr);
+        MI_HIP(hipGetLastError());
+        d_idx.download(nbr_idx, n_out, h->stream);
+        d_val.download(nbr_val, n_out, h->stream);
+        MI_HIP(hipStreamSynchronize(h->stream));
     });
 }
 

@@ -4,10 +4,11 @@ Mirrors
   SLIM_BPR_Cython_Epoch   SLIM_BPR/Cython/SLIM_BPR_Cython_Epoch.pyx:59 (ctor :87-135, epochIteration_Cython :212,
                           get_S :343-391, _dealloc :195)
   SLIM_BPR_Cython         SLIM_BPR/Cython/SLIM_BPR_Cython.py:50 (fit :78-171)
-The dense and the symmetric (triangular) weight stores are on the device; the sparse-tree training mode
-(train_with_sparse_weights=True, Sparse_Matrix_Tree_CSR :582) changes the learned model through its periodic
-top-K pruning and is not provided: it raises NotImplementedError.  As in the reference wrapper the epoch object is
-always driven with batch_size = 1 (SLIM_BPR_Cython.py:140).
+The dense and the symmetric (triangular) weight stores are on the device.  The sparse-tree training mode
+(train_with_sparse_weights=True, Sparse_Matrix_Tree_CSR :582) changes the learned model through its periodic per-row
+top-K selection (rebalance_tree :785, at the fifths of every epoch :320-324, and again inside get_S :381-382); those
+SEMANTICS run on the same dense device array (cells know whether they "have a node"), float64 like the reference.
+As in the reference wrapper the epoch object is always driven with batch_size = 1 (SLIM_BPR_Cython.py:140).
 """
 import ctypes as C
 import sys
@@ -35,15 +36,22 @@ class SLIM_BPR_MI355X_Epoch:
         if sgd_mode not in N.SGD_MODE_CODES:
             raise ValueError("Value for 'sgd_mode' not recognized. Acceptable values are {}, provided was '{}'".format(
                 list(N.SGD_MODE_CODES), sgd_mode))
-        if train_with_sparse_weights:
-            raise NotImplementedError("SLIM_BPR: the sparse-tree training store is not on the MI355X device path")
         if batch_size != 1:
             raise NotImplementedError("SLIM_BPR: the reference wrapper always trains with batch_size=1; so does the device path")
-        if precision == "auto":         # float64 S and optimiser cells for the adaptive modes (the reference is double throughout)
-            precision = "fp32" if sgd_mode == "sgd" else "fp64"
+        self.train_with_sparse_weights = bool(train_with_sparse_weights)
+        if topK is not False and topK is not None and topK < 0:
+            raise ValueError("TopK not valid. Acceptable values are either False or a positive integer value. "
+                             "Provided value was '{}'".format(topK))
+        if precision == "auto":         # float64 S and optimiser cells for the adaptive modes (the reference is double throughout);
+            # the sparse store's selections compare values, so it keeps the reference's float64 as well
+            precision = "fp32" if sgd_mode == "sgd" and not self.train_with_sparse_weights else "fp64"
         if precision not in N.PRECISION_CODES:
             raise ValueError("Value for 'precision' not recognized. Acceptable values are {}, provided was '{}'".format(
                 ["auto"] + list(N.PRECISION_CODES), precision))
+        if self.train_with_sparse_weights:
+            if precision != "fp64":
+                raise ValueError("train_with_sparse_weights keeps float64 weights (precision 'auto' or 'fp64')")
+            symmetric = False               # .pyx:112-113
         self.precision = precision
         URM_mask = check_matrix(URM_mask, "csr")
         URM_mask = URM_mask.sorted_indices()
@@ -54,7 +62,8 @@ class SLIM_BPR_MI355X_Epoch:
         self.verbose = verbose
         seed = int(random_seed) if random_seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
         cfg = N.SlimConfig(int(self.symmetric), N.SGD_MODE_CODES[sgd_mode], learning_rate, li_reg, lj_reg, gamma, beta_1,
-                           beta_2, seed & (2 ** 64 - 1), N.PRECISION_CODES[precision], 0)
+                           beta_2, seed & (2 ** 64 - 1), N.PRECISION_CODES[precision], int(self.train_with_sparse_weights),
+                           int(topK) if topK else 0, 0)
         indptr, indices = N.as_i32(URM_mask.indptr), N.as_i32(URM_mask.indices)
         self._lib = N.load()
         self._h = C.c_void_p()
@@ -108,6 +117,13 @@ class SLIM_BPR_MI355X_Epoch:
     def get_S(self):
         """Same return convention as the reference (.pyx:343-391): csr with per-row top-K, or the dense array when
         final_model_sparse_weights is False on the dense store, or the full matrix as csr when topK is False."""
+        if self.train_with_sparse_weights:
+            # get_scipy_csr of the tree (.pyx:363-366, 381-382): the non-zero nodes, after (and keeping) the per-row selection
+            if not self.topK:
+                return sps.csr_matrix(self.get_S_dense().astype(np.float64))
+            idx = np.empty((self.n_items, int(self.topK)), np.int32); val = np.empty((self.n_items, int(self.topK)), np.float32)
+            N.check(self._lib.mi355rec_slim_get_S_sparse(self._h, N.ptr(idx), N.ptr(val)))
+            return rows_slabs_to_csr(idx, val, self.n_items)
         if not self.topK:
             S = self.get_S_dense().astype(np.float64)
             return S if (not self.symmetric and not self.final_model_sparse_weights) else sps.csr_matrix(S)
@@ -138,7 +154,8 @@ class _SLIMLogic:
             beta_1=0.9, beta_2=0.999, **earlystopping_kwargs):
         self.symmetric = symmetric
         # the reference picks dense vs sparse-tree from free host RAM (.py:97-114); on the device S always lives
-        # densely in HBM (288 GB), so "auto" means dense
+        # densely in HBM (288 GB), so "auto" means dense.  train_with_sparse_weights=True selects the sparse store's
+        # SEMANTICS (periodic per-row top-K selection), still on the dense device array.
         self.train_with_sparse_weights = bool(train_with_sparse_weights) if train_with_sparse_weights is not None else False
         URM_train_positive = self.URM_train.copy()
         self.positive_threshold_BPR = positive_threshold_BPR
@@ -179,7 +196,10 @@ class _SLIMLogic:
 
     def get_S_incremental_and_set_W(self):
         self.S_incremental = self.epoch_kernel.get_S()
-        self.W_sparse = similarityMatrixTopK(self.S_incremental, k=self.topK) if self.topK else self.S_incremental
+        if self.train_with_sparse_weights or not self.topK:          # .py:193-195: the tree's get_S has selected already
+            self.W_sparse = self.S_incremental
+        else:
+            self.W_sparse = similarityMatrixTopK(self.S_incremental, k=self.topK)
         self.W_sparse = check_matrix(self.W_sparse, format="csr")
 
 

@@ -145,6 +145,29 @@ def main():
     out["cases"] = np.array(json.dumps(cases))
     np.savez_compressed(os.path.join(HERE, "slim_bpr.npz"), **out)
 
+    # ---------------- SLIM-BPR, sparse-tree store (train_with_sparse_weights=True) ----------------
+    # 79 users -> 80 steps per epoch (a multiple of 5: four rebalance points), 81 users -> 82 steps (five: 16, 32, 48, 64, 80);
+    # get_S is called in the middle of training too, because it prunes the model (SLIM_BPR_Cython_Epoch.pyx:381-382, 740-780)
+    out = {}
+    cases = []
+    for n_users, topK, mode, regs in [(79, 4, "sgd", (0.0, 0.0)), (81, 4, "sgd", (0.0, 0.0)), (79, 6, "adam", (0.01, 0.02)),
+                                      (81, 3, "adagrad", (0.0, 0.03)), (79, False, "rmsprop", (0.01, 0.0)), (81, 25, "sgd", (0.02, 0.0))]:
+        cases.append(dict(n_users=n_users, epochs=[2, 1], kw=dict(topK=topK, random_seed=404, sgd_mode=mode, learning_rate=0.05,
+                                                                 li_reg=regs[0], lj_reg=regs[1], train_with_sparse_weights=True)))
+    urms = {nu: small_urm(nu, 30, 0.2, 16, real=False) for nu in (79, 81)}
+    for nu, Xs in urms.items():
+        out.update(pack_csr("X%d" % nu, Xs))
+    for n, case in enumerate(cases):
+        e = SLIM(urms[case["n_users"]], **case["kw"])
+        for m, epochs in enumerate(case["epochs"]):
+            for _ in range(epochs):
+                quiet(e.epochIteration_Cython)
+            S = quiet(e.get_S)
+            out["indptr_%d_%d" % (n, m)] = S.indptr; out["indices_%d_%d" % (n, m)] = S.indices; out["data_%d_%d" % (n, m)] = S.data
+        quiet(e._dealloc)
+    out["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(HERE, "slim_bpr_sparse.npz"), **out)
+
     # ---------------- IALS (pure-Python reference) ----------------
     IALS = ref_loader.load_python_reference("MatrixFactorization.IALSRecommender", "IALSRecommender")
     Xi = small_urm(60, 45, 0.15, 15, real=True)

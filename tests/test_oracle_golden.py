@@ -108,6 +108,22 @@ def test_slim_oracle_is_bit_exact_with_reference_outputs():
         np.testing.assert_array_equal(e.get_S_dense(), z["S_%d" % n])
 
 
+def test_slim_sparse_store_oracle_is_bit_exact_with_reference_outputs():
+    """train_with_sparse_weights=True: the fixtures hold the reference's get_S() (csr of the tree) in the middle and at the end
+    of training -- rebalance points at the fifths of the epoch, the selection inside get_S, ties, topK=False."""
+    z, cases = load_golden("slim_bpr_sparse")
+    for n, case in enumerate(cases):
+        X = unpack_csr(z, "X%d" % case["n_users"])
+        e = O.OracleSLIM(X, **case["kw"])
+        for m, epochs in enumerate(case["epochs"]):
+            for _ in range(epochs):
+                e.epochIteration_Cython()
+            S = e.get_S()
+            np.testing.assert_array_equal(S.indptr, z["indptr_%d_%d" % (n, m)])
+            np.testing.assert_array_equal(S.indices, z["indices_%d_%d" % (n, m)])
+            np.testing.assert_array_equal(S.data, z["data_%d_%d" % (n, m)])
+
+
 def test_ials_oracle_matches_reference_outputs():
     z, cases = load_golden("ials")
     X = unpack_csr(z, "X")

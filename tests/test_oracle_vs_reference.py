@@ -69,6 +69,33 @@ def test_slim_bit_exact(ref, symmetric):
         _quiet(a._dealloc)
 
 
+@pytest.mark.parametrize("n_users", [299, 300, 303])
+def test_slim_sparse_store_bit_exact(ref, n_users):
+    """Sparse-tree store: 300 steps per epoch (4 rebalance points), 301 and 304 (5: the rule divides as C integers)."""
+    X = synthetic_urm(n_users, 40, 3000, 3, 30, seed=3, values="binary")
+    for topK, mode, regs in [(5, "sgd", (0.0, 0.0)), (7, "adam", (0.01, 0.02)), (False, "adagrad", (0.01, 0.0)), (3, "rmsprop", (0.0, 0.03)),
+                             (60, "sgd", (0.0, 0.0))]:
+        kw = dict(symmetric=True, random_seed=4, sgd_mode=mode, learning_rate=0.05, li_reg=regs[0], lj_reg=regs[1], topK=topK,
+                  train_with_sparse_weights=True)
+        a = ref["slim"](X, **kw)
+        for _ in range(2):
+            _quiet(a.epochIteration_Cython)
+        Sa = [_quiet(a.get_S)]
+        _quiet(a.epochIteration_Cython)                  # get_S pruned the model: training goes on from the pruned one
+        Sa.append(_quiet(a.get_S))
+        _quiet(a._dealloc)
+        b = O.OracleSLIM(X, **kw)
+        for _ in range(2):
+            b.epochIteration_Cython()
+        Sb = [b.get_S()]
+        b.epochIteration_Cython()
+        Sb.append(b.get_S())
+        for x, y in zip(Sa, Sb):
+            np.testing.assert_array_equal(x.indptr, y.indptr)
+            np.testing.assert_array_equal(x.indices, y.indices)
+            np.testing.assert_array_equal(x.data, y.data)
+
+
 @pytest.mark.parametrize("similarity", ["cosine", "adjusted", "asymmetric", "pearson", "jaccard", "dice", "tversky"])
 def test_similarity_bit_exact(ref, similarity):
     X = synthetic_urm(500, 200, 12000, 5, 100, seed=5, values="real")

@@ -104,7 +104,7 @@ def test_recommender_fit_surface(gpu):
         dense = X[:60].toarray() > 0
         assert np.mean([scores[r][dense[r]].mean() > scores[r][~dense[r]].mean() for r in range(60)]) > 0.9
     with pytest.raises(NotImplementedError):
-        SLIM_BPR_MI355X(X, verbose=False).fit(epochs=1, train_with_sparse_weights=True)
+        SLIM_BPR_MI355X_Epoch(X, batch_size=32)
     with pytest.raises(ValueError):
         SLIM_BPR_MI355X(X, verbose=False).fit(epochs=1, topK=0)
 
@@ -186,3 +186,74 @@ def test_long_profiles_and_hot_items(gpu):
         dev.replay_samples(u[100:], i[100:], j[100:])
         assert_factor_parity(dev.get_S_dense(), orc.get_S_dense(), "rmsprop", "S")
         dev.close()
+
+
+# ---- the sparse-tree store (train_with_sparse_weights=True) -----------------------------------------------------------------
+def _csr_parity(got, want, what):
+    """Same nodes, values within 1e-5 of the largest (the device lists float32 values of its float64 cells)."""
+    np.testing.assert_array_equal(got.indptr, want.indptr, err_msg=what)
+    np.testing.assert_array_equal(got.indices, want.indices, err_msg=what)
+    np.testing.assert_allclose(got.data, want.data, rtol=1e-5, atol=1e-5 * max(np.abs(want.data).max(), 1e-30), err_msg=what)
+
+
+SPARSE_CASES = [(5, "sgd", (0.0, 0.0)),          # every cell a sample writes first gets the same value: the selection is all ties
+                (7, "adam", (0.01, 0.02)), (False, "adagrad", (0.01, 0.0)), (3, "rmsprop", (0.0, 0.03)),
+                (60, "sgd", (0.02, 0.0)),        # rows rarely reach 60 nodes: the "fewer than TopK: leave alone" branch
+                (1, "sgd", (0.0, 0.01))]
+
+
+@pytest.mark.parametrize("n_users", [299, 300, 303])
+def test_sparse_store_replay_parity(gpu, n_users):
+    """The reference's sparse store changes the model at the fifths of every epoch and inside get_S (SLIM_BPR_Cython_Epoch.pyx:320-324,
+    381-382); the device applies the same selections to its dense array.  The oracle's sparse store is bit-exact with the compiled
+    reference (tests/test_oracle_vs_reference.py, tests/golden/slim_bpr_sparse.npz).  Steps per epoch: 300 (4 rebalance points), 301, 304 (5)."""
+    X = synthetic_urm(n_users, 40, 3000, 3, 30, seed=3, values="binary")
+    for topK, mode, regs in SPARSE_CASES:
+        kw = dict(random_seed=4, sgd_mode=mode, learning_rate=0.05, li_reg=regs[0], lj_reg=regs[1], topK=topK, train_with_sparse_weights=True)
+        orc = O.OracleSLIM(X, **kw)
+        dev = SLIM_BPR_MI355X_Epoch(X, **kw)
+        assert dev.precision == "fp64" and not dev.symmetric
+        for round_ in range(3):                         # get_S prunes the model: training continues from the pruned one, on both sides
+            orc.record_samples(10 ** 6)
+            orc.epochIteration_Cython()
+            dev.replay_samples(*orc.recorded())
+            _csr_parity(dev.get_S(), orc.get_S(), "topK=%r %s round %d" % (topK, mode, round_))
+        dev.close()
+
+
+def test_sparse_store_golden_fixture(gpu):
+    """Reference-generated get_S() outputs of the sparse store; the sample stream comes from the oracle's recorder (same rand())."""
+    z, cases = load_golden("slim_bpr_sparse")
+    for n, case in enumerate(cases):
+        X = unpack_csr(z, "X%d" % case["n_users"])
+        orc = O.OracleSLIM(X, **case["kw"])
+        dev = SLIM_BPR_MI355X_Epoch(X, **case["kw"])
+        for m, epochs in enumerate(case["epochs"]):
+            for _ in range(epochs):
+                orc.record_samples(10 ** 6)
+                orc.epochIteration_Cython()
+                dev.replay_samples(*orc.recorded())
+            orc.get_S()
+            want = sps.csr_matrix((z["data_%d_%d" % (n, m)], z["indices_%d_%d" % (n, m)], z["indptr_%d_%d" % (n, m)]), shape=(X.shape[1],) * 2)
+            _csr_parity(dev.get_S(), want, "case %d get_S %d" % (n, m))
+        dev.close()
+
+
+def test_sparse_store_native_epochs_and_wrapper(gpu):
+    """Device-drawn streams: the oracle replays what the device drew; then the recommender wrapper end to end."""
+    X = named_urm("ml1m", "binary", scale=0.1)
+    kw = dict(random_seed=21, sgd_mode="adagrad", learning_rate=0.05, li_reg=0.001, lj_reg=0.002, topK=8, train_with_sparse_weights=True)
+    dev = SLIM_BPR_MI355X_Epoch(X, **kw)
+    orc = O.OracleSLIM(X, **kw)
+    for _ in range(3):
+        dev.epochIteration_Cython()
+        orc.replay(*dev.last_epoch_samples())
+    W = dev.get_S()
+    _csr_parity(W, orc.get_S(), "native epochs")
+    assert (np.diff(W.indptr) <= 8).all() and W.diagonal().max() == 0
+    dev.close()
+    rec = SLIM_BPR_MI355X(X, verbose=False)
+    rec.fit(epochs=3, train_with_sparse_weights=True, topK=8, sgd_mode="adagrad", learning_rate=0.05, random_seed=21)
+    assert rec.train_with_sparse_weights and sps.isspmatrix_csr(rec.W_sparse) and (np.diff(rec.W_sparse.indptr) <= 8).all()
+    with pytest.raises(ValueError):
+        SLIM_BPR_MI355X_Epoch(X, train_with_sparse_weights=True, precision="fp32")
