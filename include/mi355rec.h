@@ -102,7 +102,16 @@ typedef struct {
     int32_t normalize_avg_row;  /* MI355REC_SIM_EUCLIDEAN only: squared distance divided by n_rows (Euclidean.py:181-182);
                                  * `normalize` then means squared distance / (|a| |b|) (:178-179) */
     int32_t euclidean_mode;     /* MI355REC_EUCLID_* */
+    /* Optional pre-pass: the BM25 / TF-IDF re-weighting the KNN recommenders apply to the matrix before the build
+     * (Base/IR_feature_weighting.py:13 okapi_BM_25, :55 TF_IDF; KNN/ItemKNNCFRecommender.py:40-48, UserKNNCFRecommender.py:40-48),
+     * on the stored values already in HBM.  "Documents" are the rows of the matrix the reference hands to those functions:
+     * for ItemKNN (URM.T weighted, URM built) the COLUMNS of dataMatrix, for UserKNN (URM.T weighted, URM.T built) its ROWS. */
+    int32_t feature_weighting;      /* MI355REC_WEIGHT_* */
+    int32_t weighting_documents;    /* 0: documents = columns of dataMatrix, 1: documents = rows */
+    float   bm25_k1, bm25_b;        /* okapi_BM_25(K1 = 1.2, B = 0.75) */
 } mi355rec_sim_config;
+
+enum { MI355REC_WEIGHT_NONE = 0, MI355REC_WEIGHT_BM25 = 1, MI355REC_WEIGHT_TFIDF = 2 };
 
 typedef struct mi355rec_sim *mi355rec_sim_t;
 
@@ -112,6 +121,9 @@ typedef struct mi355rec_sim *mi355rec_sim_t;
 int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, int32_t n_rows, int32_t n_cols,
                         const int32_t *csr_indptr, const int32_t *csr_indices, const float *csr_data,
                         const float *row_weights);
+/* The re-weighted stored values (feature_weighting != NONE), in the order of the csr_data passed to mi355rec_sim_create: what the
+ * reference recommender keeps as its URM_train afterwards (ItemKNNCFRecommender.py:42-43). */
+int mi355rec_sim_get_weighted_values(mi355rec_sim_t h, float *csr_data);
 /* Columns [start_col, end_col): for local column c the topK (neighbour, value) pairs in descending value
  * order at nbr_idx/nbr_val[(c - start_col) * topK ...], padded with (-1, 0).  Zero similarities are never
  * emitted (.pyx:555). */

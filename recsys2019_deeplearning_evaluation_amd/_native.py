@@ -18,6 +18,7 @@ E_INVALID, E_HIP, E_NO_DEVICE, E_UNSUPPORTED, E_NUMERIC = -1, -2, -3, -4, -5
 SIMILARITY_CODES = {"cosine": 0, "adjusted": 1, "asymmetric": 2, "pearson": 3, "jaccard": 4, "tanimoto": 4,
                     "dice": 5, "tversky": 6, "euclidean": 7}
 EUCLIDEAN_MODE_CODES = {"lin": 0, "log": 1, "exp": 2}
+FEATURE_WEIGHTING_CODES = {"none": 0, "BM25": 1, "TF-IDF": 2}
 SGD_MODE_CODES = {"sgd": 0, "adagrad": 1, "rmsprop": 2, "adam": 3}
 ALGORITHM_CODES = {"MF_BPR": 0, "FUNK_SVD": 1, "ASY_SVD": 2}
 PRECISION_CODES = {"fp32": 0, "fp64": 1}
@@ -39,7 +40,8 @@ class Stats(C.Structure):
 class SimConfig(C.Structure):
     _fields_ = [("topK", C.c_int32), ("shrink", C.c_int32), ("normalize", C.c_int32), ("similarity", C.c_int32),
                 ("asymmetric_alpha", C.c_float), ("tversky_alpha", C.c_float), ("tversky_beta", C.c_float),
-                ("unit_column_side", C.c_int32), ("normalize_avg_row", C.c_int32), ("euclidean_mode", C.c_int32)]
+                ("unit_column_side", C.c_int32), ("normalize_avg_row", C.c_int32), ("euclidean_mode", C.c_int32),
+                ("feature_weighting", C.c_int32), ("weighting_documents", C.c_int32), ("bm25_k1", C.c_float), ("bm25_b", C.c_float)]
 
 
 class MFConfig(C.Structure):
@@ -73,6 +75,7 @@ SIGNATURES = {
     "mi355rec_device_memcpy": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int]),
     "mi355rec_device_synchronize": (C.c_int, []),
     "mi355rec_sim_create": (C.c_int, [C.POINTER(_vp), C.POINTER(SimConfig), _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mi355rec_sim_get_weighted_values": (C.c_int, [_vp, _vp]),
     "mi355rec_sim_compute": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355rec_sim_compute_device": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355rec_sim_compute_dense": (C.c_int, [_vp, _i32, _i32, _vp, _i64]),

@@ -2,13 +2,13 @@
 
 Mirrors KNN/ItemKNNCFRecommender.py:17 (fit :31-54) and KNN/UserKNNCFRecommender.py:17 (fit :31-55): same fit()
 keywords, same W_sparse attribute, same scoring through the base classes.  Feature weighting (BM25 / TF-IDF,
-Base/IR_feature_weighting.py) is the reference's host-side NumPy pre-step (feature_weighting.py); the similarity
-build that follows runs on the device.
+Base/IR_feature_weighting.py) is a device pre-pass of the similarity constructor on the values it has just uploaded
+(at ML-20M shape the reference's NumPy version costs more than a hundred similarity builds); the recommender's URM_train is
+replaced by the re-weighted matrix, as in the reference.
 """
 import numpy as np
 
 from .recommender_base import (BaseItemSimilarityMatrixRecommender, BaseUserSimilarityMatrixRecommender, check_matrix)
-from .feature_weighting import apply_feature_weighting
 from .scoring import GpuSimilarityScoringMixin
 from .similarity import Compute_Similarity
 
@@ -33,9 +33,12 @@ class _ItemKNNLogic(_KNNCFMixin):
         self.topK = topK
         self.shrink = shrink
         self._check_weighting(feature_weighting)
-        self.URM_train = apply_feature_weighting(self.URM_train, feature_weighting, user_major=False)
-        builder = Compute_Similarity(self.URM_train, shrink=shrink, topK=topK, normalize=normalize,
-                                     similarity=similarity, **similarity_args)
+        # okapi_BM_25(URM.T).T / TF_IDF(URM.T).T (ItemKNNCFRecommender.py:40-48): documents = items = columns of the URM
+        builder = Compute_Similarity(self.URM_train.astype(np.float32), shrink=shrink, topK=topK, normalize=normalize,
+                                     similarity=similarity, feature_weighting=feature_weighting, weighting_documents="columns",
+                                     **similarity_args)
+        if feature_weighting != "none":
+            self.URM_train = builder.compute_similarity_object.weighted_matrix()
         self.W_sparse = builder.compute_similarity()
         self.W_sparse = check_matrix(self.W_sparse, format="csr")
         self.similarity_stats = builder.compute_similarity_object.stats()
@@ -55,9 +58,13 @@ class _UserKNNLogic(_KNNCFMixin):
         self.topK = topK
         self.shrink = shrink
         self._check_weighting(feature_weighting)
-        self.URM_train = apply_feature_weighting(self.URM_train, feature_weighting, user_major=True)
-        builder = Compute_Similarity(self.URM_train.T, shrink=shrink, topK=topK, normalize=normalize,
-                                     similarity=similarity, **similarity_args)
+        # the same okapi_BM_25(URM.T).T / TF_IDF(URM.T).T (UserKNNCFRecommender.py:40-48): the build runs on URM.T, whose ROWS
+        # are the documents (items)
+        builder = Compute_Similarity(self.URM_train.astype(np.float32).T, shrink=shrink, topK=topK, normalize=normalize,
+                                     similarity=similarity, feature_weighting=feature_weighting, weighting_documents="rows",
+                                     **similarity_args)
+        if feature_weighting != "none":
+            self.URM_train = check_matrix(builder.compute_similarity_object.weighted_matrix().T, "csr")
         self.W_sparse = builder.compute_similarity()
         self.W_sparse = check_matrix(self.W_sparse, format="csr")
         builder.compute_similarity_object.close()

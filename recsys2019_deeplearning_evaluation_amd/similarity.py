@@ -36,11 +36,24 @@ class Compute_Similarity_MI355X:
 
     def __init__(self, dataMatrix, topK=100, shrink=0, normalize=True, asymmetric_alpha=0.5, tversky_alpha=1.0,
                  tversky_beta=1.0, similarity="cosine", row_weights=None, unit_column_side=False,
-                 normalize_avg_row=False, similarity_from_distance_mode="lin"):
+                 normalize_avg_row=False, similarity_from_distance_mode="lin", feature_weighting="none",
+                 weighting_documents="columns", K1=1.2, B=0.75):
+        """feature_weighting ("none" / "BM25" / "TF-IDF"), weighting_documents ("columns" / "rows"), K1, B: the re-weighting the
+        KNN recommenders apply to the matrix before the build (Base/IR_feature_weighting.py), as a device pre-pass on the
+        uploaded values; `weighted_matrix()` hands the re-weighted matrix back.  Not arguments of the reference class."""
         if similarity not in self.SIMILARITY_VALUES and similarity != "euclidean":
             raise ValueError("Cosine_Similarity: value for parameter 'mode' not recognized."
                              " Allowed values are: 'cosine', 'pearson', 'adjusted', 'asymmetric', 'jaccard', 'tanimoto',"
                              "dice, tversky. Passed value was '{}'".format(similarity))
+        if feature_weighting not in N.FEATURE_WEIGHTING_CODES:
+            raise ValueError("Value for 'feature_weighting' not recognized. Acceptable values are {}, provided was '{}'".format(
+                list(N.FEATURE_WEIGHTING_CODES), feature_weighting))
+        if feature_weighting == "BM25":
+            assert 0 < B < 1, "okapi_BM_25: B must be in (0,1)"
+            assert K1 > 0, "okapi_BM_25: K1 must be > 0"
+        if feature_weighting == "TF-IDF":
+            assert np.all(dataMatrix.data >= 0.0), \
+                "TF_IDF: Data matrix contains {} negative values, computing the square root is not possible.".format(np.sum(dataMatrix.data < 0.0))
         self.n_rows, self.n_columns = dataMatrix.shape
         self.TopK = min(int(topK), self.n_columns)
         self.similarity = similarity
@@ -54,7 +67,10 @@ class Compute_Similarity_MI355X:
         rw = None if row_weights is None else N.as_f32(row_weights)
         cfg = N.SimConfig(self.TopK, int(shrink), int(bool(normalize)), N.SIMILARITY_CODES[similarity],
                           float(asymmetric_alpha), float(tversky_alpha), float(tversky_beta), int(bool(unit_column_side)),
-                          int(bool(normalize_avg_row)), N.EUCLIDEAN_MODE_CODES.get(similarity_from_distance_mode, -1))
+                          int(bool(normalize_avg_row)), N.EUCLIDEAN_MODE_CODES.get(similarity_from_distance_mode, -1),
+                          N.FEATURE_WEIGHTING_CODES[feature_weighting], int(weighting_documents == "rows"), float(K1), float(B))
+        assert weighting_documents in ("columns", "rows")
+        self._weighted_structure = (csr.indptr, csr.indices, csr.shape) if feature_weighting != "none" else None
         self._lib = N.load()
         self._h = C.c_void_p()
         N.check(self._lib.mi355rec_sim_create(C.byref(self._h), C.byref(cfg), self.n_rows, self.n_columns,
@@ -70,6 +86,15 @@ class Compute_Similarity_MI355X:
             self.close()
         except Exception:
             pass
+
+    def weighted_matrix(self):
+        """The BM25 / TF-IDF re-weighted dataMatrix (csr, float32), computed on the device by the constructor."""
+        if self._weighted_structure is None:
+            raise ValueError("Compute_Similarity_MI355X was created with feature_weighting='none'")
+        indptr, indices, shape = self._weighted_structure
+        data = np.empty(len(indices), np.float32)
+        N.check(self._lib.mi355rec_sim_get_weighted_values(self._h, N.ptr(data)))
+        return sps.csr_matrix((data, indices.copy(), indptr.copy()), shape=shape)
 
     def _range(self, start_col, end_col):
         # same acceptance rule as Compute_Similarity_Cython.pyx:447-451

@@ -281,15 +281,41 @@ def test_userknn_recommender_on_a_wide_user_base(gpu):
 
 
 @pytest.mark.parametrize("weighting", ["BM25", "TF-IDF"])
-def test_itemknn_with_feature_weighting(gpu, weighting):
+@pytest.mark.parametrize("user_based", [False, True])
+def test_knn_with_feature_weighting(gpu, weighting, user_based):
+    """BM25 / TF-IDF run as a device pre-pass of the build; the recommender's URM_train becomes the re-weighted matrix exactly as in
+    the reference (ItemKNNCFRecommender.py:40-48): checked against the NumPy restatement of Base/IR_feature_weighting.py (itself
+    checked against reference outputs in tests/test_host_logic.py), then the build against the oracle on that matrix."""
+    from recsys2019_deeplearning_evaluation_amd import UserKNNCFRecommender
+    from recsys2019_deeplearning_evaluation_amd.feature_weighting import apply_feature_weighting
     X = named_urm("ml1m", "real", scale=0.15)
-    rec = ItemKNNCFRecommender(X, verbose=False)
+    rec = (UserKNNCFRecommender if user_based else ItemKNNCFRecommender)(X, verbose=False)
     rec.fit(topK=20, shrink=5, similarity="cosine", feature_weighting=weighting)
+    want = apply_feature_weighting(X, weighting, user_based)
+    assert sps.isspmatrix_csr(rec.URM_train) and rec.URM_train.shape == X.shape
     assert abs(rec.URM_train - X).max() > 0                       # the recommender's URM is re-weighted, like the reference's
-    Wo = O.OracleSimilarity(rec.URM_train, topK=20, shrink=5).compute_similarity(exact_numpy_topk=True)
+    np.testing.assert_array_equal(rec.URM_train.indptr, want.indptr)
+    np.testing.assert_allclose(rec.URM_train.toarray(), want.toarray(), rtol=RTOL, atol=1e-7)
+    M = rec.URM_train.T.tocsr() if user_based else rec.URM_train
+    Wo = O.OracleSimilarity(M, topK=20, shrink=5).compute_similarity(exact_numpy_topk=True)
     assert abs(rec.W_sparse - Wo).max() <= RTOL * abs(Wo).max()
     with pytest.raises(ValueError):
         ItemKNNCFRecommender(X, verbose=False).fit(feature_weighting="nope")
+
+
+def test_feature_weighting_reference_fixture_on_device(gpu):
+    """The reference-generated fixture of okapi_BM_25(X.T).T / TF_IDF(X.T).T against the device pre-pass, both document orientations."""
+    from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_MI355X
+    z, _ = load_golden("feature_weighting")
+    X = unpack_csr(z, "X").astype(np.float32)
+    for weighting, key in (("BM25", "bm25_T"), ("TF-IDF", "tfidf_T")):
+        a = Compute_Similarity_MI355X(X, topK=5, feature_weighting=weighting, weighting_documents="columns")
+        np.testing.assert_allclose(a.weighted_matrix().toarray(), z[key], rtol=RTOL, atol=1e-7)
+        b = Compute_Similarity_MI355X(X.T.tocsr(), topK=5, feature_weighting=weighting, weighting_documents="rows")
+        np.testing.assert_allclose(b.weighted_matrix().toarray(), z[key].T, rtol=RTOL, atol=1e-7)
+        a.close(); b.close()
+    with pytest.raises(ValueError):
+        Compute_Similarity_MI355X(X, topK=5).weighted_matrix()
 
 
 @pytest.mark.parametrize("values,similarity", [("binary", "cosine"), ("real", "cosine"), ("real", "adjusted"), ("binary", "tversky")])
