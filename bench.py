@@ -352,8 +352,8 @@ def itemknn_section(urm, net, args, extra):
     sim.synchronize()
     create_s = time.perf_counter() - t_c
     costs = sim.column_costs()
-    job = ShardedSimilarityBuild(sim, net.dist, rank, world, net.comm)       # ranges + buffers once, outside the timed region
-    s, e = job.ranges[rank]
+    job = ShardedSimilarityBuild(sim, net.dist, rank, world, net.comm)       # partition + buffers once, outside the timed region
+    my_columns = job.columns[rank]
     best, kernel_ms = None, None
     for rep in range(4):
         net.barrier()
@@ -367,14 +367,14 @@ def itemknn_section(urm, net, args, extra):
     idx, val = job.download() if rank == 0 else (None, None)
     download_s = time.perf_counter() - t2
     sst = sim.stats()
-    pairs = float(np.asarray(costs[s:e], dtype=np.float64).sum())
+    pairs = float(np.asarray(costs, dtype=np.float64)[my_columns].sum())
     pair_rate = pairs / (kernel_ms * 1e-3)
     alg_gbps = sst["algorithmic_bytes"] / (sst["kernel_ms"] * 1e-3) / 1e9
     block = {
-        "cosine_build_s": best, "definition": "kernel on this rank's cost-balanced column range + one all-gather; full (n_cols x topK) "
-                                              "result resident on every rank's device (max over ranks, best of 3)",
+        "cosine_build_s": best, "definition": "kernel on this rank's columns (interleaved partition: equal counts, equal cost) + one "
+                                              "all-gather; full (n_cols x topK) result resident on every rank's device (max over ranks, best of 3)",
         "create_s": create_s, "fit_s": create_s + best, "download_to_host_rank0_s": download_s,
-        "topK": TOPK, "columns_this_rank": int(e - s), "kernel_ms_this_rank": kernel_ms,
+        "topK": TOPK, "columns_this_rank": int(len(my_columns)), "kernel_ms_this_rank": kernel_ms,
         "exchange_bytes_per_rank": job.exchange_bytes_per_rank(),
         "transport": "none" if world == 1 else ("rccl-ctypes" if net.comm is not None else "torch." + net.dist.get_backend()),
         "nnz_out": int((idx >= 0).sum()) if idx is not None else None,
@@ -385,23 +385,39 @@ def itemknn_section(urm, net, args, extra):
                      "note": "SURVEY 8(d)'s byte model (8 B per co-occurrence pair) exceeds the HBM peak because the kernel streams "
                              "2-byte ids from L2/MALL; the bound that holds is the LDS atomic rate"}}
     if world == 1 and not args.no_extras:
-        # the 8-GPU build of BASELINE config 4, one range after the other on this GPU: kernel time per range (measured) and the
-        # exchange modelled from its size -- NOT measured on hardware until the driver's 8-GPU run exists
-        ranges8 = similarity_column_ranges(sim, 8)
-        per_range = []
-        for (a, b) in ranges8:
-            sim.compute_slabs_device(a if a > 0 else None, b if b < n_items else None, job.local.address(), job.local.address(job.widest * TOPK))
+        # the 8-GPU build of BASELINE config 4, one part after the other on this GPU: kernel time per part (measured), the
+        # gathered buffer assembled with device copies (measured: what the last ring step leaves behind), and the exchange
+        # itself modelled from its size two ways -- NOT measured on hardware until the driver's 8-GPU run exists
+        from recsys2019_deeplearning_evaluation_amd._native import DeviceArray
+        G = 8
+        widest8 = -(-n_items // G)
+        slab_words = 2 * widest8 * TOPK
+        local8, gathered8 = DeviceArray(slab_words), DeviceArray(G * slab_words)
+        per_part = []
+        t_copy = 0.0
+        for r in range(G):
+            sim.compute_part_device(r, G, local8.address(), local8.address(widest8 * TOPK))
             sim.synchronize()
-            per_range.append(sim.stats()["kernel_ms"])
-        widest8 = max(b - a for a, b in ranges8)
-        slab = 2 * widest8 * TOPK * 4
-        ring_ms = 7 * slab / 50e9 * 1e3 + 0.05         # 7 ring steps of one slab over one xGMI link direction (~50 GB/s effective) + latency
-        block["emulated_8_way"] = {"kernel_ms_per_range": per_range, "slowest_range_ms": max(per_range),
-                                   "kernel_speedup_vs_1gpu": kernel_ms / max(per_range),
-                                   "modelled_allgather_ms": ring_ms,
-                                   "predicted_build_speedup": (best * 1e3) / (max(per_range) + ring_ms),
-                                   "note": "ranges run one after the other on ONE GPU; exchange modelled (7 x %.1f MB per link at 50 GB/s), "
-                                           "unmeasured on hardware" % (slab / 1e6)}
+            per_part.append(sim.stats()["kernel_ms"])
+            t3 = time.perf_counter()
+            gathered8.copy_from_device(local8, slab_words, r * slab_words)
+            t_copy += time.perf_counter() - t3
+        slab = 4 * slab_words
+        ring_ms = (G - 1) * slab / 50e9 * 1e3 + 0.05     # ONE ring over one xGMI link direction (~50 GB/s effective) + launch latency
+        direct_ms = slab / 50e9 * 1e3 + 0.05             # all 7 links at once (every peer is one hop away on the xGMI mesh)
+        ranges8 = similarity_column_ranges(sim, 8)
+        block["emulated_8_way"] = {
+            "partition": "interleaved (serpentine deal of the cost order): %d columns and 1/8 of the cost per part" % widest8,
+            "kernel_ms_per_part": per_part, "slowest_part_ms": max(per_part),
+            "kernel_speedup_vs_1gpu": kernel_ms / max(per_part),
+            "slab_MB_per_rank": slab / 1e6,
+            "slab_MB_per_rank_with_contiguous_ranges": 8 * max(b - a for a, b in ranges8) * TOPK / 1e6,
+            "device_copy_of_8_slabs_ms": t_copy * 1e3,
+            "modelled_allgather_ms": {"one_ring_50GBps_per_link": ring_ms, "seven_links_at_once": direct_ms},
+            "predicted_build_speedup": {"one_ring": (best * 1e3) / (max(per_part) + ring_ms),
+                                        "seven_links": (best * 1e3) / (max(per_part) + direct_ms)},
+            "note": "parts run one after the other on ONE GPU; the exchange is modelled from its size (7 x %.2f MB), unmeasured on hardware" % (slab / 1e6)}
+        local8.close(); gathered8.close()
     job.close()
     sim.close()
     extra["itemknn"] = block

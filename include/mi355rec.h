@@ -37,7 +37,7 @@ const char *mi355rec_last_error(void);
 
 /* Raw device buffers of the calling process's device, for callers that keep results on the GPU and exchange them between
  * GPUs themselves (sharding.py: RCCL all-gather of similarity slabs through ctypes, no PyTorch).  to_device: 1 = host -> device,
- * 0 = device -> host; both copies are blocking. */
+ * 0 = device -> host, 2 = device -> device; the copies are blocking. */
 int mi355rec_device_malloc(void **out, uint64_t bytes);
 int mi355rec_device_free(void *p);
 int mi355rec_device_memcpy(void *dst, const void *src, uint64_t bytes, int to_device);
@@ -121,6 +121,13 @@ typedef struct mi355rec_sim *mi355rec_sim_t;
 int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, int32_t n_rows, int32_t n_cols,
                         const int32_t *csr_indptr, const int32_t *csr_indices, const float *csr_data,
                         const float *row_weights);
+/* Multi-GPU partition with equal column COUNTS and equal COST per part: the columns in cost order are dealt to n_parts parts in
+ * serpentine order; part `part` computes its columns and writes column mi355rec_sim_part_columns()[q] to row q of the
+ * DEVICE slabs (ceil(n_cols / n_parts) x topK each).  Same kernel as mi355rec_sim_compute_device; the contiguous
+ * [start_col, end_col) entry points keep the reference's own seam (Compute_Similarity_Cython.pyx:411, 447-451). */
+int mi355rec_sim_compute_part_device(mi355rec_sim_t h, int32_t part, int32_t n_parts, int32_t *d_nbr_idx, float *d_nbr_val);
+/* The columns of a part in output-row order (columns may be NULL: only the count). */
+int mi355rec_sim_part_columns(mi355rec_sim_t h, int32_t part, int32_t n_parts, int32_t *columns, int32_t *n_columns);
 /* The re-weighted stored values (feature_weighting != NONE), in the order of the csr_data passed to mi355rec_sim_create: what the
  * reference recommender keeps as its URM_train afterwards (ItemKNNCFRecommender.py:42-43). */
 int mi355rec_sim_get_weighted_values(mi355rec_sim_t h, float *csr_data);

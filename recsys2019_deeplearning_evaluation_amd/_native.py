@@ -76,6 +76,8 @@ SIGNATURES = {
     "mi355rec_device_synchronize": (C.c_int, []),
     "mi355rec_sim_create": (C.c_int, [C.POINTER(_vp), C.POINTER(SimConfig), _i32, _i32, _vp, _vp, _vp, _vp]),
     "mi355rec_sim_get_weighted_values": (C.c_int, [_vp, _vp]),
+    "mi355rec_sim_compute_part_device": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "mi355rec_sim_part_columns": (C.c_int, [_vp, _i32, _i32, _vp, C.POINTER(_i32)]),
     "mi355rec_sim_compute": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355rec_sim_compute_device": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355rec_sim_compute_dense": (C.c_int, [_vp, _i32, _i32, _vp, _i64]),
@@ -212,6 +214,10 @@ class DeviceArray:
         out = np.empty(self.n_words, np.int32) if out is None else out
         check(load().mi355rec_device_memcpy(ptr(out), self.ptr, 4 * self.n_words, 0))
         return out
+
+    def copy_from_device(self, other, n_words, word_offset=0):
+        """Blocking device-to-device copy of other[0:n_words] into self[word_offset:...]."""
+        check(load().mi355rec_device_memcpy(C.c_void_p(self.address(word_offset)), other.ptr, 4 * int(n_words), 2))
 
     def close(self):
         if getattr(self, "ptr", None) is not None and self.ptr.value:

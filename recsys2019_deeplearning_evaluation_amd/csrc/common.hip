@@ -96,7 +96,8 @@ extern "C" int mi355rec_device_memcpy(void *dst, const void *src, uint64_t bytes
     return guarded([&] {
         MI_REQUIRE(dst && src, "NULL argument");
         ensure_device();
-        MI_HIP(hipMemcpy(dst, src, (size_t)bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+        MI_REQUIRE(to_device >= 0 && to_device <= 2, "to_device must be 0, 1 or 2");
+        MI_HIP(hipMemcpy(dst, src, (size_t)bytes, to_device == 2 ? hipMemcpyDeviceToDevice : (to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost)));
     });
 }
 

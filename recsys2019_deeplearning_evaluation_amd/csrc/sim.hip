@@ -53,6 +53,7 @@ struct SimParams {
     const float *norm, *norm_alpha, *norm_1ma;
     const int4 *items;  // work items of this call, most expensive first: {column, part, n_parts, first part slot}
     int n_items, start_col;
+    const int *out_slot;    // interleaved parts: output row of every column of the call (NULL: column - start_col)
     uint32_t *part_buf;     // [part slots][n_cols_pad] partial accumulators of split columns
     unsigned *part_count;   // arrival counters, indexed by the first part slot of a split column
     unsigned long long *phase_ticks;   // diagnostics (MI355REC_SIM_PHASES=1): 100 MHz ticks per phase, summed over workgroups
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             cbeg = min(cend, cbeg + item.y * per);
             cend = min(cend, cbeg + per);
         }
-        const size_t out_base = (size_t)(c - p.start_col) * p.topK;
+        const size_t out_base = (size_t)(p.out_slot ? p.out_slot[c] : c - p.start_col) * p.topK;
         int *wg_cand_idx = p.cand_idx + (size_t)blockIdx.x * p.n_tiles * p.topK;
         float *wg_cand_val = p.cand_val + (size_t)blockIdx.x * p.n_tiles * p.topK;
         long long total_nonzero = 0;
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         }
         if (p.topK == 0) {  // dense output (.pyx:507-510)
             __syncthreads();
-            float *dst = p.out_dense + (size_t)(c - p.start_col) * p.n_cols + tile_base;
+            float *dst = p.out_dense + (size_t)(p.out_slot ? p.out_slot[c] : c - p.start_col) * p.n_cols + tile_base;
             for (int j = tid; j < n_tile; j += THREADS) dst[j] = acc[j];
             __syncthreads();
             continue;
@@ -805,6 +806,7 @@ struct mi355rec_sim {
     DeviceBuffer<float> cand_val;
     int tile_w = 0, n_tiles = 1;
     DeviceBuffer<float> csr_val, csc_val, row_w, norm, norm_alpha, norm_1ma;
+    DeviceBuffer<int> out_slot;         // interleaved parts: output row per column
     DeviceBuffer<float> weighted_val;   // feature_weighting: the re-weighted values as handed back to the recommender
     DeviceBuffer<unsigned> queue;
     DeviceBuffer<int> out_idx;
@@ -860,9 +862,31 @@ void clamp_range(const mi355rec_sim *h, int32_t &s, int32_t &e) {
     if (e_in > s && e_in < h->n_cols) e = e_in;
 }
 
-// Runs the column kernel for [start,end) leaving results in d_idx/d_val (or d_dense when topK == 0).
-void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, float *d_dense) {
-    const int n_local = end - start;
+// Interleaved parts (multi-GPU): the columns in cost order are dealt to the parts in serpentine order -- position p of the
+// cost order belongs to group p / n_parts and, inside the group, to part p % n_parts (even groups) or its mirror image (odd
+// groups) -- so every part receives the same NUMBER of columns (+-1) and the same COST (the heavy head of the order is
+// spread over all parts).  A part's output rows are its groups, in order.
+inline int part_of_position(long long pos, int n_parts) {
+    const long long group = pos / n_parts;
+    const int within = (int)(pos % n_parts);
+    return (group & 1) ? n_parts - 1 - within : within;
+}
+
+// Runs the column kernel for [start,end) -- or, with n_parts > 0, for part `start` of `n_parts` interleaved parts -- leaving
+// results in d_idx/d_val (or d_dense when topK == 0).
+void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, float *d_dense, int n_parts = 0) {
+    const int part = start;
+    std::vector<int> slot_host;
+    int n_local = end - start;
+    if (n_parts > 0) {
+        slot_host.assign((size_t)h->n_cols, -1);
+        n_local = 0;
+        for (long long pos = 0; pos < h->n_cols; ++pos)
+            if (part_of_position(pos, n_parts) == part) slot_host[h->cost_order[pos]] = n_local++;
+        start = 0;
+        end = h->n_cols;
+    }
+    auto in_call = [&](int c) { return n_parts > 0 ? slot_host[c] >= 0 : (c >= start && c < end); };
     const bool unit_kernel = h->unit_values && !h->row_w.ptr;
     const int acc_words = (h->tile_w + 4) * (unit_kernel ? 1 : 2);
     const size_t lds = (size_t)acc_words * 4 + (size_t)AUX_WORDS * 4;
@@ -879,7 +903,12 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     //      the head items bound the build as soon as the range is spread over many CUs (at ML-20M shape the top
     //      column is 0.49 of a CU's share on one GPU, 3.9 on eight).  Not combined with accumulator tiling.
     long long cost_sum = 0;
-    for (int c = start; c < end; ++c) cost_sum += h->cost[c];
+    double nnz_range = 0;
+    for (int c = start; c < end; ++c)
+        if (in_call(c)) {
+            cost_sum += h->cost[c];
+            nnz_range += (double)(h->csc_ptr_host[c + 1] - h->csc_ptr_host[c]);
+        }
     int min_part_users = 4 * threads;
     if (getenv("MI355REC_SIM_MIN_PART_USERS")) min_part_users = std::max(64, atoi(getenv("MI355REC_SIM_MIN_PART_USERS")));
     const long long limit = std::max<long long>(1, cost_sum / ((long long)max_grid * 2));
@@ -889,7 +918,7 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     keyed.reserve(h->items_host.capacity());
     int part_slots = 0, n_split = 0;
     for (int c : h->cost_order) {
-        if (c < start || c >= end) continue;
+        if (!in_call(c)) continue;
         const int n_c = h->csc_ptr_host[c + 1] - h->csc_ptr_host[c];
         long long parts = 1;
         if (h->n_tiles == 1 && h->cost[c] > limit)
@@ -963,6 +992,13 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
         p.phase_ticks = h->phase_ticks.ptr;
     }
     p.start_col = start;
+    p.out_slot = nullptr;
+    if (n_parts > 0) {
+        if (h->out_slot.count < (size_t)h->n_cols) h->out_slot.alloc((size_t)h->n_cols);
+        MI_HIP(hipMemcpyAsync(h->out_slot.ptr, slot_host.data(), sizeof(int) * (size_t)h->n_cols, hipMemcpyHostToDevice, h->stream));
+        MI_HIP(hipStreamSynchronize(h->stream));       // (slot_host is a local)
+        p.out_slot = h->out_slot.ptr;
+    }
     p.queue = h->queue.ptr;
     p.out_idx = d_idx;
     p.out_val = d_val;
@@ -989,7 +1025,6 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     // ALGORITHMIC bytes, SURVEY.md section 8(d): per column c, its CSC column (8 B x n_c) + the CSR row of each of its users
     // (8 B x L_u) + topK x 8 B of output, i.e. 8 * (nnz_range + cost_range) + 8 * n_local * topK.  (The kernel's own
     // layout moves less -- uint16 ids, no values for all-ones data -- see DESIGN.md section 4.)
-    const double nnz_range = (double)(h->csc_ptr_host[end] - h->csc_ptr_host[start]);
     h->stats.algorithmic_bytes = 8.0 * (nnz_range + (double)cost_sum) + 8.0 * (double)n_local * (double)h->cfg.topK;
     h->stats.algorithmic_flops = 0;
     h->last_start = start;
@@ -1208,6 +1243,30 @@ extern "C" int mi355rec_sim_compute_device(mi355rec_sim_t h, int32_t start_col, 
         ensure_device();
         clamp_range(h, start_col, end_col);
         run_columns(h, start_col, end_col, d_nbr_idx, d_nbr_val, nullptr);
+    });
+}
+
+extern "C" int mi355rec_sim_compute_part_device(mi355rec_sim_t h, int32_t part, int32_t n_parts, int32_t *d_nbr_idx, float *d_nbr_val) {
+    return guarded([&] {
+        MI_REQUIRE(h && d_nbr_idx && d_nbr_val, "NULL argument");
+        MI_REQUIRE(n_parts >= 1 && part >= 0 && part < n_parts, "part %d of %d", part, n_parts);
+        if (h->cfg.topK == 0) fail(MI355REC_E_INVALID, "topK == 0: use mi355rec_sim_compute_dense");
+        ensure_device();
+        run_columns(h, part, 0, d_nbr_idx, d_nbr_val, nullptr, n_parts);
+    });
+}
+
+extern "C" int mi355rec_sim_part_columns(mi355rec_sim_t h, int32_t part, int32_t n_parts, int32_t *columns, int32_t *n_columns) {
+    return guarded([&] {
+        MI_REQUIRE(h && n_columns, "NULL argument");
+        MI_REQUIRE(n_parts >= 1 && part >= 0 && part < n_parts, "part %d of %d", part, n_parts);
+        int n = 0;
+        for (long long pos = 0; pos < h->n_cols; ++pos)
+            if (part_of_position(pos, n_parts) == part) {
+                if (columns) columns[n] = h->cost_order[pos];
+                ++n;
+            }
+        *n_columns = n;
     });
 }
 

@@ -70,8 +70,23 @@ def gather_slabs(local_idx, local_val, ranges, rank, topK, dist, device=None):
     return full_idx, full_val
 
 
+def interleaved_parts(cost, n_parts):
+    """The partition of mi355rec_sim_compute_part_device, restated on the host: columns sorted by descending cost (stable),
+    dealt to the parts in serpentine order.  Returns one int32 array of column ids per part (equal lengths +-1, equal cost)."""
+    order = np.argsort(-np.asarray(cost, dtype=np.int64), kind="stable")
+    pos = np.arange(len(order))
+    group, within = pos // n_parts, pos % n_parts
+    owner = np.where(group % 2 == 1, n_parts - 1 - within, within)
+    return [order[owner == p].astype(np.int32) for p in range(n_parts)]
+
+
 class ShardedSimilarityBuild:
-    """The column-sharded build as a reusable object: ranges, the rank's slab and the gathered result are allocated ONCE.
+    """The column-sharded build as a reusable object: partition, the rank's slab and the gathered result are allocated ONCE.
+
+    partition="interleaved" (default): columns in cost order dealt to the ranks in serpentine order -- every rank gets
+    n_columns / world columns AND 1 / world of the cost, so the exchanged slabs carry no padding (the contiguous cost-balanced
+    ranges of partition="ranges", the reference's own start_col/end_col seam, are up to 2.6 x wider than the average at
+    Netflix shape because unpopular columns are cheap).
 
     Device layout: every rank owns one contiguous slab `[2][widest][topK]` of 4-byte words -- neighbour ids, then the
     similarity values (float32 bits) -- which the column kernel fills directly (its two output pointers are the two halves).
@@ -82,13 +97,21 @@ class ShardedSimilarityBuild:
       `comm`: an rccl_direct.RcclCommunicator (RCCL through ctypes, no PyTorch in the process), or
       `dist`: torch.distributed ("nccl" = RCCL: device to device over xGMI; "gloo": staged through host memory, CPU-side tests)."""
 
-    def __init__(self, similarity_object, dist=None, rank=0, world=1, comm=None):
+    def __init__(self, similarity_object, dist=None, rank=0, world=1, comm=None, partition="interleaved"):
         from ._native import DeviceArray
         self.sim, self.dist, self.comm, self.rank, self.world = similarity_object, dist, comm, rank, world
         assert world == 1 or (dist is None) != (comm is None), "exactly one transport: torch.distributed (dist) or RcclCommunicator (comm)"
+        assert partition in ("interleaved", "ranges")
         self.topK, self.n = similarity_object.TopK, similarity_object.n_columns
-        self.ranges = similarity_column_ranges(similarity_object, world) if world > 1 else [(0, self.n)]
-        self.widest = max(e - s for s, e in self.ranges)
+        self.partition = partition if world > 1 else "ranges"
+        if self.partition == "interleaved":
+            self.columns = [similarity_object.part_columns(r, world) for r in range(world)]
+            self.ranges = None
+            self.widest = max(len(c) for c in self.columns)
+        else:
+            self.ranges = similarity_column_ranges(similarity_object, world) if world > 1 else [(0, self.n)]
+            self.columns = [np.arange(s, e, dtype=np.int32) for s, e in self.ranges]
+            self.widest = max(e - s for s, e in self.ranges)
         self.slab_words = 2 * self.widest * self.topK
         self.local = DeviceArray(self.slab_words)
         self.gathered = DeviceArray(world * self.slab_words) if world > 1 else self.local
@@ -100,9 +123,12 @@ class ShardedSimilarityBuild:
 
     def build(self):
         """Kernel on this rank's range (+ the exchange); afterwards the gathered slabs are valid on this device.  Blocking."""
-        s, e = self.ranges[self.rank]
-        self.sim.compute_slabs_device(s if s > 0 else None, e if e < self.n else None, self.local.address(),
-                                      self.local.address(self.widest * self.topK))
+        if self.partition == "interleaved":
+            self.sim.compute_part_device(self.rank, self.world, self.local.address(), self.local.address(self.widest * self.topK))
+        else:
+            s, e = self.ranges[self.rank]
+            self.sim.compute_slabs_device(s if s > 0 else None, e if e < self.n else None, self.local.address(),
+                                          self.local.address(self.widest * self.topK))
         self.sim.synchronize()
         if self.world == 1:
             return
@@ -122,9 +148,12 @@ class ShardedSimilarityBuild:
     def download(self):
         """(idx, val) NumPy arrays for ALL columns."""
         host = self.gathered.to_host(self._host).reshape(self.world, 2, self.widest, self.topK)
-        idx = np.concatenate([host[r, 0, :e - s] for r, (s, e) in enumerate(self.ranges)], axis=0)
-        val = np.concatenate([host[r, 1, :e - s] for r, (s, e) in enumerate(self.ranges)], axis=0).view(np.float32)
-        return idx, val
+        idx = np.empty((self.n, self.topK), np.int32)
+        val = np.empty((self.n, self.topK), np.int32)
+        for r, cols in enumerate(self.columns):
+            idx[cols] = host[r, 0, :len(cols)]
+            val[cols] = host[r, 1, :len(cols)]
+        return idx, val.view(np.float32)
 
     def exchange_bytes_per_rank(self):
         return 0 if self.world == 1 else 4 * self.slab_words
@@ -135,13 +164,13 @@ class ShardedSimilarityBuild:
             self.gathered.close()
 
 
-def sharded_similarity_build(similarity_object, dist=None, rank=0, world=1, comm=None):
+def sharded_similarity_build(similarity_object, dist=None, rank=0, world=1, comm=None, partition="interleaved"):
     """Column-sharded build with a Compute_Similarity_MI355X object: returns (idx, val) numpy arrays for ALL
     columns on every rank.  With world == 1 this is the plain single-GPU build."""
     if world == 1:
         idx, val, _ = similarity_object.compute_slabs()
         return idx, val
-    job = ShardedSimilarityBuild(similarity_object, dist, rank, world, comm)
+    job = ShardedSimilarityBuild(similarity_object, dist, rank, world, comm, partition)
     job.build()
     out = job.download()
     job.close()

@@ -119,6 +119,18 @@ class Compute_Similarity_MI355X:
         N.check(self._lib.mi355rec_sim_compute_device(self._h, s, e, C.c_void_p(d_idx_ptr), C.c_void_p(d_val_ptr)))
         return s, e
 
+    def compute_part_device(self, part, n_parts, d_idx_ptr, d_val_ptr):
+        """Asynchronous build of interleaved part `part` of `n_parts` (equal column counts and equal cost per part) into device
+        slabs of ceil(n_columns / n_parts) rows; row q holds column part_columns(part, n_parts)[q]."""
+        N.check(self._lib.mi355rec_sim_compute_part_device(self._h, int(part), int(n_parts), C.c_void_p(d_idx_ptr), C.c_void_p(d_val_ptr)))
+
+    def part_columns(self, part, n_parts):
+        n = C.c_int32()
+        N.check(self._lib.mi355rec_sim_part_columns(self._h, int(part), int(n_parts), None, C.byref(n)))
+        cols = np.empty(n.value, np.int32)
+        N.check(self._lib.mi355rec_sim_part_columns(self._h, int(part), int(n_parts), N.ptr(cols), C.byref(n)))
+        return cols
+
     def synchronize(self):
         N.check(self._lib.mi355rec_sim_sync(self._h))
 

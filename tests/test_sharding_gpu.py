@@ -27,8 +27,9 @@ rank, world = dist.get_rank(), dist.get_world_size()
 X = named_urm("ml1m", "binary", scale=0.2)
 sim = Compute_Similarity_MI355X(X, topK=30, shrink=2, similarity="jaccard")
 full_idx, full_val, _ = sim.compute_slabs()
-idx, val = sharded_similarity_build(sim, dist, rank, world)
-assert np.array_equal(idx, full_idx) and np.array_equal(val, full_val), "sharded similarity differs on rank %%d" %% rank
+for partition in ("interleaved", "ranges"):
+    idx, val = sharded_similarity_build(sim, dist, rank, world, partition=partition)
+    assert np.array_equal(idx, full_idx) and np.array_equal(val, full_val), "sharded similarity (%%s) differs on rank %%d" %% (partition, rank)
 ranges = balanced_column_ranges(sim.column_costs(), world)
 assert ranges[0][1] < X.shape[1] // 2, "cost balancing must give the popular (low-index) columns the shorter range"
 
@@ -66,3 +67,38 @@ def test_two_ranks_share_one_gpu(gpu, tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "SHARDED_GPU_OK" in outs[0]
+
+
+def test_interleaved_parts_on_one_gpu(gpu):
+    """The 8-way interleaved partition, part after part on one device: equal counts, equal cost, and the parts put together are the
+    single build bit for bit; the host restatement of the partition (sharding.interleaved_parts) names the same columns."""
+    import numpy as np
+    from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_MI355X
+    from recsys2019_deeplearning_evaluation_amd._native import DeviceArray
+    from recsys2019_deeplearning_evaluation_amd.sharding import interleaved_parts
+    from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
+    X = named_urm("ml1m", "real", scale=0.3)
+    topK = 25
+    sim = Compute_Similarity_MI355X(X, topK=topK, shrink=3)
+    full_idx, full_val, _ = sim.compute_slabs()
+    n, G = X.shape[1], 8
+    costs = sim.column_costs()
+    want_parts = interleaved_parts(costs, G)
+    widest = -(-n // G)
+    buf = DeviceArray(2 * widest * topK)
+    idx = np.full((n, topK), -7, np.int32); val = np.zeros((n, topK), np.float32)
+    part_cost = []
+    for r in range(G):
+        cols = sim.part_columns(r, G)
+        np.testing.assert_array_equal(cols, want_parts[r])
+        assert len(cols) in (n // G, widest)
+        sim.compute_part_device(r, G, buf.address(), buf.address(widest * topK))
+        sim.synchronize()
+        host = buf.to_host().reshape(2, widest, topK)
+        idx[cols] = host[0, :len(cols)]
+        val[cols] = host[1, :len(cols)].view(np.float32)
+        part_cost.append(float(costs[cols].sum()))
+    np.testing.assert_array_equal(idx, full_idx)
+    np.testing.assert_array_equal(val, full_val)
+    assert max(part_cost) <= 1.02 * min(part_cost) + float(costs.max())
+    buf.close(); sim.close()
