@@ -209,6 +209,41 @@ def other_paths(urm):
     for m in reps:
         m.close()
 
+    # SURVEY 8(e)'s exact multi-GPU mode at a batch size where a mini-batch fills the chip (65 536: outside the reference's search
+    # space, which stops at 1024): this handle plays rank 0 of 8 -- its share of every mini-batch's row tasks, the packing of the
+    # rows it owns and the merge of the other ranks' slabs are MEASURED; the all-gather between them is modelled from its size
+    big = 65536
+    one = MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, algorithm_name="MF_BPR", batch_size=big, learning_rate=1e-3,
+                                           sgd_mode="sgd", random_seed=7)
+    one.epochIteration_Cython(2)
+    one.epochIteration_Cython(20)
+    st1 = one.stats()
+    single_rate = st1["n_units"] / (st1["call_ms"] * 1e-3)
+    one.close()
+    r0 = MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, algorithm_name="MF_BPR", batch_size=big, learning_rate=1e-3,
+                                          sgd_mode="sgd", random_seed=7)
+    t_batch = t_merge = 0.0
+    n_done = 0
+    for ep in range(3):
+        _, _, nbytes, nb = r0.shard_begin_epoch(0, 8)
+        for b in range(nb):
+            t0 = time.perf_counter(); r0.shard_batch(b); t1 = time.perf_counter(); r0.shard_merge(b); t2 = time.perf_counter()
+            if ep > 0:
+                t_batch += t1 - t0; t_merge += t2 - t1; n_done += 1
+        r0.shard_end_epoch()
+    r0.close()
+    ring_s = 7 * nbytes / 50e9 + 50e-6
+    direct_s = nbytes / 50e9 + 50e-6
+    per_batch = t_batch / n_done + t_merge / n_done
+    out["bpr_mf_exact_mode_8_gpus_batch65536_emulated"] = {
+        "single_gpu_samples_per_s": single_rate, "rank_share_ms_per_batch": t_batch / n_done * 1e3, "merge_ms_per_batch": t_merge / n_done * 1e3,
+        "slab_MB_per_rank_per_batch": nbytes / 1e6,
+        "modelled_allgather_ms": {"one_ring_50GBps_per_link": ring_s * 1e3, "seven_links_at_once": direct_s * 1e3},
+        "predicted_samples_per_s": {"one_ring": big / (per_batch + ring_s), "seven_links": big / (per_batch + direct_s)},
+        "note": "rank 0 of 8 measured on one GPU (host-timed, blocking calls), exchange modelled, unmeasured on hardware: every mini-batch moves "
+                "the rows it touches (3 x batch x k x 4 B in total) over xGMI, so the exact mode cannot beat one GPU that moves the same bytes "
+                "through HBM; replicas (one model per GPU) are the mode that scales"}
+
     for symmetric in (False, True):
         sl = SLIM_BPR_MI355X_Epoch(urm, symmetric=symmetric, sgd_mode="adagrad", learning_rate=1e-4, topK=TOPK, random_seed=7)
         sl.epochIteration_Cython(1)

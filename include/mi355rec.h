@@ -203,6 +203,18 @@ int mi355rec_mf_run_epochs(mi355rec_mf_t h, int32_t n_epochs);
  * BPR: (u, i, j); FunkSVD: (u, i, rating) with j == NULL. */
 int mi355rec_mf_run_samples(mi355rec_mf_t h, const int32_t *u, const int32_t *i, const int32_t *j,
                             const float *rating, int64_t n);
+/* Exact multi-GPU mini-batches (MF_BPR with sgd): one epoch with the tasks of every mini-batch split over
+ * `world` identical replicas -- same URM, same initial factors, same random_seed, hence the same on-device sample stream and
+ * schedule.  Rank `rank` computes the new version of the rows owned by its share of a mini-batch's tasks
+ * (mi355rec_mf_shard_batch: kernel + packing of those rows into *d_send, blocking); the caller all-gathers *d_send
+ * (bytes_per_rank) into *d_recv (world x bytes_per_rank: ncclAllGather / all_gather_into_tensor); mi355rec_mf_shard_merge copies
+ * the other ranks' rows in (blocking).  After every merge all replicas hold bit-identical factors, equal to a single-GPU
+ * epoch's.  One exchange per mini-batch: only pays for large batch_size.  */
+int mi355rec_mf_shard_begin_epoch(mi355rec_mf_t h, int32_t rank, int32_t world, void **d_send, void **d_recv,
+                                  uint64_t *bytes_per_rank, int32_t *n_batches);
+int mi355rec_mf_shard_batch(mi355rec_mf_t h, int32_t batch);
+int mi355rec_mf_shard_merge(mi355rec_mf_t h, int32_t batch);
+int mi355rec_mf_shard_end_epoch(mi355rec_mf_t h);
 /* Any output pointer may be NULL.  bu/bi/mu are only written when use_bias. */
 int mi355rec_mf_get_factors(mi355rec_mf_t h, float *U, float *V, float *bu, float *bi, float *mu);
 /* Copy the (u, i, j|rating) stream drawn by the LAST mi355rec_mf_run_epochs call (at most cap entries);

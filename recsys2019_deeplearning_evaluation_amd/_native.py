@@ -90,6 +90,10 @@ SIGNATURES = {
     "mi355rec_mf_create": (C.c_int, [C.POINTER(_vp), C.POINTER(MFConfig), _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mi355rec_mf_run_epochs": (C.c_int, [_vp, _i32]),
     "mi355rec_mf_run_samples": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64]),
+    "mi355rec_mf_shard_begin_epoch": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(_i32)]),
+    "mi355rec_mf_shard_batch": (C.c_int, [_vp, _i32]),
+    "mi355rec_mf_shard_merge": (C.c_int, [_vp, _i32]),
+    "mi355rec_mf_shard_end_epoch": (C.c_int, [_vp]),
     "mi355rec_mf_get_factors": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mi355rec_mf_get_last_samples": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     "mi355rec_mf_set_profiling": (C.c_int, [_vp, _i32]),

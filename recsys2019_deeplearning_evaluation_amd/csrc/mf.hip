@@ -92,6 +92,7 @@ struct MfParams {
     const TaskHeader *tasks;
     const int4 *recs;
     unsigned long long *ticks;           // optional [tasks_per_batch][8] shader-clock stamps of the last mini-batch (MI355REC_MF_TICKS=1)
+    int wg_base;                         // first workgroup of the mini-batch this launch covers (exact multi-GPU mode: a rank's share)
 };
 
 // ---- wavefront reductions without LDS traffic ----------------------------------------------------------------------
@@ -290,8 +291,12 @@ __global__ __launch_bounds__(256) void mf_tasks_kernel(const SchedParams s) {
     }
     const int rank = s.head_scan[q] - s.head_scan[lo];
     const int parity = (s.par[entry] + rank) & 1;
-    const int at = batch * s.tasks_per_batch + atomicAdd(&s.batch_count[batch], 1);
+    // the task's header goes to the slot of its FIRST incidence (the sort is stable: the smallest sample * per + role of the run),
+    // which lies inside the mini-batch's tasks_per_batch slots and is the same on every replica of the stream (the exact
+    // multi-GPU mode splits a mini-batch's slots over the ranks); unused slots stay zero: no samples, nothing to do
+    const int at = s.slots_sorted[q];
     s.task_at[q] = at;
+    (void)batch;
     TaskHeader h;
     h.entry = entry;
     h.meta = (int)(end - q) | (parity << 31);
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
     using Ch = Chunk<T, VEC>;
     using R = Rows<T, VEC, KI, BPR>;
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int wv = __builtin_amdgcn_readfirstlane((blockIdx.x + p.wg_base) * 4 + (threadIdx.x >> 6));
     const unsigned long long tk0 = p.ticks ? stamp() : 0ull;
     // every wave-uniform input is requested before the first one is waited for (scalar loads, one wait)
     // (unused task slots of a batch are zero: a header with no samples means there is nothing to do)
@@ -789,7 +794,7 @@ __global__ __launch_bounds__(256) void mf_batch_generic_kernel(const MfParams<T>
     constexpr bool BPR = ALGO == MI355REC_MF_BPR;
     constexpr int KMAX_REG = 8;    // k <= 512 keeps the own-row gradient in registers, larger k is rejected at create
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int wv = __builtin_amdgcn_readfirstlane((blockIdx.x + p.wg_base) * 4 + (threadIdx.x >> 6));
     const TaskHeader *hp = p.tasks + ((size_t)batch_local * p.tasks_per_batch + min(wv, p.tasks_per_batch - 1));
     const int4 h0 = *reinterpret_cast<const int4 *>(hp);
     const bool active = (h0.y & LEN_MASK) != 0 && wv < p.tasks_per_batch;
@@ -889,6 +894,35 @@ __global__ __launch_bounds__(256) void mf_batch_generic_kernel(const MfParams<T>
 }
 
 // Current version of every row as float32 (the getters of .pyx:685-702), and the global bias after the last batch.
+// ---- exact multi-GPU mini-batches -----------------------------------------------------------
+// Every rank holds the same factors and the same schedule; rank r runs the tasks in slots [slot_lo, slot_hi) of a mini-batch
+// (whole workgroups), so the rows those tasks own get their new version on rank r only.  PACK copies them, in slot order, into
+// the rank's exchange slab; after the all-gather the other ranks' slabs are copied into the same rows (!PACK), and every rank
+// holds bit-identical factors again.  One wavefront per slot.
+template <class T, bool PACK>
+__global__ __launch_bounds__(256) void mf_shard_rows_kernel(const MfParams<T> p, const int batch_local, const int slot_lo, const int slot_hi,
+                                                            const int slots_per_rank, T *slab) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= p.tasks_per_batch) return;
+    const bool own = slot >= slot_lo && slot < slot_hi;
+    if (own != PACK) return;
+    const TaskHeader *hd = p.tasks + ((size_t)batch_local * p.tasks_per_batch + slot);
+    const int meta = hd->meta;
+    if ((meta & LEN_MASK) == 0) return;                                           // empty slot
+    if ((meta & META_WIDE) && ((meta >> 28) & 3) != 0) return;                    // quarters 1..3 of a wide list do not write
+    const int entry = hd->entry, own_par = (unsigned)meta >> 31;
+    const bool is_item = entry >= p.n_users;
+    const int row = is_item ? entry - p.n_users : entry;
+    T *Wn = (is_item ? (own_par ? p.V0 : p.V1) : (own_par ? p.U0 : p.U1)) + (size_t)row * p.k;
+    // slab layout: [rank][slot within the rank][k]
+    T *at = slab + (size_t)(PACK ? slot - slot_lo : slot) * p.k;
+    for (int e = lane; e < p.k; e += 64) {
+        if (PACK) at[e] = Wn[e];
+        else Wn[e] = at[e];
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void mf_gather_rows_kernel(const T *b0, const T *b1, const unsigned char *par, long long n_rows,
                                                              int k, float *out) {
@@ -1048,6 +1082,10 @@ struct mi355rec_mf {
     mi355rec_stats stats{};
     DispatchTimers dispatch_timers;
     int max_timed = 0;
+    // exact multi-GPU mode: this rank's share of every mini-batch and the exchange slabs
+    DeviceBuffer<unsigned char> shard_send, shard_recv;
+    int shard_rank = -1, shard_world = 0, shard_slots_per_rank = 0;
+    long long shard_batches = 0;
     hipGraphExec_t epoch_graph = nullptr;   // one native epoch: sampler, schedule, n_batches mini-batch kernels
     bool graph_failed = false;
     std::vector<double> host_loss;
@@ -1109,6 +1147,7 @@ void fill_params(mi355rec_mf *h, MfParams<T> &p) {
     p.samples_per_epoch = batches_per_epoch(h) * (long long)c.batch_size;
     p.tasks = h->tasks.ptr; p.recs = h->recs.ptr;
     p.ticks = h->ticks.ptr;
+    p.wg_base = 0;
 }
 
 // ---- kernel selection -------------------------------------------------------------------------------------------------
@@ -1119,9 +1158,10 @@ void launch_batch_as(mi355rec_mf *h, const MfParams<T> &p, int grid, int batch_l
 }
 
 template <int ALGO, class T>
-void launch_batch(mi355rec_mf *h, const MfParams<T> &p, int batch_local, bool timed) {
+void launch_batch(mi355rec_mf *h, const MfParams<T> &p, int batch_local, bool timed, int wg_count = -1) {
     constexpr int VEC = 16 / (int)sizeof(T);
-    const int grid = div_up(p.tasks_per_batch, 4);
+    const int grid = wg_count >= 0 ? wg_count : div_up(p.tasks_per_batch, 4);       // (p.wg_base names the first one)
+    if (grid == 0) return;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) h->dispatch_timers.next(e0, e1, h->max_timed);
     const int k = h->k, chunks = k / VEC;
@@ -1567,6 +1607,114 @@ extern "C" int mi355rec_mf_run_samples(mi355rec_mf_t h, const int32_t *u, const 
         else MI_HIP(hipMemcpyAsync(h->sr.ptr, rating, sizeof(float) * n, hipMemcpyHostToDevice, s));
         h->last_call_samples = 0;
         if (h->f64) run_samples_typed<double>(h, n); else run_samples_typed<float>(h, n);
+    });
+}
+
+// ---- exact multi-GPU mini-batches ---------------------------------------------------------------------------------------
+namespace {
+
+template <class T>
+void shard_begin_typed(mi355rec_mf *h) {
+    const long long B = h->cfg.batch_size, per_epoch = batches_per_epoch(h);
+    ensure_stream_capacity(h, (size_t)(per_epoch * B), per_epoch);
+    MfParams<T> p{};
+    fill_params(h, p);
+    begin_call(h);
+    h->timer.start(h->stream);
+    launch_sampler(h, p);                                   // the same stream on every rank: the generator is counter based
+    enqueue_schedule(h, p.samples_per_epoch, per_epoch);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(h->stream));
+}
+
+template <class T>
+void shard_batch_typed(mi355rec_mf *h, int b) {
+    MfParams<T> p{};
+    fill_params(h, p);
+    const int lo = h->shard_rank * h->shard_slots_per_rank, hi = std::min(lo + h->shard_slots_per_rank, p.tasks_per_batch);
+    p.wg_base = lo / 4;
+    launch_batch<MI355REC_MF_BPR, T>(h, p, b, true, std::max(0, div_up(hi - lo, 4)));
+    hipLaunchKernelGGL((mf_shard_rows_kernel<T, true>), dim3(div_up(p.tasks_per_batch, 4)), dim3(256), 0, h->stream, p, b, lo, hi,
+                       h->shard_slots_per_rank, as<T>(h->shard_send));
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(h->stream));                // the caller's collective may run on any stream
+}
+
+template <class T>
+void shard_merge_typed(mi355rec_mf *h, int b) {
+    MfParams<T> p{};
+    fill_params(h, p);
+    const int lo = h->shard_rank * h->shard_slots_per_rank, hi = std::min(lo + h->shard_slots_per_rank, p.tasks_per_batch);
+    hipLaunchKernelGGL((mf_shard_rows_kernel<T, false>), dim3(div_up(p.tasks_per_batch, 4)), dim3(256), 0, h->stream, p, b, lo, hi,
+                       h->shard_slots_per_rank, as<T>(h->shard_recv));
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(h->stream));                // the slab may be overwritten by the next exchange
+}
+
+template <class T>
+void shard_end_typed(mi355rec_mf *h) {
+    const long long B = h->cfg.batch_size, per_epoch = batches_per_epoch(h);
+    MfParams<T> p{};
+    fill_params(h, p);
+    hipLaunchKernelGGL(mf_stream_end_kernel<T>, dim3(1), dim3(64), 0, h->stream, p, per_epoch);
+    h->timer.stop(h->stream);
+    h->batches_done += per_epoch;
+    h->last_call_samples = per_epoch * B;
+    finish_call(h, per_epoch * B, per_epoch);               // (the loss is this rank's share)
+}
+
+}  // namespace
+
+extern "C" int mi355rec_mf_shard_begin_epoch(mi355rec_mf_t h, int32_t rank, int32_t world, void **d_send, void **d_recv,
+                                             uint64_t *bytes_per_rank, int32_t *n_batches) {
+    return guarded([&] {
+        MI_REQUIRE(h && d_send && d_recv && bytes_per_rank && n_batches, "NULL argument");
+        MI_REQUIRE(world >= 1 && rank >= 0 && rank < world, "rank %d of %d", rank, world);
+        if (h->cfg.algorithm != MI355REC_MF_BPR || h->cfg.sgd_mode != MI355REC_SGD)
+            fail(MI355REC_E_UNSUPPORTED, "the exact multi-GPU mode covers MF_BPR with sgd (optimiser moments and the FunkSVD global bias are not exchanged)");
+        ensure_device();
+        const int tpb = per_sample(h) * h->cfg.batch_size;
+        const int wgs = div_up(tpb, 4);
+        h->shard_rank = rank;
+        h->shard_world = world;
+        h->shard_slots_per_rank = div_up(wgs, world) * 4;    // whole workgroups: a wide list's four quarters stay together
+        const size_t ts = h->f64 ? sizeof(double) : sizeof(float);
+        const size_t per_rank = (size_t)h->shard_slots_per_rank * h->k * ts;
+        if (h->shard_send.count < per_rank) h->shard_send.alloc_zero(per_rank, h->stream);
+        if (h->shard_recv.count < per_rank * world) h->shard_recv.alloc_zero(per_rank * world, h->stream);
+        if (h->f64) shard_begin_typed<double>(h); else shard_begin_typed<float>(h);
+        h->shard_batches = batches_per_epoch(h);
+        *d_send = h->shard_send.ptr;
+        *d_recv = h->shard_recv.ptr;
+        *bytes_per_rank = per_rank;
+        *n_batches = (int32_t)h->shard_batches;
+    });
+}
+
+extern "C" int mi355rec_mf_shard_batch(mi355rec_mf_t h, int32_t batch) {
+    return guarded([&] {
+        MI_REQUIRE(h && h->shard_rank >= 0, "mi355rec_mf_shard_begin_epoch has not been called");
+        MI_REQUIRE(batch >= 0 && batch < h->shard_batches, "mini-batch %d of %lld", batch, h->shard_batches);
+        ensure_device();
+        if (h->f64) shard_batch_typed<double>(h, batch); else shard_batch_typed<float>(h, batch);
+    });
+}
+
+extern "C" int mi355rec_mf_shard_merge(mi355rec_mf_t h, int32_t batch) {
+    return guarded([&] {
+        MI_REQUIRE(h && h->shard_rank >= 0, "mi355rec_mf_shard_begin_epoch has not been called");
+        MI_REQUIRE(batch >= 0 && batch < h->shard_batches, "mini-batch %d of %lld", batch, h->shard_batches);
+        ensure_device();
+        if (h->f64) shard_merge_typed<double>(h, batch); else shard_merge_typed<float>(h, batch);
+    });
+}
+
+extern "C" int mi355rec_mf_shard_end_epoch(mi355rec_mf_t h) {
+    return guarded([&] {
+        MI_REQUIRE(h && h->shard_rank >= 0, "mi355rec_mf_shard_begin_epoch has not been called");
+        ensure_device();
+        if (h->f64) shard_end_typed<double>(h); else shard_end_typed<float>(h);
+        h->shard_rank = -1;
     });
 }
 

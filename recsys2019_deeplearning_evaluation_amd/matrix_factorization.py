@@ -116,6 +116,22 @@ class MatrixFactorization_MI355X_Epoch:
         N.check(self._lib.mi355rec_mf_get_last_samples(self._h, N.ptr(u), N.ptr(i), N.ptr(j), N.ptr(r), n.value, C.byref(n)))
         return (u, i, j) if self.algorithm_name == "MF_BPR" else (u, i, r)
 
+    # ---- exact multi-GPU mini-batches (sharding.sharded_bpr_epoch drives these) ----
+    def shard_begin_epoch(self, rank, world):
+        """Draws and schedules one epoch; returns (send address, receive address, bytes per rank, mini-batches)."""
+        send, recv, nbytes, nb = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_int32()
+        N.check(self._lib.mi355rec_mf_shard_begin_epoch(self._h, int(rank), int(world), C.byref(send), C.byref(recv), C.byref(nbytes), C.byref(nb)))
+        return send.value, recv.value, nbytes.value, nb.value
+
+    def shard_batch(self, batch):
+        N.check(self._lib.mi355rec_mf_shard_batch(self._h, int(batch)))
+
+    def shard_merge(self, batch):
+        N.check(self._lib.mi355rec_mf_shard_merge(self._h, int(batch)))
+
+    def shard_end_epoch(self):
+        N.check(self._lib.mi355rec_mf_shard_end_epoch(self._h))
+
     def stats(self):
         st = N.Stats()
         N.check(self._lib.mi355rec_mf_get_stats(self._h, C.byref(st)))

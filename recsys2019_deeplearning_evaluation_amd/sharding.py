@@ -177,6 +177,46 @@ def sharded_similarity_build(similarity_object, dist=None, rank=0, world=1, comm
     return out
 
 
+# --------------------------------------------------------------------------------------------------
+#                  BPR-MF: exact mini-batches, the tasks of every batch split over the ranks
+# --------------------------------------------------------------------------------------------------
+
+def sharded_bpr_epoch(epoch_object, dist=None, rank=0, world=1, comm=None):
+    """One BPR-MF epoch with EXACT single-GPU semantics on `world` GPUs.
+
+    Every rank holds an identical MatrixFactorization_MI355X_Epoch (same URM, same initial factors, same random_seed): the
+    sample stream and the row-task schedule are then identical too.  Per mini-batch each rank runs 1 / world of the row tasks,
+    the new row versions travel in ONE all-gather of fixed-size slabs (3 * batch_size / world rows of n_factors values per
+    rank), and every rank copies the others' rows in: the replicas stay bit-identical and equal to a single-GPU run.  One
+    exchange per mini-batch, so this only pays for large batch_size (the reference's search stops at 1024, where replicas --
+    one model per GPU -- are the mode that scales)."""
+    send, recv, nbytes, n_batches = epoch_object.shard_begin_epoch(rank, world)
+    if world > 1 and comm is None:
+        import torch
+        # (an epoch object may wrap its slabs itself: the CPU stand-in of tests/test_sharding_gloo.py has no device memory)
+        as_tensor = getattr(epoch_object, "shard_tensor", None) or (lambda address, n_words: device_tensor(address, (n_words,), "<i4"))
+        t_send = as_tensor(send, nbytes // 4)
+        t_recv = as_tensor(recv, world * nbytes // 4)
+        on_host = dist.get_backend() == "gloo"
+    for b in range(n_batches):
+        epoch_object.shard_batch(b)
+        if world > 1:
+            if comm is not None:
+                comm.all_gather_words(send, recv, nbytes // 4)
+            elif on_host:
+                mine = t_send.cpu()
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                t_recv.copy_(torch.cat(parts))
+                if t_recv.is_cuda:
+                    torch.cuda.synchronize()
+            else:
+                dist.all_gather_into_tensor(t_recv, t_send)
+                torch.cuda.synchronize()
+            epoch_object.shard_merge(b)
+    epoch_object.shard_end_epoch()
+
+
 def _run_range(similarity_object, s, e, n, d_idx, d_val):
     # compute_similarity's range rule treats start 0 / end n as "not given" (Compute_Similarity_Cython.pyx:447-451)
     similarity_object.compute_slabs_device(s if s > 0 else None, e if e < n else None, d_idx.data_ptr(), d_val.data_ptr())

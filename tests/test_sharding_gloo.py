@@ -71,3 +71,99 @@ def test_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "SHARDING_OK" in outs[0]
+
+
+BPR_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from recsys2019_deeplearning_evaluation_amd.sharding import sharded_bpr_epoch
+from recsys2019_deeplearning_evaluation_amd.synthetic import synthetic_urm
+
+
+class StandInEpoch:
+    """CPU stand-in with the shard_* surface of MatrixFactorization_MI355X_Epoch (there is no GPU here): BPR mini-batches in NumPy,
+    one task per (row, mini-batch) in sorted row order, the tasks of a mini-batch dealt to the ranks in contiguous slot ranges."""
+
+    def __init__(self, X, k, B, lr, seed):
+        self.X, self.k, self.B, self.lr = X.tocsr(), k, B, lr
+        rng = np.random.default_rng(seed)
+        self.nu, self.ni = X.shape
+        self.W = rng.normal(0, 0.1, (self.nu + self.ni, k)).astype(np.float32)      # users, then items
+        self.rng = np.random.default_rng(seed + 1)
+
+    def _draw(self):
+        n = (self.nu // self.B + 1) * self.B
+        u = self.rng.integers(0, self.nu, n)
+        i = np.array([self.X.indices[self.rng.integers(self.X.indptr[a], self.X.indptr[a + 1])] for a in u])
+        j = self.rng.integers(0, self.ni, n)
+        return u, i + self.nu, j + self.nu
+
+    def shard_begin_epoch(self, rank, world):
+        self.rank, self.world = rank, world
+        self.u, self.i, self.j = self._draw()
+        self.n_batches = len(self.u) // self.B
+        self.spr = -(-3 * self.B // world)
+        self.send = np.zeros((self.spr, self.k), np.float32)
+        self.recv = np.zeros((world * self.spr, self.k), np.float32)
+        return 0, 1, self.send.nbytes, self.n_batches
+
+    def shard_tensor(self, address, n_words):
+        return torch.from_numpy((self.recv if address else self.send).reshape(-1).view(np.int32))
+
+    def _tasks(self, b):
+        sl = slice(b * self.B, (b + 1) * self.B)
+        return np.unique(np.concatenate([self.u[sl], self.i[sl], self.j[sl]])), sl
+
+    def shard_batch(self, b):
+        rows, sl = self._tasks(b)
+        old = self.W.copy()
+        u, i, j = self.u[sl], self.i[sl], self.j[sl]
+        x = np.einsum("ij,ij->i", old[u], old[i] - old[j])
+        g = (1.0 / (1.0 + np.exp(x))).astype(np.float32)[:, None]
+        lo, hi = self.rank * self.spr, min((self.rank + 1) * self.spr, len(rows))
+        for slot in range(lo, hi):
+            r = rows[slot]
+            acc = (g[u == r] * (old[i[u == r]] - old[j[u == r]])).sum(0) + (g[i == r] * old[u[i == r]]).sum(0) - (g[j == r] * old[u[j == r]]).sum(0)
+            self.W[r] = old[r] + self.lr * acc / self.B
+            self.send[slot - lo] = self.W[r]
+
+    def shard_merge(self, b):
+        rows, _ = self._tasks(b)
+        lo, hi = self.rank * self.spr, (self.rank + 1) * self.spr
+        for slot, r in enumerate(rows):
+            if not lo <= slot < hi:
+                self.W[r] = self.recv[slot]
+
+    def shard_end_epoch(self):
+        pass
+
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+X = synthetic_urm(300, 120, 5000, 3, 60, seed=9, values="binary")
+single = StandInEpoch(X, 16, 64, 0.05, 3)
+split = StandInEpoch(X, 16, 64, 0.05, 3)
+for _ in range(2):
+    sharded_bpr_epoch(single, None, 0, 1)
+    sharded_bpr_epoch(split, dist, rank, world)
+assert np.array_equal(single.W, split.W), "rank %%d: the split mini-batches differ from the single-process ones" %% rank
+dist.barrier()
+if rank == 0:
+    print("SHARDED_BPR_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_exact_bpr_mode_world_size_2_gloo(tmp_path):
+    """The host side of SURVEY 8(e)'s exact multi-GPU BPR mode (sharding.sharded_bpr_epoch: per mini-batch kernel share -> one
+    all-gather of fixed slabs -> merge) over gloo with a NumPy stand-in for the epoch object; the device side is
+    tests/test_sharding_gpu.py."""
+    script = tmp_path / "bpr_worker.py"
+    script.write_text(BPR_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "SHARDED_BPR_OK" in outs[0]

@@ -17,8 +17,9 @@ sys.path.insert(0, %(root)r)
 import torch, torch.distributed as dist            # torch first: one HIP runtime in the process
 import numpy as np
 from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_MI355X, IALS_MI355X_Epoch, _native
+from recsys2019_deeplearning_evaluation_amd import MatrixFactorization_MI355X_Epoch
 from recsys2019_deeplearning_evaluation_amd.sharding import (sharded_similarity_build, sharded_ials_epoch, ials_row_ranges,
-                                                           balanced_column_ranges)
+                                                           balanced_column_ranges, sharded_bpr_epoch)
 from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
 torch.cuda.set_device(0); _native.set_device(0)
 dist.init_process_group("gloo")
@@ -44,6 +45,14 @@ for _ in range(2):
     sharded_ials_epoch(shard, dist, rank, world, ur, ir)
 Ud, Vd = shard.get_factors()
 assert np.abs(Ud - Us).max() <= 1e-12 * np.abs(Us).max() and np.abs(Vd - Vs).max() <= 1e-12 * np.abs(Vs).max(), "sharded IALS differs"
+# exact multi-GPU BPR mini-batches: the tasks of every batch split over the two ranks == the single-process epochs, bit for bit
+kw = dict(n_factors=32, algorithm_name="MF_BPR", batch_size=512, learning_rate=0.05, sgd_mode="sgd", user_reg=0.01, positive_reg=0.02,
+          negative_reg=0.03, random_seed=11)
+one = MatrixFactorization_MI355X_Epoch(X, **kw); one.epochIteration_Cython(2)
+two = MatrixFactorization_MI355X_Epoch(X, **kw)
+for _ in range(2):
+    sharded_bpr_epoch(two, dist, rank, world)
+assert np.array_equal(one.get_USER_factors(), two.get_USER_factors()) and np.array_equal(one.get_ITEM_factors(), two.get_ITEM_factors()), "sharded BPR differs"
 dist.barrier()
 if rank == 0:
     print("SHARDED_GPU_OK")
@@ -102,3 +111,44 @@ def test_interleaved_parts_on_one_gpu(gpu):
     np.testing.assert_array_equal(val, full_val)
     assert max(part_cost) <= 1.02 * min(part_cost) + float(costs.max())
     buf.close(); sim.close()
+
+
+@pytest.mark.parametrize("world,batch_size,k", [(1, 1000, 128), (4, 1000, 128), (8, 4096, 64), (3, 37, 20), (2, 2000, 8)])
+def test_exact_multi_gpu_bpr_emulated_on_one_gpu(gpu, world, batch_size, k):
+    """SURVEY 8(e)'s exact mode: `world` identical replicas in ONE process stand for the ranks; every mini-batch each runs its share of
+    the row tasks, the exchange slabs are copied between them device to device (what the all-gather does), everybody merges.
+    All replicas must end bit-identical to the plain single-GPU epochs -- including lists split over a workgroup (large batches)
+    and the any-k kernel (k = 20)."""
+    import ctypes as C
+    import numpy as np
+    from recsys2019_deeplearning_evaluation_amd import MatrixFactorization_MI355X_Epoch, _native as N
+    from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
+    X = named_urm("ml1m", "binary", scale=0.5)
+    kw = dict(n_factors=k, algorithm_name="MF_BPR", batch_size=batch_size, learning_rate=0.05, sgd_mode="sgd", user_reg=0.01,
+              positive_reg=0.02, negative_reg=0.03, random_seed=5)
+    single = MatrixFactorization_MI355X_Epoch(X, **kw)
+    single.epochIteration_Cython(2)
+    ranks = [MatrixFactorization_MI355X_Epoch(X, **kw) for _ in range(world)]
+    lib = N.load()
+    for _ in range(2):
+        slabs = [m.shard_begin_epoch(r, world) for r, m in enumerate(ranks)]
+        n_batches, nbytes = slabs[0][3], slabs[0][2]
+        for b in range(n_batches):
+            for m in ranks:
+                m.shard_batch(b)
+            for dst in range(world):                 # the all-gather: rank src's slab lands at offset src in everybody's receive buffer
+                for src in range(world):
+                    N.check(lib.mi355rec_device_memcpy(C.c_void_p(slabs[dst][1] + src * nbytes), C.c_void_p(slabs[src][0]), nbytes, 2))
+            for m in ranks:
+                m.shard_merge(b)
+        for m in ranks:
+            m.shard_end_epoch()
+    U, V = single.get_USER_factors(), single.get_ITEM_factors()
+    for m in ranks:
+        np.testing.assert_array_equal(m.get_USER_factors(), U)
+        np.testing.assert_array_equal(m.get_ITEM_factors(), V)
+    # a third epoch through the ordinary entry point continues from the same state
+    single.epochIteration_Cython(1); ranks[-1].epochIteration_Cython(1)
+    np.testing.assert_array_equal(ranks[-1].get_USER_factors(), single.get_USER_factors())
+    with pytest.raises(NotImplementedError):
+        MatrixFactorization_MI355X_Epoch(X, **dict(kw, sgd_mode="adam")).shard_begin_epoch(0, 2)
