@@ -67,7 +67,11 @@ template <class T> __device__ __forceinline__ void astore(T *p, T v) { __hip_ato
 
 template <class P> __device__ __forceinline__ size_t cell_at(const P &p, int r, int c) {
     // Triangular_Matrix.get_value/add_value (.pyx:1290-1330): in symmetric mode (r, c) with c > r lives at (c, r)
-    if (p.symmetric && c > r) { const int t = r; r = c; c = t; }
+    // and the store is the packed lower triangle, row r starting at r (r + 1) / 2 (:1237-1254): n (n + 1) / 2 cells
+    if (p.symmetric) {
+        if (c > r) { const int t = r; r = c; c = t; }
+        return ((size_t)r * ((size_t)r + 1) >> 1) + (size_t)c;
+    }
     return (size_t)r * p.n_items + c;
 }
 
@@ -162,8 +166,9 @@ __global__ __launch_bounds__(256) void slim_cell_keys_kernel(const DepParams d) 
     const long long cp = d.cellptr[t];
     for (int idx = lane; idx < L; idx += 64) {
         const int s = d.indices[rs + idx];
-        const unsigned ci = s == i ? NO_CELL : (unsigned)((size_t)max(i, s) * d.n_items + min(i, s));
-        const unsigned cj = s == j ? NO_CELL : (unsigned)((size_t)max(j, s) * d.n_items + min(j, s));
+        // (packed lower triangle, as cell_at: fits 32 bits up to 92 681 items)
+        const unsigned ci = s == i ? NO_CELL : (unsigned)(((size_t)max(i, s) * ((size_t)max(i, s) + 1) >> 1) + (size_t)min(i, s));
+        const unsigned cj = s == j ? NO_CELL : (unsigned)(((size_t)max(j, s) * ((size_t)max(j, s) + 1) >> 1) + (size_t)min(j, s));
         d.keys[cp + 2 * idx] = ((unsigned long long)ci << 32) | (unsigned)t;
         d.vals[cp + 2 * idx] = (int)(cp + 2 * idx);
         d.keys[cp + 2 * idx + 1] = ((unsigned long long)cj << 32) | (unsigned)t;
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void slim_flow_kernel(const SlimParam
     }
 }
 
-// Fallback (symmetric store with more than 65 535 items: cell ids no longer fit the 32-bit sort key): one workgroup runs
+// Fallback (symmetric store with more than 92 681 items: packed cell ids no longer fit the 32-bit sort key): one workgroup runs
 // the steps one after the other.
 template <class T>
 __global__ __launch_bounds__(1024) void slim_ordered_kernel(const SlimParams<T> p) {
@@ -710,7 +715,7 @@ void fill_params(mi355rec_slim *h, SlimParams<T> &p) {
 }
 
 bool flow_supported(const mi355rec_slim *h) {
-    return !(h->cfg.symmetric && h->n_items > 65535) && !getenv("MI355REC_SLIM_ORDERED");
+    return !(h->cfg.symmetric && h->n_items > 92681) && !getenv("MI355REC_SLIM_ORDERED");      // (cell ids are 32-bit sort keys)
 }
 
 void ensure_capacity(mi355rec_slim *h, size_t n) {
@@ -945,7 +950,9 @@ extern "C" int mi355rec_slim_create(mi355rec_slim_t *out, const mi355rec_slim_co
         const size_t ts = h->f64 ? sizeof(double) : sizeof(float);
         h->indptr.upload(indptr, (size_t)n_users + 1, s);
         h->indices.upload(indices, h->nnz, s);
-        h->S.alloc_zero((size_t)n_items * n_items * ts, s);          // .pyx:129 / :1237-1254
+        // .pyx:129 dense n x n; Triangular_Matrix :1237-1254 the packed lower triangle
+        const size_t n_cells = h->cfg.symmetric ? (size_t)n_items * ((size_t)n_items + 1) / 2 : (size_t)n_items * n_items;
+        h->S.alloc_zero(n_cells * ts, s);
         if (h->cfg.train_with_sparse_weights)                        // .pyx:124: an empty tree per row
             hipLaunchKernelGGL(slim_no_nodes_kernel, dim3(multiprocessor_count() * 8), dim3(256), 0, s,
                                reinterpret_cast<unsigned long long *>(h->S.ptr), (size_t)n_items * n_items);
