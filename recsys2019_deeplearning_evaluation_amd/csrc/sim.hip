@@ -54,6 +54,8 @@ struct SimParams {
     const int4 *items;  // work items of this call, most expensive first: {column, part, n_parts, first part slot}
     int n_items, start_col;
     const int *out_slot;    // interleaved parts: output row of every column of the call (NULL: column - start_col)
+    double fixed_scale;     // real-valued data: > 0 = the accumulator holds int64 fixed-point sums, products scaled by this power of two
+    double fixed_inv;       //                   (1 / fixed_scale); 0 = float64 sums
     uint32_t *part_buf;     // [part slots][n_cols_pad] partial accumulators of split columns
     unsigned *part_count;   // arrival counters, indexed by the first part slot of a split column
     unsigned long long *phase_ticks;   // diagnostics (MI355REC_SIM_PHASES=1): 100 MHz ticks per phase, summed over workgroups
@@ -89,6 +91,10 @@ __device__ __forceinline__ float euclidean_cell(const SimParams &p, float dot, f
     else if (p.euclid_mode == MI355REC_EUCLID_LOG) f = logf(__fadd_rn(d, 1.f));  // :192-193
     return __fdiv_rn(1.f, __fadd_rn(__fadd_rn(f, p.shrink), 1e-9f));
 }
+
+// float64 -> int64 by the "magic number" addition: for |x| < 2^51, bits(x + 1.5 * 2^52) - bits(1.5 * 2^52) = round-to-nearest-even(x)
+constexpr double FIXED_MAGIC = 6755399441055744.0;
+constexpr long long FIXED_MAGIC_BITS = 0x4338000000000000ll;
 
 // THREADS: workgroup size; G: lanes that cooperate on one user profile (sub-wave group);
 // UNIT: all stored values are 1.0 (implicit / set-based data) -> the value arrays are never read.
@@ -193,13 +199,19 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         // runs a fetch cursor DEPTH chunks ahead of its consume cursor: DEPTH loads per lane in flight, issued
         // unconditionally (finished groups re-read a hot line) so that the wait counters are static and the consume
         // side only ever waits for the oldest chunk.
-        // UNIT data accumulates integer counts with ds_add_u32; real-valued data accumulates float64 products with
-        // ds_add_f64 -- like the reference, whose accumulator is a double array.  (Measured on gfx950, random cells, per
-        // CU and ns: ds_add_u32 21.6 lane-adds, ds_add_u64 13.2, ds_add_f64 7.2, ds_add_f32 0.8 -- the float32 LDS
-        // atomic is 27x slower than the integer one and 9x slower than the float64 one.)
+        // UNIT data accumulates integer counts with ds_add_u32; real-valued data accumulates float64 products -- like the
+        // reference, whose accumulator is a double array.  (Measured on gfx950, random cells, per CU and ns: ds_add_u32 21.6
+        // lane-adds, ds_add_u64 13.2, ds_add_f64 7.2, ds_add_f32 0.8 -- the float32 LDS atomic is 27x slower than the integer
+        // one and 9x slower than the float64 one.)  Because the 64-bit INTEGER atomic is 1.8x faster than the float64 one, the
+        // products are accumulated as int64 fixed point whenever the host found a power-of-two scale that keeps every sum
+        // inside 62 bits and every product's rounding below 1e-7 of the smallest normalised result (p.fixed_scale > 0):
+        // x * scale is rounded to an integer by adding 1.5 * 2^52 in float64 (one fma) and subtracting that constant's bits;
+        // integer sums are exact and independent of the order of the adds.
         constexpr int DEPTH = UNIT ? 4 : 2;
         unsigned *acc_u = reinterpret_cast<unsigned *>(acc);
         double *acc_d = reinterpret_cast<double *>(acc);
+        unsigned long long *acc_q = reinterpret_cast<unsigned long long *>(acc);
+        const bool fixed_point = !UNIT && p.fixed_scale > 0.0;
         const uint4 *idx8 = reinterpret_cast<const uint4 *>(p.seg_idx16);
         const float4 *val4 = reinterpret_cast<const float4 *>(p.seg_val);
         int *tab = reinterpret_cast<int *>(aux) + wave * 192;       // [64] x {rs, re, weight}
@@ -261,11 +273,21 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                     const unsigned ww[4] = {ids[d].x, ids[d].y, ids[d].z, ids[d].w};
                     const float vv[8] = {vlo[d].x, vlo[d].y, vlo[d].z, vlo[d].w, vhi[d].x, vhi[d].y, vhi[d].z, vhi[d].w};
                     const double rd = (double)c_r[d];
+                    if (!UNIT && fixed_point) {
+                        const double rs = rd * p.fixed_scale;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const unsigned j = (e & 1) ? (ww[e >> 1] >> 16) : (ww[e >> 1] & 0xFFFFu);
-                        if (UNIT) atomicAdd(&acc_u[j], 1u);
-                        else atomicAdd(&acc_d[j], rd * (double)vv[e]);
+                        for (int e = 0; e < 8; ++e) {
+                            const unsigned j = (e & 1) ? (ww[e >> 1] >> 16) : (ww[e >> 1] & 0xFFFFu);
+                            const double q = __builtin_fma(rs, (double)vv[e], FIXED_MAGIC);
+                            atomicAdd(&acc_q[j], (unsigned long long)(__double_as_longlong(q) - FIXED_MAGIC_BITS));
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const unsigned j = (e & 1) ? (ww[e >> 1] >> 16) : (ww[e >> 1] & 0xFFFFu);
+                            if (UNIT) atomicAdd(&acc_u[j], 1u);
+                            else atomicAdd(&acc_d[j], rd * (double)vv[e]);
+                        }
                     }
                 }
             };
@@ -317,6 +339,10 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                     const uint4 b = src[q * stride4 + w];
                     if (UNIT) {
                         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                    } else if (p.fixed_scale > 0.0) {   // two int64 cells
+                        const unsigned long long a0 = (((unsigned long long)a.y << 32) | a.x) + (((unsigned long long)b.y << 32) | b.x);
+                        const unsigned long long a1 = (((unsigned long long)a.w << 32) | a.z) + (((unsigned long long)b.w << 32) | b.z);
+                        a = make_uint4((unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32));
                     } else {   // two float64 cells
                         const double a0 = __hiloint2double((int)a.y, (int)a.x) + __hiloint2double((int)b.y, (int)b.x);
                         const double a1 = __hiloint2double((int)a.w, (int)a.z) + __hiloint2double((int)b.w, (int)b.z);
@@ -393,7 +419,8 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                     const int j = tid + k * THREADS;
                     float v = 0.f;
                     if (j < n_tile) {
-                        v = (float)acc_d[j];
+                        v = p.fixed_scale > 0.0 ? (float)((double)(long long)reinterpret_cast<const unsigned long long *>(acc)[j] * p.fixed_inv)
+                                                : (float)acc_d[j];
                         if (euclid) {
                             v = tile_base + j != c ? euclidean_cell(p, v, sq_c, sqj[j], norm_c, nj[j]) : 0.f;
                             account(v);
@@ -735,6 +762,16 @@ __global__ __launch_bounds__(256) void weighting_apply_kernel(const int *csr_ptr
     }
 }
 
+// largest |value| (bit pattern of a non-negative float orders like the unsigned integer)
+__global__ void absmax_kernel(const float *val, size_t nnz, unsigned *out) {
+    unsigned m = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(fabsf(val[i])));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 __global__ void minmax_kernel(const float *val, size_t nnz, int *not_unit) {
     int bad = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x)
@@ -815,6 +852,7 @@ struct mi355rec_sim {
     std::vector<int> csc_ptr_host;
     std::vector<int> cost_order;   // all columns, most expensive first
     int group_lanes = 64;
+    double fixed_scale = 0.0;      // real-valued data: power-of-two scale of the int64 fixed-point accumulator (0: float64 sums)
     mi355rec_stats stats{};
     // last call
     int last_start = -1, last_end = -1;
@@ -991,6 +1029,8 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
         MI_HIP(hipMemsetAsync(h->phase_ticks.ptr, 0, 8 * sizeof(unsigned long long), h->stream));
         p.phase_ticks = h->phase_ticks.ptr;
     }
+    p.fixed_scale = unit_kernel ? 0.0 : h->fixed_scale;
+    p.fixed_inv = p.fixed_scale > 0.0 ? 1.0 / p.fixed_scale : 0.0;
     p.start_col = start;
     p.out_slot = nullptr;
     if (n_parts > 0) {
@@ -1216,6 +1256,45 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         h->csc_ptr_host.resize((size_t)n_cols + 1);
         h->csc_ptr.download(h->csc_ptr_host.data(), (size_t)n_cols + 1, s);
         MI_HIP(hipStreamSynchronize(s));
+
+        // Real-valued data: can the column sums be kept as int64 fixed point (ds_add_u64 is 1.8x faster than ds_add_f64)?
+        // Every product is at most P = max weight * max |column-side value| * max |value|; a cell sums at most N = longest
+        // column of them.  Scale 2^S with P * 2^S <= 2^50 (the float64 rounding trick needs |x| < 2^51) and N * P * 2^S <= 2^62.
+        // A cell is then off by at most N / 2 units of 2^-S; the smallest denominator it can meet is the smallest non-zero
+        // column norm squared (normalised similarities) -- accept when that WORST-CASE error stays below 1e-6 (a tenth of the
+        // parity bar; rounding errors of random sign add up to ~sqrt(N), not N), otherwise keep float64.
+        if (!(h->unit_values && !row_weights) && !getenv("MI355REC_SIM_F64_SUMS")) {
+            DeviceBuffer<unsigned> d_vmax;
+            d_vmax.alloc_zero(1, s);
+            hipLaunchKernelGGL(absmax_kernel, dim3(eg), dim3(eb), 0, s, h->csc_val.ptr, nnz, d_vmax.ptr);
+            MI_HIP(hipGetLastError());
+            unsigned vbits = 0;
+            d_vmax.download(&vbits, 1, s);
+            std::vector<double> sq((size_t)n_cols);
+            sumsq.download(sq.data(), (size_t)n_cols, s);
+            MI_HIP(hipStreamSynchronize(s));
+            float vmax_f;
+            memcpy(&vmax_f, &vbits, sizeof(float));
+            const double vmax = (double)vmax_f;
+            double wmax = 1.0;
+            if (row_weights)
+                for (int r = 0; r < n_rows; ++r) wmax = std::max(wmax, (double)std::fabs(row_weights[r]));
+            double longest = 1.0, min_sq = 0.0;
+            for (int c = 0; c < n_cols; ++c) {
+                longest = std::max(longest, (double)(h->csc_ptr_host[c + 1] - h->csc_ptr_host[c]));
+                if (sq[c] > 0.0 && (min_sq == 0.0 || sq[c] < min_sq)) min_sq = sq[c];
+            }
+            const double prod = wmax * (cfg->unit_column_side ? 1.0 : vmax) * vmax;
+            if (prod > 0.0 && std::isfinite(prod)) {
+                const int S = (int)std::floor(std::min(50.0 - std::log2(prod), 62.0 - std::log2(prod * longest)));
+                const double unit = std::ldexp(1.0, -S);
+                // denominators: norm_c * norm_j >= min_sq (normalised); otherwise the results are the sums themselves, whose
+                // scale is at least the smallest non-zero product -- bounded below by min_sq as well only for single-cell
+                // columns, so the same bar is applied (conservative for everything else)
+                const double worst = 0.5 * longest * unit / std::max(min_sq, 1e-300);
+                if (S > -1000 && S < 1000 && worst <= 1e-6) h->fixed_scale = std::ldexp(1.0, S);
+            }
+        }
 
         h->cost_order.resize(n_cols);
         std::iota(h->cost_order.begin(), h->cost_order.end(), 0);
