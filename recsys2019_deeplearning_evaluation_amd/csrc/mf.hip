@@ -92,7 +92,8 @@ struct MfParams {
     const TaskHeader *tasks;
     const int4 *recs;
     unsigned long long *ticks;           // optional [tasks_per_batch][8] shader-clock stamps of the last mini-batch (MI355REC_MF_TICKS=1)
-    int wg_base;                         // first workgroup of the mini-batch this launch covers (exact multi-GPU mode: a rank's share)
+    int wg_base, wg_stride;              // workgroup b of the launch is workgroup wg_base + b * wg_stride of the mini-batch (exact
+                                         // multi-GPU mode: rank r of G runs workgroups r, r + G, ...; otherwise 0 and 1)
 };
 
 // ---- wavefront reductions without LDS traffic ----------------------------------------------------------------------
@@ -247,6 +248,8 @@ struct SchedParams {
     unsigned char *spar;           // per incidence: buffer of the row's version this sample reads
     unsigned char *par;            // per row: buffer of the current version (advanced by the last task of the row)
     int *batch_count;
+    int *slot_flag;                // per original slot (sample * per + role): 1 where a task's first incidence sits
+    const int *slot_rank;          // exclusive scan of slot_flag
     TaskHeader *tasks;
     int4 *recs;
 };
@@ -269,7 +272,9 @@ __global__ __launch_bounds__(256) void mf_keys_kernel(const SchedParams s) {
 __global__ __launch_bounds__(256) void mf_heads_kernel(const SchedParams s) {
     const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (q >= s.n_samples * s.per) return;
-    s.head[q] = q == 0 || s.keys_sorted[q] != s.keys_sorted[q - 1];
+    const int head = q == 0 || s.keys_sorted[q] != s.keys_sorted[q - 1];
+    s.head[q] = head;
+    if (head) s.slot_flag[s.slots_sorted[q]] = 1;      // (the sort is stable: the run's first incidence in stream order)
 }
 
 // One thread per run head: version parity of the row at this batch, a place in the batch's task array, the header.
@@ -291,12 +296,20 @@ __global__ __launch_bounds__(256) void mf_tasks_kernel(const SchedParams s) {
     }
     const int rank = s.head_scan[q] - s.head_scan[lo];
     const int parity = (s.par[entry] + rank) & 1;
-    // the task's header goes to the slot of its FIRST incidence (the sort is stable: the smallest sample * per + role of the run),
-    // which lies inside the mini-batch's tasks_per_batch slots and is the same on every replica of the stream (the exact
-    // multi-GPU mode splits a mini-batch's slots over the ranks); unused slots stay zero: no samples, nothing to do
-    const int at = s.slots_sorted[q];
+    // the task's place among the mini-batch's headers = the rank of its FIRST incidence (the sort is stable: the smallest
+    // sample * per + role of the run) among the first incidences of the batch's tasks: headers are packed at the front of
+    // the batch's slots in stream order -- the same layout on every replica of the stream (the exact multi-GPU mode splits a
+    // mini-batch's slots over the ranks), with no atomic counter (three mini-batches of 65 536 samples used to serialise
+    // 590 k atomics on three addresses: 86 M samples/s against 230 M)
+    const long long first_slot = (long long)batch * s.tasks_per_batch;
+    // -- or, with a per-batch counter (s.batch_count), simply the next free one: run heads arrive roughly in key order, i.e. the
+    // batch's headers end up sorted by row (users first), which the mini-batch kernel of FunkSVD's 20 001 small batches likes
+    // better (118 vs 87 M samples/s at ML-20M shape: neighbouring wavefronts gather neighbouring rows, and the workgroups that
+    // carry global-bias terms are the leading ones)
+    int at = (int)first_slot;
+    if (s.batch_count) at += atomicAdd(&s.batch_count[batch], 1);
+    else at += s.slot_rank[s.slots_sorted[q]] - s.slot_rank[first_slot];
     s.task_at[q] = at;
-    (void)batch;
     TaskHeader h;
     h.entry = entry;
     h.meta = (int)(end - q) | (parity << 31);
@@ -584,7 +597,7 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
     using Ch = Chunk<T, VEC>;
     using R = Rows<T, VEC, KI, BPR>;
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((blockIdx.x + p.wg_base) * 4 + (threadIdx.x >> 6));
+    const int wv = __builtin_amdgcn_readfirstlane((blockIdx.x * p.wg_stride + p.wg_base) * 4 + (threadIdx.x >> 6));
     const unsigned long long tk0 = p.ticks ? stamp() : 0ull;
     // every wave-uniform input is requested before the first one is waited for (scalar loads, one wait)
     // (unused task slots of a batch are zero: a header with no samples means there is nothing to do)
@@ -794,7 +807,7 @@ __global__ __launch_bounds__(256) void mf_batch_generic_kernel(const MfParams<T>
     constexpr bool BPR = ALGO == MI355REC_MF_BPR;
     constexpr int KMAX_REG = 8;    // k <= 512 keeps the own-row gradient in registers, larger k is rejected at create
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((blockIdx.x + p.wg_base) * 4 + (threadIdx.x >> 6));
+    const int wv = __builtin_amdgcn_readfirstlane((blockIdx.x * p.wg_stride + p.wg_base) * 4 + (threadIdx.x >> 6));
     const TaskHeader *hp = p.tasks + ((size_t)batch_local * p.tasks_per_batch + min(wv, p.tasks_per_batch - 1));
     const int4 h0 = *reinterpret_cast<const int4 *>(hp);
     const bool active = (h0.y & LEN_MASK) != 0 && wv < p.tasks_per_batch;
@@ -895,18 +908,19 @@ __global__ __launch_bounds__(256) void mf_batch_generic_kernel(const MfParams<T>
 
 // Current version of every row as float32 (the getters of .pyx:685-702), and the global bias after the last batch.
 // ---- exact multi-GPU mini-batches -----------------------------------------------------------
-// Every rank holds the same factors and the same schedule; rank r runs the tasks in slots [slot_lo, slot_hi) of a mini-batch
-// (whole workgroups), so the rows those tasks own get their new version on rank r only.  PACK copies them, in slot order, into
-// the rank's exchange slab; after the all-gather the other ranks' slabs are copied into the same rows (!PACK), and every rank
-// holds bit-identical factors again.  One wavefront per slot.
+// Every rank holds the same factors and the same schedule; the workgroups (4 task slots: a split list's quarters stay together) of
+// a mini-batch are dealt round-robin to the ranks -- headers are packed at the front of a batch's slots, so contiguous shares
+// would leave the last ranks idle -- and the rows the tasks of rank r own get their new version on rank r only.  PACK copies
+// them into the rank's exchange slab (slab row = 4 * (workgroup / world) + slot % 4); after the all-gather the other ranks'
+// slabs are copied into the same rows (!PACK), and every rank holds bit-identical factors again.  One wavefront per slot.
 template <class T, bool PACK>
-__global__ __launch_bounds__(256) void mf_shard_rows_kernel(const MfParams<T> p, const int batch_local, const int slot_lo, const int slot_hi,
+__global__ __launch_bounds__(256) void mf_shard_rows_kernel(const MfParams<T> p, const int batch_local, const int rank, const int world,
                                                             const int slots_per_rank, T *slab) {
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= p.tasks_per_batch) return;
-    const bool own = slot >= slot_lo && slot < slot_hi;
-    if (own != PACK) return;
+    const int wg = slot >> 2, owner = wg % world;
+    if ((owner == rank) != PACK) return;
     const TaskHeader *hd = p.tasks + ((size_t)batch_local * p.tasks_per_batch + slot);
     const int meta = hd->meta;
     if ((meta & LEN_MASK) == 0) return;                                           // empty slot
@@ -915,8 +929,9 @@ __global__ __launch_bounds__(256) void mf_shard_rows_kernel(const MfParams<T> p,
     const bool is_item = entry >= p.n_users;
     const int row = is_item ? entry - p.n_users : entry;
     T *Wn = (is_item ? (own_par ? p.V0 : p.V1) : (own_par ? p.U0 : p.U1)) + (size_t)row * p.k;
-    // slab layout: [rank][slot within the rank][k]
-    T *at = slab + (size_t)(PACK ? slot - slot_lo : slot) * p.k;
+    // slab layout: [rank][slot within the rank][k]; PACK addresses the rank's own slab, !PACK the gathered one
+    const int local = (wg / world) * 4 + (slot & 3);
+    T *at = slab + ((size_t)(PACK ? 0 : owner) * slots_per_rank + local) * p.k;
     for (int e = lane; e < p.k; e += 64) {
         if (PACK) at[e] = Wn[e];
         else Wn[e] = at[e];
@@ -1148,6 +1163,7 @@ void fill_params(mi355rec_mf *h, MfParams<T> &p) {
     p.tasks = h->tasks.ptr; p.recs = h->recs.ptr;
     p.ticks = h->ticks.ptr;
     p.wg_base = 0;
+    p.wg_stride = 1;
 }
 
 // ---- kernel selection -------------------------------------------------------------------------------------------------
@@ -1250,7 +1266,13 @@ void enqueue_schedule(mi355rec_mf *h, long long n_samples, long long n_batches) 
     sp.keys = h->keys.ptr; sp.slots = h->slots.ptr;
     sp.keys_sorted = h->keys_sorted.ptr; sp.slots_sorted = h->slots_sorted.ptr;
     sp.head = h->head.ptr; sp.head_scan = h->head_scan.ptr; sp.task_at = h->task_at.ptr;
-    sp.spar = h->spar.ptr; sp.par = h->par.ptr; sp.batch_count = h->batch_count.ptr;
+    sp.spar = h->spar.ptr; sp.par = h->par.ptr; // placement of the headers inside a batch: by rank (reproducible layout) for the exact multi-GPU mode and for batches too large
+    // for the in-LDS schedule; by counter for streams of many small batches (see mf_tasks_kernel)
+    const bool by_rank = h->shard_rank >= 0 || sp.tasks_per_batch > FAST_MAX_SLOTS;
+    sp.batch_count = by_rank ? nullptr : h->batch_count.ptr;
+    // (the unsorted keys are dead after the sort: their buffer holds the first-incidence flags and their scan, n ints each)
+    sp.slot_flag = reinterpret_cast<int *>(h->keys.ptr);
+    sp.slot_rank = reinterpret_cast<int *>(h->keys.ptr) + n;
     sp.tasks = h->tasks.ptr; sp.recs = h->recs.ptr;
     const int end_bit = sp.batch_bits + bits_for((unsigned long long)h->n_users + h->n_items);
     MI_REQUIRE(end_bit <= 64, "sample stream too long for the schedule keys");
@@ -1260,9 +1282,12 @@ void enqueue_schedule(mi355rec_mf *h, long long n_samples, long long n_batches) 
     size_t bytes = h->cub_tmp_bytes;
     MI_HIP(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->slots.ptr,
                                               h->slots_sorted.ptr, (int)n, 0, end_bit, s));
+    MI_HIP(hipMemsetAsync(sp.slot_flag, 0, sizeof(int) * (size_t)n, s));
     hipLaunchKernelGGL(mf_heads_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, sp);
     bytes = h->cub_tmp_bytes;
     MI_HIP(hipcub::DeviceScan::InclusiveSum(h->cub_tmp.ptr, bytes, h->head.ptr, h->head_scan.ptr, (int)n, s));
+    bytes = h->cub_tmp_bytes;
+    MI_HIP(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp.ptr, bytes, sp.slot_flag, reinterpret_cast<int *>(h->keys.ptr) + n, (int)n, s));
     hipLaunchKernelGGL(mf_tasks_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, sp);
     hipLaunchKernelGGL(mf_recs_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, sp);
 }
@@ -1631,10 +1656,11 @@ template <class T>
 void shard_batch_typed(mi355rec_mf *h, int b) {
     MfParams<T> p{};
     fill_params(h, p);
-    const int lo = h->shard_rank * h->shard_slots_per_rank, hi = std::min(lo + h->shard_slots_per_rank, p.tasks_per_batch);
-    p.wg_base = lo / 4;
-    launch_batch<MI355REC_MF_BPR, T>(h, p, b, true, std::max(0, div_up(hi - lo, 4)));
-    hipLaunchKernelGGL((mf_shard_rows_kernel<T, true>), dim3(div_up(p.tasks_per_batch, 4)), dim3(256), 0, h->stream, p, b, lo, hi,
+    const int wgs = div_up(p.tasks_per_batch, 4);
+    p.wg_base = h->shard_rank;
+    p.wg_stride = h->shard_world;
+    launch_batch<MI355REC_MF_BPR, T>(h, p, b, true, wgs > h->shard_rank ? (wgs - h->shard_rank + h->shard_world - 1) / h->shard_world : 0);
+    hipLaunchKernelGGL((mf_shard_rows_kernel<T, true>), dim3(wgs), dim3(256), 0, h->stream, p, b, h->shard_rank, h->shard_world,
                        h->shard_slots_per_rank, as<T>(h->shard_send));
     MI_HIP(hipGetLastError());
     MI_HIP(hipStreamSynchronize(h->stream));                // the caller's collective may run on any stream
@@ -1644,9 +1670,8 @@ template <class T>
 void shard_merge_typed(mi355rec_mf *h, int b) {
     MfParams<T> p{};
     fill_params(h, p);
-    const int lo = h->shard_rank * h->shard_slots_per_rank, hi = std::min(lo + h->shard_slots_per_rank, p.tasks_per_batch);
-    hipLaunchKernelGGL((mf_shard_rows_kernel<T, false>), dim3(div_up(p.tasks_per_batch, 4)), dim3(256), 0, h->stream, p, b, lo, hi,
-                       h->shard_slots_per_rank, as<T>(h->shard_recv));
+    hipLaunchKernelGGL((mf_shard_rows_kernel<T, false>), dim3(div_up(p.tasks_per_batch, 4)), dim3(256), 0, h->stream, p, b, h->shard_rank,
+                       h->shard_world, h->shard_slots_per_rank, as<T>(h->shard_recv));
     MI_HIP(hipGetLastError());
     MI_HIP(hipStreamSynchronize(h->stream));                // the slab may be overwritten by the next exchange
 }
