@@ -84,7 +84,9 @@ def pmc_traffic(kernel):
         try:
             with open(path) as f:
                 doc = json.load(f)
-            return doc["kernels"][kernel]["hbm_bytes_per_launch"], "%s (collected %s)" % (os.path.basename(path), doc.get("collected", "?"))
+            for name, row in doc["kernels"].items():          # (rocprofv3 reports template instances: "mf_batch_kernel<0, float, 4, 32, 1>")
+                if name == kernel or name.split("<")[0] == kernel:
+                    return row["hbm_bytes_per_launch"], "%s: %s (collected %s)" % (os.path.basename(path), name, doc.get("collected", "?"))
         except Exception:
             continue
     return None, None

@@ -153,10 +153,10 @@ class Compute_Similarity_MI355X:
     def compute_similarity(self, start_col=None, end_col=None):
         if self.TopK == 0:
             s, e = self._range(start_col, end_col)
-            W = np.zeros((self.n_columns, self.n_columns), dtype=np.float32)
-            slab = np.empty((self.n_columns, e - s), dtype=np.float32)
-            N.check(self._lib.mi355rec_sim_compute_dense(self._h, s, e, N.ptr(slab), e - s))
-            W[:, s:e] = slab
+            # the device writes columns [s, e) straight into W (row pitch n_columns): no second n x n array on the host
+            W = np.zeros((self.n_columns, self.n_columns), dtype=np.float32) if (s, e) != (0, self.n_columns) else \
+                np.empty((self.n_columns, self.n_columns), dtype=np.float32)
+            N.check(self._lib.mi355rec_sim_compute_dense(self._h, s, e, C.c_void_p(W.ctypes.data + 4 * s), self.n_columns))
             return W
         # CSR assembled on the device: SciPy's COO/CSC -> CSR conversion of the result would cost more than the build
         s, e = self._range(start_col, end_col)
