@@ -62,6 +62,12 @@ typedef int int8v __attribute__((ext_vector_type(8)));
 constexpr int ROLE_U = 0, ROLE_I = 1;   // 2: negative item
 
 template <class T> struct MuState { T mu, c1, c2, pad; };
+// one L2 atomic per workgroup that carries global-bias terms: atomics on ONE address retire at about 0.2 us each (measured through
+// the batch kernel: 31 per address cost 3 us per mini-batch), so the terms are spread over a wavefront's worth of addresses
+constexpr int MU_SLOTS = 64;
+// (Measured and rejected: no atomics at all -- one cell per workgroup, every wavefront of the next batch folds the ~500 cells in a
+// fixed order, which makes the global bias bit-reproducible -- costs 8 loads per lane and wavefront: 157 ms per FunkSVD epoch at
+// ML-20M shape against 145 ms with 64 atomic slots and 164 ms with 16.)
 
 template <class T>
 struct MfParams {
@@ -79,7 +85,7 @@ struct MfParams {
     T *c1U, *c2U, *c1V, *c2V;            // optimiser state (one copy: only the row's own task touches it)
     T *c1_bu, *c2_bu, *c1_bi, *c2_bi;
     MuState<T> *mu_state;                // [3] ring: global bias after batch b - 1, written by batch b        (FunkSVD)
-    T *mu_acc;                           // [3][16] ring: batch b's global-bias gradient terms, spread over 16 addresses
+    T *mu_acc;                           // [3][MU_SLOTS] ring: batch b's global-bias gradient terms, spread over MU_SLOTS addresses
     T *asy_mu, *asy_c_mu;                // AsySVD: global bias and its optimiser state, updated in place
     unsigned char *par;                  // [n_u_rows + n_items] buffer of every row's current version at stream start
     double *loss_slots;                  // [tasks_per_batch * 4] per (wavefront, group) running loss
@@ -537,16 +543,25 @@ template <class T, class P> __device__ __forceinline__ void adam_powers(const P 
 
 // Global bias as the batch `gb` must see it (FunkSVD with bias): the value after batch gb - 2 plus batch gb - 1's step,
 // computed identically by every wavefront from the ring; wavefront 0 files the result for the next batch.
+// In two halves: the ring is REQUESTED before the row gathers of the wavefront's first sample are issued and folded after
+// them -- with one call in front of the gathers the fold's wait put the whole ring round trip (batch index -> ring -> sum) in
+// front of the gathers: 8.4 us per mini-batch against 5.0 without biases.
+template <class T> struct MuRequest { MuState<T> st; T part; };
+
 template <class T>
-__device__ __forceinline__ T global_bias_at(const MfParams<T> &p, long long gb, bool writer, int lane) {
-    const int prev = (int)((gb + 2) % 3), cur = (int)(gb % 3), nxt = (int)((gb + 1) % 3);
-    MuState<T> st = p.mu_state[prev];
-    T part = lane < 16 ? p.mu_acc[prev * 16 + lane] : (T)0;
-    part += dpp_mov<0x128>(part);
-    part += dpp_mov<0x124>(part);
-    part += dpp_mov<0x122>(part);
-    part += dpp_mov<0x121>(part);
-    const T sum = __shfl(part, 0);
+__device__ __forceinline__ MuRequest<T> global_bias_request(const MfParams<T> &p, long long gb, int lane) {
+    const int prev = (int)((gb + 2) % 3);
+    MuRequest<T> r;
+    r.st = p.mu_state[prev];
+    r.part = p.mu_acc[prev * MU_SLOTS + lane];
+    return r;
+}
+
+template <class T>
+__device__ __forceinline__ T global_bias_finish(const MfParams<T> &p, MuRequest<T> r, long long gb, bool writer, int lane) {
+    const int cur = (int)(gb % 3), nxt = (int)((gb + 1) % 3);
+    MuState<T> st = r.st;
+    const T sum = wave_sum(r.part);
     if (gb > 0) {
         T pw1, pw2;
         adam_powers(p, gb, pw1, pw2);           // the step belongs to batch gb - 1, whose 1-based index is gb
@@ -555,9 +570,14 @@ __device__ __forceinline__ T global_bias_at(const MfParams<T> &p, long long gb, 
     }
     if (writer) {
         if (lane == 0) p.mu_state[cur] = st;
-        if (lane < 16) p.mu_acc[nxt * 16 + lane] = (T)0;
+        p.mu_acc[nxt * MU_SLOTS + lane] = (T)0;
     }
     return st.mu;
+}
+
+template <class T>
+__device__ __forceinline__ T global_bias_at(const MfParams<T> &p, long long gb, bool writer, int lane) {
+    return global_bias_finish(p, global_bias_request(p, gb, lane), gb, writer, lane);
 }
 
 // the three rows of one sample, KI chunks of VEC elements per lane
@@ -620,7 +640,9 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
     T mu_eff = (T)0;
     unsigned long long tk1 = 0, tk2 = 0, tk3 = 0;
     if (p.ticks) tk1 = stamp();          // header has arrived (its value decided `active`)
-    if (bias) mu_eff = global_bias_at(p, gb, wv == 0, lane);
+    MuRequest<T> mu_req{};
+    if (bias) mu_req = global_bias_request(p, gb, lane);
+    if (bias && !active) mu_eff = global_bias_finish(p, mu_req, gb, wv == 0, lane);      // (wavefront 0 files the value either way)
     if (active) {
         const int entry = h0.x, len = h0.y & LEN_MASK, own_par = (unsigned)h0.y >> 31, start = h0.z;
         // a wide task (list longer than two rounds of a wavefront) owns the 4 wavefronts of this workgroup: quarter `part` takes list
@@ -644,6 +666,7 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
         int4 rec_n = rec;
         if (iters > 1) rec_n = p.recs[start + min(base + step + g, len - 1)];
         R rows = load_rows<T, VEC, LPR, KI, BPR>(p, rec, li, cok, bias);
+        if (bias) mu_eff = global_bias_finish(p, mu_req, gb, wv == 0, lane);               // folded behind the gathers just issued
         T pw1, pw2;
         adam_powers(p, gb + 1, pw1, pw2);
 
@@ -791,7 +814,7 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
         __syncthreads();
         if (threadIdx.x == 0) {
             const T sum = (s_mu[0] + s_mu[1]) + (s_mu[2] + s_mu[3]);
-            if (sum != (T)0) atomicAdd(&p.mu_acc[(int)(gb % 3) * 16 + (blockIdx.x & 15)], sum);
+            if (sum != (T)0) atomicAdd(&p.mu_acc[(int)(gb % 3) * MU_SLOTS + (blockIdx.x & (MU_SLOTS - 1))], sum);
         }
     }
     if (p.ticks && lane == 0 && wv < p.tasks_per_batch) {
@@ -901,7 +924,7 @@ __global__ __launch_bounds__(256) void mf_batch_generic_kernel(const MfParams<T>
         if (threadIdx.x == 0) {
             const T sum = (s_mu[0] + s_mu[1]) + (s_mu[2] + s_mu[3]);
             const long long gb = p.state->batch_base + batch_local;
-            if (sum != (T)0) atomicAdd(&p.mu_acc[(int)(gb % 3) * 16 + (blockIdx.x & 15)], sum);
+            if (sum != (T)0) atomicAdd(&p.mu_acc[(int)(gb % 3) * MU_SLOTS + (blockIdx.x & (MU_SLOTS - 1))], sum);
         }
     }
 }
@@ -1462,7 +1485,7 @@ void create_typed(mi355rec_mf *h, const void *U0, const void *V0) {
         }
     }
     h->mu_state.alloc_zero(3 * sizeof(MuState<T>), s);
-    h->mu_acc.alloc_zero(3 * 16 * ts, s);
+    h->mu_acc.alloc_zero(3 * MU_SLOTS * ts, s);
     h->asy_mu.alloc_zero(ts, s);
     h->asy_c_mu.alloc_zero(2 * ts, s);
 }

@@ -368,3 +368,4 @@ def test_asysvd_native_epoch_and_recommender(gpu):
     assert len(rec.recommend(3, cutoff=5)) == 5
     with pytest.raises(AssertionError):
         MatrixFactorization_MI355X_Epoch(X, n_factors=4, algorithm_name="ASY_SVD", batch_size=2)
+
