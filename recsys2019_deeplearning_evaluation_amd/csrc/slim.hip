@@ -83,21 +83,22 @@ __device__ __forceinline__ double sigmoid_of_minus(double x) { return 1.0 / (1.0
 // per-ITEM adaptive step (.pyx:398-436); pw1 / pw2 = 1 - beta^t of this step.  The cells travel between workgroups with the
 // item's ticket, hence the agent-scope accesses.
 template <class T>
-__device__ __forceinline__ T slim_adapt(const SlimParams<T> &p, T g, int item, T pw1, T pw2) {
+__device__ __forceinline__ T slim_adapt_cells(const SlimParams<T> &p, T g, int item, T pw1, T pw2, T c1, T c2) {
+    // c1 / c2: the item's optimiser cells as the owner of the item's ticket read them
     switch (p.sgd_mode) {
         case MI355REC_ADAGRAD: {
-            const T c = aload(&p.c1[item]) + g * g;
+            const T c = c1 + g * g;
             astore(&p.c1[item], c);
             return g / (root(c) + (T)1e-8);
         }
         case MI355REC_RMSPROP: {
-            const T c = aload(&p.c1[item]) * p.gamma + p.one_m_gamma * (g * g);
+            const T c = c1 * p.gamma + p.one_m_gamma * (g * g);
             astore(&p.c1[item], c);
             return g / (root(c) + (T)1e-8);
         }
         case MI355REC_ADAM: {
-            const T m1 = aload(&p.c1[item]) * p.beta_1 + p.one_m_beta_1 * g;
-            const T m2 = aload(&p.c2[item]) * p.beta_2 + p.one_m_beta_2 * (g * g);
+            const T m1 = c1 * p.beta_1 + p.one_m_beta_1 * g;
+            const T m2 = c2 * p.beta_2 + p.one_m_beta_2 * (g * g);
             astore(&p.c1[item], m1);
             astore(&p.c2[item], m2);
             return (m1 / pw1) / (root(m2 / pw2) + (T)1e-8);
@@ -105,6 +106,14 @@ __device__ __forceinline__ T slim_adapt(const SlimParams<T> &p, T g, int item, T
         default:
             return g;
     }
+}
+
+template <class T>
+__device__ __forceinline__ T slim_adapt(const SlimParams<T> &p, T g, int item, T pw1, T pw2) {
+    T c1 = (T)0, c2 = (T)0;
+    if (p.sgd_mode != MI355REC_SGD) c1 = aload(&p.c1[item]);
+    if (p.sgd_mode == MI355REC_ADAM) c2 = aload(&p.c2[item]);
+    return slim_adapt_cells(p, g, item, pw1, pw2, c1, c2);
 }
 
 template <class T>
@@ -244,6 +253,17 @@ __global__ __launch_bounds__(FLOW_THREADS) void slim_flow_kernel(const SlimParam
             __syncthreads();
         }
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        // the items' optimiser cells belong to whoever holds the items' tickets: requested now, next to the gathers, instead of
+        // after the gradient is known (one dependent round trip less per step for adagrad / rmsprop / adam)
+        T oc1_i = (T)0, oc1_j = (T)0, oc2_i = (T)0, oc2_j = (T)0;
+        if (tid == 0 && p.sgd_mode != MI355REC_SGD) {
+            oc1_i = aload(&p.c1[i]);
+            oc1_j = aload(&p.c1[j]);
+            if (p.sgd_mode == MI355REC_ADAM) {
+                oc2_i = aload(&p.c2[i]);
+                oc2_j = aload(&p.c2[j]);
+            }
+        }
         // x_uij over the profile (.pyx:243-260)
         T x = (T)0;
         T va[FLOW_REGS], vb[FLOW_REGS];
@@ -287,8 +307,8 @@ __global__ __launch_bounds__(FLOW_THREADS) void slim_flow_kernel(const SlimParam
                 pw1 = (T)(1.0 - pow(p.beta_1_d, tt));
                 pw2 = (T)(1.0 - pow(p.beta_2_d, tt));
             }
-            s_g[0] = slim_adapt(p, g, i, pw1, pw2);                    // item i first, then j, as .pyx:267-268
-            s_g[1] = slim_adapt(p, g, j, pw1, pw2);
+            s_g[0] = slim_adapt_cells(p, g, i, pw1, pw2, oc1_i, oc2_i);     // item i first, then j, as .pyx:267-268
+            s_g[1] = j != i ? slim_adapt_cells(p, g, j, pw1, pw2, oc1_j, oc2_j) : slim_adapt(p, g, j, pw1, pw2);      // (a replayed stream may repeat the item)
             atomicAdd(&p.loss_slots[t & (LOSS_SLOTS - 1)], (double)tot * (double)tot);
         }
         __syncthreads();
