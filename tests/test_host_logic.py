@@ -199,3 +199,24 @@ def test_similarity_matrix_topk_reference_unit_tests():
     on_dense = similarityMatrixTopK(dense_input, k=5).toarray()
     on_sparse = similarityMatrixTopK(sps.csc_matrix(dense_input), k=5).toarray()
     assert np.allclose(on_dense, on_sparse)                                   # sparseToSparse (:34-50)
+
+
+def test_interleaved_parts_are_equal_in_count_and_cost():
+    """The serpentine deal of the cost order (the multi-GPU partition of the similarity build, restated on the host): a partition,
+    counts within one column of each other, cost within the heaviest column of each other -- against contiguous ranges, which
+    balance cost but not counts (that imbalance is what pads the all-gather slabs)."""
+    from recsys2019_deeplearning_evaluation_amd.sharding import balanced_column_ranges, interleaved_parts
+    rng = np.random.default_rng(4)
+    cost = np.sort((rng.pareto(1.2, 5000) * 1000).astype(np.int64))[::-1].copy()        # popularity skew, heavy head first
+    for n_parts in (1, 2, 3, 8):
+        parts = interleaved_parts(cost, n_parts)
+        assert sorted(np.concatenate(parts).tolist()) == list(range(len(cost)))
+        sizes = [len(p) for p in parts]
+        assert max(sizes) - min(sizes) <= 1
+        sums = [int(cost[p].sum()) for p in parts]
+        assert max(sums) - min(sums) <= int(cost.max())
+    ranges = balanced_column_ranges(cost, 8)
+    widths = [e - s for s, e in ranges]
+    assert max(widths) > 2 * (len(cost) // 8)                       # equal-cost contiguous ranges are very unequal in width
+    # ties in the cost keep the column order (stable), as the device's cost order does
+    np.testing.assert_array_equal(interleaved_parts(np.ones(10, np.int64), 2)[0], [0, 3, 4, 7, 8])
