@@ -198,7 +198,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ short s_tI[MAX_NT], s_tJ[MAX_NT];
     __shared__ int s_row;
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, cl = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int k = p.k, KT = (k + 1 + 15) / 16, KP = KT * 16, NT = KT * (KT + 1) / 2;
     double *const ya = lds;                                         // [CHUNK][KP]   A side: (c - 1) y, c in column k
