@@ -61,3 +61,43 @@ def test_bad_enum_arguments_raise_value_error_before_touching_the_device():
         MatrixFactorization_MI355X_Epoch(X, algorithm_name="MF_BPR", sgd_mode="nope")
     with pytest.raises(ValueError):
         MatrixFactorization_MI355X_Epoch(X, algorithm_name="nope")
+
+
+def test_config_structs_have_the_layout_of_the_header(tmp_path):
+    """The ctypes mirrors of the configuration structs against the C compiler's view of include/mi355rec.h: size and the offset
+    of every field (a struct that grows in the header but not in _native.py would make the library read past the caller's
+    memory)."""
+    import ctypes as C
+    import re
+    import subprocess
+    header = os.path.join(ROOT, "include", "mi355rec.h")
+    N = _native
+    structs = {"mi355rec_sim_config": N.SimConfig, "mi355rec_mf_config": N.MFConfig, "mi355rec_slim_config": N.SlimConfig,
+               "mi355rec_stats": N.Stats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % header, 'int main(void) {']
+    for c_name, cls in structs.items():
+        lines.append('printf("%s %%zu", sizeof(%s));' % (c_name, c_name))
+        for field, _ in cls._fields_:
+            lines.append('printf(" %s:%%zu", offsetof(%s, %s));' % (field, c_name, field))
+        lines.append('printf("\\n");')
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    for line in out.strip().splitlines():
+        c_name, size, *fields = line.split()
+        cls = structs[c_name]
+        assert int(size) == C.sizeof(cls), "%s: header %s bytes, ctypes %d" % (c_name, size, C.sizeof(cls))
+        for item in fields:
+            name, off = item.split(":")
+            assert getattr(cls, name).offset == int(off), "%s.%s: header offset %s, ctypes %d" % (c_name, name, off, getattr(cls, name).offset)
+    # and the header has no field the mirrors lack
+    text = open(header).read()
+    for c_name, cls in structs.items():
+        end = text.index("} %s;" % c_name)
+        body = text[text.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        declared = [n.strip() for decl in body.split(";") if decl.strip() for n in decl.strip().split(None, 1)[1].split(",")]
+        assert declared == [f for f, _ in cls._fields_], (c_name, declared)
