@@ -257,3 +257,21 @@ def test_sparse_store_native_epochs_and_wrapper(gpu):
     assert rec.train_with_sparse_weights and sps.isspmatrix_csr(rec.W_sparse) and (np.diff(rec.W_sparse.indptr) <= 8).all()
     with pytest.raises(ValueError):
         SLIM_BPR_MI355X_Epoch(X, train_with_sparse_weights=True, precision="fp32")
+
+
+@pytest.mark.parametrize("mode,regs", [("sgd", (0.0, 0.0)), ("adagrad", (0.001, 0.002))])
+def test_sparse_store_rows_with_more_nodes_than_the_lds_select_holds(gpu, mode, regs):
+    """Profiles of ~1850 of 3000 items and 300 steps between two selections: a row written once has ~1850 nodes (packed in LDS), the
+    ~60 rows per segment written twice or more have ~2500 (> 2048: the selection runs over the row itself, the select's second
+    source) -- with plain sgd and no regularisation all nodes a sample creates in a row are tied."""
+    X = synthetic_urm(1499, 3000, 1499 * 2400, 2100, 2800, seed=5, values="binary", zipf_exponent=0.2)
+    assert np.diff(X.indptr).min() > 1700
+    kw = dict(random_seed=4, sgd_mode=mode, learning_rate=0.05, li_reg=regs[0], lj_reg=regs[1], topK=100, train_with_sparse_weights=True)
+    orc = O.OracleSLIM(X, **kw)
+    dev = SLIM_BPR_MI355X_Epoch(X, **kw)
+    for round_ in range(2):
+        orc.record_samples(10 ** 6)
+        orc.epochIteration_Cython()
+        dev.replay_samples(*orc.recorded())
+        _csr_parity(dev.get_S(), orc.get_S(), "%s round %d" % (mode, round_))
+    dev.close()
