@@ -152,6 +152,12 @@ int mi355rec_sim_column_costs(mi355rec_sim_t h, int64_t *cost /* n_cols */);
 /* Schedule of the last compute call: work items queued, columns that were split over several workgroups, and the
  * number of parts they were split into (diagnostics; a heavy column is accumulated by several workgroups). */
 int mi355rec_sim_schedule_info(mi355rec_sim_t h, int32_t *n_items, int32_t *n_split_columns, int32_t *n_parts);
+/* Type of the in-LDS column accumulator this handle's builds use: 0 = uint32 co-occurrence counts (all stored values 1.0, no
+ * row_weights), 1 = int64 fixed point (real-valued data whose products, scaled by the power of two *fixed_scale, keep every sum
+ * inside 62 bits with a worst-case rounding below 1e-6 of the smallest normalised result), 2 = float64 sums like the reference's
+ * double array (Compute_Similarity_Cython.pyx:363; chosen when no such scale exists, or with MI355REC_SIM_F64_SUMS=1 in the
+ * environment at create time).  Diagnostics for the parity tests. */
+int mi355rec_sim_accumulator_info(mi355rec_sim_t h, int32_t *kind, double *fixed_scale);
 int mi355rec_sim_sync(mi355rec_sim_t h);
 int mi355rec_sim_get_stats(mi355rec_sim_t h, mi355rec_stats *stats);
 void mi355rec_sim_destroy(mi355rec_sim_t h);
@@ -229,6 +235,25 @@ int mi355rec_mf_set_profiling(mi355rec_mf_t h, int32_t max_timed_launches);
 int mi355rec_mf_get_phase_ticks(mi355rec_mf_t h, uint64_t *out, int64_t cap, int64_t *n);
 int mi355rec_mf_get_stats(mi355rec_mf_t h, mi355rec_stats *stats);
 void mi355rec_mf_destroy(mi355rec_mf_t h);
+
+/* Replica-batched epochs: R independent models trained side by side, the way the reference's hyper-parameter search runs this
+ * path (ParameterTuning/run_parameter_search.py:498-503: a multiprocessing Pool, one model per worker; each worker's fit() is a
+ * loop over MatrixFactorization_Cython_Epoch.epochIteration_Cython, MatrixFactorization_Cython.py:126).  One epoch of ONE model
+ * is a chain of dependent mini-batches of ~3 MB each, which fills a tenth of an MI355X; a group launches mini-batch b of ALL
+ * members as one grid, so the chain keeps its length and every link moves R mini-batches.  Members are ordinary handles
+ * (not owned by the group, usable on their own between group calls, each with its own factors, hyper-parameters, optimiser,
+ * seed and sample stream); they must share what a launch shares: algorithm (MF_BPR or FUNK_SVD), precision, batch_size, the
+ * number of mini-batches per epoch and the kernel instance n_factors selects (float32: n_factors % 4 == 0 and <= 64 / <= 128 /
+ * <= 256 / <= 512; float64: % 2 and half those bounds).  Every member ends bit-identical to running its epochs alone. */
+typedef struct mi355rec_mf_group *mi355rec_mf_group_t;
+int mi355rec_mf_group_create(mi355rec_mf_group_t *out, const mi355rec_mf_t *members, int32_t n_members);
+/* n_epochs x epochIteration_Cython() of every member (blocking).  Afterwards each member's get_factors / get_last_samples /
+ * get_stats (n_units, loss of ITS samples) answer as after its own run_epochs call. */
+int mi355rec_mf_group_run_epochs(mi355rec_mf_group_t g, int32_t n_epochs);
+int mi355rec_mf_group_set_profiling(mi355rec_mf_group_t g, int32_t max_timed_launches);
+/* call_ms / kernel_ms of the last call; n_units, algorithmic_bytes and loss summed over the members. */
+int mi355rec_mf_group_get_stats(mi355rec_mf_group_t g, mi355rec_stats *stats);
+void mi355rec_mf_group_destroy(mi355rec_mf_group_t g);     /* the members stay alive */
 
 /* ------------------------------------------------------------------------------------------------------
  * SLIM-BPR epoch  (SLIM_BPR/Cython/SLIM_BPR_Cython_Epoch.pyx:59 cdef class SLIM_BPR_Cython_Epoch;

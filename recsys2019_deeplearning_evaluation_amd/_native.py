@@ -84,6 +84,7 @@ SIGNATURES = {
     "mi355rec_sim_compute_csr": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "mi355rec_sim_column_costs": (C.c_int, [_vp, _vp]),
     "mi355rec_sim_schedule_info": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "mi355rec_sim_accumulator_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_f64)]),
     "mi355rec_sim_sync": (C.c_int, [_vp]),
     "mi355rec_sim_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "mi355rec_sim_destroy": (None, [_vp]),
@@ -100,6 +101,11 @@ SIGNATURES = {
     "mi355rec_mf_get_phase_ticks": (C.c_int, [_vp, _vp, _i64, C.POINTER(_i64)]),
     "mi355rec_mf_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "mi355rec_mf_destroy": (None, [_vp]),
+    "mi355rec_mf_group_create": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), _i32]),
+    "mi355rec_mf_group_run_epochs": (C.c_int, [_vp, _i32]),
+    "mi355rec_mf_group_set_profiling": (C.c_int, [_vp, _i32]),
+    "mi355rec_mf_group_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "mi355rec_mf_group_destroy": (None, [_vp]),
     "mi355rec_slim_create": (C.c_int, [C.POINTER(_vp), C.POINTER(SlimConfig), _i32, _i32, _vp, _vp]),
     "mi355rec_slim_run_epochs": (C.c_int, [_vp, _i32]),
     "mi355rec_slim_run_samples": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),

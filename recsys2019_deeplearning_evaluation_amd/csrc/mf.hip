@@ -362,11 +362,13 @@ __global__ __launch_bounds__(256) void mf_recs_kernel(const SchedParams s) {
 // mini-batches with the row's bit set; (3) per row, the parity after the stream, bitmap cleared for the next one.
 constexpr int META_WIDE = 1 << 30;        // header.meta: bits 0-27 list length, 28-29 quarter, 30 wide, 31 buffer of the own row
 constexpr int SCHED_THREADS = 1024;
+constexpr int SLOT_ABSORBED = 0x3fffffff;   // qtask[] of an incidence whose row is updated by its sample's user task (no header of its own)
 constexpr int FAST_MAX_BATCHES = 256, FAST_MAX_SLOTS = 8192;
 
 struct FastSchedParams {
     long long n_samples;
     int per, n_users, n_entries, batch_size, tasks_per_batch, slot_bits, np, words, group;
+    int fuse;                     // BPR: a sample whose user row is touched once in the batch takes over its other once-touched rows
     const int *su, *si, *sj;
     const float *sr;
     unsigned *touched;            // [n_entries][words]: bit b of row x = mini-batch b of this stream touches x
@@ -425,30 +427,64 @@ __global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const Fast
     }
     if (tid == 0) hpos[total] = m;
     __syncthreads();
+    // FUSED SAMPLE TASKS (BPR).  Most rows of a mini-batch are touched by exactly one sample (users nearly always, uniformly drawn
+    // negative items mostly): as separate tasks each of them gathers the sample's three rows again -- nine row reads and three
+    // wavefronts per sample.  A sample whose USER row is touched once keeps one task (the user's) which also applies the update of
+    // the sample's item rows that are touched once (header word 3: bit 0 positive item, bit 1 negative item); those rows get no
+    // task of their own.  The arithmetic per row is unchanged.  single[q] = incidence q (sample * per + role) is alone in its run.
+    unsigned char *single = reinterpret_cast<unsigned char *>(tpos + np);
+    const unsigned qmask = (1u << sb) - 1u;
+    if (s.fuse) {
+        for (int q = tid; q < np; q += SCHED_THREADS) single[q] = 0;
+        __syncthreads();
+        for (int t = tid; t < total; t += SCHED_THREADS)
+            if (hpos[t + 1] - hpos[t] == 1) single[K[hpos[t]] & qmask] = 1;
+        __syncthreads();
+    }
+    auto absorbed = [&](int t) -> bool {          // a once-touched item row whose sample's user row is touched once, too
+        if (!s.fuse || hpos[t + 1] - hpos[t] != 1) return false;
+        const int inc = (int)(K[hpos[t]] & qmask), smp = inc / s.per;
+        return inc != smp * s.per && single[smp * s.per];
+    };
     // header slots: wide tasks first (4 aligned slots each), then the others; both in row order
     const int CT = (total + SCHED_THREADS - 1) / SCHED_THREADS;
     const int t_lo = min(tid * CT, total), t_hi = min(t_lo + CT, total);
-    int wcnt = 0;
+    int wcnt = 0, acnt = 0;
     const int wide_min = 2 * s.group;               // longer than two rounds of one wavefront: split over a workgroup
-    for (int t = t_lo; t < t_hi; ++t) wcnt += hpos[t + 1] - hpos[t] > wide_min;
-    int woff = 0, n_wide = 0;
+    for (int t = t_lo; t < t_hi; ++t) {
+        wcnt += hpos[t + 1] - hpos[t] > wide_min;
+        acnt += absorbed(t);
+    }
+    int woff = 0, n_wide = 0, aoff = 0, n_abs = 0;
     Scan(scan_tmp).ExclusiveSum(wcnt, woff, n_wide);
+    __syncthreads();
+    Scan(scan_tmp).ExclusiveSum(acnt, aoff, n_abs);
     TaskHeader *out = s.tasks + (size_t)b * s.tasks_per_batch;
     for (int t = t_lo; t < t_hi; ++t) {
         const int start = hpos[t], len = hpos[t + 1] - start;
         const bool wide = len > wide_min;
-        const int slot = wide ? 4 * woff : 4 * n_wide + (t - woff);
+        const int entry = (int)(K[start] >> sb);
+        atomicOr(&s.touched[(size_t)entry * s.words + (b >> 5)], 1u << (b & 31));      // (absorbed rows advance a version, too)
+        if (absorbed(t)) {
+            ++aoff;
+            tpos[t] = SLOT_ABSORBED;
+            continue;
+        }
+        const int slot = wide ? 4 * woff : 4 * n_wide + (t - woff - aoff);
         woff += wide;
         tpos[t] = slot | (wide ? META_WIDE : 0);
-        const int entry = (int)(K[start] >> sb);
+        int also = 0;
+        if (s.fuse && len == 1) {
+            const int inc = (int)(K[start] & qmask), smp = inc / s.per;
+            if (inc == smp * s.per) also = (single[inc + 1] ? 1 : 0) | (s.per == 3 && single[inc + 2] ? 2 : 0);
+        }
         for (int part = 0; part < (wide ? 4 : 1); ++part) {
             *reinterpret_cast<int4 *>(out + slot + part) =
-                make_int4(entry, len | (wide ? META_WIDE | (part << 28) : 0), b * s.tasks_per_batch + start, 0);
+                make_int4(entry, len | (wide ? META_WIDE | (part << 28) : 0), b * s.tasks_per_batch + start, also);
             out[slot + part].rec0 = make_int4(0, 0, 0, 0);     // (a short wide list leaves its last quarters without a record)
         }
-        atomicOr(&s.touched[(size_t)entry * s.words + (b >> 5)], 1u << (b & 31));
     }
-    const int used = 4 * n_wide + (total - n_wide);
+    const int used = 4 * n_wide + (total - n_wide - n_abs);
     for (int slot = used + tid; slot < s.tasks_per_batch; slot += SCHED_THREADS)
         *reinterpret_cast<int4 *>(out + slot) = make_int4(0, 0, 0, 0);          // no samples: the slot's wavefront idles
     __syncthreads();
@@ -486,6 +522,7 @@ __global__ __launch_bounds__(256) void mf_sched_emit_kernel(const FastSchedParam
     const int4 rec = make_int4(u, i, s.per == 3 ? j : __float_as_int(s.sr[t]), role | (pu << 2) | (pi << 3) | (pj << 4));
     s.recs[at] = rec;
     const int tp = s.qtask[at];
+    if (tp == SLOT_ABSORBED) return;
     TaskHeader *hd = s.tasks + (size_t)b * s.tasks_per_batch + (tp & (META_WIDE - 1));
     const int off = (int)(at - (size_t)hd->start);
     const int own = role == 0 ? pu : (role == 1 ? pi : pj);
@@ -516,6 +553,12 @@ __global__ __launch_bounds__(256) void mf_sched_finish_kernel(const FastSchedPar
 template <class T>
 __global__ void mf_stream_end_kernel(const MfParams<T> p, const long long n_batches) {
     if (threadIdx.x == 0 && blockIdx.x == 0) p.state->batch_base += n_batches;
+}
+
+template <class T>
+__global__ void mf_group_stream_end_kernel(const MfParams<T> *table, const int n_models, const long long n_batches) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < n_models) table[m].state->batch_base += n_batches;
 }
 
 // ---- the mini-batch --------------------------------------------------------------------------------------------------
@@ -610,14 +653,16 @@ __device__ __forceinline__ Rows<T, VEC, KI, BPR> load_rows(const MfParams<T> &p,
 }
 
 // KI chunks of VEC elements per lane, LPR lanes per row (64 / LPR samples of a task's list in flight per wavefront).
+// `wg` = this workgroup's index within the mini-batch's launch of ONE model (blockIdx.x; the group launch below puts the model
+// on blockIdx.y).
 template <int ALGO, class T, int VEC, int LPR, int KI>
-__global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, const int batch_local) {
+__device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int batch_local, const int wg) {
     constexpr int G = 64 / LPR;
     constexpr bool BPR = ALGO == MI355REC_MF_BPR;
     using Ch = Chunk<T, VEC>;
     using R = Rows<T, VEC, KI, BPR>;
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((blockIdx.x * p.wg_stride + p.wg_base) * 4 + (threadIdx.x >> 6));
+    const int wv = __builtin_amdgcn_readfirstlane((wg * p.wg_stride + p.wg_base) * 4 + (threadIdx.x >> 6));
     const unsigned long long tk0 = p.ticks ? stamp() : 0ull;
     // every wave-uniform input is requested before the first one is waited for (scalar loads, one wait)
     // (unused task slots of a batch are zero: a header with no samples means there is nothing to do)
@@ -659,6 +704,8 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
         // software pipeline: records two list positions ahead of the arithmetic, rows one ahead.  Positions past the
         // end of the list are clamped to the last record (valid addresses) and contribute nothing.
         int4 rec = h1;
+        const int also = BPR ? h0.w : 0;           // fused sample task: bit 0 / 1 = this task also updates the sample's positive / negative item row
+        T sg_first = (T)0;
         if (G > 1 && len > 1) {                    // single-sample tasks (most of them) go straight from the header to the rows
             const int4 r = p.recs[start + min(base + g, len - 1)];
             if (g != 0) rec = r;
@@ -702,6 +749,7 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
             if (BPR) {
                 const T x = dot;
                 const T sg = sigmoid_of_minus(x);
+                if (it == 0) sg_first = sg;
                 if (valid && role == ROLE_U && li == 0) loss += (double)x * (double)x;
 #pragma unroll
                 for (int c = 0; c < KI; ++c)
@@ -808,20 +856,90 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
                 bn[row] = own_bias + p.lr * step;
             }
         }
+        if (BPR && also) {
+            // The item rows this single-sample user task took over (mf_sched_sort_kernel): the arithmetic their own tasks would
+            // have done -- gradient of one sample, mean over batch_size, optimiser, one store of the next row version.  Every
+            // group of the wavefront holds the same record, rows and sigmoid (positions past the end of the list are clamped
+            // to the last record), so the rows are dealt to the groups: row e (1 positive, 2 negative item) to group e % G.
+            // (`rows` still holds the first record's rows: a single-sample list runs one iteration and loads nothing else)
+#pragma unroll
+            for (int e = 1; e <= 2; ++e) {
+                if (!(also & e) || g != e % G) continue;
+                const int item = e == 1 ? h1.y : h1.z;
+                const int cur = (h1.w >> (e == 1 ? 3 : 4)) & 1;               // buffer of the version just read
+                T *Wn = (cur ? p.V0 : p.V1) + (size_t)item * k;
+                T *c1 = p.c1V + (size_t)item * k, *c2 = p.c2V + (size_t)item * k;
+#pragma unroll
+                for (int c = 0; c < KI; ++c) {
+                    if (!cok[c]) continue;
+                    const size_t at = (size_t)(c * LPR + li) * VEC;
+                    Ch m1, m2, out;
+                    if (p.sgd_mode != MI355REC_SGD) m1 = *reinterpret_cast<const Ch *>(c1 + at);
+                    if (p.sgd_mode == MI355REC_ADAM) m2 = *reinterpret_cast<const Ch *>(c2 + at);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const T a = rows.A[c].v[v], b = rows.B[c].v[v], cc = rows.C[c].v[v];
+                        const T gr = e == 1 ? sg_first * a - p.positive_reg * b : sg_first * (-a) - p.negative_reg * cc;   // .pyx:632-639
+                        const T gm = ((T)0 + gr) * p.inv_batch;
+                        const T step = adapt_cell(p, gm, m1.v[v], m2.v[v], pw1, pw2);
+                        out.v[v] = (e == 1 ? b : cc) + p.lr * step;
+                    }
+                    *reinterpret_cast<Ch *>(Wn + at) = out;
+                    if (p.sgd_mode != MI355REC_SGD) *reinterpret_cast<Ch *>(c1 + at) = m1;
+                    if (p.sgd_mode == MI355REC_ADAM) *reinterpret_cast<Ch *>(c2 + at) = m2;
+                }
+            }
+        }
     }
     if (bias) {   // the batch's global-bias terms: per workgroup through LDS, then one atomic on one of 16 addresses
         if (lane == 0) s_mu[threadIdx.x >> 6] = mu_term;
         __syncthreads();
         if (threadIdx.x == 0) {
             const T sum = (s_mu[0] + s_mu[1]) + (s_mu[2] + s_mu[3]);
-            if (sum != (T)0) atomicAdd(&p.mu_acc[(int)(gb % 3) * MU_SLOTS + (blockIdx.x & (MU_SLOTS - 1))], sum);
+            if (sum != (T)0) atomicAdd(&p.mu_acc[(int)(gb % 3) * MU_SLOTS + (wg & (MU_SLOTS - 1))], sum);
         }
     }
     if (p.ticks && lane == 0 && wv < p.tasks_per_batch) {
         unsigned long long *o = p.ticks + (size_t)wv * 8;
         o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = stamp(); o[5] = (unsigned long long)(h0.y & LEN_MASK);
-        o[6] = blockIdx.x; o[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // XCC_ID
+        o[6] = (unsigned long long)wg; o[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // XCC_ID
     }
+}
+
+template <int ALGO, class T, int VEC, int LPR, int KI>
+__global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, const int batch_local) {
+    mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, blockIdx.x);
+}
+
+// REPLICA-BATCHED launch: mini-batch `batch_local` of R independent models in one grid (blockIdx.y = model).  A single model's
+// epoch is a chain of dependent mini-batches of ~3 MB each -- a launch fills a tenth of the chip, and concurrent replicas on R
+// streams still pay one dispatch per model and mini-batch at the command processor.  Here the chain keeps its length but every
+// link carries R mini-batches.  The models share nothing but the kernel instance (algorithm, storage type, lanes per row) and the
+// number of task slots per mini-batch: factors, hyper-parameters, seeds, optimiser, even k within the instance's range are per
+// model (the table row is the model's MfParams, read through the scalar cache: wave-uniform address, nothing stored before it).
+// Pointers that arrive as kernel arguments are known to point to global memory; pointers read from a table are generic ("flat")
+// to the compiler, which then gathers with flat_load and cannot use the scalar cache for the task header.  The
+// assumption below (neither LDS nor scratch) is what the address-space inference needs to use global_load / s_load again.
+template <class P> __device__ __forceinline__ P *as_global(P *q) {
+    const unsigned long long bits = (unsigned long long)q;
+    return (P *)(__attribute__((address_space(1))) P *)bits;
+}
+template <class T> __device__ __forceinline__ void globalize(MfParams<T> &p) {
+    p.indptr = as_global(p.indptr); p.indices = as_global(p.indices); p.data = as_global(p.data);
+    p.U0 = as_global(p.U0); p.U1 = as_global(p.U1); p.V0 = as_global(p.V0); p.V1 = as_global(p.V1);
+    p.bu0 = as_global(p.bu0); p.bu1 = as_global(p.bu1); p.bi0 = as_global(p.bi0); p.bi1 = as_global(p.bi1);
+    p.c1U = as_global(p.c1U); p.c2U = as_global(p.c2U); p.c1V = as_global(p.c1V); p.c2V = as_global(p.c2V);
+    p.c1_bu = as_global(p.c1_bu); p.c2_bu = as_global(p.c2_bu); p.c1_bi = as_global(p.c1_bi); p.c2_bi = as_global(p.c2_bi);
+    p.mu_state = as_global(p.mu_state); p.mu_acc = as_global(p.mu_acc);
+    p.loss_slots = as_global(p.loss_slots); p.state = as_global(p.state);
+    p.tasks = as_global(p.tasks); p.recs = as_global(p.recs); p.ticks = as_global(p.ticks);
+}
+
+template <int ALGO, class T, int VEC, int LPR, int KI>
+__global__ __launch_bounds__(256) void mf_group_batch_kernel(const MfParams<T> *__restrict__ table, const int batch_local) {
+    MfParams<T> p = table[blockIdx.y];
+    globalize(p);
+    mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, blockIdx.x);
 }
 
 // Any k (odd k, k > 64 lanes x 2 chunks): one task per wavefront, one sample at a time, rows re-read for the update.
@@ -1212,6 +1330,33 @@ void launch_batch(mi355rec_mf *h, const MfParams<T> &p, int batch_local, bool ti
     else hipLaunchKernelGGL((mf_batch_generic_kernel<ALGO, T>), dim3(grid), dim3(256), 0, h->stream, p, batch_local);
 }
 
+// instance of the mini-batch kernel a model runs on (must mirror launch_batch); -1: the any-k kernel
+int kernel_class(const mi355rec_mf *h) {
+    const int vec = h->f64 ? 2 : 4, k = h->k;
+    if (k % vec != 0) return -1;
+    const int chunks = k / vec;
+    return chunks <= 16 ? 0 : (chunks <= 32 ? 1 : (chunks <= 64 ? 2 : (chunks <= 128 ? 3 : -1)));
+}
+
+template <int ALGO, class T, int VEC, int LPR, int KI>
+void launch_group_as(hipStream_t s, const MfParams<T> *table, dim3 grid, int batch_local, hipEvent_t e0, hipEvent_t e1) {
+    if (e0) hipExtLaunchKernelGGL((mf_group_batch_kernel<ALGO, T, VEC, LPR, KI>), grid, dim3(256), 0, s, e0, e1, 0, table, batch_local);
+    else hipLaunchKernelGGL((mf_group_batch_kernel<ALGO, T, VEC, LPR, KI>), grid, dim3(256), 0, s, table, batch_local);
+}
+
+template <int ALGO, class T>
+void launch_group_batch(hipStream_t s, const MfParams<T> *table, int klass, int wgs, int n_models, int batch_local, hipEvent_t e0,
+                        hipEvent_t e1) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const dim3 grid(wgs, n_models);
+    switch (klass) {
+        case 0: launch_group_as<ALGO, T, VEC, 16, 1>(s, table, grid, batch_local, e0, e1); break;
+        case 1: launch_group_as<ALGO, T, VEC, 32, 1>(s, table, grid, batch_local, e0, e1); break;
+        case 2: launch_group_as<ALGO, T, VEC, 64, 1>(s, table, grid, batch_local, e0, e1); break;
+        default: launch_group_as<ALGO, T, VEC, 64, 2>(s, table, grid, batch_local, e0, e1); break;
+    }
+}
+
 template <class T>
 void launch_sampler(mi355rec_mf *h, const MfParams<T> &p) {
     const int grid = div_up(p.samples_per_epoch, 256);
@@ -1240,6 +1385,9 @@ bool fast_schedule_fits(const mi355rec_mf *h, long long n_batches) {
            (h->k % (h->f64 ? 2 : 4) == 0 && h->k / (h->f64 ? 2 : 4) <= 128);    // the any-k kernel does not split wide lists
 }
 
+// keys, run starts, header slots (words) + one byte per incidence for the once-touched flags
+size_t sched_lds_bytes(int np) { return sizeof(unsigned) * (3 * (size_t)np + 1) + (size_t)np + 16; }
+
 void enqueue_fast_schedule(mi355rec_mf *h, long long n_samples, long long n_batches) {
     hipStream_t s = h->stream;
     FastSchedParams f{};
@@ -1257,12 +1405,16 @@ void enqueue_fast_schedule(mi355rec_mf *h, long long n_samples, long long n_batc
     f.touched = h->touched.ptr; f.par = h->par.ptr;
     f.sorted_slot = h->sorted_slot.ptr; f.qtask = h->qtask.ptr;
     f.tasks = h->tasks.ptr; f.recs = h->recs.ptr;
-    const size_t lds = sizeof(unsigned) * (3 * (size_t)f.np + 1);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // fused sample tasks: BPR only; not in the exact multi-GPU mode, whose exchange slabs hold one row per task slot
+    f.fuse = h->cfg.algorithm == MI355REC_MF_BPR && h->shard_rank < 0 && !getenv("MI355REC_MF_NO_FUSE");
+    const size_t lds = sched_lds_bytes(f.np);
+    static bool attr_set[64] = {};              // the attribute is per DEVICE, not per process
+    int dev = 0;
+    MI_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mf_sched_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(sizeof(unsigned) * (3 * (size_t)FAST_MAX_SLOTS + 1))));
-        attr_set = true;
+                                   (int)sched_lds_bytes(FAST_MAX_SLOTS)));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(mf_sched_sort_kernel, dim3((unsigned)n_batches), dim3(SCHED_THREADS), lds, s, f);
     hipLaunchKernelGGL(mf_sched_emit_kernel, dim3(div_up(f.tasks_per_batch, 256), (unsigned)n_batches), dim3(256), 0, s, f);
@@ -1765,6 +1917,224 @@ extern "C" int mi355rec_mf_shard_end_epoch(mi355rec_mf_t h) {
         h->shard_rank = -1;
     });
 }
+
+// ---- replica-batched epochs: R independent models, one launch per mini-batch index ---------------------------------------------
+struct mi355rec_mf_group {
+    std::vector<mi355rec_mf *> members;      // not owned
+    bool f64 = false;
+    int algorithm = 0, klass = 0, tasks_per_batch = 0;
+    long long batches_per_epoch = 0;
+    hipStream_t stream = nullptr;
+    StreamTimer timer;
+    DispatchTimers dispatch_timers;
+    int max_timed = 0;
+    DeviceBuffer<unsigned char> table;       // MfParams<T>[R]
+    std::vector<unsigned char> host_table;
+    hipEvent_t fork = nullptr;
+    std::vector<hipEvent_t> join;
+    hipGraphExec_t graph = nullptr;
+    bool graph_failed = false;
+    mi355rec_stats stats{};
+
+    ~mi355rec_mf_group() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (graph) (void)hipGraphExecDestroy(graph);
+        timer.destroy();
+        dispatch_timers.destroy();
+        if (fork) (void)hipEventDestroy(fork);
+        for (auto e : join) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+// One epoch of every member: samplers and schedules on the members' own streams (parallel branches, also when captured), then
+// the shared chain of mini-batch launches on the group's stream.
+template <class T>
+void group_enqueue_epoch(mi355rec_mf_group *g, bool timed) {
+    const long long nb = g->batches_per_epoch;
+    MI_HIP(hipEventRecord(g->fork, g->stream));
+    for (size_t m = 0; m < g->members.size(); ++m) {
+        mi355rec_mf *h = g->members[m];
+        MI_HIP(hipStreamWaitEvent(h->stream, g->fork, 0));
+        MfParams<T> p{};
+        fill_params(h, p);
+        launch_sampler(h, p);
+        enqueue_schedule(h, p.samples_per_epoch, nb);
+        MI_HIP(hipEventRecord(g->join[m], h->stream));
+        MI_HIP(hipStreamWaitEvent(g->stream, g->join[m], 0));
+    }
+    const MfParams<T> *table = reinterpret_cast<const MfParams<T> *>(g->table.ptr);
+    const int wgs = div_up(g->tasks_per_batch, 4), R = (int)g->members.size();
+    for (long long b = 0; b < nb; ++b) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed) g->dispatch_timers.next(e0, e1, g->max_timed);
+        if (g->algorithm == MI355REC_MF_BPR) launch_group_batch<MI355REC_MF_BPR, T>(g->stream, table, g->klass, wgs, R, (int)b, e0, e1);
+        else launch_group_batch<MI355REC_MF_FUNK_SVD, T>(g->stream, table, g->klass, wgs, R, (int)b, e0, e1);
+    }
+    hipLaunchKernelGGL(mf_group_stream_end_kernel<T>, dim3(div_up(R, 64)), dim3(64), 0, g->stream, table, R, nb);
+}
+
+template <class T>
+void group_ensure_graph(mi355rec_mf_group *g) {
+    if (g->graph || g->graph_failed) return;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+        try {
+            group_enqueue_epoch<T>(g, false);
+        } catch (...) {
+            (void)hipStreamEndCapture(g->stream, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            g->graph_failed = true;
+            return;
+        }
+        e = hipStreamEndCapture(g->stream, &graph);
+    }
+    if (e == hipSuccess) e = hipGraphInstantiate(&g->graph, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        g->graph = nullptr;
+        g->graph_failed = true;
+    }
+}
+
+template <class T>
+void group_run_epochs_typed(mi355rec_mf_group *g, int n_epochs) {
+    const long long nb = g->batches_per_epoch;
+    const int R = (int)g->members.size();
+    std::vector<unsigned char> table(sizeof(MfParams<T>) * (size_t)R);
+    for (int m = 0; m < R; ++m) {
+        mi355rec_mf *h = g->members[m];
+        MI_REQUIRE(h->shard_rank < 0, "member %d is inside an exact multi-GPU epoch", m);
+        ensure_stream_capacity(h, (size_t)(nb * h->cfg.batch_size), nb);
+        MfParams<T> p{};
+        fill_params(h, p);
+        memcpy(table.data() + sizeof(MfParams<T>) * (size_t)m, &p, sizeof(MfParams<T>));
+        begin_call(h);
+    }
+    if (table != g->host_table) {                 // a member re-allocated its stream buffers: the graph holds the old addresses
+        if (g->graph) {
+            (void)hipGraphExecDestroy(g->graph);
+            g->graph = nullptr;
+        }
+        MI_HIP(hipStreamSynchronize(g->stream));
+        if (g->table.count < table.size()) g->table.alloc(table.size());
+        MI_HIP(hipMemcpy(g->table.ptr, table.data(), table.size(), hipMemcpyHostToDevice));
+        g->host_table = table;
+    }
+    g->dispatch_timers.reset();
+    const long long timed_epochs = g->max_timed > 0 ? std::min<long long>(n_epochs, (g->max_timed + nb - 1) / nb) : 0;
+    bool use_graph = nb <= MAX_GRAPH_BATCHES && n_epochs - timed_epochs > 0 && !getenv("MI355REC_NO_GRAPH");
+    if (use_graph) {
+        group_ensure_graph<T>(g);
+        use_graph = g->graph != nullptr;
+    }
+    g->timer.start(g->stream);
+    for (long long e = 0; e < n_epochs; ++e) {
+        if (e < timed_epochs || !use_graph) group_enqueue_epoch<T>(g, e < timed_epochs);
+        else MI_HIP(hipGraphLaunch(g->graph, g->stream));
+    }
+    g->timer.stop(g->stream);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(g->stream));
+    mi355rec_stats &st = g->stats;
+    st = mi355rec_stats{};
+    st.call_ms = g->timer.elapsed_ms();
+    st.kernel_ms = g->dispatch_timers.total_ms();
+    st.n_timed = g->dispatch_timers.used;
+    st.n_launches = nb * n_epochs;
+    for (int m = 0; m < R; ++m) {
+        mi355rec_mf *h = g->members[m];
+        const long long n = nb * n_epochs * (long long)h->cfg.batch_size;
+        h->host_loss.resize(h->loss_slots.count);
+        h->loss_slots.download(h->host_loss.data(), h->loss_slots.count, h->stream);
+        MI_HIP(hipStreamSynchronize(h->stream));
+        double loss = 0;
+        for (double v : h->host_loss) loss += v;
+        h->batches_done += nb * n_epochs;
+        h->last_call_samples = n_epochs > 0 ? nb * (long long)h->cfg.batch_size : 0;
+        h->stats = mi355rec_stats{};
+        h->stats.call_ms = st.call_ms;
+        h->stats.n_launches = st.n_launches;
+        h->stats.n_units = n;
+        h->stats.algorithmic_bytes = bytes_per_sample(h) * (double)n;
+        h->stats.loss = loss;
+        st.n_units += n;
+        st.algorithmic_bytes += h->stats.algorithmic_bytes;
+        st.loss += loss;
+    }
+}
+
+}  // namespace
+
+extern "C" int mi355rec_mf_group_create(mi355rec_mf_group_t *out, const mi355rec_mf_t *members, int32_t n_members) {
+    return guarded([&] {
+        MI_REQUIRE(out && members, "NULL argument");
+        MI_REQUIRE(n_members >= 1 && n_members <= 65535, "n_members = %d out of range", n_members);
+        ensure_device();
+        std::unique_ptr<mi355rec_mf_group> g(new mi355rec_mf_group());
+        const mi355rec_mf *first = members[0];
+        MI_REQUIRE(first, "member 0 is NULL");
+        if (first->cfg.algorithm == MI355REC_MF_ASY_SVD) fail(MI355REC_E_UNSUPPORTED, "ASY_SVD has no mini-batches to share a launch");
+        g->f64 = first->f64;
+        g->algorithm = first->cfg.algorithm;
+        g->klass = kernel_class(first);
+        if (g->klass < 0)
+            fail(MI355REC_E_UNSUPPORTED, "n_factors = %d runs on the any-k kernel, which has no replica-batched form (use a multiple of %d up to 512)",
+                 first->k, first->f64 ? 2 : 4);
+        g->tasks_per_batch = per_sample(first) * first->cfg.batch_size;
+        g->batches_per_epoch = batches_per_epoch(first);
+        for (int m = 0; m < n_members; ++m) {
+            mi355rec_mf *h = members[m];
+            MI_REQUIRE(h, "member %d is NULL", m);
+            for (int o = 0; o < m; ++o) MI_REQUIRE(members[o] != h, "member %d is listed twice", m);
+            // what ONE launch must share: the kernel instance and the grid; everything else is per model
+            MI_REQUIRE(h->cfg.algorithm == g->algorithm && h->f64 == g->f64 && kernel_class(h) == g->klass,
+                       "member %d runs a different kernel instance (algorithm, precision or n_factors class) than member 0", m);
+            MI_REQUIRE(per_sample(h) * h->cfg.batch_size == g->tasks_per_batch && batches_per_epoch(h) == g->batches_per_epoch,
+                       "member %d has a different batch_size or number of mini-batches per epoch than member 0", m);
+            g->members.push_back(h);
+        }
+        MI_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+        g->timer.init();
+        MI_HIP(hipEventCreateWithFlags(&g->fork, hipEventDisableTiming));
+        g->join.resize(n_members, nullptr);
+        for (auto &e : g->join) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        *out = g.release();
+    });
+}
+
+extern "C" int mi355rec_mf_group_run_epochs(mi355rec_mf_group_t g, int32_t n_epochs) {
+    return guarded([&] {
+        MI_REQUIRE(g, "NULL handle");
+        MI_REQUIRE(n_epochs >= 0, "n_epochs must be >= 0");
+        ensure_device();
+        if (g->f64) group_run_epochs_typed<double>(g, n_epochs); else group_run_epochs_typed<float>(g, n_epochs);
+    });
+}
+
+extern "C" int mi355rec_mf_group_set_profiling(mi355rec_mf_group_t g, int32_t max_timed_launches) {
+    return guarded([&] {
+        MI_REQUIRE(g, "NULL handle");
+        MI_REQUIRE(max_timed_launches >= 0 && max_timed_launches <= 65536, "max_timed_launches out of range");
+        ensure_device();
+        g->max_timed = max_timed_launches;
+        g->dispatch_timers.reserve(max_timed_launches);
+    });
+}
+
+extern "C" int mi355rec_mf_group_get_stats(mi355rec_mf_group_t g, mi355rec_stats *stats) {
+    return guarded([&] {
+        MI_REQUIRE(g && stats, "NULL argument");
+        *stats = g->stats;
+    });
+}
+
+extern "C" void mi355rec_mf_group_destroy(mi355rec_mf_group_t g) { delete g; }
 
 extern "C" int mi355rec_mf_get_factors(mi355rec_mf_t h, float *U, float *V, float *bu, float *bi, float *mu) {
     return guarded([&] {

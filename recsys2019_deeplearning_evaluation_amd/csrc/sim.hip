@@ -52,6 +52,7 @@ struct SimParams {
     const float *row_w;
     const float *norm, *norm_alpha, *norm_1ma;
     const int4 *items;  // work items of this call, most expensive first: {column, part, n_parts, first part slot}
+    const int2 *item_range;   // per work item: the column's [begin, end) in the CSC arrays (saves a dependent round trip per column)
     int n_items, start_col;
     const int *out_slot;    // interleaved parts: output row of every column of the call (NULL: column - start_col)
     double fixed_scale;     // real-valued data: > 0 = the accumulator holds int64 fixed-point sums, products scaled by this power of two
@@ -105,6 +106,8 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
     uint32_t *aux = reinterpret_cast<uint32_t *>(smem + p.acc_words);
     __shared__ SelectScratch sc;
     __shared__ int s_col, s_last;
+    __shared__ int4 s_item;
+    __shared__ int2 s_range;
     __shared__ uint32_t s_npos, s_nneg, s_ncand, s_kmin, s_kmax;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -118,14 +121,42 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             t_prev = now;
         }
     };
+    // The next work item is pulled while the current one is still in its normalisation / top-K phases: thread 0 issues the queue
+    // atomic after the accumulation (A), requests the item's descriptor one phase later (B) and files both in LDS after the
+    // top-K (C), where the loop head finds them -- without it every column starts with three dependent round trips (queue ->
+    // descriptor -> CSC bounds: 2-3 us of ~20).  None of this state is live during the accumulation (the register peak).
+    int nx_slot = -1;                        // thread 0 only
+    auto pull_now = [&]() {                  // thread 0, synchronous: the first item, and after a split column's part that does not finish the column
+        const int sl = nx_slot >= 0 ? nx_slot : (int)atomicAdd(p.queue, 1u);
+        s_col = sl;
+        if (sl < p.n_items) {
+            s_item = p.items[sl];
+            s_range = p.item_range[sl];
+        }
+        nx_slot = -1;
+    };
+    if (tid == 0) pull_now();
     for (;;) {
-        if (tid == 0) s_col = (int)atomicAdd(p.queue, 1u);
         __syncthreads();
         const int slot = s_col;
         if (slot >= p.n_items) break;
-        const int4 item = p.items[slot];
+        const int4 item = s_item;
         const int c = item.x;
-        int cbeg = p.csc_ptr[c], cend = p.csc_ptr[c + 1];
+        int cbeg = s_range.x, cend = s_range.y;
+        int4 nx_item = make_int4(0, 0, 0, 0);
+        int2 nx_range = make_int2(0, 0);
+        auto request_next = [&]() {          // (B) thread 0
+            if (nx_slot < p.n_items) {
+                nx_item = p.items[nx_slot];
+                nx_range = p.item_range[nx_slot];
+            }
+        };
+        auto file_next = [&]() {             // (C) thread 0
+            s_col = nx_slot;
+            s_item = nx_item;
+            s_range = nx_range;
+            nx_slot = -1;
+        };
         if (item.z > 1) {   // a heavy column split over several workgroups: this one walks users [cbeg, cend) of it
             const int per = (((cend - cbeg + item.z - 1) / item.z) + 63) & ~63;
             cbeg = min(cend, cbeg + item.y * per);
@@ -305,6 +336,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         }
         __syncthreads();
         mark(1);
+        if (tid == 0 && tile == 0) nx_slot = (int)atomicAdd(p.queue, 1u);       // next work item: requested now, looked at later
         if (item.z > 1) {
             const int pub_words = UNIT ? p.n_cols_pad : 2 * p.n_cols_pad;
             // Split column: publish this part's accumulator; the workgroup that arrives last adds the parts up (in
@@ -329,6 +361,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             __syncthreads();
             if (!s_last) {
                 mark(2);
+                if (tid == 0) pull_now();
                 continue;
             }
             const uint4 *src = reinterpret_cast<const uint4 *>(p.part_buf + (size_t)item.w * pub_words);
@@ -383,15 +416,15 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             if (UNIT) {
                 const float4 *nj4 = reinterpret_cast<const float4 *>(nj);
                 float4 *a4 = reinterpret_cast<float4 *>(acc);
+                const int n_quads = p.n_cols_pad / 4;
                 // four cells per thread and step (the norm arrays are padded to a multiple of 4; cells beyond n_tile are 0)
-                for (int w = tid; w < p.n_cols_pad / 4; w += THREADS) {
-                    const uint4 qu = reinterpret_cast<const uint4 *>(acc)[w];
-                    if (!euclid && (qu.x | qu.y | qu.z | qu.w) == 0u) continue;
-                    const float4 n4 = nj4[w];
-                    float vv[4] = {(float)qu.x, (float)qu.y, (float)qu.z, (float)qu.w};
-                    const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
-                    if (euclid) {
+                if (euclid) {
+                    for (int w = tid; w < n_quads; w += THREADS) {
+                        const uint4 qu = reinterpret_cast<const uint4 *>(acc)[w];
+                        const float4 n4 = nj4[w];
                         const float4 s4 = reinterpret_cast<const float4 *>(sqj)[w];
+                        float vv[4] = {(float)qu.x, (float)qu.y, (float)qu.z, (float)qu.w};
+                        const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
                         const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -399,47 +432,86 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                             vv[e] = (j < n_tile && tile_base + j != c) ? euclidean_cell(p, vv[e], sq_c, ss[e], norm_c, nn[e]) : 0.f;
                             account(vv[e]);
                         }
-                    } else {
+                        a4[w] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    }
+                } else {
+                    // The neighbours' norms come from L2: loaded inside the loop, behind the test for an all-zero quad, every
+                    // step paid a full round trip (6.5 of them per column at ML-20M shape = the whole phase); all of a thread's
+                    // quads are requested up front instead (8 steps cover MAX_TILE / 4 / 1024; 512-thread tiles are narrower).
+                    constexpr int NPF = 8;
+                    float4 npf[NPF];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (vv[e] != 0.f) {
-                                vv[e] = normalise(p, vv[e], norm_c, nn[e]);
-                                account(vv[e]);
+                    for (int i = 0; i < NPF; ++i) {
+                        const int w = tid + i * THREADS;
+                        npf[i] = nj4[w < n_quads ? w : 0];
+                    }
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) {
+                        const int w = tid + i * THREADS;
+                        if (w < n_quads) {
+                            const uint4 qu = reinterpret_cast<const uint4 *>(acc)[w];
+                            if ((qu.x | qu.y | qu.z | qu.w) != 0u) {
+                                float vv[4] = {(float)qu.x, (float)qu.y, (float)qu.z, (float)qu.w};
+                                const float nn[4] = {npf[i].x, npf[i].y, npf[i].z, npf[i].w};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (vv[e] != 0.f) {
+                                        vv[e] = normalise(p, vv[e], norm_c, nn[e]);
+                                        account(vv[e]);
+                                    }
+                                }
+                                a4[w] = make_float4(vv[0], vv[1], vv[2], vv[3]);
                             }
                         }
                     }
-                    a4[w] = make_float4(vv[0], vv[1], vv[2], vv[3]);
                 }
             } else {
-                // float64 sums -> normalised float32 values in the first half of the same LDS bytes: every thread reads
-                // all of its cells into registers before anyone writes
-                float reg[F64_CELLS_PER_THREAD];
+                // float64 sums -> normalised float32 values in the first half of the same LDS bytes.  In two batches of cells
+                // (half the registers of one batch of 16: the 1024-thread instance sits at its 128-register cap): batch h reads
+                // cells [8h T, 8(h+1) T) -- bytes [64h T, 64(h+1) T) -- into registers, barrier, writes float32 to bytes
+                // [32h T, 32(h+1) T): batch 0 overwrites only cells it has read itself, batch 1 only cells batch 0 has read.
+                // The norms are loaded unconditionally (not behind `v != 0`), so that the 8 loads of a batch are in flight together.
+                constexpr int HALF = F64_CELLS_PER_THREAD / 2;
 #pragma unroll
-                for (int k = 0; k < F64_CELLS_PER_THREAD; ++k) {
-                    const int j = tid + k * THREADS;
-                    float v = 0.f;
-                    if (j < n_tile) {
-                        v = p.fixed_scale > 0.0 ? (float)((double)(long long)reinterpret_cast<const unsigned long long *>(acc)[j] * p.fixed_inv)
-                                                : (float)acc_d[j];
-                        if (euclid) {
-                            v = tile_base + j != c ? euclidean_cell(p, v, sq_c, sqj[j], norm_c, nj[j]) : 0.f;
-                            account(v);
-                        } else if (v != 0.f) {
-                            v = normalise(p, v, norm_c, nj[j]);
-                            account(v);
-                        }
+                for (int half = 0; half < 2; ++half) {
+                    float reg[HALF], njv[HALF], sqv[HALF];
+#pragma unroll
+                    for (int k = 0; k < HALF; ++k) {
+                        const int j = tid + (half * HALF + k) * THREADS;
+                        njv[k] = nj[j < n_tile ? j : 0];
+                        sqv[k] = euclid ? sqj[j < n_tile ? j : 0] : 0.f;
                     }
-                    reg[k] = v;
-                }
-                __syncthreads();
 #pragma unroll
-                for (int k = 0; k < F64_CELLS_PER_THREAD; ++k) {
-                    const int j = tid + k * THREADS;
-                    if (j < p.n_cols_pad) acc[j] = reg[k];
+                    for (int k = 0; k < HALF; ++k) {
+                        const int j = tid + (half * HALF + k) * THREADS;
+                        float v = 0.f;
+                        if (j < n_tile) {
+                            v = p.fixed_scale > 0.0 ? (float)((double)(long long)reinterpret_cast<const unsigned long long *>(acc)[j] * p.fixed_inv)
+                                                    : (float)acc_d[j];
+                            if (euclid) {
+                                v = tile_base + j != c ? euclidean_cell(p, v, sq_c, sqv[k], norm_c, njv[k]) : 0.f;
+                                account(v);
+                            } else if (v != 0.f) {
+                                v = normalise(p, v, norm_c, njv[k]);
+                                account(v);
+                            }
+                        }
+                        reg[k] = v;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < HALF; ++k) {
+                        const int j = tid + (half * HALF + k) * THREADS;
+                        if (j < p.n_cols_pad) acc[j] = reg[k];
+                    }
                 }
             }
         }
         if (p.topK == 0) {  // dense output (.pyx:507-510)
+            if (tid == 0 && tile == 0) {
+                request_next();
+                file_next();
+            }
             __syncthreads();
             float *dst = p.out_dense + (size_t)(p.out_slot ? p.out_slot[c] : c - p.start_col) * p.n_cols + tile_base;
             for (int j = tid; j < n_tile; j += THREADS) dst[j] = acc[j];
@@ -466,6 +538,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         nneg = s_nneg;
         total_nonzero += npos + nneg;
         mark(3);
+        if (tid == 0 && tile == 0) request_next();                               // its descriptor arrives during the top-K
         if (p.n_tiles == 1) {
             // ---- top-K: the K largest cells of the FULL column (zeros compete, then are dropped), value-descending,
             //      emitted like the COO triples of .pyx:550-562 with -1 padding ----
@@ -476,6 +549,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             block_topk_emit<THREADS>(acc, n_tile, p.topK, npos, nneg, TOPK_NONZERO, aux, sc, &s_ncand,
                                      wg_cand_idx + tile * p.topK, wg_cand_val + tile * p.topK, tile_base);
         }
+        if (tid == 0 && tile == 0) file_next();
         __syncthreads();
         mark(4);
         }  // tiles
@@ -835,6 +909,8 @@ struct mi355rec_sim {
     DeviceBuffer<float> csr_data;
     DeviceBuffer<char> csr_sort_tmp;
     std::vector<int4> items_host;   // host staging for the current call
+    std::vector<int2> ranges_host;
+    DeviceBuffer<int2> item_range;
     int n_split_columns = 0, n_part_items = 0;
     DeviceBuffer<unsigned short> seg_idx16;
     DeviceBuffer<int> seg_ptr;
@@ -982,8 +1058,17 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     const int n_items = (int)h->items_host.size();
     h->n_split_columns = n_split;
     h->n_part_items = part_slots;
-    if (h->items.count < (size_t)n_items) h->items.alloc((size_t)n_items + 1024);
+    if (h->items.count < (size_t)n_items) {
+        h->items.alloc((size_t)n_items + 1024);
+        h->item_range.alloc((size_t)n_items + 1024);
+    }
+    h->ranges_host.resize((size_t)n_items);
+    for (int i = 0; i < n_items; ++i) {
+        const int c = h->items_host[i].x;
+        h->ranges_host[i] = make_int2(h->csc_ptr_host[c], h->csc_ptr_host[c + 1]);
+    }
     MI_HIP(hipMemcpyAsync(h->items.ptr, h->items_host.data(), sizeof(int4) * n_items, hipMemcpyHostToDevice, h->stream));
+    MI_HIP(hipMemcpyAsync(h->item_range.ptr, h->ranges_host.data(), sizeof(int2) * n_items, hipMemcpyHostToDevice, h->stream));
     MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(unsigned), h->stream));
     if (part_slots) {
         const size_t pub_words = (size_t)h->tile_w * (unit_kernel ? 1 : 2);
@@ -1021,6 +1106,7 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     p.norm_alpha = h->norm_alpha.ptr;
     p.norm_1ma = h->norm_1ma.ptr;
     p.items = h->items.ptr;
+    p.item_range = h->item_range.ptr;
     p.n_items = n_items;
     p.part_buf = h->part_buf.ptr;
     p.part_count = h->part_count.ptr;
@@ -1474,6 +1560,15 @@ extern "C" int mi355rec_sim_schedule_info(mi355rec_sim_t h, int32_t *n_items, in
         *n_items = (int32_t)h->items_host.size();
         *n_split_columns = h->n_split_columns;
         *n_parts = h->n_part_items;
+    });
+}
+
+extern "C" int mi355rec_sim_accumulator_info(mi355rec_sim_t h, int32_t *kind, double *fixed_scale) {
+    return guarded([&] {
+        MI_REQUIRE(h && kind && fixed_scale, "NULL argument");
+        const bool unit_kernel = h->unit_values && !h->row_w.ptr;
+        *kind = unit_kernel ? 0 : (h->fixed_scale > 0.0 ? 1 : 2);
+        *fixed_scale = unit_kernel ? 0.0 : h->fixed_scale;
     });
 }
 

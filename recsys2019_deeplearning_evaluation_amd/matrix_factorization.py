@@ -171,6 +171,47 @@ class MatrixFactorization_MI355X_Epoch:
         return np.array(self._download(True)[4][0])
 
 
+class MatrixFactorization_MI355X_Group:
+    """R independent epoch objects trained side by side: mini-batch b of ALL members is ONE launch (mi355rec_mf_group_*).
+
+    The reference's hyper-parameter search runs this path as a pool of workers with one model each
+    (ParameterTuning/run_parameter_search.py:498-503); one model's epoch is a chain of dependent ~3 MB mini-batches that
+    fills a tenth of an MI355X, so the device-side form of that pool is a group.  Members keep their own factors,
+    hyper-parameters, optimiser, seed and sample stream and end bit-identical to training alone; they must share
+    algorithm_name (MF_BPR / FUNK_SVD), precision, batch_size, the URM's number of mini-batches per epoch and the kernel
+    instance n_factors selects (see include/mi355rec.h).  The group does not own its members."""
+
+    def __init__(self, members):
+        self.members = list(members)
+        assert len(self.members) >= 1
+        self._lib = N.load()
+        handles = (C.c_void_p * len(self.members))(*[m._h for m in self.members])
+        self._g = C.c_void_p()
+        N.check(self._lib.mi355rec_mf_group_create(C.byref(self._g), handles, len(self.members)))
+
+    def epochIteration_Cython(self, n_epochs=1):
+        N.check(self._lib.mi355rec_mf_group_run_epochs(self._g, int(n_epochs)))
+
+    def set_profiling(self, max_timed_launches):
+        N.check(self._lib.mi355rec_mf_group_set_profiling(self._g, int(max_timed_launches)))
+
+    def stats(self):
+        st = N.Stats()
+        N.check(self._lib.mi355rec_mf_group_get_stats(self._g, C.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._lib.mi355rec_mf_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _MatrixFactorizationLogic:
     """fit() / early-stopping hooks of MatrixFactorization_Cython.py:20-170 over the device epoch object.  A mixin without
     bases: composed below with this package's re-provided recommender bases, and by reference_binding.bind() with the

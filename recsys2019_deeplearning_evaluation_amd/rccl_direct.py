@@ -1,7 +1,8 @@
 """RCCL through ctypes: the collective of the sharded similarity build without PyTorch.
 
 One process per GPU.  Rank 0 creates the `ncclUniqueId` and hands it to the other ranks over a plain TCP socket
-(MASTER_ADDR : MASTER_PORT + 1 by default -- the launcher's own store keeps MASTER_PORT); every rank then calls
+(MASTER_ADDR : MI355REC_RCCL_PORT, or MASTER_PORT + 1 -- the launcher's own store keeps MASTER_PORT; clients identify
+themselves with a job nonce and their rank, and rank 0 answers each rank once); every rank then calls
 `ncclCommInitRank`.  `all_gather` runs on the null stream and returns after the device has finished (the callers are
 blocking library calls anyway).  Only the three entry points the build needs are bound.
 """
@@ -38,6 +39,10 @@ def _load_rccl():
     lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
     lib.ncclAllGather.restype = C.c_int
     lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ncclCommCount.restype = C.c_int
+    lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.ncclCommUserRank.restype = C.c_int
+    lib.ncclCommUserRank.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.ncclCommDestroy.restype = C.c_int
     lib.ncclCommDestroy.argtypes = [C.c_void_p]
     lib.ncclGetErrorString.restype = C.c_char_p
@@ -45,33 +50,65 @@ def _load_rccl():
     return lib
 
 
+_HELLO_MAGIC = b"MI355RCL"
+
+
+def _job_nonce():
+    """8 bytes every rank of ONE launch agrees on (torchrun exports TORCHELASTIC_RUN_ID; MI355REC_RCCL_NONCE overrides)."""
+    import hashlib
+    tag = os.environ.get("MI355REC_RCCL_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID") or "mi355rec"
+    tag += ":" + os.environ.get("MASTER_ADDR", "") + ":" + os.environ.get("MASTER_PORT", "")
+    return hashlib.sha256(tag.encode()).digest()[:8]
+
+
+def _recv_exact(conn, need):
+    chunks = []
+    while need > 0:
+        part = conn.recv(need)
+        if not part:
+            raise ConnectionError("peer closed the connection early")
+        chunks.append(part)
+        need -= len(part)
+    return b"".join(chunks)
+
+
 def exchange_unique_id(payload, rank, world, address, port, timeout=120.0):
-    """Rank 0 serves `payload` (bytes) to the world - 1 other ranks; they return what they received."""
+    """Rank 0 serves `payload` (bytes) to the world - 1 other ranks; they return what they received.
+
+    Every client opens with a 20-byte hello (magic, job nonce, rank): rank 0 answers each rank of THIS job exactly once; a stray
+    or duplicate connection (another job on the same port, a port scanner, a retry) is closed without using up one of the
+    world - 1 places, so a real rank cannot be locked out by it."""
     if world == 1:
         return payload
+    nonce = _job_nonce()
     if rank == 0:
+        served = set()
+        deadline = time.time() + timeout
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((address, port))
-            srv.listen(world)
-            srv.settimeout(timeout)
-            for _ in range(world - 1):
-                conn, _ = srv.accept()
+            srv.listen(max(world, 8))
+            while len(served) < world - 1:
+                srv.settimeout(max(0.05, deadline - time.time()))
+                conn, _ = srv.accept()          # socket.timeout propagates once the deadline has passed
                 with conn:
-                    conn.sendall(payload)
+                    try:
+                        conn.settimeout(5.0)
+                        hello = _recv_exact(conn, 20)
+                        peer = int.from_bytes(hello[16:20], "little")
+                        if hello[:8] != _HELLO_MAGIC or hello[8:16] != nonce or not (0 < peer < world) or peer in served:
+                            continue
+                        conn.sendall(payload)
+                        served.add(peer)
+                    except (ConnectionError, socket.timeout, OSError):
+                        continue
         return payload
     deadline = time.time() + timeout
     while True:
         try:
             with socket.create_connection((address, port), timeout=5.0) as conn:
-                chunks, need = [], len(payload) if payload else NCCL_UNIQUE_ID_BYTES
-                while need > 0:
-                    part = conn.recv(need)
-                    if not part:
-                        raise ConnectionError("peer closed the connection early")
-                    chunks.append(part)
-                    need -= len(part)
-                return b"".join(chunks)
+                conn.sendall(_HELLO_MAGIC + nonce + int(rank).to_bytes(4, "little"))
+                return _recv_exact(conn, len(payload) if payload else NCCL_UNIQUE_ID_BYTES)
         except (ConnectionRefusedError, socket.timeout, ConnectionError):
             if time.time() > deadline:
                 raise
@@ -83,7 +120,10 @@ class RcclCommunicator:
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         address = address or os.environ.get("MASTER_ADDR", "127.0.0.1")
-        port = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + 1)
+        # the rendezvous port: explicit argument, MI355REC_RCCL_PORT, or MASTER_PORT + 1 (the launcher's store keeps MASTER_PORT)
+        if port is None:
+            port = os.environ.get("MI355REC_RCCL_PORT") or int(os.environ.get("MASTER_PORT", "29500")) + 1
+        port = int(port)
         self._lib = _load_rccl()
         N.check(N.load().mi355rec_device_synchronize())          # binds this process to its device (set_device) first
         uid = _UniqueId()
@@ -93,6 +133,17 @@ class RcclCommunicator:
         C.memmove(C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
         self._comm = C.c_void_p()
         self._check(self._lib.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+
+    def count(self):
+        """ncclCommCount: the number of ranks RCCL itself sees in this communicator (must equal WORLD_SIZE)."""
+        n = C.c_int(-1)
+        self._check(self._lib.ncclCommCount(self._comm, C.byref(n)), "ncclCommCount")
+        return n.value
+
+    def user_rank(self):
+        r = C.c_int(-1)
+        self._check(self._lib.ncclCommUserRank(self._comm, C.byref(r)), "ncclCommUserRank")
+        return r.value
 
     def _check(self, rc, what):
         if rc != 0:

@@ -1,12 +1,14 @@
-"""Multi-GPU sharding of the similarity build (one process per GPU; RCCL through torch.distributed or directly through ctypes).
+"""Multi-GPU sharding of the hot paths that shard (one process per GPU; RCCL through torch.distributed or directly through ctypes).
 
-The path shards along the seam the reference already has and never uses: `compute_similarity(start_col,
-end_col)` (Compute_Similarity_Cython.pyx:411,447-451).  Every output column depends only on the read-only
-URM, so each rank holds the whole URM, builds a contiguous, COST-balanced range of columns and the ranks
-exchange their (n_local x topK) neighbour/value slabs with ONE all-gather of fixed-width padded slabs
-(<= n_cols*topK*8 B in total, e.g. 21 MB at ML-20M shape: latency-, not bandwidth-bound over xGMI).  There
-is no collective on the data path itself.  On CPU (tests) the same code runs over gloo with a stand-in
-column builder.
+Similarity build: every output column depends only on the read-only URM, so each rank holds the whole URM and builds a share
+of the columns -- by default an INTERLEAVED part (the columns in cost order dealt to the ranks in serpentine order: every rank
+gets n_cols / G columns and 1 / G of the cost, `interleaved_parts`), or a contiguous cost-balanced range along the seam the
+reference already has and never uses, `compute_similarity(start_col, end_col)` (Compute_Similarity_Cython.pyx:411,447-451;
+`balanced_column_ranges`).  The ranks exchange their (n_local x topK) neighbour / value slabs, which the kernel fills directly,
+with ONE all-gather into a buffer allocated once (`ShardedSimilarityBuild`); there is no collective on the data path itself.
+IALS: rows of a half-step are split into cost-balanced ranges, solved shards are all-gathered (`sharded_ials_epoch`).
+BPR-MF: exact multi-GPU mini-batches (`sharded_bpr_epoch`, one all-gather of the updated rows per mini-batch).
+On CPU (tests) the same host code runs over gloo with stand-in builders.
 """
 import numpy as np
 

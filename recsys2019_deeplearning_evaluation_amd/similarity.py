@@ -145,6 +145,12 @@ class Compute_Similarity_MI355X:
         N.check(self._lib.mi355rec_sim_schedule_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def accumulator_info(self):
+        """("uint32" | "int64-fixed" | "float64", fixed-point scale): type of the in-LDS column accumulator (diagnostics)."""
+        kind, scale = C.c_int32(), C.c_double()
+        N.check(self._lib.mi355rec_sim_accumulator_info(self._h, C.byref(kind), C.byref(scale)))
+        return ("uint32", "int64-fixed", "float64")[kind.value], scale.value
+
     def stats(self):
         st = N.Stats()
         N.check(self._lib.mi355rec_sim_get_stats(self._h, C.byref(st)))

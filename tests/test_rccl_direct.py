@@ -34,37 +34,76 @@ def test_unique_id_rendezvous_over_tcp():
 
 def test_librccl_exports_what_the_binding_uses():
     lib = rccl_direct._load_rccl()
-    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclCommDestroy", "ncclGetErrorString"):
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclCommDestroy", "ncclGetErrorString", "ncclCommCount",
+                 "ncclCommUserRank"):
         assert hasattr(lib, name)
     assert rccl_direct._UniqueId.__dict__ is not None and rccl_direct.NCCL_UNIQUE_ID_BYTES == 128
 
 
+def test_rendezvous_ignores_strangers_and_duplicates():
+    """A connection without the job's hello, or a second one from a rank already served, must not use up a place."""
+    import socket
+    port = _free_port()
+    payload = bytes(range(128))
+    got = {}
+
+    def server():
+        got[0] = rccl_direct.exchange_unique_id(payload, 0, 3, "127.0.0.1", port, timeout=30)
+
+    t0 = threading.Thread(target=server)
+    t0.start()
+    for _ in range(200):                                     # a stranger, as soon as the port listens
+        try:
+            with socket.create_connection(("127.0.0.1", port), timeout=1.0) as c:
+                c.sendall(b"GET / HTTP/1.0\r\n\r\n" + b"x" * 8)
+            break
+        except ConnectionRefusedError:
+            import time
+            time.sleep(0.02)
+    got[1] = rccl_direct.exchange_unique_id(b"", 1, 3, "127.0.0.1", port, timeout=30)
+    with socket.create_connection(("127.0.0.1", port), timeout=5.0) as c:      # rank 1 again: not served twice
+        c.sendall(rccl_direct._HELLO_MAGIC + rccl_direct._job_nonce() + (1).to_bytes(4, "little"))
+        c.settimeout(2.0)
+        try:
+            assert c.recv(128) == b""
+        except (socket.timeout, ConnectionError):
+            pass
+    got[2] = rccl_direct.exchange_unique_id(b"", 2, 3, "127.0.0.1", port, timeout=30)
+    t0.join(40)
+    assert got[0] == got[1] == got[2] == payload
+
+
 @pytest.mark.gpu
-def test_single_rank_communicator_and_sharded_build_object(gpu):
-    """One rank: ncclCommInitRank / ncclAllGather on raw device buffers of the library (the code path of every rank of an
-    N-GPU run; N > 1 itself needs N devices and is the driver's multi-GPU run).  Also: ShardedSimilarityBuild at world = 1
-    equals compute_slabs()."""
-    from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_MI355X, _native as N
-    from recsys2019_deeplearning_evaluation_amd.sharding import ShardedSimilarityBuild
-    from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
+def test_single_rank_rccl_communicator_all_gather(gpu):
+    """One rank: ncclCommInitRank / ncclCommCount / ncclAllGather on raw device buffers of the library (the code path of every rank
+    of an N-GPU run).  Where RCCL itself cannot initialise (the 1-GPU sandbox hides the other KFD topology nodes,
+    profiles/r2_rccl_sandbox_init.log) the test is reported as XFAIL with RCCL's message -- never as a pass: a green line here
+    means ncclAllGather moved bytes."""
+    from recsys2019_deeplearning_evaluation_amd import _native as N
     import os
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     try:
         comm = rccl_direct.RcclCommunicator(0, 1, "127.0.0.1", _free_port())
     except N.NativeLibraryError as exc:
-        # the 1-GPU sandbox hides the other KFD topology nodes ("NCCL WARN Could not read node # ..."): RCCL itself cannot
-        # initialise there, with or without this binding (profiles/r2_rccl_sandbox_init.log); the binding is then only covered up
-        # to symbol resolution + the TCP rendezvous (CPU tests above) until the driver's multi-GPU run
         assert "ncclCommInitRank" in str(exc)
-        comm = None
-    if comm is not None:
-        a, b = N.DeviceArray(1000), N.DeviceArray(1000)
-        src = np.arange(1000, dtype=np.int32)
-        N.check(N.load().mi355rec_device_memcpy(a.ptr, N.ptr(src), 4000, 1))
-        comm.all_gather_words(a.address(), b.address(), 1000)
-        np.testing.assert_array_equal(b.to_host(), src)
-        comm.close()
-    a = N.DeviceArray(64)                                   # raw device buffers of the library: upload / download round trip
+        pytest.xfail("RCCL cannot initialise on this box (single-rank ncclCommInitRank): %s" % exc)
+    assert comm.count() == 1 and comm.user_rank() == 0
+    a, b = N.DeviceArray(1000), N.DeviceArray(1000)
+    src = np.arange(1000, dtype=np.int32)
+    N.check(N.load().mi355rec_device_memcpy(a.ptr, N.ptr(src), 4000, 1))
+    comm.all_gather_words(a.address(), b.address(), 1000)
+    np.testing.assert_array_equal(b.to_host(), src)
+    print("RCCL single-rank all-gather ran: ncclCommCount = %d" % comm.count())
+    comm.close()
+
+
+@pytest.mark.gpu
+def test_device_buffers_and_sharded_build_object_at_world_1(gpu):
+    """Raw device buffers of the library round-trip; ShardedSimilarityBuild at world = 1 equals compute_slabs()."""
+    from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_MI355X, _native as N
+    from recsys2019_deeplearning_evaluation_amd.sharding import ShardedSimilarityBuild
+    from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
+    a = N.DeviceArray(64)
     src = np.arange(64, dtype=np.int32)
     N.check(N.load().mi355rec_device_memcpy(a.ptr, N.ptr(src), 256, 1))
     np.testing.assert_array_equal(a.to_host(), src)

@@ -445,3 +445,82 @@ def test_csr_assembled_on_the_device_equals_the_host_assembly(gpu):
         assert np.array_equal(W.indptr, want.indptr) and np.array_equal(W.indices, want.indices)
         assert np.array_equal(W.data, want.data)
         dev.close()
+
+
+# ---- real-valued data at the BASELINE shapes, on BOTH accumulator types (int64 fixed point / float64) ----------------------
+@pytest.mark.parametrize("shape", ["ml20m", "netflix"])
+def test_real_valued_full_shape_fixed_point_and_float64_accumulators(gpu, shape, monkeypatch):
+    """Ratings (real-valued data) at the ML-20M and Netflix shapes: cosine, one set-based measure and pearson.  The most costly
+    columns (the ones the schedule splits) + 200 random ones are checked against the oracle column by column -- once on the
+    default accumulator (int64 fixed point wherever the host's bound admits it) and once with MI355REC_SIM_F64_SUMS=1 (float64
+    sums, like the reference's double array) -- and the two builds must agree on EVERY column: identical neighbour ids in
+    identical order, values within 2e-6 relative."""
+    X = named_urm(shape, "real")
+    n = X.shape[1]
+    for similarity, extra in (("cosine", {}), ("dice", {}), ("pearson", dict(shrink=3))):
+        kw = dict(topK=100, similarity=similarity, **extra)
+        builds = {}
+        for forced in (False, True):
+            if forced:
+                monkeypatch.setenv("MI355REC_SIM_F64_SUMS", "1")
+            else:
+                monkeypatch.delenv("MI355REC_SIM_F64_SUMS", raising=False)
+            dev = Compute_Similarity_MI355X(X, **kw)
+            kind, scale = dev.accumulator_info()
+            if similarity == "dice":
+                assert kind == "uint32"                    # set-based measures binarise the data (.pyx:219-230)
+            elif similarity == "cosine":
+                assert kind == ("float64" if forced else "int64-fixed"), (similarity, kind, scale)
+            else:
+                # pearson: a sparse column of nearly equal ratings has a tiny centred norm, for which the worst-case bound
+                # may refuse fixed point -- either way the forced build is float64
+                assert kind == "float64" if forced else kind in ("int64-fixed", "float64")
+            idx, val, _ = dev.compute_slabs()
+            cost = dev.column_costs()
+            dev.close()
+            builds[forced] = (idx, val)
+        monkeypatch.delenv("MI355REC_SIM_F64_SUMS", raising=False)
+        (idx_a, val_a), (idx_b, val_b) = builds[False], builds[True]
+        np.testing.assert_array_equal(idx_a, idx_b)
+        assert np.abs(val_a - val_b).max() <= 2e-6 * np.abs(val_b).max()
+        orc = O.OracleSimilarity(X, **dict(kw, topK=0))
+        heavy = np.argsort(-cost)[:40 if shape == "ml20m" else 12]
+        sample = np.unique(np.concatenate([heavy, np.random.default_rng(2).choice(n, 200, replace=False)]))
+        for c in sample:
+            col = orc.column(int(c))[0]
+            check_topk_against_dense(idx_a[c], val_a[c], col, 100, RTOL)
+            check_topk_against_dense(idx_b[c], val_b[c], col, 100, RTOL)
+
+
+def test_fixed_point_bound_rejects_wide_dynamic_range(gpu, monkeypatch):
+    """Data on which no power-of-two scale keeps the worst-case rounding below the bar (values over eight decades, a column whose
+    norm is tiny, row_weights): the constructor must fall back to float64 sums -- this keeps the ds_add_f64 branch covered -- and
+    the result must match the oracle; the same matrix without its tiny column is admitted to fixed point again."""
+    monkeypatch.delenv("MI355REC_SIM_F64_SUMS", raising=False)
+    rng = np.random.default_rng(4)
+    X = synthetic_urm(3000, 700, 90000, 5, 300, seed=21, values="real").tolil()
+    X[:, 5] = 0.0
+    X[7, 5] = 1e-4                                    # one cell: column norm 1e-4
+    X[11, 5] = 2e-4
+    X = X.tocsr()
+    X.data[rng.random(X.nnz) < 0.01] *= 1e4           # and a few very large ratings
+    X.eliminate_zeros(); X.sort_indices()
+    w = (0.5 + rng.random(X.shape[0]) * 40).astype(np.float64)
+    for kw in (dict(similarity="cosine"), dict(similarity="cosine", row_weights=w), dict(similarity="asymmetric", asymmetric_alpha=0.3)):
+        dev = Compute_Similarity_MI355X(X, topK=30, **kw)
+        assert dev.accumulator_info()[0] == "float64", kw
+        idx, val, _ = dev.compute_slabs()
+        orc = O.OracleSimilarity(X, topK=0, **kw)
+        for c in range(X.shape[1]):
+            check_topk_against_dense(idx[c], val[c], orc.column(c)[0], 30, RTOL)
+        dev.close()
+    Y = X.tolil(); Y[:, 5] = 0.0; Y[0, 5] = 3.0; Y = Y.tocsr()
+    Y.data = np.minimum(Y.data, 6.0)
+    dev = Compute_Similarity_MI355X(Y, topK=30, similarity="cosine")
+    kind, scale = dev.accumulator_info()
+    assert kind == "int64-fixed" and scale > 1.0
+    idx, val, _ = dev.compute_slabs()
+    orc = O.OracleSimilarity(Y, topK=0, similarity="cosine")
+    for c in range(0, Y.shape[1], 3):
+        check_topk_against_dense(idx[c], val[c], orc.column(c)[0], 30, RTOL)
+    dev.close()

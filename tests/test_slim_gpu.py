@@ -1,10 +1,10 @@
 """Parity of the HIP SLIM-BPR epoch (through the C ABI) against the CPU oracle.
 
 Replay mode: the oracle draws the (u, i, j) stream with glibc rand() exactly like the reference and runs its
-strictly sequential SGD in float64; the device executes the same stream (level-scheduled on the dense store, in
-order on the symmetric store) on a float32 S.  Tolerances: see test_mf_gpu.py -- max-norm 1e-5 for sgd; for the
-adaptive optimisers the per-item 1/sqrt(cache) scaling amplifies float32 storage rounding, so the error
-distribution is checked instead."""
+strictly sequential SGD in float64; the device executes the same stream as one persistent dataflow kernel (every step waits
+for the steps that last wrote the cells it reads) with S in float32 for sgd and float64 for the adaptive optimisers.
+Tolerance, for every optimiser and both stores: element-wise |dev - ref| <= 1e-5 |ref| + 1e-6 max|ref| (see
+test_mf_gpu.assert_factor_parity)."""
 import numpy as np
 import pytest
 import scipy.sparse as sps
@@ -110,12 +110,14 @@ def test_recommender_fit_surface(gpu):
 
 
 def _assert_blockwise_parity(dev_S, ref_S, what):
-    """1e-5 relative to max|S| without materialising an n x n float64 difference."""
+    """Element-wise |dev - ref| <= 1e-5 |ref| + 1e-6 max|ref| (see test_mf_gpu.assert_factor_parity) without materialising an
+    n x n float64 difference."""
     scale = max(np.abs(ref_S).max(), 1e-30)
-    worst = 0.0
+    worst = -np.inf
     for r0 in range(0, ref_S.shape[0], 2048):
-        worst = max(worst, np.abs(dev_S[r0:r0 + 2048].astype(np.float64) - ref_S[r0:r0 + 2048]).max())
-    assert worst / scale < 1e-5, (what, worst / scale)
+        ref = ref_S[r0:r0 + 2048]
+        worst = max(worst, (np.abs(dev_S[r0:r0 + 2048].astype(np.float64) - ref) - (1e-5 * np.abs(ref) + 1e-6 * scale)).max())
+    assert worst <= 0, (what, worst)
 
 
 @pytest.mark.parametrize("symmetric", [False, True])
