@@ -157,6 +157,154 @@ def cpu_baseline_sim(urm, costs, seconds):
                       "by cost" % (start, end, 100 * frac, t_cols, t_init)}
 
 
+def _quiet():
+    import io
+    from contextlib import redirect_stdout
+    return redirect_stdout(io.StringIO())
+
+
+def cpu_baseline_slim(urm, symmetric, seconds):
+    """The reference's compiled SLIM_BPR_Cython_Epoch (oracle/_ref; falls back to the C restatement) on ONE host core:
+    BASELINE config 3 (adagrad, dense / symmetric store), whole reference epochs of n_users + 1 steps until the budget is used."""
+    from oracle import ref_loader
+    kw = dict(train_with_sparse_weights=False, final_model_sparse_weights=True, learning_rate=1e-4, li_reg=0.0, lj_reg=0.0,
+              batch_size=1, topK=TOPK, symmetric=symmetric, sgd_mode="adagrad", random_seed=7)
+    SL = ref_loader.load("slim")
+    kind = "reference"
+    if SL is None:
+        from oracle.oracle import OracleSLIM as SL
+        kind = "port"
+    with _quiet():
+        m = SL(urm, **kw)
+        epochs, t0 = 0, time.perf_counter()
+        while True:
+            m.epochIteration_Cython()
+            epochs += 1
+            if time.perf_counter() - t0 >= seconds:
+                break
+        dt = time.perf_counter() - t0
+        if hasattr(m, "_dealloc"):
+            m._dealloc()
+        del m                                  # (the reference's __dealloc__ prints: keep it inside the redirection)
+        import gc
+        gc.collect()
+    n = epochs * (urm.shape[0] + 1)
+    return {"value": n / dt, "unit": "samples/s", "cores": 1, "kind": kind,
+            "sample": "%d reference epochs (%d steps) of SLIM_BPR adagrad, %s store, on the same URM, %.1f s" % (
+                epochs, n, "symmetric (triangular)" if symmetric else "dense", dt)}
+
+
+def _mf_reference(urm, **kw):
+    from oracle import ref_loader
+    MF = ref_loader.load("mf")
+    kind = "reference"
+    if MF is None:
+        from oracle.oracle import OracleMF as MF
+        kind = "port"
+    return MF(urm, **kw), kind
+
+
+def cpu_baseline_funk(urm, seconds):
+    """Reference FunkSVD epoch (k=128, batch 1000, biases) on ONE host core.  A reference epoch is nnz // 1000 + 1 mini-batches
+    (20 M samples at this shape: minutes on a CPU) and cannot be cut short, so the sample is the epoch of a URM of the SAME shape
+    (same factor matrices, same row gathers) holding a random 1/40 of the interactions."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    sub = urm.tocoo()
+    keep = rng.random(sub.nnz) < 1.0 / 40.0
+    import scipy.sparse as sps
+    sub = sps.csr_matrix((sub.data[keep], (sub.row[keep], sub.col[keep])), shape=urm.shape, dtype=np.float32)
+    sub.sort_indices()
+    with _quiet():
+        m, kind = _mf_reference(sub, n_factors=K_FACTORS, algorithm_name="FUNK_SVD", batch_size=BATCH, learning_rate=1e-3, sgd_mode="sgd",
+                                use_bias=True, negative_interactions_quota=0.0, random_seed=42)
+        per_epoch = (sub.nnz // BATCH + 1) * BATCH
+        epochs, t0 = 0, time.perf_counter()
+        while True:
+            m.epochIteration_Cython()
+            epochs += 1
+            if time.perf_counter() - t0 >= seconds:
+                break
+        dt = time.perf_counter() - t0
+    return {"value": epochs * per_epoch / dt, "unit": "samples/s", "cores": 1, "kind": kind,
+            "sample": "%d reference epochs (%d samples) of FUNK_SVD k=%d batch=%d with biases on a %dx%d URM holding 1/40 of the interactions "
+                      "(%d nnz; same factor matrices), %.1f s" % (epochs, epochs * per_epoch, K_FACTORS, BATCH, urm.shape[0], urm.shape[1], sub.nnz, dt)}
+
+
+def cpu_baseline_asy(urm, k, seconds):
+    """Reference AsySVD epoch (nnz + 1 ordered steps, each O(profile x k)) on ONE host core, on the rows of a random subset of the
+    users (same items, same profile-length distribution, same Y and X matrices), sized for the budget."""
+    import numpy as np
+    rng = np.random.default_rng(12)
+    n_users = urm.shape[0]
+    order = rng.permutation(n_users)
+    take = max(50, n_users // 16)
+    total_steps, total_dt, used = 0, 0.0, 0
+    kind = "reference"
+    with _quiet():
+        while total_dt < seconds and used < n_users:
+            rows = np.sort(order[used:used + take])
+            used += len(rows)
+            sub = urm[rows].tocsr()
+            sub.sort_indices()
+            m, kind = _mf_reference(sub, n_factors=k, algorithm_name="ASY_SVD", batch_size=1, learning_rate=1e-3, sgd_mode="sgd",
+                                    use_bias=True, negative_interactions_quota=0.0, random_seed=42)
+            t0 = time.perf_counter()
+            m.epochIteration_Cython()
+            total_dt += time.perf_counter() - t0
+            total_steps += sub.nnz + 1
+    return {"value": total_steps / total_dt, "unit": "samples/s", "cores": 1, "kind": kind,
+            "sample": "reference ASY_SVD epochs (k=%d, biases) on the rows of %d of the %d users (%d steps, mean profile %.0f), %.1f s" % (
+                k, used, n_users, total_steps, urm.nnz / n_users, total_dt)}
+
+
+def cpu_baseline_ials(conf, k, reg, V0, seconds):
+    """IALSRecommender._update_row (NumPy, IALSRecommender.py:170-201: gather, k x k Gramian update, np.linalg.inv) on ONE host
+    thread, as restated by oracle.oracle._ials_update_row -- the reference class itself is pure Python and does not travel to the
+    GPU box.  A random sample of user rows and item rows is timed; a whole epoch (every warm user row, then every warm item row)
+    is extrapolated by the flop cost 2 L k^2 + 2 k^3 of a row with L interactions."""
+    import numpy as np
+    from oracle import oracle as O
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=1)
+    except Exception:
+        limit = None
+    try:
+        rng = np.random.default_rng(13)
+        csr = conf.tocsr()
+        csc = conf.tocsc()
+        V = np.asarray(V0, dtype=np.float64)
+        U = rng.normal(0, 0.1, (conf.shape[0], k))
+        reg_diag = np.diag(reg * np.ones(k))
+        VV, UU = V.T.dot(V), U.T.dot(U)
+        cost = lambda L: 2.0 * L * k * k + 2.0 * k ** 3
+        full = cost(np.diff(csr.indptr)[np.diff(csr.indptr) > 0]).sum() + cost(np.diff(csc.indptr)[np.diff(csc.indptr) > 0]).sum()
+        done, t_used, n_rows = 0.0, 0.0, 0
+        users, items = rng.permutation(conf.shape[0]), rng.permutation(conf.shape[1])
+        pos = 0
+        while t_used < seconds and pos < min(len(users), len(items)):
+            t0 = time.perf_counter()
+            for u in users[pos:pos + 32]:
+                s, e = csr.indptr[u], csr.indptr[u + 1]
+                if e > s:
+                    O._ials_update_row(csr.indices[s:e], csr.data[s:e], V, VV, reg_diag)
+                    done += cost(e - s); n_rows += 1
+            for i in items[pos:pos + 8]:
+                s, e = csc.indptr[i], csc.indptr[i + 1]
+                if e > s:
+                    O._ials_update_row(csc.indices[s:e], csc.data[s:e], U, UU, reg_diag)
+                    done += cost(e - s); n_rows += 1
+            t_used += time.perf_counter() - t0
+            pos += 32
+    finally:
+        if limit is not None:
+            limit.unregister() if hasattr(limit, "unregister") else None
+    return {"value": t_used * full / max(done, 1.0), "unit": "s/epoch", "cores": 1, "kind": "port",
+            "sample": "%d rows (users and items at random) = %.3f %% of an epoch's 2 L k^2 + 2 k^3 flops in %.1f s, NumPy on one BLAS thread; "
+                      "epoch extrapolated by that cost" % (n_rows, 100.0 * done / full, t_used)}
+
+
 def hbm_block(kernel, st, seconds, note=None):
     gbps = st["algorithmic_bytes"] / seconds / 1e9
     out = {"bound": "hbm", "kernel": kernel, "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
@@ -166,7 +314,7 @@ def hbm_block(kernel, st, seconds, note=None):
     return out
 
 
-def other_paths(urm):
+def other_paths(urm, args):
     """The remaining rows of SURVEY.md section 8 on the same URM shape, one short run each (N = 1 only): one roofline block per
     path.  Throughputs come from the handle's own stream events (call_ms); fractions are ALGORITHMIC work / time against the
     MI355X peaks."""
@@ -184,10 +332,50 @@ def other_paths(urm):
         out[tag]["epochs"] = epochs
         m.close()
 
+    cpu = not args.no_cpu_baseline
     mf_run("bpr_mf_k128_batch1000_adagrad", 50, "float64 factors + moments (adaptive optimisers)", algorithm_name="MF_BPR",
            batch_size=BATCH, sgd_mode="adagrad")
     mf_run("funk_svd_k128_batch1000_bias", 1, "20 001 mini-batches per epoch, general (radix-sort) schedule", algorithm_name="FUNK_SVD",
            batch_size=BATCH, sgd_mode="sgd", use_bias=True, negative_interactions_quota=0.0)
+    if cpu:
+        out["funk_svd_k128_batch1000_bias"]["cpu_baseline"] = cpu_baseline_funk(urm, args.cpu_seconds)
+        out["funk_svd_k128_batch1000_bias"]["speedup_vs_cpu_baseline"] = (
+            out["funk_svd_k128_batch1000_bias"]["samples_per_s"] / out["funk_svd_k128_batch1000_bias"]["cpu_baseline"]["value"])
+
+    # REPLICA-BATCHED launches: 32 independent models (own factors, seed, sample stream), mini-batch b of all of them in ONE grid
+    # (mi355rec_mf_group_*) -- the device-side form of run_parameter_search.py:498's pool of workers.  Every member ends
+    # bit-identical to training alone (tests/test_mf_gpu.py::test_group_*).
+    n_grp, epochs = 32, 30
+    rng = np.random.default_rng(0)
+    U0 = rng.normal(0, 0.1, (urm.shape[0], K_FACTORS)).astype(np.float32)
+    V0 = rng.normal(0, 0.1, (urm.shape[1], K_FACTORS)).astype(np.float32)
+    from recsys2019_deeplearning_evaluation_amd import MatrixFactorization_MI355X_Group
+    members = [MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, algorithm_name="MF_BPR", batch_size=BATCH, learning_rate=1e-3,
+                                                sgd_mode="sgd", random_seed=200 + r, initial_USER_factors=U0, initial_ITEM_factors=V0)
+               for r in range(n_grp)]
+    grp = MatrixFactorization_MI355X_Group(members)
+    grp.epochIteration_Cython(2)
+    grp.epochIteration_Cython(epochs)
+    gst = grp.stats()
+    nb = urm.shape[0] // BATCH + 1
+    grp.set_profiling(2 * nb)
+    grp.epochIteration_Cython(2)
+    pst = grp.stats()
+    sec = gst["call_ms"] * 1e-3
+    launch_s = pst["kernel_ms"] / max(1, pst["n_timed"]) * 1e-3
+    alg_launch = n_grp * BATCH * 24.0 * K_FACTORS
+    traffic, traffic_source = pmc_traffic("mf_group_batch_kernel")
+    out["bpr_mf_k128_batch1000_32_models_one_launch"] = {
+        "bound": "hbm", "kernel": "mf_group_batch_kernel", "achieved": alg_launch / launch_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": alg_launch / launch_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+        "algorithmic_bytes_per_launch": alg_launch, "avg_launch_us": launch_s * 1e6, "timed_launches": pst["n_timed"],
+        "samples_per_s": gst["n_units"] / sec, "whole_epoch_frac": gst["algorithmic_bytes"] / sec / 1e9 / HBM_PEAK_GBPS,
+        "models": n_grp, "epochs": epochs, "seconds": sec,
+        "note": "aggregate of 32 independent models; one launch per mini-batch index carries all 32 (grid 750 x 32 workgroups)"}
+    grp.close()
+    for m in members:
+        m.close()
+    del U0, V0
 
     # concurrent replicas on ONE GPU: how run_parameter_search.py:498 uses the path (one model per worker); 8 handles, 8 streams
     n_rep, epochs = 8, 100
@@ -260,6 +448,9 @@ def other_paths(urm):
                     "us_per_step_amortised": sec / st["n_units"] * 1e6, "get_S_topk_s": time.perf_counter() - t0})
         out["slim_bpr_%s" % ("symmetric" if symmetric else "dense")] = blk
         sl.close()
+        if cpu:
+            blk["cpu_baseline"] = cpu_baseline_slim(urm, symmetric, args.cpu_seconds)
+            blk["speedup_vs_cpu_baseline"] = blk["samples_per_s"] / blk["cpu_baseline"]["value"]
 
     # scoring + ranking of 1000 users (the Evaluator's block size, Base/Evaluation/Evaluator.py:406-408), k = 128
     from recsys2019_deeplearning_evaluation_amd import MI355XScorer
@@ -302,6 +493,31 @@ def other_paths(urm):
                         "frac": tf / FP64_PEAK_TF, "seconds_per_epoch": sec, "row_solves_per_s": st["n_units"] / sec,
                         "row_kernel_ms": st["kernel_ms"]}
     ia.close()
+    if cpu:
+        out["ials_k200"]["cpu_baseline"] = cpu_baseline_ials(conf, k, 1e-3, V0, args.cpu_seconds)
+        out["ials_k200"]["speedup_vs_cpu_baseline"] = out["ials_k200"]["cpu_baseline"]["value"] / out["ials_k200"]["seconds_per_epoch"]
+
+    # AsySVD at the ML-1M shape, k = 64, biases: nnz + 1 strictly ordered steps, each rewriting every Y row of the
+    # sampled user's profile -- consecutive steps share the popular items' rows, so the epoch is one dependent chain
+    from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
+    x1m = named_urm("ml1m", "real")
+    ka = 64
+    asy = MatrixFactorization_MI355X_Epoch(x1m, n_factors=ka, algorithm_name="ASY_SVD", batch_size=1, learning_rate=1e-3, sgd_mode="sgd",
+                                           use_bias=True, negative_interactions_quota=0.0, random_seed=42)
+    asy.epochIteration_Cython(1)
+    st = asy.stats()
+    sec = st["call_ms"] * 1e-3
+    steps = st["n_units"]
+    mean_len = x1m.nnz / x1m.shape[0]
+    alg = steps * (16.0 * ka * mean_len + 8.0 * ka)          # every profile row of Y read and written once (fp32) + X_i
+    out["asy_svd_ml1m_k64"] = {"bound": "latency (one dependent chain of steps)", "kernel": "mf_asy_kernel", "samples_per_s": steps / sec,
+                               "seconds_per_epoch": sec, "us_per_step": sec / steps * 1e6, "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": alg / sec / 1e9 / HBM_PEAK_GBPS,
+                               "note": "ML-1M shape (6 040 x 3 706, 1 000 209 interactions); algorithmic bytes = 16 k L_u + 8 k per step"}
+    asy.close()
+    if cpu:
+        out["asy_svd_ml1m_k64"]["cpu_baseline"] = cpu_baseline_asy(x1m, ka, args.cpu_seconds)
+        out["asy_svd_ml1m_k64"]["speedup_vs_cpu_baseline"] = out["asy_svd_ml1m_k64"]["samples_per_s"] / out["asy_svd_ml1m_k64"]["cpu_baseline"]["value"]
     return out
 
 
@@ -530,7 +746,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras:
         try:
-            out["extra"]["paths"] = other_paths(urm)
+            out["extra"]["paths"] = other_paths(urm, args)
         except Exception as exc:                       # the headline line must survive a failure in the side measurements
             out["extra"]["paths_error"] = repr(exc)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

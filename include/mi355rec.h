@@ -153,7 +153,9 @@ int mi355rec_sim_column_costs(mi355rec_sim_t h, int64_t *cost /* n_cols */);
  * number of parts they were split into (diagnostics; a heavy column is accumulated by several workgroups). */
 int mi355rec_sim_schedule_info(mi355rec_sim_t h, int32_t *n_items, int32_t *n_split_columns, int32_t *n_parts);
 /* Type of the in-LDS column accumulator this handle's builds use: 0 = uint32 co-occurrence counts (all stored values 1.0, no
- * row_weights), 1 = int64 fixed point (real-valued data whose products, scaled by the power of two *fixed_scale, keep every sum
+ * row_weights), 3 = exact int32 sums (every stored value times 2^s, s <= 3, is a small integer -- star ratings, half stars -- and no
+ * row_weights / mean-centring: the products scaled by *fixed_scale = 4^s are integers; MI355REC_SIM_NO_INT32=1 disables it),
+ * 1 = int64 fixed point (real-valued data whose products, scaled by the power of two *fixed_scale, keep every sum
  * inside 62 bits with a worst-case rounding below 1e-6 of the smallest normalised result), 2 = float64 sums like the reference's
  * double array (Compute_Similarity_Cython.pyx:363; chosen when no such scale exists, or with MI355REC_SIM_F64_SUMS=1 in the
  * environment at create time).  Diagnostics for the parity tests. */

@@ -1,8 +1,8 @@
-"""BM25 / TF-IDF re-weighting of the interaction matrix: the pre-step KNN recommenders may apply before the
-similarity build (Base/IR_feature_weighting.py:13 okapi_BM_25, :55 TF_IDF; called from KNN/ItemKNNCFRecommender.py:40-48
-and KNN/UserKNNCFRecommender.py:40-48).  It is one pass of element-wise float64 arithmetic over the stored cells whose
-result REPLACES the recommender's host-side URM_train (the scorer reads it), so it stays on the host in NumPy exactly as
-in the reference; the similarity build that follows is the device path.  "Documents" are the matrix rows."""
+"""TEST INFRASTRUCTURE ONLY (imported by tests/ alone) -- NumPy restatement of the reference's BM25 / TF-IDF re-weighting of the
+interaction matrix (Base/IR_feature_weighting.py:13 okapi_BM_25, :55 TF_IDF; called from KNN/ItemKNNCFRecommender.py:40-48 and
+KNN/UserKNNCFRecommender.py:40-48), pinned to reference outputs by tests/golden/feature_weighting.npz.  The product runs the
+weighting as a device pre-pass of the similarity constructor (csrc/sim.hip: weighting_stats_kernel / weighting_apply_kernel);
+this file is its checker.  "Documents" are the matrix rows."""
 import numpy as np
 import scipy.sparse as sps
 

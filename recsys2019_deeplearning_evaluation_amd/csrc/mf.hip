@@ -59,6 +59,7 @@ constexpr int LEN_MASK = 0x0fffffff;
 typedef int int8v __attribute__((ext_vector_type(8)));
 // record .w: bits 0-1 role of the task's row in this sample (0 user, 1 item / positive item, 2 negative item),
 //            bit 2 / 3 / 4: buffer of the sample's user / item / negative-item row
+//            bit 5 / 6 (user role, fast schedule): this task also updates the sample's positive / negative item row
 constexpr int ROLE_U = 0, ROLE_I = 1;   // 2: negative item
 
 template <class T> struct MuState { T mu, c1, c2, pad; };
@@ -97,6 +98,7 @@ struct MfParams {
     // schedule
     const TaskHeader *tasks;
     const int4 *recs;
+    const int *used;                     // fast schedule: header slots in use per mini-batch of the stream (NULL: all of them may be)
     unsigned long long *ticks;           // optional [tasks_per_batch][8] shader-clock stamps of the last mini-batch (MI355REC_MF_TICKS=1)
     int wg_base, wg_stride;              // workgroup b of the launch is workgroup wg_base + b * wg_stride of the mini-batch (exact
                                          // multi-GPU mode: rank r of G runs workgroups r, r + G, ...; otherwise 0 and 1)
@@ -194,6 +196,31 @@ __device__ __forceinline__ T adapt(const P &p, T g, T *c1, T *c2, size_t at, T p
     c1[at] = a;
     if (p.sgd_mode == MI355REC_ADAM) c2[at] = b;
     return step;
+}
+
+// The gradient of one sample on one row and the application of a row's summed gradient, with every operation rounded on its own
+// (no fused multiply-add, whatever the surrounding code looks like): the same row may be updated by its own task or by the
+// sample's user task (fused sample tasks), alone or next to other samples in one launch (replica batches), and the result must not
+// depend on which -- the backend contracts a * b - c * d differently from one call site to the next.  This is also how the
+// reference's scalar double code rounds.
+template <class T> __device__ __forceinline__ T grad_term(T scale, T x, T reg, T w) {       // scale * x - reg * w   (.pyx:626-639, 343-352)
+#pragma clang fp contract(off)
+    const T a = scale * x;
+    const T b = reg * w;
+    return a - b;
+}
+template <class T> __device__ __forceinline__ T diff_of(T a, T b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+template <class T> __device__ __forceinline__ T mean_of(T sum, T inv_batch) {
+#pragma clang fp contract(off)
+    return sum * inv_batch;
+}
+template <class T> __device__ __forceinline__ T moved(T w, T lr, T step) {                   // w + lr * step   (.pyx:809-812)
+#pragma clang fp contract(off)
+    const T a = lr * step;
+    return w + a;
 }
 
 // One thread per sample of one epoch (sampleBPR_Cython .pyx:940-985 / sampleMSE_Cython :878-935).
@@ -375,6 +402,7 @@ struct FastSchedParams {
     unsigned char *par;           // [n_entries]: buffer of every row's current version at stream start
     int *sorted_slot;             // [n_batches][tasks_per_batch]: batch-local incidence ids in (row, id) order
     int *qtask;                   // per sorted position: batch-local slot of its task's (first) header | wide << 30
+    int *used;                    // [n_batches]: header slots in use
     TaskHeader *tasks;
     int4 *recs;
 };
@@ -430,8 +458,11 @@ __global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const Fast
     // FUSED SAMPLE TASKS (BPR).  Most rows of a mini-batch are touched by exactly one sample (users nearly always, uniformly drawn
     // negative items mostly): as separate tasks each of them gathers the sample's three rows again -- nine row reads and three
     // wavefronts per sample.  A sample whose USER row is touched once keeps one task (the user's) which also applies the update of
-    // the sample's item rows that are touched once (header word 3: bit 0 positive item, bit 1 negative item); those rows get no
-    // task of their own.  The arithmetic per row is unchanged.  single[q] = incidence q (sample * per + role) is alone in its run.
+    // the sample's item rows that are touched once (record bits 5 / 6: positive / negative item); those rows get no task of their
+    // own.  And `group` such tasks that sit next to each other in the sorted order share one wavefront (PAIR tasks, header word 3 =
+    // 1): its lane groups, which walk a list's samples `group` at a time, each take one of the samples and write that sample's
+    // rows -- a single-sample task leaves all but one lane group of its wavefront idle otherwise.  The arithmetic per row is
+    // unchanged.  single[q] = incidence q (sample * per + role) is alone in its run.
     unsigned char *single = reinterpret_cast<unsigned char *>(tpos + np);
     const unsigned qmask = (1u << sb) - 1u;
     if (s.fuse) {
@@ -446,14 +477,27 @@ __global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const Fast
         const int inc = (int)(K[hpos[t]] & qmask), smp = inc / s.per;
         return inc != smp * s.per && single[smp * s.per];
     };
+    auto lone_user = [&](int q) -> bool {         // sorted position q is the single-sample run of a user row
+        if (q >= m) return false;
+        const unsigned e = K[q] >> sb;
+        return e < (unsigned)s.n_users && (q == 0 || (K[q - 1] >> sb) != e) && (q + 1 == m || (K[q + 1] >> sb) != e);
+    };
+    auto paired = [&](int q) -> bool {            // q lies in an aligned block of `group` positions that are all such runs
+        if (!s.fuse || s.group < 2) return false;
+        const int q0 = q - q % s.group;
+        for (int e = 0; e < s.group; ++e)
+            if (!lone_user(q0 + e)) return false;
+        return true;
+    };
     // header slots: wide tasks first (4 aligned slots each), then the others; both in row order
     const int CT = (total + SCHED_THREADS - 1) / SCHED_THREADS;
     const int t_lo = min(tid * CT, total), t_hi = min(t_lo + CT, total);
     int wcnt = 0, acnt = 0;
     const int wide_min = 2 * s.group;               // longer than two rounds of one wavefront: split over a workgroup
     for (int t = t_lo; t < t_hi; ++t) {
-        wcnt += hpos[t + 1] - hpos[t] > wide_min;
-        acnt += absorbed(t);
+        const int start = hpos[t], len = hpos[t + 1] - start;
+        wcnt += len > wide_min;
+        acnt += absorbed(t) || (len == 1 && start % s.group != 0 && paired(start));      // runs without a header of their own
     }
     int woff = 0, n_wide = 0, aoff = 0, n_abs = 0;
     Scan(scan_tmp).ExclusiveSum(wcnt, woff, n_wide);
@@ -464,8 +508,9 @@ __global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const Fast
         const int start = hpos[t], len = hpos[t + 1] - start;
         const bool wide = len > wide_min;
         const int entry = (int)(K[start] >> sb);
-        atomicOr(&s.touched[(size_t)entry * s.words + (b >> 5)], 1u << (b & 31));      // (absorbed rows advance a version, too)
-        if (absorbed(t)) {
+        atomicOr(&s.touched[(size_t)entry * s.words + (b >> 5)], 1u << (b & 31));      // (rows without a task advance a version, too)
+        const bool pair = len == 1 && paired(start);
+        if (absorbed(t) || (pair && start % s.group != 0)) {
             ++aoff;
             tpos[t] = SLOT_ABSORBED;
             continue;
@@ -473,18 +518,14 @@ __global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const Fast
         const int slot = wide ? 4 * woff : 4 * n_wide + (t - woff - aoff);
         woff += wide;
         tpos[t] = slot | (wide ? META_WIDE : 0);
-        int also = 0;
-        if (s.fuse && len == 1) {
-            const int inc = (int)(K[start] & qmask), smp = inc / s.per;
-            if (inc == smp * s.per) also = (single[inc + 1] ? 1 : 0) | (s.per == 3 && single[inc + 2] ? 2 : 0);
-        }
         for (int part = 0; part < (wide ? 4 : 1); ++part) {
             *reinterpret_cast<int4 *>(out + slot + part) =
-                make_int4(entry, len | (wide ? META_WIDE | (part << 28) : 0), b * s.tasks_per_batch + start, also);
+                make_int4(entry, (pair ? s.group : len) | (wide ? META_WIDE | (part << 28) : 0), b * s.tasks_per_batch + start, pair ? 1 : 0);
             out[slot + part].rec0 = make_int4(0, 0, 0, 0);     // (a short wide list leaves its last quarters without a record)
         }
     }
     const int used = 4 * n_wide + (total - n_wide - n_abs);
+    if (tid == 0) s.used[b] = used;
     for (int slot = used + tid; slot < s.tasks_per_batch; slot += SCHED_THREADS)
         *reinterpret_cast<int4 *>(out + slot) = make_int4(0, 0, 0, 0);          // no samples: the slot's wavefront idles
     __syncthreads();
@@ -494,7 +535,13 @@ __global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const Fast
             const int mid = (lo + hi) >> 1;
             if (hpos[mid] <= q) lo = mid; else hi = mid;
         }
-        s.sorted_slot[(size_t)b * s.tasks_per_batch + q] = (int)(K[q] & ((1u << sb) - 1));
+        const int inc = (int)(K[q] & qmask);
+        int also = 0;                                 // the item rows a once-touched user row's task takes over (bits 16-17 here, 5-6 of the record)
+        if (s.fuse && hpos[lo + 1] - hpos[lo] == 1) {
+            const int smp = inc / s.per;
+            if (inc == smp * s.per) also = (single[inc + 1] ? 1 : 0) | (s.per == 3 && single[inc + 2] ? 2 : 0);
+        }
+        s.sorted_slot[(size_t)b * s.tasks_per_batch + q] = inc | (also << 16);
         s.qtask[(size_t)b * s.tasks_per_batch + q] = tpos[lo];
     }
 }
@@ -513,13 +560,14 @@ __global__ __launch_bounds__(256) void mf_sched_emit_kernel(const FastSchedParam
     const int n_in = (int)min((long long)s.batch_size, s.n_samples - first);
     if (q >= n_in * s.per) return;
     const size_t at = (size_t)b * s.tasks_per_batch + q;
-    const int slot = s.sorted_slot[at];
+    const int slot_word = s.sorted_slot[at];
+    const int slot = slot_word & 0xffff, also = slot_word >> 16;
     const int smp = slot / s.per, role = slot - smp * s.per;
     const long long t = first + smp;
     const int u = s.su[t], i = s.si[t], j = s.per == 3 ? s.sj[t] : 0;
     const int pu = version_parity(s, u, b), pi = version_parity(s, s.n_users + i, b);
     const int pj = s.per == 3 ? version_parity(s, s.n_users + j, b) : 0;
-    const int4 rec = make_int4(u, i, s.per == 3 ? j : __float_as_int(s.sr[t]), role | (pu << 2) | (pi << 3) | (pj << 4));
+    const int4 rec = make_int4(u, i, s.per == 3 ? j : __float_as_int(s.sr[t]), role | (pu << 2) | (pi << 3) | (pj << 4) | (also << 5));
     s.recs[at] = rec;
     const int tp = s.qtask[at];
     if (tp == SLOT_ABSORBED) return;
@@ -704,12 +752,15 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
         // software pipeline: records two list positions ahead of the arithmetic, rows one ahead.  Positions past the
         // end of the list are clamped to the last record (valid addresses) and contribute nothing.
         int4 rec = h1;
-        const int also = BPR ? h0.w : 0;           // fused sample task: bit 0 / 1 = this task also updates the sample's positive / negative item row
+        // PAIR task (fast schedule, BPR): G single-sample user tasks share this wavefront, lane group g has sample g of the "list"
+        // -- its own row to write, nothing to sum across groups
+        const bool pair = BPR && G > 1 && h0.w == 1;
         T sg_first = (T)0;
         if (G > 1 && len > 1) {                    // single-sample tasks (most of them) go straight from the header to the rows
             const int4 r = p.recs[start + min(base + g, len - 1)];
             if (g != 0) rec = r;
         }
+        const int4 rec_first = rec;                // single-sample and pair tasks: THE record of this lane group
         int4 rec_n = rec;
         if (iters > 1) rec_n = p.recs[start + min(base + step + g, len - 1)];
         R rows = load_rows<T, VEC, LPR, KI, BPR>(p, rec, li, cok, bias);
@@ -740,7 +791,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
             for (int c = 0; c < KI; ++c)
 #pragma unroll
                 for (int e = 0; e < VEC; ++e)
-                    dot += BPR ? rows.A[c].v[e] * (rows.B[c].v[e] - rows.C[c].v[e]) : rows.A[c].v[e] * rows.B[c].v[e];
+                    dot += BPR ? rows.A[c].v[e] * diff_of(rows.B[c].v[e], rows.C[c].v[e]) : rows.A[c].v[e] * rows.B[c].v[e];
             dot = group_sum<LPR>(dot);
             if (p.ticks && it == 0) {
                 asm volatile("" ::"v"(dot));
@@ -756,9 +807,9 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         const T a = rows.A[c].v[e], b = rows.B[c].v[e], cc = rows.C[c].v[e];
-                        const T gU = sg * (b - cc) - p.user_reg * a;        // .pyx:626-639
-                        const T gI = sg * a - p.positive_reg * b;
-                        const T gJ = sg * (-a) - p.negative_reg * cc;
+                        const T gU = grad_term(sg, diff_of(b, cc), p.user_reg, a);        // .pyx:626-639
+                        const T gI = grad_term(sg, a, p.positive_reg, b);
+                        const T gJ = grad_term(sg, -a, p.negative_reg, cc);
                         const T gr = role == ROLE_U ? gU : (role == ROLE_I ? gI : gJ);
                         acc[c].v[e] += valid ? gr : (T)0;
                         if (it == 0) own[c].v[e] = role == ROLE_U ? a : (role == ROLE_I ? b : cc);
@@ -779,8 +830,8 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
                     for (int e = 0; e < VEC; ++e) {
                         const T a = rows.A[c].v[e], b = rows.B[c].v[e];
                         // NB the item gradient is regularised with positive_reg (sic, .pyx:346), never item_reg
-                        const T gU = err * b - p.user_reg * a;
-                        const T gI = err * a - p.positive_reg * b;
+                        const T gU = grad_term(err, b, p.user_reg, a);
+                        const T gI = grad_term(err, a, p.positive_reg, b);
                         const T gr = role == ROLE_U ? gU : gI;
                         acc[c].v[e] += valid ? gr : (T)0;
                         if (it == 0) own[c].v[e] = role == ROLE_U ? a : b;
@@ -791,7 +842,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
             rows = rows_n;
         }
         // totals over the groups, in a fixed order
-        if (G > 1) {
+        if (G > 1 && !pair) {
 #pragma unroll
             for (int c = 0; c < KI; ++c)
 #pragma unroll
@@ -827,10 +878,12 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
             }
         }
         // _apply_minibatch_updates_to_latent_factors (.pyx:770-829): mean over batch_size (NOT over the row's count)
-        if (g == 0 && (!wide || part == 0)) {
-            const bool is_item = entry >= p.n_users;
-            const int row = is_item ? entry - p.n_users : entry;
-            T *Wn = (is_item ? (own_par ? p.V0 : p.V1) : (own_par ? p.U0 : p.U1)) + (size_t)row * k;
+        if ((g == 0 || pair) && (!wide || part == 0)) {
+            const int own_entry = pair ? rec_first.x : entry;                       // (a pair task's rows are user rows)
+            const int own_buf = pair ? (rec_first.w >> 2) & 1 : own_par;
+            const bool is_item = own_entry >= p.n_users;
+            const int row = is_item ? own_entry - p.n_users : own_entry;
+            T *Wn = (is_item ? (own_buf ? p.V0 : p.V1) : (own_buf ? p.U0 : p.U1)) + (size_t)row * k;
             T *c1 = (is_item ? p.c1V : p.c1U) + (size_t)row * k, *c2 = (is_item ? p.c2V : p.c2U) + (size_t)row * k;
 #pragma unroll
             for (int c = 0; c < KI; ++c) {
@@ -841,32 +894,34 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
                 if (p.sgd_mode == MI355REC_ADAM) m2 = *reinterpret_cast<const Ch *>(c2 + at);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    const T gm = acc[c].v[e] * p.inv_batch;
+                    const T gm = mean_of(acc[c].v[e], p.inv_batch);
                     const T step = adapt_cell(p, gm, m1.v[e], m2.v[e], pw1, pw2);
-                    out.v[e] = own[c].v[e] + p.lr * step;
+                    out.v[e] = moved(own[c].v[e], p.lr, step);
                 }
                 *reinterpret_cast<Ch *>(Wn + at) = out;
                 if (p.sgd_mode != MI355REC_SGD) *reinterpret_cast<Ch *>(c1 + at) = m1;
                 if (p.sgd_mode == MI355REC_ADAM) *reinterpret_cast<Ch *>(c2 + at) = m2;
             }
             if (bias && li == 0) {
-                T *bn = is_item ? (own_par ? p.bi0 : p.bi1) : (own_par ? p.bu0 : p.bu1);
+                T *bn = is_item ? (own_buf ? p.bi0 : p.bi1) : (own_buf ? p.bu0 : p.bu1);
                 T *b1 = is_item ? p.c1_bi : p.c1_bu, *b2 = is_item ? p.c2_bi : p.c2_bu;
                 const T step = adapt(p, bias_acc * p.inv_batch, b1, b2, (size_t)row, pw1, pw2);
                 bn[row] = own_bias + p.lr * step;
             }
         }
+        const int also = BPR && (len == 1 || pair) ? (rec_first.w >> 5) & 3 : 0;
         if (BPR && also) {
             // The item rows this single-sample user task took over (mf_sched_sort_kernel): the arithmetic their own tasks would
-            // have done -- gradient of one sample, mean over batch_size, optimiser, one store of the next row version.  Every
-            // group of the wavefront holds the same record, rows and sigmoid (positions past the end of the list are clamped
-            // to the last record), so the rows are dealt to the groups: row e (1 positive, 2 negative item) to group e % G.
-            // (`rows` still holds the first record's rows: a single-sample list runs one iteration and loads nothing else)
+            // have done -- gradient of one sample, mean over batch_size, optimiser, one store of the next row version.  In a
+            // single task every group of the wavefront holds the same record, rows and sigmoid (positions past the end of the
+            // list are clamped to the last record), so the rows are dealt to the groups: row e (1 positive, 2 negative item) to
+            // group e % G; in a pair task every group looks after its own sample.
+            // (`rows` still holds the first record's rows: these lists run one iteration and load nothing else)
 #pragma unroll
             for (int e = 1; e <= 2; ++e) {
-                if (!(also & e) || g != e % G) continue;
-                const int item = e == 1 ? h1.y : h1.z;
-                const int cur = (h1.w >> (e == 1 ? 3 : 4)) & 1;               // buffer of the version just read
+                if (!(also & e) || !(pair || g == e % G)) continue;
+                const int item = e == 1 ? rec_first.y : rec_first.z;
+                const int cur = (rec_first.w >> (e == 1 ? 3 : 4)) & 1;               // buffer of the version just read
                 T *Wn = (cur ? p.V0 : p.V1) + (size_t)item * k;
                 T *c1 = p.c1V + (size_t)item * k, *c2 = p.c2V + (size_t)item * k;
 #pragma unroll
@@ -879,10 +934,10 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         const T a = rows.A[c].v[v], b = rows.B[c].v[v], cc = rows.C[c].v[v];
-                        const T gr = e == 1 ? sg_first * a - p.positive_reg * b : sg_first * (-a) - p.negative_reg * cc;   // .pyx:632-639
-                        const T gm = ((T)0 + gr) * p.inv_batch;
+                        const T gr = e == 1 ? grad_term(sg_first, a, p.positive_reg, b) : grad_term(sg_first, -a, p.negative_reg, cc);   // .pyx:632-639
+                        const T gm = mean_of((T)0 + gr, p.inv_batch);
                         const T step = adapt_cell(p, gm, m1.v[v], m2.v[v], pw1, pw2);
-                        out.v[v] = (e == 1 ? b : cc) + p.lr * step;
+                        out.v[v] = moved(e == 1 ? b : cc, p.lr, step);
                     }
                     *reinterpret_cast<Ch *>(Wn + at) = out;
                     if (p.sgd_mode != MI355REC_SGD) *reinterpret_cast<Ch *>(c1 + at) = m1;
@@ -932,14 +987,28 @@ template <class T> __device__ __forceinline__ void globalize(MfParams<T> &p) {
     p.c1_bu = as_global(p.c1_bu); p.c2_bu = as_global(p.c2_bu); p.c1_bi = as_global(p.c1_bi); p.c2_bi = as_global(p.c2_bi);
     p.mu_state = as_global(p.mu_state); p.mu_acc = as_global(p.mu_acc);
     p.loss_slots = as_global(p.loss_slots); p.state = as_global(p.state);
-    p.tasks = as_global(p.tasks); p.recs = as_global(p.recs); p.ticks = as_global(p.ticks);
+    p.tasks = as_global(p.tasks); p.recs = as_global(p.recs); p.ticks = as_global(p.ticks); p.used = as_global(p.used);
 }
 
 template <int ALGO, class T, int VEC, int LPR, int KI>
 __global__ __launch_bounds__(256) void mf_group_batch_kernel(const MfParams<T> *__restrict__ table, const int batch_local) {
     MfParams<T> p = table[blockIdx.y];
     globalize(p);
-    mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, blockIdx.x);
+    // the grid covers a third of a mini-batch's header slots; with fused / paired tasks fewer than that are in use as a rule
+    // (the in-LDS schedule files the count), and a workgroup that finds more walks on: no wavefront is launched for an empty slot
+    const int used = p.used ? p.used[batch_local] : p.tasks_per_batch;
+    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg);
+}
+// the same with the register budget of 8 wavefronts per SIMD (64 VGPRs): a group launch is bound by the number of row gathers in
+// flight, i.e. by resident wavefronts
+template <int ALGO, class T, int VEC, int LPR, int KI>
+__global__ __launch_bounds__(256, 8) void mf_group_batch_kernel_occ8(const MfParams<T> *__restrict__ table, const int batch_local) {
+    MfParams<T> p = table[blockIdx.y];
+    globalize(p);
+    // the grid covers a third of a mini-batch's header slots; with fused / paired tasks fewer than that are in use as a rule
+    // (the in-LDS schedule files the count), and a workgroup that finds more walks on: no wavefront is launched for an empty slot
+    const int used = p.used ? p.used[batch_local] : p.tasks_per_batch;
+    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg);
 }
 
 // Any k (odd k, k > 64 lanes x 2 chunks): one task per wavefront, one sample at a time, rows re-read for the update.
@@ -1226,7 +1295,7 @@ struct mi355rec_mf {
     DeviceBuffer<unsigned char> spar, cub_tmp;
     DeviceBuffer<TaskHeader> tasks;
     DeviceBuffer<unsigned> touched;         // fast schedule: (row, mini-batch) bitmap
-    DeviceBuffer<int> sorted_slot, qtask;
+    DeviceBuffer<int> sorted_slot, qtask, used;
     bool fast_schedule = false;
     DeviceBuffer<unsigned long long> ticks;
     DeviceBuffer<int4> recs;
@@ -1273,6 +1342,8 @@ long long batches_per_epoch(const mi355rec_mf *h) {
 
 template <class T> T *as(const DeviceBuffer<unsigned char> &b) { return reinterpret_cast<T *>(b.ptr); }
 
+bool fast_schedule_fits(const mi355rec_mf *h, long long n_batches);
+
 template <class T>
 void fill_params(mi355rec_mf *h, MfParams<T> &p) {
     const auto &c = h->cfg;
@@ -1302,6 +1373,8 @@ void fill_params(mi355rec_mf *h, MfParams<T> &p) {
     p.su = h->su.ptr; p.si = h->si.ptr; p.sj = h->sj.ptr; p.sr = h->sr.ptr;
     p.samples_per_epoch = batches_per_epoch(h) * (long long)c.batch_size;
     p.tasks = h->tasks.ptr; p.recs = h->recs.ptr;
+    // (only the replica-batched launch sizes its grid below the slot count; it runs whole epochs, i.e. batches_per_epoch mini-batches)
+    p.used = h->fast_schedule && fast_schedule_fits(h, batches_per_epoch(h)) ? h->used.ptr : nullptr;
     p.ticks = h->ticks.ptr;
     p.wg_base = 0;
     p.wg_stride = 1;
@@ -1340,6 +1413,14 @@ int kernel_class(const mi355rec_mf *h) {
 
 template <int ALGO, class T, int VEC, int LPR, int KI>
 void launch_group_as(hipStream_t s, const MfParams<T> *table, dim3 grid, int batch_local, hipEvent_t e0, hipEvent_t e1) {
+    static const bool occ8 = getenv("MI355REC_MF_GROUP_OCC8") != nullptr;
+    if constexpr (ALGO == MI355REC_MF_BPR && sizeof(T) == 4 && KI == 1) {
+        if (occ8) {
+            if (e0) hipExtLaunchKernelGGL((mf_group_batch_kernel_occ8<ALGO, T, VEC, LPR, KI>), grid, dim3(256), 0, s, e0, e1, 0, table, batch_local);
+            else hipLaunchKernelGGL((mf_group_batch_kernel_occ8<ALGO, T, VEC, LPR, KI>), grid, dim3(256), 0, s, table, batch_local);
+            return;
+        }
+    }
     if (e0) hipExtLaunchKernelGGL((mf_group_batch_kernel<ALGO, T, VEC, LPR, KI>), grid, dim3(256), 0, s, e0, e1, 0, table, batch_local);
     else hipLaunchKernelGGL((mf_group_batch_kernel<ALGO, T, VEC, LPR, KI>), grid, dim3(256), 0, s, table, batch_local);
 }
@@ -1403,7 +1484,7 @@ void enqueue_fast_schedule(mi355rec_mf *h, long long n_samples, long long n_batc
     f.group = samples_in_flight(h);
     f.su = h->su.ptr; f.si = h->si.ptr; f.sj = h->sj.ptr; f.sr = h->sr.ptr;
     f.touched = h->touched.ptr; f.par = h->par.ptr;
-    f.sorted_slot = h->sorted_slot.ptr; f.qtask = h->qtask.ptr;
+    f.sorted_slot = h->sorted_slot.ptr; f.qtask = h->qtask.ptr; f.used = h->used.ptr;
     f.tasks = h->tasks.ptr; f.recs = h->recs.ptr;
     // fused sample tasks: BPR only; not in the exact multi-GPU mode, whose exchange slabs hold one row per task slot
     f.fuse = h->cfg.algorithm == MI355REC_MF_BPR && h->shard_rank < 0 && !getenv("MI355REC_MF_NO_FUSE");
@@ -1572,6 +1653,7 @@ void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batche
         if (h->fast_schedule) {
             h->sorted_slot.alloc((size_t)n_batches * tpb);
             h->qtask.alloc((size_t)n_batches * tpb);
+            h->used.alloc((size_t)n_batches);
             if (!h->touched.ptr) h->touched.alloc_zero(((size_t)h->n_users + h->n_items) * (FAST_MAX_BATCHES / 32), h->stream);
         }
         h->batch_capacity = n_batches;
@@ -1966,7 +2048,8 @@ void group_enqueue_epoch(mi355rec_mf_group *g, bool timed) {
         MI_HIP(hipStreamWaitEvent(g->stream, g->join[m], 0));
     }
     const MfParams<T> *table = reinterpret_cast<const MfParams<T> *>(g->table.ptr);
-    const int wgs = div_up(g->tasks_per_batch, 4), R = (int)g->members.size();
+    // a third of the slots' workgroups: the kernel loops over the slots in use (all of them when a member is on the general schedule)
+    const int wgs = div_up(div_up(g->tasks_per_batch, 4), 3), R = (int)g->members.size();
     for (long long b = 0; b < nb; ++b) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timed) g->dispatch_timers.next(e0, e1, g->max_timed);

@@ -55,6 +55,7 @@ struct SimParams {
     const int2 *item_range;   // per work item: the column's [begin, end) in the CSC arrays (saves a dependent round trip per column)
     int n_items, start_col;
     const int *out_slot;    // interleaved parts: output row of every column of the call (NULL: column - start_col)
+    float int_scale, int_inv;   // ACC_INT32: 4^s (both factors of a product carry 2^s) and its inverse
     double fixed_scale;     // real-valued data: > 0 = the accumulator holds int64 fixed-point sums, products scaled by this power of two
     double fixed_inv;       //                   (1 / fixed_scale); 0 = float64 sums
     uint32_t *part_buf;     // [part slots][n_cols_pad] partial accumulators of split columns
@@ -98,9 +99,17 @@ constexpr double FIXED_MAGIC = 6755399441055744.0;
 constexpr long long FIXED_MAGIC_BITS = 0x4338000000000000ll;
 
 // THREADS: workgroup size; G: lanes that cooperate on one user profile (sub-wave group);
-// UNIT: all stored values are 1.0 (implicit / set-based data) -> the value arrays are never read.
-template <int THREADS, int G, bool UNIT>
+// MODE: what the accumulator cells hold.
+//   ACC_COUNTS  all stored values are 1.0 (implicit / set-based data): uint32 co-occurrence counts, the value arrays are never read;
+//   ACC_INT32   every stored value is a small multiple of a power of two (star ratings, half stars): the products, scaled by that
+//               power of two squared, are small integers and their sums are EXACT in an int32 cell -- ds_add_u32 at the speed of the
+//               counts, and one accumulator tile where 8-byte cells need two (26 744 columns at ML-20M shape);
+//   ACC_WIDE    any other real-valued data (or row weights): int64 fixed-point or float64 sums in 8-byte cells.
+enum { ACC_COUNTS = 0, ACC_INT32 = 1, ACC_WIDE = 2 };
+template <int THREADS, int G, int MODE>
 __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) {
+    constexpr bool UNIT = MODE == ACC_COUNTS;        // no values
+    constexpr bool CELL32 = MODE != ACC_WIDE;        // 4-byte integer cells
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *acc = smem;
     uint32_t *aux = reinterpret_cast<uint32_t *>(smem + p.acc_words);
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                 rs = sp[0];
                 re = sp[1];
                 r = cv;
-                if (!UNIT && p.row_w) r *= p.row_w[u];
+                if (MODE == ACC_WIDE && p.row_w) r *= p.row_w[u];
             }
         };
         int u_first = 0, u_next = 0, t_rs = 0, t_re = 0;
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         unsigned *acc_u = reinterpret_cast<unsigned *>(acc);
         double *acc_d = reinterpret_cast<double *>(acc);
         unsigned long long *acc_q = reinterpret_cast<unsigned long long *>(acc);
-        const bool fixed_point = !UNIT && p.fixed_scale > 0.0;
+        const bool fixed_point = MODE == ACC_WIDE && p.fixed_scale > 0.0;
         const uint4 *idx8 = reinterpret_cast<const uint4 *>(p.seg_idx16);
         const float4 *val4 = reinterpret_cast<const float4 *>(p.seg_val);
         int *tab = reinterpret_cast<int *>(aux) + wave * 192;       // [64] x {rs, re, weight}
@@ -304,7 +313,15 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                     const unsigned ww[4] = {ids[d].x, ids[d].y, ids[d].z, ids[d].w};
                     const float vv[8] = {vlo[d].x, vlo[d].y, vlo[d].z, vlo[d].w, vhi[d].x, vhi[d].y, vhi[d].z, vhi[d].w};
                     const double rd = (double)c_r[d];
-                    if (!UNIT && fixed_point) {
+                    if (MODE == ACC_INT32) {
+                        // (column value * 2^s) * (row value * 2^s): integers below 2^24, exact in float32, then an integer add
+                        const float rs = c_r[d] * p.int_scale;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const unsigned j = (e & 1) ? (ww[e >> 1] >> 16) : (ww[e >> 1] & 0xFFFFu);
+                            atomicAdd(&acc_u[j], (unsigned)__float2int_rn(rs * vv[e]));
+                        }
+                    } else if (MODE == ACC_WIDE && fixed_point) {
                         const double rs = rd * p.fixed_scale;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         mark(1);
         if (tid == 0 && tile == 0) nx_slot = (int)atomicAdd(p.queue, 1u);       // next work item: requested now, looked at later
         if (item.z > 1) {
-            const int pub_words = UNIT ? p.n_cols_pad : 2 * p.n_cols_pad;
+            const int pub_words = CELL32 ? p.n_cols_pad : 2 * p.n_cols_pad;
             // Split column: publish this part's accumulator; the workgroup that arrives last adds the parts up (in
             // part order, so the float result does not depend on arrival order) and carries on with the column.
             // Nobody waits for anybody.
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                 uint4 a = src[w];
                 for (int q = 1; q < item.z; ++q) {
                     const uint4 b = src[q * stride4 + w];
-                    if (UNIT) {
+                    if (CELL32) {
                         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
                     } else if (p.fixed_scale > 0.0) {   // two int64 cells
                         const unsigned long long a0 = (((unsigned long long)a.y << 32) | a.x) + (((unsigned long long)b.y << 32) | b.x);
@@ -390,7 +407,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         }
         // the diagonal was accumulated like any other cell: clear it (the reference never adds to it, .pyx:392)
         if (tid == 0 && c >= tile_base && c < tile_base + n_tile) {
-            if (UNIT) acc[c - tile_base] = 0.f;
+            if (CELL32) acc[c - tile_base] = 0.f;
             else acc_d[c - tile_base] = 0.0;
         }
         __syncthreads();
@@ -413,7 +430,9 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                     kmax = max(kmax, key);
                 }
             };
-            if (UNIT) {
+            if (CELL32) {
+                // counts, or exact integer sums of products scaled by int_scale (a power of four)
+                auto cell_value = [&](unsigned q) { return UNIT ? (float)q : (float)(int)q * p.int_inv; };
                 const float4 *nj4 = reinterpret_cast<const float4 *>(nj);
                 float4 *a4 = reinterpret_cast<float4 *>(acc);
                 const int n_quads = p.n_cols_pad / 4;
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                         const uint4 qu = reinterpret_cast<const uint4 *>(acc)[w];
                         const float4 n4 = nj4[w];
                         const float4 s4 = reinterpret_cast<const float4 *>(sqj)[w];
-                        float vv[4] = {(float)qu.x, (float)qu.y, (float)qu.z, (float)qu.w};
+                        float vv[4] = {cell_value(qu.x), cell_value(qu.y), cell_value(qu.z), cell_value(qu.w)};
                         const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
                         const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
@@ -440,10 +459,11 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                     // quads are requested up front instead (8 steps cover MAX_TILE / 4 / 1024; 512-thread tiles are narrower).
                     constexpr int NPF = 8;
                     float4 npf[NPF];
+                    const int n_quads_valid = (n_tile + 3) >> 2;          // (the last tile is narrower than the accumulator: the norm arrays end with it)
 #pragma unroll
                     for (int i = 0; i < NPF; ++i) {
                         const int w = tid + i * THREADS;
-                        npf[i] = nj4[w < n_quads ? w : 0];
+                        npf[i] = nj4[w < n_quads_valid ? w : 0];
                     }
 #pragma unroll
                     for (int i = 0; i < NPF; ++i) {
@@ -451,7 +471,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                         if (w < n_quads) {
                             const uint4 qu = reinterpret_cast<const uint4 *>(acc)[w];
                             if ((qu.x | qu.y | qu.z | qu.w) != 0u) {
-                                float vv[4] = {(float)qu.x, (float)qu.y, (float)qu.z, (float)qu.w};
+                                float vv[4] = {cell_value(qu.x), cell_value(qu.y), cell_value(qu.z), cell_value(qu.w)};
                                 const float nn[4] = {npf[i].x, npf[i].y, npf[i].z, npf[i].w};
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
@@ -586,6 +606,22 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
 }
 
 // ---------------------------------------- set-up kernels -------------------------------------------
+
+// Which of the scales 2^0 .. 2^3 turn every value into an integer (bit s of out[0] is SET when one does not), and max |value|.
+__global__ void value_grid_kernel(const float *x, size_t n, unsigned *out) {
+    unsigned bad = 0, top = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        top = max(top, __float_as_uint(fabsf(v)));
+#pragma unroll
+        for (int sh = 0; sh <= 3; ++sh) {
+            const float t = v * (float)(1 << sh);
+            if (!(t == rintf(t))) bad |= 1u << sh;       // (NaN / inf never qualify)
+        }
+    }
+    if (bad) atomicOr(&out[0], bad);
+    atomicMax(&out[1], top);
+}
 
 __global__ void fill_kernel(float *x, size_t n, float v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = v;
@@ -929,6 +965,8 @@ struct mi355rec_sim {
     std::vector<int> cost_order;   // all columns, most expensive first
     int group_lanes = 64;
     double fixed_scale = 0.0;      // real-valued data: power-of-two scale of the int64 fixed-point accumulator (0: float64 sums)
+    int int_shift = -1;            // >= 0: every stored value times 2^int_shift is a small integer -> exact int32 sums (ACC_INT32)
+    int acc_mode() const { return unit_values && !row_w.ptr ? ACC_COUNTS : (int_shift >= 0 ? ACC_INT32 : ACC_WIDE); }
     mi355rec_stats stats{};
     // last call
     int last_start = -1, last_end = -1;
@@ -945,14 +983,14 @@ namespace {
 
 template <int THREADS, int G>
 void launch_sim(mi355rec_sim *h, const SimParams &p, int grid, size_t lds) {
-    if (h->unit_values && !h->row_w.ptr) {
-        auto k = sim_column_kernel<THREADS, G, true>;
+    auto go = [&](auto k) {
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipExtLaunchKernelGGL(k, dim3(grid), dim3(THREADS), (unsigned)lds, h->stream, h->timer.t0, h->timer.t1, 0, p);
-    } else {
-        auto k = sim_column_kernel<THREADS, G, false>;
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipExtLaunchKernelGGL(k, dim3(grid), dim3(THREADS), (unsigned)lds, h->stream, h->timer.t0, h->timer.t1, 0, p);
+    };
+    switch (h->acc_mode()) {
+        case ACC_COUNTS: go(sim_column_kernel<THREADS, G, ACC_COUNTS>); break;
+        case ACC_INT32: go(sim_column_kernel<THREADS, G, ACC_INT32>); break;
+        default: go(sim_column_kernel<THREADS, G, ACC_WIDE>); break;
     }
     MI_HIP(hipGetLastError());
 }
@@ -1001,7 +1039,7 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
         end = h->n_cols;
     }
     auto in_call = [&](int c) { return n_parts > 0 ? slot_host[c] >= 0 : (c >= start && c < end); };
-    const bool unit_kernel = h->unit_values && !h->row_w.ptr;
+    const bool unit_kernel = h->acc_mode() != ACC_WIDE;          // 4-byte cells
     const int acc_words = (h->tile_w + 4) * (unit_kernel ? 1 : 2);
     const size_t lds = (size_t)acc_words * 4 + (size_t)AUX_WORDS * 4;
     const int cus = multiprocessor_count();
@@ -1116,6 +1154,8 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
         p.phase_ticks = h->phase_ticks.ptr;
     }
     p.fixed_scale = unit_kernel ? 0.0 : h->fixed_scale;
+    p.int_scale = h->int_shift >= 0 ? (float)(1 << (2 * h->int_shift)) : 1.f;
+    p.int_inv = 1.f / p.int_scale;
     p.fixed_inv = p.fixed_scale > 0.0 ? 1.0 / p.fixed_scale : 0.0;
     p.start_col = start;
     p.out_slot = nullptr;
@@ -1243,9 +1283,31 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
             MI_HIP(hipStreamSynchronize(s));
             h->unit_values = (nu == 0);
         }
-        // accumulator tiling: the LDS holds MAX_TILE count cells (MAX_TILE_F64 float64 cells for real-valued data or row
-        // weights) next to the 32 KiB selection scratch
-        const int max_tile = (h->unit_values && !row_weights) ? MAX_TILE : MAX_TILE_F64;
+        // Quantised values (star ratings, half stars, counts): if every stored value times 2^s (s <= 3) is an integer of at most
+        // 2048 and n_rows products of that size cannot overflow an int32, the column sums are exact integers (ACC_INT32).  Not for
+        // mean-centred data (adjusted / pearson centre the values later) nor with row weights.
+        if (!h->unit_values && !row_weights && cfg->similarity != MI355REC_SIM_ADJUSTED && cfg->similarity != MI355REC_SIM_PEARSON &&
+            !getenv("MI355REC_SIM_F64_SUMS") && !getenv("MI355REC_SIM_NO_INT32")) {
+            DeviceBuffer<unsigned> grid_info;          // [0] bit s set: some value times 2^s is not an integer; [1] bits of max |value|
+            grid_info.alloc_zero(2, s);
+            hipLaunchKernelGGL(value_grid_kernel, dim3(eg), dim3(eb), 0, s, h->csr_val.ptr, nnz, grid_info.ptr);
+            MI_HIP(hipGetLastError());
+            unsigned info[2] = {0xFu, 0u};
+            grid_info.download(info, 2, s);
+            MI_HIP(hipStreamSynchronize(s));
+            float vmax_f;
+            memcpy(&vmax_f, &info[1], sizeof(float));
+            for (int sh = 0; sh <= 3; ++sh) {
+                const double m = (double)vmax_f * (double)(1 << sh);
+                if (!((info[0] >> sh) & 1u) && m <= 2048.0 && (double)n_rows * m * m < 2147483648.0) {
+                    h->int_shift = sh;
+                    break;
+                }
+            }
+        }
+        // accumulator tiling: the LDS holds MAX_TILE 4-byte cells (counts, exact integer sums) or MAX_TILE_F64 8-byte cells (other
+        // real-valued data, row weights) next to the 32 KiB selection scratch
+        const int max_tile = h->acc_mode() != ACC_WIDE ? MAX_TILE : MAX_TILE_F64;
         h->tile_w = n_cols <= max_tile ? ((n_cols + 3) & ~3) : max_tile;
         h->n_tiles = (n_cols + h->tile_w - 1) / h->tile_w;
         if ((long long)h->n_tiles * h->cfg.topK > h->tile_w)
@@ -1349,7 +1411,7 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         // A cell is then off by at most N / 2 units of 2^-S; the smallest denominator it can meet is the smallest non-zero
         // column norm squared (normalised similarities) -- accept when that WORST-CASE error stays below 1e-6 (a tenth of the
         // parity bar; rounding errors of random sign add up to ~sqrt(N), not N), otherwise keep float64.
-        if (!(h->unit_values && !row_weights) && !getenv("MI355REC_SIM_F64_SUMS")) {
+        if (h->acc_mode() == ACC_WIDE && !getenv("MI355REC_SIM_F64_SUMS")) {
             DeviceBuffer<unsigned> d_vmax;
             d_vmax.alloc_zero(1, s);
             hipLaunchKernelGGL(absmax_kernel, dim3(eg), dim3(eb), 0, s, h->csc_val.ptr, nnz, d_vmax.ptr);
@@ -1394,7 +1456,7 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         // each lane covers 8 profile entries per load: G lanes span 8*G entries
         h->group_lanes = weighted_len >= 1024 ? 64 : (weighted_len >= 320 ? 32 : 16);
         // the float64 kernel has half the loads in flight per lane (DEPTH 2): narrower groups keep more profiles going
-        if (!(h->unit_values && !row_weights)) h->group_lanes = weighted_len >= 2048 ? 64 : (weighted_len >= 640 ? 32 : 16);
+        if (h->acc_mode() != ACC_COUNTS) h->group_lanes = weighted_len >= 2048 ? 64 : (weighted_len >= 640 ? 32 : 16);
         if (getenv("MI355REC_SIM_G")) h->group_lanes = atoi(getenv("MI355REC_SIM_G"));
         *out = h.release();
     });
@@ -1566,9 +1628,9 @@ extern "C" int mi355rec_sim_schedule_info(mi355rec_sim_t h, int32_t *n_items, in
 extern "C" int mi355rec_sim_accumulator_info(mi355rec_sim_t h, int32_t *kind, double *fixed_scale) {
     return guarded([&] {
         MI_REQUIRE(h && kind && fixed_scale, "NULL argument");
-        const bool unit_kernel = h->unit_values && !h->row_w.ptr;
-        *kind = unit_kernel ? 0 : (h->fixed_scale > 0.0 ? 1 : 2);
-        *fixed_scale = unit_kernel ? 0.0 : h->fixed_scale;
+        const int mode = h->acc_mode();
+        *kind = mode == ACC_COUNTS ? 0 : (mode == ACC_INT32 ? 3 : (h->fixed_scale > 0.0 ? 1 : 2));
+        *fixed_scale = mode == ACC_COUNTS ? 0.0 : (mode == ACC_INT32 ? (double)(1 << (2 * h->int_shift)) : h->fixed_scale);
     });
 }
 

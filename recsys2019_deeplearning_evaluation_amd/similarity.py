@@ -146,10 +146,10 @@ class Compute_Similarity_MI355X:
         return a.value, b.value, c.value
 
     def accumulator_info(self):
-        """("uint32" | "int64-fixed" | "float64", fixed-point scale): type of the in-LDS column accumulator (diagnostics)."""
+        """("uint32" | "int64-fixed" | "float64" | "int32-exact", scale): type of the in-LDS column accumulator (diagnostics)."""
         kind, scale = C.c_int32(), C.c_double()
         N.check(self._lib.mi355rec_sim_accumulator_info(self._h, C.byref(kind), C.byref(scale)))
-        return ("uint32", "int64-fixed", "float64")[kind.value], scale.value
+        return ("uint32", "int64-fixed", "float64", "int32-exact")[kind.value], scale.value
 
     def stats(self):
         st = N.Stats()
@@ -186,7 +186,8 @@ class Compute_Similarity_Euclidean_MI355X(Compute_Similarity_MI355X):
     runs on square inputs."""
 
     def __init__(self, dataMatrix, topK=100, shrink=0, normalize=False, normalize_avg_row=False,
-                 similarity_from_distance_mode="lin", row_weights=None, **args):
+                 similarity_from_distance_mode="lin", row_weights=None, feature_weighting="none", weighting_documents="columns",
+                 K1=1.2, B=0.75, **args):
         if similarity_from_distance_mode not in N.EUCLIDEAN_MODE_CODES:
             raise ValueError("Compute_Similarity_Euclidean: value for parameter 'mode' not recognized."
                              " Allowed values are: 'exp', 'lin', 'log'."
@@ -196,7 +197,10 @@ class Compute_Similarity_Euclidean_MI355X(Compute_Similarity_MI355X):
                              "row_weights has {} rows, dataMatrix has {}.".format(len(row_weights), dataMatrix.shape[0]))
         super().__init__(dataMatrix, topK=topK, shrink=shrink, normalize=normalize, similarity="euclidean",
                          row_weights=row_weights, normalize_avg_row=normalize_avg_row,
-                         similarity_from_distance_mode=similarity_from_distance_mode)
+                         similarity_from_distance_mode=similarity_from_distance_mode,
+                         # the KNN recommenders' BM25 / TF-IDF pre-pass runs before the Euclidean set-up like before any other
+                         # build (run_parameter_search.py:219-239 searches feature_weighting for euclidean, too)
+                         feature_weighting=feature_weighting, weighting_documents=weighting_documents, K1=K1, B=B)
 
 
 class Compute_Similarity:

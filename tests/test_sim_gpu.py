@@ -287,7 +287,7 @@ def test_knn_with_feature_weighting(gpu, weighting, user_based):
     the reference (ItemKNNCFRecommender.py:40-48): checked against the NumPy restatement of Base/IR_feature_weighting.py (itself
     checked against reference outputs in tests/test_host_logic.py), then the build against the oracle on that matrix."""
     from recsys2019_deeplearning_evaluation_amd import UserKNNCFRecommender
-    from recsys2019_deeplearning_evaluation_amd.feature_weighting import apply_feature_weighting
+    from oracle.feature_weighting import apply_feature_weighting
     X = named_urm("ml1m", "real", scale=0.15)
     rec = (UserKNNCFRecommender if user_based else ItemKNNCFRecommender)(X, verbose=False)
     rec.fit(topK=20, shrink=5, similarity="cosine", feature_weighting=weighting)
@@ -524,3 +524,63 @@ def test_fixed_point_bound_rejects_wide_dynamic_range(gpu, monkeypatch):
     for c in range(0, Y.shape[1], 3):
         check_topk_against_dense(idx[c], val[c], orc.column(c)[0], 30, RTOL)
     dev.close()
+
+
+@pytest.mark.parametrize("weighting", ["BM25", "TF-IDF"])
+def test_knn_euclidean_with_feature_weighting(gpu, weighting):
+    """similarity="euclidean" must accept the KNN recommenders' feature weighting like every other similarity
+    (run_parameter_search.py:219-239 searches the combination): the weighted matrix replaces URM_train and the build runs on it."""
+    from oracle.feature_weighting import apply_feature_weighting
+    X = named_urm("ml1m", "real", scale=0.1)
+    X.data = np.round(X.data)
+    rec = ItemKNNCFRecommender(X.copy(), verbose=False)
+    rec.fit(topK=12, shrink=1, similarity="euclidean", normalize=False, feature_weighting=weighting, similarity_from_distance_mode="lin")
+    want_urm = apply_feature_weighting(X, weighting, False)
+    np.testing.assert_allclose(rec.URM_train.toarray(), want_urm.toarray(), rtol=RTOL, atol=1e-7)
+    want = O.OracleSimilarityEuclidean(rec.URM_train, topK=12, shrink=1, normalize=False, similarity_from_distance_mode="lin").dense()
+    W = rec.W_sparse.toarray()
+    assert ((W != 0).sum(axis=0) == 12).all()
+    assert np.abs(W[W != 0] - want[W != 0]).max() < 1e-4 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("step,similarity", [(1.0, "cosine"), (0.5, "cosine"), (0.25, "asymmetric"), (1.0, "euclidean")])
+def test_quantised_ratings_use_exact_int32_sums(gpu, step, similarity, monkeypatch):
+    """Star / half-star ratings: every product is an integer multiple of step^2, the column sums are exact in int32 cells
+    (accumulator "int32-exact", one LDS tile where 8-byte cells need two at ML-20M width) -- same result as the 8-byte-cell
+    kernel and as the oracle; jittered ratings, row_weights and mean-centred similarities stay on the wide cells."""
+    monkeypatch.delenv("MI355REC_SIM_F64_SUMS", raising=False)
+    X = synthetic_urm(2500, 18000, 260000, 5, 700, seed=31, values="real")       # 18 000 columns: one 4-byte tile, two 8-byte tiles
+    X.data = (np.maximum(1, np.round(X.data / step)) * step).astype(np.float32)
+    kw = dict(topK=40, shrink=2, similarity=similarity)
+    if similarity == "asymmetric":
+        kw["asymmetric_alpha"] = 0.3
+    if similarity == "euclidean":
+        from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_Euclidean_MI355X
+        make = lambda M: Compute_Similarity_Euclidean_MI355X(M, topK=40, shrink=2, normalize=True, similarity_from_distance_mode="log")
+        orc_cols = O.OracleSimilarityEuclidean(X, topK=40, shrink=2, normalize=True, similarity_from_distance_mode="log")
+        column = lambda c: orc_cols.columns(c, c + 1)[:, 0].astype(np.float64)
+    else:
+        make = lambda M: Compute_Similarity_MI355X(M, **kw)
+        orc = O.OracleSimilarity(X, **dict(kw, topK=0))
+        column = lambda c: orc.column(c)[0]
+    dev = make(X)
+    kind, scale = dev.accumulator_info()
+    assert kind == "int32-exact" and scale == (1.0 / step) ** 2
+    idx, val, _ = dev.compute_slabs()
+    dev.close()
+    monkeypatch.setenv("MI355REC_SIM_NO_INT32", "1")
+    wide = make(X)
+    assert wide.accumulator_info()[0] == "int64-fixed"
+    idx_w, val_w, _ = wide.compute_slabs()
+    wide.close()
+    monkeypatch.delenv("MI355REC_SIM_NO_INT32")
+    np.testing.assert_array_equal(idx, idx_w)
+    assert np.abs(val - val_w).max() <= 2e-6 * np.abs(val_w).max()
+    for c in np.random.default_rng(3).choice(X.shape[1], 150, replace=False):
+        check_topk_against_dense(idx[c], val[c], column(int(c)), 40, RTOL)
+    if similarity == "cosine" and step == 1.0:
+        Xj = X.copy(); Xj.data = Xj.data + np.float32(1e-3) * np.random.default_rng(5).random(X.nnz).astype(np.float32)
+        for M, extra in ((Xj, {}), (X, dict(row_weights=np.arange(1, X.shape[0] + 1, dtype=np.float64) % 7 + 1)), (X, dict(similarity="pearson"))):
+            other = Compute_Similarity_MI355X(M, **dict(kw, **extra))
+            assert other.accumulator_info()[0] in ("int64-fixed", "float64")
+            other.close()
