@@ -41,6 +41,15 @@ BATCH = 1000
 TOPK = 100
 
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """Progress on stderr (the JSON line on stdout stays alone): a run that is cut short still says how far it got."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %6.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,6 +60,8 @@ def parse():
     ap.add_argument("--no-sim", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each CPU baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the other hot paths (FunkSVD, SLIM-BPR, IALS, scoring, replicas)")
+    ap.add_argument("--no-ials", action="store_true", help="skip the row-sharded IALS epoch (BASELINE config 5)")
+    ap.add_argument("--no-netflix", action="store_true", help="N > 1: skip the Netflix-shape ItemKNN build (BASELINE config 4)")
     return ap.parse_args()
 
 
@@ -59,7 +70,7 @@ def load_urm(name):
     import numpy as np
     import scipy.sparse as sps
     from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
-    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mi355rec_urm_%s_binary_r%s.npz" % (name, os.environ.get("RANK", "0")))
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mi355rec_urm_%s_binary.npz" % name)
     if os.path.isfile(cache):
         try:
             return sps.load_npz(cache).tocsr().astype(np.float32)
@@ -67,9 +78,21 @@ def load_urm(name):
             pass
     urm = named_urm(name, "binary")
     try:
-        sps.save_npz(cache, urm, compressed=False)
+        tmp = "%s.%d.tmp.npz" % (cache, os.getpid())          # (ranks may race: write aside, then rename)
+        sps.save_npz(tmp, urm, compressed=False)
+        os.replace(tmp, cache)
     except Exception:
         pass
+    return urm
+
+
+def load_urm_once_per_node(name, net):
+    """N > 1: rank 0 generates (or finds) the cached URM, the other ranks load its file after a barrier."""
+    if net.world == 1 or net.rank == 0:
+        urm = load_urm(name)
+    net.barrier()
+    if net.world > 1 and net.rank != 0:
+        urm = load_urm(name)
     return urm
 
 
@@ -333,6 +356,7 @@ def other_paths(urm, args):
         m.close()
 
     cpu = not args.no_cpu_baseline
+    note("paths: adagrad, funk")
     mf_run("bpr_mf_k128_batch1000_adagrad", 50, "float64 factors + moments (adaptive optimisers)", algorithm_name="MF_BPR",
            batch_size=BATCH, sgd_mode="adagrad")
     mf_run("funk_svd_k128_batch1000_bias", 1, "20 001 mini-batches per epoch, general (radix-sort) schedule", algorithm_name="FUNK_SVD",
@@ -342,6 +366,7 @@ def other_paths(urm, args):
         out["funk_svd_k128_batch1000_bias"]["speedup_vs_cpu_baseline"] = (
             out["funk_svd_k128_batch1000_bias"]["samples_per_s"] / out["funk_svd_k128_batch1000_bias"]["cpu_baseline"]["value"])
 
+    note("paths: 32-model group")
     # REPLICA-BATCHED launches: 32 independent models (own factors, seed, sample stream), mini-batch b of all of them in ONE grid
     # (mi355rec_mf_group_*) -- the device-side form of run_parameter_search.py:498's pool of workers.  Every member ends
     # bit-identical to training alone (tests/test_mf_gpu.py::test_group_*).
@@ -377,6 +402,7 @@ def other_paths(urm, args):
         m.close()
     del U0, V0
 
+    note("paths: 8 replicas on 8 streams")
     # concurrent replicas on ONE GPU: how run_parameter_search.py:498 uses the path (one model per worker); 8 handles, 8 streams
     n_rep, epochs = 8, 100
     reps = [MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, algorithm_name="MF_BPR", batch_size=BATCH, learning_rate=1e-3,
@@ -399,6 +425,7 @@ def other_paths(urm, args):
     for m in reps:
         m.close()
 
+    note("paths: exact multi-GPU mode, emulated")
     # SURVEY 8(e)'s exact multi-GPU mode at a batch size where a mini-batch fills the chip (65 536: outside the reference's search
     # space, which stops at 1024): this handle plays rank 0 of 8 -- its share of every mini-batch's row tasks, the packing of the
     # rows it owns and the merge of the other ranks' slabs are MEASURED; the all-gather between them is modelled from its size
@@ -435,6 +462,7 @@ def other_paths(urm, args):
                 "through HBM; replicas (one model per GPU) are the mode that scales"}
 
     for symmetric in (False, True):
+        note("paths: slim symmetric=%s" % symmetric)
         sl = SLIM_BPR_MI355X_Epoch(urm, symmetric=symmetric, sgd_mode="adagrad", learning_rate=1e-4, topK=TOPK, random_seed=7)
         sl.epochIteration_Cython(1)
         n_ep = 3
@@ -452,6 +480,7 @@ def other_paths(urm, args):
             blk["cpu_baseline"] = cpu_baseline_slim(urm, symmetric, args.cpu_seconds)
             blk["speedup_vs_cpu_baseline"] = blk["samples_per_s"] / blk["cpu_baseline"]["value"]
 
+    note("paths: scoring")
     # scoring + ranking of 1000 users (the Evaluator's block size, Base/Evaluation/Evaluator.py:406-408), k = 128
     from recsys2019_deeplearning_evaluation_amd import MI355XScorer
     rng = np.random.default_rng(0)
@@ -479,6 +508,7 @@ def other_paths(urm, args):
                                              "host_numpy_users_per_s": 1000 / host_wall}
     sc.close()
 
+    note("paths: ials k=200")
     # BASELINE config 5: IALS k = 200 on the ML-20M shape (one GPU here; the row-sharded epoch is sharding.sharded_ials_epoch)
     k = 200
     conf = urm.copy()
@@ -497,6 +527,7 @@ def other_paths(urm, args):
         out["ials_k200"]["cpu_baseline"] = cpu_baseline_ials(conf, k, 1e-3, V0, args.cpu_seconds)
         out["ials_k200"]["speedup_vs_cpu_baseline"] = out["ials_k200"]["cpu_baseline"]["value"] / out["ials_k200"]["seconds_per_epoch"]
 
+    note("paths: asysvd")
     # AsySVD at the ML-1M shape, k = 64, biases: nnz + 1 strictly ordered steps, each rewriting every Y row of the
     # sampled user's profile -- consecutive steps share the popular items' rows, so the epoch is one dependent chain
     from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
@@ -579,6 +610,30 @@ class Net:
             return float(self._gather_double(x).max())
         return x
 
+    def census(self):
+        """What the transport itself says about the job: number of ranks in the communicator and the set of ranks an all-gather
+        reaches.  Raises if that is not WORLD_SIZE distinct ranks (so that a mis-launched job cannot report an N-GPU number)."""
+        import numpy as np
+        info = {"world_size_env": self.world, "transport": "none"}
+        if self.world == 1:
+            info["ranks_seen"] = 1
+            return info
+        if self.comm is not None:
+            info.update(transport="rccl-ctypes", nccl_comm_count=self.comm.count(), nccl_user_rank=self.comm.user_rank())
+            seen = sorted(int(round(x)) for x in self._gather_double(float(self.rank)))
+            count = info["nccl_comm_count"]
+        else:
+            t = self.torch.tensor([float(self.rank)], dtype=self.torch.float64, device="cpu" if self.dist.get_backend() == "gloo" else "cuda")
+            parts = [self.torch.empty_like(t) for _ in range(self.world)]
+            self.dist.all_gather(parts, t)
+            seen = sorted(int(round(float(x.item()))) for x in parts)
+            count = self.dist.get_world_size()
+            info.update(transport="torch." + self.dist.get_backend(), torch_world_size=count)
+        info["ranks_seen"] = len(set(seen))
+        if count != self.world or seen != list(range(self.world)):
+            raise SystemExit("bench.py: the communicator reaches ranks %s (count %d) but WORLD_SIZE is %d" % (seen, count, self.world))
+        return info
+
     def close(self):
         if self.dist is not None:
             self.dist.barrier()
@@ -588,7 +643,64 @@ class Net:
             self.comm.close()
 
 
-def itemknn_section(urm, net, args, extra):
+def ials_section(urm, net, args, extra):
+    """BASELINE config 5: IALS k = 200 on the ML-20M shape with the row solves of each half-step split over the ranks
+    (sharding.ShardedIALSEpoch: cost-balanced ranges, one all-gather of the solved rows per half-step).  At N = 1 it also runs the
+    ranges of the 8-way split one after the other and models the two all-gathers from their size."""
+    import numpy as np
+    from recsys2019_deeplearning_evaluation_amd import IALS_MI355X_Epoch
+    from recsys2019_deeplearning_evaluation_amd.sharding import ShardedIALSEpoch, ials_row_ranges
+    k = 200
+    conf = urm.copy()
+    conf.data = (1.0 + 1.0 * conf.data).astype(np.float32)
+    V0 = k ** -0.5 * np.random.default_rng(0).random((urm.shape[1], k))
+    ia = IALS_MI355X_Epoch(conf, k, 1e-3, V0)
+    job = ShardedIALSEpoch(ia, conf, net.dist, net.rank, net.world, net.comm)
+    job.run_epoch()                                   # warm-up (first touch of the buffers, communicator)
+    best = None
+    for _ in range(2):
+        net.barrier()
+        t0 = time.perf_counter()
+        job.run_epoch()
+        net.barrier()
+        dt = net.max(time.perf_counter() - t0)
+        best = dt if best is None or dt < best else best
+    nnz, n_u, n_i = float(urm.nnz), urm.shape[0], urm.shape[1]
+    flops = 2.0 * (2.0 * nnz * k * k) + (n_u + n_i) * (k ** 3 / 3.0 + 2.0 * k * k)
+    block = {"seconds_per_epoch": best, "definition": "both half-steps; every rank's device holds the complete updated U and V (max over ranks, best of 2)",
+             "n_factors": k, "TFLOPs_algorithmic": flops / best / 1e12, "frac_of_fp64_peak_all_gpus": flops / best / 1e12 / (FP64_PEAK_TF * net.world),
+             "exchange_bytes_per_rank_per_epoch": job.exchange_bytes_per_rank_per_epoch(),
+             "rows_this_rank": [int(job.user_ranges[net.rank][1] - job.user_ranges[net.rank][0]),
+                                int(job.item_ranges[net.rank][1] - job.item_ranges[net.rank][0])]}
+    job.close()
+    if net.world == 1 and not args.no_extras:
+        G = 8
+        ur, ir = ials_row_ranges(conf, G, k)
+        t_user, t_item = [], []
+        for r in range(G):
+            ia.user_half(*ur[r]); ia.synchronize(); t_user.append(ia.stats()["call_ms"])
+        for r in range(G):
+            ia.item_half(*ir[r]); ia.synchronize(); t_item.append(ia.stats()["call_ms"])
+        slab_u = max(e - s for s, e in ur) * k * 8
+        slab_i = max(e - s for s, e in ir) * k * 8
+        ring = lambda slab: (G - 1) * slab / 50e9 * 1e3 + 0.05
+        direct = lambda slab: slab / 50e9 * 1e3 + 0.05
+        one_ring = max(t_user) + max(t_item) + ring(slab_u) + ring(slab_i)
+        all_links = max(t_user) + max(t_item) + direct(slab_u) + direct(slab_i)
+        block["emulated_8_way"] = {
+            "user_half_ms_per_range": t_user, "item_half_ms_per_range": t_item, "slowest_user_ms": max(t_user), "slowest_item_ms": max(t_item),
+            "kernel_speedup_vs_1gpu": best * 1e3 / (max(t_user) + max(t_item)),
+            "slab_MB_per_rank": {"users": slab_u / 1e6, "items": slab_i / 1e6},
+            "modelled_allgather_ms": {"one_ring_50GBps_per_link": ring(slab_u) + ring(slab_i), "seven_links_at_once": direct(slab_u) + direct(slab_i)},
+            "predicted_seconds_per_epoch": {"one_ring": one_ring * 1e-3, "seven_links": all_links * 1e-3},
+            "predicted_speedup": {"one_ring": best * 1e3 / one_ring, "seven_links": best * 1e3 / all_links},
+            "note": "the 8 cost-balanced ranges of each half-step run one after the other on ONE GPU (measured); the two all-gathers are "
+                    "modelled from their size; unmeasured on hardware"}
+    ia.close()
+    extra["ials"] = block
+
+
+def itemknn_section(urm, net, args, extra, key="itemknn"):
     """The ItemKNN cosine build at this N: constructor, sharded build (device-resident result on every rank), download on rank 0,
     roofline blocks of the column kernel, and -- at N = 1 -- the per-range kernel times of the 8-way split."""
     import numpy as np
@@ -673,15 +785,18 @@ def itemknn_section(urm, net, args, extra):
         local8.close(); gathered8.close()
     job.close()
     sim.close()
-    extra["itemknn"] = block
-    # flat aliases kept for continuity with round 1's line
-    extra.update({"itemknn_cosine_build_s": best, "itemknn_create_s": create_s, "itemknn_fit_s": create_s + best,
-                  "itemknn_kernel_ms_this_rank": kernel_ms, "itemknn_frac_of_lds_atomic_peak": pair_rate / LDS_ATOMIC_PEAK})
+    block["shape"] = "%dx%d nnz=%d" % (urm.shape[0], urm.shape[1], urm.nnz)
+    extra[key] = block
+    if key == "itemknn":     # flat aliases kept for continuity with round 1's line
+        extra.update({"itemknn_cosine_build_s": best, "itemknn_create_s": create_s, "itemknn_fit_s": create_s + best,
+                      "itemknn_kernel_ms_this_rank": kernel_ms, "itemknn_frac_of_lds_atomic_peak": pair_rate / LDS_ATOMIC_PEAK})
     return costs
 
 
 def main():
     args = parse()
+    import faulthandler
+    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)      # a stall leaves its stack in the log
     net = Net(args)
     rank, world = net.rank, net.world
     import numpy as np  # noqa: F401
@@ -692,11 +807,14 @@ def main():
     _native.set_device(net.local_rank)
     net.attach()
 
-    urm = load_urm(args.workload)
+    note("device %d bound, communicator census" % net.local_rank)
+    census = net.census()            # fails loudly if the communicator does not reach WORLD_SIZE distinct ranks
+    urm = load_urm_once_per_node(args.workload, net)
     n_users, n_items = urm.shape
     per_epoch = (n_users // BATCH + 1) * BATCH
     n_batches = per_epoch // BATCH
 
+    note("URM %s ready: %d x %d, %d interactions" % (args.workload, n_users, n_items, urm.nnz))
     # ------------------------------------------------------------------ BPR-MF epochs (headline value)
     mf = MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, algorithm_name="MF_BPR", batch_size=BATCH,
                                           learning_rate=1e-3, sgd_mode="sgd", init_std_dev=0.1, random_seed=42 + rank)
@@ -729,10 +847,25 @@ def main():
                 "whole_epoch_frac": st["algorithmic_bytes"] / (st["call_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     mf.close()
 
-    extra = {"bpr_loss_per_sample": st["loss"] / max(1, st["n_units"]), "bpr_stream_ms": st["call_ms"]}
+    note("headline: %.1f M samples/s" % (value / 1e6))
+    extra = {"bpr_loss_per_sample": st["loss"] / max(1, st["n_units"]), "bpr_stream_ms": st["call_ms"], "communicator": census}
     costs = None
     if not args.no_sim:
         costs = itemknn_section(urm, net, args, extra)
+        extra["itemknn"]["communicator"] = census
+        if world > 1 and args.workload != "netflix" and not args.no_netflix:
+            # BASELINE config 4 is the build with the >= 6x target at 8 GPUs: always part of a multi-GPU run
+            big = load_urm_once_per_node("netflix", net)
+            itemknn_section(big, net, args, extra, key="itemknn_netflix_config4")
+            del big
+    note("itemknn sections done")
+    if not args.no_ials:
+        try:
+            ials_section(urm, net, args, extra)
+        except Exception as exc:
+            if world > 1:
+                raise
+            extra["ials_error"] = repr(exc)
 
     shape_name = {"ml20m": "ML-20M-shaped", "ml1m": "ML-1M-shaped", "netflix": "Netflix-Prize-shaped (BASELINE configs[3])"}[args.workload]
     out = {"metric": "BPR-MF SGD samples/sec (k=128, batch 1000) + ItemKNN cosine build sec on %s URM" % shape_name,
@@ -744,11 +877,13 @@ def main():
                       "batch_size": BATCH, "n_factors": K_FACTORS, "parallelism": "replicas x%d" % world},
            "roofline": roofline, "extra": extra}
 
+    note("ials section done")
     if rank == 0 and world == 1 and not args.no_extras:
         try:
             out["extra"]["paths"] = other_paths(urm, args)
         except Exception as exc:                       # the headline line must survive a failure in the side measurements
             out["extra"]["paths_error"] = repr(exc)
+    note("other paths done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline_bpr(urm, args.cpu_seconds)
         base["host_cpu_count"] = os.cpu_count()
@@ -759,6 +894,8 @@ def main():
             out["extra"]["itemknn"]["cpu_baseline"] = sb
             out["extra"]["itemknn"]["speedup_vs_cpu_baseline"] = sb["value"] / out["extra"]["itemknn"]["cosine_build_s"]
             out["extra"]["itemknn"]["fit_speedup_vs_cpu_baseline"] = sb["value"] / out["extra"]["itemknn"]["fit_s"]
+    note("done")
+    faulthandler.cancel_dump_traceback_later()
     if rank == 0:
         print(json.dumps(out))
     net.close()

@@ -34,7 +34,7 @@
 #include "common.h"
 #include "sampling.cuh"
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <memory>
 
@@ -225,7 +225,7 @@ template <class T> __device__ __forceinline__ T moved(T w, T lr, T step) {      
 
 // One thread per sample of one epoch (sampleBPR_Cython .pyx:940-985 / sampleMSE_Cython :878-935).
 template <int ALGO, class T>
-__global__ __launch_bounds__(256) void mf_sample_kernel(const MfParams<T> p) {
+__device__ __forceinline__ void mf_sample_body(const MfParams<T> &p) {
     const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const long long epoch = p.state->epoch;
     if (t < p.samples_per_epoch) {
@@ -263,6 +263,8 @@ __global__ __launch_bounds__(256) void mf_sample_kernel(const MfParams<T> p) {
     // the grid is fully drained before the next kernel starts: a plain store by one thread is enough
     if (t == 0) p.state->epoch = epoch + 1;
 }
+template <int ALGO, class T>
+__global__ __launch_bounds__(256) void mf_sample_kernel(const MfParams<T> p) { mf_sample_body<ALGO, T>(p); }
 
 // ---- schedule: (row, mini-batch) incidences -> tasks ----------------------------------------------------------------
 struct SchedParams {
@@ -395,6 +397,8 @@ constexpr int FAST_MAX_BATCHES = 256, FAST_MAX_SLOTS = 8192;
 struct FastSchedParams {
     long long n_samples;
     int per, n_users, n_entries, batch_size, tasks_per_batch, slot_bits, np, words, group;
+    int mid_bytes;                // LDS bytes between the keys and the once-touched flags (run starts + header slots, or the sort's scratch)
+    int entry_bits;               // bits of a row id (users, then items) + 1: the padding keys' all-ones field sorts last
     int fuse;                     // BPR: a sample whose user row is touched once in the batch takes over its other once-touched rows
     const int *su, *si, *sj;
     const float *sr;
@@ -407,14 +411,36 @@ struct FastSchedParams {
     int4 *recs;
 };
 
-__global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const FastSchedParams s) {
+// The keys (row << slot_bits | incidence, in incidence order) only have to be grouped by row with the incidences of a row in
+// stream order: a STABLE radix sort on the row bits does it in (row bits + 7) / 8 passes (rocPRIM block sort) where the bitonic
+// network of round 2 needed 78 barrier-separated stages for 4096 keys (74 us per mini-batch: as much as the mini-batch itself
+// once 32 models share a launch).
+template <int IPT> struct SchedSort {
+    using type = rocprim::block_radix_sort<unsigned, SCHED_THREADS, IPT>;
+    static __device__ __forceinline__ void run(unsigned *K, void *storage, int begin_bit, int end_bit) {
+        unsigned keys[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) keys[i] = K[threadIdx.x * IPT + i];
+        type().sort(keys, *reinterpret_cast<typename type::storage_type *>(storage), (unsigned)begin_bit, (unsigned)end_bit);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) K[threadIdx.x * IPT + i] = keys[i];
+    }
+};
+constexpr size_t sched_sort_storage_bytes(int np) {
+    return np <= SCHED_THREADS ? sizeof(SchedSort<1>::type::storage_type)
+           : (np <= 2 * SCHED_THREADS ? sizeof(SchedSort<2>::type::storage_type)
+              : (np <= 4 * SCHED_THREADS ? sizeof(SchedSort<4>::type::storage_type) : sizeof(SchedSort<8>::type::storage_type)));
+}
+
+__device__ __forceinline__ void mf_sched_sort_body(const FastSchedParams &s, const int b) {
     extern __shared__ __attribute__((aligned(16))) unsigned sched_lds[];
     unsigned *K = sched_lds;                                   // [np] keys: row << slot_bits | incidence
     int *hpos = reinterpret_cast<int *>(sched_lds + s.np);     // [np + 1] first sorted position of every run
     int *tpos = hpos + s.np + 1;                               // [np] header slot of every task
-    typedef hipcub::BlockScan<int, SCHED_THREADS> Scan;
-    __shared__ typename Scan::TempStorage scan_tmp;
-    const int tid = threadIdx.x, b = blockIdx.x, np = s.np, sb = s.slot_bits;
+    typedef rocprim::block_scan<int, SCHED_THREADS> Scan;
+    __shared__ typename Scan::storage_type scan_tmp;
+    const int tid = threadIdx.x, np = s.np, sb = s.slot_bits;
     const long long first = (long long)b * s.batch_size;
     const int n_in = (int)min((long long)s.batch_size, s.n_samples - first);
     const int m = n_in * s.per;
@@ -429,17 +455,14 @@ __global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const Fast
         K[q] = key;
     }
     __syncthreads();
-    for (int size = 2; size <= np; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < np / 2; t += SCHED_THREADS) {
-                const int lo = ((t / stride) * 2 * stride) + (t % stride), hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const unsigned a = K[lo], c = K[hi];
-                if ((a > c) == up) { K[lo] = c; K[hi] = a; }
-            }
-            __syncthreads();
-        }
+    // (the sort's scratch lives where the run starts / header slots go afterwards)
+    switch (np / SCHED_THREADS) {
+        case 1: SchedSort<1>::run(K, hpos, sb, sb + s.entry_bits); break;
+        case 2: SchedSort<2>::run(K, hpos, sb, sb + s.entry_bits); break;
+        case 4: SchedSort<4>::run(K, hpos, sb, sb + s.entry_bits); break;
+        default: SchedSort<8>::run(K, hpos, sb, sb + s.entry_bits); break;
     }
+    __syncthreads();
     // run heads -> hpos[]
     const int C = np / SCHED_THREADS;
     int cnt = 0;
@@ -448,7 +471,7 @@ __global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const Fast
         cnt += q < m && (q == 0 || (K[q] >> sb) != (K[q - 1] >> sb));
     }
     int off = 0, total = 0;
-    Scan(scan_tmp).ExclusiveSum(cnt, off, total);
+    Scan().exclusive_scan(cnt, off, 0, total, scan_tmp);
     for (int c = 0; c < C; ++c) {
         const int q = tid * C + c;
         if (q < m && (q == 0 || (K[q] >> sb) != (K[q - 1] >> sb))) hpos[off++] = q;
@@ -463,7 +486,7 @@ __global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const Fast
     // 1): its lane groups, which walk a list's samples `group` at a time, each take one of the samples and write that sample's
     // rows -- a single-sample task leaves all but one lane group of its wavefront idle otherwise.  The arithmetic per row is
     // unchanged.  single[q] = incidence q (sample * per + role) is alone in its run.
-    unsigned char *single = reinterpret_cast<unsigned char *>(tpos + np);
+    unsigned char *single = reinterpret_cast<unsigned char *>(sched_lds) + sizeof(unsigned) * (size_t)np + s.mid_bytes;
     const unsigned qmask = (1u << sb) - 1u;
     if (s.fuse) {
         for (int q = tid; q < np; q += SCHED_THREADS) single[q] = 0;
@@ -500,9 +523,9 @@ __global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const Fast
         acnt += absorbed(t) || (len == 1 && start % s.group != 0 && paired(start));      // runs without a header of their own
     }
     int woff = 0, n_wide = 0, aoff = 0, n_abs = 0;
-    Scan(scan_tmp).ExclusiveSum(wcnt, woff, n_wide);
+    Scan().exclusive_scan(wcnt, woff, 0, n_wide, scan_tmp);
     __syncthreads();
-    Scan(scan_tmp).ExclusiveSum(acnt, aoff, n_abs);
+    Scan().exclusive_scan(acnt, aoff, 0, n_abs, scan_tmp);
     TaskHeader *out = s.tasks + (size_t)b * s.tasks_per_batch;
     for (int t = t_lo; t < t_hi; ++t) {
         const int start = hpos[t], len = hpos[t + 1] - start;
@@ -545,6 +568,7 @@ __global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const Fast
         s.qtask[(size_t)b * s.tasks_per_batch + q] = tpos[lo];
     }
 }
+__global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const FastSchedParams s) { mf_sched_sort_body(s, blockIdx.x); }
 
 __device__ __forceinline__ int version_parity(const FastSchedParams &s, int entry, int b) {
     const unsigned *w = s.touched + (size_t)entry * s.words;
@@ -554,7 +578,7 @@ __device__ __forceinline__ int version_parity(const FastSchedParams &s, int entr
     return (s.par[entry] + cnt) & 1;
 }
 
-__global__ __launch_bounds__(256) void mf_sched_emit_kernel(const FastSchedParams s) {
+__device__ __forceinline__ void mf_sched_emit_body(const FastSchedParams &s) {
     const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
     const long long first = (long long)b * s.batch_size;
     const int n_in = (int)min((long long)s.batch_size, s.n_samples - first);
@@ -586,7 +610,9 @@ __global__ __launch_bounds__(256) void mf_sched_emit_kernel(const FastSchedParam
     }
 }
 
-__global__ __launch_bounds__(256) void mf_sched_finish_kernel(const FastSchedParams s) {
+__global__ __launch_bounds__(256) void mf_sched_emit_kernel(const FastSchedParams s) { mf_sched_emit_body(s); }
+
+__device__ __forceinline__ void mf_sched_finish_body(const FastSchedParams &s) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= s.n_entries) return;
     unsigned *w = s.touched + (size_t)x * s.words;
@@ -597,6 +623,7 @@ __global__ __launch_bounds__(256) void mf_sched_finish_kernel(const FastSchedPar
     }
     if (cnt & 1) s.par[x] ^= 1;
 }
+__global__ __launch_bounds__(256) void mf_sched_finish_kernel(const FastSchedParams s) { mf_sched_finish_body(s); }
 
 template <class T>
 __global__ void mf_stream_end_kernel(const MfParams<T> p, const long long n_batches) {
@@ -987,6 +1014,7 @@ template <class T> __device__ __forceinline__ void globalize(MfParams<T> &p) {
     p.c1_bu = as_global(p.c1_bu); p.c2_bu = as_global(p.c2_bu); p.c1_bi = as_global(p.c1_bi); p.c2_bi = as_global(p.c2_bi);
     p.mu_state = as_global(p.mu_state); p.mu_acc = as_global(p.mu_acc);
     p.loss_slots = as_global(p.loss_slots); p.state = as_global(p.state);
+    p.su = as_global(p.su); p.si = as_global(p.si); p.sj = as_global(p.sj); p.sr = as_global(p.sr);
     p.tasks = as_global(p.tasks); p.recs = as_global(p.recs); p.ticks = as_global(p.ticks); p.used = as_global(p.used);
 }
 
@@ -999,6 +1027,35 @@ __global__ __launch_bounds__(256) void mf_group_batch_kernel(const MfParams<T> *
     const int used = p.used ? p.used[batch_local] : p.tasks_per_batch;
     for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg);
 }
+// Sampler and schedule of every member in ONE launch each (model on the last grid dimension): as 4 x R small launches on R
+// streams they took a third of a 32-model epoch.
+__device__ __forceinline__ void globalize(FastSchedParams &f) {
+    f.su = as_global(f.su); f.si = as_global(f.si); f.sj = as_global(f.sj); f.sr = as_global(f.sr);
+    f.touched = as_global(f.touched); f.par = as_global(f.par); f.sorted_slot = as_global(f.sorted_slot); f.qtask = as_global(f.qtask);
+    f.used = as_global(f.used); f.tasks = as_global(f.tasks); f.recs = as_global(f.recs);
+}
+template <int ALGO, class T>
+__global__ __launch_bounds__(256) void mf_group_sample_kernel(const MfParams<T> *__restrict__ table) {
+    MfParams<T> p = table[blockIdx.y];
+    globalize(p);
+    mf_sample_body<ALGO, T>(p);
+}
+__global__ __launch_bounds__(SCHED_THREADS) void mf_group_sched_sort_kernel(const FastSchedParams *__restrict__ table) {
+    FastSchedParams f = table[blockIdx.y];
+    globalize(f);
+    mf_sched_sort_body(f, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void mf_group_sched_emit_kernel(const FastSchedParams *__restrict__ table) {
+    FastSchedParams f = table[blockIdx.z];
+    globalize(f);
+    mf_sched_emit_body(f);
+}
+__global__ __launch_bounds__(256) void mf_group_sched_finish_kernel(const FastSchedParams *__restrict__ table) {
+    FastSchedParams f = table[blockIdx.y];
+    globalize(f);
+    mf_sched_finish_body(f);
+}
+
 // the same with the register budget of 8 wavefronts per SIMD (64 VGPRs): a group launch is bound by the number of row gathers in
 // flight, i.e. by resident wavefronts
 template <int ALGO, class T, int VEC, int LPR, int KI>
@@ -1467,11 +1524,24 @@ bool fast_schedule_fits(const mi355rec_mf *h, long long n_batches) {
 }
 
 // keys, run starts, header slots (words) + one byte per incidence for the once-touched flags
-size_t sched_lds_bytes(int np) { return sizeof(unsigned) * (3 * (size_t)np + 1) + (size_t)np + 16; }
+size_t sched_mid_bytes(int np) {
+    const size_t middle = std::max(sizeof(unsigned) * (2 * (size_t)np + 1), sched_sort_storage_bytes(np));      // run starts + header slots | sort scratch
+    return (middle + 15) & ~(size_t)15;
+}
+size_t sched_lds_bytes(int np) { return sizeof(unsigned) * (size_t)np + sched_mid_bytes(np) + (size_t)np + 16; }
 
-void enqueue_fast_schedule(mi355rec_mf *h, long long n_samples, long long n_batches) {
-    hipStream_t s = h->stream;
-    FastSchedParams f{};
+void set_sched_sort_attribute(const void *kernel, bool (&attr_set)[64]) {
+    int dev = 0;
+    MI_HIP(hipGetDevice(&dev));                 // the attribute is per DEVICE, not per process
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        MI_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sched_lds_bytes(FAST_MAX_SLOTS)));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+}
+
+FastSchedParams fast_sched_params(mi355rec_mf *h, long long n_samples) {
+    FastSchedParams f;
+    memset(&f, 0, sizeof(f));                   // (padding bytes included: the group compares tables bytewise)
     f.n_samples = n_samples;
     f.per = per_sample(h);
     f.n_users = h->n_users;
@@ -1480,6 +1550,8 @@ void enqueue_fast_schedule(mi355rec_mf *h, long long n_samples, long long n_batc
     f.tasks_per_batch = f.per * h->cfg.batch_size;
     f.np = std::max(SCHED_THREADS, pow2_at_least(f.tasks_per_batch));
     f.slot_bits = bits_for((unsigned long long)f.np);
+    f.entry_bits = std::min(32 - f.slot_bits, bits_for((unsigned long long)f.n_entries) + 1);
+    f.mid_bytes = (int)sched_mid_bytes(f.np);
     f.words = FAST_MAX_BATCHES / 32;
     f.group = samples_in_flight(h);
     f.su = h->su.ptr; f.si = h->si.ptr; f.sj = h->sj.ptr; f.sr = h->sr.ptr;
@@ -1488,15 +1560,15 @@ void enqueue_fast_schedule(mi355rec_mf *h, long long n_samples, long long n_batc
     f.tasks = h->tasks.ptr; f.recs = h->recs.ptr;
     // fused sample tasks: BPR only; not in the exact multi-GPU mode, whose exchange slabs hold one row per task slot
     f.fuse = h->cfg.algorithm == MI355REC_MF_BPR && h->shard_rank < 0 && !getenv("MI355REC_MF_NO_FUSE");
+    return f;
+}
+
+void enqueue_fast_schedule(mi355rec_mf *h, long long n_samples, long long n_batches) {
+    hipStream_t s = h->stream;
+    const FastSchedParams f = fast_sched_params(h, n_samples);
     const size_t lds = sched_lds_bytes(f.np);
-    static bool attr_set[64] = {};              // the attribute is per DEVICE, not per process
-    int dev = 0;
-    MI_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mf_sched_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)sched_lds_bytes(FAST_MAX_SLOTS)));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
+    static bool attr_set[64] = {};
+    set_sched_sort_attribute(reinterpret_cast<const void *>(mf_sched_sort_kernel), attr_set);
     hipLaunchKernelGGL(mf_sched_sort_kernel, dim3((unsigned)n_batches), dim3(SCHED_THREADS), lds, s, f);
     hipLaunchKernelGGL(mf_sched_emit_kernel, dim3(div_up(f.tasks_per_batch, 256), (unsigned)n_batches), dim3(256), 0, s, f);
     hipLaunchKernelGGL(mf_sched_finish_kernel, dim3(div_up(f.n_entries, 256)), dim3(256), 0, s, f);
@@ -1536,14 +1608,14 @@ void enqueue_schedule(mi355rec_mf *h, long long n_samples, long long n_batches) 
     MI_HIP(hipMemsetAsync(h->tasks.ptr, 0, sizeof(TaskHeader) * (size_t)n_batches * sp.tasks_per_batch, s));
     hipLaunchKernelGGL(mf_keys_kernel, dim3(div_up(n_samples, 256)), dim3(256), 0, s, sp);
     size_t bytes = h->cub_tmp_bytes;
-    MI_HIP(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->slots.ptr,
+    MI_HIP(rocprim::radix_sort_pairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->slots.ptr,
                                               h->slots_sorted.ptr, (int)n, 0, end_bit, s));
     MI_HIP(hipMemsetAsync(sp.slot_flag, 0, sizeof(int) * (size_t)n, s));
     hipLaunchKernelGGL(mf_heads_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, sp);
     bytes = h->cub_tmp_bytes;
-    MI_HIP(hipcub::DeviceScan::InclusiveSum(h->cub_tmp.ptr, bytes, h->head.ptr, h->head_scan.ptr, (int)n, s));
+    MI_HIP(rocprim::inclusive_scan(h->cub_tmp.ptr, bytes, h->head.ptr, h->head_scan.ptr, (size_t)n, rocprim::plus<int>(), s));
     bytes = h->cub_tmp_bytes;
-    MI_HIP(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp.ptr, bytes, sp.slot_flag, reinterpret_cast<int *>(h->keys.ptr) + n, (int)n, s));
+    MI_HIP(rocprim::exclusive_scan(h->cub_tmp.ptr, bytes, sp.slot_flag, reinterpret_cast<int *>(h->keys.ptr) + n, 0, (size_t)n, rocprim::plus<int>(), s));
     hipLaunchKernelGGL(mf_tasks_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, sp);
     hipLaunchKernelGGL(mf_recs_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, sp);
 }
@@ -1632,9 +1704,9 @@ void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batche
             h->head.alloc(n); h->head_scan.alloc(n); h->task_at.alloc(n);
             h->spar.alloc(n);
             size_t sort_bytes = 0, scan_bytes = 0;
-            MI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, h->keys.ptr, h->keys_sorted.ptr, h->slots.ptr,
+            MI_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, h->keys.ptr, h->keys_sorted.ptr, h->slots.ptr,
                                                       h->slots_sorted.ptr, (int)n, 0, 64, h->stream));
-            MI_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, h->head.ptr, h->head_scan.ptr, (int)n, h->stream));
+            MI_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, h->head.ptr, h->head_scan.ptr, (size_t)n, rocprim::plus<int>(), h->stream));
             h->cub_tmp_bytes = std::max(sort_bytes, scan_bytes) + 256;
             h->cub_tmp.alloc(h->cub_tmp_bytes);
         }
@@ -2012,6 +2084,9 @@ struct mi355rec_mf_group {
     int max_timed = 0;
     DeviceBuffer<unsigned char> table;       // MfParams<T>[R]
     std::vector<unsigned char> host_table;
+    DeviceBuffer<FastSchedParams> sched_table;   // valid when every member is on the in-LDS schedule (all_fast)
+    std::vector<FastSchedParams> host_sched_table;
+    bool all_fast = false;
     hipEvent_t fork = nullptr;
     std::vector<hipEvent_t> join;
     hipGraphExec_t graph = nullptr;
@@ -2036,6 +2111,22 @@ namespace {
 template <class T>
 void group_enqueue_epoch(mi355rec_mf_group *g, bool timed) {
     const long long nb = g->batches_per_epoch;
+    if (g->all_fast) {      // sampler + schedule of all members: four launches on the group's stream
+        const int R = (int)g->members.size();
+        mi355rec_mf *h0 = g->members[0];
+        const MfParams<T> *table = reinterpret_cast<const MfParams<T> *>(g->table.ptr);
+        const FastSchedParams &f0 = g->host_sched_table[0];
+        const dim3 sgrid(div_up(nb * (long long)h0->cfg.batch_size, 256), R);
+        if (g->algorithm == MI355REC_MF_BPR) hipLaunchKernelGGL((mf_group_sample_kernel<MI355REC_MF_BPR, T>), sgrid, dim3(256), 0, g->stream, table);
+        else hipLaunchKernelGGL((mf_group_sample_kernel<MI355REC_MF_FUNK_SVD, T>), sgrid, dim3(256), 0, g->stream, table);
+        static bool attr_set[64] = {};
+        set_sched_sort_attribute(reinterpret_cast<const void *>(mf_group_sched_sort_kernel), attr_set);
+        int max_entries = 0;
+        for (const auto &f : g->host_sched_table) max_entries = std::max(max_entries, f.n_entries);
+        hipLaunchKernelGGL(mf_group_sched_sort_kernel, dim3((unsigned)nb, R), dim3(SCHED_THREADS), sched_lds_bytes(f0.np), g->stream, g->sched_table.ptr);
+        hipLaunchKernelGGL(mf_group_sched_emit_kernel, dim3(div_up(f0.tasks_per_batch, 256), (unsigned)nb, R), dim3(256), 0, g->stream, g->sched_table.ptr);
+        hipLaunchKernelGGL(mf_group_sched_finish_kernel, dim3(div_up(max_entries, 256), R), dim3(256), 0, g->stream, g->sched_table.ptr);
+    } else {
     MI_HIP(hipEventRecord(g->fork, g->stream));
     for (size_t m = 0; m < g->members.size(); ++m) {
         mi355rec_mf *h = g->members[m];
@@ -2046,6 +2137,7 @@ void group_enqueue_epoch(mi355rec_mf_group *g, bool timed) {
         enqueue_schedule(h, p.samples_per_epoch, nb);
         MI_HIP(hipEventRecord(g->join[m], h->stream));
         MI_HIP(hipStreamWaitEvent(g->stream, g->join[m], 0));
+    }
     }
     const MfParams<T> *table = reinterpret_cast<const MfParams<T> *>(g->table.ptr);
     // a third of the slots' workgroups: the kernel loops over the slots in use (all of them when a member is on the general schedule)
@@ -2094,10 +2186,34 @@ void group_run_epochs_typed(mi355rec_mf_group *g, int n_epochs) {
         mi355rec_mf *h = g->members[m];
         MI_REQUIRE(h->shard_rank < 0, "member %d is inside an exact multi-GPU epoch", m);
         ensure_stream_capacity(h, (size_t)(nb * h->cfg.batch_size), nb);
-        MfParams<T> p{};
+        MfParams<T> p;
+        memset(&p, 0, sizeof(p));
         fill_params(h, p);
         memcpy(table.data() + sizeof(MfParams<T>) * (size_t)m, &p, sizeof(MfParams<T>));
         begin_call(h);
+        MI_HIP(hipStreamSynchronize(h->stream));      // (its clears and first-touch memsets run on the member's own stream)
+    }
+    std::vector<FastSchedParams> sched((size_t)R);
+    bool all_fast = !getenv("MI355REC_MF_GROUP_PER_MEMBER_SCHEDULE");
+    for (int m = 0; m < R; ++m) {
+        mi355rec_mf *h = g->members[m];
+        all_fast = all_fast && h->fast_schedule && fast_schedule_fits(h, nb);
+        if (all_fast) sched[m] = fast_sched_params(h, nb * (long long)h->cfg.batch_size);
+    }
+    const bool sched_changed = all_fast != g->all_fast || (all_fast && (g->host_sched_table.size() != sched.size() ||
+                               memcmp(g->host_sched_table.data(), sched.data(), sizeof(FastSchedParams) * sched.size()) != 0));
+    if (sched_changed) {
+        if (g->graph) {
+            (void)hipGraphExecDestroy(g->graph);
+            g->graph = nullptr;
+        }
+        MI_HIP(hipStreamSynchronize(g->stream));
+        g->all_fast = all_fast;
+        g->host_sched_table = sched;
+        if (all_fast) {
+            if (g->sched_table.count < sched.size()) g->sched_table.alloc(sched.size());
+            MI_HIP(hipMemcpy(g->sched_table.ptr, sched.data(), sizeof(FastSchedParams) * sched.size(), hipMemcpyHostToDevice));
+        }
     }
     if (table != g->host_table) {                 // a member re-allocated its stream buffers: the graph holds the old addresses
         if (g->graph) {

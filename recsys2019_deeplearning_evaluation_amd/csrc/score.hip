@@ -6,9 +6,10 @@
 // the `cutoff` best items per user in descending score order, -inf items dropped) -- the step the reference's
 // EvaluatorHoldout runs on every validation (Base/Evaluation/Evaluator.py:436).
 //
-//   score_gemm_kernel  the one GEMM-shaped op next to the hot path: a 32-user x 128-item tile per workgroup, four
-//                      wavefronts each driving v_mfma_f32_32x32x2_f32 (exact f32: bitwise an fmaf chain, at the f32 vector
-//                      rate) over K in LDS-staged chunks of 64; biases added in the epilogue.
+//   score_gemm_kernel  the one GEMM-shaped op next to the hot path: a 128-user x 128-item tile per workgroup, 2 x 2 wavefronts
+//                      with four 32 x 32 accumulators each on v_mfma_f32_32x32x2_f32 (exact f32: bitwise an fmaf chain, at the
+//                      f32 vector rate), K in LDS-staged chunks of 32 with the next chunk's 16-byte loads in flight; biases
+//                      added in the epilogue.
 //   score_rank_kernel  one workgroup per user: the score row is pulled into LDS, seen / excluded items are set to -inf,
 //                      the same in-LDS radix-select + bitonic-sort top-K as the similarity build emits the ranking.
 //   wide ranking       catalogues whose score row does not fit LDS (> ~32 k items) and cutoffs above the in-LDS selection limit
@@ -18,7 +19,7 @@
 #include "common.h"
 #include "topk.cuh"
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <memory>
@@ -27,8 +28,10 @@ namespace mi355rec {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int KC = 64;              // K chunk staged in LDS
-constexpr int LD = KC + 1;          // odd leading dimension: conflict-free column reads
+constexpr int TM = 128, TN = 128;   // users x items of a workgroup's tile: 2 x 2 wavefronts, 64 x 64 (four 32 x 32 accumulators) each
+constexpr int TK = 32;              // K chunk staged in LDS
+constexpr int LDT = 129;            // leading dimension of the [k][row] tiles: consecutive rows -> consecutive banks for the MFMA operand
+                                    // reads, and 4 * LDT = 4 (mod 32) spreads the 8 k-quads x 4 rows a half-wave stores over all 32 banks
 
 struct ScoreParams {
     int n_users, n_items, k, use_bias;
@@ -39,45 +42,102 @@ struct ScoreParams {
     float *scores;                  // [n_batch][n_items]
 };
 
+// four consecutive factors of one row: one 16-byte load when the row stride keeps it aligned and the quad lies inside the row
+__device__ __forceinline__ float4 load_quad(const float *row, int kk, int k, bool aligned) {
+    if (row == nullptr || kk >= k) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (aligned && kk + 3 < k) return *reinterpret_cast<const float4 *>(row + kk);
+    float4 r;
+    r.x = row[kk];
+    r.y = kk + 1 < k ? row[kk + 1] : 0.f;
+    r.z = kk + 2 < k ? row[kk + 2] : 0.f;
+    r.w = kk + 3 < k ? row[kk + 3] : 0.f;
+    return r;
+}
+
+// scores[b][item] = U[users[b]] . V[item] (+ biases).  Round 1's kernel (32 x 128 tile, one accumulator per wavefront, the K
+// chunk staged with 40 scalar loads + 40 4-byte LDS stores per thread and nothing in flight during the MFMAs) spent its time
+// staging: 0.14 of the f32 matrix peak.  Here a 128 x 128 tile, four 32 x 32 accumulators per wavefront (every operand read from
+// LDS feeds two MFMAs), 16-byte global loads of the NEXT K chunk in flight while the current one is multiplied.
 __global__ __launch_bounds__(256) void score_gemm_kernel(const ScoreParams p) {
-    __shared__ float As[32][LD];
-    __shared__ float Bs[128][LD];
-    __shared__ int s_user[32];
+    __shared__ float As[TK][LDT];          // [k][user row of the tile]
+    __shared__ float Bs[TK][LDT];          // [k][item of the tile]
+    __shared__ int s_user[TM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.y * 32, col0 = blockIdx.x * 128;
-    if (tid < 32) s_user[tid] = row0 + tid < p.n_batch ? p.users[row0 + tid] : -1;
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < p.k; k0 += KC) {
-        __syncthreads();
-        for (int e = tid; e < 32 * KC; e += 256) {
-            const int r = e / KC, f = e % KC;
-            const int u = s_user[r];
-            As[r][f] = (u >= 0 && k0 + f < p.k) ? p.U[(size_t)u * p.k + k0 + f] : 0.f;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row0 = blockIdx.y * TM, col0 = blockIdx.x * TN;
+    if (tid < TM) s_user[tid] = row0 + tid < p.n_batch ? p.users[row0 + tid] : -1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    __syncthreads();
+    // staging: thread t moves quads e = t + 256 i (i < 4) of both tiles: row m = e / 8, k-quad kq = e % 8
+    const bool aligned = (p.k & 3) == 0;
+    const float *arow[4], *brow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = (tid + 256 * i) >> 3;
+        const int u = s_user[m];
+        arow[i] = u >= 0 ? p.U + (size_t)u * p.k : nullptr;
+        brow[i] = col0 + m < p.n_items ? p.V + (size_t)(col0 + m) * p.k : nullptr;
+    }
+    const int kq4 = (tid & 7) * 4;
+    float4 ra[4], rb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = load_quad(arow[i], kq4, p.k, aligned);
+        rb[i] = load_quad(brow[i], kq4, p.k, aligned);
+    }
+    for (int k0 = 0; k0 < p.k; k0 += TK) {
+        __syncthreads();                   // everybody has finished multiplying the previous chunk
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = (tid + 256 * i) >> 3;
+            As[kq4][m] = ra[i].x; As[kq4 + 1][m] = ra[i].y; As[kq4 + 2][m] = ra[i].z; As[kq4 + 3][m] = ra[i].w;
+            Bs[kq4][m] = rb[i].x; Bs[kq4 + 1][m] = rb[i].y; Bs[kq4 + 2][m] = rb[i].z; Bs[kq4 + 3][m] = rb[i].w;
         }
-        for (int e = tid; e < 128 * KC; e += 256) {
-            const int r = e / KC, f = e % KC;
-            const int item = col0 + r;
-            Bs[r][f] = (item < p.n_items && k0 + f < p.k) ? p.V[(size_t)item * p.k + k0 + f] : 0.f;
-        }
         __syncthreads();
-        const int kk = min(KC, p.k - k0);
-        // A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]   (32x32x2 f32 operand maps)
-        const float *a_row = &As[lane & 31][lane >> 5];
-        const float *b_row = &Bs[wave * 32 + (lane & 31)][lane >> 5];
-        for (int s = 0; s < kk; s += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_row[s], b_row[s], acc, 0, 0, 0);
+        if (k0 + TK < p.k) {               // the next chunk's loads fly during this chunk's MFMAs
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = load_quad(arow[i], k0 + TK + kq4, p.k, aligned);
+                rb[i] = load_quad(brow[i], k0 + TK + kq4, p.k, aligned);
+            }
+        }
+        // A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]   (32x32x2 f32 operand maps); factors beyond k are zero
+        const float *a_col = &As[lane >> 5][wm * 64 + (lane & 31)];
+        const float *b_col = &Bs[lane >> 5][wn * 64 + (lane & 31)];
+#pragma unroll 4
+        for (int s = 0; s < TK; s += 2) {
+            const float a0 = a_col[s * LDT], a1 = a_col[s * LDT + 32];
+            const float b0 = b_col[s * LDT], b1 = b_col[s * LDT + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
     }
     // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int item = col0 + wave * 32 + (lane & 31);
-    if (item >= p.n_items) return;
-    const float item_term = p.use_bias ? p.bi[item] + p.mu : 0.f;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        const int u = s_user[r];
-        if (u < 0) continue;
-        float v = acc[reg] + item_term;
-        if (p.use_bias) v += p.bu[u];
-        p.scores[(size_t)(row0 + r) * p.n_items + item] = v;
+    for (int b = 0; b < 2; ++b) {
+        const int item = col0 + wn * 64 + b * 32 + (lane & 31);
+        if (item >= p.n_items) continue;
+        const float item_term = p.use_bias ? p.bi[item] + p.mu : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = wm * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int u = s_user[r];
+                if (u < 0) continue;
+                float v = acc[a][b][reg] + item_term;
+                if (p.use_bias) v += p.bu[u];
+                p.scores[(size_t)(row0 + r) * p.n_items + item] = v;
+            }
+        }
     }
 }
 
@@ -178,11 +238,11 @@ struct WideRanker {
         hipLaunchKernelGGL(wide_filter_kernel, dim3(std::min(div_up(n_items, 256), 64), n), dim3(256), 0, s, scores, ids_in.ptr, n_items,
                            users, seen_ptr, seen_idx, allowed, remove_seen);
         size_t bytes = 0;
-        MI_HIP(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(nullptr, bytes, scores, keys_out.ptr, ids_in.ptr, ids_out.ptr, (int)total,
+        MI_HIP(rocprim::segmented_radix_sort_pairs_desc(nullptr, bytes, scores, keys_out.ptr, ids_in.ptr, ids_out.ptr, (int)total,
                                                                      n, offsets.ptr, offsets.ptr + 1, 0, 32, s));
         if (tmp.count < bytes) tmp.alloc(bytes + 256);
         bytes = tmp.count;
-        MI_HIP(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(tmp.ptr, bytes, scores, keys_out.ptr, ids_in.ptr, ids_out.ptr, (int)total,
+        MI_HIP(rocprim::segmented_radix_sort_pairs_desc(tmp.ptr, bytes, scores, keys_out.ptr, ids_in.ptr, ids_out.ptr, (int)total,
                                                                      n, offsets.ptr, offsets.ptr + 1, 0, 32, s));
         hipLaunchKernelGGL(wide_emit_kernel, dim3(std::min(div_up(cutoff, 256), 64), n), dim3(256), 0, s, keys_out.ptr, ids_out.ptr, n_items,
                            cutoff, ranked);
@@ -287,7 +347,7 @@ extern "C" int mi355rec_scorer_recommend(mi355rec_scorer_t h, const int32_t *use
         sp.n_users = h->n_users; sp.n_items = h->n_items; sp.k = h->k; sp.use_bias = h->use_bias;
         sp.U = h->U.ptr; sp.V = h->V.ptr; sp.bu = h->bu.ptr; sp.bi = h->bi.ptr; sp.mu = h->mu;
         sp.users = h->users.ptr; sp.n_batch = n; sp.scores = h->scores.ptr;
-        hipExtLaunchKernelGGL(score_gemm_kernel, dim3(div_up(h->n_items, 128), div_up(n, 32)), dim3(256), 0, s, h->gemm_timer.t0,
+        hipExtLaunchKernelGGL(score_gemm_kernel, dim3(div_up(h->n_items, TN), div_up(n, TM)), dim3(256), 0, s, h->gemm_timer.t0,
                               h->gemm_timer.t1, 0, sp);
         if (fits_lds_rank(h->n_items, cutoff)) {
             RankParams rp{};

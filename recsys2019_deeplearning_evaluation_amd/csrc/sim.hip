@@ -16,7 +16,7 @@
 #include "common.h"
 #include "topk.cuh"
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <memory>
@@ -965,6 +965,8 @@ struct mi355rec_sim {
     std::vector<int> cost_order;   // all columns, most expensive first
     int group_lanes = 64;
     double fixed_scale = 0.0;      // real-valued data: power-of-two scale of the int64 fixed-point accumulator (0: float64 sums)
+    bool wide_topk = false;
+    double wide_kernel_ms = -1.0, wide_call_ms = 0.0;   // >= 0 after a build with topK > MAX_TOPK (several launches: the event pair of the last one is not the build)
     int int_shift = -1;            // >= 0: every stored value times 2^int_shift is a small integer -> exact int32 sums (ACC_INT32)
     int acc_mode() const { return unit_values && !row_w.ptr ? ACC_COUNTS : (int_shift >= 0 ? ACC_INT32 : ACC_WIDE); }
     mi355rec_stats stats{};
@@ -1026,7 +1028,133 @@ inline int part_of_position(long long pos, int n_parts) {
 
 // Runs the column kernel for [start,end) -- or, with n_parts > 0, for part `start` of `n_parts` interleaved parts -- leaving
 // results in d_idx/d_val (or d_dense when topK == 0).
+void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, float *d_dense, int n_parts);
+
+// valid after the stream has been synchronised past the last build
+void read_timers(mi355rec_sim *h) {
+    if (h->wide_kernel_ms >= 0.0) {
+        h->stats.kernel_ms = h->wide_kernel_ms;
+        h->stats.call_ms = h->wide_call_ms;
+    } else {
+        h->stats.kernel_ms = h->timer.elapsed_ms();
+        h->stats.call_ms = h->call_timer.elapsed_ms();
+    }
+}
+
+// topK beyond the in-LDS selection (MAX_TOPK = 4096 candidates): the reference only clamps topK to n_cols (.pyx:146).  The columns
+// are built DENSE into HBM (the kernel's topK == 0 path), every column is sorted by descending value with one segmented radix sort
+// (rocPRIM; stable: equal values keep ascending neighbour ids, the in-LDS path's tie rule) and the K largest cells of the full
+// column -- zeros compete, then are dropped (.pyx:523-555) -- are emitted.  Blocks of columns bound the scratch memory.
+__global__ __launch_bounds__(256) void wide_topk_emit_kernel(const float *sorted_val, const int *sorted_id, int n_cols, int topK, int *out_idx,
+                                                             float *out_val) {
+    __shared__ int s_npos, s_nnonneg;
+    const float *val = sorted_val + (size_t)blockIdx.x * n_cols;
+    const int *id = sorted_id + (size_t)blockIdx.x * n_cols;
+    if (threadIdx.x < 2) {           // first position whose value is <= 0 (thread 0) / < 0 (thread 1): descending order
+        int lo = 0, hi = n_cols;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const bool before = threadIdx.x == 0 ? val[mid] > 0.f : val[mid] >= 0.f;
+            if (before) lo = mid + 1; else hi = mid;
+        }
+        if (threadIdx.x == 0) s_npos = lo; else s_nnonneg = lo;
+    }
+    __syncthreads();
+    const int npos = s_npos, nzero = s_nnonneg - s_npos;
+    const int take_pos = min(topK, npos), take_neg = max(0, min(topK - npos - nzero, n_cols - npos - nzero));
+    int *oi = out_idx + (size_t)blockIdx.x * topK;
+    float *ov = out_val + (size_t)blockIdx.x * topK;
+    for (int r = threadIdx.x; r < topK; r += 256) {
+        int src = -1;
+        if (r < take_pos) src = r;
+        else if (r < take_pos + take_neg) src = npos + nzero + (r - take_pos);
+        oi[r] = src >= 0 ? id[src] : -1;
+        ov[r] = src >= 0 ? val[src] : 0.f;
+    }
+}
+
+__global__ void wide_iota_kernel(int *ids, unsigned *offsets, int n_rows, int n_cols) {
+    const size_t n = (size_t)n_rows * n_cols;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) ids[e] = (int)(e % n_cols);
+    for (size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x; r <= (size_t)n_rows; r += (size_t)gridDim.x * blockDim.x)
+        offsets[r] = (unsigned)(r * n_cols);
+}
+
+void run_columns_wide_topk(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, int n_parts) {
+    const int topK = h->cfg.topK, n_cols = h->n_cols;
+    // rows of the output, in output order: a contiguous range, or one interleaved part (whose rows the kernel places by out_slot)
+    int n_local = end - start;
+    if (n_parts > 0) {
+        n_local = 0;
+        for (long long pos = 0; pos < n_cols; ++pos) n_local += part_of_position(pos, n_parts) == start;
+    }
+    const size_t cells_cap = (size_t)1 << 30;                                   // 4 GiB per float buffer
+    int block = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_local, cells_cap / (size_t)n_cols));
+    if (n_parts > 0 && block < n_local)
+        fail(MI355REC_E_UNSUPPORTED, "topK = %d > %d with interleaved parts needs %d x %d dense cells at once", topK, MAX_TOPK, n_local, n_cols);
+    DeviceBuffer<float> dense, sorted_val;
+    DeviceBuffer<int> ids, sorted_id;
+    DeviceBuffer<unsigned> offsets;
+    DeviceBuffer<unsigned char> tmp;
+    dense.alloc((size_t)block * n_cols); sorted_val.alloc((size_t)block * n_cols);
+    ids.alloc((size_t)block * n_cols); sorted_id.alloc((size_t)block * n_cols);
+    offsets.alloc((size_t)block + 1);
+    hipStream_t s = h->stream;
+    hipLaunchKernelGGL(wide_iota_kernel, dim3(4096), dim3(256), 0, s, ids.ptr, offsets.ptr, block, n_cols);
+    size_t tmp_bytes = 0;
+    MI_HIP(rocprim::segmented_radix_sort_pairs_desc(nullptr, tmp_bytes, dense.ptr, sorted_val.ptr, ids.ptr, sorted_id.ptr,
+                                                    (unsigned)((size_t)block * n_cols), (unsigned)block, offsets.ptr, offsets.ptr + 1, 0, 32, s));
+    tmp.alloc(tmp_bytes + 256);
+    const mi355rec_sim_config saved = h->cfg;
+    double kernel_ms = 0, units = 0, bytes = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    MI_HIP(hipEventCreate(&t0));
+    MI_HIP(hipEventCreate(&t1));
+    MI_HIP(hipEventRecord(t0, s));
+    try {
+        for (int done = 0; done < n_local; done += block) {
+            const int here = std::min(block, n_local - done);
+            h->cfg.topK = 0;
+            if (n_parts > 0) run_columns_lds(h, start, 0, nullptr, nullptr, dense.ptr, n_parts);
+            else run_columns_lds(h, start + done, start + done + here, nullptr, nullptr, dense.ptr, 0);
+            h->cfg = saved;
+            MI_HIP(hipStreamSynchronize(s));
+            kernel_ms += h->timer.elapsed_ms();
+            units += h->stats.n_units;
+            bytes += h->stats.algorithmic_bytes;
+            size_t bytes_now = tmp_bytes;
+            MI_HIP(rocprim::segmented_radix_sort_pairs_desc(tmp.ptr, bytes_now, dense.ptr, sorted_val.ptr, ids.ptr, sorted_id.ptr,
+                                                            (unsigned)((size_t)here * n_cols), (unsigned)here, offsets.ptr, offsets.ptr + 1, 0, 32, s));
+            hipLaunchKernelGGL(wide_topk_emit_kernel, dim3(here), dim3(256), 0, s, sorted_val.ptr, sorted_id.ptr, n_cols, topK,
+                               d_idx + (size_t)done * topK, d_val + (size_t)done * topK);
+            MI_HIP(hipGetLastError());
+        }
+    } catch (...) {
+        h->cfg = saved;
+        (void)hipEventDestroy(t0);
+        (void)hipEventDestroy(t1);
+        throw;
+    }
+    // the handle's timers are read by the callers after this returns: make them cover the whole wide build
+    MI_HIP(hipEventRecord(t1, s));
+    MI_HIP(hipStreamSynchronize(s));
+    float whole_ms = 0.f;
+    MI_HIP(hipEventElapsedTime(&whole_ms, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    h->wide_kernel_ms = kernel_ms;
+    h->wide_call_ms = whole_ms;
+    h->stats.n_units = (int64_t)units;
+    h->stats.algorithmic_bytes = bytes + 8.0 * (double)n_local * topK;
+}
+
 void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, float *d_dense, int n_parts = 0) {
+    h->wide_kernel_ms = -1.0;
+    if (!d_dense && h->wide_topk && h->cfg.topK > 0) run_columns_wide_topk(h, start, end, d_idx, d_val, n_parts);
+    else run_columns_lds(h, start, end, d_idx, d_val, d_dense, n_parts);
+}
+
+void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, float *d_dense, int n_parts) {
     const int part = start;
     std::vector<int> slot_host;
     int n_local = end - start;
@@ -1219,9 +1347,7 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         std::unique_ptr<mi355rec_sim> h(new mi355rec_sim());
         h->cfg = *cfg;
         h->cfg.topK = std::min(cfg->topK, n_cols);  // .pyx:146
-        if (h->cfg.topK > MAX_TOPK)
-            fail(MI355REC_E_UNSUPPORTED, "topK = %d exceeds the in-LDS selection limit of %d (use topK=0 for the dense build)",
-                 h->cfg.topK, MAX_TOPK);
+        // (topK > MAX_TOPK, the in-LDS selection's candidate buffer: dense columns + segmented sort, run_columns_wide_topk)
         const bool set_based = cfg->similarity == MI355REC_SIM_JACCARD || cfg->similarity == MI355REC_SIM_DICE ||
                                cfg->similarity == MI355REC_SIM_TVERSKY;
         if (set_based) h->cfg.normalize = 0;  // .pyx:124-135
@@ -1310,9 +1436,8 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         const int max_tile = h->acc_mode() != ACC_WIDE ? MAX_TILE : MAX_TILE_F64;
         h->tile_w = n_cols <= max_tile ? ((n_cols + 3) & ~3) : max_tile;
         h->n_tiles = (n_cols + h->tile_w - 1) / h->tile_w;
-        if ((long long)h->n_tiles * h->cfg.topK > h->tile_w)
-            fail(MI355REC_E_UNSUPPORTED, "n_cols = %d with topK = %d: the per-tile candidates (%d x %d) do not fit the merge buffer",
-                 n_cols, h->cfg.topK, h->n_tiles, h->cfg.topK);
+        // topK beyond the in-LDS selection, or per-tile candidates (n_tiles x topK) beyond the merge buffer: dense columns + segmented sort
+        h->wide_topk = h->cfg.topK > MAX_TOPK || (long long)h->n_tiles * h->cfg.topK > h->tile_w;
         DeviceBuffer<float> row_mean;
         if (cfg->similarity == MI355REC_SIM_ADJUSTED) {
             row_mean.alloc((size_t)n_rows);
@@ -1345,10 +1470,10 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         int key_bits = 1;
         while ((1ll << key_bits) < (long long)n_cols) ++key_bits;
         size_t tmp_bytes = 0;
-        MI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, pos_in.ptr, pos_out.ptr,
+        MI_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, pos_in.ptr, pos_out.ptr,
                                                   (int)nnz, 0, key_bits, s));
         sort_tmp.alloc(tmp_bytes);
-        MI_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp.ptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, pos_in.ptr, pos_out.ptr,
+        MI_HIP(rocprim::radix_sort_pairs(sort_tmp.ptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, pos_in.ptr, pos_out.ptr,
                                                   (int)nnz, 0, key_bits, s));
         hipLaunchKernelGGL(csc_ptr_kernel, dim3(div_up(n_cols + 1, 256)), dim3(256), 0, s, key_out.ptr, nnz, n_cols, h->csc_ptr.ptr);
         hipLaunchKernelGGL(gather_csc_kernel, dim3(eg), dim3(eb), 0, s, pos_out.ptr, row_of.ptr, h->csr_val.ptr, nnz,
@@ -1372,9 +1497,9 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
             hipLaunchKernelGGL(seg_len_kernel, dim3(div_up(n_seg + 1, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->row_tile_ptr.ptr,
                                n_rows, h->n_tiles, len_pad.ptr);
             size_t scan_bytes = 0;
-            MI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, (int)(n_seg + 1), s));
+            MI_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, 0, (size_t)(n_seg + 1), rocprim::plus<int>(), s));
             scan_tmp.alloc(scan_bytes);
-            MI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp.ptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, (int)(n_seg + 1), s));
+            MI_HIP(rocprim::exclusive_scan(scan_tmp.ptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, 0, (size_t)(n_seg + 1), rocprim::plus<int>(), s));
             const size_t seg_cap = nnz + 7 * (size_t)n_seg + 520;     // every segment grows by at most 7 entries
             MI_REQUIRE(seg_cap < (size_t)INT32_MAX, "matrix too large for 32-bit segment offsets");
             h->seg_idx16.alloc_zero(seg_cap, s);
@@ -1522,7 +1647,7 @@ extern "C" int mi355rec_sim_compute(mi355rec_sim_t h, int32_t start_col, int32_t
         h->out_idx.download(nbr_idx, n, h->stream);
         h->out_val.download(nbr_val, n, h->stream);
         MI_HIP(hipStreamSynchronize(h->stream));
-        h->stats.kernel_ms = h->timer.elapsed_ms(), h->stats.call_ms = h->call_timer.elapsed_ms();
+        read_timers(h);
         if (h->phase_ticks.ptr && getenv("MI355REC_SIM_PHASES")) {
             unsigned long long t[8];
             h->phase_ticks.download(t, 8, h->stream);
@@ -1558,10 +1683,10 @@ extern "C" int mi355rec_sim_compute_csr(mi355rec_sim_t h, int32_t start_col, int
         int key_bits = 1;
         while ((1ll << key_bits) < (long long)h->n_cols + 1) ++key_bits;
         size_t tmp_bytes = 0;
-        MI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->csr_key.ptr, h->csr_key_sorted.ptr, h->csr_pos.ptr,
+        MI_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->csr_key.ptr, h->csr_key_sorted.ptr, h->csr_pos.ptr,
                                                   h->csr_pos_sorted.ptr, (int)n, 0, key_bits, s));
         if (h->csr_sort_tmp.count < tmp_bytes) h->csr_sort_tmp.alloc(tmp_bytes);
-        MI_HIP(hipcub::DeviceRadixSort::SortPairs(h->csr_sort_tmp.ptr, tmp_bytes, h->csr_key.ptr, h->csr_key_sorted.ptr,
+        MI_HIP(rocprim::radix_sort_pairs(h->csr_sort_tmp.ptr, tmp_bytes, h->csr_key.ptr, h->csr_key_sorted.ptr,
                                                   h->csr_pos.ptr, h->csr_pos_sorted.ptr, (int)n, 0, key_bits, s));
         // indptr[r] = first sorted position whose key is >= r; indptr[n_cols] = number of real entries (padding sorts last)
         hipLaunchKernelGGL(csc_ptr_kernel, dim3(div_up(h->n_cols + 1, 256)), dim3(256), 0, s, h->csr_key_sorted.ptr, n, h->n_cols,
@@ -1576,7 +1701,7 @@ extern "C" int mi355rec_sim_compute_csr(mi355rec_sim_t h, int32_t start_col, int
         h->csr_indices.download(indices, nnz, s);
         h->csr_data.download(data, nnz, s);
         MI_HIP(hipStreamSynchronize(s));
-        h->stats.kernel_ms = h->timer.elapsed_ms(), h->stats.call_ms = h->call_timer.elapsed_ms();
+        read_timers(h);
     });
 }
 
@@ -1605,7 +1730,7 @@ extern "C" int mi355rec_sim_compute_dense(mi355rec_sim_t h, int32_t start_col, i
         MI_HIP(hipMemcpy2DAsync(W, (size_t)ld * sizeof(float), slab_t.ptr, (size_t)n_local * sizeof(float),
                                 (size_t)n_local * sizeof(float), (size_t)h->n_cols, hipMemcpyDeviceToHost, h->stream));
         MI_HIP(hipStreamSynchronize(h->stream));
-        h->stats.kernel_ms = h->timer.elapsed_ms(), h->stats.call_ms = h->call_timer.elapsed_ms();
+        read_timers(h);
     });
 }
 
@@ -1638,7 +1763,7 @@ extern "C" int mi355rec_sim_sync(mi355rec_sim_t h) {
     return guarded([&] {
         MI_REQUIRE(h, "NULL handle");
         MI_HIP(hipStreamSynchronize(h->stream));
-        if (h->last_start >= 0) h->stats.kernel_ms = h->timer.elapsed_ms(), h->stats.call_ms = h->call_timer.elapsed_ms();
+        if (h->last_start >= 0) read_timers(h);
     });
 }
 

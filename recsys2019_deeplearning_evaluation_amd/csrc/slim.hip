@@ -26,7 +26,7 @@
 #include "sampling.cuh"
 #include "topk.cuh"
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <memory>
@@ -770,9 +770,9 @@ void ensure_sort_capacity(mi355rec_slim *h, size_t n) {
     if (h->cell_capacity >= n) return;
     h->keys.alloc(n); h->keys_sorted.alloc(n); h->vals.alloc(n); h->vals_sorted.alloc(n); h->pred.alloc(n);
     size_t sort_bytes = 0, scan_bytes = 0;
-    MI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr, h->vals_sorted.ptr,
+    MI_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr, h->vals_sorted.ptr,
                                               (int)n, 0, 64, h->stream));
-    MI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, h->len2.ptr, h->cellptr.ptr, (int)h->stream_capacity + 1, h->stream));
+    MI_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, h->len2.ptr, h->cellptr.ptr, 0ll, h->stream_capacity + 1, rocprim::plus<long long>(), h->stream));
     h->cub_tmp.alloc(std::max(sort_bytes, scan_bytes) + 256);
     h->cell_capacity = n;
 }
@@ -810,13 +810,13 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile, int first = 0) {
     d.seq = h->seq.ptr; d.len2 = h->len2.ptr; d.cellptr = h->cellptr.ptr; d.pred = h->pred.ptr;
     hipLaunchKernelGGL(slim_item_keys_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d);
     size_t bytes = h->cub_tmp.count;
-    MI_HIP(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr, h->vals_sorted.ptr,
+    MI_HIP(rocprim::radix_sort_pairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr, h->vals_sorted.ptr,
                                               2 * n, 0, 32 + bits_for((unsigned long long)h->n_items), s));
     hipLaunchKernelGGL(slim_seq_kernel, dim3(div_up(2 * n, 256)), dim3(256), 0, s, d);
     // profile lengths -> cell slots (also the algorithmic byte count of the call)
     MI_HIP(hipMemsetAsync(h->len2.ptr + n, 0, sizeof(int), s));
     bytes = h->cub_tmp.count;
-    MI_HIP(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp.ptr, bytes, h->len2.ptr, h->cellptr.ptr, n + 1, s));
+    MI_HIP(rocprim::exclusive_scan(h->cub_tmp.ptr, bytes, h->len2.ptr, h->cellptr.ptr, 0ll, (size_t)(n + 1), rocprim::plus<long long>(), s));
     long long n_cells = 0;
     MI_HIP(hipMemcpyAsync(&n_cells, h->cellptr.ptr + n, sizeof(long long), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
@@ -829,7 +829,7 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile, int first = 0) {
         d.n_cells = n_cells;
         hipLaunchKernelGGL(slim_cell_keys_kernel, dim3(div_up(n, 4)), dim3(256), 0, s, d);
         bytes = h->cub_tmp.count;
-        MI_HIP(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr,
+        MI_HIP(rocprim::radix_sort_pairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr,
                                                   h->vals_sorted.ptr, (int)n_cells, 0, 64, s));
         hipLaunchKernelGGL(slim_pred_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, s, d);
         fill_params(h, p);          // (the sort buffers may have been re-allocated)

@@ -42,7 +42,11 @@ class MatrixFactorization_MI355X_Epoch:
         if algorithm_name == "ASY_SVD":
             assert batch_size == 1, "Batch size other than 1 not supported for ASY_SVD"
         if precision == "auto":
-            precision = "fp32" if sgd_mode == "sgd" else "fp64"
+            # plain sgd on mini-batches holds the 1e-5 bar in float32; the adaptive optimisers need float64 state (see above), and so
+            # does ASY_SVD: an epoch is nnz + 1 strictly sequential steps that each rewrite a whole profile of rows, so float32
+            # rounding compounds a million times per epoch (element-wise error 2e-6 of max|Y| after ONE ML-1M epoch) -- and the
+            # ordered kernel is latency-bound, not bandwidth-bound, so the wider type costs nothing
+            precision = "fp32" if sgd_mode == "sgd" and algorithm_name != "ASY_SVD" else "fp64"
         if precision not in N.PRECISION_CODES:
             raise ValueError("Value for 'precision' not recognized. Acceptable values are {}, provided was '{}'".format(
                 ["auto"] + list(N.PRECISION_CODES), precision))

@@ -282,6 +282,79 @@ def sharded_ials_epoch(epoch_object, dist, rank, world, user_ranges, item_ranges
     allgather_rows(V, item_ranges, rank, dist)
 
 
+class ShardedIALSEpoch:
+    """IALS epochs with the row solves of each half-step split over the ranks, as a reusable object (BASELINE config 5: "user-sharded
+    across 8 x MI355X").  Every rank holds an identical IALS_MI355X_Epoch; per half-step a rank solves its cost-balanced range of
+    rows (cost = L k^2 + k^3 / 3), stages them in a send slab, ONE all-gather of fixed-size slabs (the widest range, float64) and
+    the other ranks' rows are copied into place, so that every rank holds the whole factor matrix again (the next half-step's
+    Gramian is recomputed locally from it, IALSRecommender.py:141,156).  Buffers are raw device allocations of libmi355rec.so,
+    made once; the transport is an rccl_direct.RcclCommunicator (`comm`, no PyTorch in the process) or torch.distributed (`dist`:
+    "nccl" = RCCL device to device over xGMI, "gloo" staged through the host for the CPU-side tests)."""
+
+    def __init__(self, epoch_object, confidence_csr, dist=None, rank=0, world=1, comm=None):
+        from . import _native as N
+        self._N = N
+        self.epoch, self.dist, self.comm, self.rank, self.world = epoch_object, dist, comm, rank, world
+        assert world == 1 or (dist is None) != (comm is None), "exactly one transport: torch.distributed (dist) or RcclCommunicator (comm)"
+        self.k = epoch_object.num_factors
+        self.user_ranges, self.item_ranges = ials_row_ranges(confidence_csr, world, self.k)
+        self.dU, self.dV = epoch_object.device_factor_pointers()
+        if world > 1:
+            widest = max(max(e - s for s, e in self.user_ranges), max(e - s for s, e in self.item_ranges))
+            self.slab_words = 2 * widest * self.k                       # float64 = two 4-byte words
+            self.send = N.DeviceArray(self.slab_words)
+            self.recv = N.DeviceArray(world * self.slab_words)
+            if dist is not None:
+                self.t_send = device_tensor(self.send.address(), (self.slab_words,), "<i4")
+                self.t_recv = device_tensor(self.recv.address(), (world * self.slab_words,), "<i4")
+                self.on_host = dist.get_backend() == "gloo"
+
+    def _copy(self, dst, src, nbytes):
+        import ctypes as C
+        if nbytes:
+            self._N.check(self._N.load().mi355rec_device_memcpy(C.c_void_p(dst), C.c_void_p(src), int(nbytes), 2))
+
+    def _exchange(self, base, ranges):
+        row = 8 * self.k
+        s, e = ranges[self.rank]
+        self._copy(self.send.address(), base + s * row, (e - s) * row)
+        if self.comm is not None:
+            self.comm.all_gather_words(self.send.address(), self.recv.address(), self.slab_words)
+        else:
+            import torch
+            if self.on_host:
+                mine = self.t_send.cpu()
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                self.dist.all_gather(parts, mine)
+                self.t_recv.copy_(torch.cat(parts))
+            else:
+                self.dist.all_gather_into_tensor(self.t_recv, self.t_send)
+            torch.cuda.synchronize()
+        for r, (a, b) in enumerate(ranges):
+            if r != self.rank:
+                self._copy(base + a * row, self.recv.address(r * self.slab_words), (b - a) * row)
+
+    def run_epoch(self):
+        """One epoch; returns when every rank's device holds the complete, updated U and V.  Blocking."""
+        if self.world == 1:
+            self.epoch.run_epochs(1)
+            return
+        self.epoch.user_half(*self.user_ranges[self.rank])
+        self.epoch.synchronize()
+        self._exchange(self.dU, self.user_ranges)
+        self.epoch.item_half(*self.item_ranges[self.rank])
+        self.epoch.synchronize()
+        self._exchange(self.dV, self.item_ranges)
+
+    def exchange_bytes_per_rank_per_epoch(self):
+        return 0 if self.world == 1 else 2 * 4 * self.slab_words
+
+    def close(self):
+        if self.world > 1:
+            self.send.close()
+            self.recv.close()
+
+
 def ials_row_ranges(confidence_csr, world, num_factors):
     """Cost-balanced user and item ranges: cost(row) = L * k^2 (Gramian) + k^3 / 3 (factorisation)."""
     import scipy.sparse as sps

@@ -19,7 +19,7 @@ import numpy as np
 from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_MI355X, IALS_MI355X_Epoch, _native
 from recsys2019_deeplearning_evaluation_amd import MatrixFactorization_MI355X_Epoch
 from recsys2019_deeplearning_evaluation_amd.sharding import (sharded_similarity_build, sharded_ials_epoch, ials_row_ranges,
-                                                           balanced_column_ranges, sharded_bpr_epoch)
+                                                           balanced_column_ranges, sharded_bpr_epoch, ShardedIALSEpoch)
 from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
 torch.cuda.set_device(0); _native.set_device(0)
 dist.init_process_group("gloo")
@@ -45,6 +45,15 @@ for _ in range(2):
     sharded_ials_epoch(shard, dist, rank, world, ur, ir)
 Ud, Vd = shard.get_factors()
 assert np.abs(Ud - Us).max() <= 1e-12 * np.abs(Us).max() and np.abs(Vd - Vs).max() <= 1e-12 * np.abs(Vs).max(), "sharded IALS differs"
+# the same as a reusable object with its buffers allocated once (what bench.py --gpus N times)
+obj_epoch = IALS_MI355X_Epoch(C, k, 1e-2, V0)
+job = ShardedIALSEpoch(obj_epoch, C, dist, rank, world)
+for _ in range(2):
+    job.run_epoch()
+Uo, Vo = obj_epoch.get_factors()
+assert np.abs(Uo - Us).max() <= 1e-12 * np.abs(Us).max() and np.abs(Vo - Vs).max() <= 1e-12 * np.abs(Vs).max(), "ShardedIALSEpoch differs"
+assert job.exchange_bytes_per_rank_per_epoch() > 0
+job.close()
 # exact multi-GPU BPR mini-batches: the tasks of every batch split over the two ranks == the single-process epochs, bit for bit
 kw = dict(n_factors=32, algorithm_name="MF_BPR", batch_size=512, learning_rate=0.05, sgd_mode="sgd", user_reg=0.01, positive_reg=0.02,
           negative_reg=0.03, random_seed=11)

@@ -147,8 +147,32 @@ def test_edge_cases(gpu):
         dev.close()
     with pytest.raises(ValueError):
         Compute_Similarity_MI355X(X, row_weights=[1.0, 2.0])
-    with pytest.raises(NotImplementedError):      # 3 tiles x topK 4096 candidates exceed the merge buffer
-        Compute_Similarity_MI355X(sps.random(4, 90000, 0.01, format="csr", dtype=np.float32, random_state=0), topK=20000)
+
+
+@pytest.mark.parametrize("values,n_cols,topK", [("real", 6000, 5000), ("binary", 70000, 12000)])
+def test_topk_beyond_the_lds_selection(gpu, values, n_cols, topK):
+    """topK > 4096 (the in-LDS selection's candidate buffer) and per-tile candidates beyond the merge buffer: the reference only clamps
+    topK to n_cols (.pyx:146).  Dense columns + one segmented sort per block of columns; same rule (K largest of the full column,
+    zeros compete, then are dropped; ties to the lower id)."""
+    X = synthetic_urm(900, n_cols, 40 * n_cols // 10, 5, 600, seed=14, values=values, zipf_exponent=0.5)
+    dev = Compute_Similarity_MI355X(X, topK=topK, shrink=1, similarity="pearson" if values == "real" else "cosine")
+    rng = np.random.default_rng(6)
+    s = int(rng.integers(0, n_cols - 300))
+    idx, val, s0 = dev.compute_slabs(s, s + 300)
+    assert idx.shape == (300, topK) and s0 == s
+    orc = O.OracleSimilarity(X, topK=0, shrink=1, similarity="pearson" if values == "real" else "cosine")
+    for c in range(s, s + 300, 13):
+        check_topk_against_dense(idx[c - s], val[c - s], orc.column(c)[0], topK, RTOL)
+    if values == "real":                      # the csr_matrix entry point, whole matrix
+        W = dev.compute_similarity()
+        assert W.shape == (n_cols, n_cols)
+        c = s + 7
+        col = np.zeros(n_cols); Wc = W.tocsc()
+        col[Wc.indices[Wc.indptr[c]:Wc.indptr[c + 1]]] = Wc.data[Wc.indptr[c]:Wc.indptr[c + 1]]
+        got = idx[7][idx[7] >= 0]
+        np.testing.assert_allclose(col[got], val[7][:len(got)], rtol=1e-6)
+        assert (col != 0).sum() == len(got)
+    dev.close()
 
 
 def test_itemknn_recommender_end_to_end(gpu):
@@ -550,7 +574,8 @@ def test_quantised_ratings_use_exact_int32_sums(gpu, step, similarity, monkeypat
     kernel and as the oracle; jittered ratings, row_weights and mean-centred similarities stay on the wide cells."""
     monkeypatch.delenv("MI355REC_SIM_F64_SUMS", raising=False)
     X = synthetic_urm(2500, 18000, 260000, 5, 700, seed=31, values="real")       # 18 000 columns: one 4-byte tile, two 8-byte tiles
-    X.data = (np.maximum(1, np.round(X.data / step)) * step).astype(np.float32)
+    X.data = (np.random.default_rng(8).integers(1, int(5 / step) + 1, X.nnz) * step).astype(np.float32)       # step, 2 step, ..., 5.0
+    assert (X.data * (1.0 / step) == np.round(X.data * (1.0 / step))).all() and (step == 1.0 or (X.data != np.round(X.data)).any())
     kw = dict(topK=40, shrink=2, similarity=similarity)
     if similarity == "asymmetric":
         kw["asymmetric_alpha"] = 0.3
