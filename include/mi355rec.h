@@ -109,6 +109,14 @@ typedef struct {
     int32_t feature_weighting;      /* MI355REC_WEIGHT_* */
     int32_t weighting_documents;    /* 0: documents = columns of dataMatrix, 1: documents = rows */
     float   bm25_k1, bm25_b;        /* okapi_BM_25(K1 = 1.2, B = 0.75) */
+    /* How the reference sums the squares behind the column norms, `dataMatrix.power(2).sum(axis=0)` (.pyx:169,
+     * Compute_Similarity_Euclidean.py:112): in the matrix's own dtype -- float32 for a URM -- and in an ORDER that depends on the
+     * sparse format SciPy finds: a CSR matrix is summed as ones @ X, i.e. every column's squares are added one after the other in
+     * row order into a float32 (heavy columns of jittered ratings lose 2e-4 of their norm that way), a CSC matrix by
+     * np.add.reduceat, i.e. first square + NumPy's pairwise float32 sum of the rest.  0: the CSR order (also adjusted cosine,
+     * whose pre-pass returns CSR, .pyx:275); 1: the CSC order (also pearson, whose pre-pass returns CSC, .pyx:234). */
+    int32_t norm_sum_order;
+    int32_t reserved;
 } mi355rec_sim_config;
 
 enum { MI355REC_WEIGHT_NONE = 0, MI355REC_WEIGHT_BM25 = 1, MI355REC_WEIGHT_TFIDF = 2 };

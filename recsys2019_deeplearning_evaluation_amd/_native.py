@@ -41,7 +41,8 @@ class SimConfig(C.Structure):
     _fields_ = [("topK", C.c_int32), ("shrink", C.c_int32), ("normalize", C.c_int32), ("similarity", C.c_int32),
                 ("asymmetric_alpha", C.c_float), ("tversky_alpha", C.c_float), ("tversky_beta", C.c_float),
                 ("unit_column_side", C.c_int32), ("normalize_avg_row", C.c_int32), ("euclidean_mode", C.c_int32),
-                ("feature_weighting", C.c_int32), ("weighting_documents", C.c_int32), ("bm25_k1", C.c_float), ("bm25_b", C.c_float)]
+                ("feature_weighting", C.c_int32), ("weighting_documents", C.c_int32), ("bm25_k1", C.c_float), ("bm25_b", C.c_float),
+                ("norm_sum_order", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MFConfig(C.Structure):

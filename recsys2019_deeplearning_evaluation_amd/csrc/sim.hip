@@ -798,6 +798,46 @@ __global__ void col_center_csc_kernel(const int *csc_ptr, float *csc_val, int n_
     for (int q = csc_ptr[wave] + lane; q < csc_ptr[wave + 1]; q += 64) csc_val[q] -= m;
 }
 
+// numpy_pairwise_sum over the SQUARES of a[0 .. n) (each square rounded to float32 first, like dataMatrix.power(2))
+__device__ float numpy_pairwise_sum_sq(const float *a, int n) {
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; ++i) r = __fadd_rn(r, __fmul_rn(a[i], a[i]));
+        return r;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int j = 0; j < 8; ++j) r[j] = __fmul_rn(a[j], a[j]);
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], __fmul_rn(a[i + j], a[i + j]));
+        float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])), __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+        for (; i < n; ++i) res = __fadd_rn(res, __fmul_rn(a[i], a[i]));
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return __fadd_rn(numpy_pairwise_sum_sq(a, n2), numpy_pairwise_sum_sq(a + n2, n - n2));
+}
+
+// `dataMatrix.power(2).sum(axis=0)` as the reference gets it (.pyx:169): float32 squares, float32 sums, in SciPy's order for the
+// format at hand -- order 0 (CSR: ones @ X): a column's squares one after the other in row order (the CSC view built here keeps
+// each column's cells in row order); order 1 (CSC: np.add.reduceat): first square + NumPy's pairwise sum of the rest.  One thread
+// per column: the additions of a column are a dependent chain by definition (0.3 ms for the longest column at ML-20M shape).
+__global__ void column_sumsq_f32_kernel(const int *csc_ptr, const float *csc_val, int n_cols, int order, double *sumsq) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cols) return;
+    const int s = csc_ptr[c], e = csc_ptr[c + 1];
+    float sum = 0.f;
+    if (order == 0) {
+        for (int q = s; q < e; ++q) sum = __fadd_rn(sum, __fmul_rn(csc_val[q], csc_val[q]));
+    } else if (e > s) {
+        sum = __fmul_rn(csc_val[s], csc_val[s]);
+        if (e - s > 1) sum = __fadd_rn(sum, numpy_pairwise_sum_sq(csc_val + s + 1, e - s - 1));
+    }
+    sumsq[c] = (double)sum;
+}
+
 // sumOfSquared -> norms (.pyx:169-177)
 __global__ void norms_kernel(const double *sumsq, int n_cols, int set_based, int asymmetric, int euclidean, float alpha,
                              float *norm, float *norm_alpha, float *norm_1ma) {
@@ -1513,7 +1553,10 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         sumsq.alloc((size_t)n_cols);
         cost.alloc((size_t)n_cols);
         hipLaunchKernelGGL(column_stats_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_idx.ptr, h->csc_val.ptr,
-                           h->csr_ptr.ptr, n_cols, (float *)nullptr, sumsq.ptr, cost.ptr);
+                           h->csr_ptr.ptr, n_cols, (float *)nullptr, (double *)nullptr, cost.ptr);
+        MI_REQUIRE(cfg->norm_sum_order == 0 || cfg->norm_sum_order == 1, "norm_sum_order must be 0 (CSR order) or 1 (CSC order)");
+        hipLaunchKernelGGL(column_sumsq_f32_kernel, dim3(div_up(n_cols, 64)), dim3(64), 0, s, h->csc_ptr.ptr, h->csc_val.ptr, n_cols,
+                           cfg->norm_sum_order, sumsq.ptr);
         h->norm.alloc_zero((size_t)n_cols + 4, s);
         const bool asym = cfg->similarity == MI355REC_SIM_ASYMMETRIC;
         if (euclid) h->norm_alpha.alloc_zero((size_t)n_cols + 4, s);     // sums of squares

@@ -60,6 +60,10 @@ class Compute_Similarity_MI355X:
         if row_weights is not None and self.n_rows != len(row_weights):
             raise ValueError("Cosine_Similarity: provided row_weights and dataMatrix have different number of rows."
                              "Row_weights has {} rows, dataMatrix has {}.".format(len(row_weights), self.n_rows))
+        # the reference sums the squares behind the norms in float32, in an order that follows the sparse format it is handed
+        # (include/mi355rec.h, norm_sum_order): CSC input and pearson (whose pre-pass converts to CSC) -> NumPy's pairwise reduceat
+        # order, everything else (CSR, the adjusted-cosine pre-pass, ndarray / COO input) -> one square after the other in row order
+        norm_sum_order = 1 if (similarity == "pearson" or (sps.isspmatrix_csc(dataMatrix) and similarity != "adjusted")) else 0
         csr = check_matrix(dataMatrix, "csr", dtype=np.float32)
         if not csr.has_sorted_indices:
             csr = csr.sorted_indices()
@@ -68,7 +72,8 @@ class Compute_Similarity_MI355X:
         cfg = N.SimConfig(self.TopK, int(shrink), int(bool(normalize)), N.SIMILARITY_CODES[similarity],
                           float(asymmetric_alpha), float(tversky_alpha), float(tversky_beta), int(bool(unit_column_side)),
                           int(bool(normalize_avg_row)), N.EUCLIDEAN_MODE_CODES.get(similarity_from_distance_mode, -1),
-                          N.FEATURE_WEIGHTING_CODES[feature_weighting], int(weighting_documents == "rows"), float(K1), float(B))
+                          N.FEATURE_WEIGHTING_CODES[feature_weighting], int(weighting_documents == "rows"), float(K1), float(B),
+                          norm_sum_order, 0)
         assert weighting_documents in ("columns", "rows")
         self._weighted_structure = (csr.indptr, csr.indices, csr.shape) if feature_weighting != "none" else None
         self._lib = N.load()
