@@ -261,24 +261,13 @@ __global__ __launch_bounds__(FLOW_THREADS) void slim_flow_kernel(const SlimParam
         const int rs = p.indptr[u], L = p.indptr[u + 1] - rs;
         const long long cp = SYM ? p.cellptr[t] : 0;
         // profile entries and (symmetric) the last writers of their cells do not depend on anybody: fetch them before waiting
-        // (loads from clamped, always valid addresses, masked afterwards: with a load inside a conditional the compiler waits for
-        // each one where its branch ends -- four serial round trips here, eight for the `done` words below)
         int sv[FLOW_REGS], pa[FLOW_REGS], pb[FLOW_REGS];
 #pragma unroll
         for (int r = 0; r < FLOW_REGS; ++r) {
-            const int idx = tid + r * FLOW_THREADS, at = min(idx, L - 1);        // L >= 1: users without interactions are never drawn
-            sv[r] = p.indices[rs + at];
-            if (SYM) {
-                const int2 pp = *reinterpret_cast<const int2 *>(p.pred + cp + 2 * at);
-                pa[r] = pp.x;
-                pb[r] = pp.y;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < FLOW_REGS; ++r) {
-            const bool live = tid + r * FLOW_THREADS < L;
-            pa[r] = SYM && live ? pa[r] : -1;
-            pb[r] = SYM && live ? pb[r] : -1;
+            const int idx = tid + r * FLOW_THREADS;
+            sv[r] = idx < L ? p.indices[rs + idx] : 0;
+            pa[r] = SYM && idx < L ? p.pred[cp + 2 * idx] : -1;
+            pb[r] = SYM && idx < L ? p.pred[cp + 2 * idx + 1] : -1;
         }
         if (p.use_tickets) {
             if (tid < 2) wait_for(p, &p.ticket[tid ? j : i], p.seq[2 * t + tid], true);
@@ -296,39 +285,24 @@ __global__ __launch_bounds__(FLOW_THREADS) void slim_flow_kernel(const SlimParam
                 oc2_j = aload(&p.c2[j]);
             }
         }
-        // x_uij over the profile (.pyx:243-260).  Every dependent memory round trip of a step is on the epoch's critical path (the
-        // chain of steps through the most popular items / cells), so the loads are issued in BATCHES: first the `done` words of all
-        // last writers of this thread's cells (symmetric store) under one wait -- as a rule they were set long ago and only the
-        // stragglers are polled --, then all of its cells under one wait.  One poll, then one gather per cell in sequence cost up to
-        // 3 x FLOW_REGS round trips per step (the symmetric store's epoch was four times the dense one's).
+        // x_uij over the profile (.pyx:243-260)
         T x = (T)0;
         T va[FLOW_REGS], vb[FLOW_REGS];
-        if (SYM) {
-            int fa[FLOW_REGS], fb[FLOW_REGS];
-#pragma unroll
-            for (int r = 0; r < FLOW_REGS; ++r) {
-                fa[r] = aload(&p.done[max(pa[r], 0)]);
-                fb[r] = aload(&p.done[max(pb[r], 0)]);
-            }
-#pragma unroll
-            for (int r = 0; r < FLOW_REGS; ++r) {
-                if (pa[r] >= 0 && !fa[r]) wait_for(p, &p.done[pa[r]], 1, false);
-                if (pb[r] >= 0 && !fb[r]) wait_for(p, &p.done[pb[r]], 1, false);
-            }
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            asm volatile("" ::: "memory");
-        }
 #pragma unroll
         for (int r = 0; r < FLOW_REGS; ++r) {
-            va[r] = aload(&p.S[cell_at(p, i, sv[r])]);
-            vb[r] = aload(&p.S[cell_at(p, j, sv[r])]);
-        }
-#pragma unroll
-        for (int r = 0; r < FLOW_REGS; ++r) {
-            const bool live = tid + r * FLOW_THREADS < L;
-            va[r] = live ? va[r] : (T)0;
-            vb[r] = live ? vb[r] : (T)0;
-            x += va[r] - vb[r];
+            const int idx = tid + r * FLOW_THREADS;
+            va[r] = (T)0;
+            vb[r] = (T)0;
+            if (idx < L) {
+                if (SYM) {
+                    if (pa[r] >= 0) wait_for(p, &p.done[pa[r]], 1, false);
+                    if (pb[r] >= 0) wait_for(p, &p.done[pb[r]], 1, false);
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                }
+                va[r] = aload(&p.S[cell_at(p, i, sv[r])]);
+                vb[r] = aload(&p.S[cell_at(p, j, sv[r])]);
+                x += va[r] - vb[r];
+            }
         }
         for (int idx = tid + FLOW_REGS * FLOW_THREADS; idx < L; idx += FLOW_THREADS) {    // profiles longer than 1024
             const int s = p.indices[rs + idx];

@@ -16,6 +16,23 @@ urm = load_urm("ml20m")
 if path == "mf":
     m = MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, algorithm_name="MF_BPR", batch_size=BATCH, learning_rate=1e-3, sgd_mode="sgd", random_seed=1)
     m.epochIteration_Cython(2)
+elif path == "mf_group":
+    from recsys2019_deeplearning_evaluation_amd import MatrixFactorization_MI355X_Group
+    rng = np.random.default_rng(0)
+    U0 = rng.normal(0, 0.1, (urm.shape[0], K_FACTORS)).astype(np.float32); V0 = rng.normal(0, 0.1, (urm.shape[1], K_FACTORS)).astype(np.float32)
+    members = [MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, algorithm_name="MF_BPR", batch_size=BATCH, learning_rate=1e-3, sgd_mode="sgd",
+                                                random_seed=200 + r, initial_USER_factors=U0, initial_ITEM_factors=V0) for r in range(32)]
+    g = MatrixFactorization_MI355X_Group(members)
+    g.epochIteration_Cython(2)
+elif path == "asy":
+    from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
+    x1m = named_urm("ml1m", "real")
+    m = MatrixFactorization_MI355X_Epoch(x1m, n_factors=64, algorithm_name="ASY_SVD", batch_size=1, learning_rate=1e-3, sgd_mode="sgd", use_bias=True,
+                                         negative_interactions_quota=0.0, random_seed=1)
+    rng = np.random.default_rng(0)
+    rows = np.repeat(np.arange(x1m.shape[0]), np.diff(x1m.indptr))
+    pick = rng.integers(0, x1m.nnz, 131072)
+    m.replay_samples(rows[pick].astype(np.int32), x1m.indices[pick].astype(np.int32), rating=x1m.data[pick].astype(np.float32))
 elif path == "funk":
     m = MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, algorithm_name="FUNK_SVD", batch_size=BATCH, learning_rate=1e-3, sgd_mode="sgd", use_bias=True, random_seed=1)
     u = np.random.default_rng(0).integers(0, urm.shape[0], 200 * BATCH).astype(np.int32)

@@ -7,7 +7,7 @@ from bench import load_urm, TOPK
 from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_MI355X
 urm = load_urm("ml20m")
 real = urm.copy(); real.data = (1 + (np.arange(real.nnz) % 5)).astype(np.float32)
-for name, X in (("binary (ds_add_u32 counts)", urm), ("ratings 1..5 (int64 fixed-point sums)", real)):
+for name, X in (("binary (ds_add_u32 counts)", urm), ("integer ratings 1..5 (exact int32 sums)", real)):
     s = Compute_Similarity_MI355X(X, topK=TOPK, shrink=0, normalize=True, similarity="cosine")
     s.compute_slabs()
     print("ML-20M shape, cosine, topK=100,", name, flush=True)
