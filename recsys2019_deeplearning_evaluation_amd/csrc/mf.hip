@@ -1230,10 +1230,12 @@ __global__ void mf_final_mu_kernel(const MfParams<T> p, float *out) {
 // and the update, and the loads of a step are issued from clamped addresses in one batch (a load inside a conditional is waited
 // for where its branch ends).  Per step that leaves: one gather round trip (L2), two LDS reductions, the scalar part, the stores.
 constexpr int ASY_KMAX = 256;
-constexpr int ASY_ROWS = 4;      // profile rows per wavefront (64 rows per step) that stay in registers
-template <class T>
+constexpr int ASY_CELLS = 12;    // factors per lane that stay in registers between the gather and the update: C chunks of 64 factors x R rows
+// C = chunks of 64 factors a row needs (1: k <= 64, 2: k <= 128, 4: k <= 256); R = ASY_CELLS / C profile rows per wavefront stay
+// in registers (192 / 96 / 48 rows per step: the mean ML-1M profile has 166; 16 cells spill at float64)
+template <class T, int C>
 __global__ __launch_bounds__(1024) void mf_asy_kernel(const MfParams<T> p, const long long first, const int count) {
-    constexpr int C = ASY_KMAX / 64, R = ASY_ROWS;
+    constexpr int R = ASY_CELLS / C;
     __shared__ T s_part[16][ASY_KMAX];
     __shared__ T s_acc[ASY_KMAX], s_xi[ASY_KMAX];
     __shared__ T s_err, s_pw1, s_pw2;
@@ -1722,8 +1724,13 @@ void enqueue_asy_steps(mi355rec_mf *h, const MfParams<T> &p, long long n_steps, 
         const int count = (int)std::min<long long>(ASY_CHUNK, n_steps - first);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timed) h->dispatch_timers.next(e0, e1, h->max_timed);
-        if (e0) hipExtLaunchKernelGGL(mf_asy_kernel<T>, dim3(1), dim3(1024), 0, h->stream, e0, e1, 0, p, first, count);
-        else hipLaunchKernelGGL(mf_asy_kernel<T>, dim3(1), dim3(1024), 0, h->stream, p, first, count);
+        auto go = [&](auto kernel) {
+            if (e0) hipExtLaunchKernelGGL(kernel, dim3(1), dim3(1024), 0, h->stream, e0, e1, 0, p, first, count);
+            else hipLaunchKernelGGL(kernel, dim3(1), dim3(1024), 0, h->stream, p, first, count);
+        };
+        if (h->k <= 64) go(mf_asy_kernel<T, 1>);
+        else if (h->k <= 128) go(mf_asy_kernel<T, 2>);
+        else go(mf_asy_kernel<T, 4>);
     }
 }
 

@@ -200,16 +200,40 @@ class BaseRecommender(object):
             else:       # (files written by round-1 builds of this package carry no index)
                 index = {os.path.splitext(m)[0]: m for m in names}
             for name, member in index.items():
-                ext = os.path.splitext(member)[1]
-                with z.open(member) as f:
-                    if ext == ".npz":
-                        value = sps.load_npz(io.BytesIO(f.read()))
-                    elif ext == ".npy":
-                        value = np.load(io.BytesIO(f.read()), allow_pickle=False)
-                    else:
-                        value = json.loads(f.read().decode())
-                setattr(self, name, value)
+                loaded, value = self._load_dataio_member(z.read(member), os.path.splitext(member)[1])
+                if loaded:
+                    setattr(self, name, value)
+                else:
+                    self._print("load_model: skipping attribute '{}' (member '{}': format not handled)".format(name, member))
         self._print("Loading complete")
+
+    def _load_dataio_member(self, raw, ext):
+        """One member of a DataIO archive (Base/DataIO.py:102-186 writes .npy / .npz / .json, .csv for DataFrames and a nested .zip
+        for dictionaries whose values need their own members).  Returns (handled, value)."""
+        if ext == ".npz":
+            return True, sps.load_npz(io.BytesIO(raw))
+        if ext == ".npy":
+            return True, np.load(io.BytesIO(raw), allow_pickle=False)
+        if ext == ".json":
+            return True, json.loads(raw.decode())
+        if ext == ".csv":
+            try:
+                import pandas as pd
+            except ImportError:
+                return False, None
+            return True, pd.read_csv(io.BytesIO(raw), index_col=False)
+        if ext == ".zip":
+            value = {}
+            with zipfile.ZipFile(io.BytesIO(raw)) as inner:
+                names = inner.namelist()
+                index_member = next((m for m in (self._DATAIO_INDEX + ".json", "__DataIO_attribute_to_file_name.json") if m in names), None)
+                index = json.loads(inner.read(index_member).decode()) if index_member else {os.path.splitext(m)[0]: m for m in names}
+                for key, member in index.items():
+                    ok, item = self._load_dataio_member(inner.read(member), os.path.splitext(member)[1])
+                    if ok:
+                        value[key] = item
+            return True, value
+        return False, None
 
 
 class BaseMatrixFactorizationRecommender(BaseRecommender):

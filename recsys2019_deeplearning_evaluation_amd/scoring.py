@@ -85,6 +85,16 @@ class GpuScoringMixin:
     _scorer = None
     _scorer_src = None
 
+    def invalidate_scorer(self):
+        """Forget the device copy of the model: the next recommend() uploads USER_factors / ITEM_factors again.  The cache notices
+        REPLACED arrays (identity) and wholesale in-place changes (a strided 256-element fingerprint -- an optimiser step moves
+        practically every cell); code that edits a few rows of a factor matrix in place (folding in cold users, say) must call
+        this.  The package's own training loops call it from _prepare_model_for_validation."""
+        self._scorer_src = None
+        if self._scorer is not None:
+            self._scorer.close()
+            self._scorer = None
+
     def _scorer_sources(self):
         src = [self.USER_factors, self.ITEM_factors]
         if self.use_bias:

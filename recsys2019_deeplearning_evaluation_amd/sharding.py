@@ -116,6 +116,10 @@ class ShardedSimilarityBuild:
             self.widest = max(e - s for s, e in self.ranges)
         self.slab_words = 2 * self.widest * self.topK
         self.local = DeviceArray(self.slab_words)
+        # rows beyond this rank's columns are never written by the kernel but travel in the all-gather: (-1, 0.0) like empty slots
+        from . import _native as N
+        fill = np.concatenate([np.full(self.widest * self.topK, -1, np.int32), np.zeros(self.widest * self.topK, np.int32)])
+        N.check(N.load().mi355rec_device_memcpy(self.local.ptr, N.ptr(fill), 4 * self.slab_words, 1))
         self.gathered = DeviceArray(world * self.slab_words) if world > 1 else self.local
         self._host = np.empty(world * self.slab_words, np.int32)
         if dist is not None and world > 1:
