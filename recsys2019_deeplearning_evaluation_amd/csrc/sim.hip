@@ -837,6 +837,26 @@ __global__ void column_sumsq_f32_kernel(const int *csc_ptr, const float *csc_val
     }
     sumsq[c] = (double)sum;
 }
+// Order 0 for long columns, one WAVEFRONT per column: the chain of float32 additions cannot be split, but its operands can be
+// fetched 64 at a time (coalesced, the next chunk in flight) and handed from lane to lane with v_readlane -- 8 cycles per cell
+// instead of one exposed global load each (13 ms for the 100 000-cell columns of the ML-20M shape with one thread per column).
+// Lanes past the end contribute +0.0f, which leaves a non-negative float32 sum unchanged.
+__global__ __launch_bounds__(256) void column_sumsq_f32_rowwise_kernel(const int *csc_ptr, const float *csc_val, int n_cols, double *sumsq) {
+    const int lane = threadIdx.x & 63;
+    const int c = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
+    if (c >= n_cols) return;
+    const int s = csc_ptr[c], e = csc_ptr[c + 1];
+    float sum = 0.f;
+    float v = s + lane < e ? csc_val[s + lane] : 0.f;
+    for (int q = s; q < e; q += 64) {
+        const float sq = __fmul_rn(v, v);
+        v = q + 64 + lane < e ? csc_val[q + 64 + lane] : 0.f;            // next chunk
+#pragma unroll
+        for (int l = 0; l < 64; ++l)
+            sum = __fadd_rn(sum, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), l)));
+    }
+    if (lane == 0) sumsq[c] = (double)sum;
+}
 
 // sumOfSquared -> norms (.pyx:169-177)
 __global__ void norms_kernel(const double *sumsq, int n_cols, int set_based, int asymmetric, int euclidean, float alpha,
@@ -1555,8 +1575,12 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         hipLaunchKernelGGL(column_stats_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_idx.ptr, h->csc_val.ptr,
                            h->csr_ptr.ptr, n_cols, (float *)nullptr, (double *)nullptr, cost.ptr);
         MI_REQUIRE(cfg->norm_sum_order == 0 || cfg->norm_sum_order == 1, "norm_sum_order must be 0 (CSR order) or 1 (CSC order)");
-        hipLaunchKernelGGL(column_sumsq_f32_kernel, dim3(div_up(n_cols, 64)), dim3(64), 0, s, h->csc_ptr.ptr, h->csc_val.ptr, n_cols,
-                           cfg->norm_sum_order, sumsq.ptr);
+        if (cfg->norm_sum_order == 0)
+            hipLaunchKernelGGL(column_sumsq_f32_rowwise_kernel, dim3(div_up((int64_t)n_cols * 64, 256)), dim3(256), 0, s, h->csc_ptr.ptr,
+                               h->csc_val.ptr, n_cols, sumsq.ptr);
+        else
+            hipLaunchKernelGGL(column_sumsq_f32_kernel, dim3(div_up(n_cols, 64)), dim3(64), 0, s, h->csc_ptr.ptr, h->csc_val.ptr, n_cols,
+                               cfg->norm_sum_order, sumsq.ptr);
         h->norm.alloc_zero((size_t)n_cols + 4, s);
         const bool asym = cfg->similarity == MI355REC_SIM_ASYMMETRIC;
         if (euclid) h->norm_alpha.alloc_zero((size_t)n_cols + 4, s);     // sums of squares
