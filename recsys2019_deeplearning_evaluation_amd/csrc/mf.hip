@@ -15,7 +15,8 @@
 // This version uses (2) as well and turns the batch into ONE gather kernel with no atomics, no flags and no
 // accumulators:
 //   mf_sample_kernel   one thread per sample of the epoch (counter-based RNG, binary-search rejection);
-//   schedule           the epoch's (row, batch) incidences are radix-sorted (hipCUB) into TASKS: one task per row touched
+//   schedule           the epoch's (row, batch) incidences are grouped (in-LDS radix sort per mini-batch, or one rocPRIM sort of
+//                      the whole stream) into TASKS: one task per row touched
 //                      in a batch, holding the list of that batch's samples which touch the row.  Because every
 //                      row's tasks are ordered by batch, the VERSION of a row each sample must read is static: factor
 //                      rows live in two buffers, version v of a row in buffer (v & 1); a task reads version v of
@@ -26,8 +27,11 @@
 //                      loads; a 64-lane wavefront works on 64/LPR samples at a time), own-row gradient summed in
 //                      registers in sample order (deterministic), then mean over batch_size, optimiser, += lr * step,
 //                      one store of the new row version.
-// One dependent launch and three dependent memory round trips per mini-batch (task header -> rows -> store); 12 row
-// transfers per sample instead of 18.  The arithmetic type is the storage type: float32 for plain sgd (north_star),
+// One dependent launch and three dependent memory round trips per mini-batch (task header -> rows -> store).
+// Round 3: rows touched by ONE sample of the mini-batch (most of them) no longer get tasks of their own -- the sample's user
+// task updates them too (fused sample tasks), and neighbouring single-sample tasks share a wavefront (pair tasks): 7 row
+// transfers per sample instead of 12, HBM traffic 1.22 x the algorithmic 24 k bytes (was 1.84 x); mf_group_batch_kernel runs
+// mini-batch b of R independent models as one grid (mi355rec_mf_group_*).  The arithmetic type is the storage type: float32 for plain sgd (north_star),
 // float64 factors + moments for adagrad / rmsprop / adam, whose per-component normalisation amplifies float32 rounding
 // to O(lr); outputs are float32 either way.
 // There is no dense contraction here, hence no MFMA.
@@ -382,10 +386,10 @@ __global__ __launch_bounds__(256) void mf_recs_kernel(const SchedParams s) {
 }
 
 // ---- fast schedule: one workgroup per mini-batch sorts its incidences in LDS -----------------------------------------------
-// The general path above radix-sorts the whole stream (hipCUB picks a merge sort at this size: 120 us for the 417 k incidences
+// The general path above radix-sorts the whole stream (device-wide sort: 120 us for the 417 k incidences
 // of a BPR epoch at ML-20M shape, plus 270 us for the task kernel's dependent searches) -- two thirds of the time of the 139
 // mini-batches it prepares.  When a mini-batch fits LDS and the stream has at most 256 mini-batches the same tasks come out of
-// three short kernels: (1) per mini-batch, a bitonic sort of (row, slot) keys in LDS, run lengths, task slots (lists longer
+// three short kernels: (1) per mini-batch, a stable radix sort of (row, slot) keys in LDS, run lengths, task slots (lists longer
 // than two rounds of one wavefront get the 4 wavefronts of a workgroup: 4 aligned headers), and one bit per (row, mini-batch) in a global bitmap;
 // (2) per incidence, the version parity of each of the sample's rows = parity at stream start + number of earlier
 // mini-batches with the row's bit set; (3) per row, the parity after the stream, bitmap cleared for the next one.

@@ -14,7 +14,7 @@
 //                      the same in-LDS radix-select + bitonic-sort top-K as the similarity build emits the ranking.
 //   wide ranking       catalogues whose score row does not fit LDS (> ~32 k items) and cutoffs above the in-LDS selection limit
 //                      (the reference's default cutoff=None ranks ALL items): rows stay in HBM, a filter kernel writes -inf,
-//                      one segmented radix sort (hipCUB, stable: ties keep the lower item id, like the in-LDS path) orders every
+//                      one segmented radix sort (rocPRIM, stable: ties keep the lower item id, like the in-LDS path) orders every
 //                      row, the first `cutoff` finite entries are the ranking.
 #include "common.h"
 #include "topk.cuh"

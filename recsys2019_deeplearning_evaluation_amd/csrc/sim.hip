@@ -9,7 +9,7 @@
 //
 // Design: one persistent workgroup per CU pulls work items (columns, or parts of heavy
 // columns) from a cost-ordered queue; the per-column accumulator `this_item_weights` lives in LDS (uint32 counts for
-// all-ones data, float64 sums otherwise), the co-occurrence products are accumulated with LDS atomics from a padded
+// all-ones data, exact int32 sums for quantised ratings, int64 fixed-point or float64 sums otherwise), the co-occurrence products are accumulated with LDS atomics from a padded
 // uint16 profile stream, normalised in place and reduced to the top-K by an in-LDS radix select with early exit
 // (bank-replicated histograms) and a counting rank of the survivors.  The URM is read through L2 / Infinity Cache;
 // nothing but the K results per column (and the partial accumulators of split columns) is written to HBM.
