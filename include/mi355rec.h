@@ -330,6 +330,9 @@ int mi355rec_ials_item_half(mi355rec_ials_t h, int32_t i0, int32_t i1);
 int mi355rec_ials_device_factors(mi355rec_ials_t h, double **d_U, double **d_V);
 int mi355rec_ials_sync(mi355rec_ials_t h);
 int mi355rec_ials_get_factors(mi355rec_ials_t h, double *U, double *V);
+/* Schedule of the last half-step: rows whose Gramian was split over several workgroups (profiles longer than 8192 entries: parts of
+ * 4096, the last arriver adds the parts up in part order and solves) and the number of parts (diagnostics). */
+int mi355rec_ials_schedule_info(mi355rec_ials_t h, int32_t *n_split_rows, int32_t *n_parts);
 int mi355rec_ials_get_stats(mi355rec_ials_t h, mi355rec_stats *stats);
 void mi355rec_ials_destroy(mi355rec_ials_t h);
 

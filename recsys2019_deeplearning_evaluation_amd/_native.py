@@ -123,6 +123,7 @@ SIGNATURES = {
     "mi355rec_ials_device_factors": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "mi355rec_ials_sync": (C.c_int, [_vp]),
     "mi355rec_ials_get_factors": (C.c_int, [_vp, _vp, _vp]),
+    "mi355rec_ials_schedule_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "mi355rec_ials_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "mi355rec_ials_destroy": (None, [_vp]),
     "mi355rec_scorer_create": (C.c_int, [C.POINTER(_vp), _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _f32, _vp, _vp]),

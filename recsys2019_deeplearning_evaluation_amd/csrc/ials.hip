@@ -31,8 +31,10 @@ struct IalsParams {
     const double *Y;           // fixed side factors (n_other x k)
     const double *G;           // Y^T Y (k x k)
     double *X;                 // factors being solved (n x k)
-    const int *order;          // rows of this call, longest profile first
-    int n_local;
+    const int4 *items;         // work items of this call, most expensive first: {row, part, n_parts, first part slot}
+    int n_local;               // number of work items
+    double *part_buf;          // [part slots][SLOTS * 4 * ROW_THREADS] partial augmented Gramians of split rows (accumulator layout)
+    unsigned *part_count;      // arrival counters, indexed by the first part slot of a split row
     unsigned *queue;
     unsigned long long *phases;   // optional (MI355REC_IALS_PHASES=1): shader-clock totals of {base, Gramian, Cholesky, back substitution}, rows
 };
@@ -233,8 +235,20 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
         __syncthreads();
         const int slot = s_row;
         if (slot >= p.n_local) break;
-        const int row = p.order[slot];
-        const int beg = p.ptr[row], end = p.ptr[row + 1];
+        const int4 item = p.items[slot];
+        const int row = item.x;
+        int beg = p.ptr[row], end = p.ptr[row + 1];
+        // A row whose Gramian alone would keep one workgroup busy for a large share of the call -- the most popular item at ML-20M
+        // shape: 10^5 profile rows x k^2 on ONE CU = 26 ms, every partition of the item half-step waits for it -- is split: part q of
+        // n accumulates the profile rows [beg, end) below into its own tiles (part 0 starts from YtY + reg I, the others from zero),
+        // publishes them, and the part that arrives last adds the parts up IN PART ORDER (the result does not depend on who is
+        // last) and solves.  Nobody waits for anybody.
+        if (item.z > 1) {
+            const int per = (((end - beg + item.z - 1) / item.z) + CHUNK - 1) / CHUNK * CHUNK;
+            beg = min(end, beg + item.y * per);
+            end = min(end, beg + per);
+        }
+        const bool first_part = item.y == 0;
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         if (p.phases && tid == 0) t0 = ials_stamp();
 
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 double v = 0.0;
-                if (tIs[s] >= 0) {
+                if (tIs[s] >= 0 && first_part) {
                     const int r = 16 * tIs[s] + 4 * i + g, c = 16 * tJs[s] + cl;
                     if (r < k && c < k) v = p.G[(size_t)r * k + c] + (r == c ? p.reg : 0.0);
                     else if (r == c) v = r == k ? AUG_DIAG : 1.0;   // identity padding keeps the factorisation well defined
@@ -329,6 +343,39 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) C[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], C[s], 0, 0, 0);
             }
+        }
+        if (item.z > 1) {
+            constexpr size_t PART_DOUBLES = (size_t)SLOTS * 4 * ROW_THREADS;
+            {
+                double *dst = p.part_buf + (size_t)(item.w + item.y) * PART_DOUBLES;
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dst[(size_t)(s * 4 + i) * ROW_THREADS + tid] = C[s][i];
+            }
+            // every wavefront waits for its own stores; ONE thread then makes them visible device-wide (agent-scope release) and
+            // counts the arrival; the last arriver acquires on behalf of the workgroup (same protocol as the similarity kernel's
+            // split columns)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __threadfence();
+                const bool last = atomicAdd(&p.part_count[item.w], 1u) == (unsigned)(item.z - 1);
+                if (last) __threadfence();
+                s_row = last ? 1 : 0;
+            }
+            __syncthreads();
+            const bool last = s_row != 0;
+            if (!last) continue;
+            const double *src = p.part_buf + (size_t)item.w * PART_DOUBLES;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double v = 0.0;
+                    for (int q = 0; q < item.z; ++q) v += src[(size_t)q * PART_DOUBLES + (size_t)(s * 4 + i) * ROW_THREADS + tid];
+                    C[s][i] = v;
+                }
         }
         if (p.phases && tid == 0) { asm volatile("" ::"v"(C[0][0])); t2 = ials_stamp(); }
 
@@ -473,7 +520,12 @@ struct mi355rec_ials {
     hipStream_t stream = nullptr;
     StreamTimer call_timer;
     DispatchTimers dispatch_timers;
-    DeviceBuffer<int> u_ptr, u_idx, i_ptr, i_idx, order;
+    DeviceBuffer<int> u_ptr, u_idx, i_ptr, i_idx;
+    DeviceBuffer<int4> items;
+    DeviceBuffer<double> part_buf;
+    DeviceBuffer<unsigned> part_count;
+    std::vector<int4> items_host;
+    int n_split_rows = 0, n_part_items = 0;
     DeviceBuffer<float> u_conf, i_conf;
     DeviceBuffer<double> U, V, G;
     DeviceBuffer<unsigned> queue;
@@ -529,6 +581,14 @@ void launch_rows_t(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(ROW_THREADS), (unsigned)lds, h->stream, e0, e1, 0, p);
 }
 
+// SLOTS of the ials_row_kernel instance launch_rows picks for NT lower-triangle tiles (must mirror its switch)
+int row_slots(int NT) {
+    const int need = (NT + ROW_WAVES - 1) / ROW_WAVES;
+    if (need <= 2) return need;
+    if (need <= 12) return (need + 1) / 2 * 2;
+    return need == 13 ? 13 : 15;
+}
+
 void launch_rows(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1) {
     const int KT = (h->k + 1 + 15) / 16, NT = KT * (KT + 1) / 2;
     switch ((NT + ROW_WAVES - 1) / ROW_WAVES) {          // lower-triangle tiles per wavefront
@@ -560,8 +620,53 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
     const int n_local = (int)h->staging.size();
     launch_gram(h, users ? h->V.ptr : h->U.ptr, users ? h->n_items : h->n_users);
     if (n_local == 0) return;
-    MI_HIP(hipMemcpyAsync(h->order.ptr, h->staging.data(), sizeof(int) * n_local, hipMemcpyHostToDevice, h->stream));
+    // Work items, most expensive first.  cost(row) = L k^2 (Gramian) + k^3 / 3 (solve), in units of k^2: L + k / 3.  A row with more
+    // than 2 x PART_ROWS profile entries is split into parts of PART_ROWS (at most 64 parts); the part that arrives last merges and
+    // solves (ials_row_kernel).  The split depends on the row alone -- not on what else the call holds -- so a row-sharded epoch adds
+    // every row up in the same order as the single-GPU epoch.  (MI355REC_IALS_PART_ROWS / MI355REC_IALS_NO_SPLIT: tests.)
+    const int grid_cap = multiprocessor_count();
+    const double solve_cost = h->k / 3.0;
+    int part_rows = 4096;
+    if (getenv("MI355REC_IALS_PART_ROWS")) part_rows = std::max(CHUNK, atoi(getenv("MI355REC_IALS_PART_ROWS")) / CHUNK * CHUNK);
+    const bool may_split = !getenv("MI355REC_IALS_NO_SPLIT");
+    h->items_host.clear();
+    std::vector<std::pair<double, int>> keyed;
+    int part_slots = 0, n_split = 0;
+    for (int r : h->staging) {
+        const int L = ptr[r + 1] - ptr[r];
+        int parts = 1;
+        if (may_split && L > 2 * part_rows) parts = std::min(64, (L + part_rows - 1) / part_rows);
+        if (parts > 1) {
+            for (int q = 0; q < parts; ++q) {
+                keyed.emplace_back((double)L / parts + (q == 0 ? solve_cost : 0.0), (int)h->items_host.size());
+                h->items_host.push_back(make_int4(r, q, parts, part_slots));
+            }
+            part_slots += parts;
+            ++n_split;
+        } else {
+            keyed.emplace_back(L + solve_cost, (int)h->items_host.size());
+            h->items_host.push_back(make_int4(r, 0, 1, 0));
+        }
+    }
+    if (n_split) {
+        std::stable_sort(keyed.begin(), keyed.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+        std::vector<int4> sorted(keyed.size());
+        for (size_t i = 0; i < keyed.size(); ++i) sorted[i] = h->items_host[keyed[i].second];
+        h->items_host.swap(sorted);
+    }
+    const int n_work = (int)h->items_host.size();
+    h->n_split_rows = n_split;
+    h->n_part_items = part_slots;
+    if (h->items.count < (size_t)n_work) h->items.alloc((size_t)n_work + 1024);
+    MI_HIP(hipMemcpyAsync(h->items.ptr, h->items_host.data(), sizeof(int4) * n_work, hipMemcpyHostToDevice, h->stream));
     MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(unsigned), h->stream));
+    if (part_slots) {
+        const int KT_ = (h->k + 1 + 15) / 16, NT_ = KT_ * (KT_ + 1) / 2;
+        const size_t part_doubles = (size_t)row_slots(NT_) * 4 * ROW_THREADS;
+        if (h->part_buf.count < (size_t)part_slots * part_doubles) h->part_buf.alloc((size_t)part_slots * part_doubles);
+        if (h->part_count.count < (size_t)part_slots) h->part_count.alloc((size_t)part_slots);
+        MI_HIP(hipMemsetAsync(h->part_count.ptr, 0, sizeof(unsigned) * part_slots, h->stream));
+    }
     IalsParams p{};
     p.k = h->k;
     p.reg = h->reg;
@@ -571,11 +676,13 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
     p.Y = users ? h->V.ptr : h->U.ptr;
     p.G = h->G.ptr;
     p.X = users ? h->U.ptr : h->V.ptr;
-    p.order = h->order.ptr;
-    p.n_local = n_local;
+    p.items = h->items.ptr;
+    p.n_local = n_work;
+    p.part_buf = h->part_buf.ptr;
+    p.part_count = h->part_count.ptr;
     p.queue = h->queue.ptr;
     p.phases = h->phases.ptr;
-    const int grid = std::min(n_local, multiprocessor_count());
+    const int grid = std::min(n_work, grid_cap);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     h->dispatch_timers.next(e0, e1, 1 << 30);
     launch_rows(h, p, grid, e0, e1);
@@ -663,7 +770,6 @@ extern "C" int mi355rec_ials_create(mi355rec_ials_t *out, int32_t n_users, int32
         if (U0) h->U.upload(U0, nu, s); else h->U.alloc_zero(nu, s);
         h->V.upload(V0, ni, s);
         h->G.alloc((size_t)h->k * h->k);
-        h->order.alloc((size_t)std::max(n_users, n_items));
         h->queue.alloc(1);
         if (getenv("MI355REC_IALS_PHASES")) h->phases.alloc_zero(5, s);
         h->u_ptr_host.assign(indptr, indptr + n_users + 1);
@@ -749,6 +855,14 @@ extern "C" int mi355rec_ials_get_factors(mi355rec_ials_t h, double *U, double *V
         if (U) h->U.download(U, (size_t)h->n_users * h->k, h->stream);
         if (V) h->V.download(V, (size_t)h->n_items * h->k, h->stream);
         MI_HIP(hipStreamSynchronize(h->stream));
+    });
+}
+
+extern "C" int mi355rec_ials_schedule_info(mi355rec_ials_t h, int32_t *n_split_rows, int32_t *n_parts) {
+    return guarded([&] {
+        MI_REQUIRE(h && n_split_rows && n_parts, "NULL argument");
+        *n_split_rows = h->n_split_rows;
+        *n_parts = h->n_part_items;
     });
 }
 

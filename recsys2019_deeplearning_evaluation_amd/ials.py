@@ -67,6 +67,12 @@ class IALS_MI355X_Epoch:
         N.check(self._lib.mi355rec_ials_get_factors(self._h, N.ptr(U), N.ptr(V)))
         return U, V
 
+    def schedule_info(self):
+        """(rows split over several workgroups, parts) of the last half-step."""
+        a, b = C.c_int32(), C.c_int32()
+        N.check(self._lib.mi355rec_ials_schedule_info(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def stats(self):
         st = N.Stats()
         N.check(self._lib.mi355rec_ials_get_stats(self._h, C.byref(st)))

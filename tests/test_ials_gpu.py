@@ -145,6 +145,37 @@ def test_baseline_config_5_ml20m_k200_properties(gpu):
         Bm = UU + Yi.T @ ((c - 1)[:, None] * Yi) + reg * np.eye(k)
         rhs = Yi.T @ c
         assert np.abs(Bm @ V[i] - rhs).max() < 1e-7 * np.abs(rhs).max()
+    assert dev.schedule_info()[0] > 0, "the popular items' rows (profiles beyond 8192 entries) must have been split over workgroups"
     st = dev.stats()
     assert st["algorithmic_flops"] > 0
     dev.close()
+
+
+@pytest.mark.parametrize("k", [8, 40, 200])
+def test_rows_split_over_workgroups_equal_unsplit_rows(gpu, k, monkeypatch):
+    """A row with a long profile is accumulated by several workgroups (parts of its profile, published, added up in part order by
+    the last arriver, which solves).  Forced on a small matrix (parts of 32 profile entries): against the oracle, and against the
+    same epochs with every row on one workgroup."""
+    # k = 200: a smaller matrix and one epoch (the oracle's 200 x 200 solves dominate the test's time on the GPU box's host)
+    X = named_urm("ml1m", "real", scale=0.08 if k == 200 else 0.15)
+    epochs = 1 if k == 200 else 2
+    Cm = O.oracle_ials_confidence(X, "linear", 3.0)
+    Cc = sps.csc_matrix(Cm)
+    V0 = k ** -0.5 * np.random.default_rng(3).random((X.shape[1], k))
+    U = np.zeros((X.shape[0], k)); V = V0.copy()
+    for _ in range(epochs):
+        O.oracle_ials_epoch(Cm, Cc, U, V, 1e-2)
+    monkeypatch.setenv("MI355REC_IALS_PART_ROWS", "32")
+    split = IALS_MI355X_Epoch(Cm, k, 1e-2, V0)
+    split.run_epochs(epochs)
+    n_split, n_parts = split.schedule_info()
+    assert n_split > 20 and n_parts >= 3 * n_split, (n_split, n_parts)
+    Us, Vs = split.get_factors()
+    monkeypatch.delenv("MI355REC_IALS_PART_ROWS")
+    monkeypatch.setenv("MI355REC_IALS_NO_SPLIT", "1")
+    whole = IALS_MI355X_Epoch(Cm, k, 1e-2, V0)
+    whole.run_epochs(epochs)
+    assert whole.schedule_info() == (0, 0)
+    Uw, Vw = whole.get_factors()
+    assert rel_err(Us, U) < 1e-8 and rel_err(Vs, V) < 1e-8
+    assert rel_err(Us, Uw) < 1e-10 and rel_err(Vs, Vw) < 1e-10
