@@ -124,7 +124,8 @@ enum { MI355REC_WEIGHT_NONE = 0, MI355REC_WEIGHT_BM25 = 1, MI355REC_WEIGHT_TFIDF
 typedef struct mi355rec_sim *mi355rec_sim_t;
 
 /* dataMatrix (n_rows x n_cols) as CSR; similarities are computed between its COLUMNS.  row_weights is
- * nullable (length n_rows).  Pre-processing (mean-centring / binarisation / column norms, .pyx:153-192),
+ * nullable (length n_rows; with MI355REC_SIM_EUCLIDEAN it needs n_rows == n_cols, Compute_Similarity_Euclidean.py:174-175, else
+ * MI355REC_E_INVALID).  Pre-processing (mean-centring / binarisation / column norms, .pyx:153-192),
  * the CSR->CSC transposition (.pyx:198-207) and the cost-ordered column schedule are done on the device. */
 int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, int32_t n_rows, int32_t n_cols,
                         const int32_t *csr_indptr, const int32_t *csr_indices, const float *csr_data,

@@ -463,15 +463,23 @@ class OracleSimilarityEuclidean:
     :87-248) in NumPy, in the dtype of the input like the reference (float32 for a URM): squared distances from the
     Gram matrix (:167-172), optional division by the product of the norms (:178-179) and by n_rows (:181-182), square
     root (:184), the three distance -> similarity maps (:186-196), zero diagonal (:202), top-K of the whole column with
-    zeros dropped (:213-224).  row_weights are not restated (the reference's use of them only runs on square inputs,
-    :174-175).  `dense()` returns every column; `compute_similarity()` the csr_matrix the reference returns."""
+    zeros dropped (:213-224).  row_weights (:62-72): the Gram matrix comes from the row-weighted copy of the data (:153) and the
+    distance vector over the COLUMNS is multiplied by the weights of the ROWS (:174-175) -- NumPy only allows that on square inputs
+    and the restatement inherits the error for every other shape.  `dense()` returns every column; `compute_similarity()` the
+    csr_matrix the reference returns."""
 
     MODES = ("lin", "log", "exp")
 
     def __init__(self, dataMatrix, topK=100, shrink=0, normalize=False, normalize_avg_row=False,
-                 similarity_from_distance_mode="lin"):
+                 similarity_from_distance_mode="lin", row_weights=None):
         if similarity_from_distance_mode not in self.MODES:
             raise ValueError("Compute_Similarity_Euclidean: value for parameter 'mode' not recognized.")
+        self.row_weights = None
+        if row_weights is not None:
+            if dataMatrix.shape[0] != len(row_weights):
+                raise ValueError("Compute_Similarity_Euclidean: provided row_weights and dataMatrix have different number of rows.")
+            self.row_weights = row_weights.copy()                                              # (:70)
+            self.X_weighted = dataMatrix.T.dot(sps.diags(self.row_weights)).T                   # (:71-73)
         self.X = dataMatrix.copy()      # the caller's sparse format: float32 summation order depends on it (:44)
         self.n_rows, self.n_columns = self.X.shape
         self.TopK = min(int(topK), self.n_columns)
@@ -483,13 +491,15 @@ class OracleSimilarityEuclidean:
     def columns(self, start, end):
         """Similarity columns [start, end) as an (n_columns, end - start) array of the input dtype."""
         block = self.X[:, start:end].toarray()
-        gram = np.asarray(self.X.T.dot(block))                             # (:156)
+        gram = np.asarray((self.X if self.row_weights is None else self.X_weighted).T.dot(block))      # (:153 / :156)
         out = np.empty_like(gram)
         for k, c in enumerate(range(start, end)):
             d2 = self.sq.copy()
             d2 += self.sq[c]
             d2 -= 2 * gram[:, k]
             d2[c] = 0.0
+            if self.row_weights is not None:
+                d2 = np.multiply(d2, self.row_weights)                     # (:174-175; float64 weights promote the vector)
             if self.normalize:
                 d2 /= self.rt[c] * self.rt
             if self.normalize_avg_row:

@@ -2112,6 +2112,14 @@ void shard_end_typed(mi355rec_mf *h) {
     finish_call(h, per_epoch * B, per_epoch);               // (the loss is this rank's share)
 }
 
+// An error inside an exact multi-GPU epoch ends that epoch: the handle leaves the sharded state, so the next call is refused with
+// "begin_epoch has not been called" (or a plain epoch may follow) instead of continuing on a half-exchanged mini-batch.
+struct ShardEpochGuard {
+    mi355rec_mf *h;
+    bool ok = false;
+    ~ShardEpochGuard() { if (!ok) h->shard_rank = -1; }
+};
+
 }  // namespace
 
 extern "C" int mi355rec_mf_shard_begin_epoch(mi355rec_mf_t h, int32_t rank, int32_t world, void **d_send, void **d_recv,
@@ -2124,6 +2132,7 @@ extern "C" int mi355rec_mf_shard_begin_epoch(mi355rec_mf_t h, int32_t rank, int3
         ensure_device();
         const int tpb = per_sample(h) * h->cfg.batch_size;
         const int wgs = div_up(tpb, 4);
+        ShardEpochGuard guard{h};
         h->shard_rank = rank;
         h->shard_world = world;
         h->shard_slots_per_rank = div_up(wgs, world) * 4;    // whole workgroups: a wide list's four quarters stay together
@@ -2137,6 +2146,7 @@ extern "C" int mi355rec_mf_shard_begin_epoch(mi355rec_mf_t h, int32_t rank, int3
         *d_recv = h->shard_recv.ptr;
         *bytes_per_rank = per_rank;
         *n_batches = (int32_t)h->shard_batches;
+        guard.ok = true;
     });
 }
 
@@ -2145,7 +2155,9 @@ extern "C" int mi355rec_mf_shard_batch(mi355rec_mf_t h, int32_t batch) {
         MI_REQUIRE(h && h->shard_rank >= 0, "mi355rec_mf_shard_begin_epoch has not been called");
         MI_REQUIRE(batch >= 0 && batch < h->shard_batches, "mini-batch %d of %lld", batch, h->shard_batches);
         ensure_device();
+        ShardEpochGuard guard{h};
         if (h->f64) shard_batch_typed<double>(h, batch); else shard_batch_typed<float>(h, batch);
+        guard.ok = true;
     });
 }
 
@@ -2154,7 +2166,9 @@ extern "C" int mi355rec_mf_shard_merge(mi355rec_mf_t h, int32_t batch) {
         MI_REQUIRE(h && h->shard_rank >= 0, "mi355rec_mf_shard_begin_epoch has not been called");
         MI_REQUIRE(batch >= 0 && batch < h->shard_batches, "mini-batch %d of %lld", batch, h->shard_batches);
         ensure_device();
+        ShardEpochGuard guard{h};
         if (h->f64) shard_merge_typed<double>(h, batch); else shard_merge_typed<float>(h, batch);
+        guard.ok = true;
     });
 }
 
@@ -2162,8 +2176,8 @@ extern "C" int mi355rec_mf_shard_end_epoch(mi355rec_mf_t h) {
     return guarded([&] {
         MI_REQUIRE(h && h->shard_rank >= 0, "mi355rec_mf_shard_begin_epoch has not been called");
         ensure_device();
+        ShardEpochGuard guard{h};                            // (ends the sharded state on success too)
         if (h->f64) shard_end_typed<double>(h); else shard_end_typed<float>(h);
-        h->shard_rank = -1;
     });
 }
 

@@ -83,8 +83,13 @@ __device__ __forceinline__ float normalise(const SimParams &p, float v, float no
 // NumPy arithmetic (the dtype of the URM), one operation per statement -- restated with explicitly rounded float32
 // operations so that no multiply-add is contracted.  sq_* = sum of squares of the column, rt_* = its square root.
 // Deviation: a squared distance that rounds below zero is clamped to 0 (the reference takes sqrt of it and emits nan).
-__device__ __forceinline__ float euclidean_cell(const SimParams &p, float dot, float sq_c, float sq_j, float rt_c, float rt_j) {
+// row_weights (:62-72): the dot product is the weighted one (the accumulation multiplies every user's contribution by its weight,
+// = dataMatrix_weighted.T.dot(item_data), :153), and the distance VECTOR over the columns is multiplied element by element by the
+// weights of the ROWS (:174-175) -- defined for square inputs only, where column j meets row j's weight `w_j`.
+__device__ __forceinline__ float euclidean_cell(const SimParams &p, float dot, float sq_c, float sq_j, float rt_c, float rt_j,
+                                                float w_j = 1.f, bool weighted = false) {
     float d2 = __fsub_rn(__fadd_rn(sq_j, sq_c), __fmul_rn(2.f, dot));          // (a-b)^2 = a^2 + b^2 - 2ab   (:167-172)
+    if (weighted) d2 = __fmul_rn(d2, w_j);                                     // :174-175
     if (p.normalize) d2 = __fdiv_rn(d2, __fmul_rn(rt_c, rt_j));                // :178-179
     if (p.avg_row) d2 = __fdiv_rn(d2, (float)p.n_rows);                        // :181-182
     const float d = __fsqrt_rn(fmaxf(d2, 0.f));                                // :184
@@ -509,7 +514,12 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                             v = p.fixed_scale > 0.0 ? (float)((double)(long long)reinterpret_cast<const unsigned long long *>(acc)[j] * p.fixed_inv)
                                                     : (float)acc_d[j];
                             if (euclid) {
-                                v = tile_base + j != c ? euclidean_cell(p, v, sq_c, sqv[k], norm_c, njv[k]) : 0.f;
+                                if (tile_base + j != c) {
+                                    const bool weighted = p.row_w != nullptr;       // (weights always take this accumulator)
+                                    v = euclidean_cell(p, v, sq_c, sqv[k], norm_c, njv[k], weighted ? p.row_w[tile_base + j] : 1.f, weighted);
+                                } else {
+                                    v = 0.f;
+                                }
                                 account(v);
                             } else if (v != 0.f) {
                                 v = normalise(p, v, norm_c, njv[k]);
@@ -1399,8 +1409,11 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         if (euclid) {
             MI_REQUIRE(cfg->euclidean_mode >= MI355REC_EUCLID_LIN && cfg->euclidean_mode <= MI355REC_EUCLID_EXP,
                        "Compute_Similarity_Euclidean: value for parameter 'mode' not recognized (%d)", cfg->euclidean_mode);
-            // the reference multiplies the length-n_cols distance vector by the length-n_rows weights (Euclidean.py:174-175)
-            if (row_weights) fail(MI355REC_E_UNSUPPORTED, "Compute_Similarity_Euclidean: row_weights are not supported");
+            // the reference multiplies the distances to the n_cols columns by the n_rows weights (Euclidean.py:174-175): NumPy refuses
+            // that for any other shape ("operands could not be broadcast together")
+            if (row_weights)
+                MI_REQUIRE(n_rows == n_cols, "Compute_Similarity_Euclidean: row_weights need a square dataMatrix (the reference multiplies the "
+                           "%d column distances by the %d row weights: operands could not be broadcast together)", n_cols, n_rows);
         }
         MI_REQUIRE(cfg->topK >= 0, "topK must be >= 0");
         ensure_device();

@@ -186,9 +186,10 @@ class Compute_Similarity_Euclidean_MI355X(Compute_Similarity_MI355X):
     """Drop-in for Compute_Similarity_Euclidean (Base/Similarity/Compute_Similarity_Euclidean.py:13): same constructor
     keywords and defaults (normalize=False!), same `compute_similarity(start_col, end_col)` and csr_matrix float32
     result.  similarity = 1 / (f(distance) + shrink + 1e-9) with f = identity / log(1 + .) / exp for "lin" / "log" / "exp",
-    every pair of columns has one (no co-occurrence needed), the diagonal is 0.  `row_weights` raise NotImplementedError:
-    the reference multiplies the length-n_cols distance vector by the length-n_rows weights (:174-175), which only
-    runs on square inputs."""
+    every pair of columns has one (no co-occurrence needed), the diagonal is 0.  `row_weights` (:62-72) weight the dot
+    products and multiply the distances to the n_cols columns by the n_rows weights (:174-175), as in the reference; that
+    product only exists for square inputs -- any other shape raises ValueError here, in the constructor, where the reference
+    fails in NumPy's broadcasting inside compute_similarity."""
 
     def __init__(self, dataMatrix, topK=100, shrink=0, normalize=False, normalize_avg_row=False,
                  similarity_from_distance_mode="lin", row_weights=None, feature_weighting="none", weighting_documents="columns",

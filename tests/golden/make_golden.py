@@ -56,6 +56,31 @@ def quiet(fn, *a, **k):
         return fn(*a, **k)
 
 
+def euclidean_row_weights():
+    """Compute_Similarity_Euclidean with row_weights (Compute_Similarity_Euclidean.py:62-72, :153, :174-175): square inputs only
+    (the distances to the n_cols columns are multiplied by the n_rows weights).  float32 and float64 weights (the latter promote
+    the distance vector to float64).  `python make_golden.py euclidean_row_weights` writes this fixture alone."""
+    EUC = ref_loader.load_python_reference("Base.Similarity.Compute_Similarity_Euclidean", "Compute_Similarity_Euclidean")
+    X = small_urm(48, 48, 0.25, 23, real=True)
+    X.data = np.round(X.data)
+    out = pack_csr("X", X)
+    rng = np.random.default_rng(23)
+    out["w64"] = rng.uniform(0.25, 2.0, X.shape[0])
+    out["w32"] = out["w64"].astype(np.float32)
+    cases = []
+    for mode in ("lin", "log", "exp"):
+        for normalize, avg_row, shrink in ((False, False, 0), (True, True, 3)):
+            for w in ("w32", "w64"):
+                cases.append(dict(weights=w, kw=dict(similarity_from_distance_mode=mode, normalize=normalize, normalize_avg_row=avg_row,
+                                                     shrink=shrink)))
+    for n, case in enumerate(cases):
+        kw = dict(case["kw"], row_weights=out[case["weights"]])
+        out["dense_%d" % n] = quiet(lambda: EUC(X, topK=X.shape[1], **kw).compute_similarity()).toarray().astype(np.float32)
+        out["top_%d" % n] = quiet(lambda: EUC(X, topK=5, **kw).compute_similarity()).toarray().astype(np.float32)
+    out["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(HERE, "euclidean_row_weights.npz"), **out)
+
+
 def main():
     assert build_ref.build(), "reference sources not available: run this where /root/reference exists"
     MF, SLIM, SIM = ref_loader.load("mf"), ref_loader.load("slim"), ref_loader.load("sim")
@@ -240,10 +265,14 @@ def main():
     out["densej_0"] = quiet(lambda: EUC(Xj, topK=Xj.shape[1], **cases[0]).compute_similarity()).toarray().astype(np.float32)
     out["cases"] = np.array(json.dumps(cases))
     np.savez_compressed(os.path.join(HERE, "euclidean.npz"), **out)
+    euclidean_row_weights()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["euclidean_row_weights"]:
+        euclidean_row_weights()
+    else:
+        main()

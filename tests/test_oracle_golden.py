@@ -153,3 +153,19 @@ def test_euclidean_oracle_is_bit_exact_with_reference_outputs():
     assert np.array_equal(O.OracleSimilarityEuclidean(Xj, topK=Xj.shape[1], **cases[0]).dense().astype(np.float32), z["densej_0"])
     with pytest.raises(ValueError):
         O.OracleSimilarityEuclidean(X, similarity_from_distance_mode="sqrt")
+
+
+def test_euclidean_oracle_with_row_weights_is_bit_exact_with_reference_outputs():
+    """row_weights (Compute_Similarity_Euclidean.py:62-72, :153, :174-175) on a square matrix, float32 and float64 weights; any other
+    shape fails in NumPy's broadcasting exactly where the reference does."""
+    z, cases = load_golden("euclidean_row_weights")
+    X = unpack_csr(z, "X")
+    assert X.shape[0] == X.shape[1]
+    for n, case in enumerate(cases):
+        kw = dict(case["kw"], row_weights=z[case["weights"]])
+        assert np.array_equal(O.OracleSimilarityEuclidean(X, topK=X.shape[1], **kw).dense().astype(np.float32), z["dense_%d" % n]), case
+        assert np.array_equal(O.OracleSimilarityEuclidean(X, topK=5, **kw).compute_similarity().toarray(), z["top_%d" % n]), case
+    with pytest.raises(ValueError):
+        O.OracleSimilarityEuclidean(X, row_weights=np.ones(X.shape[0] + 1))
+    with pytest.raises(ValueError):                  # 48 column distances times 40 row weights
+        O.OracleSimilarityEuclidean(X[:40], row_weights=np.ones(40)).dense()

@@ -151,6 +151,23 @@ def test_euclidean_bit_exact(ref, mode):
         assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_euclidean_with_row_weights_bit_exact(ref, dtype):
+    """Square inputs only: the reference multiplies the distances to the columns by the weights of the rows (:174-175)."""
+    EUC = ref_loader.load_python_reference("Base.Similarity.Compute_Similarity_Euclidean", "Compute_Similarity_Euclidean")
+    X = synthetic_urm(120, 120, 2600, seed=8, values="real")
+    w = np.random.default_rng(8).uniform(0.1, 3.0, 120).astype(dtype)
+    for kw in (dict(normalize=False, normalize_avg_row=False, shrink=0, similarity_from_distance_mode="lin"),
+               dict(normalize=True, normalize_avg_row=True, shrink=2, similarity_from_distance_mode="log")):
+        want = _quiet(lambda: EUC(X, topK=12, row_weights=w, **kw).compute_similarity()).toarray()
+        got = O.OracleSimilarityEuclidean(X, topK=12, row_weights=w, **kw).compute_similarity().toarray()
+        assert np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        _quiet(lambda: EUC(X[:100], topK=12, row_weights=w[:100]).compute_similarity())
+    with pytest.raises(ValueError):
+        O.OracleSimilarityEuclidean(X[:100], topK=12, row_weights=w[:100]).compute_similarity()
+
+
 def test_package_similarity_matrix_topk_equals_the_reference_function():
     ref_topk = ref_loader.load_python_reference("Base.Recommender_utils", "similarityMatrixTopK")
     if ref_topk is None:

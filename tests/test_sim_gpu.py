@@ -406,6 +406,42 @@ def test_euclidean_golden_fixture(gpu):
     assert rel_err(Wj, z["densej_0"]) < 1e-4
 
 
+@pytest.mark.first_hardware_run("Euclidean row_weights landed after round 3's last GPU call")
+def test_euclidean_row_weights_golden_fixture_and_oracle(gpu):
+    """row_weights (Compute_Similarity_Euclidean.py:62-72): weighted dot products, and the distances to the columns times the weights
+    of the rows (:174-175; square inputs).  The reference's own outputs for float32 and float64 weights (the device works in
+    float32: 1e-5), then a larger square matrix against the oracle incl. a column range."""
+    from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_Euclidean_MI355X
+    z, cases = load_golden("euclidean_row_weights")
+    X = unpack_csr(z, "X")
+    n = X.shape[1]
+    for k, case in enumerate(cases):
+        kw = dict(case["kw"], row_weights=z[case["weights"]])
+        want = z["dense_%d" % k]
+        W = Compute_Similarity_Euclidean_MI355X(X, topK=n, **kw).compute_similarity().toarray()
+        assert (np.diag(W) == 0).all() and ((W != 0) == (want != 0)).all(), case
+        assert rel_err(W, want) < RTOL, (case, rel_err(W, want))
+        idx, val, _ = Compute_Similarity_Euclidean_MI355X(X, topK=5, **kw).compute_slabs()
+        for c in range(n):
+            check_topk_against_dense(idx[c], val[c], want[:, c].astype(np.float64), 5, RTOL)
+    X = synthetic_urm(700, 700, 30000, seed=12, values="real")
+    X.data = np.round(X.data)
+    w = np.random.default_rng(12).uniform(0.2, 2.5, 700).astype(np.float32)
+    kw = dict(shrink=1, normalize=True, normalize_avg_row=True, similarity_from_distance_mode="log", row_weights=w)
+    want = O.OracleSimilarityEuclidean(X, topK=25, **kw).dense().astype(np.float64)
+    idx, val, _ = Compute_Similarity_Euclidean_MI355X(X, topK=25, **kw).compute_slabs()
+    for c in range(700):
+        check_topk_against_dense(idx[c], val[c], want[:, c], 25, RTOL)
+    idx2, val2, _ = Compute_Similarity_Euclidean_MI355X(X, topK=25, **kw).compute_slabs(100, 333)
+    assert (idx2 == idx[100:333]).all() and (val2 == val[100:333]).all()
+    # all-ones data with weights: still the wide accumulator (the count kernel has no weights)
+    Xb = X.copy(); Xb.data[:] = 1.0
+    wantb = O.OracleSimilarityEuclidean(Xb, topK=25, **kw).dense().astype(np.float64)
+    idxb, valb, _ = Compute_Similarity_Euclidean_MI355X(Xb, topK=25, **kw).compute_slabs()
+    for c in range(0, 700, 7):
+        check_topk_against_dense(idxb[c], valb[c], wantb[:, c], 25, RTOL)
+
+
 @pytest.mark.parametrize("values,mode", [("binary", "lin"), ("real", "log"), ("binary", "exp")])
 def test_euclidean_against_the_oracle(gpu, values, mode):
     from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_Euclidean_MI355X
@@ -441,8 +477,10 @@ def test_euclidean_errors_and_knn_recommender(gpu):
     X.data = np.round(X.data)
     with pytest.raises(ValueError):
         Compute_Similarity_Euclidean_MI355X(X, similarity_from_distance_mode="sqrt")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):              # not square: the reference's `item_distance * row_weights` cannot broadcast either
         Compute_Similarity_Euclidean_MI355X(X, row_weights=np.ones(X.shape[0], np.float32))
+    with pytest.raises(ValueError):
+        Compute_Similarity_Euclidean_MI355X(X, row_weights=np.ones(X.shape[0] + 1, np.float32))
     rec = ItemKNNCFRecommender(X.copy(), verbose=False)
     rec.fit(topK=15, shrink=0, similarity="euclidean", normalize=True, normalize_avg_row=False, similarity_from_distance_mode="exp")
     want = O.OracleSimilarityEuclidean(rec.URM_train, topK=15, shrink=0, normalize=True, similarity_from_distance_mode="exp").dense()
