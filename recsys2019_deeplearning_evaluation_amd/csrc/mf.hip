@@ -1461,10 +1461,25 @@ struct mi355rec_mf {
     hipGraphExec_t epoch_graph = nullptr;   // one native epoch: sampler, schedule, n_batches mini-batch kernels
     bool graph_failed = false;
     std::vector<double> host_loss;
+    // Overlapped epochs (MI355REC_MF_OVERLAP=1, see enqueue_epoch_chain): a second set of the buffers a schedule hands to the
+    // mini-batch kernels, so that epoch e + 1 is sampled and scheduled on `side` while the mini-batches of epoch e run on `stream`.
+    DeviceBuffer<int> su2, si2, sj2, used2;
+    DeviceBuffer<float> sr2;
+    DeviceBuffer<TaskHeader> tasks2;
+    DeviceBuffer<int4> recs2;
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> chain_events;
+    hipGraphExec_t chain_graph = nullptr;   // OVERLAP_CHAIN epochs
+    bool chain_graph_failed = false;
+    int last_set = 0;                       // which set holds the samples of the last epoch run
 
     ~mi355rec_mf() {
         if (stream) (void)hipStreamSynchronize(stream);
+        if (side) (void)hipStreamSynchronize(side);
         if (epoch_graph) (void)hipGraphExecDestroy(epoch_graph);
+        if (chain_graph) (void)hipGraphExecDestroy(chain_graph);
+        for (hipEvent_t e : chain_events) (void)hipEventDestroy(e);
+        if (side) (void)hipStreamDestroy(side);
         timer.destroy();
         dispatch_timers.destroy();
         if (stream) (void)hipStreamDestroy(stream);
@@ -1586,10 +1601,11 @@ void launch_group_batch(hipStream_t s, const MfParams<T> *table, int klass, int 
 }
 
 template <class T>
-void launch_sampler(mi355rec_mf *h, const MfParams<T> &p) {
+void launch_sampler(mi355rec_mf *h, const MfParams<T> &p, hipStream_t on = nullptr) {
     const int grid = div_up(p.samples_per_epoch, 256);
-    if (h->cfg.algorithm == MI355REC_MF_BPR) hipLaunchKernelGGL((mf_sample_kernel<MI355REC_MF_BPR, T>), dim3(grid), dim3(256), 0, h->stream, p);
-    else hipLaunchKernelGGL((mf_sample_kernel<MI355REC_MF_FUNK_SVD, T>), dim3(grid), dim3(256), 0, h->stream, p);
+    hipStream_t s = on ? on : h->stream;
+    if (h->cfg.algorithm == MI355REC_MF_BPR) hipLaunchKernelGGL((mf_sample_kernel<MI355REC_MF_BPR, T>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((mf_sample_kernel<MI355REC_MF_FUNK_SVD, T>), dim3(grid), dim3(256), 0, s, p);
 }
 
 int pow2_at_least(int n) {
@@ -1653,9 +1669,10 @@ FastSchedParams fast_sched_params(mi355rec_mf *h, long long n_samples) {
     return f;
 }
 
-void enqueue_fast_schedule(mi355rec_mf *h, long long n_samples, long long n_batches) {
-    hipStream_t s = h->stream;
-    const FastSchedParams f = fast_sched_params(h, n_samples);
+void enqueue_fast_schedule(mi355rec_mf *h, long long n_samples, long long n_batches, const FastSchedParams *given = nullptr,
+                           hipStream_t on = nullptr) {
+    hipStream_t s = on ? on : h->stream;
+    const FastSchedParams f = given ? *given : fast_sched_params(h, n_samples);
     const size_t lds = sched_lds_bytes(f.np);
     static bool attr_set[64] = {};
     set_sched_sort_attribute(reinterpret_cast<const void *>(mf_sched_sort_kernel), attr_set);
@@ -1779,6 +1796,13 @@ void ensure_epoch_graph(mi355rec_mf *h, const MfParams<T> &p) {
     }
 }
 
+void drop_chain_graph(mi355rec_mf *h) {
+    if (h->chain_graph) {
+        (void)hipGraphExecDestroy(h->chain_graph);
+        h->chain_graph = nullptr;
+    }
+}
+
 void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batches) {
     const bool asy = h->cfg.algorithm == MI355REC_MF_ASY_SVD;
     if (h->stream_capacity < n_samples) {
@@ -1786,6 +1810,7 @@ void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batche
             (void)hipGraphExecDestroy(h->epoch_graph);
             h->epoch_graph = nullptr;
         }
+        drop_chain_graph(h);
         h->su.alloc(n_samples);
         h->si.alloc(n_samples);
         h->sj.alloc(n_samples);
@@ -1811,6 +1836,7 @@ void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batche
             (void)hipGraphExecDestroy(h->epoch_graph);
             h->epoch_graph = nullptr;
         }
+        drop_chain_graph(h);
         const size_t tpb = (size_t)per_sample(h) * h->cfg.batch_size;
         h->batch_count.alloc((size_t)n_batches);
         h->tasks.alloc((size_t)(n_batches + 1) * tpb);
@@ -1824,6 +1850,121 @@ void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batche
             if (!h->touched.ptr) h->touched.alloc_zero(((size_t)h->n_users + h->n_items) * (FAST_MAX_BATCHES / 32), h->stream);
         }
         h->batch_capacity = n_batches;
+    }
+}
+
+// ---- overlapped epochs (opt-in: MI355REC_MF_OVERLAP=1) ------------------------------------------------------------------------
+// The sample stream and therefore the whole schedule of an epoch do not depend on the factors, so epoch e + 1 can be sampled and
+// scheduled while the mini-batches of epoch e run.  What a schedule hands to the mini-batch kernels (samples, headers, records,
+// slot counts) exists twice; everything the schedule only uses itself (bitmap, sort output, `par`, MfState.epoch) exists once,
+// because the schedules still run one after the other -- on `side`.  Dependencies of a chain of n epochs:
+//     schedule(e + 1)  after  schedule(e)                  (stream order on `side`)
+//                      after  mini-batches(e - 1)          (they read the set it overwrites)
+//     mini-batches(e)  after  schedule(e), mini-batches(e - 1)
+// Every scheduled epoch of a chain is also run inside it, so `par` and MfState.epoch never run ahead of the factors.  Same kernels,
+// same data: the factors are those of the plain epoch loop bit for bit.
+constexpr int OVERLAP_CHAIN = 8;     // epochs per captured chain (7 of 8 schedules hidden)
+
+void ensure_chain_events(hipStream_t &side, std::vector<hipEvent_t> &events) {
+    if (!side) MI_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    if (events.empty()) {
+        events.assign(1 + 2 * OVERLAP_CHAIN, nullptr);
+        for (auto &e : events) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+}
+
+// the second set of stream / task buffers of one model (sizes follow the first set); true if it was (re-)allocated
+bool ensure_overlap_buffers(mi355rec_mf *h) {
+    if (h->su2.count == h->su.count && h->tasks2.count == h->tasks.count && h->used2.count == h->used.count) return false;
+    {
+        drop_chain_graph(h);
+        MI_HIP(hipStreamSynchronize(h->stream));
+        if (h->side) MI_HIP(hipStreamSynchronize(h->side));
+        h->su2.alloc(h->su.count); h->si2.alloc(h->si.count); h->sj2.alloc(h->sj.count); h->sr2.alloc(h->sr.count);
+        h->tasks2.alloc(h->tasks.count);
+        MI_HIP(hipMemsetAsync(h->tasks2.ptr, 0, sizeof(TaskHeader) * h->tasks.count, h->stream));
+        h->recs2.alloc(h->recs.count);
+        h->used2.alloc(h->used.count);
+        MI_HIP(hipStreamSynchronize(h->stream));
+    }
+    return true;
+}
+
+void ensure_overlap_resources(mi355rec_mf *h) {
+    ensure_chain_events(h->side, h->chain_events);
+    ensure_overlap_buffers(h);
+}
+
+// set 1's pointers in a model's kernel / schedule parameters
+template <class T>
+void use_second_set(const mi355rec_mf *h, MfParams<T> &p, FastSchedParams &f) {
+    p.su = h->su2.ptr; p.si = h->si2.ptr; p.sj = h->sj2.ptr; p.sr = h->sr2.ptr;
+    f.su = h->su2.ptr; f.si = h->si2.ptr; f.sj = h->sj2.ptr; f.sr = h->sr2.ptr;
+    p.tasks = h->tasks2.ptr; f.tasks = h->tasks2.ptr;
+    p.recs = h->recs2.ptr; f.recs = h->recs2.ptr;
+    p.used = h->used2.ptr; f.used = h->used2.ptr;
+}
+
+template <class T>
+void overlap_sets(mi355rec_mf *h, long long n_samples, MfParams<T> (&p)[2], FastSchedParams (&f)[2]) {
+    fill_params(h, p[0]);
+    f[0] = fast_sched_params(h, n_samples);
+    p[1] = p[0];
+    f[1] = f[0];
+    use_second_set(h, p[1], f[1]);
+}
+
+// n <= OVERLAP_CHAIN epochs; capturable (the event records / waits on capturing streams become the graph's edges; `side` is
+// forked from and joined back into the handle's stream).
+template <class T>
+void enqueue_epoch_chain(mi355rec_mf *h, const MfParams<T> (&p)[2], const FastSchedParams (&f)[2], int n) {
+    const long long nb = batches_per_epoch(h);
+    hipStream_t s1 = h->stream, s2 = h->side;
+    hipEvent_t *forked = &h->chain_events[0], *scheduled = &h->chain_events[1], *batches_done = &h->chain_events[1 + OVERLAP_CHAIN];
+    auto schedule = [&](int e) {
+        launch_sampler(h, p[e & 1], s2);
+        enqueue_fast_schedule(h, f[e & 1].n_samples, nb, &f[e & 1], s2);
+        MI_HIP(hipEventRecord(scheduled[e], s2));
+    };
+    MI_HIP(hipEventRecord(*forked, s1));
+    MI_HIP(hipStreamWaitEvent(s2, *forked, 0));
+    schedule(0);
+    for (int e = 0; e < n; ++e) {
+        if (e + 1 < n) {
+            if (e >= 1) {   // everything on s1 so far = the mini-batches up to epoch e - 1, the readers of the set epoch e + 1 overwrites
+                MI_HIP(hipEventRecord(batches_done[e], s1));
+                MI_HIP(hipStreamWaitEvent(s2, batches_done[e], 0));
+            }
+            schedule(e + 1);
+        }
+        MI_HIP(hipStreamWaitEvent(s1, scheduled[e], 0));      // (for e = n - 1 this is also the join of `side`)
+        enqueue_batches(h, p[e & 1], nb, false);
+    }
+}
+
+template <class T>
+void ensure_chain_graph(mi355rec_mf *h, const MfParams<T> (&p)[2], const FastSchedParams (&f)[2]) {
+    if (h->chain_graph || h->chain_graph_failed) return;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+        try {
+            enqueue_epoch_chain(h, p, f, OVERLAP_CHAIN);
+        } catch (...) {
+            (void)hipStreamEndCapture(h->stream, &g);
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            h->chain_graph_failed = true;
+            return;
+        }
+        e = hipStreamEndCapture(h->stream, &g);
+    }
+    if (e == hipSuccess) e = hipGraphInstantiate(&h->chain_graph, g, nullptr, nullptr, 0);
+    if (g) (void)hipGraphDestroy(g);
+    if (e != hipSuccess) {       // plain launches remain correct
+        (void)hipGetLastError();
+        h->chain_graph = nullptr;
+        h->chain_graph_failed = true;
     }
 }
 
@@ -1908,10 +2049,34 @@ void run_epochs_typed(mi355rec_mf *h, int n_epochs) {
         ensure_epoch_graph(h, p);
         use_graph = h->epoch_graph != nullptr;
     }
+    // MI355REC_MF_OVERLAP=1: the untimed epochs run as chains whose schedules overlap the previous epoch's mini-batches
+    const bool overlap = getenv("MI355REC_MF_OVERLAP") && !asy && h->shard_rank < 0 && n_epochs - timed_epochs >= 2 &&
+                         h->fast_schedule && fast_schedule_fits(h, per_epoch);
+    if (const char *want = getenv("MI355REC_MF_OVERLAP"))      // "require": refuse instead of silently running the plain loop
+        MI_REQUIRE(overlap || strcmp(want, "require") != 0 || n_epochs - timed_epochs < 2,
+                   "MI355REC_MF_OVERLAP=require: this model does not run on the in-LDS schedule (ASY_SVD, more than %d mini-batches per epoch, "
+                   "more than %d rows per mini-batch, or inside an exact multi-GPU epoch)", FAST_MAX_BATCHES, FAST_MAX_SLOTS);
+    MfParams<T> po[2];
+    FastSchedParams fo[2];
+    if (overlap) {
+        ensure_overlap_resources(h);
+        overlap_sets<T>(h, per_epoch * B, po, fo);
+        if (use_graph && n_epochs - timed_epochs >= OVERLAP_CHAIN) ensure_chain_graph<T>(h, po, fo);
+    }
+    h->last_set = 0;
     h->timer.start(h->stream);
-    for (long long e = 0; e < n_epochs; ++e) {
-        if (e < timed_epochs || !use_graph) enqueue_epoch(h, p, e < timed_epochs);
-        else MI_HIP(hipGraphLaunch(h->epoch_graph, h->stream));
+    for (long long e = 0; e < n_epochs;) {
+        if (e < timed_epochs || !overlap) {
+            if (e < timed_epochs || !use_graph) enqueue_epoch(h, p, e < timed_epochs);
+            else MI_HIP(hipGraphLaunch(h->epoch_graph, h->stream));
+            ++e;
+            continue;
+        }
+        const int n = (int)std::min<long long>(OVERLAP_CHAIN, n_epochs - e);
+        if (n == OVERLAP_CHAIN && use_graph && h->chain_graph) MI_HIP(hipGraphLaunch(h->chain_graph, h->stream));
+        else enqueue_epoch_chain<T>(h, po, fo, n);
+        h->last_set = (n - 1) & 1;
+        e += n;
     }
     h->timer.stop(h->stream);
     h->batches_done += per_epoch * n_epochs;
@@ -2055,6 +2220,7 @@ extern "C" int mi355rec_mf_run_samples(mi355rec_mf_t h, const int32_t *u, const 
         if (bpr) MI_HIP(hipMemcpyAsync(h->sj.ptr, j, sizeof(int) * n, hipMemcpyHostToDevice, s));
         else MI_HIP(hipMemcpyAsync(h->sr.ptr, rating, sizeof(float) * n, hipMemcpyHostToDevice, s));
         h->last_call_samples = 0;
+        h->last_set = 0;
         if (h->f64) run_samples_typed<double>(h, n); else run_samples_typed<float>(h, n);
     });
 }
@@ -2109,6 +2275,7 @@ void shard_end_typed(mi355rec_mf *h) {
     h->timer.stop(h->stream);
     h->batches_done += per_epoch;
     h->last_call_samples = per_epoch * B;
+    h->last_set = 0;
     finish_call(h, per_epoch * B, per_epoch);               // (the loss is this rank's share)
 }
 
@@ -2201,10 +2368,23 @@ struct mi355rec_mf_group {
     hipGraphExec_t graph = nullptr;
     bool graph_failed = false;
     mi355rec_stats stats{};
+    // overlapped epochs (MI355REC_MF_OVERLAP=1): the members' second buffer sets in a second pair of tables, schedules on `side`
+    DeviceBuffer<unsigned char> table2;
+    std::vector<unsigned char> host_table2;
+    DeviceBuffer<FastSchedParams> sched_table2;
+    std::vector<FastSchedParams> host_sched_table2;
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> chain_events;
+    hipGraphExec_t chain_graph = nullptr;
+    bool chain_graph_failed = false;
 
     ~mi355rec_mf_group() {
         if (stream) (void)hipStreamSynchronize(stream);
+        if (side) (void)hipStreamSynchronize(side);
         if (graph) (void)hipGraphExecDestroy(graph);
+        if (chain_graph) (void)hipGraphExecDestroy(chain_graph);
+        for (hipEvent_t e : chain_events) (void)hipEventDestroy(e);
+        if (side) (void)hipStreamDestroy(side);
         timer.destroy();
         dispatch_timers.destroy();
         if (fork) (void)hipEventDestroy(fork);
@@ -2217,24 +2397,45 @@ namespace {
 
 // One epoch of every member: samplers and schedules on the members' own streams (parallel branches, also when captured), then
 // the shared chain of mini-batch launches on the group's stream.
+// sampler + schedule of all members (all on the in-LDS schedule): four launches
+template <class T>
+void group_enqueue_schedule(mi355rec_mf_group *g, const MfParams<T> *table, const FastSchedParams *sched_table, hipStream_t s) {
+    const long long nb = g->batches_per_epoch;
+    const int R = (int)g->members.size();
+    mi355rec_mf *h0 = g->members[0];
+    const FastSchedParams &f0 = g->host_sched_table[0];
+    const dim3 sgrid(div_up(nb * (long long)h0->cfg.batch_size, 256), R);
+    if (g->algorithm == MI355REC_MF_BPR) hipLaunchKernelGGL((mf_group_sample_kernel<MI355REC_MF_BPR, T>), sgrid, dim3(256), 0, s, table);
+    else hipLaunchKernelGGL((mf_group_sample_kernel<MI355REC_MF_FUNK_SVD, T>), sgrid, dim3(256), 0, s, table);
+    static bool attr_set[64] = {};
+    set_sched_sort_attribute(reinterpret_cast<const void *>(mf_group_sched_sort_kernel), attr_set);
+    int max_entries = 0;
+    for (const auto &f : g->host_sched_table) max_entries = std::max(max_entries, f.n_entries);
+    hipLaunchKernelGGL(mf_group_sched_sort_kernel, dim3((unsigned)nb, R), dim3(SCHED_THREADS), sched_lds_bytes(f0.np), s, sched_table);
+    hipLaunchKernelGGL(mf_group_sched_emit_kernel, dim3(div_up(f0.tasks_per_batch, 256), (unsigned)nb, R), dim3(256), 0, s, sched_table);
+    hipLaunchKernelGGL(mf_group_sched_finish_kernel, dim3(div_up(max_entries, 256), R), dim3(256), 0, s, sched_table);
+}
+
+// the shared chain of mini-batch launches of one epoch, on the group's stream
+template <class T>
+void group_enqueue_batches(mi355rec_mf_group *g, const MfParams<T> *table, bool timed) {
+    const long long nb = g->batches_per_epoch;
+    // a third of the slots' workgroups: the kernel loops over the slots in use (all of them when a member is on the general schedule)
+    const int wgs = div_up(div_up(g->tasks_per_batch, 4), 3), R = (int)g->members.size();
+    for (long long b = 0; b < nb; ++b) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed) g->dispatch_timers.next(e0, e1, g->max_timed);
+        if (g->algorithm == MI355REC_MF_BPR) launch_group_batch<MI355REC_MF_BPR, T>(g->stream, table, g->klass, wgs, R, (int)b, e0, e1);
+        else launch_group_batch<MI355REC_MF_FUNK_SVD, T>(g->stream, table, g->klass, wgs, R, (int)b, e0, e1);
+    }
+    hipLaunchKernelGGL(mf_group_stream_end_kernel<T>, dim3(div_up(R, 64)), dim3(64), 0, g->stream, table, R, nb);
+}
+
 template <class T>
 void group_enqueue_epoch(mi355rec_mf_group *g, bool timed) {
     const long long nb = g->batches_per_epoch;
-    if (g->all_fast) {      // sampler + schedule of all members: four launches on the group's stream
-        const int R = (int)g->members.size();
-        mi355rec_mf *h0 = g->members[0];
-        const MfParams<T> *table = reinterpret_cast<const MfParams<T> *>(g->table.ptr);
-        const FastSchedParams &f0 = g->host_sched_table[0];
-        const dim3 sgrid(div_up(nb * (long long)h0->cfg.batch_size, 256), R);
-        if (g->algorithm == MI355REC_MF_BPR) hipLaunchKernelGGL((mf_group_sample_kernel<MI355REC_MF_BPR, T>), sgrid, dim3(256), 0, g->stream, table);
-        else hipLaunchKernelGGL((mf_group_sample_kernel<MI355REC_MF_FUNK_SVD, T>), sgrid, dim3(256), 0, g->stream, table);
-        static bool attr_set[64] = {};
-        set_sched_sort_attribute(reinterpret_cast<const void *>(mf_group_sched_sort_kernel), attr_set);
-        int max_entries = 0;
-        for (const auto &f : g->host_sched_table) max_entries = std::max(max_entries, f.n_entries);
-        hipLaunchKernelGGL(mf_group_sched_sort_kernel, dim3((unsigned)nb, R), dim3(SCHED_THREADS), sched_lds_bytes(f0.np), g->stream, g->sched_table.ptr);
-        hipLaunchKernelGGL(mf_group_sched_emit_kernel, dim3(div_up(f0.tasks_per_batch, 256), (unsigned)nb, R), dim3(256), 0, g->stream, g->sched_table.ptr);
-        hipLaunchKernelGGL(mf_group_sched_finish_kernel, dim3(div_up(max_entries, 256), R), dim3(256), 0, g->stream, g->sched_table.ptr);
+    if (g->all_fast) {
+        group_enqueue_schedule<T>(g, reinterpret_cast<const MfParams<T> *>(g->table.ptr), g->sched_table.ptr, g->stream);
     } else {
     MI_HIP(hipEventRecord(g->fork, g->stream));
     for (size_t m = 0; m < g->members.size(); ++m) {
@@ -2248,16 +2449,60 @@ void group_enqueue_epoch(mi355rec_mf_group *g, bool timed) {
         MI_HIP(hipStreamWaitEvent(g->stream, g->join[m], 0));
     }
     }
-    const MfParams<T> *table = reinterpret_cast<const MfParams<T> *>(g->table.ptr);
-    // a third of the slots' workgroups: the kernel loops over the slots in use (all of them when a member is on the general schedule)
-    const int wgs = div_up(div_up(g->tasks_per_batch, 4), 3), R = (int)g->members.size();
-    for (long long b = 0; b < nb; ++b) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (timed) g->dispatch_timers.next(e0, e1, g->max_timed);
-        if (g->algorithm == MI355REC_MF_BPR) launch_group_batch<MI355REC_MF_BPR, T>(g->stream, table, g->klass, wgs, R, (int)b, e0, e1);
-        else launch_group_batch<MI355REC_MF_FUNK_SVD, T>(g->stream, table, g->klass, wgs, R, (int)b, e0, e1);
+    group_enqueue_batches<T>(g, reinterpret_cast<const MfParams<T> *>(g->table.ptr), timed);
+}
+
+// n <= OVERLAP_CHAIN epochs of all members with the schedules of epoch e + 1 on `side` (see enqueue_epoch_chain); capturable
+template <class T>
+void group_enqueue_epoch_chain(mi355rec_mf_group *g, int n) {
+    const MfParams<T> *table[2] = {reinterpret_cast<const MfParams<T> *>(g->table.ptr), reinterpret_cast<const MfParams<T> *>(g->table2.ptr)};
+    const FastSchedParams *sched[2] = {g->sched_table.ptr, g->sched_table2.ptr};
+    hipStream_t s1 = g->stream, s2 = g->side;
+    hipEvent_t *forked = &g->chain_events[0], *scheduled = &g->chain_events[1], *batches_done = &g->chain_events[1 + OVERLAP_CHAIN];
+    auto schedule = [&](int e) {
+        group_enqueue_schedule<T>(g, table[e & 1], sched[e & 1], s2);
+        MI_HIP(hipEventRecord(scheduled[e], s2));
+    };
+    MI_HIP(hipEventRecord(*forked, s1));
+    MI_HIP(hipStreamWaitEvent(s2, *forked, 0));
+    schedule(0);
+    for (int e = 0; e < n; ++e) {
+        if (e + 1 < n) {
+            if (e >= 1) {
+                MI_HIP(hipEventRecord(batches_done[e], s1));
+                MI_HIP(hipStreamWaitEvent(s2, batches_done[e], 0));
+            }
+            schedule(e + 1);
+        }
+        MI_HIP(hipStreamWaitEvent(s1, scheduled[e], 0));
+        group_enqueue_batches<T>(g, table[e & 1], false);
     }
-    hipLaunchKernelGGL(mf_group_stream_end_kernel<T>, dim3(div_up(R, 64)), dim3(64), 0, g->stream, table, R, nb);
+}
+
+template <class T>
+void group_ensure_chain_graph(mi355rec_mf_group *g) {
+    if (g->chain_graph || g->chain_graph_failed) return;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+        try {
+            group_enqueue_epoch_chain<T>(g, OVERLAP_CHAIN);
+        } catch (...) {
+            (void)hipStreamEndCapture(g->stream, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            g->chain_graph_failed = true;
+            return;
+        }
+        e = hipStreamEndCapture(g->stream, &graph);
+    }
+    if (e == hipSuccess) e = hipGraphInstantiate(&g->chain_graph, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        g->chain_graph = nullptr;
+        g->chain_graph_failed = true;
+    }
 }
 
 template <class T>
@@ -2311,11 +2556,18 @@ void group_run_epochs_typed(mi355rec_mf_group *g, int n_epochs) {
     }
     const bool sched_changed = all_fast != g->all_fast || (all_fast && (g->host_sched_table.size() != sched.size() ||
                                memcmp(g->host_sched_table.data(), sched.data(), sizeof(FastSchedParams) * sched.size()) != 0));
+    auto drop_group_chain_graph = [&] {
+        if (g->chain_graph) {
+            (void)hipGraphExecDestroy(g->chain_graph);
+            g->chain_graph = nullptr;
+        }
+    };
     if (sched_changed) {
         if (g->graph) {
             (void)hipGraphExecDestroy(g->graph);
             g->graph = nullptr;
         }
+        drop_group_chain_graph();
         MI_HIP(hipStreamSynchronize(g->stream));
         g->all_fast = all_fast;
         g->host_sched_table = sched;
@@ -2329,6 +2581,7 @@ void group_run_epochs_typed(mi355rec_mf_group *g, int n_epochs) {
             (void)hipGraphExecDestroy(g->graph);
             g->graph = nullptr;
         }
+        drop_group_chain_graph();
         MI_HIP(hipStreamSynchronize(g->stream));
         if (g->table.count < table.size()) g->table.alloc(table.size());
         MI_HIP(hipMemcpy(g->table.ptr, table.data(), table.size(), hipMemcpyHostToDevice));
@@ -2341,10 +2594,52 @@ void group_run_epochs_typed(mi355rec_mf_group *g, int n_epochs) {
         group_ensure_graph<T>(g);
         use_graph = g->graph != nullptr;
     }
+    // MI355REC_MF_OVERLAP=1: untimed epochs as chains whose (group-wide) schedules overlap the previous epoch's launches
+    const bool overlap = getenv("MI355REC_MF_OVERLAP") && all_fast && n_epochs - timed_epochs >= 2;
+    if (const char *want = getenv("MI355REC_MF_OVERLAP"))
+        MI_REQUIRE(overlap || strcmp(want, "require") != 0 || n_epochs - timed_epochs < 2,
+                   "MI355REC_MF_OVERLAP=require: not every member of the group runs on the in-LDS schedule");
+    if (overlap) {
+        ensure_chain_events(g->side, g->chain_events);
+        std::vector<unsigned char> table2(table);
+        std::vector<FastSchedParams> sched2(sched);
+        for (int m = 0; m < R; ++m) {
+            mi355rec_mf *h = g->members[m];
+            ensure_overlap_buffers(h);
+            MfParams<T> p2;
+            memcpy(&p2, table2.data() + sizeof(MfParams<T>) * (size_t)m, sizeof(MfParams<T>));
+            use_second_set(h, p2, sched2[m]);
+            memcpy(table2.data() + sizeof(MfParams<T>) * (size_t)m, &p2, sizeof(MfParams<T>));
+        }
+        const bool changed = table2 != g->host_table2 || g->host_sched_table2.size() != sched2.size() ||
+                             memcmp(g->host_sched_table2.data(), sched2.data(), sizeof(FastSchedParams) * sched2.size()) != 0;
+        if (changed) {
+            drop_group_chain_graph();
+            MI_HIP(hipStreamSynchronize(g->stream));
+            MI_HIP(hipStreamSynchronize(g->side));
+            if (g->table2.count < table2.size()) g->table2.alloc(table2.size());
+            if (g->sched_table2.count < sched2.size()) g->sched_table2.alloc(sched2.size());
+            MI_HIP(hipMemcpy(g->table2.ptr, table2.data(), table2.size(), hipMemcpyHostToDevice));
+            MI_HIP(hipMemcpy(g->sched_table2.ptr, sched2.data(), sizeof(FastSchedParams) * sched2.size(), hipMemcpyHostToDevice));
+            g->host_table2 = table2;
+            g->host_sched_table2 = sched2;
+        }
+        if (use_graph && n_epochs - timed_epochs >= OVERLAP_CHAIN) group_ensure_chain_graph<T>(g);
+    }
+    int last_set = 0;
     g->timer.start(g->stream);
-    for (long long e = 0; e < n_epochs; ++e) {
-        if (e < timed_epochs || !use_graph) group_enqueue_epoch<T>(g, e < timed_epochs);
-        else MI_HIP(hipGraphLaunch(g->graph, g->stream));
+    for (long long e = 0; e < n_epochs;) {
+        if (e < timed_epochs || !overlap) {
+            if (e < timed_epochs || !use_graph) group_enqueue_epoch<T>(g, e < timed_epochs);
+            else MI_HIP(hipGraphLaunch(g->graph, g->stream));
+            ++e;
+            continue;
+        }
+        const int n = (int)std::min<long long>(OVERLAP_CHAIN, n_epochs - e);
+        if (n == OVERLAP_CHAIN && use_graph && g->chain_graph) MI_HIP(hipGraphLaunch(g->chain_graph, g->stream));
+        else group_enqueue_epoch_chain<T>(g, n);
+        last_set = (n - 1) & 1;
+        e += n;
     }
     g->timer.stop(g->stream);
     MI_HIP(hipGetLastError());
@@ -2365,6 +2660,7 @@ void group_run_epochs_typed(mi355rec_mf_group *g, int n_epochs) {
         for (double v : h->host_loss) loss += v;
         h->batches_done += nb * n_epochs;
         h->last_call_samples = n_epochs > 0 ? nb * (long long)h->cfg.batch_size : 0;
+        h->last_set = last_set;
         h->stats = mi355rec_stats{};
         h->stats.call_ms = st.call_ms;
         h->stats.n_launches = st.n_launches;
@@ -2460,10 +2756,11 @@ extern "C" int mi355rec_mf_get_last_samples(mi355rec_mf_t h, int32_t *u, int32_t
         *n = h->last_call_samples;
         const size_t m = (size_t)std::min<long long>(cap, h->last_call_samples);
         hipStream_t s = h->stream;
-        if (u) h->su.download(u, m, s);
-        if (i) h->si.download(i, m, s);
-        if (j && h->cfg.algorithm == MI355REC_MF_BPR) h->sj.download(j, m, s);
-        if (rating && h->cfg.algorithm != MI355REC_MF_BPR) h->sr.download(rating, m, s);
+        const bool second = h->last_set == 1;       // (overlapped epochs alternate between two sets of stream buffers)
+        if (u) (second ? h->su2 : h->su).download(u, m, s);
+        if (i) (second ? h->si2 : h->si).download(i, m, s);
+        if (j && h->cfg.algorithm == MI355REC_MF_BPR) (second ? h->sj2 : h->sj).download(j, m, s);
+        if (rating && h->cfg.algorithm != MI355REC_MF_BPR) (second ? h->sr2 : h->sr).download(rating, m, s);
         MI_HIP(hipStreamSynchronize(s));
     });
 }
