@@ -438,7 +438,11 @@ def test_euclidean_row_weights_golden_fixture_and_oracle(gpu):
     Xb = X.copy(); Xb.data[:] = 1.0
     wantb = O.OracleSimilarityEuclidean(Xb, topK=25, **kw).dense().astype(np.float64)
     idxb, valb, _ = Compute_Similarity_Euclidean_MI355X(Xb, topK=25, **kw).compute_slabs()
-    for c in range(0, 700, 7):
+    # (two all-ones columns with the same support are at distance 0; the reference's float32 a^2 + b^2 - 2ab can round below zero
+    # there and its sqrt is nan -- documented deviation: the device clamps to 0 -- so columns holding a nan are left out)
+    clean = [c for c in range(0, 700, 7) if not np.isnan(wantb[:, c]).any()]
+    assert len(clean) > 50
+    for c in clean:
         check_topk_against_dense(idxb[c], valb[c], wantb[:, c], 25, RTOL)
 
 
