@@ -401,7 +401,6 @@ def test_fused_sample_tasks_equal_one_task_per_row(gpu, mode, k, monkeypatch):
     assert ((ci == 1) & (cj == 1)).any() and ((ci > 1) & (cj == 1)).any() and ((ci > 1) | (cj > 1)).any()
 
 
-@pytest.mark.first_hardware_run("MI355REC_MF_OVERLAP landed after round 3's last GPU call (opt-in, off by default)")
 @pytest.mark.parametrize("algo,mode,graph", [("MF_BPR", "sgd", True), ("MF_BPR", "adagrad", True), ("FUNK_SVD", "adam", True),
                                              ("MF_BPR", "sgd", False)])
 def test_overlapped_epoch_chains_equal_the_plain_epoch_loop(gpu, algo, mode, graph, monkeypatch):
@@ -436,7 +435,6 @@ def test_overlapped_epoch_chains_equal_the_plain_epoch_loop(gpu, algo, mode, gra
         assert plain[3] == over[3]
 
 
-@pytest.mark.first_hardware_run("MI355REC_MF_OVERLAP landed after round 3's last GPU call (opt-in, off by default)")
 def test_overlapped_group_chains_equal_the_plain_group_epochs(gpu, monkeypatch):
     """The replica-batched launch with MI355REC_MF_OVERLAP: the group-wide sampler / schedule launches of epoch e + 1 on the group's
     second stream, the members' second buffer sets in a second pair of tables.  Members as the plain group leaves them, bit for bit."""

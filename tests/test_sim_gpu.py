@@ -406,7 +406,6 @@ def test_euclidean_golden_fixture(gpu):
     assert rel_err(Wj, z["densej_0"]) < 1e-4
 
 
-@pytest.mark.first_hardware_run("Euclidean row_weights landed after round 3's last GPU call")
 def test_euclidean_row_weights_golden_fixture_and_oracle(gpu):
     """row_weights (Compute_Similarity_Euclidean.py:62-72): weighted dot products, and the distances to the columns times the weights
     of the rows (:174-175; square inputs).  The reference's own outputs for float32 and float64 weights (the device works in
