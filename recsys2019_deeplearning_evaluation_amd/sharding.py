@@ -337,6 +337,9 @@ class ShardedIALSEpoch:
         for r, (a, b) in enumerate(ranges):
             if r != self.rank:
                 self._copy(base + a * row, self.recv.address(r * self.slab_words), (b - a) * row)
+        # the next half-step runs on the epoch object's own (non-blocking) stream: do not rely on hipMemcpy being synchronous for
+        # device-to-device copies
+        self._N.check(self._N.load().mi355rec_device_synchronize())
 
     def run_epoch(self):
         """One epoch; returns when every rank's device holds the complete, updated U and V.  Blocking."""
