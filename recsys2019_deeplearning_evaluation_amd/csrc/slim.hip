@@ -246,7 +246,12 @@ __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
-template <class T, bool SYM>
+// BATCHED (experimental, MI355REC_SLIM_BATCHED=1, symmetric store only; NOT in the test suite): the `done` words of all last
+// writers of a thread's cells are requested under one wait, only the stragglers are polled, then all cells are gathered under one
+// wait -- instead of poll, gather, poll, gather with up to 3 x FLOW_REGS dependent round trips per step.  Round 3: equal results on
+// small matrices, but the ML-1M-shape symmetric epoch stalled (twice; with `done[0]` and with `done[t]` as the dummy word of lanes
+// without a predecessor) and the cause was not found -- kept so that the next session with a GPU can debug it.
+template <class T, bool SYM, bool BATCHED = false>
 __global__ __launch_bounds__(FLOW_THREADS) void slim_flow_kernel(const SlimParams<T> p) {
     __shared__ int s_t;
     __shared__ T s_part[FLOW_THREADS / 64];
@@ -262,12 +267,31 @@ __global__ __launch_bounds__(FLOW_THREADS) void slim_flow_kernel(const SlimParam
         const long long cp = SYM ? p.cellptr[t] : 0;
         // profile entries and (symmetric) the last writers of their cells do not depend on anybody: fetch them before waiting
         int sv[FLOW_REGS], pa[FLOW_REGS], pb[FLOW_REGS];
+        if constexpr (BATCHED) {
+            // loads from clamped, always valid addresses, masked afterwards: with a load inside a conditional the compiler waits for
+            // each one where its branch ends
+#pragma unroll
+            for (int r = 0; r < FLOW_REGS; ++r) {
+                const int idx = tid + r * FLOW_THREADS, at = min(idx, L - 1);        // L >= 1: users without interactions are never drawn
+                sv[r] = p.indices[rs + at];
+                const int2 pp = *reinterpret_cast<const int2 *>(p.pred + cp + 2 * at);
+                pa[r] = pp.x;
+                pb[r] = pp.y;
+            }
+#pragma unroll
+            for (int r = 0; r < FLOW_REGS; ++r) {
+                const bool live = tid + r * FLOW_THREADS < L;
+                pa[r] = live ? pa[r] : -1;
+                pb[r] = live ? pb[r] : -1;
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < FLOW_REGS; ++r) {
             const int idx = tid + r * FLOW_THREADS;
             sv[r] = idx < L ? p.indices[rs + idx] : 0;
             pa[r] = SYM && idx < L ? p.pred[cp + 2 * idx] : -1;
             pb[r] = SYM && idx < L ? p.pred[cp + 2 * idx + 1] : -1;
+        }
         }
         if (p.use_tickets) {
             if (tid < 2) wait_for(p, &p.ticket[tid ? j : i], p.seq[2 * t + tid], true);
@@ -288,6 +312,33 @@ __global__ __launch_bounds__(FLOW_THREADS) void slim_flow_kernel(const SlimParam
         // x_uij over the profile (.pyx:243-260)
         T x = (T)0;
         T va[FLOW_REGS], vb[FLOW_REGS];
+        if constexpr (BATCHED) {
+            int fa[FLOW_REGS], fb[FLOW_REGS];
+#pragma unroll
+            for (int r = 0; r < FLOW_REGS; ++r) {       // (lanes without a predecessor read this step's own word)
+                fa[r] = aload(&p.done[pa[r] >= 0 ? pa[r] : t]);
+                fb[r] = aload(&p.done[pb[r] >= 0 ? pb[r] : t]);
+            }
+#pragma unroll
+            for (int r = 0; r < FLOW_REGS; ++r) {
+                if (pa[r] >= 0 && !fa[r]) wait_for(p, &p.done[pa[r]], 1, false);
+                if (pb[r] >= 0 && !fb[r]) wait_for(p, &p.done[pb[r]], 1, false);
+            }
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < FLOW_REGS; ++r) {
+                va[r] = aload(&p.S[cell_at(p, i, sv[r])]);
+                vb[r] = aload(&p.S[cell_at(p, j, sv[r])]);
+            }
+#pragma unroll
+            for (int r = 0; r < FLOW_REGS; ++r) {
+                const bool live = tid + r * FLOW_THREADS < L;
+                va[r] = live ? va[r] : (T)0;
+                vb[r] = live ? vb[r] : (T)0;
+                x += va[r] - vb[r];
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < FLOW_REGS; ++r) {
             const int idx = tid + r * FLOW_THREADS;
@@ -303,6 +354,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void slim_flow_kernel(const SlimParam
                 vb[r] = aload(&p.S[cell_at(p, j, sv[r])]);
                 x += va[r] - vb[r];
             }
+        }
         }
         for (int idx = tid + FLOW_REGS * FLOW_THREADS; idx < L; idx += FLOW_THREADS) {    // profiles longer than 1024
             const int s = p.indices[rs + idx];
@@ -843,7 +895,8 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile, int first = 0) {
     MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(int) * 2, s));
     const int grid = std::min(n, multiprocessor_count() * 4);
     h->dispatch_timers.next(e0, e1, 1 << 30);
-    if (sym) hipExtLaunchKernelGGL((slim_flow_kernel<T, true>), dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p);
+    if (sym && getenv("MI355REC_SLIM_BATCHED")) hipExtLaunchKernelGGL((slim_flow_kernel<T, true, true>), dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p);
+    else if (sym) hipExtLaunchKernelGGL((slim_flow_kernel<T, true>), dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p);
     else hipExtLaunchKernelGGL((slim_flow_kernel<T, false>), dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p);
     h->stats.n_launches += 1;
     MI_HIP(hipGetLastError());
