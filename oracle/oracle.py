@@ -566,12 +566,21 @@ def oracle_ials_epoch(C_csr, C_csc, U, V, reg):
     against the UPDATED U.  U and V are float64 arrays updated in place; only warm rows are touched."""
     k = V.shape[1]
     reg_diag = np.diag(reg * np.ones(k))
-    VV = V.T.dot(V)
-    for u in np.flatnonzero(np.diff(C_csr.indptr) > 0):
-        s, e = C_csr.indptr[u], C_csr.indptr[u + 1]
-        U[u, :] = _ials_update_row(C_csr.indices[s:e], C_csr.data[s:e], V, VV, reg_diag)
-    UU = U.T.dot(U)
-    for i in np.flatnonzero(np.diff(C_csc.indptr) > 0):
-        s, e = C_csc.indptr[i], C_csc.indptr[i + 1]
-        V[i, :] = _ials_update_row(C_csc.indices[s:e], C_csc.data[s:e], U, UU, reg_diag)
+    try:        # thousands of small k x k products and inverses: one BLAS thread (a 256-core host spends its time handing them out)
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=1)
+    except ImportError:
+        limit = None
+    try:
+        VV = V.T.dot(V)
+        for u in np.flatnonzero(np.diff(C_csr.indptr) > 0):
+            s, e = C_csr.indptr[u], C_csr.indptr[u + 1]
+            U[u, :] = _ials_update_row(C_csr.indices[s:e], C_csr.data[s:e], V, VV, reg_diag)
+        UU = U.T.dot(U)
+        for i in np.flatnonzero(np.diff(C_csc.indptr) > 0):
+            s, e = C_csc.indptr[i], C_csc.indptr[i + 1]
+            V[i, :] = _ials_update_row(C_csc.indices[s:e], C_csc.data[s:e], U, UU, reg_diag)
+    finally:
+        if limit is not None:
+            limit.restore_original_limits()
     return U, V
