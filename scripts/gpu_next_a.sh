@@ -10,4 +10,3 @@ cat gpurun_out/next_a/mf_overlap_32.txt
 timeout 60 python scripts/ials_only.py > gpurun_out/next_a/ials.json 2> gpurun_out/next_a/ials.err; echo "ials rc=$?"
 timeout 200 python bench.py > gpurun_out/next_a/bench.json 2> gpurun_out/next_a/bench.err; echo "bench rc=$?"
 tail -c 1500 gpurun_out/next_a/bench.json
-timeout 60 bash -c "/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/micro/lds_scatter_patterns.hip -o /tmp/lsp && /tmp/lsp" > gpurun_out/next_a/lds_scatter_patterns.txt 2>&1; cat gpurun_out/next_a/lds_scatter_patterns.txt
