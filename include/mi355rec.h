@@ -234,6 +234,9 @@ int mi355rec_mf_shard_merge(mi355rec_mf_t h, int32_t batch);
 int mi355rec_mf_shard_end_epoch(mi355rec_mf_t h);
 /* Any output pointer may be NULL.  bu/bi/mu are only written when use_bias. */
 int mi355rec_mf_get_factors(mi355rec_mf_t h, float *U, float *V, float *bu, float *bi, float *mu);
+/* The same as float64, the type the reference's getters return (.pyx:685-702): the device state itself when it is float64
+ * (adagrad / rmsprop / adam, AsySVD), the float32 state widened otherwise. */
+int mi355rec_mf_get_factors_f64(mi355rec_mf_t h, double *U, double *V, double *bu, double *bi, double *mu);
 /* Copy the (u, i, j|rating) stream drawn by the LAST mi355rec_mf_run_epochs call (at most cap entries);
  * returns the number of samples of that call in *n. */
 int mi355rec_mf_get_last_samples(mi355rec_mf_t h, int32_t *u, int32_t *i, int32_t *j, float *rating, int64_t cap, int64_t *n);
@@ -277,8 +280,10 @@ typedef struct {
     double  learning_rate, li_reg, lj_reg;
     double  gamma, beta_1, beta_2;
     uint64_t random_seed;
-    int32_t precision;       /* MI355REC_F32 / MI355REC_F64: type of S and of the per-item optimiser cells on the device (the reference
-                              * is double throughout; float32 holds 1e-5 for plain sgd, the adaptive optimisers need float64) */
+    int32_t precision;       /* MI355REC_F32 / MI355REC_F64: type of the dense store's cells and per-item optimiser cells on the device
+                              * (the reference is double throughout).  Rows an owning workgroup keeps in LDS for a launch are float32
+                              * there; the symmetric store holds float32 values in 8-byte {value, tag} cells, computes in float64
+                              * and keeps the optimiser cells as float64 (two float32 halves) whatever this field says */
     int32_t train_with_sparse_weights;   /* 1: the semantics of the Sparse_Matrix_Tree_CSR store (.pyx:582-1030) on the dense
                               * device array: a cell "has a node" once it has been written; rebalance_tree(TopK) (.pyx:320-324,
                               * 785-805) keeps the TopK largest nodes per row after every (n_steps / 5)-th step of an epoch, get_S
@@ -308,6 +313,10 @@ int mi355rec_slim_get_S_sparse(mi355rec_slim_t h, int32_t *nbr_idx, float *nbr_v
 /* Dense S (n_items x n_items, row-major, diagonal zeroed, symmetric mode mirrored). */
 int mi355rec_slim_get_S_dense(mi355rec_slim_t h, float *S);
 int mi355rec_slim_get_stats(mi355rec_slim_t h, mi355rec_stats *stats);
+/* Diagnostics of the last dense-store launch: rows kept in the LDS of an owning workgroup (the busiest items of the stream; 0 on
+ * the symmetric / sparse store, for catalogues whose row does not fit the LDS, or when no compute units could be leased) and the
+ * number of steps that ran on rows in HBM. */
+int mi355rec_slim_schedule_info(mi355rec_slim_t h, int32_t *n_owned_rows, int32_t *n_cold_steps);
 void mi355rec_slim_destroy(mi355rec_slim_t h);
 
 /* ------------------------------------------------------------------------------------------------------

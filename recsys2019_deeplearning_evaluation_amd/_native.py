@@ -97,6 +97,7 @@ SIGNATURES = {
     "mi355rec_mf_shard_merge": (C.c_int, [_vp, _i32]),
     "mi355rec_mf_shard_end_epoch": (C.c_int, [_vp]),
     "mi355rec_mf_get_factors": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi355rec_mf_get_factors_f64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mi355rec_mf_get_last_samples": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     "mi355rec_mf_set_profiling": (C.c_int, [_vp, _i32]),
     "mi355rec_mf_get_phase_ticks": (C.c_int, [_vp, _vp, _i64, C.POINTER(_i64)]),
@@ -115,6 +116,7 @@ SIGNATURES = {
     "mi355rec_slim_get_S_sparse": (C.c_int, [_vp, _vp, _vp]),
     "mi355rec_slim_get_S_dense": (C.c_int, [_vp, _vp]),
     "mi355rec_slim_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "mi355rec_slim_schedule_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "mi355rec_slim_destroy": (None, [_vp]),
     "mi355rec_ials_create": (C.c_int, [C.POINTER(_vp), _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp]),
     "mi355rec_ials_run_epochs": (C.c_int, [_vp, _i32]),

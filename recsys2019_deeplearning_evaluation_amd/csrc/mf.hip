@@ -37,6 +37,7 @@
 // There is no dense contraction here, hence no MFMA.
 #include "common.h"
 #include "sampling.cuh"
+#include "wave.cuh"
 
 #include <rocprim/rocprim.hpp>
 
@@ -107,59 +108,6 @@ struct MfParams {
     int wg_base, wg_stride;              // workgroup b of the launch is workgroup wg_base + b * wg_stride of the mini-batch (exact
                                          // multi-GPU mode: rank r of G runs workgroups r, r + G, ...; otherwise 0 and 1)
 };
-
-// ---- wavefront reductions without LDS traffic ----------------------------------------------------------------------
-// row_ror:n rotates inside each row of 16 lanes; v_permlane16_swap / v_permlane32_swap (gfx950) exchange rows / halves.
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
-    const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ float swap16_sum(float v) {   // lane l gets v[l] + v[l ^ 16] (same operand order in both rows)
-    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
-__device__ __forceinline__ float swap32_sum(float v) {
-    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
-__device__ __forceinline__ double swap16_sum(double v) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
-    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
-    const double a = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[0] << 32) | (unsigned)lo[0]);
-    const double c = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[1] << 32) | (unsigned)lo[1]);
-    return a + c;
-}
-__device__ __forceinline__ double swap32_sum(double v) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
-    auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
-    const double a = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[0] << 32) | (unsigned)lo[0]);
-    const double c = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[1] << 32) | (unsigned)lo[1]);
-    return a + c;
-}
-// sum over aligned groups of LPR lanes, every lane of the group gets the (bitwise identical) result
-template <int LPR, class T> __device__ __forceinline__ T group_sum(T v) {
-    v += dpp_mov<0x128>(v);   // row_ror:8
-    v += dpp_mov<0x124>(v);   // row_ror:4
-    v += dpp_mov<0x122>(v);   // row_ror:2
-    v += dpp_mov<0x121>(v);   // row_ror:1
-    if (LPR >= 32) v = swap16_sum(v);
-    if (LPR >= 64) v = swap32_sum(v);
-    return v;
-}
-// sum ACROSS the 64 / LPR groups (lane l of every group gets the total of the lanes l of all groups)
-template <int LPR, class T> __device__ __forceinline__ T cross_group_sum(T v) {
-    if (LPR <= 16) v = swap16_sum(v);
-    if (LPR <= 32) v = swap32_sum(v);
-    return v;
-}
-template <class T> __device__ __forceinline__ T wave_sum(T v) { return group_sum<64>(v); }
 
 __device__ __forceinline__ unsigned long long stamp() {   // shader clock; not reordered against memory operations
     unsigned long long t;
@@ -264,11 +212,15 @@ __device__ __forceinline__ void mf_sample_body(const MfParams<T> &p) {
             }
         }
     }
-    // the grid is fully drained before the next kernel starts: a plain store by one thread is enough
-    if (t == 0) p.state->epoch = epoch + 1;
+    // (the epoch counter is advanced by the NEXT kernel on the stream, mf_epoch_advance_kernel: a grid larger than the device's
+    // residency -- FunkSVD draws 20 M samples per epoch -- still has blocks to start when the first ones retire, and they must
+    // read the same epoch)
 }
 template <int ALGO, class T>
 __global__ __launch_bounds__(256) void mf_sample_kernel(const MfParams<T> p) { mf_sample_body<ALGO, T>(p); }
+__global__ void mf_epoch_advance_kernel(MfState *state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) state->epoch += 1;
+}
 
 // ---- schedule: (row, mini-batch) incidences -> tasks ----------------------------------------------------------------
 struct SchedParams {
@@ -1044,6 +996,11 @@ __global__ __launch_bounds__(256) void mf_group_sample_kernel(const MfParams<T> 
     globalize(p);
     mf_sample_body<ALGO, T>(p);
 }
+template <class T>
+__global__ void mf_group_epoch_advance_kernel(const MfParams<T> *table, const int n_models) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < n_models) table[m].state->epoch += 1;
+}
 __global__ __launch_bounds__(SCHED_THREADS) void mf_group_sched_sort_kernel(const FastSchedParams *__restrict__ table) {
     FastSchedParams f = table[blockIdx.y];
     globalize(f);
@@ -1209,19 +1166,19 @@ __global__ __launch_bounds__(256) void mf_shard_rows_kernel(const MfParams<T> p,
     }
 }
 
-template <class T>
+template <class T, class O>
 __global__ __launch_bounds__(256) void mf_gather_rows_kernel(const T *b0, const T *b1, const unsigned char *par, long long n_rows,
-                                                             int k, float *out) {
+                                                             int k, O *out) {
     const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (t >= n_rows * k) return;
     const long long row = t / k;
-    out[t] = (float)(par[row] ? b1[t] : b0[t]);
+    out[t] = (O)(par[row] ? b1[t] : b0[t]);
 }
-template <class T>
-__global__ void mf_final_mu_kernel(const MfParams<T> p, float *out) {
+template <class T, class O>
+__global__ void mf_final_mu_kernel(const MfParams<T> p, O *out) {
     const int lane = threadIdx.x & 63;
     const T mu = global_bias_at(p, p.state->batch_base, false, lane);
-    if (threadIdx.x == 0) out[0] = (float)mu;
+    if (threadIdx.x == 0) out[0] = (O)mu;
 }
 
 // AsySVD (.pyx:393-541): batch_size is 1 and every step rewrites all the Y rows of the sampled user's profile, which
@@ -1606,6 +1563,7 @@ void launch_sampler(mi355rec_mf *h, const MfParams<T> &p, hipStream_t on = nullp
     hipStream_t s = on ? on : h->stream;
     if (h->cfg.algorithm == MI355REC_MF_BPR) hipLaunchKernelGGL((mf_sample_kernel<MI355REC_MF_BPR, T>), dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((mf_sample_kernel<MI355REC_MF_FUNK_SVD, T>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(mf_epoch_advance_kernel, dim3(1), dim3(64), 0, s, p.state);
 }
 
 int pow2_at_least(int n) {
@@ -2106,20 +2064,23 @@ void run_samples_typed(mi355rec_mf *h, int64_t n) {
     finish_call(h, n, n_batches);
 }
 
-template <class T>
-void get_factors_typed(mi355rec_mf *h, float *U, float *V, float *bu, float *bi, float *mu) {
+// O = float (the float32 matrices north_star speaks of) or double (what the reference's getters return, .pyx:685-702: exact when
+// the device state is float64)
+template <class T, class O>
+void get_factors_typed(mi355rec_mf *h, O *U, O *V, O *bu, O *bi, O *mu) {
     hipStream_t s = h->stream;
     MfParams<T> p{};
     fill_params(h, p);
     const size_t nu = (size_t)h->n_u_rows * h->k, ni = (size_t)h->n_items * h->k;
-    const size_t need = std::max(std::max(nu, ni), (size_t)std::max(h->n_users, h->n_items));
+    const size_t need = std::max(std::max(nu, ni), (size_t)std::max(h->n_users, h->n_items)) * (sizeof(O) / sizeof(float));
     if (h->stage.count < need) h->stage.alloc(need);
+    O *stage = reinterpret_cast<O *>(h->stage.ptr);
     // rows of U are entries [0, n_u_rows) of `par` for BPR / FunkSVD; AsySVD never flips a buffer (par stays 0)
     const unsigned char *par_u = h->par.ptr, *par_v = h->par.ptr + h->n_users;
-    auto gather = [&](const T *b0, const T *b1, const unsigned char *par, size_t rows, int k, float *host) {
-        hipLaunchKernelGGL(mf_gather_rows_kernel<T>, dim3(div_up((long long)rows * k, 256)), dim3(256), 0, s, b0, b1, par,
-                           (long long)rows, k, h->stage.ptr);
-        h->stage.download(host, rows * k, s);
+    auto gather = [&](const T *b0, const T *b1, const unsigned char *par, size_t rows, int k, O *host) {
+        hipLaunchKernelGGL((mf_gather_rows_kernel<T, O>), dim3(div_up((long long)rows * k, 256)), dim3(256), 0, s, b0, b1, par,
+                           (long long)rows, k, stage);
+        MI_HIP(hipMemcpyAsync(host, stage, rows * k * sizeof(O), hipMemcpyDeviceToHost, s));
         MI_HIP(hipStreamSynchronize(s));
     };
     const bool asy = h->cfg.algorithm == MI355REC_MF_ASY_SVD;
@@ -2132,10 +2093,10 @@ void get_factors_typed(mi355rec_mf *h, float *U, float *V, float *bu, float *bi,
             T v;
             MI_HIP(hipMemcpyAsync(&v, p.asy_mu, sizeof(T), hipMemcpyDeviceToHost, s));
             MI_HIP(hipStreamSynchronize(s));
-            *mu = (float)v;
+            *mu = (O)v;
         } else {
-            hipLaunchKernelGGL(mf_final_mu_kernel<T>, dim3(1), dim3(64), 0, s, p, h->stage.ptr);
-            h->stage.download(mu, 1, s);
+            hipLaunchKernelGGL((mf_final_mu_kernel<T, O>), dim3(1), dim3(64), 0, s, p, stage);
+            MI_HIP(hipMemcpyAsync(mu, stage, sizeof(O), hipMemcpyDeviceToHost, s));
             MI_HIP(hipStreamSynchronize(s));
         }
     }
@@ -2407,6 +2368,7 @@ void group_enqueue_schedule(mi355rec_mf_group *g, const MfParams<T> *table, cons
     const dim3 sgrid(div_up(nb * (long long)h0->cfg.batch_size, 256), R);
     if (g->algorithm == MI355REC_MF_BPR) hipLaunchKernelGGL((mf_group_sample_kernel<MI355REC_MF_BPR, T>), sgrid, dim3(256), 0, s, table);
     else hipLaunchKernelGGL((mf_group_sample_kernel<MI355REC_MF_FUNK_SVD, T>), sgrid, dim3(256), 0, s, table);
+    hipLaunchKernelGGL(mf_group_epoch_advance_kernel<T>, dim3(div_up(R, 64)), dim3(64), 0, s, table, R);
     static bool attr_set[64] = {};
     set_sched_sort_attribute(reinterpret_cast<const void *>(mf_group_sched_sort_kernel), attr_set);
     int max_entries = 0;
@@ -2744,7 +2706,15 @@ extern "C" int mi355rec_mf_get_factors(mi355rec_mf_t h, float *U, float *V, floa
     return guarded([&] {
         MI_REQUIRE(h, "NULL handle");
         ensure_device();
-        if (h->f64) get_factors_typed<double>(h, U, V, bu, bi, mu); else get_factors_typed<float>(h, U, V, bu, bi, mu);
+        if (h->f64) get_factors_typed<double, float>(h, U, V, bu, bi, mu); else get_factors_typed<float, float>(h, U, V, bu, bi, mu);
+    });
+}
+
+extern "C" int mi355rec_mf_get_factors_f64(mi355rec_mf_t h, double *U, double *V, double *bu, double *bi, double *mu) {
+    return guarded([&] {
+        MI_REQUIRE(h, "NULL handle");
+        ensure_device();
+        if (h->f64) get_factors_typed<double, double>(h, U, V, bu, bi, mu); else get_factors_typed<float, double>(h, U, V, bu, bi, mu);
     });
 }
 

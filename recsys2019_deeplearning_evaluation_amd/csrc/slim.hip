@@ -5,40 +5,53 @@
 // adaptive_gradient :398-436, get_S :343-391.  The wrapper hard-codes batch_size = 1
 // (SLIM_BPR/Cython/SLIM_BPR_Cython.py:140), so an epoch is n_users + 1 STRICTLY ORDERED SGD steps.
 //
-// Design.  S is a dense n_items x n_items matrix in HBM (the symmetric store uses the lower triangle
-// of the same array); float32 for plain sgd, float64 (like the reference) for adagrad / rmsprop / adam.  The sample stream
-// does not depend on S, so WHICH earlier step a step has to wait for is known before the first step runs:
-//   dense store       step t owns rows i_t and j_t (and the optimiser cells of items i_t, j_t).  Per item, steps take
-//                     numbered tickets in stream order (a device sort of the 2n (item, step) pairs gives every step its two
-//                     ticket numbers);
-//   symmetric store   cell (r, c) aliases (c, r), so ownership is per CELL: the cells every step touches are sorted by
-//                     (cell, step) and each one is handed the step that touched it last (`pred`).
-// Round 1 turned the row dependencies into ~1250 host-scheduled level launches per epoch (dense, 10.6 us per level) and ran
-// the symmetric store on ONE workgroup.  Here ONE persistent kernel executes the whole stream as a dataflow graph: workgroups
-// pull steps from an in-order queue; a step waits until its two tickets come up (and, symmetric, until the last writer of
-// each of its cells is done), does its 2 L_u gathers, the two per-item optimiser steps, its 2 L_u scattered writes, drains
-// them, and passes the tickets on.  Cells are only ever accessed with agent-scope atomic loads / write-through stores
-// (L2 / MALL coherent across XCDs); waiting is a relaxed poll of ONE word per lane.  Because the queue is in order, a
-// waiting step only ever waits for steps that are already running: no deadlock, whatever the residency.
-// Exact sequential semantics; the critical path is the chain of steps on the most popular item, not launches.
-// 4-byte gathers / scatters, no dense contraction: no MFMA.
+// Design.  The sample stream does not depend on S, so WHICH earlier step a step has to wait for is
+// known before the first step runs, and an epoch is ONE persistent kernel that executes the stream as a dataflow graph.  What
+// bounds it is the longest chain of dependent steps (the steps on the busiest item row: 1 214 of 138 494 at the ML-20M shape),
+// i.e. the price of ONE hand-off between two steps -- not bytes.  Round 4 rebuilds both stores around that price:
+//   dense store       step t owns rows i_t and j_t.  The BUSIEST rows (top-H items by their number of steps in this stream,
+//                     chosen on the device) are kept in the LDS of an OWNING workgroup for the whole launch: its 16 wavefronts
+//                     take the row's steps in turn, each prefetching everything that does not depend on the row (profile,
+//                     the other row's cells once that row's ticket has come up) before its turn; a link of the chain is then
+//                     an LDS gather + wavefront reduction + LDS scatter (a few hundred cycles) instead of ticket poll ->
+//                     gather -> write-through -> drain -> ticket through L2 (4.8 us per link under load in round 3).
+//                     All other steps are run by "cold" wavefronts (one step per wavefront, no barriers), ordered per item by
+//                     numbered tickets as before.  Two busy rows in one step talk through a two-word mailbox.
+//   symmetric store   cell (r, c) aliases (c, r), so ownership is per CELL and no row can be owned.  Every cell of the packed
+//                     lower triangle is an 8-byte GRANULE {float value, tag of the step that wrote it}, written by ONE
+//                     write-through store: a reader that knows which step wrote the cell last (`pred`, from a sort of the
+//                     stream's (cell, step) pairs) polls THE CELL until the tag matches -- one round trip per link instead of
+//                     done-flag poll + gather + drain + flag store, and no step ever drains its stores.  The per-item
+//                     optimiser cells travel the same way (two granules per float64).
+// Steps are claimed from an in-order queue, so a waiting step only ever waits for steps that are already running: no deadlock
+// whatever the residency (the owners of the dense store are the exception: they are leased to one launch at a time, see
+// run_stream).  Exact sequential semantics (1e-5 element-wise against the float64 oracle for all four optimisers, both stores,
+// at the full BASELINE config-3 shape).  4-byte gathers / scatters, no dense contraction: no MFMA.
 #include "common.h"
 #include "sampling.cuh"
 #include "topk.cuh"
+#include "wave.cuh"
 
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
+#include <type_traits>
 
 namespace mi355rec {
 namespace {
 
 constexpr int LOSS_SLOTS = 1024;
-constexpr int FLOW_THREADS = 256;
-constexpr int FLOW_REGS = 4;                          // profile entries per thread whose cells stay in registers between the passes
+constexpr int FLOW_THREADS = 1024;                    // 16 wavefronts: the turn takers of an owned row, or 16 independent steps
+constexpr int FLOW_WAVES = FLOW_THREADS / 64;
+constexpr int FLOW_REGS = 4;                          // profile entries per lane whose cells stay in registers between the passes
+constexpr int MAX_OWNERS = 192;
 constexpr unsigned NO_CELL = 0xFFFFFFFFu;             // (the diagonal is read but never written: it orders nothing)
-constexpr long long SPIN_LIMIT_TICKS = 2000000000ll;  // 20 s of the 100 MHz wall clock: a stuck hand-off aborts instead of hanging
+constexpr long long SPIN_LIMIT_TICKS = 500000000ll;   // 5 s of the 100 MHz wall clock: a stuck hand-off aborts instead of hanging
+constexpr unsigned long long MAIL_EMPTY = ~0ull;
+
+struct alignas(8) Granule { float v; unsigned tag; };
 
 template <class T>
 struct SlimParams {
@@ -47,32 +60,49 @@ struct SlimParams {
     double beta_1_d, beta_2_d;
     unsigned long long seed;
     const int *indptr, *indices;
-    T *S;
-    T *c1, *c2;                     // per-ITEM optimiser scalars (.pyx:177-181): cache / first moment, second moment
+    T *S;                           // dense store: n_items x n_items
+    Granule *G;                     // symmetric store: packed lower triangle of {value, tag of the step that wrote it}
+    T *c1, *c2;                     // dense store: per-ITEM optimiser scalars (.pyx:177-181): cache / first moment, second moment
+    Granule *oc;                    // symmetric store: the same as [n_items][4] granules (c1 high, c1 low, c2 high, c2 low)
     const int *su, *si, *sj;        // sample stream of the call
-    const int *seq;                 // [2 n_steps] ticket numbers of step t on item i_t (2t) and item j_t (2t + 1)
+    const int *seq;                 // dense: [2 n_steps] ticket numbers of step t on item i_t (2t) and item j_t (2t + 1)
+    const int *iprev;               // symmetric: [2 n_steps] the step before t on item i_t / j_t in this call (-1: none)
     const long long *cellptr;       // symmetric: first cell slot of every step (2 per profile entry: row i, row j)
     const int *pred;                // symmetric: per cell slot, the step that touched the cell last (-1: nobody in this call)
-    int *ticket;                    // [n_items] steps of this call completed on the item
-    int *done;                      // symmetric: [n_steps]
-    int *queue;                     // [0] next step, [1] abort flag
+    int *ticket;                    // dense: [n_items] steps of this call completed on the item
+    int *queue;                     // [0] next step (of the cold list), [1] abort flag
     double *loss_slots;             // [LOSS_SLOTS]
     long long epoch;                // RNG counter base
     long long steps_before;         // steps executed before this call (Adam's beta^t, .pyx:313-317)
-    int n_steps, use_tickets;
+    int n_steps;
+    unsigned tag_base;              // symmetric: step t of this call writes tag tag_base + t + 1
+    // dense store, owned rows
+    const int *hot_rank;            // [n_items] owner of the item's row, -1: nobody (the row stays in HBM)
+    const int *hot_item, *lst_begin, *lst_len;   // [MAX_OWNERS] item, first position and length of its run in `item_sorted`
+    const int *n_hot;               // owners in use (decided on the device)
+    const int *item_sorted;         // 2 t + role in (item, step) order
+    const int *cold_list;           // steps with no owned row, in stream order
+    const int *n_cold;
+    unsigned long long *mail_x, *mail_g;   // [n_steps] steps on TWO owned rows: sum over the negative item's row, sigmoid
 };
 
 template <class T> __device__ __forceinline__ T aload(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> __device__ __forceinline__ void astore(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ Granule gload(const Granule *p) {
+    return __builtin_bit_cast(Granule, aload(reinterpret_cast<const unsigned long long *>(p)));
+}
+__device__ __forceinline__ void gstore(Granule *p, float v, unsigned tag) {
+    astore(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, Granule{v, tag}));
+}
 
-template <class P> __device__ __forceinline__ size_t cell_at(const P &p, int r, int c) {
-    // Triangular_Matrix.get_value/add_value (.pyx:1290-1330): in symmetric mode (r, c) with c > r lives at (c, r)
-    // and the store is the packed lower triangle, row r starting at r (r + 1) / 2 (:1237-1254): n (n + 1) / 2 cells
-    if (p.symmetric) {
-        if (c > r) { const int t = r; r = c; c = t; }
-        return ((size_t)r * ((size_t)r + 1) >> 1) + (size_t)c;
-    }
-    return (size_t)r * p.n_items + c;
+// Triangular_Matrix.get_value/add_value (.pyx:1290-1330): in symmetric mode (r, c) with c > r lives at (c, r)
+// and the store is the packed lower triangle, row r starting at r (r + 1) / 2 (:1237-1254): n (n + 1) / 2 cells
+__host__ __device__ __forceinline__ size_t packed_cell(int r, int c) {
+    if (c > r) { const int t = r; r = c; c = t; }
+    return ((size_t)r * ((size_t)r + 1) >> 1) + (size_t)c;
+}
+template <class P> __device__ __forceinline__ float stored_value(const P &p, int r, int c) {      // for get_S
+    return p.symmetric ? p.G[packed_cell(r, c)].v : (float)p.S[(size_t)r * p.n_items + c];
 }
 
 // The cell update v +- lr * (g - reg * v) (.pyx:283-309) with every operation rounded on its own, as the reference's scalar x86 code
@@ -101,40 +131,34 @@ __device__ __forceinline__ double root(double x) { return sqrt(x); }
 __device__ __forceinline__ float sigmoid_of_minus(float x) { return 1.f / (1.f + __expf(x)); }
 __device__ __forceinline__ double sigmoid_of_minus(double x) { return 1.0 / (1.0 + exp(x)); }
 
-// per-ITEM adaptive step (.pyx:398-436); pw1 / pw2 = 1 - beta^t of this step.  The cells travel between workgroups with the
-// item's ticket, hence the agent-scope accesses.
-template <class T>
-__device__ __forceinline__ T slim_adapt_cells(const SlimParams<T> &p, T g, int item, T pw1, T pw2, T c1, T c2) {
-    // c1 / c2: the item's optimiser cells as the owner of the item's ticket read them
+// per-ITEM adaptive step (.pyx:398-436) on cells passed by reference; pw1 / pw2 = 1 - beta^t of this step
+template <class T, class P>
+__device__ __forceinline__ T slim_adapt_cells(const P &p, T g, T pw1, T pw2, T &c1, T &c2) {
     switch (p.sgd_mode) {
-        case MI355REC_ADAGRAD: {
-            const T c = c1 + g * g;
-            astore(&p.c1[item], c);
-            return g / (root(c) + (T)1e-8);
-        }
-        case MI355REC_RMSPROP: {
-            const T c = c1 * p.gamma + p.one_m_gamma * (g * g);
-            astore(&p.c1[item], c);
-            return g / (root(c) + (T)1e-8);
-        }
+        case MI355REC_ADAGRAD:
+            c1 = c1 + g * g;
+            return g / (root(c1) + (T)1e-8);
+        case MI355REC_RMSPROP:
+            c1 = c1 * (T)p.gamma + (T)p.one_m_gamma * (g * g);
+            return g / (root(c1) + (T)1e-8);
         case MI355REC_ADAM: {
-            const T m1 = c1 * p.beta_1 + p.one_m_beta_1 * g;
-            const T m2 = c2 * p.beta_2 + p.one_m_beta_2 * (g * g);
-            astore(&p.c1[item], m1);
-            astore(&p.c2[item], m2);
-            return (m1 / pw1) / (root(m2 / pw2) + (T)1e-8);
+            c1 = c1 * (T)p.beta_1 + (T)p.one_m_beta_1 * g;
+            c2 = c2 * (T)p.beta_2 + (T)p.one_m_beta_2 * (g * g);
+            return (c1 / pw1) / (root(c2 / pw2) + (T)1e-8);
         }
         default:
             return g;
     }
 }
-
-template <class T>
-__device__ __forceinline__ T slim_adapt(const SlimParams<T> &p, T g, int item, T pw1, T pw2) {
-    T c1 = (T)0, c2 = (T)0;
-    if (p.sgd_mode != MI355REC_SGD) c1 = aload(&p.c1[item]);
-    if (p.sgd_mode == MI355REC_ADAM) c2 = aload(&p.c2[item]);
-    return slim_adapt_cells(p, g, item, pw1, pw2, c1, c2);
+template <class T, class P>
+__device__ __forceinline__ void adam_powers(const P &p, int t, T &pw1, T &pw2) {
+    pw1 = (T)1;
+    pw2 = (T)1;
+    if (p.sgd_mode == MI355REC_ADAM) {
+        const double tt = (double)(p.steps_before + t + 1);
+        pw1 = (T)(1.0 - pow(p.beta_1_d, tt));
+        pw2 = (T)(1.0 - pow(p.beta_2_d, tt));
+    }
 }
 
 template <class T>
@@ -156,11 +180,19 @@ struct DepParams {
     int *vals;                      // item pass: 2 step + role;      cell pass: cell slot
     const unsigned long long *keys_sorted;
     const int *vals_sorted;
-    int *seq;
+    int *seq, *iprev;
     int *len2;                      // 2 L_u per step
     const long long *cellptr;
     int *pred;
     long long n_cells;
+    // owned rows of the dense store
+    int *run_start;                 // [n_items] first position of the item's run in the sorted pairs
+    unsigned *item_cnt;             // [n_items] steps of the stream on the item (0: memset)
+    const unsigned *cnt_sorted;     // item_cnt in descending order ...
+    const int *item_by_cnt;         // ... and whose count it is
+    int *hot_rank, *hot_item, *lst_begin, *lst_len, *n_hot;
+    int max_owners, min_steps;
+    unsigned char *cold_flag;       // [n_steps] 1: neither row of the step is owned
 };
 
 __global__ __launch_bounds__(256) void slim_item_keys_kernel(const DepParams d) {
@@ -173,17 +205,49 @@ __global__ __launch_bounds__(256) void slim_item_keys_kernel(const DepParams d) 
     d.len2[t] = 2 * (d.indptr[d.su[t] + 1] - d.indptr[d.su[t]]);
 }
 
-// ticket number = how many earlier steps of the stream touch the same item = position inside the item's run
+// ticket number = how many earlier steps of the stream touch the same item = position inside the item's run; the step before it
+// on the item; per item the run's start and length
 __global__ __launch_bounds__(256) void slim_seq_kernel(const DepParams d) {
     const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= 2 * d.n_steps) return;
-    const unsigned long long first_key = d.keys_sorted[q] & 0xFFFFFFFF00000000ull;
+    const int n2 = 2 * d.n_steps;
+    if (q >= n2) return;
+    const unsigned long long key = d.keys_sorted[q];
+    const unsigned long long first_key = key & 0xFFFFFFFF00000000ull;
     int lo = 0, hi = q;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (d.keys_sorted[mid] < first_key) lo = mid + 1; else hi = mid;
     }
-    d.seq[d.vals_sorted[q]] = q - lo;
+    const int slot = d.vals_sorted[q];
+    d.seq[slot] = q - lo;
+    d.iprev[slot] = q > lo ? d.vals_sorted[q - 1] >> 1 : -1;
+    const int item = (int)(key >> 32);
+    if (q == lo) d.run_start[item] = q;
+    if (q + 1 == n2 || (int)(d.keys_sorted[q + 1] >> 32) != item) d.item_cnt[item] = (unsigned)(q - lo + 1);
+}
+
+// The busiest rows get owners: the first max_owners items of the descending count order that have at least min_steps steps.
+__global__ __launch_bounds__(256) void slim_owners_kernel(const DepParams d) {
+    const int h = threadIdx.x;
+    __shared__ int s_n;
+    if (h == 0) s_n = 0;
+    __syncthreads();
+    if (h < d.max_owners && h < d.n_items && (int)d.cnt_sorted[h] >= d.min_steps) {
+        const int item = d.item_by_cnt[h];
+        d.hot_rank[item] = h;
+        d.hot_item[h] = item;
+        d.lst_begin[h] = d.run_start[item];
+        d.lst_len[h] = (int)d.cnt_sorted[h];
+        atomicAdd(&s_n, 1);            // (the qualifying owners are a prefix of the order)
+    }
+    __syncthreads();
+    if (h == 0) *d.n_hot = s_n;
+}
+
+__global__ __launch_bounds__(256) void slim_cold_flag_kernel(const DepParams d) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= d.n_steps) return;
+    d.cold_flag[t] = d.hot_rank[d.si[t]] < 0 && d.hot_rank[d.sj[t]] < 0;
 }
 
 // symmetric store: one wavefront per step lists the canonical cells of its two rows
@@ -196,9 +260,9 @@ __global__ __launch_bounds__(256) void slim_cell_keys_kernel(const DepParams d) 
     const long long cp = d.cellptr[t];
     for (int idx = lane; idx < L; idx += 64) {
         const int s = d.indices[rs + idx];
-        // (packed lower triangle, as cell_at: fits 32 bits up to 92 681 items)
-        const unsigned ci = s == i ? NO_CELL : (unsigned)(((size_t)max(i, s) * ((size_t)max(i, s) + 1) >> 1) + (size_t)min(i, s));
-        const unsigned cj = s == j ? NO_CELL : (unsigned)(((size_t)max(j, s) * ((size_t)max(j, s) + 1) >> 1) + (size_t)min(j, s));
+        // (packed lower triangle, as packed_cell: fits 32 bits up to 92 681 items)
+        const unsigned ci = s == i ? NO_CELL : (unsigned)packed_cell(i, s);
+        const unsigned cj = s == j ? NO_CELL : (unsigned)packed_cell(j, s);
         d.keys[cp + 2 * idx] = ((unsigned long long)ci << 32) | (unsigned)t;
         d.vals[cp + 2 * idx] = (int)(cp + 2 * idx);
         d.keys[cp + 2 * idx + 1] = ((unsigned long long)cj << 32) | (unsigned)t;
@@ -220,253 +284,490 @@ __global__ __launch_bounds__(256) void slim_pred_kernel(const DepParams d) {
 }
 
 // ---- the stream ---------------------------------------------------------------------------------------------------------
-// relaxed poll of one word; a hand-off that does not arrive within SPIN_LIMIT_TICKS raises the abort flag (everybody stops
-// waiting, the call fails) instead of hanging the device
-template <class T>
-__device__ __forceinline__ void wait_for(const SlimParams<T> &p, const int *word, int want, bool exact) {
+// Every wait is a relaxed poll with a budget: a hand-off that does not arrive within SPIN_LIMIT_TICKS raises the abort flag
+// (everybody stops waiting, the call fails) instead of hanging the device.
+struct SpinGuard {
     unsigned polls = 0;
     long long t0 = 0;
+};
+template <class T>
+__device__ __forceinline__ bool give_up(const SlimParams<T> &p, SpinGuard &g) {      // wave-uniform answer
+    __builtin_amdgcn_s_sleep(1);
+    if ((++g.polls & 127u) != 0) return false;
+    int stop = aload(&p.queue[1]);
+    const long long now = wall_clock64();
+    if (g.t0 == 0) g.t0 = now;
+    else if (now - g.t0 > SPIN_LIMIT_TICKS) { astore(&p.queue[1], 1); stop = 1; }
+    return __builtin_amdgcn_readfirstlane(stop) != 0;
+}
+
+// One lane polls a word for the whole wavefront.
+template <class T>
+__device__ __forceinline__ bool wave_wait_word(const SlimParams<T> &p, const int *word, int want, int lane) {
+    SpinGuard sg;
     for (;;) {
-        const int v = aload(word);
-        if (exact ? v == want : v != 0) return;
-        __builtin_amdgcn_s_sleep(2);
-        if ((++polls & 255u) == 0) {
-            if (aload(&p.queue[1])) return;
-            const long long now = wall_clock64();
-            if (t0 == 0) t0 = now;
-            else if (now - t0 > SPIN_LIMIT_TICKS) { astore(&p.queue[1], 1); return; }
-        }
+        int v = want;
+        if (lane == 0) v = aload(word);
+        if (__builtin_amdgcn_readfirstlane(v) == want) return true;
+        if (give_up(p, sg)) return false;
+    }
+}
+template <class T>
+__device__ __forceinline__ bool wave_wait_mail(const SlimParams<T> &p, unsigned long long *word, int lane, double &out) {
+    SpinGuard sg;
+    for (;;) {
+        unsigned long long v = 0;
+        if (lane == 0) v = aload(word);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        v = ((unsigned long long)hi << 32) | lo;
+        if (v != MAIL_EMPTY) { out = __longlong_as_double((long long)v); return true; }
+        if (give_up(p, sg)) return false;
     }
 }
 
-template <class T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+// The sigmoid and the optimiser step of an OWNED row's step sit on the critical path of the whole epoch (the turn of the busiest
+// row), so their instruction count matters: the argument is reduced in float64 (x log2(e) = n + f, |f| <= 1/2, exact), 2^f comes
+// from v_exp_f32 and the reciprocals from v_rcp_f32 (1 ulp each): relative error of the step ~2e-7, against 1e-5 asked of the
+// cells it moves.  Moments stay in float64.
+__device__ __forceinline__ double fast_sigmoid_of_minus(double x) {
+    const double y = fmin(fmax(x * 1.4426950408889634, -120.0), 120.0);
+    const double n = rint(y);
+    const float e = ldexpf(__builtin_amdgcn_exp2f((float)(y - n)), (int)n);
+    return (double)__builtin_amdgcn_rcpf(1.f + e);
+}
+template <class P>
+__device__ __forceinline__ double hot_adapt(const P &p, double g, double pw1, double pw2, double &c1, double &c2) {
+    switch (p.sgd_mode) {
+        case MI355REC_ADAGRAD:
+            c1 = c1 + g * g;
+            return (double)((float)g * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf((float)c1) + 1e-8f));
+        case MI355REC_RMSPROP:
+            c1 = c1 * (double)p.gamma + (double)p.one_m_gamma * (g * g);
+            return (double)((float)g * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf((float)c1) + 1e-8f));
+        case MI355REC_ADAM:
+            c1 = c1 * (double)p.beta_1 + (double)p.one_m_beta_1 * g;
+            c2 = c2 * (double)p.beta_2 + (double)p.one_m_beta_2 * (g * g);
+            return (double)((float)(c1 / pw1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf((float)(c2 / pw2)) + 1e-8f));
+        default:
+            return g;
+    }
 }
 
-// BATCHED (experimental, MI355REC_SLIM_BATCHED=1, symmetric store only; NOT in the test suite): the `done` words of all last
-// writers of a thread's cells are requested under one wait, only the stragglers are polled, then all cells are gathered under one
-// wait -- instead of poll, gather, poll, gather with up to 3 x FLOW_REGS dependent round trips per step.  Round 3: equal results on
-// small matrices, but the ML-1M-shape symmetric epoch stalled (twice; with `done[0]` and with `done[t]` as the dummy word of lanes
-// without a predecessor) and the cause was not found -- kept so that the next session with a GPU can debug it.
-template <class T, bool SYM, bool BATCHED = false>
-__global__ __launch_bounds__(FLOW_THREADS) void slim_flow_kernel(const SlimParams<T> p) {
-    __shared__ int s_t;
-    __shared__ T s_part[FLOW_THREADS / 64];
-    __shared__ T s_g[2];
+// ---- dense store ----------------------------------------------------------------------------------------------------------
+// One step on two rows in HBM, run by ONE wavefront: tickets of the two items (lanes 0 and 1 poll), gathers, reduction, the two
+// per-item optimiser steps, write-through scatters, drain, tickets passed on.
+template <class T>
+__device__ __forceinline__ void cold_step(const SlimParams<T> &p, const int t, const int lane) {
+    const int u = p.su[t], i = p.si[t], j = p.sj[t];
+    const int rs = p.indptr[u], L = p.indptr[u + 1] - rs;
+    const size_t n = (size_t)p.n_items;
+    int sv[FLOW_REGS];
+#pragma unroll
+    for (int r = 0; r < FLOW_REGS; ++r) sv[r] = p.indices[rs + min(lane + 64 * r, L - 1)];      // L >= 1: users without interactions are never drawn
+    const int want = lane < 2 ? p.seq[2 * t + lane] : 0;
+    {
+        const int *word = &p.ticket[lane == 1 ? j : i];
+        SpinGuard sg;
+        for (;;) {
+            const int v = lane < 2 ? aload(word) : 0;
+            if (__all(v == want)) break;
+            if (give_up(p, sg)) return;
+        }
+    }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    // the items' optimiser cells belong to whoever holds the items' tickets: lane 0 looks after item i, lane 1 after item j
+    T oc1 = (T)0, oc2 = (T)0;
+    if (lane < 2 && p.sgd_mode != MI355REC_SGD) {
+        oc1 = aload(&p.c1[lane ? j : i]);
+        if (p.sgd_mode == MI355REC_ADAM) oc2 = aload(&p.c2[lane ? j : i]);
+    }
+    T *Si = p.S + (size_t)i * n, *Sj = p.S + (size_t)j * n;
+    T va[FLOW_REGS], vb[FLOW_REGS];
+    T x = (T)0;
+#pragma unroll
+    for (int r = 0; r < FLOW_REGS; ++r) {       // loads from clamped, always valid addresses, masked afterwards: one wait for all of them
+        va[r] = aload(Si + sv[r]);
+        vb[r] = aload(Sj + sv[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < FLOW_REGS; ++r) {
+        const bool live = lane + 64 * r < L;
+        va[r] = live ? va[r] : (T)0;
+        vb[r] = live ? vb[r] : (T)0;
+        x += va[r] - vb[r];                                           // x_uij over the profile (.pyx:243-260)
+    }
+    for (int idx = lane + 64 * FLOW_REGS; idx < L; idx += 64) {       // profiles longer than 256
+        const int s = p.indices[rs + idx];
+        x += aload(Si + s) - aload(Sj + s);
+    }
+    x = wave_sum(x);
+    const T g = sigmoid_of_minus(x);                                  // .pyx:263
+    T pw1, pw2;
+    adam_powers(p, t, pw1, pw2);
+    const T step = slim_adapt_cells(p, g, pw1, pw2, oc1, oc2);        // item i on lane 0, item j on lane 1 (.pyx:267-268)
+    if (lane < 2 && p.sgd_mode != MI355REC_SGD) {
+        astore(&p.c1[lane ? j : i], oc1);
+        if (p.sgd_mode == MI355REC_ADAM) astore(&p.c2[lane ? j : i], oc2);
+    }
+    const T gi = __shfl(step, 0), gj = __shfl(step, 1);
+    if (lane == 0) atomicAdd(&p.loss_slots[t & (LOSS_SLOTS - 1)], (double)x * (double)x);
+    // the two rows move (.pyx:271-309); write-through stores
+#pragma unroll
+    for (int r = 0; r < FLOW_REGS; ++r) {
+        if (lane + 64 * r < L) {
+            const int s = sv[r];
+            if (s != i) astore(Si + s, cell_plus(va[r], p.lr, gi, p.li_reg));
+            if (s != j) astore(Sj + s, cell_minus(vb[r], p.lr, gj, p.lj_reg));
+        }
+    }
+    for (int idx = lane + 64 * FLOW_REGS; idx < L; idx += 64) {
+        const int s = p.indices[rs + idx];
+        if (s != i) astore(Si + s, cell_plus(aload(Si + s), p.lr, gi, p.li_reg));
+        if (s != j) astore(Sj + s, cell_minus(aload(Sj + s), p.lr, gj, p.lj_reg));
+    }
+    // publish: drain the write-through stores, then pass the tickets on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane < 2) astore(&p.ticket[lane ? j : i], want + 1);
+}
+
+// The steps of one OWNED row, in stream order, by the 16 wavefronts of the owning workgroup in turn.  `row` is the item's row of S
+// in LDS (float32), `oc` its two optimiser cells (float64).  Entry k of the row's list is step t with the row in role 0 (the
+// positive item) or 1 (the negative item); the OTHER row of the step is
+//   in HBM    -> this wavefront does that row's half of the step as well: waits for its ticket, gathers its cells and sums them
+//                BEFORE its turn, writes them back and passes the ticket on AFTER its turn;
+//   owned too -> the two owners exchange two scalars through the step's mailbox (the negative item's owner sends its sum, the
+//                positive item's owner answers with the sigmoid), both inside their turns.
+// A turn: LDS gather, wavefront reduction, sigmoid, the item's optimiser step, LDS scatter, turn counter + 1.
+template <class T>
+__device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, float *row, volatile int *turn, volatile double *oc,
+                                          const int lane, const int wave) {
+    const int item = p.hot_item[h], first = p.lst_begin[h], len = p.lst_len[h];
+    const size_t n = (size_t)p.n_items;
+    const float lr = (float)p.lr, li_reg = (float)p.li_reg, lj_reg = (float)p.lj_reg;
+    for (int k = wave; k < len; k += FLOW_WAVES) {
+        const int slot = p.item_sorted[first + k];
+        const int t = slot >> 1, role = slot & 1;
+        const int u = p.su[t], other = role ? p.si[t] : p.sj[t];
+        const int rs = p.indptr[u], L = p.indptr[u + 1] - rs;
+        int sv[FLOW_REGS];
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) sv[r] = p.indices[rs + min(lane + 64 * r, L - 1)];
+        const bool mail = p.hot_rank[other] >= 0;
+        // ---- before the turn: the other row's half ------------------------------------------------------------------------
+        T *So = p.S + (size_t)other * n;
+        T vo[FLOW_REGS];
+        T oc1 = (T)0, oc2 = (T)0;
+        double xo = 0.0;
+        int want = 0;
+        if (!mail) {
+            want = p.seq[2 * t + (1 - role)];
+            if (!wave_wait_word(p, &p.ticket[other], want, lane)) return;
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            if (lane == 0 && p.sgd_mode != MI355REC_SGD) {
+                oc1 = aload(&p.c1[other]);
+                if (p.sgd_mode == MI355REC_ADAM) oc2 = aload(&p.c2[other]);
+            }
+#pragma unroll
+            for (int r = 0; r < FLOW_REGS; ++r) vo[r] = aload(So + sv[r]);
+#pragma unroll
+            for (int r = 0; r < FLOW_REGS; ++r) {
+                vo[r] = lane + 64 * r < L ? vo[r] : (T)0;
+                xo += (double)vo[r];
+            }
+            for (int idx = lane + 64 * FLOW_REGS; idx < L; idx += 64) xo += (double)aload(So + p.indices[rs + idx]);
+            xo = wave_sum(xo);
+        }
+        double pw1, pw2;
+        adam_powers(p, t, pw1, pw2);
+        // ---- the turn -------------------------------------------------------------------------------------------------------
+        {
+            SpinGuard sg;
+            unsigned spins = 0;
+            while (__builtin_amdgcn_readfirstlane(*turn) != k)
+                if ((++spins & 1023u) == 0 && give_up(p, sg)) return;
+        }
+        __builtin_amdgcn_s_setprio(3);
+        asm volatile("" ::: "memory");
+        float vr[FLOW_REGS];
+        double xr = 0.0;
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) {
+            vr[r] = lane + 64 * r < L ? row[sv[r]] : 0.f;
+            xr += (double)vr[r];
+        }
+        for (int idx = lane + 64 * FLOW_REGS; idx < L; idx += 64) xr += (double)row[p.indices[rs + idx]];
+        xr = wave_sum(xr);
+        double g, x = 0.0;
+        if (!mail) {
+            x = role ? xo - xr : xr - xo;                             // x_uij = sum over S[i, .] - sum over S[j, .]
+            g = fast_sigmoid_of_minus(x);
+        } else if (role) {      // this row is the step's negative item: send the sum, wait for the sigmoid
+            if (lane == 0) astore(&p.mail_x[t], (unsigned long long)__double_as_longlong(xr));
+            if (!wave_wait_mail(p, &p.mail_g[t], lane, g)) { __builtin_amdgcn_s_setprio(0); return; }
+        } else {
+            if (!wave_wait_mail(p, &p.mail_x[t], lane, xo)) { __builtin_amdgcn_s_setprio(0); return; }
+            x = xr - xo;
+            g = fast_sigmoid_of_minus(x);
+            if (lane == 0) astore(&p.mail_g[t], (unsigned long long)__double_as_longlong(g));
+        }
+        double c1 = oc[0], c2 = oc[1];
+        const double gr = hot_adapt(p, g, pw1, pw2, c1, c2);
+        if (lane == 0) { oc[0] = c1; oc[1] = c2; }
+        // (the row's cells are float32: their update in float32 arithmetic adds ~1e-7 of the INCREMENT to the rounding of the sum)
+        const float reg = role ? lj_reg : li_reg, grf = (float)gr;
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) {
+            if (lane + 64 * r < L && sv[r] != item) row[sv[r]] = role ? cell_minus(vr[r], lr, grf, reg) : cell_plus(vr[r], lr, grf, reg);
+        }
+        for (int idx = lane + 64 * FLOW_REGS; idx < L; idx += 64) {
+            const int s = p.indices[rs + idx];
+            if (s != item) row[s] = role ? cell_minus(row[s], lr, grf, reg) : cell_plus(row[s], lr, grf, reg);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the row's new cells are in LDS before the next wavefront is let in
+        if (lane == 0) *turn = k + 1;
+        __builtin_amdgcn_s_setprio(0);
+        // ---- after the turn: the other row moves, its ticket is passed on -------------------------------------------------------
+        if (!mail) {
+            T po1, po2;
+            adam_powers(p, t, po1, po2);
+            const T go = slim_adapt_cells(p, (T)g, po1, po2, oc1, oc2);
+            if (lane == 0 && p.sgd_mode != MI355REC_SGD) {
+                astore(&p.c1[other], oc1);
+                if (p.sgd_mode == MI355REC_ADAM) astore(&p.c2[other], oc2);
+            }
+            const T go_all = __shfl(go, 0);                            // (lane 0 holds the item's optimiser cells)
+            // (the other row is the negative item when this one is the positive: .pyx:296-309)
+#pragma unroll
+            for (int r = 0; r < FLOW_REGS; ++r) {
+                if (lane + 64 * r < L && sv[r] != other)
+                    astore(So + sv[r], role ? cell_plus(vo[r], p.lr, go_all, p.li_reg) : cell_minus(vo[r], p.lr, go_all, p.lj_reg));
+            }
+            for (int idx = lane + 64 * FLOW_REGS; idx < L; idx += 64) {
+                const int s = p.indices[rs + idx];
+                if (s != other)
+                    astore(So + s, role ? cell_plus(aload(So + s), p.lr, go_all, p.li_reg) : cell_minus(aload(So + s), p.lr, go_all, p.lj_reg));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) astore(&p.ticket[other], want + 1);
+        }
+        if (lane == 0 && !(mail && role)) atomicAdd(&p.loss_slots[t & (LOSS_SLOTS - 1)], x * x);
+    }
+}
+
+// Workgroups 0 .. n_hot - 1 own a row each; the others (and an owner once its list is done) run the cold list.
+template <class T>
+__global__ __launch_bounds__(FLOW_THREADS) void slim_dense_flow_kernel(const SlimParams<T> p, const int owners) {
+    extern __shared__ __attribute__((aligned(16))) float flow_lds[];
+    __shared__ int s_turn, s_base;
+    __shared__ double s_oc[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_hot = owners ? *p.n_hot : 0;
+    if ((int)blockIdx.x < n_hot) {
+        const int h = blockIdx.x, item = p.hot_item[h];
+        T *Sr = p.S + (size_t)item * p.n_items;
+        for (int c = tid; c < p.n_items; c += FLOW_THREADS) flow_lds[c] = (float)Sr[c];
+        if (tid == 0) {
+            s_turn = 0;
+            s_oc[0] = p.sgd_mode != MI355REC_SGD ? (double)p.c1[item] : 0.0;
+            s_oc[1] = p.sgd_mode == MI355REC_ADAM ? (double)p.c2[item] : 0.0;
+        }
+        __syncthreads();
+        owned_row(p, h, flow_lds, &s_turn, s_oc, lane, wave);
+        __syncthreads();
+        for (int c = tid; c < p.n_items; c += FLOW_THREADS) Sr[c] = (T)flow_lds[c];
+        if (tid == 0) {
+            if (p.sgd_mode != MI355REC_SGD) p.c1[item] = (T)s_oc[0];
+            if (p.sgd_mode == MI355REC_ADAM) p.c2[item] = (T)s_oc[1];
+        }
+    }
+    const int n_cold = *p.n_cold;
+    for (;;) {
+        if (tid == 0) s_base = aload(&p.queue[1]) ? 0x7fffffff : atomicAdd(&p.queue[0], FLOW_WAVES);       // in-order queue: everything a step can wait for is already running
+        __syncthreads();
+        const int base = s_base;
+        if (base >= n_cold) break;
+        if (base + wave < n_cold) cold_step(p, p.cold_list[base + wave], lane);
+        __syncthreads();
+    }
+}
+
+// ---- symmetric store ------------------------------------------------------------------------------------------------------
+// One step by ONE wavefront.  Every cell is a granule {value, tag of the step that wrote it}; the step knows which step wrote each
+// of its cells last (`pred`), so it loads all its granules at once and re-loads only those whose tag is not there yet.  Its own
+// stores carry its tag: nothing is drained, no flag is raised.  The optimiser cells of the two items travel as granules, too
+// (lane 0: item i, lane 1: item j; float64 as two float32 halves, each with its own tag).
+__device__ __forceinline__ bool tag_ok(int pred, unsigned tag, unsigned tag_base) { return pred < 0 || tag == tag_base + (unsigned)pred + 1u; }
+
+__device__ __forceinline__ void sym_step(const SlimParams<double> &p, const int t, const int lane) {
+    const int u = p.su[t], i = p.si[t], j = p.sj[t];
+    const int rs = p.indptr[u], L = p.indptr[u + 1] - rs;
+    const long long cp = p.cellptr[t];
+    const unsigned my_tag = p.tag_base + (unsigned)t + 1u;
+    const bool adaptive = p.sgd_mode != MI355REC_SGD, adam = p.sgd_mode == MI355REC_ADAM;
+    int sv[FLOW_REGS], pa[FLOW_REGS], pb[FLOW_REGS];
+    Granule *ca[FLOW_REGS], *cb[FLOW_REGS];
+#pragma unroll
+    for (int r = 0; r < FLOW_REGS; ++r) {
+        const int at = min(lane + 64 * r, L - 1);
+        sv[r] = p.indices[rs + at];
+        const int2 pp = *reinterpret_cast<const int2 *>(p.pred + cp + 2 * at);
+        pa[r] = pp.x;
+        pb[r] = pp.y;
+    }
+    Granule ga[FLOW_REGS], gb[FLOW_REGS];
+#pragma unroll
+    for (int r = 0; r < FLOW_REGS; ++r) {
+        const bool live = lane + 64 * r < L;
+        pa[r] = live ? pa[r] : -1;
+        pb[r] = live ? pb[r] : -1;
+        ca[r] = p.G + packed_cell(i, sv[r]);
+        cb[r] = p.G + packed_cell(j, sv[r]);
+        ga[r] = gload(ca[r]);
+        gb[r] = gload(cb[r]);
+    }
+    // optimiser granules of the lane's item
+    Granule *oc = p.oc + 4 * (size_t)(lane == 1 ? j : i);
+    const int ip = lane < 2 && adaptive ? p.iprev[2 * t + lane] : -1;
+    Granule o[4] = {{0.f, 0u}, {0.f, 0u}, {0.f, 0u}, {0.f, 0u}};
+    if (lane < 2 && adaptive) {
+        o[0] = gload(oc);
+        o[1] = gload(oc + 1);
+        if (adam) {
+            o[2] = gload(oc + 2);
+            o[3] = gload(oc + 3);
+        }
+    }
+    {
+        SpinGuard sg;
+        for (;;) {
+            bool pending = false;
+#pragma unroll
+            for (int r = 0; r < FLOW_REGS; ++r) {
+                if (!tag_ok(pa[r], ga[r].tag, p.tag_base)) { pending = true; ga[r] = gload(ca[r]); }
+                if (!tag_ok(pb[r], gb[r].tag, p.tag_base)) { pending = true; gb[r] = gload(cb[r]); }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if ((e < 2 || adam) && !tag_ok(ip, o[e].tag, p.tag_base)) { pending = true; o[e] = gload(oc + e); }
+            if (!__any(pending)) break;
+            if (give_up(p, sg)) return;
+        }
+    }
+    double x = 0.0;
+#pragma unroll
+    for (int r = 0; r < FLOW_REGS; ++r)
+        if (lane + 64 * r < L) x += (double)ga[r].v - (double)gb[r].v;                    // x_uij over the profile (.pyx:243-260)
+    for (int c0 = 64 * FLOW_REGS; c0 < L; c0 += 64) {                                     // profiles longer than 256
+        const int idx = c0 + lane;
+        const bool live = idx < L;
+        const int at = min(idx, L - 1);
+        const int s = p.indices[rs + at];
+        const int2 pp = *reinterpret_cast<const int2 *>(p.pred + cp + 2 * at);
+        const int qa = live ? pp.x : -1, qb = live ? pp.y : -1;
+        Granule *a = p.G + packed_cell(i, s), *b = p.G + packed_cell(j, s);
+        Granule va = gload(a), vb = gload(b);
+        SpinGuard sg;
+        for (;;) {
+            bool pending = false;
+            if (!tag_ok(qa, va.tag, p.tag_base)) { pending = true; va = gload(a); }
+            if (!tag_ok(qb, vb.tag, p.tag_base)) { pending = true; vb = gload(b); }
+            if (!__any(pending)) break;
+            if (give_up(p, sg)) return;
+        }
+        if (live) x += (double)va.v - (double)vb.v;
+    }
+    x = wave_sum(x);
+    const double g = sigmoid_of_minus(x);                                                 // .pyx:263
+    double pw1, pw2;
+    adam_powers(p, t, pw1, pw2);
+    double c1 = (double)o[0].v + (double)o[1].v, c2 = (double)o[2].v + (double)o[3].v;
+    const double step = slim_adapt_cells(p, g, pw1, pw2, c1, c2);                         // item i on lane 0, item j on lane 1 (.pyx:267-268)
+    if (lane < 2 && adaptive) {
+        const float h1 = (float)c1;
+        gstore(oc, h1, my_tag);
+        gstore(oc + 1, (float)(c1 - (double)h1), my_tag);
+        if (adam) {
+            const float h2 = (float)c2;
+            gstore(oc + 2, h2, my_tag);
+            gstore(oc + 3, (float)(c2 - (double)h2), my_tag);
+        }
+    }
+    const double gi = __shfl(step, 0), gj = __shfl(step, 1);
+    if (lane == 0) atomicAdd(&p.loss_slots[t & (LOSS_SLOTS - 1)], x * x);
+    // the two rows move (.pyx:271-309): one write-through store per cell, value and tag together
+#pragma unroll
+    for (int r = 0; r < FLOW_REGS; ++r) {
+        if (lane + 64 * r < L) {
+            if (sv[r] != i) gstore(ca[r], (float)cell_plus((double)ga[r].v, p.lr, gi, p.li_reg), my_tag);
+            if (sv[r] != j) gstore(cb[r], (float)cell_minus((double)gb[r].v, p.lr, gj, p.lj_reg), my_tag);
+        }
+    }
+    for (int idx = 64 * FLOW_REGS + lane; idx < L; idx += 64) {
+        // (nobody can have written these cells since they were read above: a later step waits for THIS step's tag on them)
+        const int s = p.indices[rs + idx];
+        Granule *a = p.G + packed_cell(i, s), *b = p.G + packed_cell(j, s);
+        if (s != i) gstore(a, (float)cell_plus((double)gload(a).v, p.lr, gi, p.li_reg), my_tag);
+        if (s != j) gstore(b, (float)cell_minus((double)gload(b).v, p.lr, gj, p.lj_reg), my_tag);
+    }
+}
+
+__global__ __launch_bounds__(FLOW_THREADS) void slim_sym_flow_kernel(const SlimParams<double> p) {
+    __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (;;) {
-        if (tid == 0) s_t = atomicAdd(&p.queue[0], 1);         // in-order queue: everything this step can wait for is already running
+        if (tid == 0) s_base = aload(&p.queue[1]) ? 0x7fffffff : atomicAdd(&p.queue[0], FLOW_WAVES);       // in-order queue: everything a step can wait for is already running
         __syncthreads();
-        const int t = s_t;
-        if (t >= p.n_steps) break;
-        const int u = p.su[t], i = p.si[t], j = p.sj[t];
-        const int rs = p.indptr[u], L = p.indptr[u + 1] - rs;
-        const long long cp = SYM ? p.cellptr[t] : 0;
-        // profile entries and (symmetric) the last writers of their cells do not depend on anybody: fetch them before waiting
-        int sv[FLOW_REGS], pa[FLOW_REGS], pb[FLOW_REGS];
-        if constexpr (BATCHED) {
-            // loads from clamped, always valid addresses, masked afterwards: with a load inside a conditional the compiler waits for
-            // each one where its branch ends
-#pragma unroll
-            for (int r = 0; r < FLOW_REGS; ++r) {
-                const int idx = tid + r * FLOW_THREADS, at = min(idx, L - 1);        // L >= 1: users without interactions are never drawn
-                sv[r] = p.indices[rs + at];
-                const int2 pp = *reinterpret_cast<const int2 *>(p.pred + cp + 2 * at);
-                pa[r] = pp.x;
-                pb[r] = pp.y;
-            }
-#pragma unroll
-            for (int r = 0; r < FLOW_REGS; ++r) {
-                const bool live = tid + r * FLOW_THREADS < L;
-                pa[r] = live ? pa[r] : -1;
-                pb[r] = live ? pb[r] : -1;
-            }
-        } else {
-#pragma unroll
-        for (int r = 0; r < FLOW_REGS; ++r) {
-            const int idx = tid + r * FLOW_THREADS;
-            sv[r] = idx < L ? p.indices[rs + idx] : 0;
-            pa[r] = SYM && idx < L ? p.pred[cp + 2 * idx] : -1;
-            pb[r] = SYM && idx < L ? p.pred[cp + 2 * idx + 1] : -1;
-        }
-        }
-        if (p.use_tickets) {
-            if (tid < 2) wait_for(p, &p.ticket[tid ? j : i], p.seq[2 * t + tid], true);
-            __syncthreads();
-        }
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        // the items' optimiser cells belong to whoever holds the items' tickets: requested now, next to the gathers, instead of
-        // after the gradient is known (one dependent round trip less per step for adagrad / rmsprop / adam)
-        T oc1_i = (T)0, oc1_j = (T)0, oc2_i = (T)0, oc2_j = (T)0;
-        if (tid == 0 && p.sgd_mode != MI355REC_SGD) {
-            oc1_i = aload(&p.c1[i]);
-            oc1_j = aload(&p.c1[j]);
-            if (p.sgd_mode == MI355REC_ADAM) {
-                oc2_i = aload(&p.c2[i]);
-                oc2_j = aload(&p.c2[j]);
-            }
-        }
-        // x_uij over the profile (.pyx:243-260)
-        T x = (T)0;
-        T va[FLOW_REGS], vb[FLOW_REGS];
-        if constexpr (BATCHED) {
-            int fa[FLOW_REGS], fb[FLOW_REGS];
-#pragma unroll
-            for (int r = 0; r < FLOW_REGS; ++r) {       // (lanes without a predecessor read this step's own word)
-                fa[r] = aload(&p.done[pa[r] >= 0 ? pa[r] : t]);
-                fb[r] = aload(&p.done[pb[r] >= 0 ? pb[r] : t]);
-            }
-#pragma unroll
-            for (int r = 0; r < FLOW_REGS; ++r) {
-                if (pa[r] >= 0 && !fa[r]) wait_for(p, &p.done[pa[r]], 1, false);
-                if (pb[r] >= 0 && !fb[r]) wait_for(p, &p.done[pb[r]], 1, false);
-            }
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < FLOW_REGS; ++r) {
-                va[r] = aload(&p.S[cell_at(p, i, sv[r])]);
-                vb[r] = aload(&p.S[cell_at(p, j, sv[r])]);
-            }
-#pragma unroll
-            for (int r = 0; r < FLOW_REGS; ++r) {
-                const bool live = tid + r * FLOW_THREADS < L;
-                va[r] = live ? va[r] : (T)0;
-                vb[r] = live ? vb[r] : (T)0;
-                x += va[r] - vb[r];
-            }
-        } else {
-#pragma unroll
-        for (int r = 0; r < FLOW_REGS; ++r) {
-            const int idx = tid + r * FLOW_THREADS;
-            va[r] = (T)0;
-            vb[r] = (T)0;
-            if (idx < L) {
-                if (SYM) {
-                    if (pa[r] >= 0) wait_for(p, &p.done[pa[r]], 1, false);
-                    if (pb[r] >= 0) wait_for(p, &p.done[pb[r]], 1, false);
-                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                }
-                va[r] = aload(&p.S[cell_at(p, i, sv[r])]);
-                vb[r] = aload(&p.S[cell_at(p, j, sv[r])]);
-                x += va[r] - vb[r];
-            }
-        }
-        }
-        for (int idx = tid + FLOW_REGS * FLOW_THREADS; idx < L; idx += FLOW_THREADS) {    // profiles longer than 1024
-            const int s = p.indices[rs + idx];
-            if (SYM) {
-                const int a = p.pred[cp + 2 * idx], b = p.pred[cp + 2 * idx + 1];
-                if (a >= 0) wait_for(p, &p.done[a], 1, false);
-                if (b >= 0) wait_for(p, &p.done[b], 1, false);
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            }
-            x += aload(&p.S[cell_at(p, i, s)]) - aload(&p.S[cell_at(p, j, s)]);
-        }
-        x = wave_sum(x);
-        if (lane == 0) s_part[wave] = x;
+        const int base = s_base;
+        if (base >= p.n_steps) break;
+        if (base + wave < p.n_steps) sym_step(p, base + wave, lane);
         __syncthreads();
-        if (tid == 0) {
-            T tot = (T)0;
-#pragma unroll
-            for (int w = 0; w < FLOW_THREADS / 64; ++w) tot += s_part[w];
-            const T g = sigmoid_of_minus(tot);                         // .pyx:263
-            T pw1 = (T)1, pw2 = (T)1;
-            if (p.sgd_mode == MI355REC_ADAM) {
-                const double tt = (double)(p.steps_before + t + 1);
-                pw1 = (T)(1.0 - pow(p.beta_1_d, tt));
-                pw2 = (T)(1.0 - pow(p.beta_2_d, tt));
-            }
-            s_g[0] = slim_adapt_cells(p, g, i, pw1, pw2, oc1_i, oc2_i);     // item i first, then j, as .pyx:267-268
-            s_g[1] = j != i ? slim_adapt_cells(p, g, j, pw1, pw2, oc1_j, oc2_j) : slim_adapt(p, g, j, pw1, pw2);      // (a replayed stream may repeat the item)
-            atomicAdd(&p.loss_slots[t & (LOSS_SLOTS - 1)], (double)tot * (double)tot);
-        }
-        __syncthreads();
-        const T gi = s_g[0], gj = s_g[1];
-        // the two rows move (.pyx:271-309); write-through stores
-#pragma unroll
-        for (int r = 0; r < FLOW_REGS; ++r) {
-            const int idx = tid + r * FLOW_THREADS;
-            if (idx < L) {
-                const int s = sv[r];
-                if (s != i) astore(&p.S[cell_at(p, i, s)], cell_plus(va[r], p.lr, gi, p.li_reg));
-                if (s != j) astore(&p.S[cell_at(p, j, s)], cell_minus(vb[r], p.lr, gj, p.lj_reg));
-            }
-        }
-        for (int idx = tid + FLOW_REGS * FLOW_THREADS; idx < L; idx += FLOW_THREADS) {
-            const int s = p.indices[rs + idx];
-            if (s != i) {
-                T *c = &p.S[cell_at(p, i, s)];
-                const T v = aload(c);
-                astore(c, cell_plus(v, p.lr, gi, p.li_reg));
-            }
-            if (s != j) {
-                T *c = &p.S[cell_at(p, j, s)];
-                const T v = aload(c);
-                astore(c, cell_minus(v, p.lr, gj, p.lj_reg));
-            }
-        }
-        // publish: every storing wavefront drains its write-through stores, then ONE lane passes the tickets on
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            if (p.use_tickets) {
-                astore(&p.ticket[i], p.seq[2 * t] + 1);
-                astore(&p.ticket[j], p.seq[2 * t + 1] + 1);
-            }
-            if (SYM) astore(&p.done[t], 1);
-        }
     }
 }
 
 // Fallback (symmetric store with more than 92 681 items: packed cell ids no longer fit the 32-bit sort key): one workgroup runs
-// the steps one after the other.
-template <class T>
-__global__ __launch_bounds__(1024) void slim_ordered_kernel(const SlimParams<T> p) {
-    __shared__ T s_part[16];
-    __shared__ T s_g[2];
+// the steps one after the other (plain accesses: one compute unit, one L1).
+__global__ __launch_bounds__(1024) void slim_ordered_kernel(const SlimParams<double> p) {
+    __shared__ double s_part[16];
+    __shared__ double s_g[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int t = 0; t < p.n_steps; ++t) {
         const int u = p.su[t], i = p.si[t], j = p.sj[t];
         const int rs = p.indptr[u], re = p.indptr[u + 1];
-        T x = (T)0;
+        double x = 0.0;
         for (int q = rs + tid; q < re; q += 1024) {
             const int s = p.indices[q];
-            x += p.S[cell_at(p, i, s)] - p.S[cell_at(p, j, s)];
+            x += (double)p.G[packed_cell(i, s)].v - (double)p.G[packed_cell(j, s)].v;
         }
         x = wave_sum(x);
         if (lane == 0) s_part[wave] = x;
         __syncthreads();
         if (tid == 0) {
-            T tot = (T)0;
+            double tot = 0.0;
             for (int w = 0; w < 16; ++w) tot += s_part[w];
-            const T g = sigmoid_of_minus(tot);
-            T pw1 = (T)1, pw2 = (T)1;
-            if (p.sgd_mode == MI355REC_ADAM) {
-                const double tt = (double)(p.steps_before + t + 1);
-                pw1 = (T)(1.0 - pow(p.beta_1_d, tt));
-                pw2 = (T)(1.0 - pow(p.beta_2_d, tt));
+            const double g = sigmoid_of_minus(tot);
+            double pw1, pw2;
+            adam_powers(p, t, pw1, pw2);
+            for (int e = 0; e < 2; ++e) {                                 // item i first, then j (.pyx:267-268)
+                Granule *oc = p.oc + 4 * (size_t)(e ? j : i);
+                double c1 = (double)oc[0].v + (double)oc[1].v, c2 = (double)oc[2].v + (double)oc[3].v;
+                s_g[e] = slim_adapt_cells(p, g, pw1, pw2, c1, c2);
+                const float h1 = (float)c1, h2 = (float)c2;
+                oc[0].v = h1; oc[1].v = (float)(c1 - (double)h1);
+                oc[2].v = h2; oc[3].v = (float)(c2 - (double)h2);
             }
-            s_g[0] = slim_adapt(p, g, i, pw1, pw2);
-            s_g[1] = slim_adapt(p, g, j, pw1, pw2);
-            p.loss_slots[t & (LOSS_SLOTS - 1)] += (double)tot * (double)tot;
+            p.loss_slots[t & (LOSS_SLOTS - 1)] += tot * tot;
         }
         __syncthreads();
-        const T gi = s_g[0], gj = s_g[1];
+        const double gi = s_g[0], gj = s_g[1];
         for (int q = rs + tid; q < re; q += 1024) {
             const int s = p.indices[q];
             if (s != i) {
-                T *c = &p.S[cell_at(p, i, s)];
-                const T v = *c;
-                *c = cell_plus(v, p.lr, gi, p.li_reg);
+                Granule *c = &p.G[packed_cell(i, s)];
+                c->v = (float)cell_plus((double)c->v, p.lr, gi, p.li_reg);
             }
             if (s != j) {
-                T *c = &p.S[cell_at(p, j, s)];
-                const T v = *c;
-                *c = cell_minus(v, p.lr, gj, p.lj_reg);
+                Granule *c = &p.G[packed_cell(j, s)];
+                c->v = (float)cell_minus((double)c->v, p.lr, gj, p.lj_reg);
             }
         }
         __threadfence_block();       // the next step of this workgroup must read what this one wrote
@@ -489,7 +790,7 @@ __global__ __launch_bounds__(THREADS) void slim_topk_kernel(const SlimParams<T> 
         __syncthreads();
         uint32_t npos = 0, nneg = 0;
         for (int c = tid; c < p.n_items; c += THREADS) {
-            const float v = c == r ? 0.f : (float)p.S[cell_at(p, r, c)];
+            const float v = c == r ? 0.f : stored_value(p, r, c);
             acc[c] = v;
             npos += v > 0.f;
             nneg += v < 0.f;
@@ -517,7 +818,7 @@ __global__ void slim_dense_kernel(const SlimParams<T> p, float *out) {
     const size_t n = (size_t)p.n_items;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n * n; e += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(e / n), c = (int)(e % n);
-        out[e] = r == c ? 0.f : (float)p.S[cell_at(p, r, c)];
+        out[e] = r == c ? 0.f : stored_value(p, r, c);
     }
 }
 
@@ -761,18 +1062,26 @@ using namespace mi355rec;
 struct mi355rec_slim {
     mi355rec_slim_config cfg{};
     int n_users = 0, n_items = 0;
-    bool f64 = false;
+    bool f64 = false;           // arithmetic type; storage type of the dense store and its optimiser cells
     size_t nnz = 0;
     hipStream_t stream = nullptr;
     StreamTimer call_timer;
     DispatchTimers dispatch_timers;
-    DeviceBuffer<int> indptr, indices, su, si, sj, seq, len2, ticket, done, queue, vals, vals_sorted, pred;
+    DeviceBuffer<int> indptr, indices, su, si, sj, seq, iprev, len2, ticket, queue, vals, vals_sorted, pred;
     DeviceBuffer<long long> cellptr;
     DeviceBuffer<unsigned long long> keys, keys_sorted;
-    DeviceBuffer<unsigned char> S, c1, c2, cub_tmp;     // S, c1, c2: float or double by `f64`
+    DeviceBuffer<unsigned char> S, c1, c2, cub_tmp;     // dense store: S, c1, c2 are float or double by `f64`
+    DeviceBuffer<Granule> G, oc;                        // symmetric store: packed triangle of granules, [n_items][4] optimiser granules
     DeviceBuffer<double> loss_slots;
+    // dense store: owned rows
+    DeviceBuffer<int> run_start, hot_rank, hot_tables, counters, cold_list, iota, item_by_cnt;     // hot_tables: item | first | length
+    DeviceBuffer<unsigned> item_cnt, cnt_sorted;
+    DeviceBuffer<unsigned char> cold_flag;
+    DeviceBuffer<unsigned long long> mail;              // [2][stream_capacity]
     size_t stream_capacity = 0, cell_capacity = 0;
     long long steps_done = 0, epochs_done = 0;
+    unsigned tag_base = 0;                              // symmetric store: tags handed out so far
+    int last_owners = 0, last_cold = 0;                 // owned rows / steps on rows in HBM of the last dense launch (diagnostics)
     std::vector<double> h_loss;
     mi355rec_stats stats{};
 
@@ -797,35 +1106,49 @@ void fill_params(mi355rec_slim *h, SlimParams<T> &p) {
     p.seed = c.random_seed;
     p.indptr = h->indptr.ptr; p.indices = h->indices.ptr;
     p.S = reinterpret_cast<T *>(h->S.ptr); p.c1 = reinterpret_cast<T *>(h->c1.ptr); p.c2 = reinterpret_cast<T *>(h->c2.ptr);
+    p.G = h->G.ptr; p.oc = h->oc.ptr;
     p.su = h->su.ptr; p.si = h->si.ptr; p.sj = h->sj.ptr;
-    p.seq = h->seq.ptr; p.cellptr = h->cellptr.ptr; p.pred = h->pred.ptr;
-    p.ticket = h->ticket.ptr; p.done = h->done.ptr; p.queue = h->queue.ptr;
+    p.seq = h->seq.ptr; p.iprev = h->iprev.ptr; p.cellptr = h->cellptr.ptr; p.pred = h->pred.ptr;
+    p.ticket = h->ticket.ptr; p.queue = h->queue.ptr;
     p.loss_slots = h->loss_slots.ptr;
     p.epoch = h->epochs_done;
     p.steps_before = h->steps_done;
     p.n_steps = 0;
-    p.use_tickets = 1;
+    p.tag_base = h->tag_base;
+    p.hot_rank = h->hot_rank.ptr;
+    p.hot_item = h->hot_tables.ptr; p.lst_begin = h->hot_tables.ptr + MAX_OWNERS; p.lst_len = h->hot_tables.ptr + 2 * MAX_OWNERS;
+    p.n_hot = h->counters.ptr; p.n_cold = h->counters.ptr + 1;
+    p.item_sorted = h->vals_sorted.ptr;
+    p.cold_list = h->cold_list.ptr;
+    p.mail_x = h->mail.ptr; p.mail_g = h->mail.ptr + h->stream_capacity;
 }
 
-bool flow_supported(const mi355rec_slim *h) {
-    return !(h->cfg.symmetric && h->n_items > 92681) && !getenv("MI355REC_SLIM_ORDERED");      // (cell ids are 32-bit sort keys)
-}
+bool flow_supported(const mi355rec_slim *h) { return !(h->cfg.symmetric && h->n_items > 92681); }      // (cell ids are 32-bit sort keys)
 
 void ensure_capacity(mi355rec_slim *h, size_t n) {
     if (h->stream_capacity >= n) return;
     h->su.alloc(n); h->si.alloc(n); h->sj.alloc(n);
-    h->seq.alloc(2 * n); h->len2.alloc(n + 1); h->done.alloc(n); h->cellptr.alloc(n + 1);
+    h->seq.alloc(2 * n); h->iprev.alloc(2 * n); h->len2.alloc(n + 1); h->cellptr.alloc(n + 1);
+    if (!h->cfg.symmetric) {
+        h->cold_list.alloc(n);
+        h->cold_flag.alloc(n);
+        h->mail.alloc(2 * n);
+    }
     h->stream_capacity = n;
+}
+
+void ensure_tmp(mi355rec_slim *h, size_t bytes) {
+    if (h->cub_tmp.count < bytes) {
+        MI_HIP(hipStreamSynchronize(h->stream));        // (earlier launches may still use the old block)
+        h->cub_tmp.alloc(bytes + (bytes >> 2) + 256);
+    }
 }
 
 void ensure_sort_capacity(mi355rec_slim *h, size_t n) {
     if (h->cell_capacity >= n) return;
-    h->keys.alloc(n); h->keys_sorted.alloc(n); h->vals.alloc(n); h->vals_sorted.alloc(n); h->pred.alloc(n);
-    size_t sort_bytes = 0, scan_bytes = 0;
-    MI_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr, h->vals_sorted.ptr,
-                                              (int)n, 0, 64, h->stream));
-    MI_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, h->len2.ptr, h->cellptr.ptr, 0ll, h->stream_capacity + 1, rocprim::plus<long long>(), h->stream));
-    h->cub_tmp.alloc(std::max(sort_bytes, scan_bytes) + 256);
+    MI_HIP(hipStreamSynchronize(h->stream));
+    h->keys.alloc(n); h->keys_sorted.alloc(n); h->vals.alloc(n); h->vals_sorted.alloc(n);
+    if (h->cfg.symmetric) h->pred.alloc(n);
     h->cell_capacity = n;
 }
 
@@ -835,69 +1158,165 @@ int bits_for(unsigned long long n_values) {
     return b;
 }
 
+void sort_pairs(mi355rec_slim *h, size_t n, int end_bit) {
+    size_t bytes = 0;
+    MI_HIP(rocprim::radix_sort_pairs(nullptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr, h->vals_sorted.ptr, n, 0, end_bit, h->stream));
+    ensure_tmp(h, bytes);
+    bytes = h->cub_tmp.count;
+    MI_HIP(rocprim::radix_sort_pairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr, h->vals_sorted.ptr, n, 0, end_bit, h->stream));
+}
+
+int env_int(const char *name, int fallback) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : fallback;
+}
+
+// Owned rows need a LEASE on compute units.  An owner's steps are static (its row's list), so every owner has to be resident
+// together with at least one workgroup that runs the other steps.  That holds for launches whose workgroups all fit the device
+// together (one workgroup per compute unit: a row takes most of its LDS) -- and not for persistent kernels that compete for the
+// compute units, where the workgroups of each would wait for owners that the others keep out.  The pool below has one slot per
+// compute unit; a launch takes what it is allowed (all of them, or MI355REC_SLIM_CUS of them when several models train side by
+// side) and sizes its grid by what it got.  A launch that gets fewer than 32 slots runs every step from the in-order queue, which
+// makes progress under any residency.
+std::atomic<int> g_owner_slots{-1};
+struct OwnerLease {
+    int slots = 0;
+    OwnerLease(bool wanted, int want) {
+        if (!wanted) return;
+        int expected = -1;
+        g_owner_slots.compare_exchange_strong(expected, multiprocessor_count());      // first use: one slot per compute unit
+        int have = g_owner_slots.load();
+        while (have >= 32) {
+            const int take = std::min(have, want);
+            if (g_owner_slots.compare_exchange_weak(have, have - take)) { slots = take; return; }
+        }
+    }
+    ~OwnerLease() { if (slots) g_owner_slots.fetch_add(slots); }
+};
+
+template <class Kernel>
+int blocks_per_cu(Kernel k, size_t lds) {
+    int per_cu = 0;
+    MI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, FLOW_THREADS, lds));
+    return std::max(1, std::min(per_cu, 2));            // (2048 threads per compute unit)
+}
+
 // Runs n steps of su/si/sj, starting at step `first`, exactly in stream order.
 template <class T>
 void run_stream(mi355rec_slim *h, int n, double &sum_profile, int first = 0) {
     hipStream_t s = h->stream;
     SlimParams<T> p{};
-    fill_params(h, p);
-    p.su += first; p.si += first; p.sj += first;
-    p.n_steps = n;
     const bool sym = h->cfg.symmetric != 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!flow_supported(h)) {
-        h->dispatch_timers.next(e0, e1, 1 << 30);
-        hipExtLaunchKernelGGL(slim_ordered_kernel<T>, dim3(1), dim3(1024), 0, s, e0, e1, 0, p);
-        h->stats.n_launches += 1;
-        MI_HIP(hipGetLastError());
+        if constexpr (std::is_same<T, double>::value) {
+            fill_params(h, p);
+            p.su += first; p.si += first; p.sj += first;
+            p.n_steps = n;
+            h->dispatch_timers.next(e0, e1, 1 << 30);
+            hipExtLaunchKernelGGL(slim_ordered_kernel, dim3(1), dim3(1024), 0, s, e0, e1, 0, p);
+            h->stats.n_launches += 1;
+            MI_HIP(hipGetLastError());
+        }
         h->steps_done += n;
         return;
     }
-    // ticket numbers: sort the 2n (item, step) pairs, position inside the item's run
+    // ticket numbers / previous steps per item: sort the 2n (item, step) pairs, position inside the item's run
     ensure_sort_capacity(h, std::max<size_t>(2 * (size_t)n, 1024));
     DepParams d{};
     d.n_steps = n; d.n_items = h->n_items;
     d.indptr = h->indptr.ptr; d.indices = h->indices.ptr; d.su = h->su.ptr + first; d.si = h->si.ptr + first; d.sj = h->sj.ptr + first;
     d.keys = h->keys.ptr; d.vals = h->vals.ptr; d.keys_sorted = h->keys_sorted.ptr; d.vals_sorted = h->vals_sorted.ptr;
-    d.seq = h->seq.ptr; d.len2 = h->len2.ptr; d.cellptr = h->cellptr.ptr; d.pred = h->pred.ptr;
+    d.seq = h->seq.ptr; d.iprev = h->iprev.ptr; d.len2 = h->len2.ptr; d.cellptr = h->cellptr.ptr; d.pred = h->pred.ptr;
+    d.run_start = h->run_start.ptr; d.item_cnt = h->item_cnt.ptr; d.cnt_sorted = h->cnt_sorted.ptr; d.item_by_cnt = h->item_by_cnt.ptr;
+    d.hot_rank = h->hot_rank.ptr;
+    d.hot_item = h->hot_tables.ptr; d.lst_begin = h->hot_tables.ptr + MAX_OWNERS; d.lst_len = h->hot_tables.ptr + 2 * MAX_OWNERS;
+    d.n_hot = h->counters.ptr;
+    d.cold_flag = h->cold_flag.ptr;
+    MI_HIP(hipMemsetAsync(h->item_cnt.ptr, 0, sizeof(unsigned) * (size_t)h->n_items, s));
     hipLaunchKernelGGL(slim_item_keys_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d);
-    size_t bytes = h->cub_tmp.count;
-    MI_HIP(rocprim::radix_sort_pairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr, h->vals_sorted.ptr,
-                                              2 * n, 0, 32 + bits_for((unsigned long long)h->n_items), s));
+    sort_pairs(h, 2 * (size_t)n, 32 + bits_for((unsigned long long)h->n_items));
     hipLaunchKernelGGL(slim_seq_kernel, dim3(div_up(2 * n, 256)), dim3(256), 0, s, d);
     // profile lengths -> cell slots (also the algorithmic byte count of the call)
     MI_HIP(hipMemsetAsync(h->len2.ptr + n, 0, sizeof(int), s));
+    size_t bytes = 0;
+    MI_HIP(rocprim::exclusive_scan(nullptr, bytes, h->len2.ptr, h->cellptr.ptr, 0ll, (size_t)(n + 1), rocprim::plus<long long>(), s));
+    ensure_tmp(h, bytes);
     bytes = h->cub_tmp.count;
     MI_HIP(rocprim::exclusive_scan(h->cub_tmp.ptr, bytes, h->len2.ptr, h->cellptr.ptr, 0ll, (size_t)(n + 1), rocprim::plus<long long>(), s));
     long long n_cells = 0;
     MI_HIP(hipMemcpyAsync(&n_cells, h->cellptr.ptr + n, sizeof(long long), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
     sum_profile += 0.5 * (double)n_cells;
+    MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(int) * 2, s));
     if (sym) {
+        // per cell the step that touched it last: sort the (cell, step) pairs of the stream
         MI_REQUIRE(n_cells < (1ll << 31), "stream too long for the cell sort (%lld cells)", n_cells);
         ensure_sort_capacity(h, (size_t)std::max<long long>(n_cells, 1024));
         d.keys = h->keys.ptr; d.vals = h->vals.ptr; d.keys_sorted = h->keys_sorted.ptr; d.vals_sorted = h->vals_sorted.ptr;
         d.pred = h->pred.ptr;
         d.n_cells = n_cells;
         hipLaunchKernelGGL(slim_cell_keys_kernel, dim3(div_up(n, 4)), dim3(256), 0, s, d);
-        bytes = h->cub_tmp.count;
-        MI_HIP(rocprim::radix_sort_pairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr,
-                                                  h->vals_sorted.ptr, (int)n_cells, 0, 64, s));
+        sort_pairs(h, (size_t)n_cells, 64);
         hipLaunchKernelGGL(slim_pred_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, s, d);
-        fill_params(h, p);          // (the sort buffers may have been re-allocated)
+        if constexpr (std::is_same<T, double>::value) {
+            fill_params(h, p);
+            p.su += first; p.si += first; p.sj += first;
+            p.n_steps = n;
+            h->tag_base += (unsigned)n;                  // (wraps after 4 G steps; a tag is compared only with the tag of a step of the same call)
+            const int grid = std::min(div_up(n, FLOW_WAVES), multiprocessor_count() * blocks_per_cu(slim_sym_flow_kernel, 0));
+            h->dispatch_timers.next(e0, e1, 1 << 30);
+            hipExtLaunchKernelGGL(slim_sym_flow_kernel, dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p);
+        }
+    } else {
+        // the busiest rows of this stream get owners (if this launch holds the lease and a row fits the LDS)
+        const size_t row_bytes = ((size_t)h->n_items * sizeof(float) + 15) & ~(size_t)15;
+        auto kernel = slim_dense_flow_kernel<T>;
+        int max_owners = std::min(MAX_OWNERS, env_int("MI355REC_SLIM_OWNERS", 128));
+        const bool wanted = max_owners > 0 && row_bytes + 4096 <= 160 * 1024 && !h->cfg.train_with_sparse_weights;
+        OwnerLease lease(wanted, std::max(32, std::min(multiprocessor_count(), env_int("MI355REC_SLIM_CUS", multiprocessor_count()))));
+        const bool owners = lease.slots > 0;
+        const size_t lds = owners ? row_bytes : 0;
+        if (lds > 48 * 1024) MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // with owners: one workgroup per leased compute unit (they must all be resident); without: whatever fits
+        const int grid = owners ? lease.slots : multiprocessor_count() * blocks_per_cu(kernel, 0);
+        max_owners = std::min(max_owners, grid / 2);
+        MI_HIP(hipMemsetAsync(h->hot_rank.ptr, 0xFF, sizeof(int) * (size_t)h->n_items, s));
+        MI_HIP(hipMemsetAsync(h->counters.ptr, 0, sizeof(int) * 2, s));
+        if (owners) {
+            bytes = 0;
+            MI_HIP(rocprim::radix_sort_pairs_desc(nullptr, bytes, h->item_cnt.ptr, h->cnt_sorted.ptr, h->iota.ptr, h->item_by_cnt.ptr,
+                                                  (size_t)h->n_items, 0, 32, s));
+            ensure_tmp(h, bytes);
+            bytes = h->cub_tmp.count;
+            MI_HIP(rocprim::radix_sort_pairs_desc(h->cub_tmp.ptr, bytes, h->item_cnt.ptr, h->cnt_sorted.ptr, h->iota.ptr, h->item_by_cnt.ptr,
+                                                  (size_t)h->n_items, 0, 32, s));
+            d.max_owners = max_owners;
+            d.min_steps = std::max(2, env_int("MI355REC_SLIM_OWNER_MIN_STEPS", 24));
+            hipLaunchKernelGGL(slim_owners_kernel, dim3(1), dim3(256), 0, s, d);
+            MI_HIP(hipMemsetAsync(h->mail.ptr, 0xFF, sizeof(unsigned long long) * 2 * h->stream_capacity, s));
+        }
+        hipLaunchKernelGGL(slim_cold_flag_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d);
+        bytes = 0;
+        MI_HIP(rocprim::select(nullptr, bytes, rocprim::counting_iterator<int>(0), h->cold_flag.ptr, h->cold_list.ptr, h->counters.ptr + 1,
+                               (size_t)n, s));
+        ensure_tmp(h, bytes);
+        bytes = h->cub_tmp.count;
+        MI_HIP(rocprim::select(h->cub_tmp.ptr, bytes, rocprim::counting_iterator<int>(0), h->cold_flag.ptr, h->cold_list.ptr, h->counters.ptr + 1,
+                               (size_t)n, s));
+        MI_HIP(hipMemsetAsync(h->ticket.ptr, 0, sizeof(int) * (size_t)h->n_items, s));
+        fill_params(h, p);
         p.su += first; p.si += first; p.sj += first;
         p.n_steps = n;
-        MI_HIP(hipMemsetAsync(h->done.ptr, 0, sizeof(int) * (size_t)n, s));
+        h->dispatch_timers.next(e0, e1, 1 << 30);
+        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(FLOW_THREADS), lds, s, e0, e1, 0, p, owners ? 1 : 0);
+        MI_HIP(hipGetLastError());
+        int counters[2] = {0, 0};
+        MI_HIP(hipMemcpyAsync(counters, h->counters.ptr, sizeof(counters), hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));                 // (the lease is held until the kernel has ended)
+        h->last_owners = counters[0];
+        h->last_cold = counters[1];
     }
-    // the symmetric store orders steps per cell; item tickets are then only needed for the per-item optimiser cells
-    p.use_tickets = !sym || h->cfg.sgd_mode != MI355REC_SGD;
-    MI_HIP(hipMemsetAsync(h->ticket.ptr, 0, sizeof(int) * (size_t)h->n_items, s));
-    MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(int) * 2, s));
-    const int grid = std::min(n, multiprocessor_count() * 4);
-    h->dispatch_timers.next(e0, e1, 1 << 30);
-    if (sym && getenv("MI355REC_SLIM_BATCHED")) hipExtLaunchKernelGGL((slim_flow_kernel<T, true, true>), dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p);
-    else if (sym) hipExtLaunchKernelGGL((slim_flow_kernel<T, true>), dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p);
-    else hipExtLaunchKernelGGL((slim_flow_kernel<T, false>), dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p);
     h->stats.n_launches += 1;
     MI_HIP(hipGetLastError());
     int flags[2] = {0, 0};
@@ -1034,7 +1453,8 @@ extern "C" int mi355rec_slim_create(mi355rec_slim_t *out, const mi355rec_slim_co
         }
         h->n_users = n_users;
         h->n_items = n_items;
-        h->f64 = cfg->precision == MI355REC_F64;
+        // the symmetric store keeps float32 values inside 8-byte granules and computes in float64 whatever `precision` says
+        h->f64 = cfg->precision == MI355REC_F64 || h->cfg.symmetric;
         h->nnz = (size_t)indptr[n_users];
         MI_REQUIRE(h->nnz > 0, "URM has no interactions");
         MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -1044,15 +1464,30 @@ extern "C" int mi355rec_slim_create(mi355rec_slim_t *out, const mi355rec_slim_co
         const size_t ts = h->f64 ? sizeof(double) : sizeof(float);
         h->indptr.upload(indptr, (size_t)n_users + 1, s);
         h->indices.upload(indices, h->nnz, s);
-        // .pyx:129 dense n x n; Triangular_Matrix :1237-1254 the packed lower triangle
-        const size_t n_cells = h->cfg.symmetric ? (size_t)n_items * ((size_t)n_items + 1) / 2 : (size_t)n_items * n_items;
-        h->S.alloc_zero(n_cells * ts, s);
-        if (h->cfg.train_with_sparse_weights)                        // .pyx:124: an empty tree per row
-            hipLaunchKernelGGL(slim_no_nodes_kernel, dim3(multiprocessor_count() * 8), dim3(256), 0, s,
-                               reinterpret_cast<unsigned long long *>(h->S.ptr), (size_t)n_items * n_items);
-        h->c1.alloc_zero((size_t)n_items * ts, s);
-        h->c2.alloc_zero((size_t)n_items * ts, s);
-        h->ticket.alloc_zero((size_t)n_items, s);
+        h->run_start.alloc_zero((size_t)n_items, s);
+        h->item_cnt.alloc_zero((size_t)n_items, s);
+        if (h->cfg.symmetric) {
+            // Triangular_Matrix :1237-1254 the packed lower triangle
+            h->G.alloc_zero((size_t)n_items * ((size_t)n_items + 1) / 2, s);
+            h->oc.alloc_zero(4 * (size_t)n_items, s);
+        } else {
+            h->S.alloc_zero((size_t)n_items * n_items * ts, s);     // .pyx:129 dense n x n
+            if (h->cfg.train_with_sparse_weights)                        // .pyx:124: an empty tree per row
+                hipLaunchKernelGGL(slim_no_nodes_kernel, dim3(multiprocessor_count() * 8), dim3(256), 0, s,
+                                   reinterpret_cast<unsigned long long *>(h->S.ptr), (size_t)n_items * n_items);
+            h->c1.alloc_zero((size_t)n_items * ts, s);
+            h->c2.alloc_zero((size_t)n_items * ts, s);
+            h->ticket.alloc_zero((size_t)n_items, s);
+            h->hot_rank.alloc((size_t)n_items);
+            h->hot_tables.alloc_zero(3 * MAX_OWNERS, s);
+            h->counters.alloc_zero(2, s);
+            h->cnt_sorted.alloc((size_t)n_items);
+            h->item_by_cnt.alloc((size_t)n_items);
+            std::vector<int> iota((size_t)n_items);
+            for (int i = 0; i < n_items; ++i) iota[(size_t)i] = i;
+            h->iota.upload(iota.data(), iota.size(), s);
+            MI_HIP(hipStreamSynchronize(s));                         // (iota is read from host memory)
+        }
         h->queue.alloc_zero(2, s);
         h->loss_slots.alloc_zero(LOSS_SLOTS, s);
         MI_HIP(hipStreamSynchronize(s));
@@ -1078,8 +1513,8 @@ extern "C" int mi355rec_slim_run_samples(mi355rec_slim_t h, const int32_t *u, co
         ensure_capacity(h, (size_t)n);
         hipStream_t s = h->stream;
         for (int64_t t = 0; t < n; ++t)
-            MI_REQUIRE(u[t] >= 0 && u[t] < h->n_users && i[t] >= 0 && i[t] < h->n_items && j[t] >= 0 && j[t] < h->n_items,
-                       "sample %lld out of range", (long long)t);
+            MI_REQUIRE(u[t] >= 0 && u[t] < h->n_users && i[t] >= 0 && i[t] < h->n_items && j[t] >= 0 && j[t] < h->n_items && i[t] != j[t],
+                       "sample %lld out of range (or its positive item is its negative item)", (long long)t);
         MI_HIP(hipMemcpyAsync(h->su.ptr, u, sizeof(int) * n, hipMemcpyHostToDevice, s));
         MI_HIP(hipMemcpyAsync(h->si.ptr, i, sizeof(int) * n, hipMemcpyHostToDevice, s));
         MI_HIP(hipMemcpyAsync(h->sj.ptr, j, sizeof(int) * n, hipMemcpyHostToDevice, s));
@@ -1150,6 +1585,14 @@ extern "C" int mi355rec_slim_get_stats(mi355rec_slim_t h, mi355rec_stats *stats)
     return guarded([&] {
         MI_REQUIRE(h && stats, "NULL argument");
         *stats = h->stats;
+    });
+}
+
+extern "C" int mi355rec_slim_schedule_info(mi355rec_slim_t h, int32_t *n_owned_rows, int32_t *n_cold_steps) {
+    return guarded([&] {
+        MI_REQUIRE(h && n_owned_rows && n_cold_steps, "NULL argument");
+        *n_owned_rows = h->last_owners;
+        *n_cold_steps = h->last_cold;
     });
 }
 

@@ -145,14 +145,18 @@ class MatrixFactorization_MI355X_Epoch:
         """Attach start/stop events to (at most) that many gradient-kernel dispatches of every following call."""
         N.check(self._lib.mi355rec_mf_set_profiling(self._h, int(max_timed_launches)))
 
-    # ---- model read-back (fresh host copies, float32) ----
+    # ---- model read-back (fresh host copies; float64 like the reference's getters, .pyx:685-702, when the device state is
+    # float64 -- adagrad / rmsprop / adam, AsySVD -- and the float32 state as it is otherwise) ----
     def _download(self, want_bias):
-        U = np.empty((self.n_user_rows, self.n_factors), np.float32)
-        V = np.empty((self.n_items, self.n_factors), np.float32)
+        f64 = self.precision == "fp64"
+        dt = np.float64 if f64 else np.float32
+        U = np.empty((self.n_user_rows, self.n_factors), dt)
+        V = np.empty((self.n_items, self.n_factors), dt)
         bu = bi = mu = None
         if want_bias:
-            bu = np.empty(self.n_users, np.float32); bi = np.empty(self.n_items, np.float32); mu = np.empty(1, np.float32)
-        N.check(self._lib.mi355rec_mf_get_factors(self._h, N.ptr(U), N.ptr(V), N.ptr(bu), N.ptr(bi), N.ptr(mu)))
+            bu = np.empty(self.n_users, dt); bi = np.empty(self.n_items, dt); mu = np.empty(1, dt)
+        get = self._lib.mi355rec_mf_get_factors_f64 if f64 else self._lib.mi355rec_mf_get_factors
+        N.check(get(self._h, N.ptr(U), N.ptr(V), N.ptr(bu), N.ptr(bi), N.ptr(mu)))
         return U, V, bu, bi, mu
 
     def get_factors(self):

@@ -42,8 +42,9 @@ class SLIM_BPR_MI355X_Epoch:
         if topK is not False and topK is not None and topK < 0:
             raise ValueError("TopK not valid. Acceptable values are either False or a positive integer value. "
                              "Provided value was '{}'".format(topK))
-        if precision == "auto":         # float64 S and optimiser cells for the adaptive modes (the reference is double throughout);
-            # the sparse store's selections compare values, so it keeps the reference's float64 as well
+        if precision == "auto":         # dense store: float64 cells and optimiser cells for the adaptive modes (the reference is double
+            # throughout); the sparse store's selections compare values, so it keeps the reference's float64 as well.  The symmetric
+            # store always holds float32 values in {value, tag} cells and computes in float64 (include/mi355rec.h)
             precision = "fp32" if sgd_mode == "sgd" and not self.train_with_sparse_weights else "fp64"
         if precision not in N.PRECISION_CODES:
             raise ValueError("Value for 'precision' not recognized. Acceptable values are {}, provided was '{}'".format(
@@ -136,6 +137,12 @@ class SLIM_BPR_MI355X_Epoch:
         st = N.Stats()
         N.check(self._lib.mi355rec_slim_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def schedule_info(self):
+        """(rows an owning workgroup kept in LDS, steps that ran on rows in HBM) of the last dense-store launch."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        N.check(self._lib.mi355rec_slim_schedule_info(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
 
 class _SLIMLogic:

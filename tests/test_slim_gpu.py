@@ -136,6 +136,9 @@ def test_baseline_config_3_ml20m_replay_vs_oracle(gpu, symmetric):
     dev.replay_samples(u, i, j)
     st = dev.stats()
     assert st["n_units"] == len(u) and st["n_launches"] == 1          # one persistent dataflow kernel, not one launch per level
+    if not symmetric:                                                 # the busiest rows of the stream were kept in LDS by owning workgroups
+        owned, cold = dev.schedule_info()
+        assert owned >= 32 and 0 < cold < len(u), (owned, cold)
     ref = orc.get_S_dense()
     S = dev.get_S_dense()
     _assert_blockwise_parity(S, ref, "S")
@@ -155,6 +158,42 @@ def test_baseline_config_3_ml20m_replay_vs_oracle(gpu, symmetric):
         kth = row[order[-1]] if len(order) else 0.0
         clear = np.abs(row[order] - kth) > 1e-6 * max(np.abs(row).max(), 1e-30)
         assert np.isin(order[clear], got).all() and len(got) == len(order)
+    dev.close()
+
+
+@pytest.mark.parametrize("mode", ["sgd", "adam"])
+def test_owned_rows_on_and_off(gpu, monkeypatch, mode):
+    """The dense store with and without rows owned in LDS (MI355REC_SLIM_OWNERS=0: every step from the in-order queue): both within
+    the bar of the oracle; with owners, steps whose TWO rows are owned (the mailbox path) occur and are counted."""
+    X = named_urm("ml1m", "binary", scale=0.3)            # 1 812 x 1 111
+    kw = dict(symmetric=False, random_seed=5, sgd_mode=mode, learning_rate=0.02, li_reg=0.002, lj_reg=0.001)
+    orc = O.OracleSLIM(X, topK=False, final_model_sparse_weights=False, **kw)
+    orc.record_samples(10 ** 6)
+    for _ in range(4):
+        orc.epochIteration_Cython()
+    u, i, j = orc.recorded()
+    ref = orc.get_S_dense()
+    cnt = np.bincount(np.concatenate([i, j]), minlength=X.shape[1])
+    for owners in ("0", "64"):
+        monkeypatch.setenv("MI355REC_SLIM_OWNERS", owners)
+        dev = SLIM_BPR_MI355X_Epoch(X, topK=False, final_model_sparse_weights=False, **kw)
+        dev.replay_samples(u, i, j)
+        owned, cold = dev.schedule_info()
+        if owners == "0":
+            assert owned == 0 and cold == len(u)
+        else:
+            hot = np.argsort(-cnt, kind="stable")[:owned]
+            assert owned == 64 and cold == int((~np.isin(i, hot) & ~np.isin(j, hot)).sum())
+            assert (np.isin(i, hot) & np.isin(j, hot)).sum() > 0       # steps on two owned rows exist in this stream
+        assert_factor_parity(dev.get_S_dense(), ref, mode, "S owners=" + owners)
+        dev.close()
+
+
+def test_replay_rejects_a_sample_whose_items_coincide(gpu):
+    X = named_urm("ml1m", "binary", scale=0.1)
+    dev = SLIM_BPR_MI355X_Epoch(X, topK=False, symmetric=False, sgd_mode="sgd", random_seed=1)
+    with pytest.raises(Exception, match="positive item is its negative item"):
+        dev.replay_samples(np.array([0, 1]), np.array([3, 4]), np.array([5, 4]))
     dev.close()
 
 
