@@ -53,6 +53,20 @@ constexpr unsigned long long MAIL_EMPTY = ~0ull;
 
 struct alignas(8) Granule { float v; unsigned tag; };
 
+// Everything a step needs before its first gather, in ONE 32-byte load (instead of stream position -> sample -> CSR bounds -> ticket
+// numbers: four dependent round trips).  Three uses:
+//   dense store, steps in stream order / compacted into the cold queue:  a, b = ticket numbers of items i and j
+//   dense store, the list of an owned row (sorted order):  i = the OTHER item, j = role of the owned row (0 positive, 1 negative),
+//                                                       a = the other item's ticket number, b = 1 if that row is owned, too
+//   symmetric store, stream order:  a, b = the step before this one on item i / j (-1: none), (t, c) = first cell slot (low, high)
+struct alignas(32) StepDesc { int rs, L, i, j, a, b, t, c; };
+
+// Steps are handed to single wavefronts: one of them fetches LQ_CHUNK consecutive steps from the global in-order queue (one device
+// atomic per chunk: 88 per microsecond is all one word sustains) and the wavefronts of the workgroup pop them one by one from LDS.
+constexpr int LQ_CHUNK = 16, LQ_RING = 8;
+struct LocalQueue { int next, ready; int base[LQ_RING]; };
+constexpr int NO_STEP = 0x7fffffff;
+
 template <class T>
 struct SlimParams {
     int n_users, n_items, symmetric, sgd_mode;
@@ -78,11 +92,13 @@ struct SlimParams {
     unsigned tag_base;              // symmetric: step t of this call writes tag tag_base + t + 1
     // dense store, owned rows
     const int *hot_rank;            // [n_items] owner of the item's row, -1: nobody (the row stays in HBM)
-    const int *hot_item, *lst_begin, *lst_len;   // [MAX_OWNERS] item, first position and length of its run in `item_sorted`
+    const int *hot_item, *lst_begin, *lst_len;   // [MAX_OWNERS] item, first position and length of its run in the sorted pairs
     const int *n_hot;               // owners in use (decided on the device)
-    const int *item_sorted;         // 2 t + role in (item, step) order
-    const int *cold_list;           // steps with no owned row, in stream order
+    const StepDesc *desc;           // symmetric store: per step, in stream order
+    const StepDesc *cold_desc;      // dense store: the steps with no owned row, in stream order
+    const StepDesc *own_desc;       // dense store: per (item, step) pair in sorted order (only the owned items' runs are filled in)
     const int *n_cold;
+    unsigned long long *prof;       // optional phase clocks (MI355REC_SLIM_PROF=1), NULL otherwise
     unsigned long long *mail_x, *mail_g;   // [n_steps] steps on TWO owned rows: sum over the negative item's row, sigmoid
 };
 
@@ -193,6 +209,7 @@ struct DepParams {
     int *hot_rank, *hot_item, *lst_begin, *lst_len, *n_hot;
     int max_owners, min_steps;
     unsigned char *cold_flag;       // [n_steps] 1: neither row of the step is owned
+    StepDesc *desc, *own_desc;
 };
 
 __global__ __launch_bounds__(256) void slim_item_keys_kernel(const DepParams d) {
@@ -244,10 +261,34 @@ __global__ __launch_bounds__(256) void slim_owners_kernel(const DepParams d) {
     if (h == 0) *d.n_hot = s_n;
 }
 
-__global__ __launch_bounds__(256) void slim_cold_flag_kernel(const DepParams d) {
+// per step, stream order (dense store: after the owners are known)
+__global__ __launch_bounds__(256) void slim_desc_kernel(const DepParams d, const int symmetric) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= d.n_steps) return;
-    d.cold_flag[t] = d.hot_rank[d.si[t]] < 0 && d.hot_rank[d.sj[t]] < 0;
+    const int u = d.su[t], i = d.si[t], j = d.sj[t];
+    const int rs = d.indptr[u], L = d.indptr[u + 1] - rs;
+    StepDesc e;
+    e.rs = rs; e.L = L; e.i = i; e.j = j;
+    if (symmetric) {
+        const long long cp = d.cellptr[t];
+        e.a = d.iprev[2 * t]; e.b = d.iprev[2 * t + 1]; e.t = (int)(unsigned)cp; e.c = (int)(cp >> 32);
+    } else {
+        e.a = d.seq[2 * t]; e.b = d.seq[2 * t + 1]; e.t = t; e.c = 0;
+        d.cold_flag[t] = d.hot_rank[i] < 0 && d.hot_rank[j] < 0;
+    }
+    d.desc[t] = e;
+}
+// per (item, step) pair in sorted order: the entries of the owned rows' lists
+__global__ __launch_bounds__(256) void slim_owner_desc_kernel(const DepParams d) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= 2 * d.n_steps) return;
+    if (d.hot_rank[(int)(d.keys_sorted[q] >> 32)] < 0) return;
+    const int slot = d.vals_sorted[q], t = slot >> 1, role = slot & 1;
+    const int u = d.su[t], other = role ? d.si[t] : d.sj[t];
+    StepDesc e;
+    e.rs = d.indptr[u]; e.L = d.indptr[u + 1] - e.rs; e.i = other; e.j = role;
+    e.a = d.seq[2 * t + (1 - role)]; e.b = d.hot_rank[other] >= 0; e.t = t; e.c = 0;
+    d.own_desc[q] = e;
 }
 
 // symmetric store: one wavefront per step lists the canonical cells of its two rows
@@ -325,6 +366,47 @@ __device__ __forceinline__ bool wave_wait_mail(const SlimParams<T> &p, unsigned 
     }
 }
 
+__device__ __forceinline__ unsigned long long shader_clock() {   // not reordered against memory operations
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+// Next step of the in-order queue for this wavefront (NO_STEP: the queue is empty or the launch is being abandoned).  The chunks are
+// fetched in the order of their generations, so what a workgroup holds is always a prefix of what it will hold: a step it has not
+// handed out yet can only be waited for by steps it has not handed out either.
+template <class T>
+__device__ __forceinline__ int claim_step(const SlimParams<T> &p, LocalQueue *lq, const int lane) {
+    int k = 0;
+    if (lane == 0) k = atomicAdd(&lq->next, 1);
+    k = __builtin_amdgcn_readfirstlane(k);
+    const int gen = k / LQ_CHUNK, off = k % LQ_CHUNK;
+    volatile int *ready = &lq->ready;
+    volatile int *bases = lq->base;
+    SpinGuard sg;
+    unsigned spins = 0;
+    if (off == 0) {
+        while (__builtin_amdgcn_readfirstlane(*ready) != gen)
+            if ((++spins & 1023u) == 0 && give_up(p, sg)) return NO_STEP;
+        int base = 0;
+        if (lane == 0) base = aload(&p.queue[1]) ? NO_STEP : atomicAdd(&p.queue[0], LQ_CHUNK);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane == 0) bases[gen % LQ_RING] = base;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) *ready = gen + 1;
+        return base;
+    }
+    while (__builtin_amdgcn_readfirstlane(*ready) <= gen)
+        if ((++spins & 1023u) == 0 && give_up(p, sg)) return NO_STEP;
+    asm volatile("" ::: "memory");
+    const int base = __builtin_amdgcn_readfirstlane(bases[gen % LQ_RING]);
+    if (__builtin_amdgcn_readfirstlane(*ready) > gen + LQ_RING) {       // (the ring slot may have been reused: never seen, checked anyway)
+        if (lane == 0) astore(&p.queue[1], 1);
+        return NO_STEP;
+    }
+    return base >= NO_STEP - LQ_CHUNK ? NO_STEP : base + off;
+}
+
 // The sigmoid and the optimiser step of an OWNED row's step sit on the critical path of the whole epoch (the turn of the busiest
 // row), so their instruction count matters: the argument is reduced in float64 (x log2(e) = n + f, |f| <= 1/2, exact), 2^f comes
 // from v_exp_f32 and the reciprocals from v_rcp_f32 (1 ulp each): relative error of the step ~2e-7, against 1e-5 asked of the
@@ -357,14 +439,14 @@ __device__ __forceinline__ double hot_adapt(const P &p, double g, double pw1, do
 // One step on two rows in HBM, run by ONE wavefront: tickets of the two items (lanes 0 and 1 poll), gathers, reduction, the two
 // per-item optimiser steps, write-through scatters, drain, tickets passed on.
 template <class T>
-__device__ __forceinline__ void cold_step(const SlimParams<T> &p, const int t, const int lane) {
-    const int u = p.su[t], i = p.si[t], j = p.sj[t];
-    const int rs = p.indptr[u], L = p.indptr[u + 1] - rs;
+__device__ __forceinline__ void cold_step(const SlimParams<T> &p, const StepDesc e, const int lane) {
+    const int t = e.t, i = e.i, j = e.j, rs = e.rs, L = e.L;
     const size_t n = (size_t)p.n_items;
+    const unsigned long long k0 = p.prof ? shader_clock() : 0ull;
     int sv[FLOW_REGS];
 #pragma unroll
     for (int r = 0; r < FLOW_REGS; ++r) sv[r] = p.indices[rs + min(lane + 64 * r, L - 1)];      // L >= 1: users without interactions are never drawn
-    const int want = lane < 2 ? p.seq[2 * t + lane] : 0;
+    const int want = lane == 0 ? e.a : (lane == 1 ? e.b : 0);
     {
         const int *word = &p.ticket[lane == 1 ? j : i];
         SpinGuard sg;
@@ -374,6 +456,7 @@ __device__ __forceinline__ void cold_step(const SlimParams<T> &p, const int t, c
             if (give_up(p, sg)) return;
         }
     }
+    const unsigned long long k1 = p.prof ? shader_clock() : 0ull;
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     // the items' optimiser cells belong to whoever holds the items' tickets: lane 0 looks after item i, lane 1 after item j
     T oc1 = (T)0, oc2 = (T)0;
@@ -428,6 +511,12 @@ __device__ __forceinline__ void cold_step(const SlimParams<T> &p, const int t, c
     // publish: drain the write-through stores, then pass the tickets on
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane < 2) astore(&p.ticket[lane ? j : i], want + 1);
+    if (p.prof && lane == 0) {
+        unsigned long long *o = p.prof + 8 * MAX_OWNERS;
+        atomicAdd(&o[0], 1ull);
+        atomicAdd(&o[1], k1 - k0);                   // profile ids + ticket wait
+        atomicAdd(&o[2], shader_clock() - k1);       // gathers ... tickets passed on
+    }
 }
 
 // The steps of one OWNED row, in stream order, by the 16 wavefronts of the owning workgroup in turn.  `row` is the item's row of S
@@ -444,25 +533,27 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
     const int item = p.hot_item[h], first = p.lst_begin[h], len = p.lst_len[h];
     const size_t n = (size_t)p.n_items;
     const float lr = (float)p.lr, li_reg = (float)p.li_reg, lj_reg = (float)p.lj_reg;
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     for (int k = wave; k < len; k += FLOW_WAVES) {
-        const int slot = p.item_sorted[first + k];
-        const int t = slot >> 1, role = slot & 1;
-        const int u = p.su[t], other = role ? p.si[t] : p.sj[t];
-        const int rs = p.indptr[u], L = p.indptr[u + 1] - rs;
+        const unsigned long long k0 = p.prof ? shader_clock() : 0ull;
+        const StepDesc e = p.own_desc[first + k];
+        const int t = e.t, role = e.j, other = e.i, rs = e.rs, L = e.L;
         int sv[FLOW_REGS];
 #pragma unroll
         for (int r = 0; r < FLOW_REGS; ++r) sv[r] = p.indices[rs + min(lane + 64 * r, L - 1)];
-        const bool mail = p.hot_rank[other] >= 0;
+        const bool mail = e.b != 0;
         // ---- before the turn: the other row's half ------------------------------------------------------------------------
         T *So = p.S + (size_t)other * n;
         T vo[FLOW_REGS];
         T oc1 = (T)0, oc2 = (T)0;
         double xo = 0.0;
         int want = 0;
+        unsigned long long k1 = k0;
         if (!mail) {
-            want = p.seq[2 * t + (1 - role)];
+            want = e.a;
             if (!wave_wait_word(p, &p.ticket[other], want, lane)) return;
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            if (p.prof) k1 = shader_clock();
             if (lane == 0 && p.sgd_mode != MI355REC_SGD) {
                 oc1 = aload(&p.c1[other]);
                 if (p.sgd_mode == MI355REC_ADAM) oc2 = aload(&p.c2[other]);
@@ -479,6 +570,7 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
         }
         double pw1, pw2;
         adam_powers(p, t, pw1, pw2);
+        const unsigned long long k2 = p.prof ? shader_clock() : 0ull;
         // ---- the turn -------------------------------------------------------------------------------------------------------
         {
             SpinGuard sg;
@@ -488,6 +580,7 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
         }
         __builtin_amdgcn_s_setprio(3);
         asm volatile("" ::: "memory");
+        const unsigned long long k3 = p.prof ? shader_clock() : 0ull;
         float vr[FLOW_REGS];
         double xr = 0.0;
 #pragma unroll
@@ -526,6 +619,7 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the row's new cells are in LDS before the next wavefront is let in
         if (lane == 0) *turn = k + 1;
         __builtin_amdgcn_s_setprio(0);
+        const unsigned long long k4 = p.prof ? shader_clock() : 0ull;
         // ---- after the turn: the other row moves, its ticket is passed on -------------------------------------------------------
         if (!mail) {
             T po1, po2;
@@ -551,6 +645,13 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
             if (lane == 0) astore(&p.ticket[other], want + 1);
         }
         if (lane == 0 && !(mail && role)) atomicAdd(&p.loss_slots[t & (LOSS_SLOTS - 1)], x * x);
+        if (p.prof) {
+            acc[0] += 1; acc[1] += k1 - k0; acc[2] += k2 - k1; acc[3] += k3 - k2; acc[4] += k4 - k3; acc[5] += shader_clock() - k4;
+        }
+    }
+    if (p.prof && lane == 0) {       // entries | descriptor + ticket wait | gather + sum | wait for the turn | the turn | other row's write-back
+        unsigned long long *o = p.prof + 8 * h;
+        for (int c = 0; c < 6; ++c) atomicAdd(&o[c], acc[c]);
     }
 }
 
@@ -558,9 +659,11 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
 template <class T>
 __global__ __launch_bounds__(FLOW_THREADS) void slim_dense_flow_kernel(const SlimParams<T> p, const int owners) {
     extern __shared__ __attribute__((aligned(16))) float flow_lds[];
-    __shared__ int s_turn, s_base;
+    __shared__ int s_turn;
+    __shared__ LocalQueue s_queue;
     __shared__ double s_oc[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_queue.next = 0; s_queue.ready = 0; }
     const int n_hot = owners ? *p.n_hot : 0;
     if ((int)blockIdx.x < n_hot) {
         const int h = blockIdx.x, item = p.hot_item[h];
@@ -580,14 +683,12 @@ __global__ __launch_bounds__(FLOW_THREADS) void slim_dense_flow_kernel(const Sli
             if (p.sgd_mode == MI355REC_ADAM) p.c2[item] = (T)s_oc[1];
         }
     }
+    __syncthreads();
     const int n_cold = *p.n_cold;
-    for (;;) {
-        if (tid == 0) s_base = aload(&p.queue[1]) ? 0x7fffffff : atomicAdd(&p.queue[0], FLOW_WAVES);       // in-order queue: everything a step can wait for is already running
-        __syncthreads();
-        const int base = s_base;
-        if (base >= n_cold) break;
-        if (base + wave < n_cold) cold_step(p, p.cold_list[base + wave], lane);
-        __syncthreads();
+    for (;;) {          // in-order queue: everything a step can wait for is already running
+        const int q = claim_step(p, &s_queue, lane);
+        if (q >= n_cold) break;
+        cold_step(p, p.cold_desc[q], lane);
     }
 }
 
@@ -599,9 +700,11 @@ __global__ __launch_bounds__(FLOW_THREADS) void slim_dense_flow_kernel(const Sli
 __device__ __forceinline__ bool tag_ok(int pred, unsigned tag, unsigned tag_base) { return pred < 0 || tag == tag_base + (unsigned)pred + 1u; }
 
 __device__ __forceinline__ void sym_step(const SlimParams<double> &p, const int t, const int lane) {
-    const int u = p.su[t], i = p.si[t], j = p.sj[t];
-    const int rs = p.indptr[u], L = p.indptr[u + 1] - rs;
-    const long long cp = p.cellptr[t];
+    const StepDesc e = p.desc[t];
+    const int i = e.i, j = e.j, rs = e.rs, L = e.L;
+    const long long cp = (long long)(((unsigned long long)(unsigned)e.c << 32) | (unsigned)e.t);
+    const unsigned long long k0 = p.prof ? shader_clock() : 0ull;
+    unsigned repolls = 0;
     const unsigned my_tag = p.tag_base + (unsigned)t + 1u;
     const bool adaptive = p.sgd_mode != MI355REC_SGD, adam = p.sgd_mode == MI355REC_ADAM;
     int sv[FLOW_REGS], pa[FLOW_REGS], pb[FLOW_REGS];
@@ -627,7 +730,7 @@ __device__ __forceinline__ void sym_step(const SlimParams<double> &p, const int 
     }
     // optimiser granules of the lane's item
     Granule *oc = p.oc + 4 * (size_t)(lane == 1 ? j : i);
-    const int ip = lane < 2 && adaptive ? p.iprev[2 * t + lane] : -1;
+    const int ip = lane < 2 && adaptive ? (lane ? e.b : e.a) : -1;
     Granule o[4] = {{0.f, 0u}, {0.f, 0u}, {0.f, 0u}, {0.f, 0u}};
     if (lane < 2 && adaptive) {
         o[0] = gload(oc);
@@ -650,9 +753,11 @@ __device__ __forceinline__ void sym_step(const SlimParams<double> &p, const int 
             for (int e = 0; e < 4; ++e)
                 if ((e < 2 || adam) && !tag_ok(ip, o[e].tag, p.tag_base)) { pending = true; o[e] = gload(oc + e); }
             if (!__any(pending)) break;
+            ++repolls;
             if (give_up(p, sg)) return;
         }
     }
+    const unsigned long long k1 = p.prof ? shader_clock() : 0ull;
     double x = 0.0;
 #pragma unroll
     for (int r = 0; r < FLOW_REGS; ++r)
@@ -709,18 +814,23 @@ __device__ __forceinline__ void sym_step(const SlimParams<double> &p, const int 
         if (s != i) gstore(a, (float)cell_plus((double)gload(a).v, p.lr, gi, p.li_reg), my_tag);
         if (s != j) gstore(b, (float)cell_minus((double)gload(b).v, p.lr, gj, p.lj_reg), my_tag);
     }
+    if (p.prof && lane == 0) {       // steps | descriptor .. all tags there | the rest | polling rounds that found a tag missing
+        atomicAdd(&p.prof[0], 1ull);
+        atomicAdd(&p.prof[1], k1 - k0);
+        atomicAdd(&p.prof[2], shader_clock() - k1);
+        atomicAdd(&p.prof[3], (unsigned long long)repolls);
+    }
 }
 
 __global__ __launch_bounds__(FLOW_THREADS) void slim_sym_flow_kernel(const SlimParams<double> p) {
-    __shared__ int s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (;;) {
-        if (tid == 0) s_base = aload(&p.queue[1]) ? 0x7fffffff : atomicAdd(&p.queue[0], FLOW_WAVES);       // in-order queue: everything a step can wait for is already running
-        __syncthreads();
-        const int base = s_base;
-        if (base >= p.n_steps) break;
-        if (base + wave < p.n_steps) sym_step(p, base + wave, lane);
-        __syncthreads();
+    __shared__ LocalQueue s_queue;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) { s_queue.next = 0; s_queue.ready = 0; }
+    __syncthreads();
+    for (;;) {          // in-order queue: everything a step can wait for is already running
+        const int t = claim_step(p, &s_queue, lane);
+        if (t >= p.n_steps) break;
+        sym_step(p, t, lane);
     }
 }
 
@@ -1074,7 +1184,9 @@ struct mi355rec_slim {
     DeviceBuffer<Granule> G, oc;                        // symmetric store: packed triangle of granules, [n_items][4] optimiser granules
     DeviceBuffer<double> loss_slots;
     // dense store: owned rows
-    DeviceBuffer<int> run_start, hot_rank, hot_tables, counters, cold_list, iota, item_by_cnt;     // hot_tables: item | first | length
+    DeviceBuffer<int> run_start, hot_rank, hot_tables, counters, iota, item_by_cnt;     // hot_tables: item | first | length
+    DeviceBuffer<StepDesc> desc, cold_desc, own_desc;
+    DeviceBuffer<unsigned long long> prof;              // MI355REC_SLIM_PROF=1: phase clocks of the last launch
     DeviceBuffer<unsigned> item_cnt, cnt_sorted;
     DeviceBuffer<unsigned char> cold_flag;
     DeviceBuffer<unsigned long long> mail;              // [2][stream_capacity]
@@ -1118,8 +1230,8 @@ void fill_params(mi355rec_slim *h, SlimParams<T> &p) {
     p.hot_rank = h->hot_rank.ptr;
     p.hot_item = h->hot_tables.ptr; p.lst_begin = h->hot_tables.ptr + MAX_OWNERS; p.lst_len = h->hot_tables.ptr + 2 * MAX_OWNERS;
     p.n_hot = h->counters.ptr; p.n_cold = h->counters.ptr + 1;
-    p.item_sorted = h->vals_sorted.ptr;
-    p.cold_list = h->cold_list.ptr;
+    p.desc = h->desc.ptr; p.cold_desc = h->cold_desc.ptr; p.own_desc = h->own_desc.ptr;
+    p.prof = h->prof.ptr;
     p.mail_x = h->mail.ptr; p.mail_g = h->mail.ptr + h->stream_capacity;
 }
 
@@ -1129,8 +1241,10 @@ void ensure_capacity(mi355rec_slim *h, size_t n) {
     if (h->stream_capacity >= n) return;
     h->su.alloc(n); h->si.alloc(n); h->sj.alloc(n);
     h->seq.alloc(2 * n); h->iprev.alloc(2 * n); h->len2.alloc(n + 1); h->cellptr.alloc(n + 1);
+    h->desc.alloc(n);
     if (!h->cfg.symmetric) {
-        h->cold_list.alloc(n);
+        h->cold_desc.alloc(n);
+        h->own_desc.alloc(2 * n);
         h->cold_flag.alloc(n);
         h->mail.alloc(2 * n);
     }
@@ -1233,6 +1347,12 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile, int first = 0) {
     d.hot_item = h->hot_tables.ptr; d.lst_begin = h->hot_tables.ptr + MAX_OWNERS; d.lst_len = h->hot_tables.ptr + 2 * MAX_OWNERS;
     d.n_hot = h->counters.ptr;
     d.cold_flag = h->cold_flag.ptr;
+    d.desc = h->desc.ptr; d.own_desc = h->own_desc.ptr;
+    const bool profile = getenv("MI355REC_SLIM_PROF") != nullptr;
+    if (profile) {
+        if (!h->prof.ptr) h->prof.alloc(8 * (MAX_OWNERS + 1));
+        MI_HIP(hipMemsetAsync(h->prof.ptr, 0, sizeof(unsigned long long) * h->prof.count, s));
+    }
     MI_HIP(hipMemsetAsync(h->item_cnt.ptr, 0, sizeof(unsigned) * (size_t)h->n_items, s));
     hipLaunchKernelGGL(slim_item_keys_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d);
     sort_pairs(h, 2 * (size_t)n, 32 + bits_for((unsigned long long)h->n_items));
@@ -1259,12 +1379,15 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile, int first = 0) {
         hipLaunchKernelGGL(slim_cell_keys_kernel, dim3(div_up(n, 4)), dim3(256), 0, s, d);
         sort_pairs(h, (size_t)n_cells, 64);
         hipLaunchKernelGGL(slim_pred_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(slim_desc_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d, 1);
         if constexpr (std::is_same<T, double>::value) {
             fill_params(h, p);
             p.su += first; p.si += first; p.sj += first;
             p.n_steps = n;
             h->tag_base += (unsigned)n;                  // (wraps after 4 G steps; a tag is compared only with the tag of a step of the same call)
-            const int grid = std::min(div_up(n, FLOW_WAVES), multiprocessor_count() * blocks_per_cu(slim_sym_flow_kernel, 0));
+            // steps in flight = wavefronts of the grid: more of them only adds pollers once the chain of dependent steps is the bound
+            const int wgs = env_int("MI355REC_SLIM_SYM_WGS", multiprocessor_count() * blocks_per_cu(slim_sym_flow_kernel, 0));
+            const int grid = std::max(1, std::min(div_up(n, FLOW_WAVES), wgs));
             h->dispatch_timers.next(e0, e1, 1 << 30);
             hipExtLaunchKernelGGL(slim_sym_flow_kernel, dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p);
         }
@@ -1296,14 +1419,13 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile, int first = 0) {
             hipLaunchKernelGGL(slim_owners_kernel, dim3(1), dim3(256), 0, s, d);
             MI_HIP(hipMemsetAsync(h->mail.ptr, 0xFF, sizeof(unsigned long long) * 2 * h->stream_capacity, s));
         }
-        hipLaunchKernelGGL(slim_cold_flag_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(slim_desc_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d, 0);
+        if (owners) hipLaunchKernelGGL(slim_owner_desc_kernel, dim3(div_up(2 * n, 256)), dim3(256), 0, s, d);
         bytes = 0;
-        MI_HIP(rocprim::select(nullptr, bytes, rocprim::counting_iterator<int>(0), h->cold_flag.ptr, h->cold_list.ptr, h->counters.ptr + 1,
-                               (size_t)n, s));
+        MI_HIP(rocprim::select(nullptr, bytes, h->desc.ptr, h->cold_flag.ptr, h->cold_desc.ptr, h->counters.ptr + 1, (size_t)n, s));
         ensure_tmp(h, bytes);
         bytes = h->cub_tmp.count;
-        MI_HIP(rocprim::select(h->cub_tmp.ptr, bytes, rocprim::counting_iterator<int>(0), h->cold_flag.ptr, h->cold_list.ptr, h->counters.ptr + 1,
-                               (size_t)n, s));
+        MI_HIP(rocprim::select(h->cub_tmp.ptr, bytes, h->desc.ptr, h->cold_flag.ptr, h->cold_desc.ptr, h->counters.ptr + 1, (size_t)n, s));
         MI_HIP(hipMemsetAsync(h->ticket.ptr, 0, sizeof(int) * (size_t)h->n_items, s));
         fill_params(h, p);
         p.su += first; p.si += first; p.sj += first;
@@ -1323,6 +1445,24 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile, int first = 0) {
     MI_HIP(hipMemcpyAsync(flags, h->queue.ptr, sizeof(flags), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
     if (flags[1]) fail(MI355REC_E_HIP, "SLIM-BPR: a hand-off between steps did not arrive (dataflow kernel aborted)");
+    if (profile) {
+        std::vector<unsigned long long> c(h->prof.count);
+        MI_HIP(hipMemcpy(c.data(), h->prof.ptr, sizeof(unsigned long long) * c.size(), hipMemcpyDeviceToHost));
+        if (sym) {
+            fprintf(stderr, "[slim prof] symmetric: %llu steps, mean cycles: until all tags were there %.0f, rest %.0f; %.2f extra polling rounds per step\n",
+                    c[0], (double)c[1] / std::max(1ull, c[0]), (double)c[2] / std::max(1ull, c[0]), (double)c[3] / std::max(1ull, c[0]));
+        } else {
+            for (int o = 0; o < h->last_owners; o += std::max(1, h->last_owners / 8)) {
+                const unsigned long long *q = c.data() + 8 * o;
+                const double e = (double)std::max(1ull, q[0]);
+                fprintf(stderr, "[slim prof] owner %3d: %5llu entries, mean cycles: ticket %.0f, gather %.0f, wait for turn %.0f, turn %.0f, write-back %.0f\n",
+                        o, q[0], q[1] / e, q[2] / e, q[3] / e, q[4] / e, q[5] / e);
+            }
+            const unsigned long long *q = c.data() + 8 * MAX_OWNERS;
+            fprintf(stderr, "[slim prof] cold: %llu steps, mean cycles: ids + tickets %.0f, gather .. tickets passed on %.0f\n", q[0],
+                    (double)q[1] / std::max(1ull, q[0]), (double)q[2] / std::max(1ull, q[0]));
+        }
+    }
     h->steps_done += n;
 }
 
