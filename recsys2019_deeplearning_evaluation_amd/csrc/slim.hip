@@ -435,6 +435,11 @@ __device__ __forceinline__ double hot_adapt(const P &p, double g, double pw1, do
     }
 }
 
+// Profiles longer than the FLOW_REGS x 64 entries whose cells a wavefront keeps in registers are walked in BLOCKS of the same
+// size with all loads of a block in flight (round 4's first version took them 64 at a time, one dependent round trip each: 14 % of
+// the ML-20M users have more than 256 items, and those steps made up most of every critical section).
+constexpr int FLOW_BLOCK = 64 * FLOW_REGS;
+
 // ---- dense store ----------------------------------------------------------------------------------------------------------
 // One step on two rows in HBM, run by ONE wavefront: tickets of the two items (lanes 0 and 1 poll), gathers, reduction, the two
 // per-item optimiser steps, write-through scatters, drain, tickets passed on.
@@ -479,9 +484,19 @@ __device__ __forceinline__ void cold_step(const SlimParams<T> &p, const StepDesc
         vb[r] = live ? vb[r] : (T)0;
         x += va[r] - vb[r];                                           // x_uij over the profile (.pyx:243-260)
     }
-    for (int idx = lane + 64 * FLOW_REGS; idx < L; idx += 64) {       // profiles longer than 256
-        const int s = p.indices[rs + idx];
-        x += aload(Si + s) - aload(Sj + s);
+    for (int b0 = FLOW_BLOCK; b0 < L; b0 += FLOW_BLOCK) {             // profiles longer than 256
+        int s[FLOW_REGS];
+        T a[FLOW_REGS], b[FLOW_REGS];
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) s[r] = p.indices[rs + min(b0 + lane + 64 * r, L - 1)];
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) {
+            a[r] = aload(Si + s[r]);
+            b[r] = aload(Sj + s[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r)
+            if (b0 + lane + 64 * r < L) x += a[r] - b[r];
     }
     x = wave_sum(x);
     const T g = sigmoid_of_minus(x);                                  // .pyx:263
@@ -503,10 +518,23 @@ __device__ __forceinline__ void cold_step(const SlimParams<T> &p, const StepDesc
             if (s != j) astore(Sj + s, cell_minus(vb[r], p.lr, gj, p.lj_reg));
         }
     }
-    for (int idx = lane + 64 * FLOW_REGS; idx < L; idx += 64) {
-        const int s = p.indices[rs + idx];
-        if (s != i) astore(Si + s, cell_plus(aload(Si + s), p.lr, gi, p.li_reg));
-        if (s != j) astore(Sj + s, cell_minus(aload(Sj + s), p.lr, gj, p.lj_reg));
+    for (int b0 = FLOW_BLOCK; b0 < L; b0 += FLOW_BLOCK) {
+        int s[FLOW_REGS];
+        T a[FLOW_REGS], b[FLOW_REGS];
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) s[r] = p.indices[rs + min(b0 + lane + 64 * r, L - 1)];
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) {
+            a[r] = aload(Si + s[r]);
+            b[r] = aload(Sj + s[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) {
+            if (b0 + lane + 64 * r < L) {
+                if (s[r] != i) astore(Si + s[r], cell_plus(a[r], p.lr, gi, p.li_reg));
+                if (s[r] != j) astore(Sj + s[r], cell_minus(b[r], p.lr, gj, p.lj_reg));
+            }
+        }
     }
     // publish: drain the write-through stores, then pass the tickets on
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -526,7 +554,11 @@ __device__ __forceinline__ void cold_step(const SlimParams<T> &p, const StepDesc
 //                BEFORE its turn, writes them back and passes the ticket on AFTER its turn;
 //   owned too -> the two owners exchange two scalars through the step's mailbox (the negative item's owner sends its sum, the
 //                positive item's owner answers with the sigmoid), both inside their turns.
-// A turn: LDS gather, wavefront reduction, sigmoid, the item's optimiser step, LDS scatter, turn counter + 1.
+// A turn: LDS gather, wavefront reduction, sigmoid, the item's optimiser step, LDS scatter, turn counter + 1 -- and nothing that
+// leaves the compute unit: the profile's ids (up to OWN_IDS x 64 of them, two 16-bit ids per register: a row that fits the LDS has
+// fewer than 65 536 columns) are in registers before the turn starts.
+constexpr int OWN_IDS = 16;
+
 template <class T>
 __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, float *row, volatile int *turn, volatile double *oc,
                                           const int lane, const int wave) {
@@ -538,9 +570,17 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
         const unsigned long long k0 = p.prof ? shader_clock() : 0ull;
         const StepDesc e = p.own_desc[first + k];
         const int t = e.t, role = e.j, other = e.i, rs = e.rs, L = e.L;
-        int sv[FLOW_REGS];
+        unsigned ids[OWN_IDS / 2];
 #pragma unroll
-        for (int r = 0; r < FLOW_REGS; ++r) sv[r] = p.indices[rs + min(lane + 64 * r, L - 1)];
+        for (int r = 0; r < OWN_IDS; r += 2) {
+            ids[r / 2] = 0;
+            if (64 * r < L) {         // (wave-uniform: chunks the profile does not reach are not fetched)
+                const unsigned lo = (unsigned)p.indices[rs + min(lane + 64 * r, L - 1)];
+                const unsigned hi = (unsigned)p.indices[rs + min(lane + 64 * (r + 1), L - 1)];
+                ids[r / 2] = lo | (hi << 16);
+            }
+        }
+        auto id_of = [&](int r) -> int { return (int)((ids[r / 2] >> (16 * (r & 1))) & 0xffffu); };
         const bool mail = e.b != 0;
         // ---- before the turn: the other row's half ------------------------------------------------------------------------
         T *So = p.S + (size_t)other * n;
@@ -559,13 +599,31 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
                 if (p.sgd_mode == MI355REC_ADAM) oc2 = aload(&p.c2[other]);
             }
 #pragma unroll
-            for (int r = 0; r < FLOW_REGS; ++r) vo[r] = aload(So + sv[r]);
+            for (int r = 0; r < FLOW_REGS; ++r) vo[r] = aload(So + id_of(r));
 #pragma unroll
             for (int r = 0; r < FLOW_REGS; ++r) {
                 vo[r] = lane + 64 * r < L ? vo[r] : (T)0;
                 xo += (double)vo[r];
             }
-            for (int idx = lane + 64 * FLOW_REGS; idx < L; idx += 64) xo += (double)aload(So + p.indices[rs + idx]);
+#pragma unroll
+            for (int blk = 1; blk < OWN_IDS / FLOW_REGS; ++blk) {         // entries 256 .. 1023: ids in registers
+                if (blk * FLOW_BLOCK < L) {
+                    T a[FLOW_REGS];
+#pragma unroll
+                    for (int r = 0; r < FLOW_REGS; ++r) a[r] = aload(So + id_of(blk * FLOW_REGS + r));
+#pragma unroll
+                    for (int r = 0; r < FLOW_REGS; ++r)
+                        if (blk * FLOW_BLOCK + lane + 64 * r < L) xo += (double)a[r];
+                }
+            }
+            for (int b0 = 64 * OWN_IDS; b0 < L; b0 += FLOW_BLOCK) {
+                T a[FLOW_REGS];
+#pragma unroll
+                for (int r = 0; r < FLOW_REGS; ++r) a[r] = aload(So + p.indices[rs + min(b0 + lane + 64 * r, L - 1)]);
+#pragma unroll
+                for (int r = 0; r < FLOW_REGS; ++r)
+                    if (b0 + lane + 64 * r < L) xo += (double)a[r];
+            }
             xo = wave_sum(xo);
         }
         double pw1, pw2;
@@ -581,14 +639,11 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
         __builtin_amdgcn_s_setprio(3);
         asm volatile("" ::: "memory");
         const unsigned long long k3 = p.prof ? shader_clock() : 0ull;
-        float vr[FLOW_REGS];
         double xr = 0.0;
 #pragma unroll
-        for (int r = 0; r < FLOW_REGS; ++r) {
-            vr[r] = lane + 64 * r < L ? row[sv[r]] : 0.f;
-            xr += (double)vr[r];
-        }
-        for (int idx = lane + 64 * FLOW_REGS; idx < L; idx += 64) xr += (double)row[p.indices[rs + idx]];
+        for (int r = 0; r < OWN_IDS; ++r)
+            if (64 * r < L) xr += lane + 64 * r < L ? (double)row[id_of(r)] : 0.0;
+        for (int idx = lane + 64 * OWN_IDS; idx < L; idx += 64) xr += (double)row[p.indices[rs + idx]];      // (0.7 % of the ML-20M users)
         xr = wave_sum(xr);
         double g, x = 0.0;
         if (!mail) {
@@ -609,10 +664,13 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
         // (the row's cells are float32: their update in float32 arithmetic adds ~1e-7 of the INCREMENT to the rounding of the sum)
         const float reg = role ? lj_reg : li_reg, grf = (float)gr;
 #pragma unroll
-        for (int r = 0; r < FLOW_REGS; ++r) {
-            if (lane + 64 * r < L && sv[r] != item) row[sv[r]] = role ? cell_minus(vr[r], lr, grf, reg) : cell_plus(vr[r], lr, grf, reg);
+        for (int r = 0; r < OWN_IDS; ++r) {
+            if (64 * r < L) {
+                const int s = id_of(r);
+                if (lane + 64 * r < L && s != item) row[s] = role ? cell_minus(row[s], lr, grf, reg) : cell_plus(row[s], lr, grf, reg);
+            }
         }
-        for (int idx = lane + 64 * FLOW_REGS; idx < L; idx += 64) {
+        for (int idx = lane + 64 * OWN_IDS; idx < L; idx += 64) {
             const int s = p.indices[rs + idx];
             if (s != item) row[s] = role ? cell_minus(row[s], lr, grf, reg) : cell_plus(row[s], lr, grf, reg);
         }
@@ -633,13 +691,36 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
             // (the other row is the negative item when this one is the positive: .pyx:296-309)
 #pragma unroll
             for (int r = 0; r < FLOW_REGS; ++r) {
-                if (lane + 64 * r < L && sv[r] != other)
-                    astore(So + sv[r], role ? cell_plus(vo[r], p.lr, go_all, p.li_reg) : cell_minus(vo[r], p.lr, go_all, p.lj_reg));
+                const int s = id_of(r);
+                if (lane + 64 * r < L && s != other)
+                    astore(So + s, role ? cell_plus(vo[r], p.lr, go_all, p.li_reg) : cell_minus(vo[r], p.lr, go_all, p.lj_reg));
             }
-            for (int idx = lane + 64 * FLOW_REGS; idx < L; idx += 64) {
-                const int s = p.indices[rs + idx];
-                if (s != other)
-                    astore(So + s, role ? cell_plus(aload(So + s), p.lr, go_all, p.li_reg) : cell_minus(aload(So + s), p.lr, go_all, p.lj_reg));
+#pragma unroll
+            for (int blk = 1; blk < OWN_IDS / FLOW_REGS; ++blk) {
+                if (blk * FLOW_BLOCK < L) {
+                    T a[FLOW_REGS];
+#pragma unroll
+                    for (int r = 0; r < FLOW_REGS; ++r) a[r] = aload(So + id_of(blk * FLOW_REGS + r));
+#pragma unroll
+                    for (int r = 0; r < FLOW_REGS; ++r) {
+                        const int s = id_of(blk * FLOW_REGS + r);
+                        if (blk * FLOW_BLOCK + lane + 64 * r < L && s != other)
+                            astore(So + s, role ? cell_plus(a[r], p.lr, go_all, p.li_reg) : cell_minus(a[r], p.lr, go_all, p.lj_reg));
+                    }
+                }
+            }
+            for (int b0 = 64 * OWN_IDS; b0 < L; b0 += FLOW_BLOCK) {
+                int s[FLOW_REGS];
+                T a[FLOW_REGS];
+#pragma unroll
+                for (int r = 0; r < FLOW_REGS; ++r) {
+                    s[r] = p.indices[rs + min(b0 + lane + 64 * r, L - 1)];
+                    a[r] = aload(So + s[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < FLOW_REGS; ++r)
+                    if (b0 + lane + 64 * r < L && s[r] != other)
+                        astore(So + s[r], role ? cell_plus(a[r], p.lr, go_all, p.li_reg) : cell_minus(a[r], p.lr, go_all, p.lj_reg));
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) astore(&p.ticket[other], want + 1);
@@ -696,39 +777,61 @@ __global__ __launch_bounds__(FLOW_THREADS) void slim_dense_flow_kernel(const Sli
 // One step by ONE wavefront.  Every cell is a granule {value, tag of the step that wrote it}; the step knows which step wrote each
 // of its cells last (`pred`), so it loads all its granules at once and re-loads only those whose tag is not there yet.  Its own
 // stores carry its tag: nothing is drained, no flag is raised.  The optimiser cells of the two items travel as granules, too
-// (lane 0: item i, lane 1: item j; float64 as two float32 halves, each with its own tag).
+// (lane 0: item i, lane 1: item j; float64 as two float32 halves, each with its own tag).  Between the arrival of a step's last
+// tag and its stores sits the chain of the whole epoch (3 839 links at the ML-20M shape): sigmoid and optimiser step use the
+// short forms of the owned rows' turns.
 __device__ __forceinline__ bool tag_ok(int pred, unsigned tag, unsigned tag_base) { return pred < 0 || tag == tag_base + (unsigned)pred + 1u; }
+
+// one block of FLOW_BLOCK profile entries: ids, last writers, granules of both rows -- fetched, then polled until every tag is there
+struct SymBlock {
+    int s[FLOW_REGS], pa[FLOW_REGS], pb[FLOW_REGS];
+    Granule ga[FLOW_REGS], gb[FLOW_REGS];
+};
+__device__ __forceinline__ bool sym_fetch(const SlimParams<double> &p, const StepDesc &e, const long long cp, const int b0, const int lane,
+                                          const bool poll, SymBlock &k, unsigned &repolls) {
+    const int i = e.i, j = e.j, rs = e.rs, L = e.L;
+#pragma unroll
+    for (int r = 0; r < FLOW_REGS; ++r) {
+        const int at = min(b0 + lane + 64 * r, L - 1);
+        k.s[r] = p.indices[rs + at];
+        if (poll) {
+            const int2 pp = *reinterpret_cast<const int2 *>(p.pred + cp + 2 * at);
+            k.pa[r] = pp.x;
+            k.pb[r] = pp.y;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FLOW_REGS; ++r) {
+        const bool live = b0 + lane + 64 * r < L;
+        k.pa[r] = live && poll ? k.pa[r] : -1;
+        k.pb[r] = live && poll ? k.pb[r] : -1;
+        k.ga[r] = gload(p.G + packed_cell(i, k.s[r]));
+        k.gb[r] = gload(p.G + packed_cell(j, k.s[r]));
+    }
+    if (!poll) return true;
+    SpinGuard sg;
+    for (;;) {
+        bool pending = false;
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) {
+            if (!tag_ok(k.pa[r], k.ga[r].tag, p.tag_base)) { pending = true; k.ga[r] = gload(p.G + packed_cell(i, k.s[r])); }
+            if (!tag_ok(k.pb[r], k.gb[r].tag, p.tag_base)) { pending = true; k.gb[r] = gload(p.G + packed_cell(j, k.s[r])); }
+        }
+        if (!__any(pending)) return true;
+        ++repolls;
+        if (give_up(p, sg)) return false;
+    }
+}
 
 __device__ __forceinline__ void sym_step(const SlimParams<double> &p, const int t, const int lane) {
     const StepDesc e = p.desc[t];
-    const int i = e.i, j = e.j, rs = e.rs, L = e.L;
+    const int i = e.i, j = e.j, L = e.L;
     const long long cp = (long long)(((unsigned long long)(unsigned)e.c << 32) | (unsigned)e.t);
     const unsigned long long k0 = p.prof ? shader_clock() : 0ull;
     unsigned repolls = 0;
     const unsigned my_tag = p.tag_base + (unsigned)t + 1u;
     const bool adaptive = p.sgd_mode != MI355REC_SGD, adam = p.sgd_mode == MI355REC_ADAM;
-    int sv[FLOW_REGS], pa[FLOW_REGS], pb[FLOW_REGS];
-    Granule *ca[FLOW_REGS], *cb[FLOW_REGS];
-#pragma unroll
-    for (int r = 0; r < FLOW_REGS; ++r) {
-        const int at = min(lane + 64 * r, L - 1);
-        sv[r] = p.indices[rs + at];
-        const int2 pp = *reinterpret_cast<const int2 *>(p.pred + cp + 2 * at);
-        pa[r] = pp.x;
-        pb[r] = pp.y;
-    }
-    Granule ga[FLOW_REGS], gb[FLOW_REGS];
-#pragma unroll
-    for (int r = 0; r < FLOW_REGS; ++r) {
-        const bool live = lane + 64 * r < L;
-        pa[r] = live ? pa[r] : -1;
-        pb[r] = live ? pb[r] : -1;
-        ca[r] = p.G + packed_cell(i, sv[r]);
-        cb[r] = p.G + packed_cell(j, sv[r]);
-        ga[r] = gload(ca[r]);
-        gb[r] = gload(cb[r]);
-    }
-    // optimiser granules of the lane's item
+    // optimiser granules of the lane's item (requested first: they are polled last)
     Granule *oc = p.oc + 4 * (size_t)(lane == 1 ? j : i);
     const int ip = lane < 2 && adaptive ? (lane ? e.b : e.a) : -1;
     Granule o[4] = {{0.f, 0u}, {0.f, 0u}, {0.f, 0u}, {0.f, 0u}};
@@ -740,53 +843,47 @@ __device__ __forceinline__ void sym_step(const SlimParams<double> &p, const int 
             o[3] = gload(oc + 3);
         }
     }
+    SymBlock k;                                                       // the first block stays in registers for the second pass
+    if (!sym_fetch(p, e, cp, 0, lane, true, k, repolls)) return;
+    double x = 0.0;
+#pragma unroll
+    for (int r = 0; r < FLOW_REGS; ++r)
+        if (lane + 64 * r < L) x += (double)k.ga[r].v - (double)k.gb[r].v;                // x_uij over the profile (.pyx:243-260)
+    for (int b0 = FLOW_BLOCK; b0 < L; b0 += FLOW_BLOCK) {                                 // profiles longer than 256
+        SymBlock m;
+        if (!sym_fetch(p, e, cp, b0, lane, true, m, repolls)) return;
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r)
+            if (b0 + lane + 64 * r < L) x += (double)m.ga[r].v - (double)m.gb[r].v;
+    }
     {
         SpinGuard sg;
         for (;;) {
             bool pending = false;
 #pragma unroll
-            for (int r = 0; r < FLOW_REGS; ++r) {
-                if (!tag_ok(pa[r], ga[r].tag, p.tag_base)) { pending = true; ga[r] = gload(ca[r]); }
-                if (!tag_ok(pb[r], gb[r].tag, p.tag_base)) { pending = true; gb[r] = gload(cb[r]); }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if ((e < 2 || adam) && !tag_ok(ip, o[e].tag, p.tag_base)) { pending = true; o[e] = gload(oc + e); }
+            for (int c = 0; c < 4; ++c)
+                if ((c < 2 || adam) && !tag_ok(ip, o[c].tag, p.tag_base)) { pending = true; o[c] = gload(oc + c); }
             if (!__any(pending)) break;
             ++repolls;
             if (give_up(p, sg)) return;
         }
     }
     const unsigned long long k1 = p.prof ? shader_clock() : 0ull;
-    double x = 0.0;
-#pragma unroll
-    for (int r = 0; r < FLOW_REGS; ++r)
-        if (lane + 64 * r < L) x += (double)ga[r].v - (double)gb[r].v;                    // x_uij over the profile (.pyx:243-260)
-    for (int c0 = 64 * FLOW_REGS; c0 < L; c0 += 64) {                                     // profiles longer than 256
-        const int idx = c0 + lane;
-        const bool live = idx < L;
-        const int at = min(idx, L - 1);
-        const int s = p.indices[rs + at];
-        const int2 pp = *reinterpret_cast<const int2 *>(p.pred + cp + 2 * at);
-        const int qa = live ? pp.x : -1, qb = live ? pp.y : -1;
-        Granule *a = p.G + packed_cell(i, s), *b = p.G + packed_cell(j, s);
-        Granule va = gload(a), vb = gload(b);
-        SpinGuard sg;
-        for (;;) {
-            bool pending = false;
-            if (!tag_ok(qa, va.tag, p.tag_base)) { pending = true; va = gload(a); }
-            if (!tag_ok(qb, vb.tag, p.tag_base)) { pending = true; vb = gload(b); }
-            if (!__any(pending)) break;
-            if (give_up(p, sg)) return;
-        }
-        if (live) x += (double)va.v - (double)vb.v;
-    }
     x = wave_sum(x);
-    const double g = sigmoid_of_minus(x);                                                 // .pyx:263
+    const double g = fast_sigmoid_of_minus(x);                                            // .pyx:263
     double pw1, pw2;
     adam_powers(p, t, pw1, pw2);
     double c1 = (double)o[0].v + (double)o[1].v, c2 = (double)o[2].v + (double)o[3].v;
-    const double step = slim_adapt_cells(p, g, pw1, pw2, c1, c2);                         // item i on lane 0, item j on lane 1 (.pyx:267-268)
+    const double step = hot_adapt(p, g, pw1, pw2, c1, c2);                                // item i on lane 0, item j on lane 1 (.pyx:267-268)
+    const double gi = __shfl(step, 0), gj = __shfl(step, 1);
+    // the two rows move (.pyx:271-309): one write-through store per cell, value and tag together
+#pragma unroll
+    for (int r = 0; r < FLOW_REGS; ++r) {
+        if (lane + 64 * r < L) {
+            if (k.s[r] != i) gstore(p.G + packed_cell(i, k.s[r]), (float)cell_plus((double)k.ga[r].v, p.lr, gi, p.li_reg), my_tag);
+            if (k.s[r] != j) gstore(p.G + packed_cell(j, k.s[r]), (float)cell_minus((double)k.gb[r].v, p.lr, gj, p.lj_reg), my_tag);
+        }
+    }
     if (lane < 2 && adaptive) {
         const float h1 = (float)c1;
         gstore(oc, h1, my_tag);
@@ -797,23 +894,19 @@ __device__ __forceinline__ void sym_step(const SlimParams<double> &p, const int 
             gstore(oc + 3, (float)(c2 - (double)h2), my_tag);
         }
     }
-    const double gi = __shfl(step, 0), gj = __shfl(step, 1);
-    if (lane == 0) atomicAdd(&p.loss_slots[t & (LOSS_SLOTS - 1)], x * x);
-    // the two rows move (.pyx:271-309): one write-through store per cell, value and tag together
+    for (int b0 = FLOW_BLOCK; b0 < L; b0 += FLOW_BLOCK) {
+        // (nobody can have written these cells since they were read above: a later step waits for THIS step's tag on them)
+        SymBlock m;
+        sym_fetch(p, e, cp, b0, lane, false, m, repolls);
 #pragma unroll
-    for (int r = 0; r < FLOW_REGS; ++r) {
-        if (lane + 64 * r < L) {
-            if (sv[r] != i) gstore(ca[r], (float)cell_plus((double)ga[r].v, p.lr, gi, p.li_reg), my_tag);
-            if (sv[r] != j) gstore(cb[r], (float)cell_minus((double)gb[r].v, p.lr, gj, p.lj_reg), my_tag);
+        for (int r = 0; r < FLOW_REGS; ++r) {
+            if (b0 + lane + 64 * r < L) {
+                if (m.s[r] != i) gstore(p.G + packed_cell(i, m.s[r]), (float)cell_plus((double)m.ga[r].v, p.lr, gi, p.li_reg), my_tag);
+                if (m.s[r] != j) gstore(p.G + packed_cell(j, m.s[r]), (float)cell_minus((double)m.gb[r].v, p.lr, gj, p.lj_reg), my_tag);
+            }
         }
     }
-    for (int idx = 64 * FLOW_REGS + lane; idx < L; idx += 64) {
-        // (nobody can have written these cells since they were read above: a later step waits for THIS step's tag on them)
-        const int s = p.indices[rs + idx];
-        Granule *a = p.G + packed_cell(i, s), *b = p.G + packed_cell(j, s);
-        if (s != i) gstore(a, (float)cell_plus((double)gload(a).v, p.lr, gi, p.li_reg), my_tag);
-        if (s != j) gstore(b, (float)cell_minus((double)gload(b).v, p.lr, gj, p.lj_reg), my_tag);
-    }
+    if (lane == 0) atomicAdd(&p.loss_slots[t & (LOSS_SLOTS - 1)], x * x);
     if (p.prof && lane == 0) {       // steps | descriptor .. all tags there | the rest | polling rounds that found a tag missing
         atomicAdd(&p.prof[0], 1ull);
         atomicAdd(&p.prof[1], k1 - k0);
