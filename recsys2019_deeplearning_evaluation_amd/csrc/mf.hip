@@ -65,6 +65,8 @@ typedef int int8v __attribute__((ext_vector_type(8)));
 // record .w: bits 0-1 role of the task's row in this sample (0 user, 1 item / positive item, 2 negative item),
 //            bit 2 / 3 / 4: buffer of the sample's user / item / negative-item row
 //            bit 5 / 6 (user role, fast schedule): this task also updates the sample's positive / negative item row
+//            bits 8-15 / 16-23 / 24-31 (fast schedule): how many earlier mini-batches of the stream touch the sample's user /
+//            item / negative-item row = the version of that row the sample reads (the dataflow epoch waits for it)
 constexpr int ROLE_U = 0, ROLE_I = 1;   // 2: negative item
 
 template <class T> struct MuState { T mu, c1, c2, pad; };
@@ -107,6 +109,13 @@ struct MfParams {
     unsigned long long *ticks;           // optional [tasks_per_batch][8] shader-clock stamps of the last mini-batch (MI355REC_MF_TICKS=1)
     int wg_base, wg_stride;              // workgroup b of the launch is workgroup wg_base + b * wg_stride of the mini-batch (exact
                                          // multi-GPU mode: rank r of G runs workgroups r, r + G, ...; otherwise 0 and 1)
+    // dataflow epoch (mf_flow_kernel): one persistent launch runs every mini-batch of the stream
+    int *ver;                            // [n_users + n_items] versions of the row written in this stream so far
+    int *rd;                             // [n_batches][RD_SHARDS] tasks of the mini-batch that have finished READING
+    int *flow;                           // [0] next unit of the in-order queue, [1] abort flag, [2] mini-batches whose reads are all done
+    const int *unit_base;                // [n_batches + 1] first unit of every mini-batch
+    const int *wide;                     // [n_batches] header quads of the mini-batch that hold a split list (they lead its slots)
+    int n_batches;
 };
 
 __device__ __forceinline__ unsigned long long stamp() {   // shader clock; not reordered against memory operations
@@ -363,6 +372,7 @@ struct FastSchedParams {
     int *sorted_slot;             // [n_batches][tasks_per_batch]: batch-local incidence ids in (row, id) order
     int *qtask;                   // per sorted position: batch-local slot of its task's (first) header | wide << 30
     int *used;                    // [n_batches]: header slots in use
+    int *wide;                    // [n_batches]: split lists of the mini-batch (4 leading header slots each)
     TaskHeader *tasks;
     int4 *recs;
 };
@@ -504,7 +514,7 @@ __device__ __forceinline__ void mf_sched_sort_body(const FastSchedParams &s, con
         }
     }
     const int used = 4 * n_wide + (total - n_wide - n_abs);
-    if (tid == 0) s.used[b] = used;
+    if (tid == 0) { s.used[b] = used; s.wide[b] = n_wide; }
     for (int slot = used + tid; slot < s.tasks_per_batch; slot += SCHED_THREADS)
         *reinterpret_cast<int4 *>(out + slot) = make_int4(0, 0, 0, 0);          // no samples: the slot's wavefront idles
     __syncthreads();
@@ -526,12 +536,13 @@ __device__ __forceinline__ void mf_sched_sort_body(const FastSchedParams &s, con
 }
 __global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const FastSchedParams s) { mf_sched_sort_body(s, blockIdx.x); }
 
-__device__ __forceinline__ int version_parity(const FastSchedParams &s, int entry, int b) {
+// mini-batches before b that touch the row = version of the row mini-batch b reads (version v lives in buffer (par + v) & 1)
+__device__ __forceinline__ int version_count(const FastSchedParams &s, int entry, int b) {
     const unsigned *w = s.touched + (size_t)entry * s.words;
     int cnt = 0;
     for (int k = 0; k < (b >> 5); ++k) cnt += __popc(w[k]);
     cnt += __popc(w[b >> 5] & ((1u << (b & 31)) - 1u));
-    return (s.par[entry] + cnt) & 1;
+    return cnt;
 }
 
 __device__ __forceinline__ void mf_sched_emit_body(const FastSchedParams &s) {
@@ -545,9 +556,11 @@ __device__ __forceinline__ void mf_sched_emit_body(const FastSchedParams &s) {
     const int smp = slot / s.per, role = slot - smp * s.per;
     const long long t = first + smp;
     const int u = s.su[t], i = s.si[t], j = s.per == 3 ? s.sj[t] : 0;
-    const int pu = version_parity(s, u, b), pi = version_parity(s, s.n_users + i, b);
-    const int pj = s.per == 3 ? version_parity(s, s.n_users + j, b) : 0;
-    const int4 rec = make_int4(u, i, s.per == 3 ? j : __float_as_int(s.sr[t]), role | (pu << 2) | (pi << 3) | (pj << 4) | (also << 5));
+    const int cu = version_count(s, u, b), ci = version_count(s, s.n_users + i, b);
+    const int cj = s.per == 3 ? version_count(s, s.n_users + j, b) : 0;
+    const int pu = (s.par[u] + cu) & 1, pi = (s.par[s.n_users + i] + ci) & 1, pj = s.per == 3 ? (s.par[s.n_users + j] + cj) & 1 : 0;
+    const int4 rec = make_int4(u, i, s.per == 3 ? j : __float_as_int(s.sr[t]),
+                               role | (pu << 2) | (pi << 3) | (pj << 4) | (also << 5) | (cu << 8) | (ci << 16) | (cj << 24));
     s.recs[at] = rec;
     const int tp = s.qtask[at];
     if (tp == SLOT_ABSORBED) return;
@@ -597,12 +610,35 @@ template <class T, int VEC> struct alignas(sizeof(T) * VEC) Chunk { T v[VEC]; };
 
 // Loads are issued unconditionally from clamped (always valid) addresses and masked afterwards: no branch sits between
 // two loads, so the compiler batches them under one wait.
-template <class T, int VEC>
+// FLOW (the dataflow epoch): rows written by another compute unit earlier in the same launch are read past the L1 and written
+// through (agent-scope atomics on the two 8-byte halves of a chunk: `global_load / global_store ... sc1`).
+template <class T, int VEC, bool FLOW = false>
 __device__ __forceinline__ Chunk<T, VEC> load_chunk(const T *row, int chunk, bool ok) {
-    Chunk<T, VEC> r = *reinterpret_cast<const Chunk<T, VEC> *>(row + (size_t)(ok ? chunk : 0) * VEC);
+    Chunk<T, VEC> r;
+    if constexpr (FLOW) {
+        const unsigned long long *q = reinterpret_cast<const unsigned long long *>(row + (size_t)(ok ? chunk : 0) * VEC);
+        struct Halves { unsigned long long h[2]; } b;
+        b.h[0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b.h[1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r = __builtin_bit_cast(Chunk<T, VEC>, b);
+    } else {
+        r = *reinterpret_cast<const Chunk<T, VEC> *>(row + (size_t)(ok ? chunk : 0) * VEC);
+    }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) r.v[e] = ok ? r.v[e] : (T)0;
     return r;
+}
+template <class T, int VEC, bool FLOW = false>
+__device__ __forceinline__ void store_chunk(T *at, const Chunk<T, VEC> &c) {
+    if constexpr (FLOW) {
+        struct Halves { unsigned long long h[2]; };
+        const Halves b = __builtin_bit_cast(Halves, c);
+        unsigned long long *q = reinterpret_cast<unsigned long long *>(at);
+        __hip_atomic_store(q, b.h[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, b.h[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *reinterpret_cast<Chunk<T, VEC> *>(at) = c;
+    }
 }
 
 // Adam's 1 - beta^t for the 1-based mini-batch index t
@@ -654,13 +690,84 @@ __device__ __forceinline__ T global_bias_at(const MfParams<T> &p, long long gb, 
     return global_bias_finish(p, global_bias_request(p, gb, lane), gb, writer, lane);
 }
 
+// ---- the dataflow epoch's waits ---------------------------------------------------------------------------------------------------
+// One persistent launch (mf_flow_kernel) runs every mini-batch of a stream: workgroups claim units of task slots in stream order
+// and a task waits for exactly what it depends on -- the VERSIONS of the rows its samples read (`ver`, raised by the task that
+// wrote the version after draining its write-through stores) and, before it writes, the end of all READS of earlier mini-batches
+// (`rd` + the watermark flow[2]): with two buffers per row, version v + 1 overwrites version v - 1, whose last readers sit in the
+// mini-batch that produced version v.  Every wait is a relaxed agent-scope poll with a budget: a hand-off that does not arrive
+// within FLOW_SPIN_TICKS raises the abort flag (flow[1]; nobody waits any more, the call fails) instead of hanging the device.
+constexpr int RD_SHARDS = 32;              // arrival counters per mini-batch (one address retires an atomic in ~13 ns)
+constexpr int UNIT_QUADS = 4;              // header quads (4 task slots, one workgroup pass each) per claimed unit; split lists: 1
+constexpr long long FLOW_SPIN_TICKS = 500000000ll;       // 5 s of the 100 MHz wall clock
+struct FlowSpin {
+    unsigned polls = 0;
+    long long t0 = 0;
+};
+template <class T>
+__device__ __forceinline__ bool flow_give_up(const MfParams<T> &p, FlowSpin &g) {      // wave-uniform answer
+    if ((++g.polls & 63u) != 0) return false;
+    int stop = __hip_atomic_load(&p.flow[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long now = wall_clock64();
+    if (g.t0 == 0) g.t0 = now;
+    else if (now - g.t0 > FLOW_SPIN_TICKS) { __hip_atomic_store(&p.flow[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); stop = 1; }
+    return __builtin_amdgcn_readfirstlane(stop) != 0;
+}
+// The versions of all rows of this wavefront's share of a task's list (positions base + it * step + g, it < n_mine / G): 21 samples
+// per round, one lane per (sample, row).  A row whose version is more than one step away is polled at leisure.
+template <class T, int G>
+__device__ __forceinline__ void flow_wait_rows(const MfParams<T> &p, const int start, const int len, const int base, const int step,
+                                               const int n_mine, const int lane) {
+    for (int first = 0; first < n_mine; first += 21) {
+        const int sidx = first + lane / 3, r = lane - 3 * (lane / 3);
+        const int idx = base + (sidx / G) * step + (sidx % G);
+        const bool live = lane < 63 && sidx < n_mine && idx < len;
+        const int4 rc = p.recs[start + (live ? idx : 0)];
+        const int entry = r == 0 ? rc.x : p.n_users + (r == 1 ? rc.y : rc.z);
+        const int cnt = (rc.w >> (8 + 8 * r)) & 255;
+        const bool need = live && cnt > 0;
+        FlowSpin sg;
+        for (;;) {
+            const int v = need ? __hip_atomic_load(&p.ver[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            const bool missing = need && v < cnt;
+            if (!__any(missing)) break;
+            if (__any(missing && cnt - v == 1)) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(16);
+            if (flow_give_up(p, sg)) break;
+        }
+    }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+// All mini-batches before b have finished reading (wm_known: the watermark as this wavefront last saw it).  Whoever finds the
+// watermark short of what it needs checks the next mini-batch's arrivals itself and moves the watermark on.
+template <class T>
+__device__ __forceinline__ void flow_wait_reads(const MfParams<T> &p, const int b, int &wm_known, const int lane) {
+    if (b <= wm_known) return;
+    FlowSpin sg;
+    for (;;) {
+        int wm = 0;
+        if (lane == 0) wm = __hip_atomic_load(&p.flow[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wm = __builtin_amdgcn_readfirstlane(wm);
+        if (wm >= b) { wm_known = wm; return; }
+        float c = 0.f;
+        if (lane < RD_SHARDS) c = (float)__hip_atomic_load(&p.rd[wm * RD_SHARDS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c = wave_sum(c);
+        if ((int)c == p.used[wm]) {
+            if (lane == 0) atomicMax(&p.flow[2], wm + 1);
+            if (wm + 1 >= b) { wm_known = wm + 1; return; }
+            continue;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if (flow_give_up(p, sg)) return;
+    }
+}
+
 // the three rows of one sample, KI chunks of VEC elements per lane
 template <class T, int VEC, int KI, bool BPR> struct Rows {
     Chunk<T, VEC> A[KI], B[KI], C[BPR ? KI : 1];
     T bu, bi;
 };
 
-template <class T, int VEC, int LPR, int KI, bool BPR>
+template <class T, int VEC, int LPR, int KI, bool BPR, bool FLOW = false>
 __device__ __forceinline__ Rows<T, VEC, KI, BPR> load_rows(const MfParams<T> &p, const int4 rec, int li, const bool (&cok)[KI],
                                                            bool bias) {
     Rows<T, VEC, KI, BPR> r;
@@ -670,9 +777,9 @@ __device__ __forceinline__ Rows<T, VEC, KI, BPR> load_rows(const MfParams<T> &p,
     const T *Hj = ((rec.w >> 4) & 1 ? p.V1 : p.V0) + (size_t)(BPR ? rec.z : 0) * k;
 #pragma unroll
     for (int c = 0; c < KI; ++c) {
-        r.A[c] = load_chunk<T, VEC>(Wu, c * LPR + li, cok[c]);
-        r.B[c] = load_chunk<T, VEC>(Hi, c * LPR + li, cok[c]);
-        if (BPR) r.C[c] = load_chunk<T, VEC>(Hj, c * LPR + li, cok[c]);
+        r.A[c] = load_chunk<T, VEC, FLOW>(Wu, c * LPR + li, cok[c]);
+        r.B[c] = load_chunk<T, VEC, FLOW>(Hi, c * LPR + li, cok[c]);
+        if (BPR) r.C[c] = load_chunk<T, VEC, FLOW>(Hj, c * LPR + li, cok[c]);
     }
     r.bu = (T)0;
     r.bi = (T)0;
@@ -686,8 +793,8 @@ __device__ __forceinline__ Rows<T, VEC, KI, BPR> load_rows(const MfParams<T> &p,
 // KI chunks of VEC elements per lane, LPR lanes per row (64 / LPR samples of a task's list in flight per wavefront).
 // `wg` = this workgroup's index within the mini-batch's launch of ONE model (blockIdx.x; the group launch below puts the model
 // on blockIdx.y).
-template <int ALGO, class T, int VEC, int LPR, int KI>
-__device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int batch_local, const int wg) {
+template <int ALGO, class T, int VEC, int LPR, int KI, bool FLOW = false>
+__device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int batch_local, const int wg, int &wm_known) {
     constexpr int G = 64 / LPR;
     constexpr bool BPR = ALGO == MI355REC_MF_BPR;
     using Ch = Chunk<T, VEC>;
@@ -746,7 +853,8 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
         const int4 rec_first = rec;                // single-sample and pair tasks: THE record of this lane group
         int4 rec_n = rec;
         if (iters > 1) rec_n = p.recs[start + min(base + step + g, len - 1)];
-        R rows = load_rows<T, VEC, LPR, KI, BPR>(p, rec, li, cok, bias);
+        if constexpr (FLOW) flow_wait_rows<T, G>(p, start, len, base, step, iters * G, lane);
+        R rows = load_rows<T, VEC, LPR, KI, BPR, FLOW>(p, rec, li, cok, bias);
         if (bias) mu_eff = global_bias_finish(p, mu_req, gb, wv == 0, lane);               // folded behind the gathers just issued
         T pw1, pw2;
         adam_powers(p, gb + 1, pw1, pw2);
@@ -766,7 +874,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
             int4 rec_nn = rec_n;
             if (it + 2 < iters) rec_nn = p.recs[start + min(idx + 2 * step, len - 1)];
             R rows_n = rows;
-            if (it + 1 < iters) rows_n = load_rows<T, VEC, LPR, KI, BPR>(p, rec_n, li, cok, bias);
+            if (it + 1 < iters) rows_n = load_rows<T, VEC, LPR, KI, BPR, FLOW>(p, rec_n, li, cok, bias);
 
             const int role = rec.w & 3;
             T dot = (T)0;
@@ -840,6 +948,11 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
         // dependent memory round trip out of the tail of the wavefront
         if (li == 0 && loss != 0.0) atomicAdd(&p.loss_slots[wv * 4 + g], loss);
         if (p.ticks) tk3 = stamp();      // list done
+        if constexpr (FLOW) {            // every row this task reads is in registers: say so, then wait for the readers this task's stores could hurt
+            if (lane == 0) atomicAdd(&p.rd[batch_local * RD_SHARDS + (wv & (RD_SHARDS - 1))], 1);
+            flow_wait_reads(p, batch_local, wm_known, lane);
+        }
+        int pub_row[3] = {-1, -1, -1}, pub_ver[3] = {0, 0, 0};      // FLOW: rows this lane's group writes, and their new versions
         if (wide) {                      // the four quarters meet in LDS and are summed in quarter order by the first
             if (g == 0) {
 #pragma unroll
@@ -873,17 +986,22 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
                 if (!cok[c]) continue;
                 const size_t at = (size_t)(c * LPR + li) * VEC;
                 Ch m1, m2, out;
-                if (p.sgd_mode != MI355REC_SGD) m1 = *reinterpret_cast<const Ch *>(c1 + at);
-                if (p.sgd_mode == MI355REC_ADAM) m2 = *reinterpret_cast<const Ch *>(c2 + at);
+                if (p.sgd_mode != MI355REC_SGD) m1 = load_chunk<T, VEC, FLOW>(c1 + at, 0, true);
+                if (p.sgd_mode == MI355REC_ADAM) m2 = load_chunk<T, VEC, FLOW>(c2 + at, 0, true);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     const T gm = mean_of(acc[c].v[e], p.inv_batch);
                     const T step = adapt_cell(p, gm, m1.v[e], m2.v[e], pw1, pw2);
                     out.v[e] = moved(own[c].v[e], p.lr, step);
                 }
-                *reinterpret_cast<Ch *>(Wn + at) = out;
-                if (p.sgd_mode != MI355REC_SGD) *reinterpret_cast<Ch *>(c1 + at) = m1;
-                if (p.sgd_mode == MI355REC_ADAM) *reinterpret_cast<Ch *>(c2 + at) = m2;
+                store_chunk<T, VEC, FLOW>(Wn + at, out);
+                if (p.sgd_mode != MI355REC_SGD) store_chunk<T, VEC, FLOW>(c1 + at, m1);
+                if (p.sgd_mode == MI355REC_ADAM) store_chunk<T, VEC, FLOW>(c2 + at, m2);
+            }
+            {
+                const int role = rec_first.w & 3;
+                pub_row[0] = own_entry;
+                pub_ver[0] = ((rec_first.w >> (8 + 8 * role)) & 255) + 1;
             }
             if (bias && li == 0) {
                 T *bn = is_item ? (own_buf ? p.bi0 : p.bi1) : (own_buf ? p.bu0 : p.bu1);
@@ -912,8 +1030,8 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
                     if (!cok[c]) continue;
                     const size_t at = (size_t)(c * LPR + li) * VEC;
                     Ch m1, m2, out;
-                    if (p.sgd_mode != MI355REC_SGD) m1 = *reinterpret_cast<const Ch *>(c1 + at);
-                    if (p.sgd_mode == MI355REC_ADAM) m2 = *reinterpret_cast<const Ch *>(c2 + at);
+                    if (p.sgd_mode != MI355REC_SGD) m1 = load_chunk<T, VEC, FLOW>(c1 + at, 0, true);
+                    if (p.sgd_mode == MI355REC_ADAM) m2 = load_chunk<T, VEC, FLOW>(c2 + at, 0, true);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         const T a = rows.A[c].v[v], b = rows.B[c].v[v], cc = rows.C[c].v[v];
@@ -922,10 +1040,20 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
                         const T step = adapt_cell(p, gm, m1.v[v], m2.v[v], pw1, pw2);
                         out.v[v] = moved(e == 1 ? b : cc, p.lr, step);
                     }
-                    *reinterpret_cast<Ch *>(Wn + at) = out;
-                    if (p.sgd_mode != MI355REC_SGD) *reinterpret_cast<Ch *>(c1 + at) = m1;
-                    if (p.sgd_mode == MI355REC_ADAM) *reinterpret_cast<Ch *>(c2 + at) = m2;
+                    store_chunk<T, VEC, FLOW>(Wn + at, out);
+                    if (p.sgd_mode != MI355REC_SGD) store_chunk<T, VEC, FLOW>(c1 + at, m1);
+                    if (p.sgd_mode == MI355REC_ADAM) store_chunk<T, VEC, FLOW>(c2 + at, m2);
                 }
+                pub_row[e] = p.n_users + item;
+                pub_ver[e] = ((rec_first.w >> (8 + 8 * e)) & 255) + 1;
+            }
+        }
+        if constexpr (FLOW) {            // the new versions are in memory before anybody is told about them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (li == 0) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                    if (pub_row[e] >= 0) __hip_atomic_store(&p.ver[pub_row[e]], pub_ver[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -946,7 +1074,50 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
 
 template <int ALGO, class T, int VEC, int LPR, int KI>
 __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, const int batch_local) {
-    mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, blockIdx.x);
+    int unused = 0;
+    mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, blockIdx.x, unused);
+}
+
+// The dataflow epoch: ONE persistent launch for all mini-batches of the stream (BPR on the in-LDS schedule).  Units of task slots
+// are claimed in stream order (a split list = one header quad = one unit, so that no busy row's task queues behind another one;
+// the rest in fours), which is what makes the waits safe: whatever a claimed task waits for belongs to an earlier mini-batch and
+// is therefore claimed already, by a workgroup that only waits for still earlier ones.
+template <int ALGO, class T, int VEC, int LPR, int KI>
+__global__ __launch_bounds__(256) void mf_flow_kernel(const MfParams<T> p) {
+    __shared__ int s_unit;
+    int b_cur = 0, wm_known = 0;
+    const int total = p.unit_base[p.n_batches];
+    for (;;) {
+        if (threadIdx.x == 0)
+            s_unit = __hip_atomic_load(&p.flow[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0x7fffffff : atomicAdd(&p.flow[0], 1);
+        __syncthreads();
+        const int u = s_unit;
+        if (u >= total) break;
+        while (u >= p.unit_base[b_cur + 1]) ++b_cur;
+        const int local = u - p.unit_base[b_cur], n_wide = p.wide[b_cur], n_quads = (p.used[b_cur] + 3) >> 2;
+        if (local < n_wide) {
+            mf_batch_body<ALGO, T, VEC, LPR, KI, true>(p, b_cur, local, wm_known);
+        } else {
+            const int q0 = n_wide + UNIT_QUADS * (local - n_wide);
+            for (int q = q0; q < min(q0 + UNIT_QUADS, n_quads); ++q) mf_batch_body<ALGO, T, VEC, LPR, KI, true>(p, b_cur, q, wm_known);
+        }
+        __syncthreads();
+    }
+}
+// units per mini-batch -> first unit of every mini-batch (at most FAST_MAX_BATCHES of them: one block)
+__global__ __launch_bounds__(256) void mf_flow_units_kernel(const int *used, const int *wide, const int n_batches, int *unit_base) {
+    typedef rocprim::block_scan<int, 256> Scan;
+    __shared__ typename Scan::storage_type tmp;
+    const int b = threadIdx.x;
+    int units = 0;
+    if (b < n_batches) {
+        const int n_quads = (used[b] + 3) >> 2, n_wide = wide[b];
+        units = n_wide + (max(n_quads - n_wide, 0) + UNIT_QUADS - 1) / UNIT_QUADS;
+    }
+    int first = 0, total = 0;
+    Scan().exclusive_scan(units, first, 0, total, tmp);
+    if (b < n_batches) unit_base[b] = first;
+    if (b == 0) unit_base[n_batches] = total;
 }
 
 // REPLICA-BATCHED launch: mini-batch `batch_local` of R independent models in one grid (blockIdx.y = model).  A single model's
@@ -981,14 +1152,15 @@ __global__ __launch_bounds__(256) void mf_group_batch_kernel(const MfParams<T> *
     // the grid covers a third of a mini-batch's header slots; with fused / paired tasks fewer than that are in use as a rule
     // (the in-LDS schedule files the count), and a workgroup that finds more walks on: no wavefront is launched for an empty slot
     const int used = p.used ? p.used[batch_local] : p.tasks_per_batch;
-    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg);
+    int unused = 0;
+    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg, unused);
 }
 // Sampler and schedule of every member in ONE launch each (model on the last grid dimension): as 4 x R small launches on R
 // streams they took a third of a 32-model epoch.
 __device__ __forceinline__ void globalize(FastSchedParams &f) {
     f.su = as_global(f.su); f.si = as_global(f.si); f.sj = as_global(f.sj); f.sr = as_global(f.sr);
     f.touched = as_global(f.touched); f.par = as_global(f.par); f.sorted_slot = as_global(f.sorted_slot); f.qtask = as_global(f.qtask);
-    f.used = as_global(f.used); f.tasks = as_global(f.tasks); f.recs = as_global(f.recs);
+    f.used = as_global(f.used); f.wide = as_global(f.wide); f.tasks = as_global(f.tasks); f.recs = as_global(f.recs);
 }
 template <int ALGO, class T>
 __global__ __launch_bounds__(256) void mf_group_sample_kernel(const MfParams<T> *__restrict__ table) {
@@ -1026,7 +1198,8 @@ __global__ __launch_bounds__(256, 8) void mf_group_batch_kernel_occ8(const MfPar
     // the grid covers a third of a mini-batch's header slots; with fused / paired tasks fewer than that are in use as a rule
     // (the in-LDS schedule files the count), and a workgroup that finds more walks on: no wavefront is launched for an empty slot
     const int used = p.used ? p.used[batch_local] : p.tasks_per_batch;
-    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg);
+    int unused = 0;
+    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg, unused);
 }
 
 // Any k (odd k, k > 64 lanes x 2 chunks): one task per wavefront, one sample at a time, rows re-read for the update.
@@ -1399,7 +1572,9 @@ struct mi355rec_mf {
     DeviceBuffer<unsigned char> spar, cub_tmp;
     DeviceBuffer<TaskHeader> tasks;
     DeviceBuffer<unsigned> touched;         // fast schedule: (row, mini-batch) bitmap
-    DeviceBuffer<int> sorted_slot, qtask, used;
+    DeviceBuffer<int> sorted_slot, qtask, used, wide;
+    DeviceBuffer<int> flow_ver, flow_rd, flow_state, flow_units;      // dataflow epoch: row versions, arrival counters, queue / abort / watermark, unit table
+    int flow_grid = 0;                // workgroups of the dataflow kernel that fit the device
     bool fast_schedule = false;
     DeviceBuffer<unsigned long long> ticks;
     DeviceBuffer<int4> recs;
@@ -1418,25 +1593,10 @@ struct mi355rec_mf {
     hipGraphExec_t epoch_graph = nullptr;   // one native epoch: sampler, schedule, n_batches mini-batch kernels
     bool graph_failed = false;
     std::vector<double> host_loss;
-    // Overlapped epochs (MI355REC_MF_OVERLAP=1, see enqueue_epoch_chain): a second set of the buffers a schedule hands to the
-    // mini-batch kernels, so that epoch e + 1 is sampled and scheduled on `side` while the mini-batches of epoch e run on `stream`.
-    DeviceBuffer<int> su2, si2, sj2, used2;
-    DeviceBuffer<float> sr2;
-    DeviceBuffer<TaskHeader> tasks2;
-    DeviceBuffer<int4> recs2;
-    hipStream_t side = nullptr;
-    std::vector<hipEvent_t> chain_events;
-    hipGraphExec_t chain_graph = nullptr;   // OVERLAP_CHAIN epochs
-    bool chain_graph_failed = false;
-    int last_set = 0;                       // which set holds the samples of the last epoch run
 
     ~mi355rec_mf() {
         if (stream) (void)hipStreamSynchronize(stream);
-        if (side) (void)hipStreamSynchronize(side);
         if (epoch_graph) (void)hipGraphExecDestroy(epoch_graph);
-        if (chain_graph) (void)hipGraphExecDestroy(chain_graph);
-        for (hipEvent_t e : chain_events) (void)hipEventDestroy(e);
-        if (side) (void)hipStreamDestroy(side);
         timer.destroy();
         dispatch_timers.destroy();
         if (stream) (void)hipStreamDestroy(stream);
@@ -1497,6 +1657,9 @@ void fill_params(mi355rec_mf *h, MfParams<T> &p) {
     p.ticks = h->ticks.ptr;
     p.wg_base = 0;
     p.wg_stride = 1;
+    p.ver = h->flow_ver.ptr; p.rd = h->flow_rd.ptr; p.flow = h->flow_state.ptr;
+    p.unit_base = h->flow_units.ptr; p.wide = h->wide.ptr;
+    p.n_batches = 0;
 }
 
 // ---- kernel selection -------------------------------------------------------------------------------------------------
@@ -1620,7 +1783,7 @@ FastSchedParams fast_sched_params(mi355rec_mf *h, long long n_samples) {
     f.group = samples_in_flight(h);
     f.su = h->su.ptr; f.si = h->si.ptr; f.sj = h->sj.ptr; f.sr = h->sr.ptr;
     f.touched = h->touched.ptr; f.par = h->par.ptr;
-    f.sorted_slot = h->sorted_slot.ptr; f.qtask = h->qtask.ptr; f.used = h->used.ptr;
+    f.sorted_slot = h->sorted_slot.ptr; f.qtask = h->qtask.ptr; f.used = h->used.ptr; f.wide = h->wide.ptr;
     f.tasks = h->tasks.ptr; f.recs = h->recs.ptr;
     // fused sample tasks: BPR only; not in the exact multi-GPU mode, whose exchange slabs hold one row per task slot
     f.fuse = h->cfg.algorithm == MI355REC_MF_BPR && h->shard_rank < 0 && !getenv("MI355REC_MF_NO_FUSE");
@@ -1685,9 +1848,58 @@ void enqueue_schedule(mi355rec_mf *h, long long n_samples, long long n_batches) 
     hipLaunchKernelGGL(mf_recs_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, sp);
 }
 
+// The dataflow epoch replaces the chain of dependent mini-batch launches (one launch boundary + three dependent round trips each:
+// 4.5 us per mini-batch of 3 MB) where it applies: BPR on the in-LDS schedule, outside the exact multi-GPU mode.
+bool flow_applies(const mi355rec_mf *h, long long n_batches) {
+    return h->cfg.algorithm == MI355REC_MF_BPR && h->fast_schedule && fast_schedule_fits(h, n_batches) && h->shard_rank < 0 &&
+           kernel_class(h) >= 0 && !h->ticks.ptr && !getenv("MI355REC_MF_NO_FLOW");
+}
+
+// grid == 0: only ask how many workgroups of the instance fit the device (outside any stream capture)
+template <class T, int VEC, int LPR, int KI>
+int launch_flow_as(mi355rec_mf *h, const MfParams<T> &p, int grid, hipEvent_t e0, hipEvent_t e1) {
+    auto kernel = mf_flow_kernel<MI355REC_MF_BPR, T, VEC, LPR, KI>;
+    if (grid == 0) {
+        int per_cu = 0;
+        MI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0));
+        return multiprocessor_count() * std::max(1, std::min(per_cu, 8));
+    }
+    if (e0) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p);
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, h->stream, p);       // capturable
+    return grid;
+}
+template <class T>
+int launch_flow(mi355rec_mf *h, const MfParams<T> &p, int grid, hipEvent_t e0, hipEvent_t e1) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    switch (kernel_class(h)) {
+        case 0: return launch_flow_as<T, VEC, 16, 1>(h, p, grid, e0, e1);
+        case 1: return launch_flow_as<T, VEC, 32, 1>(h, p, grid, e0, e1);
+        case 2: return launch_flow_as<T, VEC, 64, 1>(h, p, grid, e0, e1);
+        default: return launch_flow_as<T, VEC, 64, 2>(h, p, grid, e0, e1);
+    }
+}
+
+template <class T>
+void enqueue_flow(mi355rec_mf *h, MfParams<T> p, long long n_batches, bool timed) {
+    hipStream_t s = h->stream;
+    p.n_batches = (int)n_batches;
+    MI_HIP(hipMemsetAsync(h->flow_ver.ptr, 0, sizeof(int) * h->flow_ver.count, s));
+    MI_HIP(hipMemsetAsync(h->flow_rd.ptr, 0, sizeof(int) * (size_t)n_batches * RD_SHARDS, s));
+    MI_HIP(hipMemsetAsync(h->flow_state.ptr, 0, sizeof(int) * 4, s));
+    hipLaunchKernelGGL(mf_flow_units_kernel, dim3(1), dim3(256), 0, s, h->used.ptr, h->wide.ptr, (int)n_batches, h->flow_units.ptr);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) h->dispatch_timers.next(e0, e1, std::max(1, h->max_timed));
+    launch_flow(h, p, h->flow_grid, e0, e1);
+}
+
 template <class T>
 void enqueue_batches(mi355rec_mf *h, const MfParams<T> &p, long long n_batches, bool timed) {
     const bool bpr = h->cfg.algorithm == MI355REC_MF_BPR;
+    if (flow_applies(h, n_batches)) {
+        enqueue_flow(h, p, n_batches, timed);
+        hipLaunchKernelGGL(mf_stream_end_kernel<T>, dim3(1), dim3(64), 0, h->stream, p, n_batches);
+        return;
+    }
     for (long long b = 0; b < n_batches; ++b) {
         if (bpr) launch_batch<MI355REC_MF_BPR, T>(h, p, (int)b, timed);
         else launch_batch<MI355REC_MF_FUNK_SVD, T>(h, p, (int)b, timed);
@@ -1754,13 +1966,6 @@ void ensure_epoch_graph(mi355rec_mf *h, const MfParams<T> &p) {
     }
 }
 
-void drop_chain_graph(mi355rec_mf *h) {
-    if (h->chain_graph) {
-        (void)hipGraphExecDestroy(h->chain_graph);
-        h->chain_graph = nullptr;
-    }
-}
-
 void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batches) {
     const bool asy = h->cfg.algorithm == MI355REC_MF_ASY_SVD;
     if (h->stream_capacity < n_samples) {
@@ -1768,7 +1973,6 @@ void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batche
             (void)hipGraphExecDestroy(h->epoch_graph);
             h->epoch_graph = nullptr;
         }
-        drop_chain_graph(h);
         h->su.alloc(n_samples);
         h->si.alloc(n_samples);
         h->sj.alloc(n_samples);
@@ -1794,7 +1998,6 @@ void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batche
             (void)hipGraphExecDestroy(h->epoch_graph);
             h->epoch_graph = nullptr;
         }
-        drop_chain_graph(h);
         const size_t tpb = (size_t)per_sample(h) * h->cfg.batch_size;
         h->batch_count.alloc((size_t)n_batches);
         h->tasks.alloc((size_t)(n_batches + 1) * tpb);
@@ -1805,124 +2008,16 @@ void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batche
             h->sorted_slot.alloc((size_t)n_batches * tpb);
             h->qtask.alloc((size_t)n_batches * tpb);
             h->used.alloc((size_t)n_batches);
+            h->wide.alloc((size_t)n_batches);
+            if (!h->flow_ver.ptr) {
+                h->flow_ver.alloc_zero((size_t)h->n_users + h->n_items, h->stream);
+                h->flow_rd.alloc_zero((size_t)FAST_MAX_BATCHES * RD_SHARDS, h->stream);
+                h->flow_state.alloc_zero(4, h->stream);
+                h->flow_units.alloc_zero(FAST_MAX_BATCHES + 1, h->stream);
+            }
             if (!h->touched.ptr) h->touched.alloc_zero(((size_t)h->n_users + h->n_items) * (FAST_MAX_BATCHES / 32), h->stream);
         }
         h->batch_capacity = n_batches;
-    }
-}
-
-// ---- overlapped epochs (opt-in: MI355REC_MF_OVERLAP=1) ------------------------------------------------------------------------
-// The sample stream and therefore the whole schedule of an epoch do not depend on the factors, so epoch e + 1 can be sampled and
-// scheduled while the mini-batches of epoch e run.  What a schedule hands to the mini-batch kernels (samples, headers, records,
-// slot counts) exists twice; everything the schedule only uses itself (bitmap, sort output, `par`, MfState.epoch) exists once,
-// because the schedules still run one after the other -- on `side`.  Dependencies of a chain of n epochs:
-//     schedule(e + 1)  after  schedule(e)                  (stream order on `side`)
-//                      after  mini-batches(e - 1)          (they read the set it overwrites)
-//     mini-batches(e)  after  schedule(e), mini-batches(e - 1)
-// Every scheduled epoch of a chain is also run inside it, so `par` and MfState.epoch never run ahead of the factors.  Same kernels,
-// same data: the factors are those of the plain epoch loop bit for bit.
-constexpr int OVERLAP_CHAIN = 8;     // epochs per captured chain (7 of 8 schedules hidden)
-
-void ensure_chain_events(hipStream_t &side, std::vector<hipEvent_t> &events) {
-    if (!side) MI_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    if (events.empty()) {
-        events.assign(1 + 2 * OVERLAP_CHAIN, nullptr);
-        for (auto &e : events) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-}
-
-// the second set of stream / task buffers of one model (sizes follow the first set); true if it was (re-)allocated
-bool ensure_overlap_buffers(mi355rec_mf *h) {
-    if (h->su2.count == h->su.count && h->tasks2.count == h->tasks.count && h->used2.count == h->used.count) return false;
-    {
-        drop_chain_graph(h);
-        MI_HIP(hipStreamSynchronize(h->stream));
-        if (h->side) MI_HIP(hipStreamSynchronize(h->side));
-        h->su2.alloc(h->su.count); h->si2.alloc(h->si.count); h->sj2.alloc(h->sj.count); h->sr2.alloc(h->sr.count);
-        h->tasks2.alloc(h->tasks.count);
-        MI_HIP(hipMemsetAsync(h->tasks2.ptr, 0, sizeof(TaskHeader) * h->tasks.count, h->stream));
-        h->recs2.alloc(h->recs.count);
-        h->used2.alloc(h->used.count);
-        MI_HIP(hipStreamSynchronize(h->stream));
-    }
-    return true;
-}
-
-void ensure_overlap_resources(mi355rec_mf *h) {
-    ensure_chain_events(h->side, h->chain_events);
-    ensure_overlap_buffers(h);
-}
-
-// set 1's pointers in a model's kernel / schedule parameters
-template <class T>
-void use_second_set(const mi355rec_mf *h, MfParams<T> &p, FastSchedParams &f) {
-    p.su = h->su2.ptr; p.si = h->si2.ptr; p.sj = h->sj2.ptr; p.sr = h->sr2.ptr;
-    f.su = h->su2.ptr; f.si = h->si2.ptr; f.sj = h->sj2.ptr; f.sr = h->sr2.ptr;
-    p.tasks = h->tasks2.ptr; f.tasks = h->tasks2.ptr;
-    p.recs = h->recs2.ptr; f.recs = h->recs2.ptr;
-    p.used = h->used2.ptr; f.used = h->used2.ptr;
-}
-
-template <class T>
-void overlap_sets(mi355rec_mf *h, long long n_samples, MfParams<T> (&p)[2], FastSchedParams (&f)[2]) {
-    fill_params(h, p[0]);
-    f[0] = fast_sched_params(h, n_samples);
-    p[1] = p[0];
-    f[1] = f[0];
-    use_second_set(h, p[1], f[1]);
-}
-
-// n <= OVERLAP_CHAIN epochs; capturable (the event records / waits on capturing streams become the graph's edges; `side` is
-// forked from and joined back into the handle's stream).
-template <class T>
-void enqueue_epoch_chain(mi355rec_mf *h, const MfParams<T> (&p)[2], const FastSchedParams (&f)[2], int n) {
-    const long long nb = batches_per_epoch(h);
-    hipStream_t s1 = h->stream, s2 = h->side;
-    hipEvent_t *forked = &h->chain_events[0], *scheduled = &h->chain_events[1], *batches_done = &h->chain_events[1 + OVERLAP_CHAIN];
-    auto schedule = [&](int e) {
-        launch_sampler(h, p[e & 1], s2);
-        enqueue_fast_schedule(h, f[e & 1].n_samples, nb, &f[e & 1], s2);
-        MI_HIP(hipEventRecord(scheduled[e], s2));
-    };
-    MI_HIP(hipEventRecord(*forked, s1));
-    MI_HIP(hipStreamWaitEvent(s2, *forked, 0));
-    schedule(0);
-    for (int e = 0; e < n; ++e) {
-        if (e + 1 < n) {
-            if (e >= 1) {   // everything on s1 so far = the mini-batches up to epoch e - 1, the readers of the set epoch e + 1 overwrites
-                MI_HIP(hipEventRecord(batches_done[e], s1));
-                MI_HIP(hipStreamWaitEvent(s2, batches_done[e], 0));
-            }
-            schedule(e + 1);
-        }
-        MI_HIP(hipStreamWaitEvent(s1, scheduled[e], 0));      // (for e = n - 1 this is also the join of `side`)
-        enqueue_batches(h, p[e & 1], nb, false);
-    }
-}
-
-template <class T>
-void ensure_chain_graph(mi355rec_mf *h, const MfParams<T> (&p)[2], const FastSchedParams (&f)[2]) {
-    if (h->chain_graph || h->chain_graph_failed) return;
-    hipGraph_t g = nullptr;
-    hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
-    if (e == hipSuccess) {
-        try {
-            enqueue_epoch_chain(h, p, f, OVERLAP_CHAIN);
-        } catch (...) {
-            (void)hipStreamEndCapture(h->stream, &g);
-            if (g) (void)hipGraphDestroy(g);
-            (void)hipGetLastError();
-            h->chain_graph_failed = true;
-            return;
-        }
-        e = hipStreamEndCapture(h->stream, &g);
-    }
-    if (e == hipSuccess) e = hipGraphInstantiate(&h->chain_graph, g, nullptr, nullptr, 0);
-    if (g) (void)hipGraphDestroy(g);
-    if (e != hipSuccess) {       // plain launches remain correct
-        (void)hipGetLastError();
-        h->chain_graph = nullptr;
-        h->chain_graph_failed = true;
     }
 }
 
@@ -1943,7 +2038,10 @@ void finish_call(mi355rec_mf *h, long long n_samples, long long n_launches) {
     MI_HIP(hipGetLastError());
     h->host_loss.resize(h->loss_slots.count);
     h->loss_slots.download(h->host_loss.data(), h->loss_slots.count, h->stream);
+    int flow_state[4] = {0, 0, 0, 0};
+    if (h->flow_state.ptr) MI_HIP(hipMemcpyAsync(flow_state, h->flow_state.ptr, sizeof(flow_state), hipMemcpyDeviceToHost, h->stream));
     MI_HIP(hipStreamSynchronize(h->stream));
+    if (flow_state[1]) fail(MI355REC_E_HIP, "BPR-MF: a hand-off between tasks did not arrive (dataflow epoch aborted)");
     double loss = 0;
     for (double v : h->host_loss) loss += v;
     if (h->cfg.algorithm == MI355REC_MF_ASY_SVD) {
@@ -1998,48 +2096,28 @@ void run_epochs_typed(mi355rec_mf *h, int n_epochs) {
     ensure_stream_capacity(h, (size_t)(per_epoch * B), per_epoch);
     MfParams<T> p{};
     fill_params(h, p);
+    if (!h->flow_grid && flow_applies(h, per_epoch)) h->flow_grid = launch_flow(h, p, 0, nullptr, nullptr);
     begin_call(h);
     // epochs whose mini-batch launches carry timing events run as plain launches, the rest replays the graph
-    const long long timed_epochs = h->max_timed > 0 ? std::min<long long>(n_epochs, (h->max_timed + per_epoch - 1) / per_epoch) : 0;
+    // (the dataflow epoch is ONE launch: max_timed of them carry events)
+    const long long timed_epochs = h->max_timed > 0 ? std::min<long long>(n_epochs, flow_applies(h, per_epoch) ? h->max_timed : (h->max_timed + per_epoch - 1) / per_epoch) : 0;
     // MI355REC_NO_GRAPH=1: plain launches only (rocprofv3 on ROCm 7.2 crashes while tracing graph replays)
     bool use_graph = per_epoch <= MAX_GRAPH_BATCHES && n_epochs - timed_epochs > 0 && !getenv("MI355REC_NO_GRAPH") && !asy;
     if (use_graph) {
         ensure_epoch_graph(h, p);
         use_graph = h->epoch_graph != nullptr;
     }
-    // MI355REC_MF_OVERLAP=1: the untimed epochs run as chains whose schedules overlap the previous epoch's mini-batches
-    const bool overlap = getenv("MI355REC_MF_OVERLAP") && !asy && h->shard_rank < 0 && n_epochs - timed_epochs >= 2 &&
-                         h->fast_schedule && fast_schedule_fits(h, per_epoch);
-    if (const char *want = getenv("MI355REC_MF_OVERLAP"))      // "require": refuse instead of silently running the plain loop
-        MI_REQUIRE(overlap || strcmp(want, "require") != 0 || n_epochs - timed_epochs < 2,
-                   "MI355REC_MF_OVERLAP=require: this model does not run on the in-LDS schedule (ASY_SVD, more than %d mini-batches per epoch, "
-                   "more than %d rows per mini-batch, or inside an exact multi-GPU epoch)", FAST_MAX_BATCHES, FAST_MAX_SLOTS);
-    MfParams<T> po[2];
-    FastSchedParams fo[2];
-    if (overlap) {
-        ensure_overlap_resources(h);
-        overlap_sets<T>(h, per_epoch * B, po, fo);
-        if (use_graph && n_epochs - timed_epochs >= OVERLAP_CHAIN) ensure_chain_graph<T>(h, po, fo);
-    }
-    h->last_set = 0;
     h->timer.start(h->stream);
-    for (long long e = 0; e < n_epochs;) {
-        if (e < timed_epochs || !overlap) {
-            if (e < timed_epochs || !use_graph) enqueue_epoch(h, p, e < timed_epochs);
-            else MI_HIP(hipGraphLaunch(h->epoch_graph, h->stream));
-            ++e;
-            continue;
-        }
-        const int n = (int)std::min<long long>(OVERLAP_CHAIN, n_epochs - e);
-        if (n == OVERLAP_CHAIN && use_graph && h->chain_graph) MI_HIP(hipGraphLaunch(h->chain_graph, h->stream));
-        else enqueue_epoch_chain<T>(h, po, fo, n);
-        h->last_set = (n - 1) & 1;
-        e += n;
+    for (long long e = 0; e < n_epochs; ++e) {
+        if (e < timed_epochs || !use_graph) enqueue_epoch(h, p, e < timed_epochs);
+        else MI_HIP(hipGraphLaunch(h->epoch_graph, h->stream));
     }
     h->timer.stop(h->stream);
     h->batches_done += per_epoch * n_epochs;
     h->last_call_samples = n_epochs > 0 ? per_epoch * B : 0;
-    finish_call(h, per_epoch * n_epochs * B, asy ? n_epochs * ((per_epoch + ASY_CHUNK - 1) / ASY_CHUNK) : per_epoch * n_epochs);
+    // launches of the dominant kernel: one per mini-batch, or one per epoch where the dataflow epoch applies
+    const long long launches = asy ? n_epochs * ((per_epoch + ASY_CHUNK - 1) / ASY_CHUNK) : (flow_applies(h, per_epoch) ? n_epochs : per_epoch * n_epochs);
+    finish_call(h, per_epoch * n_epochs * B, launches);
 }
 
 template <class T>
@@ -2048,6 +2126,7 @@ void run_samples_typed(mi355rec_mf *h, int64_t n) {
     MfParams<T> p{};
     fill_params(h, p);
     const long long n_batches = (n + B - 1) / B;
+    if (!h->flow_grid && h->cfg.algorithm == MI355REC_MF_BPR && flow_applies(h, n_batches)) h->flow_grid = launch_flow(h, p, 0, nullptr, nullptr);
     begin_call(h);
     h->timer.start(h->stream);
     if (h->cfg.algorithm == MI355REC_MF_ASY_SVD) {
@@ -2061,7 +2140,7 @@ void run_samples_typed(mi355rec_mf *h, int64_t n) {
     enqueue_batches(h, p, n_batches, true);
     h->timer.stop(h->stream);
     h->batches_done += n_batches;
-    finish_call(h, n, n_batches);
+    finish_call(h, n, flow_applies(h, n_batches) ? 1 : n_batches);
 }
 
 // O = float (the float32 matrices north_star speaks of) or double (what the reference's getters return, .pyx:685-702: exact when
@@ -2181,7 +2260,6 @@ extern "C" int mi355rec_mf_run_samples(mi355rec_mf_t h, const int32_t *u, const 
         if (bpr) MI_HIP(hipMemcpyAsync(h->sj.ptr, j, sizeof(int) * n, hipMemcpyHostToDevice, s));
         else MI_HIP(hipMemcpyAsync(h->sr.ptr, rating, sizeof(float) * n, hipMemcpyHostToDevice, s));
         h->last_call_samples = 0;
-        h->last_set = 0;
         if (h->f64) run_samples_typed<double>(h, n); else run_samples_typed<float>(h, n);
     });
 }
@@ -2236,7 +2314,6 @@ void shard_end_typed(mi355rec_mf *h) {
     h->timer.stop(h->stream);
     h->batches_done += per_epoch;
     h->last_call_samples = per_epoch * B;
-    h->last_set = 0;
     finish_call(h, per_epoch * B, per_epoch);               // (the loss is this rank's share)
 }
 
@@ -2329,23 +2406,10 @@ struct mi355rec_mf_group {
     hipGraphExec_t graph = nullptr;
     bool graph_failed = false;
     mi355rec_stats stats{};
-    // overlapped epochs (MI355REC_MF_OVERLAP=1): the members' second buffer sets in a second pair of tables, schedules on `side`
-    DeviceBuffer<unsigned char> table2;
-    std::vector<unsigned char> host_table2;
-    DeviceBuffer<FastSchedParams> sched_table2;
-    std::vector<FastSchedParams> host_sched_table2;
-    hipStream_t side = nullptr;
-    std::vector<hipEvent_t> chain_events;
-    hipGraphExec_t chain_graph = nullptr;
-    bool chain_graph_failed = false;
 
     ~mi355rec_mf_group() {
         if (stream) (void)hipStreamSynchronize(stream);
-        if (side) (void)hipStreamSynchronize(side);
         if (graph) (void)hipGraphExecDestroy(graph);
-        if (chain_graph) (void)hipGraphExecDestroy(chain_graph);
-        for (hipEvent_t e : chain_events) (void)hipEventDestroy(e);
-        if (side) (void)hipStreamDestroy(side);
         timer.destroy();
         dispatch_timers.destroy();
         if (fork) (void)hipEventDestroy(fork);
@@ -2414,59 +2478,6 @@ void group_enqueue_epoch(mi355rec_mf_group *g, bool timed) {
     group_enqueue_batches<T>(g, reinterpret_cast<const MfParams<T> *>(g->table.ptr), timed);
 }
 
-// n <= OVERLAP_CHAIN epochs of all members with the schedules of epoch e + 1 on `side` (see enqueue_epoch_chain); capturable
-template <class T>
-void group_enqueue_epoch_chain(mi355rec_mf_group *g, int n) {
-    const MfParams<T> *table[2] = {reinterpret_cast<const MfParams<T> *>(g->table.ptr), reinterpret_cast<const MfParams<T> *>(g->table2.ptr)};
-    const FastSchedParams *sched[2] = {g->sched_table.ptr, g->sched_table2.ptr};
-    hipStream_t s1 = g->stream, s2 = g->side;
-    hipEvent_t *forked = &g->chain_events[0], *scheduled = &g->chain_events[1], *batches_done = &g->chain_events[1 + OVERLAP_CHAIN];
-    auto schedule = [&](int e) {
-        group_enqueue_schedule<T>(g, table[e & 1], sched[e & 1], s2);
-        MI_HIP(hipEventRecord(scheduled[e], s2));
-    };
-    MI_HIP(hipEventRecord(*forked, s1));
-    MI_HIP(hipStreamWaitEvent(s2, *forked, 0));
-    schedule(0);
-    for (int e = 0; e < n; ++e) {
-        if (e + 1 < n) {
-            if (e >= 1) {
-                MI_HIP(hipEventRecord(batches_done[e], s1));
-                MI_HIP(hipStreamWaitEvent(s2, batches_done[e], 0));
-            }
-            schedule(e + 1);
-        }
-        MI_HIP(hipStreamWaitEvent(s1, scheduled[e], 0));
-        group_enqueue_batches<T>(g, table[e & 1], false);
-    }
-}
-
-template <class T>
-void group_ensure_chain_graph(mi355rec_mf_group *g) {
-    if (g->chain_graph || g->chain_graph_failed) return;
-    hipGraph_t graph = nullptr;
-    hipError_t e = hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal);
-    if (e == hipSuccess) {
-        try {
-            group_enqueue_epoch_chain<T>(g, OVERLAP_CHAIN);
-        } catch (...) {
-            (void)hipStreamEndCapture(g->stream, &graph);
-            if (graph) (void)hipGraphDestroy(graph);
-            (void)hipGetLastError();
-            g->chain_graph_failed = true;
-            return;
-        }
-        e = hipStreamEndCapture(g->stream, &graph);
-    }
-    if (e == hipSuccess) e = hipGraphInstantiate(&g->chain_graph, graph, nullptr, nullptr, 0);
-    if (graph) (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        g->chain_graph = nullptr;
-        g->chain_graph_failed = true;
-    }
-}
-
 template <class T>
 void group_ensure_graph(mi355rec_mf_group *g) {
     if (g->graph || g->graph_failed) return;
@@ -2518,18 +2529,11 @@ void group_run_epochs_typed(mi355rec_mf_group *g, int n_epochs) {
     }
     const bool sched_changed = all_fast != g->all_fast || (all_fast && (g->host_sched_table.size() != sched.size() ||
                                memcmp(g->host_sched_table.data(), sched.data(), sizeof(FastSchedParams) * sched.size()) != 0));
-    auto drop_group_chain_graph = [&] {
-        if (g->chain_graph) {
-            (void)hipGraphExecDestroy(g->chain_graph);
-            g->chain_graph = nullptr;
-        }
-    };
     if (sched_changed) {
         if (g->graph) {
             (void)hipGraphExecDestroy(g->graph);
             g->graph = nullptr;
         }
-        drop_group_chain_graph();
         MI_HIP(hipStreamSynchronize(g->stream));
         g->all_fast = all_fast;
         g->host_sched_table = sched;
@@ -2543,7 +2547,6 @@ void group_run_epochs_typed(mi355rec_mf_group *g, int n_epochs) {
             (void)hipGraphExecDestroy(g->graph);
             g->graph = nullptr;
         }
-        drop_group_chain_graph();
         MI_HIP(hipStreamSynchronize(g->stream));
         if (g->table.count < table.size()) g->table.alloc(table.size());
         MI_HIP(hipMemcpy(g->table.ptr, table.data(), table.size(), hipMemcpyHostToDevice));
@@ -2556,52 +2559,10 @@ void group_run_epochs_typed(mi355rec_mf_group *g, int n_epochs) {
         group_ensure_graph<T>(g);
         use_graph = g->graph != nullptr;
     }
-    // MI355REC_MF_OVERLAP=1: untimed epochs as chains whose (group-wide) schedules overlap the previous epoch's launches
-    const bool overlap = getenv("MI355REC_MF_OVERLAP") && all_fast && n_epochs - timed_epochs >= 2;
-    if (const char *want = getenv("MI355REC_MF_OVERLAP"))
-        MI_REQUIRE(overlap || strcmp(want, "require") != 0 || n_epochs - timed_epochs < 2,
-                   "MI355REC_MF_OVERLAP=require: not every member of the group runs on the in-LDS schedule");
-    if (overlap) {
-        ensure_chain_events(g->side, g->chain_events);
-        std::vector<unsigned char> table2(table);
-        std::vector<FastSchedParams> sched2(sched);
-        for (int m = 0; m < R; ++m) {
-            mi355rec_mf *h = g->members[m];
-            ensure_overlap_buffers(h);
-            MfParams<T> p2;
-            memcpy(&p2, table2.data() + sizeof(MfParams<T>) * (size_t)m, sizeof(MfParams<T>));
-            use_second_set(h, p2, sched2[m]);
-            memcpy(table2.data() + sizeof(MfParams<T>) * (size_t)m, &p2, sizeof(MfParams<T>));
-        }
-        const bool changed = table2 != g->host_table2 || g->host_sched_table2.size() != sched2.size() ||
-                             memcmp(g->host_sched_table2.data(), sched2.data(), sizeof(FastSchedParams) * sched2.size()) != 0;
-        if (changed) {
-            drop_group_chain_graph();
-            MI_HIP(hipStreamSynchronize(g->stream));
-            MI_HIP(hipStreamSynchronize(g->side));
-            if (g->table2.count < table2.size()) g->table2.alloc(table2.size());
-            if (g->sched_table2.count < sched2.size()) g->sched_table2.alloc(sched2.size());
-            MI_HIP(hipMemcpy(g->table2.ptr, table2.data(), table2.size(), hipMemcpyHostToDevice));
-            MI_HIP(hipMemcpy(g->sched_table2.ptr, sched2.data(), sizeof(FastSchedParams) * sched2.size(), hipMemcpyHostToDevice));
-            g->host_table2 = table2;
-            g->host_sched_table2 = sched2;
-        }
-        if (use_graph && n_epochs - timed_epochs >= OVERLAP_CHAIN) group_ensure_chain_graph<T>(g);
-    }
-    int last_set = 0;
     g->timer.start(g->stream);
-    for (long long e = 0; e < n_epochs;) {
-        if (e < timed_epochs || !overlap) {
-            if (e < timed_epochs || !use_graph) group_enqueue_epoch<T>(g, e < timed_epochs);
-            else MI_HIP(hipGraphLaunch(g->graph, g->stream));
-            ++e;
-            continue;
-        }
-        const int n = (int)std::min<long long>(OVERLAP_CHAIN, n_epochs - e);
-        if (n == OVERLAP_CHAIN && use_graph && g->chain_graph) MI_HIP(hipGraphLaunch(g->chain_graph, g->stream));
-        else group_enqueue_epoch_chain<T>(g, n);
-        last_set = (n - 1) & 1;
-        e += n;
+    for (long long e = 0; e < n_epochs; ++e) {
+        if (e < timed_epochs || !use_graph) group_enqueue_epoch<T>(g, e < timed_epochs);
+        else MI_HIP(hipGraphLaunch(g->graph, g->stream));
     }
     g->timer.stop(g->stream);
     MI_HIP(hipGetLastError());
@@ -2622,7 +2583,6 @@ void group_run_epochs_typed(mi355rec_mf_group *g, int n_epochs) {
         for (double v : h->host_loss) loss += v;
         h->batches_done += nb * n_epochs;
         h->last_call_samples = n_epochs > 0 ? nb * (long long)h->cfg.batch_size : 0;
-        h->last_set = last_set;
         h->stats = mi355rec_stats{};
         h->stats.call_ms = st.call_ms;
         h->stats.n_launches = st.n_launches;
@@ -2726,11 +2686,10 @@ extern "C" int mi355rec_mf_get_last_samples(mi355rec_mf_t h, int32_t *u, int32_t
         *n = h->last_call_samples;
         const size_t m = (size_t)std::min<long long>(cap, h->last_call_samples);
         hipStream_t s = h->stream;
-        const bool second = h->last_set == 1;       // (overlapped epochs alternate between two sets of stream buffers)
-        if (u) (second ? h->su2 : h->su).download(u, m, s);
-        if (i) (second ? h->si2 : h->si).download(i, m, s);
-        if (j && h->cfg.algorithm == MI355REC_MF_BPR) (second ? h->sj2 : h->sj).download(j, m, s);
-        if (rating && h->cfg.algorithm != MI355REC_MF_BPR) (second ? h->sr2 : h->sr).download(rating, m, s);
+        if (u) h->su.download(u, m, s);
+        if (i) h->si.download(i, m, s);
+        if (j && h->cfg.algorithm == MI355REC_MF_BPR) h->sj.download(j, m, s);
+        if (rating && h->cfg.algorithm != MI355REC_MF_BPR) h->sr.download(rating, m, s);
         MI_HIP(hipStreamSynchronize(s));
     });
 }

@@ -47,7 +47,6 @@ constexpr int FLOW_THREADS = 1024;                    // 16 wavefronts: the turn
 constexpr int FLOW_WAVES = FLOW_THREADS / 64;
 constexpr int FLOW_REGS = 4;                          // profile entries per lane whose cells stay in registers between the passes
 constexpr int MAX_OWNERS = 192;
-constexpr unsigned NO_CELL = 0xFFFFFFFFu;             // (the diagonal is read but never written: it orders nothing)
 constexpr long long SPIN_LIMIT_TICKS = 500000000ll;   // 5 s of the 100 MHz wall clock: a stuck hand-off aborts instead of hanging
 constexpr unsigned long long MAIL_EMPTY = ~0ull;
 
@@ -89,6 +88,7 @@ struct SlimParams {
     long long epoch;                // RNG counter base
     long long steps_before;         // steps executed before this call (Adam's beta^t, .pyx:313-317)
     int n_steps;
+    int turn_sleep;                 // owned rows: wavefronts waiting for their turn sleep and are woken by the one that releases it
     unsigned tag_base;              // symmetric: step t of this call writes tag tag_base + t + 1
     // dense store, owned rows
     const int *hot_rank;            // [n_items] owner of the item's row, -1: nobody (the row stays in HBM)
@@ -201,6 +201,8 @@ struct DepParams {
     const long long *cellptr;
     int *pred;
     long long n_cells;
+    int step_bits;                  // cell pass: key = cell << step_bits | step (the radix sort walks as few bits as the stream needs)
+    unsigned no_cell;               // the diagonal's stand-in: all ones in the cell field (it is read but never written: it orders nothing)
     // owned rows of the dense store
     int *run_start;                 // [n_items] first position of the item's run in the sorted pairs
     unsigned *item_cnt;             // [n_items] steps of the stream on the item (0: memset)
@@ -302,11 +304,11 @@ __global__ __launch_bounds__(256) void slim_cell_keys_kernel(const DepParams d) 
     for (int idx = lane; idx < L; idx += 64) {
         const int s = d.indices[rs + idx];
         // (packed lower triangle, as packed_cell: fits 32 bits up to 92 681 items)
-        const unsigned ci = s == i ? NO_CELL : (unsigned)packed_cell(i, s);
-        const unsigned cj = s == j ? NO_CELL : (unsigned)packed_cell(j, s);
-        d.keys[cp + 2 * idx] = ((unsigned long long)ci << 32) | (unsigned)t;
+        const unsigned ci = s == i ? d.no_cell : (unsigned)packed_cell(i, s);
+        const unsigned cj = s == j ? d.no_cell : (unsigned)packed_cell(j, s);
+        d.keys[cp + 2 * idx] = ((unsigned long long)ci << d.step_bits) | (unsigned)t;
         d.vals[cp + 2 * idx] = (int)(cp + 2 * idx);
-        d.keys[cp + 2 * idx + 1] = ((unsigned long long)cj << 32) | (unsigned)t;
+        d.keys[cp + 2 * idx + 1] = ((unsigned long long)cj << d.step_bits) | (unsigned)t;
         d.vals[cp + 2 * idx + 1] = (int)(cp + 2 * idx + 1);
     }
 }
@@ -315,11 +317,11 @@ __global__ __launch_bounds__(256) void slim_pred_kernel(const DepParams d) {
     const long long q = blockIdx.x * 256ll + threadIdx.x;
     if (q >= d.n_cells) return;
     const unsigned long long key = d.keys_sorted[q];
-    const unsigned cell = (unsigned)(key >> 32);
+    const unsigned cell = (unsigned)(key >> d.step_bits);
     int pred = -1;
-    if (q > 0 && cell != NO_CELL) {
+    if (q > 0 && cell != d.no_cell) {
         const unsigned long long before = d.keys_sorted[q - 1];
-        if ((unsigned)(before >> 32) == cell) pred = (int)(before & 0xFFFFFFFFull);
+        if ((unsigned)(before >> d.step_bits) == cell) pred = (int)(before & ((1ull << d.step_bits) - 1ull));
     }
     d.pred[d.vals_sorted[q]] = pred;
 }
@@ -565,7 +567,7 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
     const int item = p.hot_item[h], first = p.lst_begin[h], len = p.lst_len[h];
     const size_t n = (size_t)p.n_items;
     const float lr = (float)p.lr, li_reg = (float)p.li_reg, lj_reg = (float)p.lj_reg;
-    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = wave; k < len; k += FLOW_WAVES) {
         const unsigned long long k0 = p.prof ? shader_clock() : 0ull;
         const StepDesc e = p.own_desc[first + k];
@@ -633,8 +635,10 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
         {
             SpinGuard sg;
             unsigned spins = 0;
-            while (__builtin_amdgcn_readfirstlane(*turn) != k)
+            while (__builtin_amdgcn_readfirstlane(*turn) != k) {
+                if (p.turn_sleep) __builtin_amdgcn_s_sleep(4);          // (256 cycles at most: s_wakeup below ends it early)
                 if ((++spins & 1023u) == 0 && give_up(p, sg)) return;
+            }
         }
         __builtin_amdgcn_s_setprio(3);
         asm volatile("" ::: "memory");
@@ -645,6 +649,7 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
             if (64 * r < L) xr += lane + 64 * r < L ? (double)row[id_of(r)] : 0.0;
         for (int idx = lane + 64 * OWN_IDS; idx < L; idx += 64) xr += (double)row[p.indices[rs + idx]];      // (0.7 % of the ML-20M users)
         xr = wave_sum(xr);
+        const unsigned long long k3a = p.prof ? shader_clock() : 0ull;
         double g, x = 0.0;
         if (!mail) {
             x = role ? xo - xr : xr - xo;                             // x_uij = sum over S[i, .] - sum over S[j, .]
@@ -661,6 +666,7 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
         double c1 = oc[0], c2 = oc[1];
         const double gr = hot_adapt(p, g, pw1, pw2, c1, c2);
         if (lane == 0) { oc[0] = c1; oc[1] = c2; }
+        const unsigned long long k3b = p.prof ? shader_clock() : 0ull;
         // (the row's cells are float32: their update in float32 arithmetic adds ~1e-7 of the INCREMENT to the rounding of the sum)
         const float reg = role ? lj_reg : li_reg, grf = (float)gr;
 #pragma unroll
@@ -676,6 +682,7 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the row's new cells are in LDS before the next wavefront is let in
         if (lane == 0) *turn = k + 1;
+        if (p.turn_sleep) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
         __builtin_amdgcn_s_setprio(0);
         const unsigned long long k4 = p.prof ? shader_clock() : 0ull;
         // ---- after the turn: the other row moves, its ticket is passed on -------------------------------------------------------
@@ -728,11 +735,12 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
         if (lane == 0 && !(mail && role)) atomicAdd(&p.loss_slots[t & (LOSS_SLOTS - 1)], x * x);
         if (p.prof) {
             acc[0] += 1; acc[1] += k1 - k0; acc[2] += k2 - k1; acc[3] += k3 - k2; acc[4] += k4 - k3; acc[5] += shader_clock() - k4;
+            acc[6] += k3a - k3; acc[7] += k3b - k3a;
         }
     }
     if (p.prof && lane == 0) {       // entries | descriptor + ticket wait | gather + sum | wait for the turn | the turn | other row's write-back
         unsigned long long *o = p.prof + 8 * h;
-        for (int c = 0; c < 6; ++c) atomicAdd(&o[c], acc[c]);
+        for (int c = 0; c < 8; ++c) atomicAdd(&o[c], acc[c]);
     }
 }
 
@@ -1300,6 +1308,11 @@ struct mi355rec_slim {
 
 namespace {
 
+int env_int(const char *name, int fallback) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : fallback;
+}
+
 template <class T>
 void fill_params(mi355rec_slim *h, SlimParams<T> &p) {
     const auto &c = h->cfg;
@@ -1320,6 +1333,7 @@ void fill_params(mi355rec_slim *h, SlimParams<T> &p) {
     p.steps_before = h->steps_done;
     p.n_steps = 0;
     p.tag_base = h->tag_base;
+    p.turn_sleep = env_int("MI355REC_SLIM_TURN_SLEEP", 0);
     p.hot_rank = h->hot_rank.ptr;
     p.hot_item = h->hot_tables.ptr; p.lst_begin = h->hot_tables.ptr + MAX_OWNERS; p.lst_len = h->hot_tables.ptr + 2 * MAX_OWNERS;
     p.n_hot = h->counters.ptr; p.n_cold = h->counters.ptr + 1;
@@ -1371,11 +1385,6 @@ void sort_pairs(mi355rec_slim *h, size_t n, int end_bit) {
     ensure_tmp(h, bytes);
     bytes = h->cub_tmp.count;
     MI_HIP(rocprim::radix_sort_pairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr, h->vals_sorted.ptr, n, 0, end_bit, h->stream));
-}
-
-int env_int(const char *name, int fallback) {
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : fallback;
 }
 
 // Owned rows need a LEASE on compute units.  An owner's steps are static (its row's list), so every owner has to be resident
@@ -1469,8 +1478,11 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile, int first = 0) {
         d.keys = h->keys.ptr; d.vals = h->vals.ptr; d.keys_sorted = h->keys_sorted.ptr; d.vals_sorted = h->vals_sorted.ptr;
         d.pred = h->pred.ptr;
         d.n_cells = n_cells;
+        d.step_bits = bits_for((unsigned long long)n);
+        const int cell_bits = bits_for((unsigned long long)h->n_items * ((unsigned long long)h->n_items + 1) / 2 + 1);
+        d.no_cell = (unsigned)((1ull << cell_bits) - 1ull);
         hipLaunchKernelGGL(slim_cell_keys_kernel, dim3(div_up(n, 4)), dim3(256), 0, s, d);
-        sort_pairs(h, (size_t)n_cells, 64);
+        sort_pairs(h, (size_t)n_cells, cell_bits + d.step_bits);
         hipLaunchKernelGGL(slim_pred_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, s, d);
         hipLaunchKernelGGL(slim_desc_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d, 1);
         if constexpr (std::is_same<T, double>::value) {
@@ -1548,8 +1560,8 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile, int first = 0) {
             for (int o = 0; o < h->last_owners; o += std::max(1, h->last_owners / 8)) {
                 const unsigned long long *q = c.data() + 8 * o;
                 const double e = (double)std::max(1ull, q[0]);
-                fprintf(stderr, "[slim prof] owner %3d: %5llu entries, mean cycles: ticket %.0f, gather %.0f, wait for turn %.0f, turn %.0f, write-back %.0f\n",
-                        o, q[0], q[1] / e, q[2] / e, q[3] / e, q[4] / e, q[5] / e);
+                fprintf(stderr, "[slim prof] owner %3d: %5llu entries, mean cycles: ticket %.0f, gather %.0f, wait for turn %.0f, turn %.0f (row sum %.0f, sigmoid + optimiser %.0f, "
+                        "row update + release %.0f), write-back %.0f\n", o, q[0], q[1] / e, q[2] / e, q[3] / e, q[4] / e, q[6] / e, q[7] / e, (q[4] - q[6] - q[7]) / e, q[5] / e);
             }
             const unsigned long long *q = c.data() + 8 * MAX_OWNERS;
             fprintf(stderr, "[slim prof] cold: %llu steps, mean cycles: ids + tickets %.0f, gather .. tickets passed on %.0f\n", q[0],

@@ -36,6 +36,13 @@ if which in ("dense", "both"):
         run(False, "owners 64 on %d CUs" % cus, MI355REC_SLIM_OWNERS=64, MI355REC_SLIM_CUS=cus)
     for steps in (8, 48):
         run(False, "owners 128, rows with >= %d steps" % steps, MI355REC_SLIM_OWNER_MIN_STEPS=steps)
+if which == "turn":
+    run(False, "default + phase clocks", MI355REC_SLIM_PROF=1)
+    run(False, "default")
+    run(False, "waiters sleep + s_wakeup", MI355REC_SLIM_TURN_SLEEP=1)
+    run(False, "waiters sleep + clocks", MI355REC_SLIM_TURN_SLEEP=1, MI355REC_SLIM_PROF=1)
+    run(True, "default + phase clocks", MI355REC_SLIM_PROF=1)
+    run(True, "default")
 if which in ("symmetric", "both"):
     run(True, "default + phase clocks", MI355REC_SLIM_PROF=1)
     for wgs in (8, 16, 32, 64, 128, 256):

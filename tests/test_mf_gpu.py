@@ -401,71 +401,6 @@ def test_fused_sample_tasks_equal_one_task_per_row(gpu, mode, k, monkeypatch):
     assert ((ci == 1) & (cj == 1)).any() and ((ci > 1) & (cj == 1)).any() and ((ci > 1) | (cj > 1)).any()
 
 
-@pytest.mark.parametrize("algo,mode,graph", [("MF_BPR", "sgd", True), ("MF_BPR", "adagrad", True), ("FUNK_SVD", "adam", True),
-                                             ("MF_BPR", "sgd", False)])
-def test_overlapped_epoch_chains_equal_the_plain_epoch_loop(gpu, algo, mode, graph, monkeypatch):
-    """MI355REC_MF_OVERLAP=1: epoch e + 1 is sampled and scheduled on a second stream (second set of stream / task buffers) while the
-    mini-batches of epoch e run.  Same kernels on the same data: factors, loss and the last epoch's samples must equal the plain
-    loop's bit for bit -- for a captured chain of 8 plus a shorter direct one (11 epochs), for an even and an odd remainder, after
-    a second call, and without graphs."""
-    X = named_urm("ml1m", "real" if algo == "FUNK_SVD" else "binary", scale=0.3)
-    kw = dict(n_factors=32, algorithm_name=algo, batch_size=500 if algo == "FUNK_SVD" else 200, random_seed=23, sgd_mode=mode, learning_rate=0.02,
-              user_reg=0.01, item_reg=0.01, positive_reg=0.02, negative_reg=0.03, use_bias=(algo == "FUNK_SVD"),
-              negative_interactions_quota=0.3 if algo == "FUNK_SVD" else 0.0)
-    if not graph:
-        monkeypatch.setenv("MI355REC_NO_GRAPH", "1")
-    out = []
-    for overlapped in (False, True):
-        if overlapped:
-            monkeypatch.setenv("MI355REC_MF_OVERLAP", "require")     # (an error if the chains cannot be used for this model)
-        dev = MatrixFactorization_MI355X_Epoch(X, **kw)
-        snaps = []
-        for n in (11, 2, 5):
-            dev.epochIteration_Cython(n)
-            snaps.append((dev.get_USER_factors(), dev.get_ITEM_factors(), dev.last_epoch_samples(), dev.stats()["loss"]))
-        if algo == "FUNK_SVD":
-            snaps.append((dev.get_USER_bias(), dev.get_ITEM_bias(), (np.float32(dev.get_GLOBAL_bias()),), 0.0))
-        out.append(snaps)
-        dev.close()
-    for plain, over in zip(*out):
-        for a, b in zip(plain[2], over[2]):
-            np.testing.assert_array_equal(a, b)
-        np.testing.assert_array_equal(plain[0], over[0])
-        np.testing.assert_array_equal(plain[1], over[1])
-        assert plain[3] == over[3]
-
-
-def test_overlapped_group_chains_equal_the_plain_group_epochs(gpu, monkeypatch):
-    """The replica-batched launch with MI355REC_MF_OVERLAP: the group-wide sampler / schedule launches of epoch e + 1 on the group's
-    second stream, the members' second buffer sets in a second pair of tables.  Members as the plain group leaves them, bit for bit."""
-    X = named_urm("ml1m", "binary", scale=0.3)
-    kws = [dict(n_factors=64, algorithm_name="MF_BPR", batch_size=200, random_seed=50 + r, sgd_mode="sgd", learning_rate=0.01 * (r + 1),
-                positive_reg=0.01 * r, negative_reg=0.02) for r in range(3)]
-    out = []
-    for overlapped in (False, True):
-        if overlapped:
-            monkeypatch.setenv("MI355REC_MF_OVERLAP", "require")
-        members = [MatrixFactorization_MI355X_Epoch(X, **kw) for kw in kws]
-        group = MatrixFactorization_MI355X_Group(members)
-        snaps = []
-        for n in (10, 3):
-            group.epochIteration_Cython(n)
-            snaps.append([(m.get_USER_factors(), m.get_ITEM_factors(), m.last_epoch_samples(), m.stats()["loss"]) for m in members])
-        members[1].epochIteration_Cython(4)             # a member on its own afterwards (its own chains / plain loop)
-        snaps.append([(members[1].get_USER_factors(), members[1].get_ITEM_factors(), members[1].last_epoch_samples(), 0.0)])
-        out.append(snaps)
-        group.close()
-        for m in members:
-            m.close()
-    for plain, over in zip(*out):
-        for a, b in zip(plain, over):
-            for x, y in zip(a[2], b[2]):
-                np.testing.assert_array_equal(x, y)
-            np.testing.assert_array_equal(a[0], b[0])
-            np.testing.assert_array_equal(a[1], b[1])
-            assert a[3] == b[3]
-
-
 def _group_case(X, kws, epochs, exact=True):
     solo = [MatrixFactorization_MI355X_Epoch(X, **kw) for kw in kws]
     members = [MatrixFactorization_MI355X_Epoch(X, **kw) for kw in kws]
@@ -534,6 +469,33 @@ def test_group_at_headline_shape_and_rejections(gpu):
         MatrixFactorization_MI355X_Group([a, c])            # different kernel instance
     with pytest.raises(ValueError):
         MatrixFactorization_MI355X_Group([a, a])
+
+
+@pytest.mark.parametrize("mode,k,batch", [("sgd", 64, 200), ("adagrad", 32, 1000), ("sgd", 128, 1000), ("adam", 16, 50)])
+def test_dataflow_epoch_equals_the_launch_per_mini_batch_loop(gpu, monkeypatch, mode, k, batch):
+    """BPR on the in-LDS schedule runs an epoch as ONE persistent launch (mf_flow_kernel: tasks wait for row versions instead of
+    launch boundaries).  Same tasks, same arithmetic: factors, loss and sample stream are bit-identical to the chain of
+    mini-batch launches (MI355REC_MF_NO_FLOW=1), for native epochs (graph replays) and for a replayed stream."""
+    X = named_urm("ml1m", "binary", scale=0.5 if batch < 1000 else 1.0)
+    kw = dict(n_factors=k, algorithm_name="MF_BPR", batch_size=batch, random_seed=31, sgd_mode=mode, learning_rate=0.05,
+              user_reg=0.002, positive_reg=0.003, negative_reg=0.004)
+    got = []
+    for flow in (True, False):
+        if flow:
+            monkeypatch.delenv("MI355REC_MF_NO_FLOW", raising=False)
+        else:
+            monkeypatch.setenv("MI355REC_MF_NO_FLOW", "1")
+        dev = MatrixFactorization_MI355X_Epoch(X, **kw)
+        dev.epochIteration_Cython(7)
+        st = dev.stats()
+        n_batches = X.shape[0] // batch + 1
+        assert st["n_launches"] == (7 if flow else 7 * n_batches)
+        u, i, j = dev.last_epoch_samples()
+        dev.replay_samples(u[:5 * batch + 3], i[:5 * batch + 3], neg_item=j[:5 * batch + 3])
+        got.append((dev.get_USER_factors(), dev.get_ITEM_factors(), st["loss"], u, i, j))
+        dev.close()
+    for a, b in zip(got[0], got[1]):
+        np.testing.assert_array_equal(a, b)
 
 
 def test_asysvd_full_ml1m_shape_k64_replay(gpu):
