@@ -170,6 +170,11 @@ template <class T> __device__ __forceinline__ T grad_term(T scale, T x, T reg, T
     const T b = reg * w;
     return a - b;
 }
+// a * b + c in ONE rounding, spelled out: left to the backend, the sum of products of a dot product came out fused in one
+// instantiation of the mini-batch body and as packed multiply + packed add in another (4 of 72 480 cells one ulp apart between a
+// model trained alone and the same model inside a group)
+__device__ __forceinline__ float fused_add(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fused_add(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <class T> __device__ __forceinline__ T diff_of(T a, T b) {
 #pragma clang fp contract(off)
     return a - b;
@@ -698,7 +703,6 @@ __device__ __forceinline__ T global_bias_at(const MfParams<T> &p, long long gb, 
 // mini-batch that produced version v.  Every wait is a relaxed agent-scope poll with a budget: a hand-off that does not arrive
 // within FLOW_SPIN_TICKS raises the abort flag (flow[1]; nobody waits any more, the call fails) instead of hanging the device.
 constexpr int RD_SHARDS = 32;              // arrival counters per mini-batch (one address retires an atomic in ~13 ns)
-constexpr int UNIT_QUADS = 4;              // header quads (4 task slots, one workgroup pass each) per claimed unit; split lists: 1
 constexpr long long FLOW_SPIN_TICKS = 500000000ll;       // 5 s of the 100 MHz wall clock
 struct FlowSpin {
     unsigned polls = 0;
@@ -793,14 +797,27 @@ __device__ __forceinline__ Rows<T, VEC, KI, BPR> load_rows(const MfParams<T> &p,
 // KI chunks of VEC elements per lane, LPR lanes per row (64 / LPR samples of a task's list in flight per wavefront).
 // `wg` = this workgroup's index within the mini-batch's launch of ONE model (blockIdx.x; the group launch below puts the model
 // on blockIdx.y).
-template <int ALGO, class T, int VEC, int LPR, int KI, bool FLOW = false>
-__device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int batch_local, const int wg, int &wm_known) {
+// Barrier of the 4 wavefronts that share a header quad, for workgroups that run several quads side by side (the dataflow kernel):
+// an arrival counter in LDS that only ever grows; `gen` = barriers this wavefront has passed.
+__device__ __forceinline__ void quad_barrier(int *arrivals, int &gen, const int lane) {
+    ++gen;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wavefront's LDS stores are in place
+    if (lane == 0) atomicAdd(arrivals, 1);
+    while (__builtin_amdgcn_readfirstlane(*(volatile int *)arrivals) < 4 * gen) {}
+    asm volatile("" ::: "memory");
+}
+
+// QUADS header quads per workgroup (256 x QUADS threads): quad `wg + threadIdx.x / 256` is this wavefront's.
+template <int ALGO, class T, int VEC, int LPR, int KI, bool FLOW = false, int QUADS = 1>
+__device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int batch_local, const int wg, int &wm_known, int &quad_gen,
+                                              int *quad_arrivals = nullptr) {
     constexpr int G = 64 / LPR;
     constexpr bool BPR = ALGO == MI355REC_MF_BPR;
     using Ch = Chunk<T, VEC>;
     using R = Rows<T, VEC, KI, BPR>;
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((wg * p.wg_stride + p.wg_base) * 4 + (threadIdx.x >> 6));
+    const int qs = QUADS > 1 ? (int)(threadIdx.x >> 8) : 0;                  // quad slot of the workgroup
+    const int wv = __builtin_amdgcn_readfirstlane(((wg + qs) * p.wg_stride + p.wg_base) * 4 + (int)((threadIdx.x >> 6) & 3));
     const unsigned long long tk0 = p.ticks ? stamp() : 0ull;
     // every wave-uniform input is requested before the first one is waited for (scalar loads, one wait)
     // (unused task slots of a batch are zero: a header with no samples means there is nothing to do)
@@ -817,8 +834,8 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
     const int4 h0 = make_int4(hd[0], hd[1], hd[2], hd[3]), h1 = make_int4(hd[4], hd[5], hd[6], hd[7]);
     const bool active = (h0.y & LEN_MASK) != 0 && wv < p.tasks_per_batch;
     __shared__ T s_mu[4];
-    __shared__ T s_wide[4][LPR * KI * VEC];
-    __shared__ T s_wide_bias[4];
+    __shared__ T s_wide_all[QUADS][2][4][LPR * KI * VEC];      // (two sets: a quad's next split list may start before its last sum is read)
+    __shared__ T s_wide_bias_all[QUADS][2][4];
     T mu_term = (T)0;
     T mu_eff = (T)0;
     unsigned long long tk1 = 0, tk2 = 0, tk3 = 0;
@@ -882,7 +899,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
             for (int c = 0; c < KI; ++c)
 #pragma unroll
                 for (int e = 0; e < VEC; ++e)
-                    dot += BPR ? rows.A[c].v[e] * diff_of(rows.B[c].v[e], rows.C[c].v[e]) : rows.A[c].v[e] * rows.B[c].v[e];
+                    dot = fused_add(rows.A[c].v[e], BPR ? diff_of(rows.B[c].v[e], rows.C[c].v[e]) : rows.B[c].v[e], dot);
             dot = group_sum<LPR>(dot);
             if (p.ticks && it == 0) {
                 asm volatile("" ::"v"(dot));
@@ -954,6 +971,8 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
         }
         int pub_row[3] = {-1, -1, -1}, pub_ver[3] = {0, 0, 0};      // FLOW: rows this lane's group writes, and their new versions
         if (wide) {                      // the four quarters meet in LDS and are summed in quarter order by the first
+            T (*s_wide)[LPR * KI * VEC] = s_wide_all[qs][QUADS > 1 ? (quad_gen + 1) & 1 : 0];
+            T *s_wide_bias = s_wide_bias_all[qs][QUADS > 1 ? (quad_gen + 1) & 1 : 0];
             if (g == 0) {
 #pragma unroll
                 for (int c = 0; c < KI; ++c)
@@ -961,7 +980,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
                     for (int e = 0; e < VEC; ++e) s_wide[part][(c * VEC + e) * LPR + li] = acc[c].v[e];
                 if (li == 0) s_wide_bias[part] = bias_acc;
             }
-            __syncthreads();
+            if (QUADS > 1) quad_barrier(&quad_arrivals[qs], quad_gen, lane); else __syncthreads();
             if (part == 0 && g == 0) {
 #pragma unroll
                 for (int c = 0; c < KI; ++c)
@@ -1074,18 +1093,22 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
 
 template <int ALGO, class T, int VEC, int LPR, int KI>
 __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, const int batch_local) {
-    int unused = 0;
-    mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, blockIdx.x, unused);
+    int unused = 0, gen = 0;
+    mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, blockIdx.x, unused, gen);
 }
 
-// The dataflow epoch: ONE persistent launch for all mini-batches of the stream (BPR on the in-LDS schedule).  Units of task slots
-// are claimed in stream order (a split list = one header quad = one unit, so that no busy row's task queues behind another one;
-// the rest in fours), which is what makes the waits safe: whatever a claimed task waits for belongs to an earlier mini-batch and
-// is therefore claimed already, by a workgroup that only waits for still earlier ones.
-template <int ALGO, class T, int VEC, int LPR, int KI>
-__global__ __launch_bounds__(256) void mf_flow_kernel(const MfParams<T> p) {
+// The dataflow epoch: ONE persistent launch for all mini-batches of the stream (BPR on the in-LDS schedule).  A workgroup of
+// QUADS x 256 threads claims QUADS consecutive header quads at a time, in stream order, and runs them SIDE BY SIDE (one claim per
+// quad would need more atomics than one address sustains: 33 000 per epoch against 88 per microsecond; quads taken one after
+// the other read late, and every mini-batch's writes wait for the last reader of the mini-batch before).  Stream order is what
+// makes the waits safe: whatever a claimed task waits for belongs to an earlier mini-batch and is therefore claimed already, by
+// a workgroup that only waits for still earlier ones.
+template <int ALGO, class T, int VEC, int LPR, int KI, int QUADS>
+__global__ __launch_bounds__(256 * QUADS) void mf_flow_kernel(const MfParams<T> p) {
     __shared__ int s_unit;
-    int b_cur = 0, wm_known = 0;
+    __shared__ int s_quad_arrivals[QUADS];
+    int b_cur = 0, wm_known = 0, quad_gen = 0;
+    if (threadIdx.x < QUADS) s_quad_arrivals[threadIdx.x] = 0;
     const int total = p.unit_base[p.n_batches];
     for (;;) {
         if (threadIdx.x == 0)
@@ -1094,25 +1117,20 @@ __global__ __launch_bounds__(256) void mf_flow_kernel(const MfParams<T> p) {
         const int u = s_unit;
         if (u >= total) break;
         while (u >= p.unit_base[b_cur + 1]) ++b_cur;
-        const int local = u - p.unit_base[b_cur], n_wide = p.wide[b_cur], n_quads = (p.used[b_cur] + 3) >> 2;
-        if (local < n_wide) {
-            mf_batch_body<ALGO, T, VEC, LPR, KI, true>(p, b_cur, local, wm_known);
-        } else {
-            const int q0 = n_wide + UNIT_QUADS * (local - n_wide);
-            for (int q = q0; q < min(q0 + UNIT_QUADS, n_quads); ++q) mf_batch_body<ALGO, T, VEC, LPR, KI, true>(p, b_cur, q, wm_known);
-        }
+        // (a quad past the mini-batch's last one finds empty headers and idles)
+        mf_batch_body<ALGO, T, VEC, LPR, KI, true, QUADS>(p, b_cur, QUADS * (u - p.unit_base[b_cur]), wm_known, quad_gen, s_quad_arrivals);
         __syncthreads();
     }
 }
 // units per mini-batch -> first unit of every mini-batch (at most FAST_MAX_BATCHES of them: one block)
-__global__ __launch_bounds__(256) void mf_flow_units_kernel(const int *used, const int *wide, const int n_batches, int *unit_base) {
+__global__ __launch_bounds__(256) void mf_flow_units_kernel(const int *used, const int quads_per_unit, const int n_batches, int *unit_base) {
     typedef rocprim::block_scan<int, 256> Scan;
     __shared__ typename Scan::storage_type tmp;
     const int b = threadIdx.x;
     int units = 0;
     if (b < n_batches) {
-        const int n_quads = (used[b] + 3) >> 2, n_wide = wide[b];
-        units = n_wide + (max(n_quads - n_wide, 0) + UNIT_QUADS - 1) / UNIT_QUADS;
+        const int n_quads = (used[b] + 3) >> 2;
+        units = (n_quads + quads_per_unit - 1) / quads_per_unit;
     }
     int first = 0, total = 0;
     Scan().exclusive_scan(units, first, 0, total, tmp);
@@ -1152,8 +1170,8 @@ __global__ __launch_bounds__(256) void mf_group_batch_kernel(const MfParams<T> *
     // the grid covers a third of a mini-batch's header slots; with fused / paired tasks fewer than that are in use as a rule
     // (the in-LDS schedule files the count), and a workgroup that finds more walks on: no wavefront is launched for an empty slot
     const int used = p.used ? p.used[batch_local] : p.tasks_per_batch;
-    int unused = 0;
-    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg, unused);
+    int unused = 0, gen = 0;
+    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg, unused, gen);
 }
 // Sampler and schedule of every member in ONE launch each (model on the last grid dimension): as 4 x R small launches on R
 // streams they took a third of a 32-model epoch.
@@ -1198,8 +1216,8 @@ __global__ __launch_bounds__(256, 8) void mf_group_batch_kernel_occ8(const MfPar
     // the grid covers a third of a mini-batch's header slots; with fused / paired tasks fewer than that are in use as a rule
     // (the in-LDS schedule files the count), and a workgroup that finds more walks on: no wavefront is launched for an empty slot
     const int used = p.used ? p.used[batch_local] : p.tasks_per_batch;
-    int unused = 0;
-    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg, unused);
+    int unused = 0, gen = 0;
+    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg, unused, gen);
 }
 
 // Any k (odd k, k > 64 lanes x 2 chunks): one task per wavefront, one sample at a time, rows re-read for the update.
@@ -1856,16 +1874,21 @@ bool flow_applies(const mi355rec_mf *h, long long n_batches) {
 }
 
 // grid == 0: only ask how many workgroups of the instance fit the device (outside any stream capture)
+// quads a workgroup of the dataflow kernel runs side by side: 16 wavefronts leave 128 registers per lane (the float32 instances fit),
+// 8 wavefronts 256 (float64)
+template <class T> constexpr int flow_quads() { return sizeof(T) == 4 ? 4 : 2; }
+
 template <class T, int VEC, int LPR, int KI>
 int launch_flow_as(mi355rec_mf *h, const MfParams<T> &p, int grid, hipEvent_t e0, hipEvent_t e1) {
-    auto kernel = mf_flow_kernel<MI355REC_MF_BPR, T, VEC, LPR, KI>;
+    constexpr int Q = flow_quads<T>();
+    auto kernel = mf_flow_kernel<MI355REC_MF_BPR, T, VEC, LPR, KI, Q>;
     if (grid == 0) {
         int per_cu = 0;
-        MI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0));
-        return multiprocessor_count() * std::max(1, std::min(per_cu, 8));
+        MI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256 * Q, 0));
+        return multiprocessor_count() * std::max(1, std::min(per_cu, 8 / Q));
     }
-    if (e0) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p);
-    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, h->stream, p);       // capturable
+    if (e0) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256 * Q), 0, h->stream, e0, e1, 0, p);
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(256 * Q), 0, h->stream, p);       // capturable
     return grid;
 }
 template <class T>
@@ -1886,7 +1909,7 @@ void enqueue_flow(mi355rec_mf *h, MfParams<T> p, long long n_batches, bool timed
     MI_HIP(hipMemsetAsync(h->flow_ver.ptr, 0, sizeof(int) * h->flow_ver.count, s));
     MI_HIP(hipMemsetAsync(h->flow_rd.ptr, 0, sizeof(int) * (size_t)n_batches * RD_SHARDS, s));
     MI_HIP(hipMemsetAsync(h->flow_state.ptr, 0, sizeof(int) * 4, s));
-    hipLaunchKernelGGL(mf_flow_units_kernel, dim3(1), dim3(256), 0, s, h->used.ptr, h->wide.ptr, (int)n_batches, h->flow_units.ptr);
+    hipLaunchKernelGGL(mf_flow_units_kernel, dim3(1), dim3(256), 0, s, h->used.ptr, flow_quads<T>(), (int)n_batches, h->flow_units.ptr);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) h->dispatch_timers.next(e0, e1, std::max(1, h->max_timed));
     launch_flow(h, p, h->flow_grid, e0, e1);

@@ -88,7 +88,6 @@ struct SlimParams {
     long long epoch;                // RNG counter base
     long long steps_before;         // steps executed before this call (Adam's beta^t, .pyx:313-317)
     int n_steps;
-    int turn_sleep;                 // owned rows: wavefronts waiting for their turn sleep and are woken by the one that releases it
     unsigned tag_base;              // symmetric: step t of this call writes tag tag_base + t + 1
     // dense store, owned rows
     const int *hot_rank;            // [n_items] owner of the item's row, -1: nobody (the row stays in HBM)
@@ -635,19 +634,24 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
         {
             SpinGuard sg;
             unsigned spins = 0;
-            while (__builtin_amdgcn_readfirstlane(*turn) != k) {
-                if (p.turn_sleep) __builtin_amdgcn_s_sleep(4);          // (256 cycles at most: s_wakeup below ends it early)
+            while (__builtin_amdgcn_readfirstlane(*turn) != k)
                 if ((++spins & 1023u) == 0 && give_up(p, sg)) return;
-            }
         }
         __builtin_amdgcn_s_setprio(3);
         asm volatile("" ::: "memory");
         const unsigned long long k3 = p.prof ? shader_clock() : 0ull;
         double xr = 0.0;
+        float vr[FLOW_REGS];            // the cells of the first 256 entries stay in registers between the sum and the update
 #pragma unroll
-        for (int r = 0; r < OWN_IDS; ++r)
-            if (64 * r < L) xr += lane + 64 * r < L ? (double)row[id_of(r)] : 0.0;
-        for (int idx = lane + 64 * OWN_IDS; idx < L; idx += 64) xr += (double)row[p.indices[rs + idx]];      // (0.7 % of the ML-20M users)
+        for (int r = 0; r < FLOW_REGS; ++r) vr[r] = lane + 64 * r < L ? row[id_of(r)] : 0.f;
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) xr += (double)vr[r];
+        if (L > FLOW_BLOCK) {           // (14 % of the ML-20M users)
+#pragma unroll
+            for (int r = FLOW_REGS; r < OWN_IDS; ++r)
+                if (64 * r < L) xr += lane + 64 * r < L ? (double)row[id_of(r)] : 0.0;
+            for (int idx = lane + 64 * OWN_IDS; idx < L; idx += 64) xr += (double)row[p.indices[rs + idx]];      // (0.7 %)
+        }
         xr = wave_sum(xr);
         const unsigned long long k3a = p.prof ? shader_clock() : 0ull;
         double g, x = 0.0;
@@ -670,19 +674,25 @@ __device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, f
         // (the row's cells are float32: their update in float32 arithmetic adds ~1e-7 of the INCREMENT to the rounding of the sum)
         const float reg = role ? lj_reg : li_reg, grf = (float)gr;
 #pragma unroll
-        for (int r = 0; r < OWN_IDS; ++r) {
-            if (64 * r < L) {
-                const int s = id_of(r);
-                if (lane + 64 * r < L && s != item) row[s] = role ? cell_minus(row[s], lr, grf, reg) : cell_plus(row[s], lr, grf, reg);
-            }
+        for (int r = 0; r < FLOW_REGS; ++r) {
+            const int s = id_of(r);
+            if (lane + 64 * r < L && s != item) row[s] = role ? cell_minus(vr[r], lr, grf, reg) : cell_plus(vr[r], lr, grf, reg);
         }
-        for (int idx = lane + 64 * OWN_IDS; idx < L; idx += 64) {
-            const int s = p.indices[rs + idx];
-            if (s != item) row[s] = role ? cell_minus(row[s], lr, grf, reg) : cell_plus(row[s], lr, grf, reg);
+        if (L > FLOW_BLOCK) {
+#pragma unroll
+            for (int r = FLOW_REGS; r < OWN_IDS; ++r) {
+                if (64 * r < L) {
+                    const int s = id_of(r);
+                    if (lane + 64 * r < L && s != item) row[s] = role ? cell_minus(row[s], lr, grf, reg) : cell_plus(row[s], lr, grf, reg);
+                }
+            }
+            for (int idx = lane + 64 * OWN_IDS; idx < L; idx += 64) {
+                const int s = p.indices[rs + idx];
+                if (s != item) row[s] = role ? cell_minus(row[s], lr, grf, reg) : cell_plus(row[s], lr, grf, reg);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the row's new cells are in LDS before the next wavefront is let in
         if (lane == 0) *turn = k + 1;
-        if (p.turn_sleep) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
         __builtin_amdgcn_s_setprio(0);
         const unsigned long long k4 = p.prof ? shader_clock() : 0ull;
         // ---- after the turn: the other row moves, its ticket is passed on -------------------------------------------------------
@@ -1333,7 +1343,6 @@ void fill_params(mi355rec_slim *h, SlimParams<T> &p) {
     p.steps_before = h->steps_done;
     p.n_steps = 0;
     p.tag_base = h->tag_base;
-    p.turn_sleep = env_int("MI355REC_SLIM_TURN_SLEEP", 0);
     p.hot_rank = h->hot_rank.ptr;
     p.hot_item = h->hot_tables.ptr; p.lst_begin = h->hot_tables.ptr + MAX_OWNERS; p.lst_len = h->hot_tables.ptr + 2 * MAX_OWNERS;
     p.n_hot = h->counters.ptr; p.n_cold = h->counters.ptr + 1;

@@ -39,8 +39,7 @@ if which in ("dense", "both"):
 if which == "turn":
     run(False, "default + phase clocks", MI355REC_SLIM_PROF=1)
     run(False, "default")
-    run(False, "waiters sleep + s_wakeup", MI355REC_SLIM_TURN_SLEEP=1)
-    run(False, "waiters sleep + clocks", MI355REC_SLIM_TURN_SLEEP=1, MI355REC_SLIM_PROF=1)
+    run(False, "owners 64", MI355REC_SLIM_OWNERS=64)
     run(True, "default + phase clocks", MI355REC_SLIM_PROF=1)
     run(True, "default")
 if which in ("symmetric", "both"):
