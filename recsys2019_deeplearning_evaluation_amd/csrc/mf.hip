@@ -65,8 +65,6 @@ typedef int int8v __attribute__((ext_vector_type(8)));
 // record .w: bits 0-1 role of the task's row in this sample (0 user, 1 item / positive item, 2 negative item),
 //            bit 2 / 3 / 4: buffer of the sample's user / item / negative-item row
 //            bit 5 / 6 (user role, fast schedule): this task also updates the sample's positive / negative item row
-//            bits 8-15 / 16-23 / 24-31 (fast schedule): how many earlier mini-batches of the stream touch the sample's user /
-//            item / negative-item row = the version of that row the sample reads (the dataflow epoch waits for it)
 constexpr int ROLE_U = 0, ROLE_I = 1;   // 2: negative item
 
 template <class T> struct MuState { T mu, c1, c2, pad; };
@@ -109,13 +107,6 @@ struct MfParams {
     unsigned long long *ticks;           // optional [tasks_per_batch][8] shader-clock stamps of the last mini-batch (MI355REC_MF_TICKS=1)
     int wg_base, wg_stride;              // workgroup b of the launch is workgroup wg_base + b * wg_stride of the mini-batch (exact
                                          // multi-GPU mode: rank r of G runs workgroups r, r + G, ...; otherwise 0 and 1)
-    // dataflow epoch (mf_flow_kernel): one persistent launch runs every mini-batch of the stream
-    int *ver;                            // [n_users + n_items] versions of the row written in this stream so far
-    int *rd;                             // [n_batches][RD_SHARDS] tasks of the mini-batch that have finished READING
-    int *flow;                           // [0] next unit of the in-order queue, [1] abort flag, [2] mini-batches whose reads are all done
-    const int *unit_base;                // [n_batches + 1] first unit of every mini-batch
-    const int *wide;                     // [n_batches] header quads of the mini-batch that hold a split list (they lead its slots)
-    int n_batches;
 };
 
 __device__ __forceinline__ unsigned long long stamp() {   // shader clock; not reordered against memory operations
@@ -171,8 +162,8 @@ template <class T> __device__ __forceinline__ T grad_term(T scale, T x, T reg, T
     return a - b;
 }
 // a * b + c in ONE rounding, spelled out: left to the backend, the sum of products of a dot product came out fused in one
-// instantiation of the mini-batch body and as packed multiply + packed add in another (4 of 72 480 cells one ulp apart between a
-// model trained alone and the same model inside a group)
+// instantiation of the mini-batch body and as packed multiply + packed add in another (seen in round 4 between a model trained
+// alone and the same model inside a group, once the two were built from different instantiations: 4 of 72 480 cells one ulp apart)
 __device__ __forceinline__ float fused_add(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fused_add(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <class T> __device__ __forceinline__ T diff_of(T a, T b) {
@@ -377,7 +368,6 @@ struct FastSchedParams {
     int *sorted_slot;             // [n_batches][tasks_per_batch]: batch-local incidence ids in (row, id) order
     int *qtask;                   // per sorted position: batch-local slot of its task's (first) header | wide << 30
     int *used;                    // [n_batches]: header slots in use
-    int *wide;                    // [n_batches]: split lists of the mini-batch (4 leading header slots each)
     TaskHeader *tasks;
     int4 *recs;
 };
@@ -519,7 +509,7 @@ __device__ __forceinline__ void mf_sched_sort_body(const FastSchedParams &s, con
         }
     }
     const int used = 4 * n_wide + (total - n_wide - n_abs);
-    if (tid == 0) { s.used[b] = used; s.wide[b] = n_wide; }
+    if (tid == 0) s.used[b] = used;
     for (int slot = used + tid; slot < s.tasks_per_batch; slot += SCHED_THREADS)
         *reinterpret_cast<int4 *>(out + slot) = make_int4(0, 0, 0, 0);          // no samples: the slot's wavefront idles
     __syncthreads();
@@ -541,13 +531,12 @@ __device__ __forceinline__ void mf_sched_sort_body(const FastSchedParams &s, con
 }
 __global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const FastSchedParams s) { mf_sched_sort_body(s, blockIdx.x); }
 
-// mini-batches before b that touch the row = version of the row mini-batch b reads (version v lives in buffer (par + v) & 1)
-__device__ __forceinline__ int version_count(const FastSchedParams &s, int entry, int b) {
+__device__ __forceinline__ int version_parity(const FastSchedParams &s, int entry, int b) {
     const unsigned *w = s.touched + (size_t)entry * s.words;
     int cnt = 0;
     for (int k = 0; k < (b >> 5); ++k) cnt += __popc(w[k]);
     cnt += __popc(w[b >> 5] & ((1u << (b & 31)) - 1u));
-    return cnt;
+    return (s.par[entry] + cnt) & 1;
 }
 
 __device__ __forceinline__ void mf_sched_emit_body(const FastSchedParams &s) {
@@ -561,11 +550,9 @@ __device__ __forceinline__ void mf_sched_emit_body(const FastSchedParams &s) {
     const int smp = slot / s.per, role = slot - smp * s.per;
     const long long t = first + smp;
     const int u = s.su[t], i = s.si[t], j = s.per == 3 ? s.sj[t] : 0;
-    const int cu = version_count(s, u, b), ci = version_count(s, s.n_users + i, b);
-    const int cj = s.per == 3 ? version_count(s, s.n_users + j, b) : 0;
-    const int pu = (s.par[u] + cu) & 1, pi = (s.par[s.n_users + i] + ci) & 1, pj = s.per == 3 ? (s.par[s.n_users + j] + cj) & 1 : 0;
-    const int4 rec = make_int4(u, i, s.per == 3 ? j : __float_as_int(s.sr[t]),
-                               role | (pu << 2) | (pi << 3) | (pj << 4) | (also << 5) | (cu << 8) | (ci << 16) | (cj << 24));
+    const int pu = version_parity(s, u, b), pi = version_parity(s, s.n_users + i, b);
+    const int pj = s.per == 3 ? version_parity(s, s.n_users + j, b) : 0;
+    const int4 rec = make_int4(u, i, s.per == 3 ? j : __float_as_int(s.sr[t]), role | (pu << 2) | (pi << 3) | (pj << 4) | (also << 5));
     s.recs[at] = rec;
     const int tp = s.qtask[at];
     if (tp == SLOT_ABSORBED) return;
@@ -615,35 +602,12 @@ template <class T, int VEC> struct alignas(sizeof(T) * VEC) Chunk { T v[VEC]; };
 
 // Loads are issued unconditionally from clamped (always valid) addresses and masked afterwards: no branch sits between
 // two loads, so the compiler batches them under one wait.
-// FLOW (the dataflow epoch): rows written by another compute unit earlier in the same launch are read past the L1 and written
-// through (agent-scope atomics on the two 8-byte halves of a chunk: `global_load / global_store ... sc1`).
-template <class T, int VEC, bool FLOW = false>
+template <class T, int VEC>
 __device__ __forceinline__ Chunk<T, VEC> load_chunk(const T *row, int chunk, bool ok) {
-    Chunk<T, VEC> r;
-    if constexpr (FLOW) {
-        const unsigned long long *q = reinterpret_cast<const unsigned long long *>(row + (size_t)(ok ? chunk : 0) * VEC);
-        struct Halves { unsigned long long h[2]; } b;
-        b.h[0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b.h[1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r = __builtin_bit_cast(Chunk<T, VEC>, b);
-    } else {
-        r = *reinterpret_cast<const Chunk<T, VEC> *>(row + (size_t)(ok ? chunk : 0) * VEC);
-    }
+    Chunk<T, VEC> r = *reinterpret_cast<const Chunk<T, VEC> *>(row + (size_t)(ok ? chunk : 0) * VEC);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) r.v[e] = ok ? r.v[e] : (T)0;
     return r;
-}
-template <class T, int VEC, bool FLOW = false>
-__device__ __forceinline__ void store_chunk(T *at, const Chunk<T, VEC> &c) {
-    if constexpr (FLOW) {
-        struct Halves { unsigned long long h[2]; };
-        const Halves b = __builtin_bit_cast(Halves, c);
-        unsigned long long *q = reinterpret_cast<unsigned long long *>(at);
-        __hip_atomic_store(q, b.h[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(q + 1, b.h[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        *reinterpret_cast<Chunk<T, VEC> *>(at) = c;
-    }
 }
 
 // Adam's 1 - beta^t for the 1-based mini-batch index t
@@ -695,83 +659,13 @@ __device__ __forceinline__ T global_bias_at(const MfParams<T> &p, long long gb, 
     return global_bias_finish(p, global_bias_request(p, gb, lane), gb, writer, lane);
 }
 
-// ---- the dataflow epoch's waits ---------------------------------------------------------------------------------------------------
-// One persistent launch (mf_flow_kernel) runs every mini-batch of a stream: workgroups claim units of task slots in stream order
-// and a task waits for exactly what it depends on -- the VERSIONS of the rows its samples read (`ver`, raised by the task that
-// wrote the version after draining its write-through stores) and, before it writes, the end of all READS of earlier mini-batches
-// (`rd` + the watermark flow[2]): with two buffers per row, version v + 1 overwrites version v - 1, whose last readers sit in the
-// mini-batch that produced version v.  Every wait is a relaxed agent-scope poll with a budget: a hand-off that does not arrive
-// within FLOW_SPIN_TICKS raises the abort flag (flow[1]; nobody waits any more, the call fails) instead of hanging the device.
-constexpr int RD_SHARDS = 32;              // arrival counters per mini-batch (one address retires an atomic in ~13 ns)
-constexpr long long FLOW_SPIN_TICKS = 500000000ll;       // 5 s of the 100 MHz wall clock
-struct FlowSpin {
-    unsigned polls = 0;
-    long long t0 = 0;
-};
-template <class T>
-__device__ __forceinline__ bool flow_give_up(const MfParams<T> &p, FlowSpin &g) {      // wave-uniform answer
-    if ((++g.polls & 63u) != 0) return false;
-    int stop = __hip_atomic_load(&p.flow[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long now = wall_clock64();
-    if (g.t0 == 0) g.t0 = now;
-    else if (now - g.t0 > FLOW_SPIN_TICKS) { __hip_atomic_store(&p.flow[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); stop = 1; }
-    return __builtin_amdgcn_readfirstlane(stop) != 0;
-}
-// The versions of all rows of this wavefront's share of a task's list (positions base + it * step + g, it < n_mine / G): 21 samples
-// per round, one lane per (sample, row).  A row whose version is more than one step away is polled at leisure.
-template <class T, int G>
-__device__ __forceinline__ void flow_wait_rows(const MfParams<T> &p, const int start, const int len, const int base, const int step,
-                                               const int n_mine, const int lane) {
-    for (int first = 0; first < n_mine; first += 21) {
-        const int sidx = first + lane / 3, r = lane - 3 * (lane / 3);
-        const int idx = base + (sidx / G) * step + (sidx % G);
-        const bool live = lane < 63 && sidx < n_mine && idx < len;
-        const int4 rc = p.recs[start + (live ? idx : 0)];
-        const int entry = r == 0 ? rc.x : p.n_users + (r == 1 ? rc.y : rc.z);
-        const int cnt = (rc.w >> (8 + 8 * r)) & 255;
-        const bool need = live && cnt > 0;
-        FlowSpin sg;
-        for (;;) {
-            const int v = need ? __hip_atomic_load(&p.ver[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            const bool missing = need && v < cnt;
-            if (!__any(missing)) break;
-            if (__any(missing && cnt - v == 1)) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(16);
-            if (flow_give_up(p, sg)) break;
-        }
-    }
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-}
-// All mini-batches before b have finished reading (wm_known: the watermark as this wavefront last saw it).  Whoever finds the
-// watermark short of what it needs checks the next mini-batch's arrivals itself and moves the watermark on.
-template <class T>
-__device__ __forceinline__ void flow_wait_reads(const MfParams<T> &p, const int b, int &wm_known, const int lane) {
-    if (b <= wm_known) return;
-    FlowSpin sg;
-    for (;;) {
-        int wm = 0;
-        if (lane == 0) wm = __hip_atomic_load(&p.flow[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        wm = __builtin_amdgcn_readfirstlane(wm);
-        if (wm >= b) { wm_known = wm; return; }
-        float c = 0.f;
-        if (lane < RD_SHARDS) c = (float)__hip_atomic_load(&p.rd[wm * RD_SHARDS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c = wave_sum(c);
-        if ((int)c == p.used[wm]) {
-            if (lane == 0) atomicMax(&p.flow[2], wm + 1);
-            if (wm + 1 >= b) { wm_known = wm + 1; return; }
-            continue;
-        }
-        __builtin_amdgcn_s_sleep(1);
-        if (flow_give_up(p, sg)) return;
-    }
-}
-
 // the three rows of one sample, KI chunks of VEC elements per lane
 template <class T, int VEC, int KI, bool BPR> struct Rows {
     Chunk<T, VEC> A[KI], B[KI], C[BPR ? KI : 1];
     T bu, bi;
 };
 
-template <class T, int VEC, int LPR, int KI, bool BPR, bool FLOW = false>
+template <class T, int VEC, int LPR, int KI, bool BPR>
 __device__ __forceinline__ Rows<T, VEC, KI, BPR> load_rows(const MfParams<T> &p, const int4 rec, int li, const bool (&cok)[KI],
                                                            bool bias) {
     Rows<T, VEC, KI, BPR> r;
@@ -781,9 +675,9 @@ __device__ __forceinline__ Rows<T, VEC, KI, BPR> load_rows(const MfParams<T> &p,
     const T *Hj = ((rec.w >> 4) & 1 ? p.V1 : p.V0) + (size_t)(BPR ? rec.z : 0) * k;
 #pragma unroll
     for (int c = 0; c < KI; ++c) {
-        r.A[c] = load_chunk<T, VEC, FLOW>(Wu, c * LPR + li, cok[c]);
-        r.B[c] = load_chunk<T, VEC, FLOW>(Hi, c * LPR + li, cok[c]);
-        if (BPR) r.C[c] = load_chunk<T, VEC, FLOW>(Hj, c * LPR + li, cok[c]);
+        r.A[c] = load_chunk<T, VEC>(Wu, c * LPR + li, cok[c]);
+        r.B[c] = load_chunk<T, VEC>(Hi, c * LPR + li, cok[c]);
+        if (BPR) r.C[c] = load_chunk<T, VEC>(Hj, c * LPR + li, cok[c]);
     }
     r.bu = (T)0;
     r.bi = (T)0;
@@ -797,27 +691,14 @@ __device__ __forceinline__ Rows<T, VEC, KI, BPR> load_rows(const MfParams<T> &p,
 // KI chunks of VEC elements per lane, LPR lanes per row (64 / LPR samples of a task's list in flight per wavefront).
 // `wg` = this workgroup's index within the mini-batch's launch of ONE model (blockIdx.x; the group launch below puts the model
 // on blockIdx.y).
-// Barrier of the 4 wavefronts that share a header quad, for workgroups that run several quads side by side (the dataflow kernel):
-// an arrival counter in LDS that only ever grows; `gen` = barriers this wavefront has passed.
-__device__ __forceinline__ void quad_barrier(int *arrivals, int &gen, const int lane) {
-    ++gen;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wavefront's LDS stores are in place
-    if (lane == 0) atomicAdd(arrivals, 1);
-    while (__builtin_amdgcn_readfirstlane(*(volatile int *)arrivals) < 4 * gen) {}
-    asm volatile("" ::: "memory");
-}
-
-// QUADS header quads per workgroup (256 x QUADS threads): quad `wg + threadIdx.x / 256` is this wavefront's.
-template <int ALGO, class T, int VEC, int LPR, int KI, bool FLOW = false, int QUADS = 1>
-__device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int batch_local, const int wg, int &wm_known, int &quad_gen,
-                                              int *quad_arrivals = nullptr) {
+template <int ALGO, class T, int VEC, int LPR, int KI>
+__device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int batch_local, const int wg) {
     constexpr int G = 64 / LPR;
     constexpr bool BPR = ALGO == MI355REC_MF_BPR;
     using Ch = Chunk<T, VEC>;
     using R = Rows<T, VEC, KI, BPR>;
     const int lane = threadIdx.x & 63;
-    const int qs = QUADS > 1 ? (int)(threadIdx.x >> 8) : 0;                  // quad slot of the workgroup
-    const int wv = __builtin_amdgcn_readfirstlane(((wg + qs) * p.wg_stride + p.wg_base) * 4 + (int)((threadIdx.x >> 6) & 3));
+    const int wv = __builtin_amdgcn_readfirstlane((wg * p.wg_stride + p.wg_base) * 4 + (threadIdx.x >> 6));
     const unsigned long long tk0 = p.ticks ? stamp() : 0ull;
     // every wave-uniform input is requested before the first one is waited for (scalar loads, one wait)
     // (unused task slots of a batch are zero: a header with no samples means there is nothing to do)
@@ -834,8 +715,8 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
     const int4 h0 = make_int4(hd[0], hd[1], hd[2], hd[3]), h1 = make_int4(hd[4], hd[5], hd[6], hd[7]);
     const bool active = (h0.y & LEN_MASK) != 0 && wv < p.tasks_per_batch;
     __shared__ T s_mu[4];
-    __shared__ T s_wide_all[QUADS][2][4][LPR * KI * VEC];      // (two sets: a quad's next split list may start before its last sum is read)
-    __shared__ T s_wide_bias_all[QUADS][2][4];
+    __shared__ T s_wide[4][LPR * KI * VEC];
+    __shared__ T s_wide_bias[4];
     T mu_term = (T)0;
     T mu_eff = (T)0;
     unsigned long long tk1 = 0, tk2 = 0, tk3 = 0;
@@ -870,8 +751,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
         const int4 rec_first = rec;                // single-sample and pair tasks: THE record of this lane group
         int4 rec_n = rec;
         if (iters > 1) rec_n = p.recs[start + min(base + step + g, len - 1)];
-        if constexpr (FLOW) flow_wait_rows<T, G>(p, start, len, base, step, iters * G, lane);
-        R rows = load_rows<T, VEC, LPR, KI, BPR, FLOW>(p, rec, li, cok, bias);
+        R rows = load_rows<T, VEC, LPR, KI, BPR>(p, rec, li, cok, bias);
         if (bias) mu_eff = global_bias_finish(p, mu_req, gb, wv == 0, lane);               // folded behind the gathers just issued
         T pw1, pw2;
         adam_powers(p, gb + 1, pw1, pw2);
@@ -891,7 +771,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
             int4 rec_nn = rec_n;
             if (it + 2 < iters) rec_nn = p.recs[start + min(idx + 2 * step, len - 1)];
             R rows_n = rows;
-            if (it + 1 < iters) rows_n = load_rows<T, VEC, LPR, KI, BPR, FLOW>(p, rec_n, li, cok, bias);
+            if (it + 1 < iters) rows_n = load_rows<T, VEC, LPR, KI, BPR>(p, rec_n, li, cok, bias);
 
             const int role = rec.w & 3;
             T dot = (T)0;
@@ -965,14 +845,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
         // dependent memory round trip out of the tail of the wavefront
         if (li == 0 && loss != 0.0) atomicAdd(&p.loss_slots[wv * 4 + g], loss);
         if (p.ticks) tk3 = stamp();      // list done
-        if constexpr (FLOW) {            // every row this task reads is in registers: say so, then wait for the readers this task's stores could hurt
-            if (lane == 0) atomicAdd(&p.rd[batch_local * RD_SHARDS + (wv & (RD_SHARDS - 1))], 1);
-            flow_wait_reads(p, batch_local, wm_known, lane);
-        }
-        int pub_row[3] = {-1, -1, -1}, pub_ver[3] = {0, 0, 0};      // FLOW: rows this lane's group writes, and their new versions
         if (wide) {                      // the four quarters meet in LDS and are summed in quarter order by the first
-            T (*s_wide)[LPR * KI * VEC] = s_wide_all[qs][QUADS > 1 ? (quad_gen + 1) & 1 : 0];
-            T *s_wide_bias = s_wide_bias_all[qs][QUADS > 1 ? (quad_gen + 1) & 1 : 0];
             if (g == 0) {
 #pragma unroll
                 for (int c = 0; c < KI; ++c)
@@ -980,7 +853,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
                     for (int e = 0; e < VEC; ++e) s_wide[part][(c * VEC + e) * LPR + li] = acc[c].v[e];
                 if (li == 0) s_wide_bias[part] = bias_acc;
             }
-            if (QUADS > 1) quad_barrier(&quad_arrivals[qs], quad_gen, lane); else __syncthreads();
+            __syncthreads();
             if (part == 0 && g == 0) {
 #pragma unroll
                 for (int c = 0; c < KI; ++c)
@@ -1005,22 +878,17 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
                 if (!cok[c]) continue;
                 const size_t at = (size_t)(c * LPR + li) * VEC;
                 Ch m1, m2, out;
-                if (p.sgd_mode != MI355REC_SGD) m1 = load_chunk<T, VEC, FLOW>(c1 + at, 0, true);
-                if (p.sgd_mode == MI355REC_ADAM) m2 = load_chunk<T, VEC, FLOW>(c2 + at, 0, true);
+                if (p.sgd_mode != MI355REC_SGD) m1 = *reinterpret_cast<const Ch *>(c1 + at);
+                if (p.sgd_mode == MI355REC_ADAM) m2 = *reinterpret_cast<const Ch *>(c2 + at);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     const T gm = mean_of(acc[c].v[e], p.inv_batch);
                     const T step = adapt_cell(p, gm, m1.v[e], m2.v[e], pw1, pw2);
                     out.v[e] = moved(own[c].v[e], p.lr, step);
                 }
-                store_chunk<T, VEC, FLOW>(Wn + at, out);
-                if (p.sgd_mode != MI355REC_SGD) store_chunk<T, VEC, FLOW>(c1 + at, m1);
-                if (p.sgd_mode == MI355REC_ADAM) store_chunk<T, VEC, FLOW>(c2 + at, m2);
-            }
-            {
-                const int role = rec_first.w & 3;
-                pub_row[0] = own_entry;
-                pub_ver[0] = ((rec_first.w >> (8 + 8 * role)) & 255) + 1;
+                *reinterpret_cast<Ch *>(Wn + at) = out;
+                if (p.sgd_mode != MI355REC_SGD) *reinterpret_cast<Ch *>(c1 + at) = m1;
+                if (p.sgd_mode == MI355REC_ADAM) *reinterpret_cast<Ch *>(c2 + at) = m2;
             }
             if (bias && li == 0) {
                 T *bn = is_item ? (own_buf ? p.bi0 : p.bi1) : (own_buf ? p.bu0 : p.bu1);
@@ -1049,8 +917,8 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
                     if (!cok[c]) continue;
                     const size_t at = (size_t)(c * LPR + li) * VEC;
                     Ch m1, m2, out;
-                    if (p.sgd_mode != MI355REC_SGD) m1 = load_chunk<T, VEC, FLOW>(c1 + at, 0, true);
-                    if (p.sgd_mode == MI355REC_ADAM) m2 = load_chunk<T, VEC, FLOW>(c2 + at, 0, true);
+                    if (p.sgd_mode != MI355REC_SGD) m1 = *reinterpret_cast<const Ch *>(c1 + at);
+                    if (p.sgd_mode == MI355REC_ADAM) m2 = *reinterpret_cast<const Ch *>(c2 + at);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         const T a = rows.A[c].v[v], b = rows.B[c].v[v], cc = rows.C[c].v[v];
@@ -1059,20 +927,10 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
                         const T step = adapt_cell(p, gm, m1.v[v], m2.v[v], pw1, pw2);
                         out.v[v] = moved(e == 1 ? b : cc, p.lr, step);
                     }
-                    store_chunk<T, VEC, FLOW>(Wn + at, out);
-                    if (p.sgd_mode != MI355REC_SGD) store_chunk<T, VEC, FLOW>(c1 + at, m1);
-                    if (p.sgd_mode == MI355REC_ADAM) store_chunk<T, VEC, FLOW>(c2 + at, m2);
+                    *reinterpret_cast<Ch *>(Wn + at) = out;
+                    if (p.sgd_mode != MI355REC_SGD) *reinterpret_cast<Ch *>(c1 + at) = m1;
+                    if (p.sgd_mode == MI355REC_ADAM) *reinterpret_cast<Ch *>(c2 + at) = m2;
                 }
-                pub_row[e] = p.n_users + item;
-                pub_ver[e] = ((rec_first.w >> (8 + 8 * e)) & 255) + 1;
-            }
-        }
-        if constexpr (FLOW) {            // the new versions are in memory before anybody is told about them
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (li == 0) {
-#pragma unroll
-                for (int e = 0; e < 3; ++e)
-                    if (pub_row[e] >= 0) __hip_atomic_store(&p.ver[pub_row[e]], pub_ver[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1093,49 +951,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
 
 template <int ALGO, class T, int VEC, int LPR, int KI>
 __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, const int batch_local) {
-    int unused = 0, gen = 0;
-    mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, blockIdx.x, unused, gen);
-}
-
-// The dataflow epoch: ONE persistent launch for all mini-batches of the stream (BPR on the in-LDS schedule).  A workgroup of
-// QUADS x 256 threads claims QUADS consecutive header quads at a time, in stream order, and runs them SIDE BY SIDE (one claim per
-// quad would need more atomics than one address sustains: 33 000 per epoch against 88 per microsecond; quads taken one after
-// the other read late, and every mini-batch's writes wait for the last reader of the mini-batch before).  Stream order is what
-// makes the waits safe: whatever a claimed task waits for belongs to an earlier mini-batch and is therefore claimed already, by
-// a workgroup that only waits for still earlier ones.
-template <int ALGO, class T, int VEC, int LPR, int KI, int QUADS>
-__global__ __launch_bounds__(256 * QUADS) void mf_flow_kernel(const MfParams<T> p) {
-    __shared__ int s_unit;
-    __shared__ int s_quad_arrivals[QUADS];
-    int b_cur = 0, wm_known = 0, quad_gen = 0;
-    if (threadIdx.x < QUADS) s_quad_arrivals[threadIdx.x] = 0;
-    const int total = p.unit_base[p.n_batches];
-    for (;;) {
-        if (threadIdx.x == 0)
-            s_unit = __hip_atomic_load(&p.flow[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0x7fffffff : atomicAdd(&p.flow[0], 1);
-        __syncthreads();
-        const int u = s_unit;
-        if (u >= total) break;
-        while (u >= p.unit_base[b_cur + 1]) ++b_cur;
-        // (a quad past the mini-batch's last one finds empty headers and idles)
-        mf_batch_body<ALGO, T, VEC, LPR, KI, true, QUADS>(p, b_cur, QUADS * (u - p.unit_base[b_cur]), wm_known, quad_gen, s_quad_arrivals);
-        __syncthreads();
-    }
-}
-// units per mini-batch -> first unit of every mini-batch (at most FAST_MAX_BATCHES of them: one block)
-__global__ __launch_bounds__(256) void mf_flow_units_kernel(const int *used, const int quads_per_unit, const int n_batches, int *unit_base) {
-    typedef rocprim::block_scan<int, 256> Scan;
-    __shared__ typename Scan::storage_type tmp;
-    const int b = threadIdx.x;
-    int units = 0;
-    if (b < n_batches) {
-        const int n_quads = (used[b] + 3) >> 2;
-        units = (n_quads + quads_per_unit - 1) / quads_per_unit;
-    }
-    int first = 0, total = 0;
-    Scan().exclusive_scan(units, first, 0, total, tmp);
-    if (b < n_batches) unit_base[b] = first;
-    if (b == 0) unit_base[n_batches] = total;
+    mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, blockIdx.x);
 }
 
 // REPLICA-BATCHED launch: mini-batch `batch_local` of R independent models in one grid (blockIdx.y = model).  A single model's
@@ -1170,15 +986,14 @@ __global__ __launch_bounds__(256) void mf_group_batch_kernel(const MfParams<T> *
     // the grid covers a third of a mini-batch's header slots; with fused / paired tasks fewer than that are in use as a rule
     // (the in-LDS schedule files the count), and a workgroup that finds more walks on: no wavefront is launched for an empty slot
     const int used = p.used ? p.used[batch_local] : p.tasks_per_batch;
-    int unused = 0, gen = 0;
-    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg, unused, gen);
+    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg);
 }
 // Sampler and schedule of every member in ONE launch each (model on the last grid dimension): as 4 x R small launches on R
 // streams they took a third of a 32-model epoch.
 __device__ __forceinline__ void globalize(FastSchedParams &f) {
     f.su = as_global(f.su); f.si = as_global(f.si); f.sj = as_global(f.sj); f.sr = as_global(f.sr);
     f.touched = as_global(f.touched); f.par = as_global(f.par); f.sorted_slot = as_global(f.sorted_slot); f.qtask = as_global(f.qtask);
-    f.used = as_global(f.used); f.wide = as_global(f.wide); f.tasks = as_global(f.tasks); f.recs = as_global(f.recs);
+    f.used = as_global(f.used); f.tasks = as_global(f.tasks); f.recs = as_global(f.recs);
 }
 template <int ALGO, class T>
 __global__ __launch_bounds__(256) void mf_group_sample_kernel(const MfParams<T> *__restrict__ table) {
@@ -1216,8 +1031,7 @@ __global__ __launch_bounds__(256, 8) void mf_group_batch_kernel_occ8(const MfPar
     // the grid covers a third of a mini-batch's header slots; with fused / paired tasks fewer than that are in use as a rule
     // (the in-LDS schedule files the count), and a workgroup that finds more walks on: no wavefront is launched for an empty slot
     const int used = p.used ? p.used[batch_local] : p.tasks_per_batch;
-    int unused = 0, gen = 0;
-    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg, unused, gen);
+    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg);
 }
 
 // Any k (odd k, k > 64 lanes x 2 chunks): one task per wavefront, one sample at a time, rows re-read for the update.
@@ -1590,9 +1404,7 @@ struct mi355rec_mf {
     DeviceBuffer<unsigned char> spar, cub_tmp;
     DeviceBuffer<TaskHeader> tasks;
     DeviceBuffer<unsigned> touched;         // fast schedule: (row, mini-batch) bitmap
-    DeviceBuffer<int> sorted_slot, qtask, used, wide;
-    DeviceBuffer<int> flow_ver, flow_rd, flow_state, flow_units;      // dataflow epoch: row versions, arrival counters, queue / abort / watermark, unit table
-    int flow_grid = 0;                // workgroups of the dataflow kernel that fit the device
+    DeviceBuffer<int> sorted_slot, qtask, used;
     bool fast_schedule = false;
     DeviceBuffer<unsigned long long> ticks;
     DeviceBuffer<int4> recs;
@@ -1675,9 +1487,6 @@ void fill_params(mi355rec_mf *h, MfParams<T> &p) {
     p.ticks = h->ticks.ptr;
     p.wg_base = 0;
     p.wg_stride = 1;
-    p.ver = h->flow_ver.ptr; p.rd = h->flow_rd.ptr; p.flow = h->flow_state.ptr;
-    p.unit_base = h->flow_units.ptr; p.wide = h->wide.ptr;
-    p.n_batches = 0;
 }
 
 // ---- kernel selection -------------------------------------------------------------------------------------------------
@@ -1801,7 +1610,7 @@ FastSchedParams fast_sched_params(mi355rec_mf *h, long long n_samples) {
     f.group = samples_in_flight(h);
     f.su = h->su.ptr; f.si = h->si.ptr; f.sj = h->sj.ptr; f.sr = h->sr.ptr;
     f.touched = h->touched.ptr; f.par = h->par.ptr;
-    f.sorted_slot = h->sorted_slot.ptr; f.qtask = h->qtask.ptr; f.used = h->used.ptr; f.wide = h->wide.ptr;
+    f.sorted_slot = h->sorted_slot.ptr; f.qtask = h->qtask.ptr; f.used = h->used.ptr;
     f.tasks = h->tasks.ptr; f.recs = h->recs.ptr;
     // fused sample tasks: BPR only; not in the exact multi-GPU mode, whose exchange slabs hold one row per task slot
     f.fuse = h->cfg.algorithm == MI355REC_MF_BPR && h->shard_rank < 0 && !getenv("MI355REC_MF_NO_FUSE");
@@ -1866,63 +1675,9 @@ void enqueue_schedule(mi355rec_mf *h, long long n_samples, long long n_batches) 
     hipLaunchKernelGGL(mf_recs_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, sp);
 }
 
-// The dataflow epoch replaces the chain of dependent mini-batch launches (one launch boundary + three dependent round trips each:
-// 4.5 us per mini-batch of 3 MB) where it applies: BPR on the in-LDS schedule, outside the exact multi-GPU mode.
-bool flow_applies(const mi355rec_mf *h, long long n_batches) {
-    return h->cfg.algorithm == MI355REC_MF_BPR && h->fast_schedule && fast_schedule_fits(h, n_batches) && h->shard_rank < 0 &&
-           kernel_class(h) >= 0 && !h->ticks.ptr && !getenv("MI355REC_MF_NO_FLOW");
-}
-
-// grid == 0: only ask how many workgroups of the instance fit the device (outside any stream capture)
-// quads a workgroup of the dataflow kernel runs side by side: 16 wavefronts leave 128 registers per lane (the float32 instances fit),
-// 8 wavefronts 256 (float64)
-template <class T> constexpr int flow_quads() { return sizeof(T) == 4 ? 4 : 2; }
-
-template <class T, int VEC, int LPR, int KI>
-int launch_flow_as(mi355rec_mf *h, const MfParams<T> &p, int grid, hipEvent_t e0, hipEvent_t e1) {
-    constexpr int Q = flow_quads<T>();
-    auto kernel = mf_flow_kernel<MI355REC_MF_BPR, T, VEC, LPR, KI, Q>;
-    if (grid == 0) {
-        int per_cu = 0;
-        MI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256 * Q, 0));
-        return multiprocessor_count() * std::max(1, std::min(per_cu, 8 / Q));
-    }
-    if (e0) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256 * Q), 0, h->stream, e0, e1, 0, p);
-    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(256 * Q), 0, h->stream, p);       // capturable
-    return grid;
-}
-template <class T>
-int launch_flow(mi355rec_mf *h, const MfParams<T> &p, int grid, hipEvent_t e0, hipEvent_t e1) {
-    constexpr int VEC = 16 / (int)sizeof(T);
-    switch (kernel_class(h)) {
-        case 0: return launch_flow_as<T, VEC, 16, 1>(h, p, grid, e0, e1);
-        case 1: return launch_flow_as<T, VEC, 32, 1>(h, p, grid, e0, e1);
-        case 2: return launch_flow_as<T, VEC, 64, 1>(h, p, grid, e0, e1);
-        default: return launch_flow_as<T, VEC, 64, 2>(h, p, grid, e0, e1);
-    }
-}
-
-template <class T>
-void enqueue_flow(mi355rec_mf *h, MfParams<T> p, long long n_batches, bool timed) {
-    hipStream_t s = h->stream;
-    p.n_batches = (int)n_batches;
-    MI_HIP(hipMemsetAsync(h->flow_ver.ptr, 0, sizeof(int) * h->flow_ver.count, s));
-    MI_HIP(hipMemsetAsync(h->flow_rd.ptr, 0, sizeof(int) * (size_t)n_batches * RD_SHARDS, s));
-    MI_HIP(hipMemsetAsync(h->flow_state.ptr, 0, sizeof(int) * 4, s));
-    hipLaunchKernelGGL(mf_flow_units_kernel, dim3(1), dim3(256), 0, s, h->used.ptr, flow_quads<T>(), (int)n_batches, h->flow_units.ptr);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (timed) h->dispatch_timers.next(e0, e1, std::max(1, h->max_timed));
-    launch_flow(h, p, h->flow_grid, e0, e1);
-}
-
 template <class T>
 void enqueue_batches(mi355rec_mf *h, const MfParams<T> &p, long long n_batches, bool timed) {
     const bool bpr = h->cfg.algorithm == MI355REC_MF_BPR;
-    if (flow_applies(h, n_batches)) {
-        enqueue_flow(h, p, n_batches, timed);
-        hipLaunchKernelGGL(mf_stream_end_kernel<T>, dim3(1), dim3(64), 0, h->stream, p, n_batches);
-        return;
-    }
     for (long long b = 0; b < n_batches; ++b) {
         if (bpr) launch_batch<MI355REC_MF_BPR, T>(h, p, (int)b, timed);
         else launch_batch<MI355REC_MF_FUNK_SVD, T>(h, p, (int)b, timed);
@@ -2031,13 +1786,6 @@ void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batche
             h->sorted_slot.alloc((size_t)n_batches * tpb);
             h->qtask.alloc((size_t)n_batches * tpb);
             h->used.alloc((size_t)n_batches);
-            h->wide.alloc((size_t)n_batches);
-            if (!h->flow_ver.ptr) {
-                h->flow_ver.alloc_zero((size_t)h->n_users + h->n_items, h->stream);
-                h->flow_rd.alloc_zero((size_t)FAST_MAX_BATCHES * RD_SHARDS, h->stream);
-                h->flow_state.alloc_zero(4, h->stream);
-                h->flow_units.alloc_zero(FAST_MAX_BATCHES + 1, h->stream);
-            }
             if (!h->touched.ptr) h->touched.alloc_zero(((size_t)h->n_users + h->n_items) * (FAST_MAX_BATCHES / 32), h->stream);
         }
         h->batch_capacity = n_batches;
@@ -2061,10 +1809,7 @@ void finish_call(mi355rec_mf *h, long long n_samples, long long n_launches) {
     MI_HIP(hipGetLastError());
     h->host_loss.resize(h->loss_slots.count);
     h->loss_slots.download(h->host_loss.data(), h->loss_slots.count, h->stream);
-    int flow_state[4] = {0, 0, 0, 0};
-    if (h->flow_state.ptr) MI_HIP(hipMemcpyAsync(flow_state, h->flow_state.ptr, sizeof(flow_state), hipMemcpyDeviceToHost, h->stream));
     MI_HIP(hipStreamSynchronize(h->stream));
-    if (flow_state[1]) fail(MI355REC_E_HIP, "BPR-MF: a hand-off between tasks did not arrive (dataflow epoch aborted)");
     double loss = 0;
     for (double v : h->host_loss) loss += v;
     if (h->cfg.algorithm == MI355REC_MF_ASY_SVD) {
@@ -2119,11 +1864,9 @@ void run_epochs_typed(mi355rec_mf *h, int n_epochs) {
     ensure_stream_capacity(h, (size_t)(per_epoch * B), per_epoch);
     MfParams<T> p{};
     fill_params(h, p);
-    if (!h->flow_grid && flow_applies(h, per_epoch)) h->flow_grid = launch_flow(h, p, 0, nullptr, nullptr);
     begin_call(h);
     // epochs whose mini-batch launches carry timing events run as plain launches, the rest replays the graph
-    // (the dataflow epoch is ONE launch: max_timed of them carry events)
-    const long long timed_epochs = h->max_timed > 0 ? std::min<long long>(n_epochs, flow_applies(h, per_epoch) ? h->max_timed : (h->max_timed + per_epoch - 1) / per_epoch) : 0;
+    const long long timed_epochs = h->max_timed > 0 ? std::min<long long>(n_epochs, (h->max_timed + per_epoch - 1) / per_epoch) : 0;
     // MI355REC_NO_GRAPH=1: plain launches only (rocprofv3 on ROCm 7.2 crashes while tracing graph replays)
     bool use_graph = per_epoch <= MAX_GRAPH_BATCHES && n_epochs - timed_epochs > 0 && !getenv("MI355REC_NO_GRAPH") && !asy;
     if (use_graph) {
@@ -2138,9 +1881,7 @@ void run_epochs_typed(mi355rec_mf *h, int n_epochs) {
     h->timer.stop(h->stream);
     h->batches_done += per_epoch * n_epochs;
     h->last_call_samples = n_epochs > 0 ? per_epoch * B : 0;
-    // launches of the dominant kernel: one per mini-batch, or one per epoch where the dataflow epoch applies
-    const long long launches = asy ? n_epochs * ((per_epoch + ASY_CHUNK - 1) / ASY_CHUNK) : (flow_applies(h, per_epoch) ? n_epochs : per_epoch * n_epochs);
-    finish_call(h, per_epoch * n_epochs * B, launches);
+    finish_call(h, per_epoch * n_epochs * B, asy ? n_epochs * ((per_epoch + ASY_CHUNK - 1) / ASY_CHUNK) : per_epoch * n_epochs);
 }
 
 template <class T>
@@ -2149,7 +1890,6 @@ void run_samples_typed(mi355rec_mf *h, int64_t n) {
     MfParams<T> p{};
     fill_params(h, p);
     const long long n_batches = (n + B - 1) / B;
-    if (!h->flow_grid && h->cfg.algorithm == MI355REC_MF_BPR && flow_applies(h, n_batches)) h->flow_grid = launch_flow(h, p, 0, nullptr, nullptr);
     begin_call(h);
     h->timer.start(h->stream);
     if (h->cfg.algorithm == MI355REC_MF_ASY_SVD) {
@@ -2163,7 +1903,7 @@ void run_samples_typed(mi355rec_mf *h, int64_t n) {
     enqueue_batches(h, p, n_batches, true);
     h->timer.stop(h->stream);
     h->batches_done += n_batches;
-    finish_call(h, n, flow_applies(h, n_batches) ? 1 : n_batches);
+    finish_call(h, n, n_batches);
 }
 
 // O = float (the float32 matrices north_star speaks of) or double (what the reference's getters return, .pyx:685-702: exact when

@@ -471,33 +471,6 @@ def test_group_at_headline_shape_and_rejections(gpu):
         MatrixFactorization_MI355X_Group([a, a])
 
 
-@pytest.mark.parametrize("mode,k,batch", [("sgd", 64, 200), ("adagrad", 32, 1000), ("sgd", 128, 1000), ("adam", 16, 50)])
-def test_dataflow_epoch_equals_the_launch_per_mini_batch_loop(gpu, monkeypatch, mode, k, batch):
-    """BPR on the in-LDS schedule runs an epoch as ONE persistent launch (mf_flow_kernel: tasks wait for row versions instead of
-    launch boundaries).  Same tasks, same arithmetic: factors, loss and sample stream are bit-identical to the chain of
-    mini-batch launches (MI355REC_MF_NO_FLOW=1), for native epochs (graph replays) and for a replayed stream."""
-    X = named_urm("ml1m", "binary", scale=0.5 if batch < 1000 else 1.0)
-    kw = dict(n_factors=k, algorithm_name="MF_BPR", batch_size=batch, random_seed=31, sgd_mode=mode, learning_rate=0.05,
-              user_reg=0.002, positive_reg=0.003, negative_reg=0.004)
-    got = []
-    for flow in (True, False):
-        if flow:
-            monkeypatch.delenv("MI355REC_MF_NO_FLOW", raising=False)
-        else:
-            monkeypatch.setenv("MI355REC_MF_NO_FLOW", "1")
-        dev = MatrixFactorization_MI355X_Epoch(X, **kw)
-        dev.epochIteration_Cython(7)
-        st = dev.stats()
-        n_batches = X.shape[0] // batch + 1
-        assert st["n_launches"] == (7 if flow else 7 * n_batches)
-        u, i, j = dev.last_epoch_samples()
-        dev.replay_samples(u[:5 * batch + 3], i[:5 * batch + 3], neg_item=j[:5 * batch + 3])
-        got.append((dev.get_USER_factors(), dev.get_ITEM_factors(), st["loss"], u, i, j))
-        dev.close()
-    for a, b in zip(got[0], got[1]):
-        np.testing.assert_array_equal(a, b)
-
-
 def test_asysvd_full_ml1m_shape_k64_replay(gpu):
     """AsySVD at the full ML-1M shape (6 040 x 3 706, 1 000 209 interactions), k = 64, biases on: one whole reference epoch
     (nnz + 1 strictly ordered steps, each rewriting every Y row of the sampled user's profile) replayed against the oracle."""
