@@ -18,6 +18,8 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <chrono>
+
 #include <algorithm>
 #include <memory>
 #include <numeric>
@@ -1433,6 +1435,16 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         h->call_timer.init();
         hipStream_t s = h->stream;
         const size_t nnz = h->nnz;
+        // MI355REC_SIM_CREATE_PHASES=1: wall clock of the constructor's phases on stderr (each one drained before the next starts)
+        const bool phases = getenv("MI355REC_SIM_CREATE_PHASES") != nullptr;
+        auto t_phase = std::chrono::steady_clock::now();
+        auto phase = [&](const char *what) {
+            if (!phases) return;
+            (void)hipStreamSynchronize(s);
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "[sim create] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_phase).count());
+            t_phase = now;
+        };
         h->csr_ptr.upload(csr_indptr, (size_t)n_rows + 1, s);
         // padding: the column kernel reads the profiles in aligned 16-byte chunks, a whole lane group at a time
         h->csr_idx.alloc_zero(nnz + 520, s);
@@ -1440,6 +1452,7 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         MI_HIP(hipMemcpyAsync(h->csr_idx.ptr, csr_indices, nnz * sizeof(int), hipMemcpyHostToDevice, s));
         MI_HIP(hipMemcpyAsync(h->csr_val.ptr, csr_data, nnz * sizeof(float), hipMemcpyHostToDevice, s));
         if (row_weights) h->row_w.upload(row_weights, n_rows, s);
+        phase("allocate + upload (PCIe)");
         const int eb = 256, eg = std::min<size_t>((nnz + eb - 1) / eb, 4096);
 
         // optional pre-pass: BM25 / TF-IDF on the stored values (what the KNN recommenders do to the matrix before the build)
@@ -1504,6 +1517,7 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
                 }
             }
         }
+        phase("value checks (weighting, units, grid)");
         // accumulator tiling: the LDS holds MAX_TILE 4-byte cells (counts, exact integer sums) or MAX_TILE_F64 8-byte cells (other
         // real-valued data, row weights) next to the 32 KiB selection scratch
         const int max_tile = h->acc_mode() != ACC_WIDE ? MAX_TILE : MAX_TILE_F64;
@@ -1552,6 +1566,7 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         hipLaunchKernelGGL(gather_csc_kernel, dim3(eg), dim3(eb), 0, s, pos_out.ptr, row_of.ptr, h->csr_val.ptr, nnz,
                            h->csc_idx.ptr, h->csc_val.ptr);
 
+        phase("CSR -> CSC (allocations, radix sort, gather)");
         const int cg = div_up((int64_t)n_cols * 64, 256);
         if (cfg->similarity == MI355REC_SIM_PEARSON) {
             mean.alloc((size_t)n_cols);
@@ -1583,6 +1598,7 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
             MI_HIP(hipGetLastError());
             MI_HIP(hipStreamSynchronize(s));      // the temporaries above go out of scope
         }
+        phase("profile stream");
         sumsq.alloc((size_t)n_cols);
         cost.alloc((size_t)n_cols);
         hipLaunchKernelGGL(column_stats_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_idx.ptr, h->csc_val.ptr,
@@ -1609,6 +1625,7 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         h->csc_ptr_host.resize((size_t)n_cols + 1);
         h->csc_ptr.download(h->csc_ptr_host.data(), (size_t)n_cols + 1, s);
         MI_HIP(hipStreamSynchronize(s));
+        phase("column costs + norms + downloads");
 
         // Real-valued data: can the column sums be kept as int64 fixed point (ds_add_u64 is 1.8x faster than ds_add_f64)?
         // Every product is at most P = max weight * max |column-side value| * max |value|; a cell sums at most N = longest
@@ -1663,6 +1680,7 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         // the float64 kernel has half the loads in flight per lane (DEPTH 2): narrower groups keep more profiles going
         if (h->acc_mode() != ACC_COUNTS) h->group_lanes = weighted_len >= 2048 ? 64 : (weighted_len >= 640 ? 32 : 16);
         if (getenv("MI355REC_SIM_G")) h->group_lanes = atoi(getenv("MI355REC_SIM_G"));
+        phase("fixed-point check + cost order (host)");
         *out = h.release();
     });
 }

@@ -128,12 +128,26 @@ def test_baseline_config_5_ml20m_k200_properties(gpu):
     U, V_same = dev.get_factors()
     np.testing.assert_array_equal(V_same, V0)
     VV = V0.T @ V0
+    reg_diag = np.diag(reg * np.ones(k))
+    rng = np.random.default_rng(1)
+
+    def against_update_row(rows, C, Y, YtY, X_dev, what):
+        """the device rows against the reference's _update_row (IALSRecommender.py:170-201, restated in oracle.py): 1e-8 of the row's scale"""
+        for r in rows:
+            s, e = C.indptr[r], C.indptr[r + 1]
+            ref = O._ials_update_row(C.indices[s:e], C.data[s:e].astype(np.float64), Y, YtY, reg_diag)
+            err = np.abs(X_dev[r] - ref).max() / max(np.abs(ref).max(), 1e-300)
+            assert err < 1e-8, (what, int(r), e - s, err)
+
     for u in [0, 1, nu // 2, nu - 1, int(np.argmax(np.diff(Cm.indptr)))]:
         s, e = Cm.indptr[u], Cm.indptr[u + 1]
         Yi = V0[Cm.indices[s:e]]; c = Cm.data[s:e].astype(np.float64)
         Bm = VV + Yi.T @ ((c - 1)[:, None] * Yi) + reg * np.eye(k)
         rhs = Yi.T @ c
         assert np.abs(Bm @ U[u] - rhs).max() < 1e-7 * np.abs(rhs).max()
+    Lu = np.diff(Cm.indptr)
+    users = np.unique(np.concatenate([rng.choice(nu, 500, replace=False), np.argsort(-Lu)[:8]]))
+    against_update_row(users, Cm, V0, VV, U, "user row")
     dev.item_half(0, ni); dev.synchronize()
     U2, V = dev.get_factors()
     np.testing.assert_array_equal(U2, U)
@@ -145,7 +159,14 @@ def test_baseline_config_5_ml20m_k200_properties(gpu):
         Bm = UU + Yi.T @ ((c - 1)[:, None] * Yi) + reg * np.eye(k)
         rhs = Yi.T @ c
         assert np.abs(Bm @ V[i] - rhs).max() < 1e-7 * np.abs(rhs).max()
-    assert dev.schedule_info()[0] > 0, "the popular items' rows (profiles beyond 8192 entries) must have been split over workgroups"
+    n_split = dev.schedule_info()[0]
+    assert n_split > 0, "the popular items' rows (profiles beyond 8192 entries) must have been split over workgroups"
+    # every row whose profile was split over workgroups (parts published, summed by the last arriver), and 300 random ones
+    Li = np.diff(Cc.indptr)
+    split_rows = np.flatnonzero(Li > 2 * 4096)
+    assert len(split_rows) == n_split, (len(split_rows), n_split)
+    items = np.unique(np.concatenate([split_rows, rng.choice(ni, 300, replace=False)]))
+    against_update_row(items, Cc, U, UU, V, "item row")
     st = dev.stats()
     assert st["algorithmic_flops"] > 0
     dev.close()
