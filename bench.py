@@ -471,14 +471,49 @@ def other_paths(urm, args):
         sec = st["call_ms"] * 1e-3
         t0 = time.perf_counter()
         sl.get_S_slabs(TOPK)
-        blk = hbm_block("slim_flow_kernel", st, sec, "BASELINE config 3 (adagrad, float64 S); one persistent dataflow kernel per epoch")
+        kernel = "slim_sym_flow_kernel" if symmetric else "slim_dense_flow_kernel"
+        blk = hbm_block(kernel, st, sec, "BASELINE config 3 (adagrad); one persistent dataflow kernel per epoch: " + (
+            "8-byte {value, tag} cells polled in place" if symmetric else "the busiest rows owned in LDS by turn-taking workgroups, the other steps one wavefront each"))
+        traffic, traffic_source = pmc_traffic(kernel)
         blk.update({"seconds_per_epoch": sec / n_ep, "flow_kernel_ms_per_epoch": st["kernel_ms"] / n_ep,
-                    "us_per_step_amortised": sec / st["n_units"] * 1e6, "get_S_topk_s": time.perf_counter() - t0})
+                    "us_per_step_amortised": sec / st["n_units"] * 1e6, "get_S_topk_s": time.perf_counter() - t0,
+                    "traffic": traffic, "traffic_source": traffic_source, "bound_note": "latency: the chain of dependent steps on the busiest "
+                    "row / cells (1 214 / 3 839 links at this shape), not bytes"})
+        if not symmetric:
+            owned, cold = sl.schedule_info()
+            blk.update({"owned_rows": owned, "steps_on_rows_in_hbm": cold})
         out["slim_bpr_%s" % ("symmetric" if symmetric else "dense")] = blk
         sl.close()
         if cpu:
             blk["cpu_baseline"] = cpu_baseline_slim(urm, symmetric, args.cpu_seconds)
             blk["speedup_vs_cpu_baseline"] = blk["samples_per_s"] / blk["cpu_baseline"]["value"]
+
+    note("paths: slim, 4 models side by side")
+    # R independent SLIM models on R streams (how the reference's search runs every SGD path: run_parameter_search.py:498-503); the
+    # dense store's compute units are leased R ways so that every model's owned rows stay resident
+    R = 4
+    os.environ["MI355REC_SLIM_CUS"] = str(256 // R)
+    try:
+        reps = [SLIM_BPR_MI355X_Epoch(urm, symmetric=False, sgd_mode="adagrad", learning_rate=1e-4, topK=TOPK, random_seed=300 + r) for r in range(R)]
+        for m in reps:
+            m.epochIteration_Cython(1)
+        n_ep = 4
+        threads = [threading.Thread(target=m.epochIteration_Cython, args=(n_ep,)) for m in reps]
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        wall = time.perf_counter() - t0
+        out["slim_bpr_dense_4_models_side_by_side"] = {
+            "samples_per_s": R * n_ep * (urm.shape[0] + 1) / wall, "models": R, "seconds": wall, "owned_rows_per_model": [m.schedule_info()[0] for m in reps],
+            "note": "aggregate of 4 independent models (4 handles, streams and host threads); one model alone: slim_bpr_dense.  The epoch of one "
+                    "model is bound by its chain of dependent steps, and the polling of concurrent persistent kernels lengthens every link: "
+                    "models side by side add little (profiles/r4_slim_replicas_first.txt)"}
+        for m in reps:
+            m.close()
+    finally:
+        os.environ.pop("MI355REC_SLIM_CUS", None)
 
     note("paths: scoring")
     # scoring + ranking of 1000 users (the Evaluator's block size, Base/Evaluation/Evaluator.py:406-408), k = 128
@@ -526,6 +561,17 @@ def other_paths(urm, args):
     if cpu:
         out["ials_k200"]["cpu_baseline"] = cpu_baseline_ials(conf, k, 1e-3, V0, args.cpu_seconds)
         out["ials_k200"]["speedup_vs_cpu_baseline"] = out["ials_k200"]["cpu_baseline"]["value"] / out["ials_k200"]["seconds_per_epoch"]
+    # the REFERENCE's own _update_row timed where /root/reference exists (tests/golden/make_ials_reference_timing.py): a committed fixture,
+    # from another host than this run's -- next to, not instead of, the same-run port above
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "ials_reference_timing.json")) as f:
+            fx = json.load(f)
+        out["ials_k200"]["cpu_baseline_reference_fixture"] = {
+            "value": fx["seconds_per_epoch_extrapolated"], "unit": "s/epoch", "cores": fx["blas_threads"], "kind": "reference-fixture",
+            "sample": "%d rows = %.2f %% of an epoch's flops in %.1f s on %s (%s)" % (fx["rows_timed"], 100 * fx["fraction_of_an_epochs_flops"], fx["seconds"],
+                                                                                   fx["cpu"], fx["generated"])}
+    except Exception:
+        pass
 
     note("paths: asysvd")
     # AsySVD at the ML-1M shape, k = 64, biases: nnz + 1 strictly ordered steps, each rewriting every Y row of the
@@ -894,6 +940,22 @@ def main():
             out["extra"]["itemknn"]["cpu_baseline"] = sb
             out["extra"]["itemknn"]["speedup_vs_cpu_baseline"] = sb["value"] / out["extra"]["itemknn"]["cosine_build_s"]
             out["extra"]["itemknn"]["fit_speedup_vs_cpu_baseline"] = sb["value"] / out["extra"]["itemknn"]["fit_s"]
+    # one compact row per path at the TOP level (value, unit, fraction of the bound, CPU baseline of the same run)
+    table = {"bpr_mf_k128_batch1000_one_model": {"value": value, "unit": "samples/s", "bound": "hbm", "frac": roofline["frac"],
+                                                 "cpu_value": out.get("cpu_baseline", {}).get("value"), "cpu_kind": out.get("cpu_baseline", {}).get("kind")}}
+    for name, blk in out["extra"].get("paths", {}).items():
+        if not isinstance(blk, dict):
+            continue
+        val = blk.get("samples_per_s", blk.get("users_per_s", blk.get("seconds_per_epoch")))
+        table[name] = {"value": val, "unit": "samples/s" if "samples_per_s" in blk else ("users/s" if "users_per_s" in blk else "s/epoch"),
+                       "bound": blk.get("bound"), "frac": blk.get("frac"), "cpu_value": (blk.get("cpu_baseline") or {}).get("value"),
+                       "cpu_kind": (blk.get("cpu_baseline") or {}).get("kind")}
+    if "itemknn" in out["extra"]:
+        ik = out["extra"]["itemknn"]
+        table["itemknn_cosine_top100"] = {"value": ik.get("fit_s"), "unit": "s (constructor incl. PCIe upload + build)", "build_s": ik.get("cosine_build_s"),
+                                          "bound": "lds-atomics", "frac": ik.get("roofline", {}).get("frac"),
+                                          "cpu_value": (ik.get("cpu_baseline") or {}).get("value"), "cpu_kind": (ik.get("cpu_baseline") or {}).get("kind")}
+    out["paths"] = table
     note("done")
     faulthandler.cancel_dump_traceback_later()
     if rank == 0:

@@ -1,6 +1,10 @@
 // common.hip -- error state, device binding and the device-query entry points of libmi355rec.so.
 #include "common.h"
 
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
 namespace mi355rec {
 
 static thread_local std::string g_last_error;
@@ -40,6 +44,94 @@ void ensure_device() {
 }
 
 int multiprocessor_count() { return g_cu_count > 0 ? g_cu_count : 256; }
+
+// ---- cache of device blocks (common.h) -----------------------------------------------------------------------------------------
+namespace {
+struct BlockCache {
+    std::mutex lock;
+    std::multimap<size_t, void *> free_blocks;       // size -> block (of the device the cache was first used on)
+    std::unordered_map<void *, size_t> size_of;      // every block handed out by device_block: its true size
+    int device = -1;                                 // one process drives one GPU; blocks of any other device bypass the cache
+    size_t cached = 0, limit = 0;
+    BlockCache() {
+        const char *v = getenv("MI355REC_POOL_BYTES");
+        limit = v && *v ? (size_t)strtoull(v, nullptr, 10) : (size_t)8 << 30;
+    }
+};
+BlockCache &block_cache() {
+    static BlockCache *c = new BlockCache();         // never destroyed: the HIP runtime may be gone before static destructors run
+    return *c;
+}
+constexpr size_t MAX_CACHED_BLOCK = (size_t)1 << 30;
+}  // namespace
+
+void *device_block(size_t bytes) {
+    BlockCache &c = block_cache();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> g(c.lock);
+        if (c.device < 0) c.device = dev;
+        auto it = c.device == dev ? c.free_blocks.lower_bound(bytes) : c.free_blocks.end();
+        if (it != c.free_blocks.end() && it->first <= 2 * bytes + 4096) {
+            void *p = it->second;
+            c.cached -= it->first;
+            c.size_of[p] = it->first;
+            c.free_blocks.erase(it);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {                           // out of memory: give the cache back and try once more
+        (void)hipGetLastError();
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> g(c.lock);
+            for (auto &kv : c.free_blocks) drop.push_back(kv.second);
+            c.free_blocks.clear();
+            c.cached = 0;
+        }
+        for (void *q : drop) (void)hipFree(q);
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) fail(MI355REC_E_HIP, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    std::lock_guard<std::mutex> g(c.lock);
+    if (c.device == dev) c.size_of[p] = bytes;       // (unknown blocks are simply freed when they come back)
+    return p;
+}
+
+void device_block_return(void *p, size_t) {
+    if (!p) return;
+    BlockCache &c = block_cache();
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> g(c.lock);
+        auto it = c.size_of.find(p);
+        if (it != c.size_of.end()) {
+            bytes = it->second;
+            c.size_of.erase(it);
+        }
+    }
+    if (bytes == 0 || bytes > MAX_CACHED_BLOCK || c.limit == 0) {
+        (void)hipFree(p);
+        return;
+    }
+    (void)hipDeviceSynchronize();                    // what hipFree would have waited for
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> g(c.lock);
+        c.free_blocks.emplace(bytes, p);
+        c.cached += bytes;
+        while (c.cached > c.limit && !c.free_blocks.empty()) {       // largest first
+            auto last = std::prev(c.free_blocks.end());
+            drop.push_back(last->second);
+            c.cached -= last->first;
+            c.free_blocks.erase(last);
+        }
+    }
+    for (void *q : drop) (void)hipFree(q);
+}
 
 }  // namespace mi355rec
 

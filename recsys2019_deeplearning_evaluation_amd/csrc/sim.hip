@@ -870,6 +870,17 @@ __global__ __launch_bounds__(256) void column_sumsq_f32_rowwise_kernel(const int
     if (lane == 0) sumsq[c] = (double)sum;
 }
 
+// all-ones data: the sum of a column's squares is its number of stored cells, exactly, in any order (float32 holds every count
+// below 2^24; beyond that the serial float32 chain decides)
+__global__ void column_count_sumsq_kernel(const int *csc_ptr, int n_cols, double *sumsq) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_cols) sumsq[c] = (double)(csc_ptr[c + 1] - csc_ptr[c]);
+}
+__global__ void iota_kernel(int *out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
 // sumOfSquared -> norms (.pyx:169-177)
 __global__ void norms_kernel(const double *sumsq, int n_cols, int set_based, int asymmetric, int euclidean, float alpha,
                              float *norm, float *norm_alpha, float *norm_1ma) {
@@ -1100,7 +1111,8 @@ inline int part_of_position(long long pos, int n_parts) {
 
 // Runs the column kernel for [start,end) -- or, with n_parts > 0, for part `start` of `n_parts` interleaved parts -- leaving
 // results in d_idx/d_val (or d_dense when topK == 0).
-void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, float *d_dense, int n_parts);
+void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, float *d_dense, int n_parts, int slot_first = 0,
+                     int slot_count = 0x7fffffff);
 
 // valid after the stream has been synchronised past the last build
 void read_timers(mi355rec_sim *h) {
@@ -1160,10 +1172,9 @@ void run_columns_wide_topk(mi355rec_sim *h, int32_t start, int32_t end, int *d_i
         n_local = 0;
         for (long long pos = 0; pos < n_cols; ++pos) n_local += part_of_position(pos, n_parts) == start;
     }
-    const size_t cells_cap = (size_t)1 << 30;                                   // 4 GiB per float buffer
+    // 4 GiB per float buffer (MI355REC_SIM_WIDE_CELLS: a smaller bound, for tests of the block walk)
+    const size_t cells_cap = getenv("MI355REC_SIM_WIDE_CELLS") ? (size_t)std::max(1ll, atoll(getenv("MI355REC_SIM_WIDE_CELLS"))) : (size_t)1 << 30;
     int block = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_local, cells_cap / (size_t)n_cols));
-    if (n_parts > 0 && block < n_local)
-        fail(MI355REC_E_UNSUPPORTED, "topK = %d > %d with interleaved parts needs %d x %d dense cells at once", topK, MAX_TOPK, n_local, n_cols);
     DeviceBuffer<float> dense, sorted_val;
     DeviceBuffer<int> ids, sorted_id;
     DeviceBuffer<unsigned> offsets;
@@ -1187,7 +1198,7 @@ void run_columns_wide_topk(mi355rec_sim *h, int32_t start, int32_t end, int *d_i
         for (int done = 0; done < n_local; done += block) {
             const int here = std::min(block, n_local - done);
             h->cfg.topK = 0;
-            if (n_parts > 0) run_columns_lds(h, start, 0, nullptr, nullptr, dense.ptr, n_parts);
+            if (n_parts > 0) run_columns_lds(h, start, 0, nullptr, nullptr, dense.ptr, n_parts, done, here);
             else run_columns_lds(h, start + done, start + done + here, nullptr, nullptr, dense.ptr, 0);
             h->cfg = saved;
             MI_HIP(hipStreamSynchronize(s));
@@ -1226,15 +1237,22 @@ void run_columns(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float 
     else run_columns_lds(h, start, end, d_idx, d_val, d_dense, n_parts);
 }
 
-void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, float *d_dense, int n_parts) {
+// n_parts > 0: interleaved part `start` of n_parts; of its columns (in output order) only slots [slot_first, slot_first + slot_count)
+// are built, into output rows 0 .. slot_count - 1 (the wide top-K path walks a part in blocks).
+void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, float *d_dense, int n_parts, int slot_first,
+                     int slot_count) {
     const int part = start;
     std::vector<int> slot_host;
     int n_local = end - start;
     if (n_parts > 0) {
         slot_host.assign((size_t)h->n_cols, -1);
         n_local = 0;
+        int seen = 0;
         for (long long pos = 0; pos < h->n_cols; ++pos)
-            if (part_of_position(pos, n_parts) == part) slot_host[h->cost_order[pos]] = n_local++;
+            if (part_of_position(pos, n_parts) == part) {
+                if (seen >= slot_first && n_local < slot_count) slot_host[h->cost_order[pos]] = n_local++;
+                ++seen;
+            }
         start = 0;
         end = h->n_cols;
     }
@@ -1604,7 +1622,9 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         hipLaunchKernelGGL(column_stats_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_idx.ptr, h->csc_val.ptr,
                            h->csr_ptr.ptr, n_cols, (float *)nullptr, (double *)nullptr, cost.ptr);
         MI_REQUIRE(cfg->norm_sum_order == 0 || cfg->norm_sum_order == 1, "norm_sum_order must be 0 (CSR order) or 1 (CSC order)");
-        if (cfg->norm_sum_order == 0)
+        if (h->unit_values && n_rows < (1 << 24))
+            hipLaunchKernelGGL(column_count_sumsq_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, s, h->csc_ptr.ptr, n_cols, sumsq.ptr);
+        else if (cfg->norm_sum_order == 0)
             hipLaunchKernelGGL(column_sumsq_f32_rowwise_kernel, dim3(div_up((int64_t)n_cols * 64, 256)), dim3(256), 0, s, h->csc_ptr.ptr,
                                h->csc_val.ptr, n_cols, sumsq.ptr);
         else
@@ -1620,6 +1640,18 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         hipLaunchKernelGGL(norms_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, s, sumsq.ptr, n_cols, (int)set_based,
                            (int)asym, (int)euclid, cfg->asymmetric_alpha, h->norm.ptr, h->norm_alpha.ptr, h->norm_1ma.ptr);
         MI_HIP(hipGetLastError());
+        // columns by descending cost (stable: ties keep ascending column ids), sorted where the costs are
+        DeviceBuffer<long long> cost_sorted;
+        DeviceBuffer<int> col_ids, col_order;
+        DeviceBuffer<char> order_tmp;
+        cost_sorted.alloc((size_t)n_cols); col_ids.alloc((size_t)n_cols); col_order.alloc((size_t)n_cols);
+        hipLaunchKernelGGL(iota_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, s, col_ids.ptr, n_cols);
+        size_t order_bytes = 0;
+        MI_HIP(rocprim::radix_sort_pairs_desc(nullptr, order_bytes, cost.ptr, cost_sorted.ptr, col_ids.ptr, col_order.ptr, (size_t)n_cols, 0, 64, s));
+        order_tmp.alloc(order_bytes + 16);
+        MI_HIP(rocprim::radix_sort_pairs_desc(order_tmp.ptr, order_bytes, cost.ptr, cost_sorted.ptr, col_ids.ptr, col_order.ptr, (size_t)n_cols, 0, 64, s));
+        h->cost_order.resize(n_cols);
+        col_order.download(h->cost_order.data(), (size_t)n_cols, s);
         h->cost.resize(n_cols);
         cost.download(h->cost.data(), n_cols, s);
         h->csc_ptr_host.resize((size_t)n_cols + 1);
@@ -1666,10 +1698,6 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
             }
         }
 
-        h->cost_order.resize(n_cols);
-        std::iota(h->cost_order.begin(), h->cost_order.end(), 0);
-        std::stable_sort(h->cost_order.begin(), h->cost_order.end(),
-                         [&](int a, int b) { return h->cost[a] > h->cost[b]; });
         h->queue.alloc(1);
         // lanes per user profile: sized to the profile length seen from an item (cost-weighted mean)
         long long total_cost = 0;

@@ -114,6 +114,9 @@ class _IALSLogic:
 
     def _prepare_model_for_validation(self):
         self.USER_factors, self.ITEM_factors = self.epoch_kernel.get_factors()
+        invalidate = getattr(self, "invalidate_scorer", None)         # (the device scorer of the scoring mixin, if the class has one)
+        if invalidate is not None:
+            invalidate()
 
     def _update_best_model(self):
         self.USER_factors_best = self.USER_factors.copy()

@@ -194,10 +194,16 @@ class MatrixFactorization_MI355X_Group:
         assert len(self.members) >= 1
         self._lib = N.load()
         handles = (C.c_void_p * len(self.members))(*[m._h for m in self.members])
+        self._member_handles = [m._h.value for m in self.members]      # the native group keeps these raw handles
         self._g = C.c_void_p()
         N.check(self._lib.mi355rec_mf_group_create(C.byref(self._g), handles, len(self.members)))
 
     def epochIteration_Cython(self, n_epochs=1):
+        # a member that was closed (or closed and re-created) since the group was built would be a dangling handle on the device side
+        for n, (m, h) in enumerate(zip(self.members, self._member_handles)):
+            if getattr(m, "_h", None) is None or m._h.value != h:
+                raise RuntimeError("MatrixFactorization_MI355X_Group: member %d was closed after the group was created; "
+                                   "build a new group from live epoch objects" % n)
         N.check(self._lib.mi355rec_mf_group_run_epochs(self._g, int(n_epochs)))
 
     def set_profiling(self, max_timed_launches):
@@ -274,8 +280,14 @@ class _MatrixFactorizationLogic:
         self.epoch_kernel.close()
         sys.stdout.flush()
 
+    def _forget_device_scorer(self):
+        invalidate = getattr(self, "invalidate_scorer", None)         # (the device scorer of the scoring mixin, if the class has one)
+        if invalidate is not None:
+            invalidate()
+
     def _prepare_model_for_validation(self):     # the only device -> host copy of the training loop
         self.USER_factors, self.ITEM_factors = self.epoch_kernel.get_factors()
+        self._forget_device_scorer()
         if self.use_bias:
             self.USER_bias = self.epoch_kernel.get_USER_bias()
             self.ITEM_bias = self.epoch_kernel.get_ITEM_bias()
@@ -334,6 +346,7 @@ class _AsySVDLogic(_MatrixFactorizationLogic):
     def _prepare_model_for_validation(self):
         self.ITEM_factors_Y, self.ITEM_factors = self.epoch_kernel.get_factors()
         self.USER_factors = self._estimate_user_factors(self.ITEM_factors_Y)
+        self._forget_device_scorer()
         if self.use_bias:
             self.USER_bias = self.epoch_kernel.get_USER_bias()
             self.ITEM_bias = self.epoch_kernel.get_ITEM_bias()

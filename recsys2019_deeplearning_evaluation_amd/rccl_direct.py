@@ -75,9 +75,10 @@ def _recv_exact(conn, need):
 def exchange_unique_id(payload, rank, world, address, port, timeout=120.0):
     """Rank 0 serves `payload` (bytes) to the world - 1 other ranks; they return what they received.
 
-    Every client opens with a 20-byte hello (magic, job nonce, rank): rank 0 answers each rank of THIS job exactly once; a stray
-    or duplicate connection (another job on the same port, a port scanner, a retry) is closed without using up one of the
-    world - 1 places, so a real rank cannot be locked out by it."""
+    Every client opens with a 20-byte hello (magic, job nonce, rank): rank 0 answers EVERY valid hello of this job with the payload
+    and stops once world - 1 distinct ranks have been answered.  A stray connection (another job on the same port, a port scanner)
+    uses up no place; a rank that gave up on its first connection (rank 0 was busy with a slow peer) and comes back is simply
+    answered again -- it cannot be locked out by its own retry.  Rank 0 waits 2 s for a hello, the clients 30 s for the answer."""
     if world == 1:
         return payload
     nonce = _job_nonce()
@@ -93,10 +94,10 @@ def exchange_unique_id(payload, rank, world, address, port, timeout=120.0):
                 conn, _ = srv.accept()          # socket.timeout propagates once the deadline has passed
                 with conn:
                     try:
-                        conn.settimeout(5.0)
+                        conn.settimeout(2.0)
                         hello = _recv_exact(conn, 20)
                         peer = int.from_bytes(hello[16:20], "little")
-                        if hello[:8] != _HELLO_MAGIC or hello[8:16] != nonce or not (0 < peer < world) or peer in served:
+                        if hello[:8] != _HELLO_MAGIC or hello[8:16] != nonce or not (0 < peer < world):
                             continue
                         conn.sendall(payload)
                         served.add(peer)
@@ -106,7 +107,7 @@ def exchange_unique_id(payload, rank, world, address, port, timeout=120.0):
     deadline = time.time() + timeout
     while True:
         try:
-            with socket.create_connection((address, port), timeout=5.0) as conn:
+            with socket.create_connection((address, port), timeout=30.0) as conn:
                 conn.sendall(_HELLO_MAGIC + nonce + int(rank).to_bytes(4, "little"))
                 return _recv_exact(conn, len(payload) if payload else NCCL_UNIQUE_ID_BYTES)
         except (ConnectionRefusedError, socket.timeout, ConnectionError):

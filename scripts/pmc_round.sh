@@ -5,7 +5,7 @@
 #   --pmc SQ_* for the similarity and IALS kernels (LDS activity / bank conflicts, VALU issue)
 # Usage: scripts/pmc_round.sh <tag>     (writes gpurun_out/pmc_<tag>/..., summary in gpurun_out/pmc_<tag>/summary.txt + pmc_traffic.json)
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT

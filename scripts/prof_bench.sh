@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of the bench command itself (plain launches: rocprofv3 on ROCm 7.2 crashes while tracing hipGraph
 # replays), then the default bench line.  Usage (through gpurun, from the repo root): bash scripts/prof_bench.sh <tag>
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_bench_$TAG
 mkdir -p $OUT

@@ -34,10 +34,10 @@ elif path == "asy":
     pick = rng.integers(0, x1m.nnz, 131072)
     m.replay_samples(rows[pick].astype(np.int32), x1m.indices[pick].astype(np.int32), rating=x1m.data[pick].astype(np.float32))
 elif path == "funk":
-    m = MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, algorithm_name="FUNK_SVD", batch_size=BATCH, learning_rate=1e-3, sgd_mode="sgd", use_bias=True, random_seed=1)
-    u = np.random.default_rng(0).integers(0, urm.shape[0], 200 * BATCH).astype(np.int32)
-    i = urm.indices[urm.indptr[u]]
-    m.replay_samples(u, i, rating=np.ones(len(u), np.float32))
+    # the bench's workload: ONE native epoch (20 001 mini-batches of on-device samples, general schedule, global-bias ring)
+    m = MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, algorithm_name="FUNK_SVD", batch_size=BATCH, learning_rate=1e-3, sgd_mode="sgd", use_bias=True,
+                                         negative_interactions_quota=0.0, random_seed=1)
+    m.epochIteration_Cython(1)
 elif path == "sim":
     s = Compute_Similarity_MI355X(urm, topK=TOPK, shrink=0, normalize=True, similarity="cosine")
     s.compute_slabs()
@@ -55,4 +55,11 @@ elif path == "score":
     sc.recommend(rng.choice(urm.shape[0], 1000, replace=False).astype(np.int32), 20)
 else:
     raise SystemExit("unknown path " + path)
+# the path's own stream time (events around the call), for scripts/summarize_pmc.py: launches x average duration of a kernel
+# cannot exceed it
+for obj in ("m", "g", "s", "ia", "sc"):
+    if obj in dir() and hasattr(globals()[obj], "stats"):
+        st = globals()[obj].stats()
+        print("path_call_ms=%.6f kernel_ms=%.6f n_launches=%d n_units=%d" % (st.get("call_ms", 0.0), st.get("kernel_ms", 0.0), st.get("n_launches", 0), st.get("n_units", 0)))
+        break
 print("done", path)

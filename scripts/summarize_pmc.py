@@ -27,12 +27,29 @@ for path in ("mf", "mf_group", "funk", "sim", "slim_dense", "slim_symmetric", "i
     print("=" * 30, path, "=" * 30)
     stats = find(path + "/trace", "*kernel_stats.csv")
     durations = {}
+    call_ms, n_launches = None, 0
+    log = os.path.join(root, path + ".trace.log")
+    if os.path.isfile(log):
+        for line in open(log, errors="replace"):
+            if line.startswith("path_call_ms="):
+                fields = dict(f.split("=") for f in line.split())
+                call_ms, n_launches = float(fields["path_call_ms"]), int(fields.get("n_launches", "0"))
     if stats:
         print("%-72s %7s %14s %12s %6s" % ("kernel (rocprofv3 --kernel-trace --stats)", "calls", "total_ns", "avg_ns", "%"))
-        for r in list(csv.DictReader(open(stats)))[:8]:
+        rows = list(csv.DictReader(open(stats)))
+        for r in rows[:16 if path == "sim" else 8]:
             k = short(r["Name"])
             durations[k] = float(r["AverageNs"])
             print("%-72s %7s %14s %12.1f %6.2f" % (k, r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), float(r["Percentage"])))
+        if call_ms is not None and rows:
+            # consistency: the handle's stream events around its LAST call bound the kernels of that call:
+            # (launches of the dominant kernel in the call) x (rocprofv3's average duration of that kernel) <= the call
+            top = rows[0]
+            need_ms = float(top["AverageNs"]) * 1e-6 * max(1, min(n_launches, int(top["Calls"])))
+            print("  handle's stream events: last call %.3f ms, %d launches of the dominant kernel; %s: %d x %.1f ns = %.3f ms" % (
+                call_ms, n_launches, short(top["Name"])[:40], max(1, min(n_launches, int(top["Calls"]))), float(top["AverageNs"]), need_ms))
+            if short(top["Name"]).startswith(OURS) and need_ms > call_ms * 1.10 + 0.05:
+                raise SystemExit("INCONSISTENT with the handle's own timing: the workload profiled is not the workload timed")
     per = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
     for sub in ("fetch", "write", "sq"):
         f = find(path + "/" + sub, "*counter_collection.csv")

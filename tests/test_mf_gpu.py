@@ -469,6 +469,13 @@ def test_group_at_headline_shape_and_rejections(gpu):
         MatrixFactorization_MI355X_Group([a, c])            # different kernel instance
     with pytest.raises(ValueError):
         MatrixFactorization_MI355X_Group([a, a])
+    a2 = MatrixFactorization_MI355X_Epoch(X, n_factors=128, algorithm_name="MF_BPR", batch_size=1000, random_seed=2,
+                                          initial_USER_factors=U0, initial_ITEM_factors=V0)
+    g = MatrixFactorization_MI355X_Group([a, a2])
+    a2.close()
+    with pytest.raises(RuntimeError, match="member 1 was closed"):
+        g.epochIteration_Cython()                       # (a dangling native handle otherwise)
+    g.close()
 
 
 def test_asysvd_full_ml1m_shape_k64_replay(gpu):

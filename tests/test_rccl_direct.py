@@ -40,8 +40,9 @@ def test_librccl_exports_what_the_binding_uses():
     assert rccl_direct._UniqueId.__dict__ is not None and rccl_direct.NCCL_UNIQUE_ID_BYTES == 128
 
 
-def test_rendezvous_ignores_strangers_and_duplicates():
-    """A connection without the job's hello, or a second one from a rank already served, must not use up a place."""
+def test_rendezvous_ignores_strangers_and_answers_retries():
+    """A connection without the job's hello must not use up a place; a second hello of a rank already answered (a retry after the
+    rank gave up on its first connection) is answered again and does not use up a place either."""
     import socket
     port = _free_port()
     payload = bytes(range(128))
@@ -61,40 +62,50 @@ def test_rendezvous_ignores_strangers_and_duplicates():
             import time
             time.sleep(0.02)
     got[1] = rccl_direct.exchange_unique_id(b"", 1, 3, "127.0.0.1", port, timeout=30)
-    with socket.create_connection(("127.0.0.1", port), timeout=5.0) as c:      # rank 1 again: not served twice
+    with socket.create_connection(("127.0.0.1", port), timeout=5.0) as c:      # rank 1 again: answered again, rank 2's place stays free
         c.sendall(rccl_direct._HELLO_MAGIC + rccl_direct._job_nonce() + (1).to_bytes(4, "little"))
-        c.settimeout(2.0)
-        try:
-            assert c.recv(128) == b""
-        except (socket.timeout, ConnectionError):
-            pass
+        c.settimeout(5.0)
+        assert rccl_direct._recv_exact(c, 128) == payload
     got[2] = rccl_direct.exchange_unique_id(b"", 2, 3, "127.0.0.1", port, timeout=30)
     t0.join(40)
     assert got[0] == got[1] == got[2] == payload
 
 
+_ONE_RANK = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from recsys2019_deeplearning_evaluation_amd import _native as N, rccl_direct
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+comm = rccl_direct.RcclCommunicator(0, 1, "127.0.0.1", %d)
+assert comm.count() == 1 and comm.user_rank() == 0
+a, b = N.DeviceArray(1000), N.DeviceArray(1000)
+src = np.arange(1000, dtype=np.int32)
+N.check(N.load().mi355rec_device_memcpy(a.ptr, N.ptr(src), 4000, 1))
+comm.all_gather_words(a.address(), b.address(), 1000)
+assert (b.to_host() == src).all()
+print("RCCL single-rank all-gather ran: ncclCommCount = %%d" %% comm.count())
+comm.close()
+"""
+
+
 @pytest.mark.gpu
 def test_single_rank_rccl_communicator_all_gather(gpu):
     """One rank: ncclCommInitRank / ncclCommCount / ncclAllGather on raw device buffers of the library (the code path of every rank
-    of an N-GPU run).  Where RCCL itself cannot initialise (the 1-GPU sandbox hides the other KFD topology nodes,
-    profiles/r2_rccl_sandbox_init.log) the test is reported as XFAIL with RCCL's message -- never as a pass: a green line here
-    means ncclAllGather moved bytes."""
-    from recsys2019_deeplearning_evaluation_amd import _native as N
+    of an N-GPU run), in a process of its own -- one process per GPU is how the library is run, and RCCL's bootstrap inside a
+    process that has already driven the device through a whole test suite is what failed in round 3 (64 s, "remote process exited
+    or there was a network error"; scripts/rccl_probe.py: in a fresh process both ncclCommInitRank and ncclCommInitAll work on the
+    1-GPU box).  A green line here means ncclAllGather moved bytes; a box on which RCCL cannot initialise at all reports XFAIL
+    with RCCL's own message, never a pass."""
     import os
-    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-    try:
-        comm = rccl_direct.RcclCommunicator(0, 1, "127.0.0.1", _free_port())
-    except N.NativeLibraryError as exc:
-        assert "ncclCommInitRank" in str(exc)
-        pytest.xfail("RCCL cannot initialise on this box (single-rank ncclCommInitRank): %s" % exc)
-    assert comm.count() == 1 and comm.user_rank() == 0
-    a, b = N.DeviceArray(1000), N.DeviceArray(1000)
-    src = np.arange(1000, dtype=np.int32)
-    N.check(N.load().mi355rec_device_memcpy(a.ptr, N.ptr(src), 4000, 1))
-    comm.all_gather_words(a.address(), b.address(), 1000)
-    np.testing.assert_array_equal(b.to_host(), src)
-    print("RCCL single-rank all-gather ran: ncclCommCount = %d" % comm.count())
-    comm.close()
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _ONE_RANK % (root, _free_port())], capture_output=True, text=True, timeout=180)
+    if r.returncode != 0 and "ncclCommInitRank failed" in (r.stdout + r.stderr):
+        pytest.xfail("RCCL cannot initialise on this box (single-rank ncclCommInitRank): %s" % (r.stdout + r.stderr).strip().splitlines()[-1])
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "RCCL single-rank all-gather ran: ncclCommCount = 1" in r.stdout
 
 
 @pytest.mark.gpu

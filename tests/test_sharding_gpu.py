@@ -122,6 +122,33 @@ def test_interleaved_parts_on_one_gpu(gpu):
     buf.close(); sim.close()
 
 
+def test_interleaved_parts_with_topk_beyond_the_lds_selection(gpu, monkeypatch):
+    """topK > 4096 goes through dense columns + a segmented sort, a block of columns at a time.  An interleaved part (the default
+    partition of the sharded build) is walked in blocks too: 3 parts, blocks of 100 columns, against the single build."""
+    import numpy as np
+    from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_MI355X
+    from recsys2019_deeplearning_evaluation_amd._native import DeviceArray
+    from recsys2019_deeplearning_evaluation_amd.synthetic import synthetic_urm
+    n, topK, G = 4500, 4200, 3
+    X = synthetic_urm(700, n, 30 * n // 10, 5, 500, seed=21, values="real", zipf_exponent=0.5)
+    sim = Compute_Similarity_MI355X(X, topK=topK, shrink=1)
+    full_idx, full_val, _ = sim.compute_slabs()
+    monkeypatch.setenv("MI355REC_SIM_WIDE_CELLS", str(100 * n))
+    widest = -(-n // G)
+    buf = DeviceArray(2 * widest * topK)
+    idx = np.full((n, topK), -7, np.int32); val = np.zeros((n, topK), np.float32)
+    for r in range(G):
+        cols = sim.part_columns(r, G)
+        sim.compute_part_device(r, G, buf.address(), buf.address(widest * topK))
+        sim.synchronize()
+        host = buf.to_host().reshape(2, widest, topK)
+        idx[cols] = host[0, :len(cols)]
+        val[cols] = host[1, :len(cols)].view(np.float32)
+    np.testing.assert_array_equal(idx, full_idx)
+    np.testing.assert_array_equal(val, full_val)
+    buf.close(); sim.close()
+
+
 @pytest.mark.parametrize("world,batch_size,k", [(1, 1000, 128), (4, 1000, 128), (8, 4096, 64), (3, 37, 20), (2, 2000, 8)])
 def test_exact_multi_gpu_bpr_emulated_on_one_gpu(gpu, world, batch_size, k):
     """SURVEY 8(e)'s exact mode: `world` identical replicas in ONE process stand for the ranks; every mini-batch each runs its share of
