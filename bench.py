@@ -804,8 +804,10 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
         widest8 = -(-n_items // G)
         slab_words = 2 * widest8 * TOPK
         local8, gathered8 = DeviceArray(slab_words), DeviceArray(G * slab_words)
-        per_part = []
+        from recsys2019_deeplearning_evaluation_amd.sharding import chunk_bounds
+        per_part, per_piece = [], []
         t_copy = 0.0
+        pieces = chunk_bounds(widest8, 4)                # what ShardedSimilarityBuild does at world > 1: 4 pieces per part
         for r in range(G):
             sim.compute_part_device(r, G, local8.address(), local8.address(widest8 * TOPK))
             sim.synchronize()
@@ -813,9 +815,29 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
             t3 = time.perf_counter()
             gathered8.copy_from_device(local8, slab_words, r * slab_words)
             t_copy += time.perf_counter() - t3
+            n_mine = len(sim.part_columns(r, G))
+            row = []
+            for r0, r1 in pieces:
+                cnt = max(0, min(r1, n_mine) - r0)
+                if cnt:
+                    sim.compute_part_chunk_device(r, G, r0, cnt, local8.address(2 * r0 * TOPK), local8.address(2 * r0 * TOPK + (r1 - r0) * TOPK))
+                    sim.synchronize()
+                    row.append(sim.stats()["kernel_ms"])
+                else:
+                    row.append(0.0)
+            per_piece.append(row)
         slab = 4 * slab_words
-        ring_ms = (G - 1) * slab / 50e9 * 1e3 + 0.05     # ONE ring over one xGMI link direction (~50 GB/s effective) + launch latency
-        direct_ms = slab / 50e9 * 1e3 + 0.05             # all 7 links at once (every peer is one hop away on the xGMI mesh)
+        ring_of = lambda nbytes: (G - 1) * nbytes / 50e9 * 1e3 + 0.05     # ONE ring over one xGMI link direction (~50 GB/s effective) + launch latency
+        direct_of = lambda nbytes: nbytes / 50e9 * 1e3 + 0.05             # all 7 links at once (every peer is one hop away on the xGMI mesh)
+        ring_ms, direct_ms = ring_of(slab), direct_of(slab)
+
+        def overlapped(row, gather_of):
+            """kernel of piece c + 1 hides the all-gather of piece c; what sticks out is added (the last piece's gather always does)"""
+            t = 0.0
+            for c, k_ms in enumerate(row):
+                g_prev = gather_of(slab * (pieces[c - 1][1] - pieces[c - 1][0]) / widest8) if c else 0.0
+                t += max(k_ms, g_prev)
+            return t + gather_of(slab * (pieces[-1][1] - pieces[-1][0]) / widest8)
         ranges8 = similarity_column_ranges(sim, 8)
         block["emulated_8_way"] = {
             "partition": "interleaved (serpentine deal of the cost order): %d columns and 1/8 of the cost per part" % widest8,
@@ -825,8 +847,12 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
             "slab_MB_per_rank_with_contiguous_ranges": 8 * max(b - a for a, b in ranges8) * TOPK / 1e6,
             "device_copy_of_8_slabs_ms": t_copy * 1e3,
             "modelled_allgather_ms": {"one_ring_50GBps_per_link": ring_ms, "seven_links_at_once": direct_ms},
-            "predicted_build_speedup": {"one_ring": (best * 1e3) / (max(per_part) + ring_ms),
-                                        "seven_links": (best * 1e3) / (max(per_part) + direct_ms)},
+            "predicted_build_speedup_one_exchange_at_the_end": {"one_ring": (best * 1e3) / (max(per_part) + ring_ms),
+                                                                "seven_links": (best * 1e3) / (max(per_part) + direct_ms)},
+            "kernel_ms_per_piece": per_piece,
+            "predicted_build_speedup": {"one_ring": (best * 1e3) / max(overlapped(row, ring_of) for row in per_piece),
+                                        "seven_links": (best * 1e3) / max(overlapped(row, direct_of) for row in per_piece)},
+            "exchange": "4 pieces per part, the all-gather of a finished piece behind the kernel of the next one (ShardedSimilarityBuild)",
             "note": "parts run one after the other on ONE GPU; the exchange is modelled from its size (7 x %.2f MB), unmeasured on hardware" % (slab / 1e6)}
         local8.close(); gathered8.close()
     job.close()

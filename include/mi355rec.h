@@ -135,6 +135,10 @@ int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, int
  * DEVICE slabs (ceil(n_cols / n_parts) x topK each).  Same kernel as mi355rec_sim_compute_device; the contiguous
  * [start_col, end_col) entry points keep the reference's own seam (Compute_Similarity_Cython.pyx:411, 447-451). */
 int mi355rec_sim_compute_part_device(mi355rec_sim_t h, int32_t part, int32_t n_parts, int32_t *d_nbr_idx, float *d_nbr_val);
+/* The same for rows [slot_first, slot_first + slot_count) of the part only, written to rows 0 .. slot_count - 1 of the slabs handed
+ * in: a sharded build computes its part in chunks so that the all-gather of a finished chunk travels while the next one is built. */
+int mi355rec_sim_compute_part_chunk_device(mi355rec_sim_t h, int32_t part, int32_t n_parts, int32_t slot_first, int32_t slot_count,
+                                           int32_t *d_nbr_idx, float *d_nbr_val);
 /* The columns of a part in output-row order (columns may be NULL: only the count). */
 int mi355rec_sim_part_columns(mi355rec_sim_t h, int32_t part, int32_t n_parts, int32_t *columns, int32_t *n_columns);
 /* The re-weighted stored values (feature_weighting != NONE), in the order of the csr_data passed to mi355rec_sim_create: what the

@@ -1734,6 +1734,21 @@ extern "C" int mi355rec_sim_compute_part_device(mi355rec_sim_t h, int32_t part, 
     });
 }
 
+extern "C" int mi355rec_sim_compute_part_chunk_device(mi355rec_sim_t h, int32_t part, int32_t n_parts, int32_t slot_first, int32_t slot_count,
+                                                      int32_t *d_nbr_idx, float *d_nbr_val) {
+    return guarded([&] {
+        MI_REQUIRE(h && d_nbr_idx && d_nbr_val, "NULL argument");
+        MI_REQUIRE(n_parts >= 1 && part >= 0 && part < n_parts, "part %d of %d", part, n_parts);
+        MI_REQUIRE(slot_first >= 0 && slot_count >= 0, "rows %d + %d of a part", slot_first, slot_count);
+        if (h->cfg.topK == 0) fail(MI355REC_E_INVALID, "topK == 0: use mi355rec_sim_compute_dense");
+        if (h->wide_topk) fail(MI355REC_E_UNSUPPORTED, "topK beyond the in-LDS selection: build the part in one piece (mi355rec_sim_compute_part_device)");
+        ensure_device();
+        if (slot_count == 0) return;
+        h->wide_kernel_ms = -1.0;
+        run_columns_lds(h, part, 0, d_nbr_idx, d_nbr_val, nullptr, n_parts, slot_first, slot_count);
+    });
+}
+
 extern "C" int mi355rec_sim_part_columns(mi355rec_sim_t h, int32_t part, int32_t n_parts, int32_t *columns, int32_t *n_columns) {
     return guarded([&] {
         MI_REQUIRE(h && n_columns, "NULL argument");

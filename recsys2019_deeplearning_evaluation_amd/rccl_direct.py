@@ -156,6 +156,15 @@ class RcclCommunicator:
                     "ncclAllGather")
         N.check(N.load().mi355rec_device_synchronize())
 
+    def all_gather_words_async(self, send_address, recv_address, n_words):
+        """The same, enqueued only (null stream): the library's own non-blocking streams keep running; synchronize() before the
+        receive buffer is read."""
+        self._check(self._lib.ncclAllGather(C.c_void_p(send_address), C.c_void_p(recv_address), n_words, NCCL_INT32, self._comm, None),
+                    "ncclAllGather")
+
+    def synchronize(self):
+        N.check(N.load().mi355rec_device_synchronize())
+
     def close(self):
         if getattr(self, "_comm", None) is not None and self._comm.value:
             self._lib.ncclCommDestroy(self._comm)

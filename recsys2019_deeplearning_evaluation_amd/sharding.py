@@ -82,6 +82,78 @@ def interleaved_parts(cost, n_parts):
     return [order[owner == p].astype(np.int32) for p in range(n_parts)]
 
 
+def chunk_bounds(n_rows, chunks):
+    """Row ranges [(r0, r1), ...] of `chunks` near-equal pieces of n_rows rows (the last ones may be empty for tiny inputs)."""
+    chunks = max(1, int(chunks))
+    step = -(-n_rows // chunks) if n_rows else 0
+    return [(min(c * step, n_rows), min((c + 1) * step, n_rows)) for c in range(chunks)]
+
+
+def assemble_gathered_pieces(host_words, world, rows, topK, columns, n_columns):
+    """The piece-major gathered buffer of a sharded similarity build (piece c: `[world][2][rows_c][topK]` words, pieces one after the
+    other) as (idx, val) arrays for all columns; `columns[r]` are rank r's columns in the order of its output rows."""
+    idx = np.empty((n_columns, topK), np.int32)
+    val = np.empty((n_columns, topK), np.int32)
+    at = 0
+    for r0, r1 in rows:
+        words = 2 * (r1 - r0) * topK
+        for r, cols in enumerate(columns):
+            have = max(0, min(r1, len(cols)) - r0)
+            if have:
+                piece = host_words[at + r * words:at + (r + 1) * words].reshape(2, r1 - r0, topK)
+                idx[cols[r0:r0 + have]] = piece[0, :have]
+                val[cols[r0:r0 + have]] = piece[1, :have]
+        at += world * words
+    return idx, val.view(np.float32)
+
+
+class ChunkedAllGather:
+    """All-gather of a send slab in pieces, so that a finished piece travels while the next one is computed.
+
+    send: piece c = `words[c]` 4-byte words at word offset sum(words[:c]);  receive buffer: piece c of ALL ranks, rank-major, at word
+    offset world * sum(words[:c]) -- every piece is one ordinary all-gather into a contiguous block.  start(c) returns at once where
+    the transport can (RCCL through ctypes: the collective is enqueued on the null stream, which the library's non-blocking streams
+    do not wait for; torch.distributed "nccl": async_op on RCCL's own stream); gloo stages through host memory and blocks (CPU-side
+    tests).  The caller has synchronised the stream that produced piece c before start(c)."""
+
+    def __init__(self, send, recv, words, world, dist=None, comm=None):
+        self.send, self.recv, self.words, self.world, self.dist, self.comm = send, recv, list(words), world, dist, comm
+        self.offsets = [int(o) for o in np.concatenate([[0], np.cumsum(self.words)])]
+        self.pending = []
+        if dist is not None:
+            self.on_host = dist.get_backend() == "gloo"
+            self.t_send = [device_tensor(send.address(self.offsets[c]), (w,), "<i4") if w else None for c, w in enumerate(self.words)]
+            self.t_recv = [device_tensor(recv.address(world * self.offsets[c]), (world * w,), "<i4") if w else None for c, w in enumerate(self.words)]
+
+    def start(self, c):
+        w = self.words[c]
+        if not w or self.world == 1:
+            return
+        if self.comm is not None:
+            self.comm.all_gather_words_async(self.send.address(self.offsets[c]), self.recv.address(self.world * self.offsets[c]), w)
+            return
+        import torch
+        if self.on_host:
+            mine = self.t_send[c].cpu()
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine)
+            self.t_recv[c].copy_(torch.cat(parts))
+        else:
+            self.pending.append(self.dist.all_gather_into_tensor(self.t_recv[c], self.t_send[c], async_op=True))
+
+    def finish(self):
+        if self.world == 1:
+            return
+        if self.comm is not None:
+            self.comm.synchronize()
+            return
+        import torch
+        for work in self.pending:
+            work.wait()
+        self.pending = []
+        torch.cuda.synchronize()
+
+
 class ShardedSimilarityBuild:
     """The column-sharded build as a reusable object: partition, the rank's slab and the gathered result are allocated ONCE.
 
@@ -90,16 +162,18 @@ class ShardedSimilarityBuild:
     ranges of partition="ranges", the reference's own start_col/end_col seam, are up to 2.6 x wider than the average at
     Netflix shape because unpopular columns are cheap).
 
-    Device layout: every rank owns one contiguous slab `[2][widest][topK]` of 4-byte words -- neighbour ids, then the
-    similarity values (float32 bits) -- which the column kernel fills directly (its two output pointers are the two halves).
-    The exchange is ONE all-gather of that slab into `[world][2][widest][topK]`; the result stays on the device of every
-    rank.  `build()` returns when the full result is resident on this rank's device -- the same definition at world == 1 (no
-    exchange) -- and `download()` copies it to the host, which only a caller that needs NumPy arrays pays.
+    The rank's `widest` output rows are built in `chunks` pieces (default 4 when world > 1): the all-gather of a finished piece
+    overlaps the kernel of the next one, so only the LAST piece's exchange is exposed (the one-ring model of the 8-GPU ML-20M
+    build: kernel 0.63 ms + 0.42 / 4 ms instead of + 0.42 ms).  Device layout, piece-major: piece c of the rank's slab is
+    `[2][rows_c][topK]` 4-byte words -- neighbour ids, then the similarity values (float32 bits) -- which the column kernel fills
+    directly (its two output pointers are the two halves); the gathered buffer holds, piece after piece, `[world][2][rows_c][topK]`.
+    `build()` returns when the full result is resident on this rank's device -- the same definition at world == 1 (no exchange) --
+    and `download()` copies it to the host, which only a caller that needs NumPy arrays pays.
     Buffers belong to libmi355rec.so (raw device allocations); the transport is either
       `comm`: an rccl_direct.RcclCommunicator (RCCL through ctypes, no PyTorch in the process), or
       `dist`: torch.distributed ("nccl" = RCCL: device to device over xGMI; "gloo": staged through host memory, CPU-side tests)."""
 
-    def __init__(self, similarity_object, dist=None, rank=0, world=1, comm=None, partition="interleaved"):
+    def __init__(self, similarity_object, dist=None, rank=0, world=1, comm=None, partition="interleaved", chunks=None):
         from ._native import DeviceArray
         self.sim, self.dist, self.comm, self.rank, self.world = similarity_object, dist, comm, rank, world
         assert world == 1 or (dist is None) != (comm is None), "exactly one transport: torch.distributed (dist) or RcclCommunicator (comm)"
@@ -114,52 +188,52 @@ class ShardedSimilarityBuild:
             self.ranges = similarity_column_ranges(similarity_object, world) if world > 1 else [(0, self.n)]
             self.columns = [np.arange(s, e, dtype=np.int32) for s, e in self.ranges]
             self.widest = max(e - s for s, e in self.ranges)
+        if chunks is None:
+            chunks = 4 if world > 1 else 1
+        if getattr(similarity_object, "TopK", 0) > 4096:           # beyond the in-LDS selection a part is built in one piece
+            chunks = 1
+        self.rows = chunk_bounds(self.widest, chunks)
         self.slab_words = 2 * self.widest * self.topK
         self.local = DeviceArray(self.slab_words)
         # rows beyond this rank's columns are never written by the kernel but travel in the all-gather: (-1, 0.0) like empty slots
         from . import _native as N
-        fill = np.concatenate([np.full(self.widest * self.topK, -1, np.int32), np.zeros(self.widest * self.topK, np.int32)])
+        fill = np.concatenate([np.concatenate([np.full((r1 - r0) * self.topK, -1, np.int32), np.zeros((r1 - r0) * self.topK, np.int32)])
+                               for r0, r1 in self.rows])
         N.check(N.load().mi355rec_device_memcpy(self.local.ptr, N.ptr(fill), 4 * self.slab_words, 1))
         self.gathered = DeviceArray(world * self.slab_words) if world > 1 else self.local
         self._host = np.empty(world * self.slab_words, np.int32)
-        if dist is not None and world > 1:
-            self.t_local = device_tensor(self.local.address(), (self.slab_words,), "<i4")
-            self.t_all = device_tensor(self.gathered.address(), (world * self.slab_words,), "<i4")
-            self.on_host = dist.get_backend() == "gloo"
+        self.gather = ChunkedAllGather(self.local, self.gathered, [2 * (r1 - r0) * self.topK for r0, r1 in self.rows], world, dist, comm)
 
-    def build(self):
-        """Kernel on this rank's range (+ the exchange); afterwards the gathered slabs are valid on this device.  Blocking."""
+    def _build_piece(self, c):
+        r0, r1 = self.rows[c]
+        mine = len(self.columns[self.rank])
+        count = max(0, min(r1, mine) - r0)
+        if count == 0:
+            return
+        at = self.gather.offsets[c]
+        d_idx, d_val = self.local.address(at), self.local.address(at + (r1 - r0) * self.topK)
         if self.partition == "interleaved":
-            self.sim.compute_part_device(self.rank, self.world, self.local.address(), self.local.address(self.widest * self.topK))
+            if len(self.rows) == 1:
+                self.sim.compute_part_device(self.rank, self.world, d_idx, d_val)
+            else:
+                self.sim.compute_part_chunk_device(self.rank, self.world, r0, count, d_idx, d_val)
         else:
             s, e = self.ranges[self.rank]
-            self.sim.compute_slabs_device(s if s > 0 else None, e if e < self.n else None, self.local.address(),
-                                          self.local.address(self.widest * self.topK))
-        self.sim.synchronize()
-        if self.world == 1:
-            return
-        if self.comm is not None:
-            self.comm.all_gather_words(self.local.address(), self.gathered.address(), self.slab_words)
-            return
-        import torch
-        if self.on_host:            # gloo: CPU-side tests / the single-GPU dry run of bench.py
-            mine = self.t_local.cpu()
-            parts = [torch.empty_like(mine) for _ in range(self.world)]
-            self.dist.all_gather(parts, mine)
-            self.t_all.copy_(torch.cat(parts))
-        else:
-            self.dist.all_gather_into_tensor(self.t_all, self.t_local)
-        torch.cuda.synchronize()
+            a, b = s + r0, s + r0 + count
+            self.sim.compute_slabs_device(a if a > 0 else None, b if b < self.n else None, d_idx, d_val)
+
+    def build(self):
+        """Kernel on this rank's columns, piece by piece, each piece's all-gather behind the next piece's kernel; afterwards the
+        gathered slabs are valid on this device.  Blocking."""
+        for c in range(len(self.rows)):
+            self._build_piece(c)
+            self.sim.synchronize()
+            self.gather.start(c)
+        self.gather.finish()
 
     def download(self):
         """(idx, val) NumPy arrays for ALL columns."""
-        host = self.gathered.to_host(self._host).reshape(self.world, 2, self.widest, self.topK)
-        idx = np.empty((self.n, self.topK), np.int32)
-        val = np.empty((self.n, self.topK), np.int32)
-        for r, cols in enumerate(self.columns):
-            idx[cols] = host[r, 0, :len(cols)]
-            val[cols] = host[r, 1, :len(cols)]
-        return idx, val.view(np.float32)
+        return assemble_gathered_pieces(self.gathered.to_host(self._host), self.world, self.rows, self.topK, self.columns, self.n)
 
     def exchange_bytes_per_rank(self):
         return 0 if self.world == 1 else 4 * self.slab_words
@@ -295,7 +369,7 @@ class ShardedIALSEpoch:
     made once; the transport is an rccl_direct.RcclCommunicator (`comm`, no PyTorch in the process) or torch.distributed (`dist`:
     "nccl" = RCCL device to device over xGMI, "gloo" staged through the host for the CPU-side tests)."""
 
-    def __init__(self, epoch_object, confidence_csr, dist=None, rank=0, world=1, comm=None):
+    def __init__(self, epoch_object, confidence_csr, dist=None, rank=0, world=1, comm=None, chunks=None):
         from . import _native as N
         self._N = N
         self.epoch, self.dist, self.comm, self.rank, self.world = epoch_object, dist, comm, rank, world
@@ -304,39 +378,40 @@ class ShardedIALSEpoch:
         self.user_ranges, self.item_ranges = ials_row_ranges(confidence_csr, world, self.k)
         self.dU, self.dV = epoch_object.device_factor_pointers()
         if world > 1:
-            widest = max(max(e - s for s, e in self.user_ranges), max(e - s for s, e in self.item_ranges))
-            self.slab_words = 2 * widest * self.k                       # float64 = two 4-byte words
+            # a half-step's rows are solved in `chunks` pieces: the all-gather of a finished piece travels while the next one is solved
+            self.widest = max(max(e - s for s, e in self.user_ranges), max(e - s for s, e in self.item_ranges))
+            self.rows = chunk_bounds(self.widest, 4 if chunks is None else chunks)
+            self.slab_words = 2 * self.widest * self.k                       # float64 = two 4-byte words
             self.send = N.DeviceArray(self.slab_words)
             self.recv = N.DeviceArray(world * self.slab_words)
-            if dist is not None:
-                self.t_send = device_tensor(self.send.address(), (self.slab_words,), "<i4")
-                self.t_recv = device_tensor(self.recv.address(), (world * self.slab_words,), "<i4")
-                self.on_host = dist.get_backend() == "gloo"
+            self.gather = ChunkedAllGather(self.send, self.recv, [2 * (r1 - r0) * self.k for r0, r1 in self.rows], world, dist, comm)
 
     def _copy(self, dst, src, nbytes):
         import ctypes as C
         if nbytes:
             self._N.check(self._N.load().mi355rec_device_memcpy(C.c_void_p(dst), C.c_void_p(src), int(nbytes), 2))
 
-    def _exchange(self, base, ranges):
+    def _half(self, solve, base, ranges):
+        """The rank's rows piece by piece: solve, stage in the send slab, start the piece's all-gather, go on with the next piece;
+        at the end the other ranks' rows are copied into place."""
         row = 8 * self.k
         s, e = ranges[self.rank]
-        self._copy(self.send.address(), base + s * row, (e - s) * row)
-        if self.comm is not None:
-            self.comm.all_gather_words(self.send.address(), self.recv.address(), self.slab_words)
-        else:
-            import torch
-            if self.on_host:
-                mine = self.t_send.cpu()
-                parts = [torch.empty_like(mine) for _ in range(self.world)]
-                self.dist.all_gather(parts, mine)
-                self.t_recv.copy_(torch.cat(parts))
-            else:
-                self.dist.all_gather_into_tensor(self.t_recv, self.t_send)
-            torch.cuda.synchronize()
-        for r, (a, b) in enumerate(ranges):
-            if r != self.rank:
-                self._copy(base + a * row, self.recv.address(r * self.slab_words), (b - a) * row)
+        for c, (r0, r1) in enumerate(self.rows):
+            a, b = min(s + r0, e), min(s + r1, e)
+            if b > a:
+                solve(a, b)
+                self.epoch.synchronize()
+                self._copy(self.send.address(self.gather.offsets[c]), base + a * row, (b - a) * row)
+                self._N.check(self._N.load().mi355rec_device_synchronize())
+            self.gather.start(c)
+        self.gather.finish()
+        for r, (ra, rb) in enumerate(ranges):
+            if r == self.rank:
+                continue
+            for c, (r0, r1) in enumerate(self.rows):
+                a, b = min(ra + r0, rb), min(ra + r1, rb)
+                if b > a:
+                    self._copy(base + a * row, self.recv.address(self.world * self.gather.offsets[c] + r * self.gather.words[c]), (b - a) * row)
         # the next half-step runs on the epoch object's own (non-blocking) stream: do not rely on hipMemcpy being synchronous for
         # device-to-device copies
         self._N.check(self._N.load().mi355rec_device_synchronize())
@@ -346,12 +421,8 @@ class ShardedIALSEpoch:
         if self.world == 1:
             self.epoch.run_epochs(1)
             return
-        self.epoch.user_half(*self.user_ranges[self.rank])
-        self.epoch.synchronize()
-        self._exchange(self.dU, self.user_ranges)
-        self.epoch.item_half(*self.item_ranges[self.rank])
-        self.epoch.synchronize()
-        self._exchange(self.dV, self.item_ranges)
+        self._half(self.epoch.user_half, self.dU, self.user_ranges)
+        self._half(self.epoch.item_half, self.dV, self.item_ranges)
 
     def exchange_bytes_per_rank_per_epoch(self):
         return 0 if self.world == 1 else 2 * 4 * self.slab_words

@@ -129,6 +129,11 @@ class Compute_Similarity_MI355X:
         slabs of ceil(n_columns / n_parts) rows; row q holds column part_columns(part, n_parts)[q]."""
         N.check(self._lib.mi355rec_sim_compute_part_device(self._h, int(part), int(n_parts), C.c_void_p(d_idx_ptr), C.c_void_p(d_val_ptr)))
 
+    def compute_part_chunk_device(self, part, n_parts, slot_first, slot_count, d_idx_ptr, d_val_ptr):
+        """Rows [slot_first, slot_first + slot_count) of interleaved part `part` only, into rows 0 .. slot_count - 1 of the slabs."""
+        N.check(self._lib.mi355rec_sim_compute_part_chunk_device(self._h, int(part), int(n_parts), int(slot_first), int(slot_count),
+                                                                 C.c_void_p(d_idx_ptr), C.c_void_p(d_val_ptr)))
+
     def part_columns(self, part, n_parts):
         n = C.c_int32()
         N.check(self._lib.mi355rec_sim_part_columns(self._h, int(part), int(n_parts), None, C.byref(n)))

@@ -101,9 +101,12 @@ def test_single_rank_rccl_communicator_all_gather(gpu):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", _ONE_RANK % (root, _free_port())], capture_output=True, text=True, timeout=180)
+    env = dict(os.environ, NCCL_DEBUG="WARN")
+    env.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    r = subprocess.run([sys.executable, "-c", _ONE_RANK % (root, _free_port())], capture_output=True, text=True, timeout=180, env=env)
     if r.returncode != 0 and "ncclCommInitRank failed" in (r.stdout + r.stderr):
-        pytest.xfail("RCCL cannot initialise on this box (single-rank ncclCommInitRank): %s" % (r.stdout + r.stderr).strip().splitlines()[-1])
+        pytest.xfail("RCCL cannot initialise on this box (single-rank ncclCommInitRank): %s" % " | ".join(
+            ln[-160:] for ln in (r.stdout + r.stderr).strip().splitlines()[-6:]))
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     assert "RCCL single-rank all-gather ran: ncclCommCount = 1" in r.stdout
 

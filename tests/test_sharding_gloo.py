@@ -49,6 +49,21 @@ for r, cols in enumerate(parts):
 assert np.array_equal(got_idx, ref_idx) and np.array_equal(got_val, ref_val), "interleaved rank %%d mismatch" %% rank
 costs_per_part = [cost[p].sum() for p in parts]
 assert max(costs_per_part) - min(costs_per_part) <= cost.max(), costs_per_part
+# the same in PIECES (ShardedSimilarityBuild builds a part in chunks and gathers a finished one behind the next one's kernel): piece c of
+# a slab is [2][rows_c][topK], the gathered buffer piece-major; reassembled by the function download() uses
+from recsys2019_deeplearning_evaluation_amd.sharding import assemble_gathered_pieces, chunk_bounds
+for chunks in (1, 3, 4, widest + 5):
+    rows = chunk_bounds(widest, chunks)
+    assert rows[0][0] == 0 and max(r1 for _, r1 in rows) == widest and all(a <= b for a, b in rows)
+    gathered = []
+    for r0, r1 in rows:
+        piece = mine[:, r0:r1, :].contiguous().reshape(-1)
+        out = torch.empty(world * piece.numel(), dtype=torch.int32)
+        if piece.numel():
+            dist.all_gather_into_tensor(out, piece)
+        gathered.append(out)
+    got_idx, got_val = assemble_gathered_pieces(torch.cat(gathered).numpy(), world, rows, 12, parts, X.shape[1])
+    assert np.array_equal(got_idx, ref_idx) and np.array_equal(got_val, ref_val), "pieces (%%d) rank %%d mismatch" %% (chunks, rank)
 dist.barrier()
 if rank == 0:
     print("SHARDING_OK", ranges)
