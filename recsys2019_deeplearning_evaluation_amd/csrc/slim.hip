@@ -83,7 +83,7 @@ struct SlimParams {
     const long long *cellptr;       // symmetric: first cell slot of every step (2 per profile entry: row i, row j)
     const int *pred;                // symmetric: per cell slot, the step that touched the cell last (-1: nobody in this call)
     int *ticket;                    // dense: [n_items] steps of this call completed on the item
-    int *queue;                     // [0] next step (of the cold list), [1] abort flag
+    int *queue;                     // [0] next step (of the cold list / the short profiles), [1] abort flag, [2] next long profile
     double *loss_slots;             // [LOSS_SLOTS]
     long long epoch;                // RNG counter base
     long long steps_before;         // steps executed before this call (Adam's beta^t, .pyx:313-317)
@@ -94,6 +94,8 @@ struct SlimParams {
     const int *hot_item, *lst_begin, *lst_len;   // [MAX_OWNERS] item, first position and length of its run in the sorted pairs
     const int *n_hot;               // owners in use (decided on the device)
     const StepDesc *desc;           // symmetric store: per step, in stream order
+    const int *order;               // symmetric store: the steps with short profiles in stream order, then the others backwards
+    int n_short;
     const StepDesc *cold_desc;      // dense store: the steps with no owned row, in stream order
     const StepDesc *own_desc;       // dense store: per (item, step) pair in sorted order (only the owned items' runs are filled in)
     const int *n_cold;
@@ -933,15 +935,146 @@ __device__ __forceinline__ void sym_step(const SlimParams<double> &p, const int 
     }
 }
 
-__global__ __launch_bounds__(FLOW_THREADS) void slim_sym_flow_kernel(const SlimParams<double> p) {
-    __shared__ LocalQueue s_queue;
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid == 0) { s_queue.next = 0; s_queue.ready = 0; }
+// A step with a LONG profile (more than FLOW_BLOCK entries) by a whole workgroup: every wavefront takes a block, so the granules
+// of up to 4 096 entries are in flight together and stay in registers for the stores.  One wavefront would fetch them block after
+// block, twice -- and steps with long profiles touch the most cells, so they sit on the chain of the epoch more often than
+// their 14 % share of the steps: with them at one round trip per block the chain of the ML-20M shape weighs 13.5 ms, without 7.8 ms
+// (scratch: chain2.c on a stream of the bench's epoch).  Every wavefront adds the sixteen partial sums in the same order and does
+// the (cheap) scalar part itself: one barrier per step.
+__device__ __forceinline__ bool sym_step_wide(const SlimParams<double> &p, const int t, const int lane, const int wave, double *s_x, int *s_bad) {
+    const StepDesc e = p.desc[t];
+    const int i = e.i, j = e.j, L = e.L;
+    const long long cp = (long long)(((unsigned long long)(unsigned)e.c << 32) | (unsigned)e.t);
+    const unsigned long long k0 = p.prof ? shader_clock() : 0ull;
+    unsigned repolls = 0;
+    const unsigned my_tag = p.tag_base + (unsigned)t + 1u;
+    const bool adaptive = p.sgd_mode != MI355REC_SGD, adam = p.sgd_mode == MI355REC_ADAM;
+    Granule *oc = p.oc + 4 * (size_t)(lane == 1 ? j : i);
+    const int ip = lane < 2 && adaptive ? (lane ? e.b : e.a) : -1;
+    Granule o[4] = {{0.f, 0u}, {0.f, 0u}, {0.f, 0u}, {0.f, 0u}};
+    if (lane < 2 && adaptive) {
+        o[0] = gload(oc);
+        o[1] = gload(oc + 1);
+        if (adam) {
+            o[2] = gload(oc + 2);
+            o[3] = gload(oc + 3);
+        }
+    }
+    constexpr int ROUND = FLOW_WAVES * FLOW_BLOCK;
+    const int first = wave * FLOW_BLOCK;
+    bool ok = true;
+    SymBlock k;
+    double x = 0.0;
+    if (first < L) {
+        ok = sym_fetch(p, e, cp, first, lane, true, k, repolls);
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r)
+            if (first + lane + 64 * r < L) x += (double)k.ga[r].v - (double)k.gb[r].v;
+    }
+    for (int b0 = first + ROUND; ok && b0 < L; b0 += ROUND) {                             // profiles longer than 4 096
+        SymBlock m;
+        ok = sym_fetch(p, e, cp, b0, lane, true, m, repolls);
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r)
+            if (b0 + lane + 64 * r < L) x += (double)m.ga[r].v - (double)m.gb[r].v;
+    }
+    if (ok) {
+        SpinGuard sg;
+        for (;;) {
+            bool pending = false;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if ((c < 2 || adam) && !tag_ok(ip, o[c].tag, p.tag_base)) { pending = true; o[c] = gload(oc + c); }
+            if (!__any(pending)) break;
+            ++repolls;
+            if (give_up(p, sg)) { ok = false; break; }
+        }
+    }
+    x = wave_sum(x);
+    if (lane == 0) {
+        s_x[wave] = x;
+        if (!ok) *s_bad = 1;
+    }
     __syncthreads();
+    if (*s_bad) return false;                                                             // (the same answer in every wavefront)
+    const unsigned long long k1 = p.prof ? shader_clock() : 0ull;
+    x = 0.0;
+#pragma unroll
+    for (int w = 0; w < FLOW_WAVES; ++w) x += s_x[w];
+    const double g = fast_sigmoid_of_minus(x);
+    double pw1, pw2;
+    adam_powers(p, t, pw1, pw2);
+    double c1 = (double)o[0].v + (double)o[1].v, c2 = (double)o[2].v + (double)o[3].v;
+    const double step = hot_adapt(p, g, pw1, pw2, c1, c2);
+    const double gi = __shfl(step, 0), gj = __shfl(step, 1);
+    if (first < L) {
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) {
+            if (first + lane + 64 * r < L) {
+                if (k.s[r] != i) gstore(p.G + packed_cell(i, k.s[r]), (float)cell_plus((double)k.ga[r].v, p.lr, gi, p.li_reg), my_tag);
+                if (k.s[r] != j) gstore(p.G + packed_cell(j, k.s[r]), (float)cell_minus((double)k.gb[r].v, p.lr, gj, p.lj_reg), my_tag);
+            }
+        }
+    }
+    if (wave == 0 && lane < 2 && adaptive) {
+        const float h1 = (float)c1;
+        gstore(oc, h1, my_tag);
+        gstore(oc + 1, (float)(c1 - (double)h1), my_tag);
+        if (adam) {
+            const float h2 = (float)c2;
+            gstore(oc + 2, h2, my_tag);
+            gstore(oc + 3, (float)(c2 - (double)h2), my_tag);
+        }
+    }
+    for (int b0 = first + ROUND; b0 < L; b0 += ROUND) {
+        SymBlock m;
+        sym_fetch(p, e, cp, b0, lane, false, m, repolls);
+#pragma unroll
+        for (int r = 0; r < FLOW_REGS; ++r) {
+            if (b0 + lane + 64 * r < L) {
+                if (m.s[r] != i) gstore(p.G + packed_cell(i, m.s[r]), (float)cell_plus((double)m.ga[r].v, p.lr, gi, p.li_reg), my_tag);
+                if (m.s[r] != j) gstore(p.G + packed_cell(j, m.s[r]), (float)cell_minus((double)m.gb[r].v, p.lr, gj, p.lj_reg), my_tag);
+            }
+        }
+    }
+    if (wave == 0 && lane == 0) {
+        atomicAdd(&p.loss_slots[t & (LOSS_SLOTS - 1)], x * x);
+        if (p.prof) {                // long profiles | claim .. barrier passed | the rest | polling rounds of wavefront 0
+            atomicAdd(&p.prof[4], 1ull);
+            atomicAdd(&p.prof[5], k1 - k0);
+            atomicAdd(&p.prof[6], shader_clock() - k1);
+            atomicAdd(&p.prof[7], (unsigned long long)repolls);
+        }
+    }
+    return true;
+}
+
+// Workgroups 0 .. long_wgs - 1 take the steps with long profiles, one step per workgroup, the others (and those once that queue is
+// empty) the steps with short profiles, one per wavefront.  Both queues hand out steps in stream order and every workgroup of
+// the grid is resident: the oldest step that has not run is either running or the next one of its queue, and the consumers of
+// that queue that are busy are busy with older steps.
+__global__ __launch_bounds__(FLOW_THREADS) void slim_sym_flow_kernel(const SlimParams<double> p, const int long_wgs) {
+    __shared__ LocalQueue s_queue;
+    __shared__ double s_x[FLOW_WAVES];
+    __shared__ int s_next, s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_queue.next = 0; s_queue.ready = 0; s_bad = 0; }
+    __syncthreads();
+    if ((int)blockIdx.x < long_wgs) {
+        const int n_long = p.n_steps - p.n_short;
+        for (;;) {
+            if (tid == 0) s_next = aload(&p.queue[1]) ? NO_STEP : atomicAdd(&p.queue[2], 1);
+            __syncthreads();
+            const int q = s_next;
+            __syncthreads();
+            if (q >= n_long) break;
+            if (!sym_step_wide(p, p.order[p.n_steps - 1 - q], lane, wave, s_x, &s_bad)) break;
+        }
+    }
     for (;;) {          // in-order queue: everything a step can wait for is already running
-        const int t = claim_step(p, &s_queue, lane);
-        if (t >= p.n_steps) break;
-        sym_step(p, t, lane);
+        const int q = claim_step(p, &s_queue, lane);
+        if (q >= p.n_short) break;
+        sym_step(p, p.order[q], lane);
     }
 }
 
@@ -1280,28 +1413,52 @@ __global__ __launch_bounds__(PRUNE_THREADS) void slim_list_kernel(const unsigned
 
 using namespace mi355rec;
 
+// What the schedule of ONE stream of steps hands to the launch that runs it.  There are two: the sample stream of an epoch does not
+// depend on S, so while the dataflow kernel of epoch e runs, epoch e + 1 is drawn and scheduled on a second HIP stream (the item
+// sort, the 40 M-pair cell sort of the symmetric store: 0.35 / 3.7 ms of a 2.1 / 18.9 ms epoch at the ML-20M shape) -- also across
+// calls: the reference's fit loop asks for one epoch per call.
+struct StreamSet {
+    DeviceBuffer<int> su, si, sj, seq, iprev, len2, item_vals, pred, run_start;
+    DeviceBuffer<unsigned long long> item_keys;          // (item, step) pairs in sorted order: the owned rows' lists are runs of it
+    DeviceBuffer<long long> cellptr;
+    DeviceBuffer<StepDesc> desc;                         // symmetric store: one descriptor per step ...
+    DeviceBuffer<int> order, n_short_dev;                // ... and the two queues: short profiles in stream order, then the long ones backwards
+    int n_short = 0;
+    DeviceBuffer<unsigned> item_cnt;
+    size_t capacity = 0, pred_capacity = 0;
+    long long epoch = -1;                                // the native epoch this set is scheduled for (-1: none / a replayed stream)
+    int n = 0;
+    long long n_cells = 0;
+};
+
 struct mi355rec_slim {
     mi355rec_slim_config cfg{};
     int n_users = 0, n_items = 0;
     bool f64 = false;           // arithmetic type; storage type of the dense store and its optimiser cells
     size_t nnz = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, side = nullptr;       // `side`: schedules of the next epoch
     StreamTimer call_timer;
     DispatchTimers dispatch_timers;
-    DeviceBuffer<int> indptr, indices, su, si, sj, seq, iprev, len2, ticket, queue, vals, vals_sorted, pred;
-    DeviceBuffer<long long> cellptr;
+    StreamSet set[2];
+    int cur = 0;                                        // the set whose stream ran last
+    bool last_native = false;                           // ... and whether that was an epoch of the on-device sampler
+    DeviceBuffer<int> indptr, indices, ticket, queue;
+    // scratch of the schedules (one schedule at a time)
+    DeviceBuffer<int> vals, vals_sorted;
     DeviceBuffer<unsigned long long> keys, keys_sorted;
-    DeviceBuffer<unsigned char> S, c1, c2, cub_tmp;     // dense store: S, c1, c2 are float or double by `f64`
+    DeviceBuffer<unsigned char> sched_tmp;
+    size_t sort_capacity = 0;
+    DeviceBuffer<unsigned char> S, c1, c2;              // dense store: S, c1, c2 are float or double by `f64`
     DeviceBuffer<Granule> G, oc;                        // symmetric store: packed triangle of granules, [n_items][4] optimiser granules
     DeviceBuffer<double> loss_slots;
-    // dense store: owned rows
-    DeviceBuffer<int> run_start, hot_rank, hot_tables, counters, iota, item_by_cnt;     // hot_tables: item | first | length
+    // dense store, filled at launch time on the main stream: owned rows, descriptors, the cold queue
+    DeviceBuffer<int> hot_rank, hot_tables, counters, iota, item_by_cnt;     // hot_tables: item | first | length
     DeviceBuffer<StepDesc> desc, cold_desc, own_desc;
+    DeviceBuffer<unsigned> cnt_sorted;
+    DeviceBuffer<unsigned char> cold_flag, launch_tmp;
+    DeviceBuffer<unsigned long long> mail;              // [2][launch_capacity]
+    size_t launch_capacity = 0;
     DeviceBuffer<unsigned long long> prof;              // MI355REC_SLIM_PROF=1: phase clocks of the last launch
-    DeviceBuffer<unsigned> item_cnt, cnt_sorted;
-    DeviceBuffer<unsigned char> cold_flag;
-    DeviceBuffer<unsigned long long> mail;              // [2][stream_capacity]
-    size_t stream_capacity = 0, cell_capacity = 0;
     long long steps_done = 0, epochs_done = 0;
     unsigned tag_base = 0;                              // symmetric store: tags handed out so far
     int last_owners = 0, last_cold = 0;                 // owned rows / steps on rows in HBM of the last dense launch (diagnostics)
@@ -1310,8 +1467,10 @@ struct mi355rec_slim {
 
     ~mi355rec_slim() {
         if (stream) (void)hipStreamSynchronize(stream);
+        if (side) (void)hipStreamSynchronize(side);
         call_timer.destroy();
         dispatch_timers.destroy();
+        if (side) (void)hipStreamDestroy(side);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -1324,7 +1483,7 @@ int env_int(const char *name, int fallback) {
 }
 
 template <class T>
-void fill_params(mi355rec_slim *h, SlimParams<T> &p) {
+void fill_params(mi355rec_slim *h, const StreamSet &st, SlimParams<T> &p) {
     const auto &c = h->cfg;
     p.n_users = h->n_users; p.n_items = h->n_items; p.symmetric = c.symmetric; p.sgd_mode = c.sgd_mode;
     p.lr = (T)c.learning_rate; p.li_reg = (T)c.li_reg; p.lj_reg = (T)c.lj_reg;
@@ -1335,8 +1494,8 @@ void fill_params(mi355rec_slim *h, SlimParams<T> &p) {
     p.indptr = h->indptr.ptr; p.indices = h->indices.ptr;
     p.S = reinterpret_cast<T *>(h->S.ptr); p.c1 = reinterpret_cast<T *>(h->c1.ptr); p.c2 = reinterpret_cast<T *>(h->c2.ptr);
     p.G = h->G.ptr; p.oc = h->oc.ptr;
-    p.su = h->su.ptr; p.si = h->si.ptr; p.sj = h->sj.ptr;
-    p.seq = h->seq.ptr; p.iprev = h->iprev.ptr; p.cellptr = h->cellptr.ptr; p.pred = h->pred.ptr;
+    p.su = st.su.ptr; p.si = st.si.ptr; p.sj = st.sj.ptr;
+    p.seq = st.seq.ptr; p.iprev = st.iprev.ptr; p.cellptr = st.cellptr.ptr; p.pred = st.pred.ptr;
     p.ticket = h->ticket.ptr; p.queue = h->queue.ptr;
     p.loss_slots = h->loss_slots.ptr;
     p.epoch = h->epochs_done;
@@ -1346,40 +1505,62 @@ void fill_params(mi355rec_slim *h, SlimParams<T> &p) {
     p.hot_rank = h->hot_rank.ptr;
     p.hot_item = h->hot_tables.ptr; p.lst_begin = h->hot_tables.ptr + MAX_OWNERS; p.lst_len = h->hot_tables.ptr + 2 * MAX_OWNERS;
     p.n_hot = h->counters.ptr; p.n_cold = h->counters.ptr + 1;
-    p.desc = h->desc.ptr; p.cold_desc = h->cold_desc.ptr; p.own_desc = h->own_desc.ptr;
+    p.desc = c.symmetric ? st.desc.ptr : h->desc.ptr; p.cold_desc = h->cold_desc.ptr; p.own_desc = h->own_desc.ptr;
+    p.order = st.order.ptr; p.n_short = st.n_short;
     p.prof = h->prof.ptr;
-    p.mail_x = h->mail.ptr; p.mail_g = h->mail.ptr + h->stream_capacity;
+    p.mail_x = h->mail.ptr; p.mail_g = h->mail.ptr + h->launch_capacity;
 }
 
 bool flow_supported(const mi355rec_slim *h) { return !(h->cfg.symmetric && h->n_items > 92681); }      // (cell ids are 32-bit sort keys)
 
-void ensure_capacity(mi355rec_slim *h, size_t n) {
-    if (h->stream_capacity >= n) return;
-    h->su.alloc(n); h->si.alloc(n); h->sj.alloc(n);
-    h->seq.alloc(2 * n); h->iprev.alloc(2 * n); h->len2.alloc(n + 1); h->cellptr.alloc(n + 1);
-    h->desc.alloc(n);
-    if (!h->cfg.symmetric) {
-        h->cold_desc.alloc(n);
-        h->own_desc.alloc(2 * n);
-        h->cold_flag.alloc(n);
-        h->mail.alloc(2 * n);
-    }
-    h->stream_capacity = n;
-}
+// the sparse store cuts an epoch into segments with a pruning pass between them: those are scheduled one after the other
+bool schedules_ahead(const mi355rec_slim *h) { return !h->cfg.train_with_sparse_weights && flow_supported(h) && !getenv("MI355REC_SLIM_NO_PRESCHED"); }
 
-void ensure_tmp(mi355rec_slim *h, size_t bytes) {
-    if (h->cub_tmp.count < bytes) {
-        MI_HIP(hipStreamSynchronize(h->stream));        // (earlier launches may still use the old block)
-        h->cub_tmp.alloc(bytes + (bytes >> 2) + 256);
-    }
-}
-
-void ensure_sort_capacity(mi355rec_slim *h, size_t n) {
-    if (h->cell_capacity >= n) return;
+void ensure_set_capacity(mi355rec_slim *h, StreamSet &st, size_t n) {
+    if (st.capacity >= n) return;
     MI_HIP(hipStreamSynchronize(h->stream));
-    h->keys.alloc(n); h->keys_sorted.alloc(n); h->vals.alloc(n); h->vals_sorted.alloc(n);
-    if (h->cfg.symmetric) h->pred.alloc(n);
-    h->cell_capacity = n;
+    MI_HIP(hipStreamSynchronize(h->side));
+    st.su.alloc(n); st.si.alloc(n); st.sj.alloc(n);
+    st.seq.alloc(2 * n); st.iprev.alloc(2 * n); st.len2.alloc(n + 1); st.cellptr.alloc(n + 1);
+    st.item_keys.alloc(std::max<size_t>(2 * n, 1024)); st.item_vals.alloc(std::max<size_t>(2 * n, 1024));
+    if (h->cfg.symmetric) {
+        st.desc.alloc(n);
+        st.order.alloc(n);
+        if (!st.n_short_dev.ptr) st.n_short_dev.alloc(1);
+    }
+    if (!st.run_start.ptr) {
+        st.run_start.alloc((size_t)h->n_items);
+        st.item_cnt.alloc((size_t)h->n_items);
+    }
+    st.capacity = n;
+    st.epoch = -1;
+    st.n = 0;
+}
+
+void ensure_launch_capacity(mi355rec_slim *h, size_t n) {      // dense store
+    if (h->cfg.symmetric || h->launch_capacity >= n) return;
+    MI_HIP(hipStreamSynchronize(h->stream));
+    h->desc.alloc(n);
+    h->cold_desc.alloc(n);
+    h->own_desc.alloc(2 * n);
+    h->cold_flag.alloc(n);
+    h->mail.alloc(2 * n);
+    h->launch_capacity = n;
+}
+
+void ensure_tmp(DeviceBuffer<unsigned char> &tmp, size_t bytes, hipStream_t s) {
+    if (tmp.count < bytes) {
+        MI_HIP(hipStreamSynchronize(s));                // (earlier work of the stream may still use the old block)
+        tmp.alloc(bytes + (bytes >> 2) + 256);
+    }
+}
+
+void ensure_sort_capacity(mi355rec_slim *h, size_t n, hipStream_t s) {
+    if (h->sort_capacity >= n) return;
+    MI_HIP(hipStreamSynchronize(s));
+    h->keys.alloc(n); h->vals.alloc(n);
+    if (h->cfg.symmetric) { h->keys_sorted.alloc(n); h->vals_sorted.alloc(n); }      // (the item pass sorts into the set's own arrays)
+    h->sort_capacity = n;
 }
 
 int bits_for(unsigned long long n_values) {
@@ -1388,12 +1569,12 @@ int bits_for(unsigned long long n_values) {
     return b;
 }
 
-void sort_pairs(mi355rec_slim *h, size_t n, int end_bit) {
+void sort_pairs(mi355rec_slim *h, unsigned long long *keys_out, int *vals_out, size_t n, int end_bit, hipStream_t s) {
     size_t bytes = 0;
-    MI_HIP(rocprim::radix_sort_pairs(nullptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr, h->vals_sorted.ptr, n, 0, end_bit, h->stream));
-    ensure_tmp(h, bytes);
-    bytes = h->cub_tmp.count;
-    MI_HIP(rocprim::radix_sort_pairs(h->cub_tmp.ptr, bytes, h->keys.ptr, h->keys_sorted.ptr, h->vals.ptr, h->vals_sorted.ptr, n, 0, end_bit, h->stream));
+    MI_HIP(rocprim::radix_sort_pairs(nullptr, bytes, h->keys.ptr, keys_out, h->vals.ptr, vals_out, std::max(n, h->sort_capacity), 0, end_bit, s));
+    ensure_tmp(h->sched_tmp, bytes, s);                 // (sized for the scratch arrays' capacity: it does not grow from epoch to epoch)
+    bytes = h->sched_tmp.count;
+    MI_HIP(rocprim::radix_sort_pairs(h->sched_tmp.ptr, bytes, h->keys.ptr, keys_out, h->vals.ptr, vals_out, n, 0, end_bit, s));
 }
 
 // Owned rows need a LEASE on compute units.  An owner's steps are static (its row's list), so every owner has to be resident
@@ -1406,17 +1587,21 @@ void sort_pairs(mi355rec_slim *h, size_t n, int end_bit) {
 std::atomic<int> g_owner_slots{-1};
 struct OwnerLease {
     int slots = 0;
-    OwnerLease(bool wanted, int want) {
+    void take(bool wanted, int want) {
         if (!wanted) return;
         int expected = -1;
         g_owner_slots.compare_exchange_strong(expected, multiprocessor_count());      // first use: one slot per compute unit
         int have = g_owner_slots.load();
         while (have >= 32) {
-            const int take = std::min(have, want);
-            if (g_owner_slots.compare_exchange_weak(have, have - take)) { slots = take; return; }
+            const int n = std::min(have, want);
+            if (g_owner_slots.compare_exchange_weak(have, have - n)) { slots = n; return; }
         }
     }
-    ~OwnerLease() { if (slots) g_owner_slots.fetch_add(slots); }
+    void give_back() {
+        if (slots) g_owner_slots.fetch_add(slots);
+        slots = 0;
+    }
+    ~OwnerLease() { give_back(); }
 };
 
 template <class Kernel>
@@ -1426,145 +1611,220 @@ int blocks_per_cu(Kernel k, size_t lds) {
     return std::max(1, std::min(per_cu, 2));            // (2048 threads per compute unit)
 }
 
-// Runs n steps of su/si/sj, starting at step `first`, exactly in stream order.
-template <class T>
-void run_stream(mi355rec_slim *h, int n, double &sum_profile, int first = 0) {
-    hipStream_t s = h->stream;
-    SlimParams<T> p{};
-    const bool sym = h->cfg.symmetric != 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (!flow_supported(h)) {
-        if constexpr (std::is_same<T, double>::value) {
-            fill_params(h, p);
-            p.su += first; p.si += first; p.sj += first;
-            p.n_steps = n;
-            h->dispatch_timers.next(e0, e1, 1 << 30);
-            hipExtLaunchKernelGGL(slim_ordered_kernel, dim3(1), dim3(1024), 0, s, e0, e1, 0, p);
-            h->stats.n_launches += 1;
-            MI_HIP(hipGetLastError());
-        }
-        h->steps_done += n;
-        return;
-    }
-    // ticket numbers / previous steps per item: sort the 2n (item, step) pairs, position inside the item's run
-    ensure_sort_capacity(h, std::max<size_t>(2 * (size_t)n, 1024));
+DepParams dep_params(mi355rec_slim *h, StreamSet &st, int n, int first) {
     DepParams d{};
     d.n_steps = n; d.n_items = h->n_items;
-    d.indptr = h->indptr.ptr; d.indices = h->indices.ptr; d.su = h->su.ptr + first; d.si = h->si.ptr + first; d.sj = h->sj.ptr + first;
-    d.keys = h->keys.ptr; d.vals = h->vals.ptr; d.keys_sorted = h->keys_sorted.ptr; d.vals_sorted = h->vals_sorted.ptr;
-    d.seq = h->seq.ptr; d.iprev = h->iprev.ptr; d.len2 = h->len2.ptr; d.cellptr = h->cellptr.ptr; d.pred = h->pred.ptr;
-    d.run_start = h->run_start.ptr; d.item_cnt = h->item_cnt.ptr; d.cnt_sorted = h->cnt_sorted.ptr; d.item_by_cnt = h->item_by_cnt.ptr;
+    d.indptr = h->indptr.ptr; d.indices = h->indices.ptr; d.su = st.su.ptr + first; d.si = st.si.ptr + first; d.sj = st.sj.ptr + first;
+    d.keys = h->keys.ptr; d.vals = h->vals.ptr; d.keys_sorted = st.item_keys.ptr; d.vals_sorted = st.item_vals.ptr;
+    d.seq = st.seq.ptr; d.iprev = st.iprev.ptr; d.len2 = st.len2.ptr; d.cellptr = st.cellptr.ptr; d.pred = st.pred.ptr;
+    d.run_start = st.run_start.ptr; d.item_cnt = st.item_cnt.ptr; d.cnt_sorted = h->cnt_sorted.ptr; d.item_by_cnt = h->item_by_cnt.ptr;
     d.hot_rank = h->hot_rank.ptr;
     d.hot_item = h->hot_tables.ptr; d.lst_begin = h->hot_tables.ptr + MAX_OWNERS; d.lst_len = h->hot_tables.ptr + 2 * MAX_OWNERS;
     d.n_hot = h->counters.ptr;
     d.cold_flag = h->cold_flag.ptr;
-    d.desc = h->desc.ptr; d.own_desc = h->own_desc.ptr;
-    const bool profile = getenv("MI355REC_SLIM_PROF") != nullptr;
-    if (profile) {
-        if (!h->prof.ptr) h->prof.alloc(8 * (MAX_OWNERS + 1));
-        MI_HIP(hipMemsetAsync(h->prof.ptr, 0, sizeof(unsigned long long) * h->prof.count, s));
+    d.desc = h->cfg.symmetric ? st.desc.ptr : h->desc.ptr; d.own_desc = h->own_desc.ptr;
+    return d;
+}
+
+struct ShortProfile {
+    const int *len2;
+    __device__ bool operator()(const int t) const { return len2[t] <= 2 * FLOW_BLOCK; }
+};
+
+template <class T>
+void draw_epoch(mi355rec_slim *h, StreamSet &st, long long epoch, int n, hipStream_t s) {
+    SlimParams<T> p{};
+    fill_params(h, st, p);
+    p.epoch = epoch;
+    p.n_steps = n;
+    hipLaunchKernelGGL(slim_sample_kernel<T>, dim3(div_up(n, 256)), dim3(256), 0, s, p, st.su.ptr, st.si.ptr, st.sj.ptr);
+    st.epoch = -1;
+    st.n = 0;
+}
+
+// Everything about steps first .. first + n - 1 of st.su / si / sj that does not depend on S, on stream `s`: ticket numbers and
+// previous steps per item (a sort of the 2n (item, step) pairs), cell slots, and -- symmetric store -- the last writer of every
+// cell (a sort of the (cell, step) pairs) and the step descriptors.  Returns with `s` drained (the number of cells sizes the sort).
+void schedule_stream(mi355rec_slim *h, StreamSet &st, int n, int first, hipStream_t s) {
+    if (!flow_supported(h)) {
+        st.n = n;
+        st.n_cells = 0;
+        return;
     }
-    MI_HIP(hipMemsetAsync(h->item_cnt.ptr, 0, sizeof(unsigned) * (size_t)h->n_items, s));
+    ensure_sort_capacity(h, std::max<size_t>(2 * (size_t)n, 1024), s);
+    DepParams d = dep_params(h, st, n, first);
+    MI_HIP(hipMemsetAsync(st.item_cnt.ptr, 0, sizeof(unsigned) * (size_t)h->n_items, s));
     hipLaunchKernelGGL(slim_item_keys_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d);
-    sort_pairs(h, 2 * (size_t)n, 32 + bits_for((unsigned long long)h->n_items));
+    sort_pairs(h, st.item_keys.ptr, st.item_vals.ptr, 2 * (size_t)n, 32 + bits_for((unsigned long long)h->n_items), s);
     hipLaunchKernelGGL(slim_seq_kernel, dim3(div_up(2 * n, 256)), dim3(256), 0, s, d);
     // profile lengths -> cell slots (also the algorithmic byte count of the call)
-    MI_HIP(hipMemsetAsync(h->len2.ptr + n, 0, sizeof(int), s));
+    MI_HIP(hipMemsetAsync(st.len2.ptr + n, 0, sizeof(int), s));
     size_t bytes = 0;
-    MI_HIP(rocprim::exclusive_scan(nullptr, bytes, h->len2.ptr, h->cellptr.ptr, 0ll, (size_t)(n + 1), rocprim::plus<long long>(), s));
-    ensure_tmp(h, bytes);
-    bytes = h->cub_tmp.count;
-    MI_HIP(rocprim::exclusive_scan(h->cub_tmp.ptr, bytes, h->len2.ptr, h->cellptr.ptr, 0ll, (size_t)(n + 1), rocprim::plus<long long>(), s));
+    MI_HIP(rocprim::exclusive_scan(nullptr, bytes, st.len2.ptr, st.cellptr.ptr, 0ll, (size_t)(n + 1), rocprim::plus<long long>(), s));
+    ensure_tmp(h->sched_tmp, bytes, s);
+    bytes = h->sched_tmp.count;
+    MI_HIP(rocprim::exclusive_scan(h->sched_tmp.ptr, bytes, st.len2.ptr, st.cellptr.ptr, 0ll, (size_t)(n + 1), rocprim::plus<long long>(), s));
     long long n_cells = 0;
-    MI_HIP(hipMemcpyAsync(&n_cells, h->cellptr.ptr + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+    int n_short = n;
+    if (h->cfg.symmetric) {
+        // the two queues of the symmetric store's kernel: profiles of up to FLOW_BLOCK entries (a wavefront each), longer ones (a workgroup each)
+        const ShortProfile is_short{st.len2.ptr};
+        bytes = 0;
+        MI_HIP(rocprim::partition(nullptr, bytes, rocprim::counting_iterator<int>(0), st.order.ptr, st.n_short_dev.ptr, (size_t)n, is_short, s));
+        ensure_tmp(h->sched_tmp, bytes, s);
+        bytes = h->sched_tmp.count;
+        MI_HIP(rocprim::partition(h->sched_tmp.ptr, bytes, rocprim::counting_iterator<int>(0), st.order.ptr, st.n_short_dev.ptr, (size_t)n, is_short, s));
+        MI_HIP(hipMemcpyAsync(&n_short, st.n_short_dev.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    MI_HIP(hipMemcpyAsync(&n_cells, st.cellptr.ptr + n, sizeof(long long), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
-    sum_profile += 0.5 * (double)n_cells;
-    MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(int) * 2, s));
-    if (sym) {
+    st.n_cells = n_cells;
+    st.n_short = n_short;
+    if (h->cfg.symmetric) {
         // per cell the step that touched it last: sort the (cell, step) pairs of the stream
         MI_REQUIRE(n_cells < (1ll << 31), "stream too long for the cell sort (%lld cells)", n_cells);
-        ensure_sort_capacity(h, (size_t)std::max<long long>(n_cells, 1024));
-        d.keys = h->keys.ptr; d.vals = h->vals.ptr; d.keys_sorted = h->keys_sorted.ptr; d.vals_sorted = h->vals_sorted.ptr;
-        d.pred = h->pred.ptr;
+        // (a buffer that grows is handed back to the block cache, which waits for the device -- and so for the dataflow kernel this
+        // schedule is meant to run behind: sized once, 25 % above the expected 2 nnz n / n_users cells of n uniformly drawn users)
+        const size_t roomy = std::max((size_t)(2.5 * (double)h->nnz * (double)n / (double)h->n_users) + 1024, (size_t)n_cells + (size_t)(n_cells >> 2));
+        if (h->sort_capacity < (size_t)n_cells) ensure_sort_capacity(h, roomy, s);
+        if (st.pred_capacity < (size_t)n_cells) {
+            MI_HIP(hipStreamSynchronize(h->stream));
+            st.pred.alloc(roomy);
+            st.pred_capacity = st.pred.count;
+        }
+        d = dep_params(h, st, n, first);
+        d.keys_sorted = h->keys_sorted.ptr; d.vals_sorted = h->vals_sorted.ptr;
         d.n_cells = n_cells;
         d.step_bits = bits_for((unsigned long long)n);
         const int cell_bits = bits_for((unsigned long long)h->n_items * ((unsigned long long)h->n_items + 1) / 2 + 1);
         d.no_cell = (unsigned)((1ull << cell_bits) - 1ull);
         hipLaunchKernelGGL(slim_cell_keys_kernel, dim3(div_up(n, 4)), dim3(256), 0, s, d);
-        sort_pairs(h, (size_t)n_cells, cell_bits + d.step_bits);
+        sort_pairs(h, h->keys_sorted.ptr, h->vals_sorted.ptr, (size_t)n_cells, cell_bits + d.step_bits, s);
         hipLaunchKernelGGL(slim_pred_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, s, d);
         hipLaunchKernelGGL(slim_desc_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d, 1);
+        MI_HIP(hipGetLastError());
+        MI_HIP(hipStreamSynchronize(s));
+    }
+    st.n = n;
+}
+
+struct Launched {
+    OwnerLease lease;
+    bool dense = false, profile = false;
+};
+
+// The dataflow kernel of a scheduled stream, enqueued on the handle's main stream.
+template <class T>
+void launch_stream(mi355rec_slim *h, StreamSet &st, int n, int first, Launched &L) {
+    hipStream_t s = h->stream;
+    SlimParams<T> p{};
+    const bool sym = h->cfg.symmetric != 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    L.profile = getenv("MI355REC_SLIM_PROF") != nullptr;
+    if (L.profile) {
+        if (!h->prof.ptr) h->prof.alloc(8 * (MAX_OWNERS + 1));
+        MI_HIP(hipMemsetAsync(h->prof.ptr, 0, sizeof(unsigned long long) * h->prof.count, s));
+    }
+    MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(int) * 4, s));
+    if (!flow_supported(h)) {
         if constexpr (std::is_same<T, double>::value) {
-            fill_params(h, p);
+            fill_params(h, st, p);
+            p.su += first; p.si += first; p.sj += first;
+            p.n_steps = n;
+            h->dispatch_timers.next(e0, e1, 1 << 30);
+            hipExtLaunchKernelGGL(slim_ordered_kernel, dim3(1), dim3(1024), 0, s, e0, e1, 0, p);
+        }
+    } else if (sym) {
+        if constexpr (std::is_same<T, double>::value) {
+            fill_params(h, st, p);
             p.su += first; p.si += first; p.sj += first;
             p.n_steps = n;
             h->tag_base += (unsigned)n;                  // (wraps after 4 G steps; a tag is compared only with the tag of a step of the same call)
             // steps in flight = wavefronts of the grid: more of them only adds pollers once the chain of dependent steps is the bound
-            const int wgs = env_int("MI355REC_SLIM_SYM_WGS", multiprocessor_count() * blocks_per_cu(slim_sym_flow_kernel, 0));
-            const int grid = std::max(1, std::min(div_up(n, FLOW_WAVES), wgs));
+            // (every workgroup has to be resident: at most what the device holds at once)
+            // ... leaving some compute units to the schedule of the next epoch (the kernel is bound by its chain of dependent
+            // steps, not by the number of steps in flight: 512 of them were as fast as 8 192)
+            const int per_cu = blocks_per_cu(slim_sym_flow_kernel, 0);
+            const int spare = schedules_ahead(h) ? std::max(0, std::min(multiprocessor_count() / 2, env_int("MI355REC_SLIM_SYM_SPARE_CUS", 64))) : 0;
+            const int fit = (multiprocessor_count() - spare) * per_cu;
+            const int most = std::max(2, std::min(env_int("MI355REC_SLIM_SYM_WGS", fit), fit));
+            // a quarter of them for the long profiles (14 % of the steps at the ML-20M shape, a workgroup each)
+            const int n_long = n - st.n_short;
+            const int long_wgs = std::min(n_long, std::max(1, std::min(most - 1, env_int("MI355REC_SLIM_SYM_LONG_WGS", most / 4))));
+            const int grid = long_wgs + std::max(1, std::min(div_up(st.n_short, FLOW_WAVES), most - long_wgs));
             h->dispatch_timers.next(e0, e1, 1 << 30);
-            hipExtLaunchKernelGGL(slim_sym_flow_kernel, dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p);
+            hipExtLaunchKernelGGL(slim_sym_flow_kernel, dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p, long_wgs);
         }
     } else {
-        // the busiest rows of this stream get owners (if this launch holds the lease and a row fits the LDS)
+        L.dense = true;
+        ensure_launch_capacity(h, st.capacity);
+        DepParams d = dep_params(h, st, n, first);
+        // the busiest rows of this stream get owners (if this launch gets compute units leased and a row fits the LDS)
         const size_t row_bytes = ((size_t)h->n_items * sizeof(float) + 15) & ~(size_t)15;
         auto kernel = slim_dense_flow_kernel<T>;
         int max_owners = std::min(MAX_OWNERS, env_int("MI355REC_SLIM_OWNERS", 128));
         const bool wanted = max_owners > 0 && row_bytes + 4096 <= 160 * 1024 && !h->cfg.train_with_sparse_weights;
-        OwnerLease lease(wanted, std::max(32, std::min(multiprocessor_count(), env_int("MI355REC_SLIM_CUS", multiprocessor_count()))));
-        const bool owners = lease.slots > 0;
+        L.lease.take(wanted, std::max(32, std::min(multiprocessor_count(), env_int("MI355REC_SLIM_CUS", multiprocessor_count()))));
+        const bool owners = L.lease.slots > 0;
         const size_t lds = owners ? row_bytes : 0;
         if (lds > 48 * 1024) MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // with owners: one workgroup per leased compute unit (they must all be resident); without: whatever fits
-        const int grid = owners ? lease.slots : multiprocessor_count() * blocks_per_cu(kernel, 0);
+        const int grid = owners ? L.lease.slots : multiprocessor_count() * blocks_per_cu(kernel, 0);
         max_owners = std::min(max_owners, grid / 2);
         MI_HIP(hipMemsetAsync(h->hot_rank.ptr, 0xFF, sizeof(int) * (size_t)h->n_items, s));
         MI_HIP(hipMemsetAsync(h->counters.ptr, 0, sizeof(int) * 2, s));
+        size_t bytes = 0;
         if (owners) {
-            bytes = 0;
-            MI_HIP(rocprim::radix_sort_pairs_desc(nullptr, bytes, h->item_cnt.ptr, h->cnt_sorted.ptr, h->iota.ptr, h->item_by_cnt.ptr,
+            MI_HIP(rocprim::radix_sort_pairs_desc(nullptr, bytes, st.item_cnt.ptr, h->cnt_sorted.ptr, h->iota.ptr, h->item_by_cnt.ptr,
                                                   (size_t)h->n_items, 0, 32, s));
-            ensure_tmp(h, bytes);
-            bytes = h->cub_tmp.count;
-            MI_HIP(rocprim::radix_sort_pairs_desc(h->cub_tmp.ptr, bytes, h->item_cnt.ptr, h->cnt_sorted.ptr, h->iota.ptr, h->item_by_cnt.ptr,
+            ensure_tmp(h->launch_tmp, bytes, s);
+            bytes = h->launch_tmp.count;
+            MI_HIP(rocprim::radix_sort_pairs_desc(h->launch_tmp.ptr, bytes, st.item_cnt.ptr, h->cnt_sorted.ptr, h->iota.ptr, h->item_by_cnt.ptr,
                                                   (size_t)h->n_items, 0, 32, s));
             d.max_owners = max_owners;
             d.min_steps = std::max(2, env_int("MI355REC_SLIM_OWNER_MIN_STEPS", 24));
             hipLaunchKernelGGL(slim_owners_kernel, dim3(1), dim3(256), 0, s, d);
-            MI_HIP(hipMemsetAsync(h->mail.ptr, 0xFF, sizeof(unsigned long long) * 2 * h->stream_capacity, s));
+            MI_HIP(hipMemsetAsync(h->mail.ptr, 0xFF, sizeof(unsigned long long) * 2 * h->launch_capacity, s));
         }
         hipLaunchKernelGGL(slim_desc_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d, 0);
         if (owners) hipLaunchKernelGGL(slim_owner_desc_kernel, dim3(div_up(2 * n, 256)), dim3(256), 0, s, d);
         bytes = 0;
         MI_HIP(rocprim::select(nullptr, bytes, h->desc.ptr, h->cold_flag.ptr, h->cold_desc.ptr, h->counters.ptr + 1, (size_t)n, s));
-        ensure_tmp(h, bytes);
-        bytes = h->cub_tmp.count;
-        MI_HIP(rocprim::select(h->cub_tmp.ptr, bytes, h->desc.ptr, h->cold_flag.ptr, h->cold_desc.ptr, h->counters.ptr + 1, (size_t)n, s));
+        ensure_tmp(h->launch_tmp, bytes, s);
+        bytes = h->launch_tmp.count;
+        MI_HIP(rocprim::select(h->launch_tmp.ptr, bytes, h->desc.ptr, h->cold_flag.ptr, h->cold_desc.ptr, h->counters.ptr + 1, (size_t)n, s));
         MI_HIP(hipMemsetAsync(h->ticket.ptr, 0, sizeof(int) * (size_t)h->n_items, s));
-        fill_params(h, p);
+        fill_params(h, st, p);
         p.su += first; p.si += first; p.sj += first;
         p.n_steps = n;
         h->dispatch_timers.next(e0, e1, 1 << 30);
         hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(FLOW_THREADS), lds, s, e0, e1, 0, p, owners ? 1 : 0);
-        MI_HIP(hipGetLastError());
-        int counters[2] = {0, 0};
-        MI_HIP(hipMemcpyAsync(counters, h->counters.ptr, sizeof(counters), hipMemcpyDeviceToHost, s));
-        MI_HIP(hipStreamSynchronize(s));                 // (the lease is held until the kernel has ended)
-        h->last_owners = counters[0];
-        h->last_cold = counters[1];
     }
     h->stats.n_launches += 1;
     MI_HIP(hipGetLastError());
-    int flags[2] = {0, 0};
+}
+
+// Waits for the launch, gives the leased compute units back, fails if the kernel gave up on a hand-off.
+void finish_stream(mi355rec_slim *h, Launched &L, int n) {
+    hipStream_t s = h->stream;
+    int flags[2] = {0, 0}, counters[2] = {0, 0};
     MI_HIP(hipMemcpyAsync(flags, h->queue.ptr, sizeof(flags), hipMemcpyDeviceToHost, s));
+    if (L.dense) MI_HIP(hipMemcpyAsync(counters, h->counters.ptr, sizeof(counters), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
+    L.lease.give_back();
+    if (L.dense) {
+        h->last_owners = counters[0];
+        h->last_cold = counters[1];
+    }
     if (flags[1]) fail(MI355REC_E_HIP, "SLIM-BPR: a hand-off between steps did not arrive (dataflow kernel aborted)");
-    if (profile) {
+    if (L.profile) {
         std::vector<unsigned long long> c(h->prof.count);
         MI_HIP(hipMemcpy(c.data(), h->prof.ptr, sizeof(unsigned long long) * c.size(), hipMemcpyDeviceToHost));
-        if (sym) {
-            fprintf(stderr, "[slim prof] symmetric: %llu steps, mean cycles: until all tags were there %.0f, rest %.0f; %.2f extra polling rounds per step\n",
+        if (h->cfg.symmetric) {
+            fprintf(stderr, "[slim prof] symmetric: %llu steps by a wavefront, mean cycles: until all tags were there %.0f, rest %.0f; %.2f extra polling rounds per step\n",
                     c[0], (double)c[1] / std::max(1ull, c[0]), (double)c[2] / std::max(1ull, c[0]), (double)c[3] / std::max(1ull, c[0]));
+            fprintf(stderr, "[slim prof] symmetric: %llu steps by a workgroup, mean cycles: until all tags were there %.0f, rest %.0f; %.2f extra polling rounds per step\n",
+                    c[4], (double)c[5] / std::max(1ull, c[4]), (double)c[6] / std::max(1ull, c[4]), (double)c[7] / std::max(1ull, c[4]));
         } else {
             for (int o = 0; o < h->last_owners; o += std::max(1, h->last_owners / 8)) {
                 const unsigned long long *q = c.data() + 8 * o;
@@ -1580,6 +1840,17 @@ void run_stream(mi355rec_slim *h, int n, double &sum_profile, int first = 0) {
     h->steps_done += n;
 }
 
+// Steps first .. first + n - 1 of a set, scheduled and run on the main stream, one thing after the other.
+template <class T>
+void run_stream(mi355rec_slim *h, StreamSet &st, int n, double &sum_profile, int first = 0) {
+    schedule_stream(h, st, n, first, h->stream);
+    sum_profile += 0.5 * (double)st.n_cells;
+    Launched L;
+    launch_stream<T>(h, st, n, first, L);
+    finish_stream(h, L, n);
+    st.epoch = -1;
+}
+
 void prune_rows(mi355rec_slim *h, int with_diag) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     h->dispatch_timers.next(e0, e1, 1 << 30);
@@ -1589,13 +1860,13 @@ void prune_rows(mi355rec_slim *h, int with_diag) {
     MI_HIP(hipGetLastError());
 }
 
-// One epoch of n steps on whichever store the handle has.  Sparse store: the stream is cut after every step whose index is a
-// positive multiple of n / 5 -- `numCurrentBatch % (totalNumberOfBatch/5) == 0 and numCurrentBatch != 0` with C integer
+// One epoch of n steps of a set, scheduled and run on the main stream.  Sparse store: the stream is cut after every step whose
+// index is a positive multiple of n / 5 -- `numCurrentBatch % (totalNumberOfBatch/5) == 0 and numCurrentBatch != 0` with C integer
 // division (.pyx:320-324; the module sets cdivision) -- and the rows are pruned there.
 template <class T>
-void run_epoch_stream(mi355rec_slim *h, int n, double &sum_profile) {
+void run_epoch_stream(mi355rec_slim *h, StreamSet &st, int n, double &sum_profile) {
     if (!h->cfg.train_with_sparse_weights || n < 5) {
-        run_stream<T>(h, n, sum_profile);
+        run_stream<T>(h, st, n, sum_profile);
         return;
     }
     const int every = n / 5;
@@ -1604,7 +1875,7 @@ void run_epoch_stream(mi355rec_slim *h, int n, double &sum_profile) {
         // steps first .. cut (inclusive) run, then the rows are pruned if `cut` is a rebalance point
         const int cut = std::max(1, (first + every - 1) / every) * every;      // next multiple of `every` at or after `first`, never step 0
         const int last = std::min(cut, n - 1);
-        run_stream<T>(h, last - first + 1, sum_profile, first);
+        run_stream<T>(h, st, last - first + 1, sum_profile, first);
         if (cut <= n - 1) prune_rows(h, 0);
         first = last + 1;
     }
@@ -1636,16 +1907,36 @@ void end_call(mi355rec_slim *h, long long n_steps, double sum_profile) {
 template <class T>
 void run_epochs_typed(mi355rec_slim *h, int n_epochs) {
     const int n = h->n_users + 1;                            // totalNumberOfBatch with batch_size 1 (.pyx:215)
-    ensure_capacity(h, (size_t)n);
+    ensure_set_capacity(h, h->set[0], (size_t)n);
+    ensure_set_capacity(h, h->set[1], (size_t)n);
     begin_call(h);
     double sum_profile = 0;
+    const bool ahead = schedules_ahead(h);
     for (int e = 0; e < n_epochs; ++e) {
-        SlimParams<T> p{};
-        fill_params(h, p);
-        p.n_steps = n;
-        hipLaunchKernelGGL(slim_sample_kernel<T>, dim3(div_up(n, 256)), dim3(256), 0, h->stream, p, h->su.ptr, h->si.ptr, h->sj.ptr);
-        run_epoch_stream<T>(h, n, sum_profile);
+        const long long epoch = h->epochs_done;
+        StreamSet &st = h->set[h->cur ^ 1];
+        if (!ahead) {
+            draw_epoch<T>(h, st, epoch, n, h->stream);
+            run_epoch_stream<T>(h, st, n, sum_profile);
+        } else {
+            if (!(st.epoch == epoch && st.n == n)) {            // (first epoch of the handle, or a replayed stream took the set)
+                draw_epoch<T>(h, st, epoch, n, h->side);
+                schedule_stream(h, st, n, 0, h->side);
+                st.epoch = epoch;
+            }
+            sum_profile += 0.5 * (double)st.n_cells;
+            Launched L;
+            launch_stream<T>(h, st, n, 0, L);
+            // ... and while it runs: the next epoch's stream, into the other set (kept for the next call if this was the last)
+            StreamSet &nx = h->set[h->cur];
+            draw_epoch<T>(h, nx, epoch + 1, n, h->side);
+            schedule_stream(h, nx, n, 0, h->side);
+            nx.epoch = epoch + 1;
+            finish_stream(h, L, n);
+        }
+        h->cur ^= 1;
         h->epochs_done += 1;
+        h->last_native = true;
     }
     end_call(h, (long long)n * n_epochs, sum_profile);
 }
@@ -1662,7 +1953,7 @@ void get_topk_typed(mi355rec_slim *h, int topK, int *nbr_idx, float *nbr_val) {
     d_idx.alloc(n_out);
     d_val.alloc(n_out);
     SlimParams<T> p{};
-    fill_params(h, p);
+    fill_params(h, h->set[h->cur], p);
     auto k = slim_topk_kernel<T, 1024>;
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds + 2048))));
@@ -1680,7 +1971,7 @@ void get_dense_typed(mi355rec_slim *h, float *S) {
     DeviceBuffer<float> out;
     out.alloc(n2);
     SlimParams<T> p{};
-    fill_params(h, p);
+    fill_params(h, h->set[h->cur], p);
     hipLaunchKernelGGL(slim_dense_kernel<T>, dim3((unsigned)std::min<size_t>((n2 + 255) / 256, 8192)), dim3(256), 0, h->stream, p, out.ptr);
     MI_HIP(hipGetLastError());
     out.download(S, n2, h->stream);
@@ -1712,14 +2003,13 @@ extern "C" int mi355rec_slim_create(mi355rec_slim_t *out, const mi355rec_slim_co
         h->nnz = (size_t)indptr[n_users];
         MI_REQUIRE(h->nnz > 0, "URM has no interactions");
         MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        MI_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
         h->call_timer.init();
         h->dispatch_timers.reserve(64);
         hipStream_t s = h->stream;
         const size_t ts = h->f64 ? sizeof(double) : sizeof(float);
         h->indptr.upload(indptr, (size_t)n_users + 1, s);
         h->indices.upload(indices, h->nnz, s);
-        h->run_start.alloc_zero((size_t)n_items, s);
-        h->item_cnt.alloc_zero((size_t)n_items, s);
         if (h->cfg.symmetric) {
             // Triangular_Matrix :1237-1254 the packed lower triangle
             h->G.alloc_zero((size_t)n_items * ((size_t)n_items + 1) / 2, s);
@@ -1742,7 +2032,7 @@ extern "C" int mi355rec_slim_create(mi355rec_slim_t *out, const mi355rec_slim_co
             h->iota.upload(iota.data(), iota.size(), s);
             MI_HIP(hipStreamSynchronize(s));                         // (iota is read from host memory)
         }
-        h->queue.alloc_zero(2, s);
+        h->queue.alloc_zero(4, s);
         h->loss_slots.alloc_zero(LOSS_SLOTS, s);
         MI_HIP(hipStreamSynchronize(s));
         *out = h.release();
@@ -1764,18 +2054,22 @@ extern "C" int mi355rec_slim_run_samples(mi355rec_slim_t h, const int32_t *u, co
         MI_REQUIRE(n >= 0 && n < (1ll << 30), "n out of range");
         ensure_device();
         if (n == 0) return;
-        ensure_capacity(h, (size_t)n);
+        StreamSet &st = h->set[h->cur ^ 1];                  // (a stream scheduled ahead for the next native epoch, if any, is given up)
+        ensure_set_capacity(h, st, (size_t)n);
+        st.epoch = -1;
         hipStream_t s = h->stream;
         for (int64_t t = 0; t < n; ++t)
             MI_REQUIRE(u[t] >= 0 && u[t] < h->n_users && i[t] >= 0 && i[t] < h->n_items && j[t] >= 0 && j[t] < h->n_items && i[t] != j[t],
                        "sample %lld out of range (or its positive item is its negative item)", (long long)t);
-        MI_HIP(hipMemcpyAsync(h->su.ptr, u, sizeof(int) * n, hipMemcpyHostToDevice, s));
-        MI_HIP(hipMemcpyAsync(h->si.ptr, i, sizeof(int) * n, hipMemcpyHostToDevice, s));
-        MI_HIP(hipMemcpyAsync(h->sj.ptr, j, sizeof(int) * n, hipMemcpyHostToDevice, s));
+        MI_HIP(hipMemcpyAsync(st.su.ptr, u, sizeof(int) * n, hipMemcpyHostToDevice, s));
+        MI_HIP(hipMemcpyAsync(st.si.ptr, i, sizeof(int) * n, hipMemcpyHostToDevice, s));
+        MI_HIP(hipMemcpyAsync(st.sj.ptr, j, sizeof(int) * n, hipMemcpyHostToDevice, s));
         begin_call(h);
         double sum_profile = 0;
         // (the n samples are ONE epoch of n steps: that is what the sparse store's rebalance rule counts against)
-        if (h->f64) run_epoch_stream<double>(h, (int)n, sum_profile); else run_epoch_stream<float>(h, (int)n, sum_profile);
+        if (h->f64) run_epoch_stream<double>(h, st, (int)n, sum_profile); else run_epoch_stream<float>(h, st, (int)n, sum_profile);
+        h->cur ^= 1;
+        h->last_native = false;
         end_call(h, n, sum_profile);
     });
 }
@@ -1784,12 +2078,13 @@ extern "C" int mi355rec_slim_get_last_samples(mi355rec_slim_t h, int32_t *u, int
     return guarded([&] {
         MI_REQUIRE(h && n, "NULL argument");
         ensure_device();
-        const int64_t have = h->epochs_done > 0 ? h->n_users + 1 : 0;
+        const int64_t have = h->epochs_done > 0 && h->last_native ? h->n_users + 1 : 0;
         *n = have;
         const size_t m = (size_t)std::min<int64_t>(cap, have);
-        if (u) h->su.download(u, m, h->stream);
-        if (i) h->si.download(i, m, h->stream);
-        if (j) h->sj.download(j, m, h->stream);
+        const StreamSet &st = h->set[h->cur];
+        if (u && m) st.su.download(u, m, h->stream);
+        if (i && m) st.si.download(i, m, h->stream);
+        if (j && m) st.sj.download(j, m, h->stream);
         MI_HIP(hipStreamSynchronize(h->stream));
     });
 }

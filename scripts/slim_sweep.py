@@ -46,3 +46,18 @@ if which in ("symmetric", "both"):
     run(True, "default + phase clocks", MI355REC_SLIM_PROF=1)
     for wgs in (8, 16, 32, 64, 128, 256):
         run(True, "%d workgroups (%d steps in flight)" % (wgs, wgs * 16), MI355REC_SLIM_SYM_WGS=wgs)
+if which == "presched":
+    # the next epoch's schedule behind the running kernel (default) against one thing after the other, one epoch per call and four
+    for sym in (False, True):
+        run(sym, "schedule ahead (default)")
+        run(sym, "no schedule ahead", MI355REC_SLIM_NO_PRESCHED=1)
+    run(True, "default + phase clocks", MI355REC_SLIM_PROF=1)
+    for spare in (0, 8, 16, 64, 96):
+        run(True, "%d compute units left free" % spare, MI355REC_SLIM_SYM_SPARE_CUS=spare)
+    run(True, "32 free, 96 workgroups for long profiles", MI355REC_SLIM_SYM_LONG_WGS=96)
+    ep = SLIM_BPR_MI355X_Epoch(X, symmetric=True, topK=100, learning_rate=1e-4, sgd_mode="adagrad", random_seed=3)
+    ep.epochIteration_Cython()
+    t = time.perf_counter()
+    for _ in range(4):
+        ep.epochIteration_Cython()
+    print("symmetric, one epoch per call: %.3f ms per epoch" % ((time.perf_counter() - t) / 4 * 1e3))
