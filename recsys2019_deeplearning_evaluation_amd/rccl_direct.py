@@ -21,6 +21,10 @@ class _UniqueId(C.Structure):
     _fields_ = [("internal", C.c_char * NCCL_UNIQUE_ID_BYTES)]
 
 
+def _unique_id_bytes(uid):
+    return C.string_at(C.byref(uid), NCCL_UNIQUE_ID_BYTES)
+
+
 def _load_rccl():
     last = None
     for name in (os.environ.get("MI355REC_RCCL_LIBRARY"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"):
@@ -130,7 +134,10 @@ class RcclCommunicator:
         uid = _UniqueId()
         if self.rank == 0:
             self._check(self._lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        raw = exchange_unique_id(bytes(uid.internal) if self.rank == 0 else b"", self.rank, self.world, address, port)
+        # (all 128 bytes: reading the c_char array field itself would stop at the first NUL of the socket address inside)
+        raw = exchange_unique_id(_unique_id_bytes(uid) if self.rank == 0 else b"", self.rank, self.world, address, port)
+        if len(raw) != NCCL_UNIQUE_ID_BYTES:
+            raise N.NativeLibraryError("RCCL rendezvous: got %d bytes of unique id, expected %d" % (len(raw), NCCL_UNIQUE_ID_BYTES))
         C.memmove(C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
         self._comm = C.c_void_p()
         self._check(self._lib.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")

@@ -32,6 +32,15 @@ def test_unique_id_rendezvous_over_tcp():
     assert rccl_direct.exchange_unique_id(payload, 0, 1, "127.0.0.1", port) == payload
 
 
+def test_unique_id_travels_whole():
+    """The id holds a socket address: NUL bytes in the middle (this is what kept RCCL from initialising through the binding)."""
+    import ctypes as C
+    uid = rccl_direct._UniqueId()
+    raw = bytes([2, 0, 0x7f, 0, 0, 1] + [0] * 10 + list(range(1, 113)))
+    C.memmove(C.byref(uid), raw, 128)
+    assert rccl_direct._unique_id_bytes(uid) == raw
+
+
 def test_librccl_exports_what_the_binding_uses():
     lib = rccl_direct._load_rccl()
     for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclCommDestroy", "ncclGetErrorString", "ncclCommCount",
