@@ -359,7 +359,7 @@ def other_paths(urm, args):
     note("paths: adagrad, funk")
     mf_run("bpr_mf_k128_batch1000_adagrad", 50, "float64 factors + moments (adaptive optimisers)", algorithm_name="MF_BPR",
            batch_size=BATCH, sgd_mode="adagrad")
-    mf_run("funk_svd_k128_batch1000_bias", 1, "20 001 mini-batches per epoch, general (radix-sort) schedule", algorithm_name="FUNK_SVD",
+    mf_run("funk_svd_k128_batch1000_bias", 1, "20 001 mini-batches per epoch, in-LDS schedule 256 mini-batches at a time", algorithm_name="FUNK_SVD",
            batch_size=BATCH, sgd_mode="sgd", use_bias=True, negative_interactions_quota=0.0)
     if cpu:
         out["funk_svd_k128_batch1000_bias"]["cpu_baseline"] = cpu_baseline_funk(urm, args.cpu_seconds)

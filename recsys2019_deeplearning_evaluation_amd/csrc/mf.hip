@@ -586,15 +586,34 @@ __device__ __forceinline__ void mf_sched_finish_body(const FastSchedParams &s) {
 }
 __global__ __launch_bounds__(256) void mf_sched_finish_kernel(const FastSchedParams s) { mf_sched_finish_body(s); }
 
+// The global-bias ring is indexed by the mini-batch's position in its STREAM (a kernel knows that from its arguments: the ring
+// entry is requested together with everything else, not after the global index has arrived).  A stream of n mini-batches leaves
+// the newest state and terms in entry (n - 1) % 3; mini-batch 0 of the next stream looks for them in entry 2 and adds its own
+// terms to entry 0.
 template <class T>
-__global__ void mf_stream_end_kernel(const MfParams<T> p, const long long n_batches) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) p.state->batch_base += n_batches;
+__device__ __forceinline__ void ring_to_stream_start(const MfParams<T> &p, const long long n_batches, const int slot) {
+    if (n_batches <= 0) return;
+    const int src = (int)((n_batches - 1) % 3);
+    if (src != 2) {
+        if (slot == 0) p.mu_state[2] = p.mu_state[src];
+        p.mu_acc[2 * MU_SLOTS + slot] = p.mu_acc[src * MU_SLOTS + slot];
+    }
+    p.mu_acc[slot] = (T)0;
+}
+
+template <class T>
+__global__ void mf_stream_end_kernel(const MfParams<T> p, const long long n_batches) {      // one wavefront
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x == 0) p.state->batch_base += n_batches;
+    if (threadIdx.x < MU_SLOTS) ring_to_stream_start(p, n_batches, (int)threadIdx.x);
 }
 
 template <class T>
 __global__ void mf_group_stream_end_kernel(const MfParams<T> *table, const int n_models, const long long n_batches) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < n_models) table[m].state->batch_base += n_batches;
+    if (m >= n_models) return;
+    table[m].state->batch_base += n_batches;
+    for (int slot = 0; slot < MU_SLOTS; ++slot) ring_to_stream_start(table[m], n_batches, slot);
 }
 
 // ---- the mini-batch --------------------------------------------------------------------------------------------------
@@ -628,8 +647,7 @@ template <class T, class P> __device__ __forceinline__ void adam_powers(const P 
 template <class T> struct MuRequest { MuState<T> st; T part; };
 
 template <class T>
-__device__ __forceinline__ MuRequest<T> global_bias_request(const MfParams<T> &p, long long gb, int lane) {
-    const int prev = (int)((gb + 2) % 3);
+__device__ __forceinline__ MuRequest<T> global_bias_request(const MfParams<T> &p, const int prev, int lane) {
     MuRequest<T> r;
     r.st = p.mu_state[prev];
     r.part = p.mu_acc[prev * MU_SLOTS + lane];
@@ -637,8 +655,8 @@ __device__ __forceinline__ MuRequest<T> global_bias_request(const MfParams<T> &p
 }
 
 template <class T>
-__device__ __forceinline__ T global_bias_finish(const MfParams<T> &p, MuRequest<T> r, long long gb, bool writer, int lane) {
-    const int cur = (int)(gb % 3), nxt = (int)((gb + 1) % 3);
+__device__ __forceinline__ T global_bias_finish(const MfParams<T> &p, MuRequest<T> r, long long gb, const int at, bool writer, int lane) {
+    const int cur = at % 3, nxt = (at + 1) % 3;                   // `at`: position in the stream, gb: global index
     MuState<T> st = r.st;
     const T sum = wave_sum(r.part);
     if (gb > 0) {
@@ -655,8 +673,8 @@ __device__ __forceinline__ T global_bias_finish(const MfParams<T> &p, MuRequest<
 }
 
 template <class T>
-__device__ __forceinline__ T global_bias_at(const MfParams<T> &p, long long gb, bool writer, int lane) {
-    return global_bias_finish(p, global_bias_request(p, gb, lane), gb, writer, lane);
+__device__ __forceinline__ T global_bias_at(const MfParams<T> &p, long long gb, const int at, bool writer, int lane) {
+    return global_bias_finish(p, global_bias_request(p, (at + 2) % 3, lane), gb, at, writer, lane);
 }
 
 // the three rows of one sample, KI chunks of VEC elements per lane
@@ -699,19 +717,44 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
     using R = Rows<T, VEC, KI, BPR>;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((wg * p.wg_stride + p.wg_base) * 4 + (threadIdx.x >> 6));
+    // Every kernel argument the start of the kernel needs is requested in ONE batch of scalar loads: left to itself the compiler
+    // fetched them piecewise as the code came to need them -- three waits for a cold kernarg segment before FunkSVD's header load
+    // was even issued, one for BPR's.
+    asm volatile("" ::"s"(p.tasks), "s"(p.tasks_per_batch), "s"(p.wg_base), "s"(p.wg_stride), "s"(p.ticks), "s"(p.use_bias), "s"(p.sgd_mode),
+                 "s"(p.state), "s"(p.mu_state), "s"(p.mu_acc), "s"(p.k), "s"(p.U0), "s"(p.U1), "s"(p.V0), "s"(p.V1), "s"(p.recs));
     const unsigned long long tk0 = p.ticks ? stamp() : 0ull;
     // every wave-uniform input is requested before the first one is waited for (scalar loads, one wait)
     // (unused task slots of a batch are zero: a header with no samples means there is nothing to do)
     // (the grid is rounded up to whole workgroups: wavefronts past the batch's last slot re-read that slot and idle)
-    const TaskHeader *hp = p.tasks + ((size_t)batch_local * p.tasks_per_batch + min(wv, p.tasks_per_batch - 1));
-    const int8v hd = *reinterpret_cast<const int8v *>(hp);      // one 32-byte scalar load: header and first record
-    // (the kernel arguments the row gathers need are requested now, next to the header, rather than in a second scalar
-    // round trip after the header has arrived; the statement sits after the load because a side effect before it would
-    // stop the compiler from using the scalar cache for the header)
     const bool bias = !BPR && p.use_bias;
-    long long gb = batch_local;                                  // global mini-batch index: only Adam and the global bias need it
-    if (bias || p.sgd_mode == MI355REC_ADAM) gb += p.state->batch_base;
+    long long gb = batch_local;
+    const TaskHeader *hp = p.tasks + ((size_t)batch_local * p.tasks_per_batch + min(wv, p.tasks_per_batch - 1));
+    const int8v hd = *reinterpret_cast<const int8v *>(hp);      // one 32-byte load: header and first record
+    // The global mini-batch index (Adam and the global bias need it) and the global-bias ring entry are requested right behind the
+    // header (the wait for the header does not cover younger loads; both were written by the kernel before this one and take
+    // 2 400 cycles to arrive where the header, last written by the schedule, takes 900) -- not after it has arrived, and the ring
+    // not after the index: a FunkSVD kernel began with three round trips one after the other.  Unconditionally for FunkSVD: a
+    // branch around a load makes the compiler wait for it before the next one is issued.
+    long long batch_base = 0;
+    MuRequest<T> mu_req;
+    mu_req.st = MuState<T>{};
+    mu_req.part = (T)0;
+    if constexpr (!BPR) {
+        // (through a zero the compiler cannot see: it moves the result of a load it knows to be wave-uniform into scalar
+        // registers on the spot, which is a wait for these loads in front of the row gathers)
+        int zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+        batch_base = (&p.state->batch_base)[zero];
+        mu_req = global_bias_request(p, (batch_local + 2) % 3 + zero, lane);
+    }
+    // (the kernel arguments the row gathers need are requested now, next to the header, rather than in a second scalar
+    // round trip after the header has arrived)
     asm volatile("" ::"s"(p.k), "s"(p.U0), "s"(p.U1), "s"(p.V0), "s"(p.V1), "s"(p.recs));
+    if constexpr (BPR) {
+        if (p.sgd_mode == MI355REC_ADAM) gb += p.state->batch_base;
+    } else {
+        gb += batch_base;
+    }
     const int4 h0 = make_int4(hd[0], hd[1], hd[2], hd[3]), h1 = make_int4(hd[4], hd[5], hd[6], hd[7]);
     const bool active = (h0.y & LEN_MASK) != 0 && wv < p.tasks_per_batch;
     __shared__ T s_mu[4];
@@ -721,9 +764,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
     T mu_eff = (T)0;
     unsigned long long tk1 = 0, tk2 = 0, tk3 = 0;
     if (p.ticks) tk1 = stamp();          // header has arrived (its value decided `active`)
-    MuRequest<T> mu_req{};
-    if (bias) mu_req = global_bias_request(p, gb, lane);
-    if (bias && !active) mu_eff = global_bias_finish(p, mu_req, gb, wv == 0, lane);      // (wavefront 0 files the value either way)
+    if (bias && !active) mu_eff = global_bias_finish(p, mu_req, gb, batch_local, wv == 0, lane);      // (wavefront 0 files the value either way)
     if (active) {
         const int entry = h0.x, len = h0.y & LEN_MASK, own_par = (unsigned)h0.y >> 31, start = h0.z;
         // a wide task (list longer than two rounds of a wavefront) owns the 4 wavefronts of this workgroup: quarter `part` takes list
@@ -752,7 +793,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
         int4 rec_n = rec;
         if (iters > 1) rec_n = p.recs[start + min(base + step + g, len - 1)];
         R rows = load_rows<T, VEC, LPR, KI, BPR>(p, rec, li, cok, bias);
-        if (bias) mu_eff = global_bias_finish(p, mu_req, gb, wv == 0, lane);               // folded behind the gathers just issued
+        if (bias) mu_eff = global_bias_finish(p, mu_req, gb, batch_local, wv == 0, lane);   // folded behind the gathers just issued
         T pw1, pw2;
         adam_powers(p, gb + 1, pw1, pw2);
 
@@ -939,7 +980,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
         __syncthreads();
         if (threadIdx.x == 0) {
             const T sum = (s_mu[0] + s_mu[1]) + (s_mu[2] + s_mu[3]);
-            if (sum != (T)0) atomicAdd(&p.mu_acc[(int)(gb % 3) * MU_SLOTS + (wg & (MU_SLOTS - 1))], sum);
+            if (sum != (T)0) atomicAdd(&p.mu_acc[(batch_local % 3) * MU_SLOTS + (wg & (MU_SLOTS - 1))], sum);
         }
     }
     if (p.ticks && lane == 0 && wv < p.tasks_per_batch) {
@@ -1050,7 +1091,7 @@ __global__ __launch_bounds__(256) void mf_batch_generic_kernel(const MfParams<T>
     if (active || bias) {
         const long long gb = p.state->batch_base + batch_local;
         T mu_eff = (T)0;
-        if (bias) mu_eff = global_bias_at(p, gb, wv == 0, lane);
+        if (bias) mu_eff = global_bias_at(p, gb, batch_local, wv == 0, lane);
         if (active) {
             const int entry = h0.x, len = h0.y & LEN_MASK, own_par = (unsigned)h0.y >> 31, start = h0.z;
             const int k = p.k;
@@ -1133,8 +1174,7 @@ __global__ __launch_bounds__(256) void mf_batch_generic_kernel(const MfParams<T>
         __syncthreads();
         if (threadIdx.x == 0) {
             const T sum = (s_mu[0] + s_mu[1]) + (s_mu[2] + s_mu[3]);
-            const long long gb = p.state->batch_base + batch_local;
-            if (sum != (T)0) atomicAdd(&p.mu_acc[(int)(gb % 3) * MU_SLOTS + (blockIdx.x & (MU_SLOTS - 1))], sum);
+            if (sum != (T)0) atomicAdd(&p.mu_acc[(batch_local % 3) * MU_SLOTS + (blockIdx.x & (MU_SLOTS - 1))], sum);
         }
     }
 }
@@ -1182,7 +1222,7 @@ __global__ __launch_bounds__(256) void mf_gather_rows_kernel(const T *b0, const 
 template <class T, class O>
 __global__ void mf_final_mu_kernel(const MfParams<T> p, O *out) {
     const int lane = threadIdx.x & 63;
-    const T mu = global_bias_at(p, p.state->batch_base, false, lane);
+    const T mu = global_bias_at(p, p.state->batch_base, 0, false, lane);      // (between streams: the ring stands at a stream's start)
     if (threadIdx.x == 0) out[0] = (O)mu;
 }
 
@@ -1420,13 +1460,19 @@ struct mi355rec_mf {
     DeviceBuffer<unsigned char> shard_send, shard_recv;
     int shard_rank = -1, shard_world = 0, shard_slots_per_rank = 0;
     long long shard_batches = 0;
-    hipGraphExec_t epoch_graph = nullptr;   // one native epoch: sampler, schedule, n_batches mini-batch kernels
+    // one native epoch: sampler, schedule, n_batches mini-batch kernels -- in graphs of up to GRAPH_SEGMENT mini-batches each
+    std::vector<hipGraphExec_t> epoch_graphs;
+    size_t general_capacity = 0;            // samples the radix-sort schedule's buffers hold
     bool graph_failed = false;
     std::vector<double> host_loss;
 
+    void drop_graphs() {
+        for (hipGraphExec_t g : epoch_graphs) (void)hipGraphExecDestroy(g);
+        epoch_graphs.clear();
+    }
     ~mi355rec_mf() {
         if (stream) (void)hipStreamSynchronize(stream);
-        if (epoch_graph) (void)hipGraphExecDestroy(epoch_graph);
+        drop_graphs();
         timer.destroy();
         dispatch_timers.destroy();
         if (stream) (void)hipStreamDestroy(stream);
@@ -1675,14 +1721,41 @@ void enqueue_schedule(mi355rec_mf *h, long long n_samples, long long n_batches) 
     hipLaunchKernelGGL(mf_recs_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, sp);
 }
 
+// Mini-batches per schedule.  A stream the in-LDS schedule cannot hold at once (more than FAST_MAX_BATCHES mini-batches: FunkSVD's
+// epoch at the ML-20M shape has 20 001) is scheduled and run FAST_MAX_BATCHES mini-batches at a time, each part a stream of its
+// own (its end moves the global batch index and the global-bias ring on): three schedule launches per 256 mini-batch launches,
+// against the radix-sort schedule of the whole stream they keep the split of long lists over a workgroup (a list of 10
+// held the kernel for 14 000 cycles where the median wavefront took 7 300), headers and records in 16 MB that stay cached instead of
+// 1.9 GB, and 1.5 GB of sort buffers are never allocated.  Whole stream: when it fits, when the in-LDS schedule is not available
+// for this handle, and in the exact multi-GPU mode (its exchange walks one schedule).
+long long schedule_span(const mi355rec_mf *h, long long n_batches) {
+    if (h->shard_rank < 0 && n_batches > FAST_MAX_BATCHES && fast_schedule_fits(h, 1) && !getenv("MI355REC_MF_WHOLE_STREAM_SCHEDULE"))
+        return FAST_MAX_BATCHES;
+    return n_batches;
+}
+
+// mini-batches first .. last - 1 of a stream of n_batches, with the schedules and stream ends that fall into that range
 template <class T>
-void enqueue_batches(mi355rec_mf *h, const MfParams<T> &p, long long n_batches, bool timed) {
+void enqueue_stream(mi355rec_mf *h, const MfParams<T> &p, long long n_samples, long long n_batches, bool timed, long long first = 0,
+                    long long last = -1) {
     const bool bpr = h->cfg.algorithm == MI355REC_MF_BPR;
-    for (long long b = 0; b < n_batches; ++b) {
-        if (bpr) launch_batch<MI355REC_MF_BPR, T>(h, p, (int)b, timed);
-        else launch_batch<MI355REC_MF_FUNK_SVD, T>(h, p, (int)b, timed);
+    const long long span = schedule_span(h, n_batches), B = h->cfg.batch_size;
+    if (last < 0) last = n_batches;
+    for (long long b = first; b < last; ++b) {
+        const long long part = b / span * span, local = b - part, part_batches = std::min(span, n_batches - part);
+        if (local == 0) {
+            if (span == n_batches) {
+                enqueue_schedule(h, n_samples, n_batches);
+            } else {
+                FastSchedParams f = fast_sched_params(h, std::min(n_samples - part * B, part_batches * B));
+                f.su += part * B; f.si += part * B; f.sj += part * B; f.sr += part * B;
+                enqueue_fast_schedule(h, f.n_samples, part_batches, &f);
+            }
+        }
+        if (bpr) launch_batch<MI355REC_MF_BPR, T>(h, p, (int)local, timed);
+        else launch_batch<MI355REC_MF_FUNK_SVD, T>(h, p, (int)local, timed);
+        if (local + 1 == part_batches) hipLaunchKernelGGL(mf_stream_end_kernel<T>, dim3(1), dim3(64), 0, h->stream, p, part_batches);
     }
-    hipLaunchKernelGGL(mf_stream_end_kernel<T>, dim3(1), dim3(64), 0, h->stream, p, n_batches);
 }
 
 constexpr int ASY_CHUNK = 1 << 16;   // steps per launch of the ordered AsySVD kernel (keeps single launches short)
@@ -1703,92 +1776,104 @@ void enqueue_asy_steps(mi355rec_mf *h, const MfParams<T> &p, long long n_steps, 
     }
 }
 
-// One native epoch as plain launches (the first `max_timed` mini-batch launches carry per-dispatch events when `timed`).
+// One native epoch as plain launches (the first `max_timed` mini-batch launches carry per-dispatch events when `timed`) -- or the
+// part of it that holds mini-batches first .. last - 1: sampler and schedule go with the first part.
 template <class T>
-void enqueue_epoch(mi355rec_mf *h, const MfParams<T> &p, bool timed) {
-    launch_sampler(h, p);
+void enqueue_epoch(mi355rec_mf *h, const MfParams<T> &p, bool timed, long long first = 0, long long last = -1) {
+    if (first == 0) launch_sampler(h, p);
     if (h->cfg.algorithm == MI355REC_MF_ASY_SVD) {
         enqueue_asy_steps(h, p, p.samples_per_epoch, timed);
         return;
     }
-    const long long nb = batches_per_epoch(h);
-    enqueue_schedule(h, p.samples_per_epoch, nb);
-    enqueue_batches(h, p, nb, timed);
+    enqueue_stream(h, p, p.samples_per_epoch, batches_per_epoch(h), timed, first, last);
 }
 
-// Capture one epoch into a graph (once per handle; re-captured only if the stream buffers are re-allocated).
-constexpr long long MAX_GRAPH_BATCHES = 4096;
+// Capture one epoch into graphs of up to GRAPH_SEGMENT mini-batches (once per handle; re-captured only if the stream buffers are
+// re-allocated).  FunkSVD's epoch at the ML-20M shape is 20 001 mini-batches: as plain launches the host's launch rate (8.8 us
+// per mini-batch) was the bound, not the chain of kernels.
+constexpr long long GRAPH_SEGMENT = 4096, MAX_GRAPH_BATCHES = 64 * GRAPH_SEGMENT;
 template <class T>
 void ensure_epoch_graph(mi355rec_mf *h, const MfParams<T> &p) {
-    if (h->epoch_graph || h->graph_failed) return;
-    hipGraph_t g = nullptr;
-    hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
-    if (e == hipSuccess) {
-        try {
-            enqueue_epoch(h, p, false);
-        } catch (...) {
-            (void)hipStreamEndCapture(h->stream, &g);
-            if (g) (void)hipGraphDestroy(g);
+    if (!h->epoch_graphs.empty() || h->graph_failed) return;
+    const long long nb = h->cfg.algorithm == MI355REC_MF_ASY_SVD ? 1 : batches_per_epoch(h);
+    for (long long first = 0; first < nb; first += GRAPH_SEGMENT) {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            try {
+                enqueue_epoch(h, p, false, first, std::min(nb, first + GRAPH_SEGMENT));
+            } catch (...) {
+                (void)hipStreamEndCapture(h->stream, &g);
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipGetLastError();
+                h->drop_graphs();
+                h->graph_failed = true;
+                return;
+            }
+            e = hipStreamEndCapture(h->stream, &g);
+        }
+        if (e == hipSuccess) e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+        if (g) (void)hipGraphDestroy(g);
+        if (e != hipSuccess) {       // plain launches remain correct, only slower: remember and go on
             (void)hipGetLastError();
+            h->drop_graphs();
             h->graph_failed = true;
             return;
         }
-        e = hipStreamEndCapture(h->stream, &g);
-    }
-    if (e == hipSuccess) e = hipGraphInstantiate(&h->epoch_graph, g, nullptr, nullptr, 0);
-    if (g) (void)hipGraphDestroy(g);
-    if (e != hipSuccess) {       // plain launches remain correct, only slower: remember and go on
-        (void)hipGetLastError();
-        h->epoch_graph = nullptr;
-        h->graph_failed = true;
+        h->epoch_graphs.push_back(exec);
     }
 }
 
-void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batches) {
+// `whole_stream`: the caller schedules the stream in one piece whatever its length (group members, exact multi-GPU mode)
+void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batches, bool whole_stream = false) {
     const bool asy = h->cfg.algorithm == MI355REC_MF_ASY_SVD;
     if (h->stream_capacity < n_samples) {
-        if (h->epoch_graph) {   // the graph holds the old buffer addresses
-            (void)hipGraphExecDestroy(h->epoch_graph);
-            h->epoch_graph = nullptr;
-        }
+        h->drop_graphs();       // they hold the old buffer addresses
         h->su.alloc(n_samples);
         h->si.alloc(n_samples);
         h->sj.alloc(n_samples);
         h->sr.alloc(n_samples);
         h->stream_capacity = n_samples;
-        if (!asy) {
-            const size_t n = n_samples * (size_t)per_sample(h);
-            MI_REQUIRE(n < (1ull << 31), "sample stream too long (%zu incidences)", n);
-            h->keys.alloc(n); h->keys_sorted.alloc(n);
-            h->slots.alloc(n); h->slots_sorted.alloc(n);
-            h->head.alloc(n); h->head_scan.alloc(n); h->task_at.alloc(n);
-            h->spar.alloc(n);
-            size_t sort_bytes = 0, scan_bytes = 0;
-            MI_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, h->keys.ptr, h->keys_sorted.ptr, h->slots.ptr,
-                                                      h->slots_sorted.ptr, (int)n, 0, 64, h->stream));
-            MI_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, h->head.ptr, h->head_scan.ptr, (size_t)n, rocprim::plus<int>(), h->stream));
-            h->cub_tmp_bytes = std::max(sort_bytes, scan_bytes) + 256;
-            h->cub_tmp.alloc(h->cub_tmp_bytes);
-        }
     }
-    if (!asy && h->batch_capacity < n_batches) {
-        if (h->epoch_graph) {
-            (void)hipGraphExecDestroy(h->epoch_graph);
-            h->epoch_graph = nullptr;
-        }
+    if (asy) return;
+    const bool fast1 = fast_schedule_fits(h, 1);
+    // the radix-sort schedule's buffers: only for streams it will actually see
+    whole_stream = whole_stream || getenv("MI355REC_MF_WHOLE_STREAM_SCHEDULE");
+    const bool general = !fast1 || (whole_stream && !fast_schedule_fits(h, n_batches));
+    if (general && h->general_capacity < n_samples) {
+        h->drop_graphs();
+        const size_t n = n_samples * (size_t)per_sample(h);
+        MI_REQUIRE(n < (1ull << 31), "sample stream too long (%zu incidences)", n);
+        h->keys.alloc(n); h->keys_sorted.alloc(n);
+        h->slots.alloc(n); h->slots_sorted.alloc(n);
+        h->head.alloc(n); h->head_scan.alloc(n); h->task_at.alloc(n);
+        h->spar.alloc(n);
+        size_t sort_bytes = 0, scan_bytes = 0;
+        MI_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, h->keys.ptr, h->keys_sorted.ptr, h->slots.ptr,
+                                                  h->slots_sorted.ptr, (int)n, 0, 64, h->stream));
+        MI_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, h->head.ptr, h->head_scan.ptr, (size_t)n, rocprim::plus<int>(), h->stream));
+        h->cub_tmp_bytes = std::max(sort_bytes, scan_bytes) + 256;
+        h->cub_tmp.alloc(h->cub_tmp_bytes);
+        h->general_capacity = n_samples;
+    }
+    // headers and records: per mini-batch of a SCHEDULE (a long stream on the in-LDS schedule reuses FAST_MAX_BATCHES of them)
+    const long long table_batches = general ? n_batches : std::min<long long>(n_batches, FAST_MAX_BATCHES);
+    if (h->batch_capacity < table_batches) {
+        h->drop_graphs();
         const size_t tpb = (size_t)per_sample(h) * h->cfg.batch_size;
-        h->batch_count.alloc((size_t)n_batches);
-        h->tasks.alloc((size_t)(n_batches + 1) * tpb);
-        MI_HIP(hipMemsetAsync(h->tasks.ptr, 0, sizeof(TaskHeader) * (size_t)(n_batches + 1) * tpb, h->stream));
-        h->recs.alloc((size_t)n_batches * tpb);          // records of batch b start at b * tpb in both schedule paths
-        h->fast_schedule = fast_schedule_fits(h, 1);
+        h->batch_count.alloc((size_t)table_batches);
+        h->tasks.alloc((size_t)(table_batches + 1) * tpb);
+        MI_HIP(hipMemsetAsync(h->tasks.ptr, 0, sizeof(TaskHeader) * (size_t)(table_batches + 1) * tpb, h->stream));
+        h->recs.alloc((size_t)table_batches * tpb);          // records of batch b start at b * tpb in both schedule paths
+        h->fast_schedule = fast1;
         if (h->fast_schedule) {
-            h->sorted_slot.alloc((size_t)n_batches * tpb);
-            h->qtask.alloc((size_t)n_batches * tpb);
-            h->used.alloc((size_t)n_batches);
+            h->sorted_slot.alloc((size_t)table_batches * tpb);
+            h->qtask.alloc((size_t)table_batches * tpb);
+            h->used.alloc((size_t)table_batches);
             if (!h->touched.ptr) h->touched.alloc_zero(((size_t)h->n_users + h->n_items) * (FAST_MAX_BATCHES / 32), h->stream);
         }
-        h->batch_capacity = n_batches;
+        h->batch_capacity = table_batches;
     }
 }
 
@@ -1871,12 +1956,12 @@ void run_epochs_typed(mi355rec_mf *h, int n_epochs) {
     bool use_graph = per_epoch <= MAX_GRAPH_BATCHES && n_epochs - timed_epochs > 0 && !getenv("MI355REC_NO_GRAPH") && !asy;
     if (use_graph) {
         ensure_epoch_graph(h, p);
-        use_graph = h->epoch_graph != nullptr;
+        use_graph = !h->epoch_graphs.empty();
     }
     h->timer.start(h->stream);
     for (long long e = 0; e < n_epochs; ++e) {
         if (e < timed_epochs || !use_graph) enqueue_epoch(h, p, e < timed_epochs);
-        else MI_HIP(hipGraphLaunch(h->epoch_graph, h->stream));
+        else for (hipGraphExec_t g : h->epoch_graphs) MI_HIP(hipGraphLaunch(g, h->stream));
     }
     h->timer.stop(h->stream);
     h->batches_done += per_epoch * n_epochs;
@@ -1899,8 +1984,7 @@ void run_samples_typed(mi355rec_mf *h, int64_t n) {
         finish_call(h, n, (n + ASY_CHUNK - 1) / ASY_CHUNK);
         return;
     }
-    enqueue_schedule(h, n, n_batches);
-    enqueue_batches(h, p, n_batches, true);
+    enqueue_stream(h, p, n, n_batches, true);
     h->timer.stop(h->stream);
     h->batches_done += n_batches;
     finish_call(h, n, n_batches);
@@ -2033,7 +2117,7 @@ namespace {
 template <class T>
 void shard_begin_typed(mi355rec_mf *h) {
     const long long B = h->cfg.batch_size, per_epoch = batches_per_epoch(h);
-    ensure_stream_capacity(h, (size_t)(per_epoch * B), per_epoch);
+    ensure_stream_capacity(h, (size_t)(per_epoch * B), per_epoch, true);
     MfParams<T> p{};
     fill_params(h, p);
     begin_call(h);
@@ -2275,7 +2359,7 @@ void group_run_epochs_typed(mi355rec_mf_group *g, int n_epochs) {
     for (int m = 0; m < R; ++m) {
         mi355rec_mf *h = g->members[m];
         MI_REQUIRE(h->shard_rank < 0, "member %d is inside an exact multi-GPU epoch", m);
-        ensure_stream_capacity(h, (size_t)(nb * h->cfg.batch_size), nb);
+        ensure_stream_capacity(h, (size_t)(nb * h->cfg.batch_size), nb, true);
         MfParams<T> p;
         memset(&p, 0, sizeof(p));
         fill_params(h, p);
@@ -2317,7 +2401,7 @@ void group_run_epochs_typed(mi355rec_mf_group *g, int n_epochs) {
     }
     g->dispatch_timers.reset();
     const long long timed_epochs = g->max_timed > 0 ? std::min<long long>(n_epochs, (g->max_timed + nb - 1) / nb) : 0;
-    bool use_graph = nb <= MAX_GRAPH_BATCHES && n_epochs - timed_epochs > 0 && !getenv("MI355REC_NO_GRAPH");
+    bool use_graph = nb <= GRAPH_SEGMENT && n_epochs - timed_epochs > 0 && !getenv("MI355REC_NO_GRAPH");
     if (use_graph) {
         group_ensure_graph<T>(g);
         use_graph = g->graph != nullptr;
