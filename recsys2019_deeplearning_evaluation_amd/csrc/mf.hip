@@ -717,11 +717,6 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
     using R = Rows<T, VEC, KI, BPR>;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((wg * p.wg_stride + p.wg_base) * 4 + (threadIdx.x >> 6));
-    // Every kernel argument the start of the kernel needs is requested in ONE batch of scalar loads: left to itself the compiler
-    // fetched them piecewise as the code came to need them -- three waits for a cold kernarg segment before FunkSVD's header load
-    // was even issued, one for BPR's.
-    asm volatile("" ::"s"(p.tasks), "s"(p.tasks_per_batch), "s"(p.wg_base), "s"(p.wg_stride), "s"(p.ticks), "s"(p.use_bias), "s"(p.sgd_mode),
-                 "s"(p.state), "s"(p.mu_state), "s"(p.mu_acc), "s"(p.k), "s"(p.U0), "s"(p.U1), "s"(p.V0), "s"(p.V1), "s"(p.recs));
     const unsigned long long tk0 = p.ticks ? stamp() : 0ull;
     // every wave-uniform input is requested before the first one is waited for (scalar loads, one wait)
     // (unused task slots of a batch are zero: a header with no samples means there is nothing to do)
@@ -992,6 +987,13 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
 
 template <int ALGO, class T, int VEC, int LPR, int KI>
 __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, const int batch_local) {
+    // Every kernel argument the start of the kernel needs is requested in ONE batch of scalar loads: left to itself the compiler
+    // fetched them piecewise as the code came to need them -- three waits for a cold kernarg segment before FunkSVD's header load
+    // was even issued, one for BPR's.
+    asm volatile("" ::"s"(p.tasks), "s"(p.tasks_per_batch), "s"(p.wg_base), "s"(p.wg_stride), "s"(p.ticks), "s"(p.use_bias), "s"(p.sgd_mode),
+                 "s"(p.state), "s"(p.mu_state), "s"(p.mu_acc), "s"(p.k), "s"(p.U0), "s"(p.U1), "s"(p.V0), "s"(p.V1), "s"(p.recs));
+    // (here and not in the body: the group launch below reads its parameters from a table in memory, where holding them all in
+    // scalar registers from the start costs occupancy)
     mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, blockIdx.x);
 }
 

@@ -771,31 +771,44 @@ __global__ void gather_csc_kernel(const int *perm, const int *row_of, const floa
     }
 }
 
-// Per column (one wave each): mean of the stored cells (pearson), sum of squares, cost = sum of profile lengths.
-__global__ void column_stats_kernel(const int *csc_ptr, const int *csc_idx, const float *csc_val, const int *csr_ptr,
-                                    int n_cols, float *mean, double *sumsq, long long *cost) {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= n_cols) return;
-    const int s = csc_ptr[wave], e = csc_ptr[wave + 1];
-    double sum = 0.0, sq = 0.0;
-    long long c = 0;
-    for (int q = s + lane; q < e; q += 64) {
-        const double v = csc_val[q];
-        sum += v;
-        sq += v * v;
-        const int u = csc_idx[q];
-        c += csr_ptr[u + 1] - csr_ptr[u];
+// cost = sum of the profile lengths of a column's rows, for ALL columns with the cells dealt evenly: a wavefront per 4 096 cells of
+// the column-ordered arrays (one wavefront per column spent 1.2 ms on the longest column of the ML-20M shape alone).  `col_of` is the
+// sorted key array of the CSR -> CSC sort.  Runs of one column are summed in registers, one atomic per run and wavefront; the few
+// cells of a stretch of 64 that spans several columns add themselves.
+constexpr int COST_CHUNK = 4096;
+__global__ __launch_bounds__(256) void column_cost_kernel(const int *col_of, const int *csc_idx, const int *csr_ptr, size_t nnz,
+                                                          unsigned long long *cost) {
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const size_t first = wave * COST_CHUNK, last = first + COST_CHUNK < nnz ? first + COST_CHUNK : nnz;
+    if (first >= nnz) return;
+    int cur = -1;
+    unsigned long long part = 0;
+    auto flush = [&]() {
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == 0 && cur >= 0 && part) atomicAdd(&cost[cur], part);
+        part = 0;
+    };
+    for (size_t q0 = first; q0 < last; q0 += 64) {
+        const size_t q = q0 + lane;
+        const bool live = q < last;
+        const int col = live ? col_of[q] : -1;
+        const int u = live ? csc_idx[q] : 0;
+        const unsigned long long len = live ? (unsigned long long)(csr_ptr[u + 1] - csr_ptr[u]) : 0ull;
+        const int col0 = __builtin_amdgcn_readfirstlane(col);
+        if (__all(!live || col == col0)) {
+            if (col0 != cur) {
+                flush();
+                cur = col0;
+            }
+            part += len;
+        } else {
+            flush();
+            cur = -1;
+            if (live) atomicAdd(&cost[col], len);
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        sum += __shfl_xor(sum, off);
-        sq += __shfl_xor(sq, off);
-        c += __shfl_xor(c, off);
-    }
-    if (lane == 0) {
-        if (mean) mean[wave] = e > s ? (float)(sum / (double)(e - s)) : 0.f;
-        if (sumsq) sumsq[wave] = sq;
-        if (cost) cost[wave] = c;
-    }
+    flush();
 }
 
 // applyPearsonCorrelation (.pyx:234-271): subtract the column mean from every stored cell, both views.
@@ -1471,6 +1484,30 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         MI_HIP(hipMemcpyAsync(h->csr_val.ptr, csr_data, nnz * sizeof(float), hipMemcpyHostToDevice, s));
         if (row_weights) h->row_w.upload(row_weights, n_rows, s);
         phase("allocate + upload (PCIe)");
+        // CSR -> CSC (.pyx:203-207), on the device: stable radix sort of the cell positions by column; the values are gathered
+        // into column order further down, after their pre-processing.  (Measured and rejected: the sort on a second stream behind the
+        // upload of the values -- it needs the structure only --: the upload of pageable memory and the sort's kernels got into each
+        // other's way, 5.96 ms for the two against 2.92 + 1.16 ms one after the other.)
+        DeviceBuffer<int> row_of, pos_in, pos_out, key_out;
+        DeviceBuffer<char> sort_tmp;
+        {
+            h->csc_ptr.alloc((size_t)n_cols + 1);
+            row_of.alloc(nnz);
+            pos_in.alloc(nnz);
+            pos_out.alloc(nnz);
+            key_out.alloc(nnz);
+            int key_bits = 1;
+            while ((1ll << key_bits) < (long long)n_cols) ++key_bits;
+            size_t tmp_bytes = 0;
+            MI_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, pos_in.ptr, pos_out.ptr,
+                                                      (int)nnz, 0, key_bits, s));
+            sort_tmp.alloc(tmp_bytes);
+            hipLaunchKernelGGL(expand_rows_kernel, dim3(div_up((int64_t)n_rows * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr, n_rows,
+                               row_of.ptr, pos_in.ptr);
+            MI_HIP(rocprim::radix_sort_pairs(sort_tmp.ptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, pos_in.ptr, pos_out.ptr,
+                                                      (int)nnz, 0, key_bits, s));
+            hipLaunchKernelGGL(csc_ptr_kernel, dim3(div_up(n_cols + 1, 256)), dim3(256), 0, s, key_out.ptr, nnz, n_cols, h->csc_ptr.ptr);
+        }
         const int eb = 256, eg = std::min<size_t>((nnz + eb - 1) / eb, 4096);
 
         // optional pre-pass: BM25 / TF-IDF on the stored values (what the KNN recommenders do to the matrix before the build)
@@ -1552,35 +1589,17 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
                                h->csr_val.ptr, n_rows, row_mean.ptr);
         }
 
-        // CSR -> CSC (.pyx:203-207), on the device: stable radix sort of the cell positions by column
-        DeviceBuffer<int> row_of, pos_in, pos_out, key_out;
+        // gather the pre-processed values into the column order
         DeviceBuffer<float> mean;
         DeviceBuffer<double> sumsq;
         DeviceBuffer<long long> cost;
-        DeviceBuffer<char> sort_tmp;
-        h->csc_ptr.alloc((size_t)n_cols + 1);
         h->csc_idx.alloc(nnz);
         h->csc_val.alloc(nnz);
-        row_of.alloc(nnz);
-        pos_in.alloc(nnz);
-        pos_out.alloc(nnz);
-        key_out.alloc(nnz);
         if (h->n_tiles > 1) {
             h->row_tile_ptr.alloc((size_t)n_rows * (h->n_tiles + 1));
             hipLaunchKernelGGL(row_tile_ptr_kernel, dim3(div_up((int64_t)n_rows * (h->n_tiles + 1), 256)), dim3(256), 0, s,
                                h->csr_ptr.ptr, h->csr_idx.ptr, n_rows, h->tile_w, h->n_tiles, h->row_tile_ptr.ptr);
         }
-        hipLaunchKernelGGL(expand_rows_kernel, dim3(div_up((int64_t)n_rows * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr, n_rows,
-                           row_of.ptr, pos_in.ptr);
-        int key_bits = 1;
-        while ((1ll << key_bits) < (long long)n_cols) ++key_bits;
-        size_t tmp_bytes = 0;
-        MI_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, pos_in.ptr, pos_out.ptr,
-                                                  (int)nnz, 0, key_bits, s));
-        sort_tmp.alloc(tmp_bytes);
-        MI_HIP(rocprim::radix_sort_pairs(sort_tmp.ptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, pos_in.ptr, pos_out.ptr,
-                                                  (int)nnz, 0, key_bits, s));
-        hipLaunchKernelGGL(csc_ptr_kernel, dim3(div_up(n_cols + 1, 256)), dim3(256), 0, s, key_out.ptr, nnz, n_cols, h->csc_ptr.ptr);
         hipLaunchKernelGGL(gather_csc_kernel, dim3(eg), dim3(eb), 0, s, pos_out.ptr, row_of.ptr, h->csr_val.ptr, nnz,
                            h->csc_idx.ptr, h->csc_val.ptr);
 
@@ -1619,8 +1638,9 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         phase("profile stream");
         sumsq.alloc((size_t)n_cols);
         cost.alloc((size_t)n_cols);
-        hipLaunchKernelGGL(column_stats_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_idx.ptr, h->csc_val.ptr,
-                           h->csr_ptr.ptr, n_cols, (float *)nullptr, (double *)nullptr, cost.ptr);
+        MI_HIP(hipMemsetAsync(cost.ptr, 0, sizeof(long long) * (size_t)n_cols, s));
+        hipLaunchKernelGGL(column_cost_kernel, dim3(div_up((int64_t)div_up((int64_t)nnz, COST_CHUNK) * 64, 256)), dim3(256), 0, s, key_out.ptr,
+                           h->csc_idx.ptr, h->csr_ptr.ptr, nnz, reinterpret_cast<unsigned long long *>(cost.ptr));
         MI_REQUIRE(cfg->norm_sum_order == 0 || cfg->norm_sum_order == 1, "norm_sum_order must be 0 (CSR order) or 1 (CSC order)");
         if (h->unit_values && n_rows < (1 << 24))
             hipLaunchKernelGGL(column_count_sumsq_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, s, h->csc_ptr.ptr, n_cols, sumsq.ptr);

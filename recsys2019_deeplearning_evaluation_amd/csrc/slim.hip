@@ -96,6 +96,7 @@ struct SlimParams {
     const StepDesc *desc;           // symmetric store: per step, in stream order
     const int *order;               // symmetric store: the steps with short profiles in stream order, then the others backwards
     int n_short;
+    int nap;                        // how much longer a wavefront sleeps between polls once it has polled 24 times in vain
     const StepDesc *cold_desc;      // dense store: the steps with no owned row, in stream order
     const StepDesc *own_desc;       // dense store: per (item, step) pair in sorted order (only the owned items' runs are filled in)
     const int *n_cold;
@@ -336,7 +337,11 @@ struct SpinGuard {
 };
 template <class T>
 __device__ __forceinline__ bool give_up(const SlimParams<T> &p, SpinGuard &g) {      // wave-uniform answer
-    __builtin_amdgcn_s_sleep(1);
+    // a waiter that has polled for a while polls less often (p.nap; 0: always every 64 cycles)
+    if (p.nap == 0 || g.polls < 24u) __builtin_amdgcn_s_sleep(1);
+    else if (p.nap == 1) __builtin_amdgcn_s_sleep(4);
+    else if (p.nap == 2) __builtin_amdgcn_s_sleep(12);
+    else __builtin_amdgcn_s_sleep(32);
     if ((++g.polls & 127u) != 0) return false;
     int stop = aload(&p.queue[1]);
     const long long now = wall_clock64();
@@ -1507,6 +1512,7 @@ void fill_params(mi355rec_slim *h, const StreamSet &st, SlimParams<T> &p) {
     p.n_hot = h->counters.ptr; p.n_cold = h->counters.ptr + 1;
     p.desc = c.symmetric ? st.desc.ptr : h->desc.ptr; p.cold_desc = h->cold_desc.ptr; p.own_desc = h->own_desc.ptr;
     p.order = st.order.ptr; p.n_short = st.n_short;
+    p.nap = env_int("MI355REC_SLIM_NAP", 1);
     p.prof = h->prof.ptr;
     p.mail_x = h->mail.ptr; p.mail_g = h->mail.ptr + h->launch_capacity;
 }

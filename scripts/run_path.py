@@ -34,7 +34,7 @@ elif path == "asy":
     pick = rng.integers(0, x1m.nnz, 131072)
     m.replay_samples(rows[pick].astype(np.int32), x1m.indices[pick].astype(np.int32), rating=x1m.data[pick].astype(np.float32))
 elif path == "funk":
-    # the bench's workload: ONE native epoch (20 001 mini-batches of on-device samples, general schedule, global-bias ring)
+    # the bench workload: ONE native epoch (20 001 mini-batches of on-device samples, in-LDS schedule 256 at a time, global-bias ring)
     m = MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, algorithm_name="FUNK_SVD", batch_size=BATCH, learning_rate=1e-3, sgd_mode="sgd", use_bias=True,
                                          negative_interactions_quota=0.0, random_seed=1)
     m.epochIteration_Cython(1)

@@ -61,3 +61,7 @@ if which == "presched":
     for _ in range(4):
         ep.epochIteration_Cython()
     print("symmetric, one epoch per call: %.3f ms per epoch" % ((time.perf_counter() - t) / 4 * 1e3))
+if which == "nap":
+    for sym in (False, True):
+        for nap in (0, 1, 2, 3):
+            run(sym, "nap %d" % nap, MI355REC_SLIM_NAP=nap)
