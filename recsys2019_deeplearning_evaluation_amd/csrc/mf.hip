@@ -1538,6 +1538,9 @@ void fill_params(mi355rec_mf *h, MfParams<T> &p) {
 }
 
 // ---- kernel selection -------------------------------------------------------------------------------------------------
+// (Measured and rejected, round 4: rows of 17 .. 32 chunks on 16 lanes with two chunks each instead of 32 lanes with one -- four samples
+// per wavefront, twice the bytes in flight per wavefront: the row gathers of a wavefront took 3 840 cycles instead of 2 350, one model
+// 140 M samples/s instead of 176 M, the 32-model group 567 M instead of 678 M.)
 template <int ALGO, class T, int VEC, int LPR, int KI>
 void launch_batch_as(mi355rec_mf *h, const MfParams<T> &p, int grid, int batch_local, hipEvent_t e0, hipEvent_t e1) {
     if (e0) hipExtLaunchKernelGGL((mf_batch_kernel<ALGO, T, VEC, LPR, KI>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p, batch_local);
