@@ -735,17 +735,44 @@ def ials_section(urm, net, args, extra):
         slab_i = max(e - s for s, e in ir) * k * 8
         ring = lambda slab: (G - 1) * slab / 50e9 * 1e3 + 0.05
         direct = lambda slab: slab / 50e9 * 1e3 + 0.05
-        one_ring = max(t_user) + max(t_item) + ring(slab_u) + ring(slab_i)
-        all_links = max(t_user) + max(t_item) + direct(slab_u) + direct(slab_i)
+        # what ShardedIALSEpoch runs at N > 1: a rank's rows in 4 pieces, the all-gather of a finished piece behind the solve of the
+        # next one.  The pieces of the slowest range of each half are measured, the gathers modelled (piece c's starts when both its
+        # solve and piece c - 1's gather are done).
+        from recsys2019_deeplearning_evaluation_amd.sharding import chunk_bounds
+        CH = 4
+
+        def pieces_of(half, rng):
+            out = []
+            for r0, r1 in chunk_bounds(rng[1] - rng[0], CH):
+                if r1 > r0:
+                    half(rng[0] + r0, rng[0] + r1); ia.synchronize(); out.append(ia.stats()["call_ms"])
+            return out
+
+        def pipelined(pieces, gather_ms):
+            t_solve = t_net = 0.0
+            for p_ms in pieces:
+                t_solve += p_ms
+                t_net = max(t_net, t_solve) + gather_ms / len(pieces)
+            return t_net
+
+        pu = pieces_of(ia.user_half, ur[int(np.argmax(t_user))])
+        pi = pieces_of(ia.item_half, ir[int(np.argmax(t_item))])
+        one_ring_end = max(t_user) + max(t_item) + ring(slab_u) + ring(slab_i)
+        all_links_end = max(t_user) + max(t_item) + direct(slab_u) + direct(slab_i)
+        one_ring = pipelined(pu, ring(slab_u)) + pipelined(pi, ring(slab_i))
+        all_links = pipelined(pu, direct(slab_u)) + pipelined(pi, direct(slab_i))
         block["emulated_8_way"] = {
             "user_half_ms_per_range": t_user, "item_half_ms_per_range": t_item, "slowest_user_ms": max(t_user), "slowest_item_ms": max(t_item),
             "kernel_speedup_vs_1gpu": best * 1e3 / (max(t_user) + max(t_item)),
             "slab_MB_per_rank": {"users": slab_u / 1e6, "items": slab_i / 1e6},
             "modelled_allgather_ms": {"one_ring_50GBps_per_link": ring(slab_u) + ring(slab_i), "seven_links_at_once": direct(slab_u) + direct(slab_i)},
+            "pieces_ms_of_the_slowest_range": {"users": pu, "items": pi},
+            "predicted_seconds_per_epoch_one_exchange_at_the_end": {"one_ring": one_ring_end * 1e-3, "seven_links": all_links_end * 1e-3},
             "predicted_seconds_per_epoch": {"one_ring": one_ring * 1e-3, "seven_links": all_links * 1e-3},
             "predicted_speedup": {"one_ring": best * 1e3 / one_ring, "seven_links": best * 1e3 / all_links},
-            "note": "the 8 cost-balanced ranges of each half-step run one after the other on ONE GPU (measured); the two all-gathers are "
-                    "modelled from their size; unmeasured on hardware"}
+            "note": "the 8 cost-balanced ranges of each half-step run one after the other on ONE GPU (measured), the slowest range again in the 4 "
+                    "pieces ShardedIALSEpoch runs it in (measured); the all-gathers are modelled from their size, a piece's gather behind the "
+                    "next piece's solve; unmeasured on hardware"}
     ia.close()
     extra["ials"] = block
 
@@ -980,6 +1007,9 @@ def main():
         table[name] = {"value": val, "unit": "samples/s" if "samples_per_s" in blk else ("users/s" if "users_per_s" in blk else "s/epoch"),
                        "bound": blk.get("bound"), "frac": blk.get("frac"), "cpu_value": (blk.get("cpu_baseline") or {}).get("value"),
                        "cpu_kind": (blk.get("cpu_baseline") or {}).get("kind")}
+        fx = blk.get("cpu_baseline_reference_fixture")          # the reference's own class, timed where /root/reference exists (committed fixture)
+        if fx:
+            table[name].update({"cpu_reference_fixture_value": fx.get("value"), "cpu_reference_fixture_kind": fx.get("kind")})
     if "itemknn" in out["extra"]:
         ik = out["extra"]["itemknn"]
         table["itemknn_cosine_top100"] = {"value": ik.get("fit_s"), "unit": "s (constructor incl. PCIe upload + build)", "build_s": ik.get("cosine_build_s"),

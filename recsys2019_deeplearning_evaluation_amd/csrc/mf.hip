@@ -757,7 +757,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
     __shared__ T s_wide_bias[4];
     T mu_term = (T)0;
     T mu_eff = (T)0;
-    unsigned long long tk1 = 0, tk2 = 0, tk3 = 0;
+    unsigned long long tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, tk5 = 0;
     if (p.ticks) tk1 = stamp();          // header has arrived (its value decided `active`)
     if (bias && !active) mu_eff = global_bias_finish(p, mu_req, gb, batch_local, wv == 0, lane);      // (wavefront 0 files the value either way)
     if (active) {
@@ -933,6 +933,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
                 bn[row] = own_bias + p.lr * step;
             }
         }
+        if (p.ticks) tk4 = stamp();      // own row written
         const int also = BPR && (len == 1 || pair) ? (rec_first.w >> 5) & 3 : 0;
         if (BPR && also) {
             // The item rows this single-sample user task took over (mf_sched_sort_kernel): the arithmetic their own tasks would
@@ -970,6 +971,7 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
             }
         }
     }
+    if (p.ticks) tk5 = stamp();          // item rows the task took over written
     if (bias) {   // the batch's global-bias terms: per workgroup through LDS, then one atomic on one of 16 addresses
         if (lane == 0) s_mu[threadIdx.x >> 6] = mu_term;
         __syncthreads();
@@ -981,12 +983,17 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
     if (p.ticks && lane == 0 && wv < p.tasks_per_batch) {
         unsigned long long *o = p.ticks + (size_t)wv * 8;
         o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = stamp(); o[5] = (unsigned long long)(h0.y & LEN_MASK);
-        o[6] = (unsigned long long)wg; o[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // XCC_ID
+        o[6] = tk4; o[7] = tk5;
     }
 }
 
-template <int ALGO, class T, int VEC, int LPR, int KI>
+// PLAIN_SGD: the instance for sgd_mode == "sgd" (the reference's default, the headline): every branch on the optimiser is decided at
+// compile time.  The update of the item rows a pair task took over ran through 1 600 instructions of optimiser cases -- 1 730 cycles
+// of the 6 500 a wavefront lives (MI355REC_MF_TICKS, round 4).
+template <int ALGO, class T, int VEC, int LPR, int KI, bool PLAIN_SGD>
 __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, const int batch_local) {
+    // (an assumption about the argument, not a modified copy: a copy that is passed on by reference lands in scratch memory)
+    if constexpr (PLAIN_SGD) __builtin_assume(p.sgd_mode == MI355REC_SGD);
     // Every kernel argument the start of the kernel needs is requested in ONE batch of scalar loads: left to itself the compiler
     // fetched them piecewise as the code came to need them -- three waits for a cold kernarg segment before FunkSVD's header load
     // was even issued, one for BPR's.
@@ -1022,10 +1029,11 @@ template <class T> __device__ __forceinline__ void globalize(MfParams<T> &p) {
     p.tasks = as_global(p.tasks); p.recs = as_global(p.recs); p.ticks = as_global(p.ticks); p.used = as_global(p.used);
 }
 
-template <int ALGO, class T, int VEC, int LPR, int KI>
-__global__ __launch_bounds__(256) void mf_group_batch_kernel(const MfParams<T> *__restrict__ table, const int batch_local) {
+template <int ALGO, class T, int VEC, int LPR, int KI, bool PLAIN_SGD>
+__global__ __launch_bounds__(256, (PLAIN_SGD && ALGO == MI355REC_MF_BPR && sizeof(T) == 4 && LPR == 32) ? 6 : 1) void mf_group_batch_kernel(const MfParams<T> *__restrict__ table, const int batch_local) {
     MfParams<T> p = table[blockIdx.y];
     globalize(p);
+    if constexpr (PLAIN_SGD) __builtin_assume(p.sgd_mode == MI355REC_SGD);       // (every member runs plain sgd: see mf_batch_kernel)
     // the grid covers a third of a mini-batch's header slots; with fused / paired tasks fewer than that are in use as a rule
     // (the in-LDS schedule files the count), and a workgroup that finds more walks on: no wavefront is launched for an empty slot
     const int used = p.used ? p.used[batch_local] : p.tasks_per_batch;
@@ -1063,18 +1071,6 @@ __global__ __launch_bounds__(256) void mf_group_sched_finish_kernel(const FastSc
     FastSchedParams f = table[blockIdx.y];
     globalize(f);
     mf_sched_finish_body(f);
-}
-
-// the same with the register budget of 8 wavefronts per SIMD (64 VGPRs): a group launch is bound by the number of row gathers in
-// flight, i.e. by resident wavefronts
-template <int ALGO, class T, int VEC, int LPR, int KI>
-__global__ __launch_bounds__(256, 8) void mf_group_batch_kernel_occ8(const MfParams<T> *__restrict__ table, const int batch_local) {
-    MfParams<T> p = table[blockIdx.y];
-    globalize(p);
-    // the grid covers a third of a mini-batch's header slots; with fused / paired tasks fewer than that are in use as a rule
-    // (the in-LDS schedule files the count), and a workgroup that finds more walks on: no wavefront is launched for an empty slot
-    const int used = p.used ? p.used[batch_local] : p.tasks_per_batch;
-    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg);
 }
 
 // Any k (odd k, k > 64 lanes x 2 chunks): one task per wavefront, one sample at a time, rows re-read for the update.
@@ -1543,8 +1539,13 @@ void fill_params(mi355rec_mf *h, MfParams<T> &p) {
 // 140 M samples/s instead of 176 M, the 32-model group 567 M instead of 678 M.)
 template <int ALGO, class T, int VEC, int LPR, int KI>
 void launch_batch_as(mi355rec_mf *h, const MfParams<T> &p, int grid, int batch_local, hipEvent_t e0, hipEvent_t e1) {
-    if (e0) hipExtLaunchKernelGGL((mf_batch_kernel<ALGO, T, VEC, LPR, KI>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p, batch_local);
-    else hipLaunchKernelGGL((mf_batch_kernel<ALGO, T, VEC, LPR, KI>), dim3(grid), dim3(256), 0, h->stream, p, batch_local);   // capturable
+    if (p.sgd_mode == MI355REC_SGD) {
+        if (e0) hipExtLaunchKernelGGL((mf_batch_kernel<ALGO, T, VEC, LPR, KI, true>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p, batch_local);
+        else hipLaunchKernelGGL((mf_batch_kernel<ALGO, T, VEC, LPR, KI, true>), dim3(grid), dim3(256), 0, h->stream, p, batch_local);   // capturable
+        return;
+    }
+    if (e0) hipExtLaunchKernelGGL((mf_batch_kernel<ALGO, T, VEC, LPR, KI, false>), dim3(grid), dim3(256), 0, h->stream, e0, e1, 0, p, batch_local);
+    else hipLaunchKernelGGL((mf_batch_kernel<ALGO, T, VEC, LPR, KI, false>), dim3(grid), dim3(256), 0, h->stream, p, batch_local);
 }
 
 template <int ALGO, class T>
@@ -1572,29 +1573,27 @@ int kernel_class(const mi355rec_mf *h) {
 }
 
 template <int ALGO, class T, int VEC, int LPR, int KI>
-void launch_group_as(hipStream_t s, const MfParams<T> *table, dim3 grid, int batch_local, hipEvent_t e0, hipEvent_t e1) {
-    static const bool occ8 = getenv("MI355REC_MF_GROUP_OCC8") != nullptr;
-    if constexpr (ALGO == MI355REC_MF_BPR && sizeof(T) == 4 && KI == 1) {
-        if (occ8) {
-            if (e0) hipExtLaunchKernelGGL((mf_group_batch_kernel_occ8<ALGO, T, VEC, LPR, KI>), grid, dim3(256), 0, s, e0, e1, 0, table, batch_local);
-            else hipLaunchKernelGGL((mf_group_batch_kernel_occ8<ALGO, T, VEC, LPR, KI>), grid, dim3(256), 0, s, table, batch_local);
-            return;
-        }
+void launch_group_as(hipStream_t s, const MfParams<T> *table, dim3 grid, int batch_local, bool plain_sgd, hipEvent_t e0, hipEvent_t e1) {
+    // (a 64-VGPR build for 8 wavefronts per SIMD was measured twice and is gone: 20 spilled registers, 422 M against 678 M samples/s)
+    if (plain_sgd) {
+        if (e0) hipExtLaunchKernelGGL((mf_group_batch_kernel<ALGO, T, VEC, LPR, KI, true>), grid, dim3(256), 0, s, e0, e1, 0, table, batch_local);
+        else hipLaunchKernelGGL((mf_group_batch_kernel<ALGO, T, VEC, LPR, KI, true>), grid, dim3(256), 0, s, table, batch_local);
+        return;
     }
-    if (e0) hipExtLaunchKernelGGL((mf_group_batch_kernel<ALGO, T, VEC, LPR, KI>), grid, dim3(256), 0, s, e0, e1, 0, table, batch_local);
-    else hipLaunchKernelGGL((mf_group_batch_kernel<ALGO, T, VEC, LPR, KI>), grid, dim3(256), 0, s, table, batch_local);
+    if (e0) hipExtLaunchKernelGGL((mf_group_batch_kernel<ALGO, T, VEC, LPR, KI, false>), grid, dim3(256), 0, s, e0, e1, 0, table, batch_local);
+    else hipLaunchKernelGGL((mf_group_batch_kernel<ALGO, T, VEC, LPR, KI, false>), grid, dim3(256), 0, s, table, batch_local);
 }
 
 template <int ALGO, class T>
-void launch_group_batch(hipStream_t s, const MfParams<T> *table, int klass, int wgs, int n_models, int batch_local, hipEvent_t e0,
-                        hipEvent_t e1) {
+void launch_group_batch(hipStream_t s, const MfParams<T> *table, int klass, int wgs, int n_models, int batch_local, bool plain_sgd,
+                        hipEvent_t e0, hipEvent_t e1) {
     constexpr int VEC = 16 / (int)sizeof(T);
     const dim3 grid(wgs, n_models);
     switch (klass) {
-        case 0: launch_group_as<ALGO, T, VEC, 16, 1>(s, table, grid, batch_local, e0, e1); break;
-        case 1: launch_group_as<ALGO, T, VEC, 32, 1>(s, table, grid, batch_local, e0, e1); break;
-        case 2: launch_group_as<ALGO, T, VEC, 64, 1>(s, table, grid, batch_local, e0, e1); break;
-        default: launch_group_as<ALGO, T, VEC, 64, 2>(s, table, grid, batch_local, e0, e1); break;
+        case 0: launch_group_as<ALGO, T, VEC, 16, 1>(s, table, grid, batch_local, plain_sgd, e0, e1); break;
+        case 1: launch_group_as<ALGO, T, VEC, 32, 1>(s, table, grid, batch_local, plain_sgd, e0, e1); break;
+        case 2: launch_group_as<ALGO, T, VEC, 64, 1>(s, table, grid, batch_local, plain_sgd, e0, e1); break;
+        default: launch_group_as<ALGO, T, VEC, 64, 2>(s, table, grid, batch_local, plain_sgd, e0, e1); break;
     }
 }
 
@@ -2243,6 +2242,7 @@ struct mi355rec_mf_group {
     std::vector<mi355rec_mf *> members;      // not owned
     bool f64 = false;
     int algorithm = 0, klass = 0, tasks_per_batch = 0;
+    bool plain_sgd = false;                 // every member runs sgd_mode "sgd"
     long long batches_per_epoch = 0;
     hipStream_t stream = nullptr;
     StreamTimer timer;
@@ -2303,8 +2303,8 @@ void group_enqueue_batches(mi355rec_mf_group *g, const MfParams<T> *table, bool 
     for (long long b = 0; b < nb; ++b) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timed) g->dispatch_timers.next(e0, e1, g->max_timed);
-        if (g->algorithm == MI355REC_MF_BPR) launch_group_batch<MI355REC_MF_BPR, T>(g->stream, table, g->klass, wgs, R, (int)b, e0, e1);
-        else launch_group_batch<MI355REC_MF_FUNK_SVD, T>(g->stream, table, g->klass, wgs, R, (int)b, e0, e1);
+        if (g->algorithm == MI355REC_MF_BPR) launch_group_batch<MI355REC_MF_BPR, T>(g->stream, table, g->klass, wgs, R, (int)b, g->plain_sgd, e0, e1);
+        else launch_group_batch<MI355REC_MF_FUNK_SVD, T>(g->stream, table, g->klass, wgs, R, (int)b, g->plain_sgd, e0, e1);
     }
     hipLaunchKernelGGL(mf_group_stream_end_kernel<T>, dim3(div_up(R, 64)), dim3(64), 0, g->stream, table, R, nb);
 }
@@ -2477,6 +2477,8 @@ extern "C" int mi355rec_mf_group_create(mi355rec_mf_group_t *out, const mi355rec
                        "member %d has a different batch_size or number of mini-batches per epoch than member 0", m);
             g->members.push_back(h);
         }
+        g->plain_sgd = true;
+        for (const mi355rec_mf *h : g->members) g->plain_sgd = g->plain_sgd && h->cfg.sgd_mode == MI355REC_SGD;
         MI_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
         g->timer.init();
         MI_HIP(hipEventCreateWithFlags(&g->fork, hipEventDisableTiming));

@@ -36,9 +36,10 @@ for lo, hi in ((1, 1), (2, 2), (3, 4), (5, 8), (9, 16), (17, 32), (33, 1000)):
     if sel.any():
         print("len %3d-%3d: n %5d  header %5d rows %5d list %6d tail %5d  (median cycles per phase)" % (
             lo, hi, sel.sum(), np.median(a[sel, 1] - a[sel, 0]), np.median(a[sel, 2] - a[sel, 1]), np.median(a[sel, 3] - a[sel, 2]), np.median(a[sel, 4] - a[sel, 3])))
+for lo, hi in ((1, 1), (2, 2), (3, 1000)):
+    sel = (a[:, 5] >= lo) & (a[:, 5] <= hi) & (a[:, 6] > 0)
+    if sel.any():
+        print("len %3d-%3d: tail split: list done -> own row written %5d, -> taken-over item rows written %5d, -> exit %5d (median cycles)" % (
+            lo, hi, np.median(a[sel, 6] - a[sel, 3]), np.median(a[sel, 7] - a[sel, 6]), np.median(a[sel, 4] - a[sel, 7])))
 print("inactive waves exit after (median)", np.median(t[~act][:, 4] - t[~act][:, 0]) if (~act).any() else None)
 print("max len", a[:, 5].max())
-big = a[a[:, 5] >= 5]
-print("waves of the long lists (len, workgroup, header, rows, list, tail):")
-for r in big[np.lexsort((big[:, 6], big[:, 5]))][:48]:
-    print("  len %3d wg %4d  %6d %6d %6d %6d" % (r[5], r[6], r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3]))
