@@ -1001,6 +1001,8 @@ __global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, cons
                  "s"(p.state), "s"(p.mu_state), "s"(p.mu_acc), "s"(p.k), "s"(p.U0), "s"(p.U1), "s"(p.V0), "s"(p.V1), "s"(p.recs));
     // (here and not in the body: the group launch below reads its parameters from a table in memory, where holding them all in
     // scalar registers from the start costs occupancy)
+    // (Measured and rejected, round 4: a launch over a third of the slots with a loop over the slots in use, as the group launch does --
+    // BPR 198 against 196 M samples/s, FunkSVD, whose slots are nearly all in use, 102 against 161 M.)
     mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, blockIdx.x);
 }
 
