@@ -103,6 +103,8 @@ struct MfParams {
     // schedule
     const TaskHeader *tasks;
     const int4 *recs;
+    const int4 *slot_recs;               // in-LDS schedule: [mini-batch][slot][3] records 1 .. group - 1 of a PAIR task, by header slot: their
+    long long slot_rec_stride;           // address does not depend on the header (0: radix-sort schedule, one dummy mini-batch)
     const int *used;                     // fast schedule: header slots in use per mini-batch of the stream (NULL: all of them may be)
     unsigned long long *ticks;           // optional [tasks_per_batch][8] shader-clock stamps of the last mini-batch (MI355REC_MF_TICKS=1)
     int wg_base, wg_stride;              // workgroup b of the launch is workgroup wg_base + b * wg_stride of the mini-batch (exact
@@ -370,6 +372,7 @@ struct FastSchedParams {
     int *used;                    // [n_batches]: header slots in use
     TaskHeader *tasks;
     int4 *recs;
+    int4 *slot_recs;              // [n_batches][tasks_per_batch][3]: see MfParams
 };
 
 // The keys (row << slot_bits | incidence, in incidence order) only have to be grouped by row with the incidences of a row in
@@ -555,7 +558,20 @@ __device__ __forceinline__ void mf_sched_emit_body(const FastSchedParams &s) {
     const int4 rec = make_int4(u, i, s.per == 3 ? j : __float_as_int(s.sr[t]), role | (pu << 2) | (pi << 3) | (pj << 4) | (also << 5));
     s.recs[at] = rec;
     const int tp = s.qtask[at];
-    if (tp == SLOT_ABSORBED) return;
+    if (tp == SLOT_ABSORBED) {
+        // a sample of a PAIR task other than its first (pairs are aligned blocks of `group` sorted positions, the header belongs to the
+        // first): its record also goes where the mini-batch kernel finds it without having seen the header -- by header slot
+        const int q0 = q - q % s.group;
+        if (s.fuse && q0 != q) {
+            const int tp0 = s.qtask[(size_t)b * s.tasks_per_batch + q0];
+            if (tp0 != SLOT_ABSORBED && !(tp0 & META_WIDE)) {
+                const TaskHeader *lead = s.tasks + (size_t)b * s.tasks_per_batch + tp0;
+                if (lead->pad == 1 && lead->start == (int)((size_t)b * s.tasks_per_batch + q0))
+                    s.slot_recs[((size_t)b * s.tasks_per_batch + tp0) * 3 + (q - q0 - 1)] = rec;
+            }
+        }
+        return;
+    }
     TaskHeader *hd = s.tasks + (size_t)b * s.tasks_per_batch + (tp & (META_WIDE - 1));
     const int off = (int)(at - (size_t)hd->start);
     const int own = role == 0 ? pu : (role == 1 ? pi : pj);
@@ -730,6 +746,11 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
     // 2 400 cycles to arrive where the header, last written by the schedule, takes 900) -- not after it has arrived, and the ring
     // not after the index: a FunkSVD kernel began with three round trips one after the other.  Unconditionally for FunkSVD: a
     // branch around a load makes the compiler wait for it before the next one is issued.
+    // a pair task's other records: by slot, requested with the header (through the record list they were a dependent round trip
+    // in front of the row gathers of the lane groups 1 .. G - 1: 2 300 cycles until the rows were there against 1 800 for one sample)
+    int4 slot_rec = make_int4(0, 0, 0, 0);
+    if constexpr (BPR && G > 1)
+        slot_rec = p.slot_recs[(size_t)batch_local * p.slot_rec_stride + (size_t)min(wv, p.tasks_per_batch - 1) * 3 + max(lane / LPR - 1, 0)];
     long long batch_base = 0;
     MuRequest<T> mu_req;
     mu_req.st = MuState<T>{};
@@ -780,7 +801,9 @@ __device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int ba
         // -- its own row to write, nothing to sum across groups
         const bool pair = BPR && G > 1 && h0.w == 1;
         T sg_first = (T)0;
-        if (G > 1 && len > 1) {                    // single-sample tasks (most of them) go straight from the header to the rows
+        if (BPR && G > 1 && h0.w == 1) {           // pair task: the lane groups' records came with the header
+            if (g != 0) rec = slot_rec;
+        } else if (G > 1 && len > 1) {             // single-sample tasks (most of them) go straight from the header to the rows
             const int4 r = p.recs[start + min(base + g, len - 1)];
             if (g != 0) rec = r;
         }
@@ -1029,6 +1052,7 @@ template <class T> __device__ __forceinline__ void globalize(MfParams<T> &p) {
     p.loss_slots = as_global(p.loss_slots); p.state = as_global(p.state);
     p.su = as_global(p.su); p.si = as_global(p.si); p.sj = as_global(p.sj); p.sr = as_global(p.sr);
     p.tasks = as_global(p.tasks); p.recs = as_global(p.recs); p.ticks = as_global(p.ticks); p.used = as_global(p.used);
+    p.slot_recs = as_global(p.slot_recs);
 }
 
 template <int ALGO, class T, int VEC, int LPR, int KI, bool PLAIN_SGD>
@@ -1046,7 +1070,7 @@ __global__ __launch_bounds__(256, (PLAIN_SGD && ALGO == MI355REC_MF_BPR && sizeo
 __device__ __forceinline__ void globalize(FastSchedParams &f) {
     f.su = as_global(f.su); f.si = as_global(f.si); f.sj = as_global(f.sj); f.sr = as_global(f.sr);
     f.touched = as_global(f.touched); f.par = as_global(f.par); f.sorted_slot = as_global(f.sorted_slot); f.qtask = as_global(f.qtask);
-    f.used = as_global(f.used); f.tasks = as_global(f.tasks); f.recs = as_global(f.recs);
+    f.used = as_global(f.used); f.tasks = as_global(f.tasks); f.recs = as_global(f.recs); f.slot_recs = as_global(f.slot_recs);
 }
 template <int ALGO, class T>
 __global__ __launch_bounds__(256) void mf_group_sample_kernel(const MfParams<T> *__restrict__ table) {
@@ -1447,7 +1471,7 @@ struct mi355rec_mf {
     DeviceBuffer<int> sorted_slot, qtask, used;
     bool fast_schedule = false;
     DeviceBuffer<unsigned long long> ticks;
-    DeviceBuffer<int4> recs;
+    DeviceBuffer<int4> recs, slot_recs;
     size_t cub_tmp_bytes = 0;
     size_t stream_capacity = 0;      // samples
     long long batch_capacity = 0;    // mini-batches the task arrays can hold
@@ -1528,6 +1552,8 @@ void fill_params(mi355rec_mf *h, MfParams<T> &p) {
     p.su = h->su.ptr; p.si = h->si.ptr; p.sj = h->sj.ptr; p.sr = h->sr.ptr;
     p.samples_per_epoch = batches_per_epoch(h) * (long long)c.batch_size;
     p.tasks = h->tasks.ptr; p.recs = h->recs.ptr;
+    p.slot_recs = h->slot_recs.ptr;
+    p.slot_rec_stride = h->fast_schedule ? 3ll * per_sample(h) * c.batch_size : 0;      // (see ensure_stream_capacity)
     // (only the replica-batched launch sizes its grid below the slot count; it runs whole epochs, i.e. batches_per_epoch mini-batches)
     p.used = h->fast_schedule && fast_schedule_fits(h, batches_per_epoch(h)) ? h->used.ptr : nullptr;
     p.ticks = h->ticks.ptr;
@@ -1663,7 +1689,7 @@ FastSchedParams fast_sched_params(mi355rec_mf *h, long long n_samples) {
     f.su = h->su.ptr; f.si = h->si.ptr; f.sj = h->sj.ptr; f.sr = h->sr.ptr;
     f.touched = h->touched.ptr; f.par = h->par.ptr;
     f.sorted_slot = h->sorted_slot.ptr; f.qtask = h->qtask.ptr; f.used = h->used.ptr;
-    f.tasks = h->tasks.ptr; f.recs = h->recs.ptr;
+    f.tasks = h->tasks.ptr; f.recs = h->recs.ptr; f.slot_recs = h->slot_recs.ptr;
     // fused sample tasks: BPR only; not in the exact multi-GPU mode, whose exchange slabs hold one row per task slot
     f.fuse = h->cfg.algorithm == MI355REC_MF_BPR && h->shard_rank < 0 && !getenv("MI355REC_MF_NO_FUSE");
     return f;
@@ -1873,6 +1899,8 @@ void ensure_stream_capacity(mi355rec_mf *h, size_t n_samples, long long n_batche
         MI_HIP(hipMemsetAsync(h->tasks.ptr, 0, sizeof(TaskHeader) * (size_t)(table_batches + 1) * tpb, h->stream));
         h->recs.alloc((size_t)table_batches * tpb);          // records of batch b start at b * tpb in both schedule paths
         h->fast_schedule = fast1;
+        // (the mini-batch kernel reads a slot's pair records whatever the schedule: without the in-LDS schedule one mini-batch of zeros)
+        h->slot_recs.alloc_zero(3 * tpb * (size_t)(fast1 ? table_batches : 1), h->stream);
         if (h->fast_schedule) {
             h->sorted_slot.alloc((size_t)table_batches * tpb);
             h->qtask.alloc((size_t)table_batches * tpb);
