@@ -212,6 +212,39 @@ def test_native_epochs_match_oracle_on_the_device_stream(gpu):
         dev.close()
 
 
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_epochs_scheduled_ahead_equal_epochs_scheduled_in_turn(gpu, monkeypatch, symmetric):
+    """The next epoch's sample stream is drawn and scheduled on a second stream while an epoch's kernel runs, also across calls;
+    a replayed stream in between gives the prepared one up.  Same steps in the same order either way: S and the sample streams
+    must be equal to a run that schedules every epoch in turn (MI355REC_SLIM_NO_PRESCHED=1), call pattern 2 + 1 + replay + 1 + 2."""
+    X = synthetic_urm(700, 260, 21000, 1, 200, seed=11, values="binary")
+    rng = np.random.default_rng(3)
+    ru = rng.integers(0, X.shape[0], 500).astype(np.int32)
+    lens = np.diff(X.indptr)
+    ri = X.indices[X.indptr[ru] + (rng.random(500) * lens[ru]).astype(np.int64)].astype(np.int32)
+    rj = np.array([(int(i) + 1 + int(k)) % X.shape[1] for i, k in zip(ri, rng.integers(0, X.shape[1] - 1, 500))], np.int32)
+
+    def run():
+        ep = SLIM_BPR_MI355X_Epoch(X, symmetric=symmetric, learning_rate=0.05, sgd_mode="adagrad", random_seed=9, topK=50)
+        streams = []
+        ep.epochIteration_Cython(2); streams.append(ep.last_epoch_samples())
+        ep.epochIteration_Cython(1); streams.append(ep.last_epoch_samples())
+        ep.replay_samples(ru, ri, rj)
+        ep.epochIteration_Cython(1); streams.append(ep.last_epoch_samples())
+        ep.epochIteration_Cython(2); streams.append(ep.last_epoch_samples())
+        S = ep.get_S_dense()
+        ep._dealloc()
+        return S, streams
+
+    S_ahead, st_ahead = run()
+    monkeypatch.setenv("MI355REC_SLIM_NO_PRESCHED", "1")
+    S_turn, st_turn = run()
+    for a, b in zip(st_ahead, st_turn):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    np.testing.assert_allclose(S_ahead, S_turn, rtol=0, atol=1e-12)
+
+
 def test_long_profiles_and_hot_items(gpu):
     """Profiles longer than the 1024 entries a workgroup keeps in registers, and a stream that hammers two items."""
     X = synthetic_urm(300, 3000, 200000, 20, 2900, seed=5, values="binary")
