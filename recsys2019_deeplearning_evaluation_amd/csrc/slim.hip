@@ -204,6 +204,7 @@ struct DepParams {
     int *pred;
     long long n_cells;
     int step_bits;                  // cell pass: key = cell << step_bits | step (the radix sort walks as few bits as the stream needs)
+    int *bad_step;                  // symmetric store: first step whose negative item is in its user's profile (INT_MAX: none)
     unsigned no_cell;               // the diagonal's stand-in: all ones in the cell field (it is read but never written: it orders nothing)
     // owned rows of the dense store
     int *run_start;                 // [n_items] first position of the item's run in the sorted pairs
@@ -308,6 +309,9 @@ __global__ __launch_bounds__(256) void slim_cell_keys_kernel(const DepParams d) 
         // (packed lower triangle, as packed_cell: fits 32 bits up to 92 681 items)
         const unsigned ci = s == i ? d.no_cell : (unsigned)packed_cell(i, s);
         const unsigned cj = s == j ? d.no_cell : (unsigned)packed_cell(j, s);
+        // A negative item that the user has seen (the reference's sampler never draws one, .pyx:224-232; a replayed stream might):
+        // cell (i, j) IS cell (j, i) in this store, the step would touch it twice and wait for its own tag.  Reported, not run.
+        if (s == j) atomicMin(d.bad_step, t);
         d.keys[cp + 2 * idx] = ((unsigned long long)ci << d.step_bits) | (unsigned)t;
         d.vals[cp + 2 * idx] = (int)(cp + 2 * idx);
         d.keys[cp + 2 * idx + 1] = ((unsigned long long)cj << d.step_bits) | (unsigned)t;
@@ -1543,7 +1547,7 @@ void ensure_set_capacity(mi355rec_slim *h, StreamSet &st, size_t n) {
     if (h->cfg.symmetric) {
         st.desc.alloc(n);
         st.order.alloc(n);
-        if (!st.n_short_dev.ptr) st.n_short_dev.alloc(1);
+        if (!st.n_short_dev.ptr) st.n_short_dev.alloc(2);      // [1]: first step with a seen negative item
     }
     if (!st.run_start.ptr) {
         st.run_start.alloc((size_t)h->n_items);
@@ -1715,12 +1719,19 @@ void schedule_stream(mi355rec_slim *h, StreamSet &st, int n, int first, hipStrea
         d.step_bits = bits_for((unsigned long long)n);
         const int cell_bits = bits_for((unsigned long long)h->n_items * ((unsigned long long)h->n_items + 1) / 2 + 1);
         d.no_cell = (unsigned)((1ull << cell_bits) - 1ull);
+        d.bad_step = st.n_short_dev.ptr + 1;
+        MI_HIP(hipMemsetAsync(d.bad_step, 0x7F, sizeof(int), s));
         hipLaunchKernelGGL(slim_cell_keys_kernel, dim3(div_up(n, 4)), dim3(256), 0, s, d);
         sort_pairs(h, h->keys_sorted.ptr, h->vals_sorted.ptr, (size_t)n_cells, cell_bits + d.step_bits, s);
         hipLaunchKernelGGL(slim_pred_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, s, d);
         hipLaunchKernelGGL(slim_desc_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, d, 1);
         MI_HIP(hipGetLastError());
+        int bad = 0;
+        MI_HIP(hipMemcpyAsync(&bad, d.bad_step, sizeof(int), hipMemcpyDeviceToHost, s));
         MI_HIP(hipStreamSynchronize(s));
+        if (bad < n)
+            fail(MI355REC_E_INVALID, "sample %d: the negative item is in the user's profile (the symmetric store holds cell (i, j) and cell (j, i) "
+                 "as one cell; the reference's sampler never draws a seen item)", first + bad);
     }
     st.n = n;
 }

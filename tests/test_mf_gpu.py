@@ -110,22 +110,22 @@ def test_funk_replay_parity(gpu, mode, use_bias):
 @pytest.mark.parametrize("mode", ["sgd", "adam"])
 def test_long_streams_in_several_calls_and_schedule_parts(gpu, mode):
     """A stream longer than the in-LDS schedule holds (256 mini-batches) is scheduled part by part, each part a stream of its own
-    for the global mini-batch index (Adam's t) and the global-bias ring; so is every call.  700 mini-batches of FunkSVD with
-    biases, handed over in three calls of 300 + 1 + 399 mini-batches, must land where the oracle's one epoch lands."""
+    for the global mini-batch index (Adam's t) and the global-bias ring; so is every call.  600 mini-batches of FunkSVD with
+    biases, in one call and handed over in three calls of 300 + 1 + 299 mini-batches, must land where the oracle lands."""
     X = named_urm("ml1m", "real", scale=0.08)
-    kw = dict(n_factors=16, algorithm_name="FUNK_SVD", batch_size=64, random_seed=5, sgd_mode=mode, learning_rate=0.01,
+    kw = dict(n_factors=16, algorithm_name="FUNK_SVD", batch_size=16, random_seed=5, sgd_mode=mode, learning_rate=0.01,
               user_reg=0.01, item_reg=0.3, positive_reg=0.0, bias_reg=0.02, use_bias=True, negative_interactions_quota=0.2)
     orc = O.OracleMF(X, **kw)
     orc.record_samples(10 ** 7)
     orc.epochIteration_Cython()
     u, i, j, r = orc.recorded()
-    n = 700 * 64
+    n = 600 * 16
     assert len(u) >= n
     orc = O.OracleMF(X, **kw)
     orc.replay(u[:n], i[:n], rating=r[:n])
     dev = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=orc.initial_USER_factors, initial_ITEM_factors=orc.initial_ITEM_factors, **kw)
     one = MatrixFactorization_MI355X_Epoch(X, initial_USER_factors=orc.initial_USER_factors, initial_ITEM_factors=orc.initial_ITEM_factors, **kw)
-    for a, b in ((0, 300 * 64), (300 * 64, 301 * 64), (301 * 64, n)):
+    for a, b in ((0, 300 * 16), (300 * 16, 301 * 16), (301 * 16, n)):
         dev.replay_samples(u[a:b], i[a:b], rating=r[a:b])
     one.replay_samples(u[:n], i[:n], rating=r[:n])
     for m in (dev, one):

@@ -195,6 +195,14 @@ def test_replay_rejects_a_sample_whose_items_coincide(gpu):
     with pytest.raises(Exception, match="positive item is its negative item"):
         dev.replay_samples(np.array([0, 1]), np.array([3, 4]), np.array([5, 4]))
     dev.close()
+    # symmetric store: a negative item the user has seen would make cell (i, j) and cell (j, i) -- one cell there -- part of the
+    # same step twice; the reference's sampler never draws one (.pyx:224-232), a replayed stream that holds one is refused
+    sym = SLIM_BPR_MI355X_Epoch(X, topK=False, symmetric=True, sgd_mode="sgd", random_seed=1)
+    row = X.indices[X.indptr[7]:X.indptr[8]]
+    assert len(row) >= 2
+    with pytest.raises(ValueError, match="negative item is in the user's profile"):
+        sym.replay_samples(np.array([7]), np.array([row[0]]), np.array([row[1]]))
+    sym.close()
 
 
 def test_native_epochs_match_oracle_on_the_device_stream(gpu):
@@ -222,7 +230,13 @@ def test_epochs_scheduled_ahead_equal_epochs_scheduled_in_turn(gpu, monkeypatch,
     ru = rng.integers(0, X.shape[0], 500).astype(np.int32)
     lens = np.diff(X.indptr)
     ri = X.indices[X.indptr[ru] + (rng.random(500) * lens[ru]).astype(np.int64)].astype(np.int32)
-    rj = np.array([(int(i) + 1 + int(k)) % X.shape[1] for i, k in zip(ri, rng.integers(0, X.shape[1] - 1, 500))], np.int32)
+    rj = np.empty(500, np.int32)
+    for t in range(500):                                     # an item the user has not seen, as the reference's sampler draws it
+        seen = X.indices[X.indptr[ru[t]]:X.indptr[ru[t] + 1]]
+        while True:
+            rj[t] = rng.integers(0, X.shape[1])
+            if rj[t] not in seen:
+                break
 
     def run():
         ep = SLIM_BPR_MI355X_Epoch(X, symmetric=symmetric, learning_rate=0.05, sgd_mode="adagrad", random_seed=9, topK=50)
