@@ -378,40 +378,47 @@ class ShardedIALSEpoch:
         self.user_ranges, self.item_ranges = ials_row_ranges(confidence_csr, world, self.k)
         self.dU, self.dV = epoch_object.device_factor_pointers()
         if world > 1:
-            # a half-step's rows are solved in `chunks` pieces: the all-gather of a finished piece travels while the next one is solved
+            # a half-step's rows are solved in pieces: the all-gather of a finished piece travels while the next one is solved.  `chunks`:
+            # one number, or (user half, item half).  Default (4, 1): measured on one GPU (bench.py extra.ials.emulated_8_way, ML-20M shape,
+            # k = 200) the four pieces of a user range cost 12.3 ms against 11.2 ms in one go -- less than the 3 ms of exchange they hide
+            # on one ring --, the four pieces of an item range 10.3 ms against 7.6 ms (the longest-first order inside a range is what keeps
+            # its tail short): the item half goes in one piece.
+            cu, ci = (chunks if isinstance(chunks, (tuple, list)) else (chunks, chunks)) if chunks is not None else (4, 1)
             self.widest = max(max(e - s for s, e in self.user_ranges), max(e - s for s, e in self.item_ranges))
-            self.rows = chunk_bounds(self.widest, 4 if chunks is None else chunks)
             self.slab_words = 2 * self.widest * self.k                       # float64 = two 4-byte words
             self.send = N.DeviceArray(self.slab_words)
             self.recv = N.DeviceArray(world * self.slab_words)
-            self.gather = ChunkedAllGather(self.send, self.recv, [2 * (r1 - r0) * self.k for r0, r1 in self.rows], world, dist, comm)
+            self.rows_of = {"users": chunk_bounds(self.widest, cu), "items": chunk_bounds(self.widest, ci)}
+            self.gather_of = {half: ChunkedAllGather(self.send, self.recv, [2 * (r1 - r0) * self.k for r0, r1 in rows], world, dist, comm)
+                              for half, rows in self.rows_of.items()}
 
     def _copy(self, dst, src, nbytes):
         import ctypes as C
         if nbytes:
             self._N.check(self._N.load().mi355rec_device_memcpy(C.c_void_p(dst), C.c_void_p(src), int(nbytes), 2))
 
-    def _half(self, solve, base, ranges):
+    def _half(self, solve, base, ranges, half):
         """The rank's rows piece by piece: solve, stage in the send slab, start the piece's all-gather, go on with the next piece;
         at the end the other ranks' rows are copied into place."""
         row = 8 * self.k
+        rows, gather = self.rows_of[half], self.gather_of[half]
         s, e = ranges[self.rank]
-        for c, (r0, r1) in enumerate(self.rows):
+        for c, (r0, r1) in enumerate(rows):
             a, b = min(s + r0, e), min(s + r1, e)
             if b > a:
                 solve(a, b)
                 self.epoch.synchronize()
-                self._copy(self.send.address(self.gather.offsets[c]), base + a * row, (b - a) * row)
+                self._copy(self.send.address(gather.offsets[c]), base + a * row, (b - a) * row)
                 self._N.check(self._N.load().mi355rec_device_synchronize())
-            self.gather.start(c)
-        self.gather.finish()
+            gather.start(c)
+        gather.finish()
         for r, (ra, rb) in enumerate(ranges):
             if r == self.rank:
                 continue
-            for c, (r0, r1) in enumerate(self.rows):
+            for c, (r0, r1) in enumerate(rows):
                 a, b = min(ra + r0, rb), min(ra + r1, rb)
                 if b > a:
-                    self._copy(base + a * row, self.recv.address(self.world * self.gather.offsets[c] + r * self.gather.words[c]), (b - a) * row)
+                    self._copy(base + a * row, self.recv.address(self.world * gather.offsets[c] + r * gather.words[c]), (b - a) * row)
         # the next half-step runs on the epoch object's own (non-blocking) stream: do not rely on hipMemcpy being synchronous for
         # device-to-device copies
         self._N.check(self._N.load().mi355rec_device_synchronize())
@@ -421,8 +428,8 @@ class ShardedIALSEpoch:
         if self.world == 1:
             self.epoch.run_epochs(1)
             return
-        self._half(self.epoch.user_half, self.dU, self.user_ranges)
-        self._half(self.epoch.item_half, self.dV, self.item_ranges)
+        self._half(self.epoch.user_half, self.dU, self.user_ranges, "users")
+        self._half(self.epoch.item_half, self.dV, self.item_ranges, "items")
 
     def exchange_bytes_per_rank_per_epoch(self):
         return 0 if self.world == 1 else 2 * 4 * self.slab_words
