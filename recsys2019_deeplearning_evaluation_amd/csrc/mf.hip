@@ -43,1406 +43,13 @@
 
 #include <memory>
 
-namespace mi355rec {
-namespace {
+// One translation unit, split by stage (round 4): the device code lives in the four headers below (parameters + optimiser step +
+// sampler | schedules | mini-batch kernels | AsySVD), this file holds the handles, kernel selection, graphs and the C ABI.
+#include "mf_core.cuh"
+#include "mf_schedule.cuh"
+#include "mf_batch.cuh"
+#include "mf_asy.cuh"
 
-struct MfState {           // lives in device memory so that graph replays carry no per-epoch host arguments
-    long long batch_base;  // mini-batches executed before the stream now in the buffers (Adam's t, global-bias ring)
-    long long epoch;       // index (since create) of the epoch the next sampling kernel draws
-    double beta_1_power, beta_2_power;   // AsySVD: Adam's running products (advanced once per step, .pyx:536-539)
-    double asy_loss;
-};
-
-struct TaskHeader {        // 32 bytes, one per (row, mini-batch) incidence
-    int entry;             // user row u, or n_users + item
-    int meta;              // bit 31: buffer holding the row's current version; bits 0..27: number of samples
-    int start;             // first record of the list (recs[], sorted order)
-    int pad;
-    int4 rec0;             // the first record itself: single-sample tasks (most of them) need no second load
-};
-constexpr int LEN_MASK = 0x0fffffff;
-typedef int int8v __attribute__((ext_vector_type(8)));
-// record .w: bits 0-1 role of the task's row in this sample (0 user, 1 item / positive item, 2 negative item),
-//            bit 2 / 3 / 4: buffer of the sample's user / item / negative-item row
-//            bit 5 / 6 (user role, fast schedule): this task also updates the sample's positive / negative item row
-constexpr int ROLE_U = 0, ROLE_I = 1;   // 2: negative item
-
-template <class T> struct MuState { T mu, c1, c2, pad; };
-// one L2 atomic per workgroup that carries global-bias terms: atomics on ONE address retire at about 0.2 us each (measured through
-// the batch kernel: 31 per address cost 3 us per mini-batch), so the terms are spread over a wavefront's worth of addresses
-constexpr int MU_SLOTS = 64;
-// (Measured and rejected: no atomics at all -- one cell per workgroup, every wavefront of the next batch folds the ~500 cells in a
-// fixed order, which makes the global bias bit-reproducible -- costs 8 loads per lane and wavefront: 157 ms per FunkSVD epoch at
-// ML-20M shape against 145 ms with 64 atomic slots and 164 ms with 16.)
-
-template <class T>
-struct MfParams {
-    int n_users, n_items, k, batch_size;
-    int use_bias, sgd_mode, sample_negatives, tasks_per_batch;
-    T lr, user_reg, item_reg, bias_reg, positive_reg, negative_reg, inv_batch;
-    T gamma, beta_1, beta_2, one_m_gamma, one_m_beta_1, one_m_beta_2;
-    float quota;
-    double beta_1_d, beta_2_d;
-    unsigned long long seed;
-    const int *indptr, *indices;
-    const float *data;
-    T *U0, *U1, *V0, *V1;                // two buffers per factor matrix: version v of a row lives in buffer v & 1
-    T *bu0, *bu1, *bi0, *bi1;
-    T *c1U, *c2U, *c1V, *c2V;            // optimiser state (one copy: only the row's own task touches it)
-    T *c1_bu, *c2_bu, *c1_bi, *c2_bi;
-    MuState<T> *mu_state;                // [3] ring: global bias after batch b - 1, written by batch b        (FunkSVD)
-    T *mu_acc;                           // [3][MU_SLOTS] ring: batch b's global-bias gradient terms, spread over MU_SLOTS addresses
-    T *asy_mu, *asy_c_mu;                // AsySVD: global bias and its optimiser state, updated in place
-    unsigned char *par;                  // [n_u_rows + n_items] buffer of every row's current version at stream start
-    double *loss_slots;                  // [tasks_per_batch * 4] per (wavefront, group) running loss
-    MfState *state;
-    // sample stream: one epoch drawn by mf_sample_kernel (native) or the caller's stream (replay)
-    int *su, *si, *sj;
-    float *sr;
-    long long samples_per_epoch;
-    // schedule
-    const TaskHeader *tasks;
-    const int4 *recs;
-    const int4 *slot_recs;               // in-LDS schedule: [mini-batch][slot][3] records 1 .. group - 1 of a PAIR task, by header slot: their
-    long long slot_rec_stride;           // address does not depend on the header (0: radix-sort schedule, one dummy mini-batch)
-    const int *used;                     // fast schedule: header slots in use per mini-batch of the stream (NULL: all of them may be)
-    unsigned long long *ticks;           // optional [tasks_per_batch][8] shader-clock stamps of the last mini-batch (MI355REC_MF_TICKS=1)
-    int wg_base, wg_stride;              // workgroup b of the launch is workgroup wg_base + b * wg_stride of the mini-batch (exact
-                                         // multi-GPU mode: rank r of G runs workgroups r, r + G, ...; otherwise 0 and 1)
-};
-
-__device__ __forceinline__ unsigned long long stamp() {   // shader clock; not reordered against memory operations
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-}
-
-__device__ __forceinline__ float sigmoid_of_minus(float x) { return 1.f / (1.f + __expf(x)); }   // .pyx:619
-__device__ __forceinline__ double sigmoid_of_minus(double x) { return 1.0 / (1.0 + exp(x)); }
-__device__ __forceinline__ float root(float x) { return sqrtf(x); }
-__device__ __forceinline__ double root(double x) { return sqrt(x); }
-
-// adaptive_gradient (.pyx:835-873) on one cell whose state is passed by reference; pw1/pw2 = 1 - beta^t
-template <class T, class P>
-__device__ __forceinline__ T adapt_cell(const P &p, T g, T &c1, T &c2, T pw1, T pw2) {
-    switch (p.sgd_mode) {
-        case MI355REC_ADAGRAD:
-            c1 = c1 + g * g;
-            return g / (root(c1) + (T)1e-8);
-        case MI355REC_RMSPROP:
-            c1 = c1 * p.gamma + p.one_m_gamma * (g * g);
-            return g / (root(c1) + (T)1e-8);
-        case MI355REC_ADAM: {
-            c1 = c1 * p.beta_1 + p.one_m_beta_1 * g;
-            c2 = c2 * p.beta_2 + p.one_m_beta_2 * (g * g);
-            return (c1 / pw1) / (root(c2 / pw2) + (T)1e-8);
-        }
-        default:
-            return g;
-    }
-}
-// the same on a cell in memory
-template <class T, class P>
-__device__ __forceinline__ T adapt(const P &p, T g, T *c1, T *c2, size_t at, T pw1, T pw2) {
-    if (p.sgd_mode == MI355REC_SGD) return g;
-    T a = c1[at], b = p.sgd_mode == MI355REC_ADAM ? c2[at] : (T)0;
-    const T step = adapt_cell(p, g, a, b, pw1, pw2);
-    c1[at] = a;
-    if (p.sgd_mode == MI355REC_ADAM) c2[at] = b;
-    return step;
-}
-
-// The gradient of one sample on one row and the application of a row's summed gradient, with every operation rounded on its own
-// (no fused multiply-add, whatever the surrounding code looks like): the same row may be updated by its own task or by the
-// sample's user task (fused sample tasks), alone or next to other samples in one launch (replica batches), and the result must not
-// depend on which -- the backend contracts a * b - c * d differently from one call site to the next.  This is also how the
-// reference's scalar double code rounds.
-template <class T> __device__ __forceinline__ T grad_term(T scale, T x, T reg, T w) {       // scale * x - reg * w   (.pyx:626-639, 343-352)
-#pragma clang fp contract(off)
-    const T a = scale * x;
-    const T b = reg * w;
-    return a - b;
-}
-// a * b + c in ONE rounding, spelled out: left to the backend, the sum of products of a dot product came out fused in one
-// instantiation of the mini-batch body and as packed multiply + packed add in another (seen in round 4 between a model trained
-// alone and the same model inside a group, once the two were built from different instantiations: 4 of 72 480 cells one ulp apart)
-__device__ __forceinline__ float fused_add(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double fused_add(double a, double b, double c) { return __builtin_fma(a, b, c); }
-template <class T> __device__ __forceinline__ T diff_of(T a, T b) {
-#pragma clang fp contract(off)
-    return a - b;
-}
-template <class T> __device__ __forceinline__ T mean_of(T sum, T inv_batch) {
-#pragma clang fp contract(off)
-    return sum * inv_batch;
-}
-template <class T> __device__ __forceinline__ T moved(T w, T lr, T step) {                   // w + lr * step   (.pyx:809-812)
-#pragma clang fp contract(off)
-    const T a = lr * step;
-    return w + a;
-}
-
-// One thread per sample of one epoch (sampleBPR_Cython .pyx:940-985 / sampleMSE_Cython :878-935).
-template <int ALGO, class T>
-__device__ __forceinline__ void mf_sample_body(const MfParams<T> &p) {
-    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    const long long epoch = p.state->epoch;
-    if (t < p.samples_per_epoch) {
-        const unsigned long long sid = (unsigned long long)(epoch * p.samples_per_epoch + t);   // global sample id
-        unsigned d = 0;
-        int u, start = 0, n_seen = 0;
-        do {   // users with no interactions or with no negative item are skipped (.pyx:950-958)
-            u = bounded(draw32(p.seed, sid, d++), p.n_users);
-            start = p.indptr[u];
-            n_seen = p.indptr[u + 1] - start;
-        } while (n_seen == 0 || n_seen == p.n_items);
-        const int *row = p.indices + start;
-        p.su[t] = u;
-        if (ALGO == MI355REC_MF_BPR) {
-            p.si[t] = row[bounded(draw32(p.seed, sid, d++), n_seen)];
-            int j;
-            do { j = bounded(draw32(p.seed, sid, d++), p.n_items); } while (!profile_lacks(row, n_seen, j));
-            p.sj[t] = j;
-        } else {
-            // .pyx:898: a POSITIVE is drawn with probability `quota` (sic); no quota -> always positive
-            bool positive = true;
-            if (p.sample_negatives) positive = (float)draw32(p.seed, sid, d++) * 2.3283064365386963e-10f <= p.quota;
-            if (positive) {
-                const int at = bounded(draw32(p.seed, sid, d++), n_seen);
-                p.si[t] = row[at];
-                p.sr[t] = p.data[start + at];
-            } else {
-                int i;
-                do { i = bounded(draw32(p.seed, sid, d++), p.n_items); } while (!profile_lacks(row, n_seen, i));
-                p.si[t] = i;
-                p.sr[t] = 0.f;
-            }
-        }
-    }
-    // (the epoch counter is advanced by the NEXT kernel on the stream, mf_epoch_advance_kernel: a grid larger than the device's
-    // residency -- FunkSVD draws 20 M samples per epoch -- still has blocks to start when the first ones retire, and they must
-    // read the same epoch)
-}
-template <int ALGO, class T>
-__global__ __launch_bounds__(256) void mf_sample_kernel(const MfParams<T> p) { mf_sample_body<ALGO, T>(p); }
-__global__ void mf_epoch_advance_kernel(MfState *state) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) state->epoch += 1;
-}
-
-// ---- schedule: (row, mini-batch) incidences -> tasks ----------------------------------------------------------------
-struct SchedParams {
-    long long n_samples;
-    int per;                 // incidences per sample: 3 (BPR) / 2 (FunkSVD)
-    int n_users, batch_size, batch_bits, tasks_per_batch;
-    const int *su, *si, *sj;
-    const float *sr;
-    unsigned long long *keys;      // unsorted keys: entry << batch_bits | batch
-    int *slots;                    // unsorted values: sample * per + role
-    const unsigned long long *keys_sorted;
-    const int *slots_sorted;
-    int *head;                     // 1 where a new (row, batch) run starts
-    const int *head_scan;          // inclusive scan of head
-    int *task_at;                  // for run heads: index of the task header
-    unsigned char *spar;           // per incidence: buffer of the row's version this sample reads
-    unsigned char *par;            // per row: buffer of the current version (advanced by the last task of the row)
-    int *batch_count;
-    int *slot_flag;                // per original slot (sample * per + role): 1 where a task's first incidence sits
-    const int *slot_rank;          // exclusive scan of slot_flag
-    TaskHeader *tasks;
-    int4 *recs;
-};
-
-__global__ __launch_bounds__(256) void mf_keys_kernel(const SchedParams s) {
-    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (t >= s.n_samples) return;
-    const unsigned long long batch = (unsigned long long)(t / s.batch_size);
-    const long long q = t * s.per;
-    s.keys[q] = ((unsigned long long)s.su[t] << s.batch_bits) | batch;
-    s.slots[q] = (int)q;
-    s.keys[q + 1] = ((unsigned long long)(s.n_users + s.si[t]) << s.batch_bits) | batch;
-    s.slots[q + 1] = (int)q + 1;
-    if (s.per == 3) {
-        s.keys[q + 2] = ((unsigned long long)(s.n_users + s.sj[t]) << s.batch_bits) | batch;
-        s.slots[q + 2] = (int)q + 2;
-    }
-}
-
-__global__ __launch_bounds__(256) void mf_heads_kernel(const SchedParams s) {
-    const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (q >= s.n_samples * s.per) return;
-    const int head = q == 0 || s.keys_sorted[q] != s.keys_sorted[q - 1];
-    s.head[q] = head;
-    if (head) s.slot_flag[s.slots_sorted[q]] = 1;      // (the sort is stable: the run's first incidence in stream order)
-}
-
-// One thread per run head: version parity of the row at this batch, a place in the batch's task array, the header.
-__global__ __launch_bounds__(256) void mf_tasks_kernel(const SchedParams s) {
-    const long long n = s.n_samples * s.per;
-    const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (q >= n || !s.head[q]) return;
-    const unsigned long long key = s.keys_sorted[q];
-    const int entry = (int)(key >> s.batch_bits);
-    const int batch = (int)(key & ((1ull << s.batch_bits) - 1));
-    long long end = q + 1;
-    while (end < n && !s.head[end]) ++end;
-    // rank of this batch among the batches of the stream that touch the row = number of run heads since the row's first
-    const unsigned long long first_key = (unsigned long long)entry << s.batch_bits;
-    long long lo = 0, hi = q;
-    while (lo < hi) {
-        const long long mid = (lo + hi) >> 1;
-        if (s.keys_sorted[mid] < first_key) lo = mid + 1; else hi = mid;
-    }
-    const int rank = s.head_scan[q] - s.head_scan[lo];
-    const int parity = (s.par[entry] + rank) & 1;
-    // the task's place among the mini-batch's headers = the rank of its FIRST incidence (the sort is stable: the smallest
-    // sample * per + role of the run) among the first incidences of the batch's tasks: headers are packed at the front of
-    // the batch's slots in stream order -- the same layout on every replica of the stream (the exact multi-GPU mode splits a
-    // mini-batch's slots over the ranks), with no atomic counter (three mini-batches of 65 536 samples used to serialise
-    // 590 k atomics on three addresses: 86 M samples/s against 230 M)
-    const long long first_slot = (long long)batch * s.tasks_per_batch;
-    // -- or, with a per-batch counter (s.batch_count), simply the next free one: run heads arrive roughly in key order, i.e. the
-    // batch's headers end up sorted by row (users first), which the mini-batch kernel of FunkSVD's 20 001 small batches likes
-    // better (118 vs 87 M samples/s at ML-20M shape: neighbouring wavefronts gather neighbouring rows, and the workgroups that
-    // carry global-bias terms are the leading ones)
-    int at = (int)first_slot;
-    if (s.batch_count) at += atomicAdd(&s.batch_count[batch], 1);
-    else at += s.slot_rank[s.slots_sorted[q]] - s.slot_rank[first_slot];
-    s.task_at[q] = at;
-    TaskHeader h;
-    h.entry = entry;
-    h.meta = (int)(end - q) | (parity << 31);
-    h.start = (int)q;
-    h.pad = 0;
-    s.tasks[at].entry = h.entry;
-    s.tasks[at].meta = h.meta;
-    s.tasks[at].start = h.start;
-    s.tasks[at].pad = 0;
-    for (long long r = q; r < end; ++r) s.spar[s.slots_sorted[r]] = (unsigned char)parity;
-}
-
-// One thread per incidence (sorted order): the sample record with the parities of all its rows.
-__global__ __launch_bounds__(256) void mf_recs_kernel(const SchedParams s) {
-    const long long n = s.n_samples * s.per;
-    const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    const int slot = s.slots_sorted[q];
-    const int sample = slot / s.per, role = slot - sample * s.per;
-    const long long base = (long long)sample * s.per;
-    int4 rec;
-    rec.x = s.su[sample];
-    rec.y = s.si[sample];
-    rec.z = s.per == 3 ? s.sj[sample] : __float_as_int(s.sr[sample]);
-    rec.w = role | (s.spar[base] << 2) | (s.spar[base + 1] << 3) | (s.per == 3 ? s.spar[base + 2] << 4 : 0);
-    s.recs[q] = rec;
-    if (s.head[q]) {
-        s.tasks[s.task_at[q]].rec0 = rec;
-        // last task of this row in the stream: the next stream starts from the other buffer
-        const int entry = (int)(s.keys_sorted[q] >> s.batch_bits);
-        long long end = q + 1;
-        while (end < n && !s.head[end]) ++end;
-        if (end == n || (int)(s.keys_sorted[end] >> s.batch_bits) != entry) s.par[entry] = s.spar[slot] ^ 1;
-    }
-}
-
-// ---- fast schedule: one workgroup per mini-batch sorts its incidences in LDS -----------------------------------------------
-// The general path above radix-sorts the whole stream (device-wide sort: 120 us for the 417 k incidences
-// of a BPR epoch at ML-20M shape, plus 270 us for the task kernel's dependent searches) -- two thirds of the time of the 139
-// mini-batches it prepares.  When a mini-batch fits LDS and the stream has at most 256 mini-batches the same tasks come out of
-// three short kernels: (1) per mini-batch, a stable radix sort of (row, slot) keys in LDS, run lengths, task slots (lists longer
-// than two rounds of one wavefront get the 4 wavefronts of a workgroup: 4 aligned headers), and one bit per (row, mini-batch) in a global bitmap;
-// (2) per incidence, the version parity of each of the sample's rows = parity at stream start + number of earlier
-// mini-batches with the row's bit set; (3) per row, the parity after the stream, bitmap cleared for the next one.
-constexpr int META_WIDE = 1 << 30;        // header.meta: bits 0-27 list length, 28-29 quarter, 30 wide, 31 buffer of the own row
-constexpr int SCHED_THREADS = 1024;
-constexpr int SLOT_ABSORBED = 0x3fffffff;   // qtask[] of an incidence whose row is updated by its sample's user task (no header of its own)
-constexpr int FAST_MAX_BATCHES = 256, FAST_MAX_SLOTS = 8192;
-
-struct FastSchedParams {
-    long long n_samples;
-    int per, n_users, n_entries, batch_size, tasks_per_batch, slot_bits, np, words, group;
-    int mid_bytes;                // LDS bytes between the keys and the once-touched flags (run starts + header slots, or the sort's scratch)
-    int entry_bits;               // bits of a row id (users, then items) + 1: the padding keys' all-ones field sorts last
-    int fuse;                     // BPR: a sample whose user row is touched once in the batch takes over its other once-touched rows
-    const int *su, *si, *sj;
-    const float *sr;
-    unsigned *touched;            // [n_entries][words]: bit b of row x = mini-batch b of this stream touches x
-    unsigned char *par;           // [n_entries]: buffer of every row's current version at stream start
-    int *sorted_slot;             // [n_batches][tasks_per_batch]: batch-local incidence ids in (row, id) order
-    int *qtask;                   // per sorted position: batch-local slot of its task's (first) header | wide << 30
-    int *used;                    // [n_batches]: header slots in use
-    TaskHeader *tasks;
-    int4 *recs;
-    int4 *slot_recs;              // [n_batches][tasks_per_batch][3]: see MfParams
-};
-
-// The keys (row << slot_bits | incidence, in incidence order) only have to be grouped by row with the incidences of a row in
-// stream order: a STABLE radix sort on the row bits does it in (row bits + 7) / 8 passes (rocPRIM block sort) where the bitonic
-// network of round 2 needed 78 barrier-separated stages for 4096 keys (74 us per mini-batch: as much as the mini-batch itself
-// once 32 models share a launch).
-template <int IPT> struct SchedSort {
-    using type = rocprim::block_radix_sort<unsigned, SCHED_THREADS, IPT>;
-    static __device__ __forceinline__ void run(unsigned *K, void *storage, int begin_bit, int end_bit) {
-        unsigned keys[IPT];
-#pragma unroll
-        for (int i = 0; i < IPT; ++i) keys[i] = K[threadIdx.x * IPT + i];
-        type().sort(keys, *reinterpret_cast<typename type::storage_type *>(storage), (unsigned)begin_bit, (unsigned)end_bit);
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < IPT; ++i) K[threadIdx.x * IPT + i] = keys[i];
-    }
-};
-constexpr size_t sched_sort_storage_bytes(int np) {
-    return np <= SCHED_THREADS ? sizeof(SchedSort<1>::type::storage_type)
-           : (np <= 2 * SCHED_THREADS ? sizeof(SchedSort<2>::type::storage_type)
-              : (np <= 4 * SCHED_THREADS ? sizeof(SchedSort<4>::type::storage_type) : sizeof(SchedSort<8>::type::storage_type)));
-}
-
-__device__ __forceinline__ void mf_sched_sort_body(const FastSchedParams &s, const int b) {
-    extern __shared__ __attribute__((aligned(16))) unsigned sched_lds[];
-    unsigned *K = sched_lds;                                   // [np] keys: row << slot_bits | incidence
-    int *hpos = reinterpret_cast<int *>(sched_lds + s.np);     // [np + 1] first sorted position of every run
-    int *tpos = hpos + s.np + 1;                               // [np] header slot of every task
-    typedef rocprim::block_scan<int, SCHED_THREADS> Scan;
-    __shared__ typename Scan::storage_type scan_tmp;
-    const int tid = threadIdx.x, np = s.np, sb = s.slot_bits;
-    const long long first = (long long)b * s.batch_size;
-    const int n_in = (int)min((long long)s.batch_size, s.n_samples - first);
-    const int m = n_in * s.per;
-    for (int q = tid; q < np; q += SCHED_THREADS) {
-        unsigned key = 0xFFFFFFFFu;
-        if (q < m) {
-            const int smp = q / s.per, role = q - smp * s.per;
-            const long long t = first + smp;
-            const int entry = role == 0 ? s.su[t] : s.n_users + (role == 1 ? s.si[t] : s.sj[t]);
-            key = ((unsigned)entry << sb) | (unsigned)q;
-        }
-        K[q] = key;
-    }
-    __syncthreads();
-    // (the sort's scratch lives where the run starts / header slots go afterwards)
-    switch (np / SCHED_THREADS) {
-        case 1: SchedSort<1>::run(K, hpos, sb, sb + s.entry_bits); break;
-        case 2: SchedSort<2>::run(K, hpos, sb, sb + s.entry_bits); break;
-        case 4: SchedSort<4>::run(K, hpos, sb, sb + s.entry_bits); break;
-        default: SchedSort<8>::run(K, hpos, sb, sb + s.entry_bits); break;
-    }
-    __syncthreads();
-    // run heads -> hpos[]
-    const int C = np / SCHED_THREADS;
-    int cnt = 0;
-    for (int c = 0; c < C; ++c) {
-        const int q = tid * C + c;
-        cnt += q < m && (q == 0 || (K[q] >> sb) != (K[q - 1] >> sb));
-    }
-    int off = 0, total = 0;
-    Scan().exclusive_scan(cnt, off, 0, total, scan_tmp);
-    for (int c = 0; c < C; ++c) {
-        const int q = tid * C + c;
-        if (q < m && (q == 0 || (K[q] >> sb) != (K[q - 1] >> sb))) hpos[off++] = q;
-    }
-    if (tid == 0) hpos[total] = m;
-    __syncthreads();
-    // FUSED SAMPLE TASKS (BPR).  Most rows of a mini-batch are touched by exactly one sample (users nearly always, uniformly drawn
-    // negative items mostly): as separate tasks each of them gathers the sample's three rows again -- nine row reads and three
-    // wavefronts per sample.  A sample whose USER row is touched once keeps one task (the user's) which also applies the update of
-    // the sample's item rows that are touched once (record bits 5 / 6: positive / negative item); those rows get no task of their
-    // own.  And `group` such tasks that sit next to each other in the sorted order share one wavefront (PAIR tasks, header word 3 =
-    // 1): its lane groups, which walk a list's samples `group` at a time, each take one of the samples and write that sample's
-    // rows -- a single-sample task leaves all but one lane group of its wavefront idle otherwise.  The arithmetic per row is
-    // unchanged.  single[q] = incidence q (sample * per + role) is alone in its run.
-    unsigned char *single = reinterpret_cast<unsigned char *>(sched_lds) + sizeof(unsigned) * (size_t)np + s.mid_bytes;
-    const unsigned qmask = (1u << sb) - 1u;
-    if (s.fuse) {
-        for (int q = tid; q < np; q += SCHED_THREADS) single[q] = 0;
-        __syncthreads();
-        for (int t = tid; t < total; t += SCHED_THREADS)
-            if (hpos[t + 1] - hpos[t] == 1) single[K[hpos[t]] & qmask] = 1;
-        __syncthreads();
-    }
-    auto absorbed = [&](int t) -> bool {          // a once-touched item row whose sample's user row is touched once, too
-        if (!s.fuse || hpos[t + 1] - hpos[t] != 1) return false;
-        const int inc = (int)(K[hpos[t]] & qmask), smp = inc / s.per;
-        return inc != smp * s.per && single[smp * s.per];
-    };
-    auto lone_user = [&](int q) -> bool {         // sorted position q is the single-sample run of a user row
-        if (q >= m) return false;
-        const unsigned e = K[q] >> sb;
-        return e < (unsigned)s.n_users && (q == 0 || (K[q - 1] >> sb) != e) && (q + 1 == m || (K[q + 1] >> sb) != e);
-    };
-    auto paired = [&](int q) -> bool {            // q lies in an aligned block of `group` positions that are all such runs
-        if (!s.fuse || s.group < 2) return false;
-        const int q0 = q - q % s.group;
-        for (int e = 0; e < s.group; ++e)
-            if (!lone_user(q0 + e)) return false;
-        return true;
-    };
-    // header slots: wide tasks first (4 aligned slots each), then the others; both in row order
-    const int CT = (total + SCHED_THREADS - 1) / SCHED_THREADS;
-    const int t_lo = min(tid * CT, total), t_hi = min(t_lo + CT, total);
-    int wcnt = 0, acnt = 0;
-    const int wide_min = 2 * s.group;               // longer than two rounds of one wavefront: split over a workgroup
-    for (int t = t_lo; t < t_hi; ++t) {
-        const int start = hpos[t], len = hpos[t + 1] - start;
-        wcnt += len > wide_min;
-        acnt += absorbed(t) || (len == 1 && start % s.group != 0 && paired(start));      // runs without a header of their own
-    }
-    int woff = 0, n_wide = 0, aoff = 0, n_abs = 0;
-    Scan().exclusive_scan(wcnt, woff, 0, n_wide, scan_tmp);
-    __syncthreads();
-    Scan().exclusive_scan(acnt, aoff, 0, n_abs, scan_tmp);
-    TaskHeader *out = s.tasks + (size_t)b * s.tasks_per_batch;
-    for (int t = t_lo; t < t_hi; ++t) {
-        const int start = hpos[t], len = hpos[t + 1] - start;
-        const bool wide = len > wide_min;
-        const int entry = (int)(K[start] >> sb);
-        atomicOr(&s.touched[(size_t)entry * s.words + (b >> 5)], 1u << (b & 31));      // (rows without a task advance a version, too)
-        const bool pair = len == 1 && paired(start);
-        if (absorbed(t) || (pair && start % s.group != 0)) {
-            ++aoff;
-            tpos[t] = SLOT_ABSORBED;
-            continue;
-        }
-        const int slot = wide ? 4 * woff : 4 * n_wide + (t - woff - aoff);
-        woff += wide;
-        tpos[t] = slot | (wide ? META_WIDE : 0);
-        for (int part = 0; part < (wide ? 4 : 1); ++part) {
-            *reinterpret_cast<int4 *>(out + slot + part) =
-                make_int4(entry, (pair ? s.group : len) | (wide ? META_WIDE | (part << 28) : 0), b * s.tasks_per_batch + start, pair ? 1 : 0);
-            out[slot + part].rec0 = make_int4(0, 0, 0, 0);     // (a short wide list leaves its last quarters without a record)
-        }
-    }
-    const int used = 4 * n_wide + (total - n_wide - n_abs);
-    if (tid == 0) s.used[b] = used;
-    for (int slot = used + tid; slot < s.tasks_per_batch; slot += SCHED_THREADS)
-        *reinterpret_cast<int4 *>(out + slot) = make_int4(0, 0, 0, 0);          // no samples: the slot's wavefront idles
-    __syncthreads();
-    for (int q = tid; q < m; q += SCHED_THREADS) {
-        int lo = 0, hi = total;                       // last run starting at or before q
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (hpos[mid] <= q) lo = mid; else hi = mid;
-        }
-        const int inc = (int)(K[q] & qmask);
-        int also = 0;                                 // the item rows a once-touched user row's task takes over (bits 16-17 here, 5-6 of the record)
-        if (s.fuse && hpos[lo + 1] - hpos[lo] == 1) {
-            const int smp = inc / s.per;
-            if (inc == smp * s.per) also = (single[inc + 1] ? 1 : 0) | (s.per == 3 && single[inc + 2] ? 2 : 0);
-        }
-        s.sorted_slot[(size_t)b * s.tasks_per_batch + q] = inc | (also << 16);
-        s.qtask[(size_t)b * s.tasks_per_batch + q] = tpos[lo];
-    }
-}
-__global__ __launch_bounds__(SCHED_THREADS) void mf_sched_sort_kernel(const FastSchedParams s) { mf_sched_sort_body(s, blockIdx.x); }
-
-__device__ __forceinline__ int version_parity(const FastSchedParams &s, int entry, int b) {
-    const unsigned *w = s.touched + (size_t)entry * s.words;
-    int cnt = 0;
-    for (int k = 0; k < (b >> 5); ++k) cnt += __popc(w[k]);
-    cnt += __popc(w[b >> 5] & ((1u << (b & 31)) - 1u));
-    return (s.par[entry] + cnt) & 1;
-}
-
-__device__ __forceinline__ void mf_sched_emit_body(const FastSchedParams &s) {
-    const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
-    const long long first = (long long)b * s.batch_size;
-    const int n_in = (int)min((long long)s.batch_size, s.n_samples - first);
-    if (q >= n_in * s.per) return;
-    const size_t at = (size_t)b * s.tasks_per_batch + q;
-    const int slot_word = s.sorted_slot[at];
-    const int slot = slot_word & 0xffff, also = slot_word >> 16;
-    const int smp = slot / s.per, role = slot - smp * s.per;
-    const long long t = first + smp;
-    const int u = s.su[t], i = s.si[t], j = s.per == 3 ? s.sj[t] : 0;
-    const int pu = version_parity(s, u, b), pi = version_parity(s, s.n_users + i, b);
-    const int pj = s.per == 3 ? version_parity(s, s.n_users + j, b) : 0;
-    const int4 rec = make_int4(u, i, s.per == 3 ? j : __float_as_int(s.sr[t]), role | (pu << 2) | (pi << 3) | (pj << 4) | (also << 5));
-    s.recs[at] = rec;
-    const int tp = s.qtask[at];
-    if (tp == SLOT_ABSORBED) {
-        // a sample of a PAIR task other than its first (pairs are aligned blocks of `group` sorted positions, the header belongs to the
-        // first): its record also goes where the mini-batch kernel finds it without having seen the header -- by header slot
-        const int q0 = q - q % s.group;
-        if (s.fuse && q0 != q) {
-            const int tp0 = s.qtask[(size_t)b * s.tasks_per_batch + q0];
-            if (tp0 != SLOT_ABSORBED && !(tp0 & META_WIDE)) {
-                const TaskHeader *lead = s.tasks + (size_t)b * s.tasks_per_batch + tp0;
-                if (lead->pad == 1 && lead->start == (int)((size_t)b * s.tasks_per_batch + q0))
-                    s.slot_recs[((size_t)b * s.tasks_per_batch + tp0) * 3 + (q - q0 - 1)] = rec;
-            }
-        }
-        return;
-    }
-    TaskHeader *hd = s.tasks + (size_t)b * s.tasks_per_batch + (tp & (META_WIDE - 1));
-    const int off = (int)(at - (size_t)hd->start);
-    const int own = role == 0 ? pu : (role == 1 ? pi : pj);
-    int part = -1;
-    if (tp & META_WIDE) {           // quarter k of a wide list starts at position k * group
-        if (off % s.group == 0 && off / s.group < 4) part = off / s.group;      // (quarters past the end of the list stay empty)
-    } else if (off == 0) {
-        part = 0;
-    }
-    if (part >= 0) {
-        hd[part].rec0 = rec;
-        hd[part].meta |= own << 31;
-    }
-}
-
-__global__ __launch_bounds__(256) void mf_sched_emit_kernel(const FastSchedParams s) { mf_sched_emit_body(s); }
-
-__device__ __forceinline__ void mf_sched_finish_body(const FastSchedParams &s) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= s.n_entries) return;
-    unsigned *w = s.touched + (size_t)x * s.words;
-    int cnt = 0;
-    for (int k = 0; k < s.words; ++k) {
-        const unsigned v = w[k];
-        if (v) { cnt += __popc(v); w[k] = 0; }
-    }
-    if (cnt & 1) s.par[x] ^= 1;
-}
-__global__ __launch_bounds__(256) void mf_sched_finish_kernel(const FastSchedParams s) { mf_sched_finish_body(s); }
-
-// The global-bias ring is indexed by the mini-batch's position in its STREAM (a kernel knows that from its arguments: the ring
-// entry is requested together with everything else, not after the global index has arrived).  A stream of n mini-batches leaves
-// the newest state and terms in entry (n - 1) % 3; mini-batch 0 of the next stream looks for them in entry 2 and adds its own
-// terms to entry 0.
-template <class T>
-__device__ __forceinline__ void ring_to_stream_start(const MfParams<T> &p, const long long n_batches, const int slot) {
-    if (n_batches <= 0) return;
-    const int src = (int)((n_batches - 1) % 3);
-    if (src != 2) {
-        if (slot == 0) p.mu_state[2] = p.mu_state[src];
-        p.mu_acc[2 * MU_SLOTS + slot] = p.mu_acc[src * MU_SLOTS + slot];
-    }
-    p.mu_acc[slot] = (T)0;
-}
-
-template <class T>
-__global__ void mf_stream_end_kernel(const MfParams<T> p, const long long n_batches) {      // one wavefront
-    if (blockIdx.x != 0) return;
-    if (threadIdx.x == 0) p.state->batch_base += n_batches;
-    if (threadIdx.x < MU_SLOTS) ring_to_stream_start(p, n_batches, (int)threadIdx.x);
-}
-
-template <class T>
-__global__ void mf_group_stream_end_kernel(const MfParams<T> *table, const int n_models, const long long n_batches) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n_models) return;
-    table[m].state->batch_base += n_batches;
-    for (int slot = 0; slot < MU_SLOTS; ++slot) ring_to_stream_start(table[m], n_batches, slot);
-}
-
-// ---- the mini-batch --------------------------------------------------------------------------------------------------
-template <class T, int VEC> struct alignas(sizeof(T) * VEC) Chunk { T v[VEC]; };
-
-// Loads are issued unconditionally from clamped (always valid) addresses and masked afterwards: no branch sits between
-// two loads, so the compiler batches them under one wait.
-template <class T, int VEC>
-__device__ __forceinline__ Chunk<T, VEC> load_chunk(const T *row, int chunk, bool ok) {
-    Chunk<T, VEC> r = *reinterpret_cast<const Chunk<T, VEC> *>(row + (size_t)(ok ? chunk : 0) * VEC);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) r.v[e] = ok ? r.v[e] : (T)0;
-    return r;
-}
-
-// Adam's 1 - beta^t for the 1-based mini-batch index t
-template <class T, class P> __device__ __forceinline__ void adam_powers(const P &p, long long t, T &pw1, T &pw2) {
-    pw1 = (T)1;
-    pw2 = (T)1;
-    if (p.sgd_mode == MI355REC_ADAM) {
-        pw1 = (T)(1.0 - pow(p.beta_1_d, (double)t));
-        pw2 = (T)(1.0 - pow(p.beta_2_d, (double)t));
-    }
-}
-
-// Global bias as the batch `gb` must see it (FunkSVD with bias): the value after batch gb - 2 plus batch gb - 1's step,
-// computed identically by every wavefront from the ring; wavefront 0 files the result for the next batch.
-// In two halves: the ring is REQUESTED before the row gathers of the wavefront's first sample are issued and folded after
-// them -- with one call in front of the gathers the fold's wait put the whole ring round trip (batch index -> ring -> sum) in
-// front of the gathers: 8.4 us per mini-batch against 5.0 without biases.
-template <class T> struct MuRequest { MuState<T> st; T part; };
-
-template <class T>
-__device__ __forceinline__ MuRequest<T> global_bias_request(const MfParams<T> &p, const int prev, int lane) {
-    MuRequest<T> r;
-    r.st = p.mu_state[prev];
-    r.part = p.mu_acc[prev * MU_SLOTS + lane];
-    return r;
-}
-
-template <class T>
-__device__ __forceinline__ T global_bias_finish(const MfParams<T> &p, MuRequest<T> r, long long gb, const int at, bool writer, int lane) {
-    const int cur = at % 3, nxt = (at + 1) % 3;                   // `at`: position in the stream, gb: global index
-    MuState<T> st = r.st;
-    const T sum = wave_sum(r.part);
-    if (gb > 0) {
-        T pw1, pw2;
-        adam_powers(p, gb, pw1, pw2);           // the step belongs to batch gb - 1, whose 1-based index is gb
-        const T step = adapt_cell(p, sum * p.inv_batch, st.c1, st.c2, pw1, pw2);
-        st.mu += p.lr * step;
-    }
-    if (writer) {
-        if (lane == 0) p.mu_state[cur] = st;
-        p.mu_acc[nxt * MU_SLOTS + lane] = (T)0;
-    }
-    return st.mu;
-}
-
-template <class T>
-__device__ __forceinline__ T global_bias_at(const MfParams<T> &p, long long gb, const int at, bool writer, int lane) {
-    return global_bias_finish(p, global_bias_request(p, (at + 2) % 3, lane), gb, at, writer, lane);
-}
-
-// the three rows of one sample, KI chunks of VEC elements per lane
-template <class T, int VEC, int KI, bool BPR> struct Rows {
-    Chunk<T, VEC> A[KI], B[KI], C[BPR ? KI : 1];
-    T bu, bi;
-};
-
-template <class T, int VEC, int LPR, int KI, bool BPR>
-__device__ __forceinline__ Rows<T, VEC, KI, BPR> load_rows(const MfParams<T> &p, const int4 rec, int li, const bool (&cok)[KI],
-                                                           bool bias) {
-    Rows<T, VEC, KI, BPR> r;
-    const int k = p.k;
-    const T *Wu = ((rec.w >> 2) & 1 ? p.U1 : p.U0) + (size_t)rec.x * k;
-    const T *Hi = ((rec.w >> 3) & 1 ? p.V1 : p.V0) + (size_t)rec.y * k;
-    const T *Hj = ((rec.w >> 4) & 1 ? p.V1 : p.V0) + (size_t)(BPR ? rec.z : 0) * k;
-#pragma unroll
-    for (int c = 0; c < KI; ++c) {
-        r.A[c] = load_chunk<T, VEC>(Wu, c * LPR + li, cok[c]);
-        r.B[c] = load_chunk<T, VEC>(Hi, c * LPR + li, cok[c]);
-        if (BPR) r.C[c] = load_chunk<T, VEC>(Hj, c * LPR + li, cok[c]);
-    }
-    r.bu = (T)0;
-    r.bi = (T)0;
-    if (bias) {                                   // wave-uniform
-        r.bu = ((rec.w >> 2) & 1 ? p.bu1 : p.bu0)[rec.x];
-        r.bi = ((rec.w >> 3) & 1 ? p.bi1 : p.bi0)[rec.y];
-    }
-    return r;
-}
-
-// KI chunks of VEC elements per lane, LPR lanes per row (64 / LPR samples of a task's list in flight per wavefront).
-// `wg` = this workgroup's index within the mini-batch's launch of ONE model (blockIdx.x; the group launch below puts the model
-// on blockIdx.y).
-template <int ALGO, class T, int VEC, int LPR, int KI>
-__device__ __forceinline__ void mf_batch_body(const MfParams<T> &p, const int batch_local, const int wg) {
-    constexpr int G = 64 / LPR;
-    constexpr bool BPR = ALGO == MI355REC_MF_BPR;
-    using Ch = Chunk<T, VEC>;
-    using R = Rows<T, VEC, KI, BPR>;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((wg * p.wg_stride + p.wg_base) * 4 + (threadIdx.x >> 6));
-    const unsigned long long tk0 = p.ticks ? stamp() : 0ull;
-    // every wave-uniform input is requested before the first one is waited for (scalar loads, one wait)
-    // (unused task slots of a batch are zero: a header with no samples means there is nothing to do)
-    // (the grid is rounded up to whole workgroups: wavefronts past the batch's last slot re-read that slot and idle)
-    const bool bias = !BPR && p.use_bias;
-    long long gb = batch_local;
-    const TaskHeader *hp = p.tasks + ((size_t)batch_local * p.tasks_per_batch + min(wv, p.tasks_per_batch - 1));
-    const int8v hd = *reinterpret_cast<const int8v *>(hp);      // one 32-byte load: header and first record
-    // The global mini-batch index (Adam and the global bias need it) and the global-bias ring entry are requested right behind the
-    // header (the wait for the header does not cover younger loads; both were written by the kernel before this one and take
-    // 2 400 cycles to arrive where the header, last written by the schedule, takes 900) -- not after it has arrived, and the ring
-    // not after the index: a FunkSVD kernel began with three round trips one after the other.  Unconditionally for FunkSVD: a
-    // branch around a load makes the compiler wait for it before the next one is issued.
-    // a pair task's other records: by slot, requested with the header (through the record list they were a dependent round trip
-    // in front of the row gathers of the lane groups 1 .. G - 1: 2 300 cycles until the rows were there against 1 800 for one sample)
-    int4 slot_rec = make_int4(0, 0, 0, 0);
-    if constexpr (BPR && G > 1)
-        slot_rec = p.slot_recs[(size_t)batch_local * p.slot_rec_stride + (size_t)min(wv, p.tasks_per_batch - 1) * 3 + max(lane / LPR - 1, 0)];
-    long long batch_base = 0;
-    MuRequest<T> mu_req;
-    mu_req.st = MuState<T>{};
-    mu_req.part = (T)0;
-    if constexpr (!BPR) {
-        // (through a zero the compiler cannot see: it moves the result of a load it knows to be wave-uniform into scalar
-        // registers on the spot, which is a wait for these loads in front of the row gathers)
-        int zero;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-        batch_base = (&p.state->batch_base)[zero];
-        mu_req = global_bias_request(p, (batch_local + 2) % 3 + zero, lane);
-    }
-    // (the kernel arguments the row gathers need are requested now, next to the header, rather than in a second scalar
-    // round trip after the header has arrived)
-    asm volatile("" ::"s"(p.k), "s"(p.U0), "s"(p.U1), "s"(p.V0), "s"(p.V1), "s"(p.recs));
-    if constexpr (BPR) {
-        if (p.sgd_mode == MI355REC_ADAM) gb += p.state->batch_base;
-    } else {
-        gb += batch_base;
-    }
-    const int4 h0 = make_int4(hd[0], hd[1], hd[2], hd[3]), h1 = make_int4(hd[4], hd[5], hd[6], hd[7]);
-    const bool active = (h0.y & LEN_MASK) != 0 && wv < p.tasks_per_batch;
-    __shared__ T s_mu[4];
-    __shared__ T s_wide[4][LPR * KI * VEC];
-    __shared__ T s_wide_bias[4];
-    T mu_term = (T)0;
-    T mu_eff = (T)0;
-    unsigned long long tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, tk5 = 0;
-    if (p.ticks) tk1 = stamp();          // header has arrived (its value decided `active`)
-    if (bias && !active) mu_eff = global_bias_finish(p, mu_req, gb, batch_local, wv == 0, lane);      // (wavefront 0 files the value either way)
-    if (active) {
-        const int entry = h0.x, len = h0.y & LEN_MASK, own_par = (unsigned)h0.y >> 31, start = h0.z;
-        // a wide task (list longer than two rounds of a wavefront) owns the 4 wavefronts of this workgroup: quarter `part` takes list
-        // positions part * G + g, then every 4 * G; h1 is the record at part * G
-        const bool wide = (h0.y & META_WIDE) != 0;
-        const int part = (h0.y >> 28) & 3;
-        const int base = wide ? part * G : 0, step = wide ? 4 * G : G;
-        const int g = lane / LPR, li = lane % LPR;
-        const int k = p.k, chunks = k / VEC;
-        bool cok[KI];
-#pragma unroll
-        for (int c = 0; c < KI; ++c) cok[c] = c * LPR + li < chunks;
-        const int iters = len > base ? (len - base + step - 1) / step : 0;      // (a short wide list leaves late quarters empty)
-        // software pipeline: records two list positions ahead of the arithmetic, rows one ahead.  Positions past the
-        // end of the list are clamped to the last record (valid addresses) and contribute nothing.
-        int4 rec = h1;
-        // PAIR task (fast schedule, BPR): G single-sample user tasks share this wavefront, lane group g has sample g of the "list"
-        // -- its own row to write, nothing to sum across groups
-        const bool pair = BPR && G > 1 && h0.w == 1;
-        T sg_first = (T)0;
-        if (BPR && G > 1 && h0.w == 1) {           // pair task: the lane groups' records came with the header
-            if (g != 0) rec = slot_rec;
-        } else if (G > 1 && len > 1) {             // single-sample tasks (most of them) go straight from the header to the rows
-            const int4 r = p.recs[start + min(base + g, len - 1)];
-            if (g != 0) rec = r;
-        }
-        const int4 rec_first = rec;                // single-sample and pair tasks: THE record of this lane group
-        int4 rec_n = rec;
-        if (iters > 1) rec_n = p.recs[start + min(base + step + g, len - 1)];
-        R rows = load_rows<T, VEC, LPR, KI, BPR>(p, rec, li, cok, bias);
-        if (bias) mu_eff = global_bias_finish(p, mu_req, gb, batch_local, wv == 0, lane);   // folded behind the gathers just issued
-        T pw1, pw2;
-        adam_powers(p, gb + 1, pw1, pw2);
-
-        Ch acc[KI], own[KI];
-#pragma unroll
-        for (int c = 0; c < KI; ++c)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) { acc[c].v[e] = (T)0; own[c].v[e] = (T)0; }
-        T bias_acc = (T)0, own_bias = (T)0;
-        double loss = 0.0;
-
-        for (int it = 0; it < iters; ++it) {
-            const int idx = base + it * step + g;
-            const bool valid = idx < len;
-            // issue the next position's loads before this position's arithmetic (wave-uniform conditions)
-            int4 rec_nn = rec_n;
-            if (it + 2 < iters) rec_nn = p.recs[start + min(idx + 2 * step, len - 1)];
-            R rows_n = rows;
-            if (it + 1 < iters) rows_n = load_rows<T, VEC, LPR, KI, BPR>(p, rec_n, li, cok, bias);
-
-            const int role = rec.w & 3;
-            T dot = (T)0;
-#pragma unroll
-            for (int c = 0; c < KI; ++c)
-#pragma unroll
-                for (int e = 0; e < VEC; ++e)
-                    dot = fused_add(rows.A[c].v[e], BPR ? diff_of(rows.B[c].v[e], rows.C[c].v[e]) : rows.B[c].v[e], dot);
-            dot = group_sum<LPR>(dot);
-            if (p.ticks && it == 0) {
-                asm volatile("" ::"v"(dot));
-                tk2 = stamp();           // first rows have arrived
-            }
-            if (BPR) {
-                const T x = dot;
-                const T sg = sigmoid_of_minus(x);
-                if (it == 0) sg_first = sg;
-                if (valid && role == ROLE_U && li == 0) loss += (double)x * (double)x;
-#pragma unroll
-                for (int c = 0; c < KI; ++c)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const T a = rows.A[c].v[e], b = rows.B[c].v[e], cc = rows.C[c].v[e];
-                        const T gU = grad_term(sg, diff_of(b, cc), p.user_reg, a);        // .pyx:626-639
-                        const T gI = grad_term(sg, a, p.positive_reg, b);
-                        const T gJ = grad_term(sg, -a, p.negative_reg, cc);
-                        const T gr = role == ROLE_U ? gU : (role == ROLE_I ? gI : gJ);
-                        acc[c].v[e] += valid ? gr : (T)0;
-                        if (it == 0) own[c].v[e] = role == ROLE_U ? a : (role == ROLE_I ? b : cc);
-                    }
-            } else {
-                T pred = dot;
-                if (bias) pred += mu_eff + rows.bu + rows.bi;
-                const T err = (T)__int_as_float(rec.z) - pred;
-                if (valid && role == ROLE_U) {
-                    if (li == 0) loss += (double)err * (double)err;
-                    if (bias) mu_term += err - p.bias_reg * mu_eff;            // .pyx:329-336
-                }
-                if (bias && valid) bias_acc += err - p.bias_reg * (role == ROLE_U ? rows.bu : rows.bi);
-                if (it == 0) own_bias = role == ROLE_U ? rows.bu : rows.bi;
-#pragma unroll
-                for (int c = 0; c < KI; ++c)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const T a = rows.A[c].v[e], b = rows.B[c].v[e];
-                        // NB the item gradient is regularised with positive_reg (sic, .pyx:346), never item_reg
-                        const T gU = grad_term(err, b, p.user_reg, a);
-                        const T gI = grad_term(err, a, p.positive_reg, b);
-                        const T gr = role == ROLE_U ? gU : gI;
-                        acc[c].v[e] += valid ? gr : (T)0;
-                        if (it == 0) own[c].v[e] = role == ROLE_U ? a : b;
-                    }
-            }
-            rec = rec_n;
-            rec_n = rec_nn;
-            rows = rows_n;
-        }
-        // totals over the groups, in a fixed order
-        if (G > 1 && !pair) {
-#pragma unroll
-            for (int c = 0; c < KI; ++c)
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[c].v[e] = cross_group_sum<LPR>(acc[c].v[e]);
-            if (bias) bias_acc = cross_group_sum<LPR>(bias_acc);
-        }
-        if (bias) {   // every lane of a group carries the group's terms: one lane per group counts
-            mu_term = li == 0 ? mu_term : (T)0;
-            mu_term = wave_sum(mu_term);
-        }
-        // (wavefront, group) slots are private; an atomic without return value instead of load + add + store keeps a
-        // dependent memory round trip out of the tail of the wavefront
-        if (li == 0 && loss != 0.0) atomicAdd(&p.loss_slots[wv * 4 + g], loss);
-        if (p.ticks) tk3 = stamp();      // list done
-        if (wide) {                      // the four quarters meet in LDS and are summed in quarter order by the first
-            if (g == 0) {
-#pragma unroll
-                for (int c = 0; c < KI; ++c)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) s_wide[part][(c * VEC + e) * LPR + li] = acc[c].v[e];
-                if (li == 0) s_wide_bias[part] = bias_acc;
-            }
-            __syncthreads();
-            if (part == 0 && g == 0) {
-#pragma unroll
-                for (int c = 0; c < KI; ++c)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const int at = (c * VEC + e) * LPR + li;
-                        acc[c].v[e] = ((s_wide[0][at] + s_wide[1][at]) + s_wide[2][at]) + s_wide[3][at];
-                    }
-                bias_acc = ((s_wide_bias[0] + s_wide_bias[1]) + s_wide_bias[2]) + s_wide_bias[3];
-            }
-        }
-        // _apply_minibatch_updates_to_latent_factors (.pyx:770-829): mean over batch_size (NOT over the row's count)
-        if ((g == 0 || pair) && (!wide || part == 0)) {
-            const int own_entry = pair ? rec_first.x : entry;                       // (a pair task's rows are user rows)
-            const int own_buf = pair ? (rec_first.w >> 2) & 1 : own_par;
-            const bool is_item = own_entry >= p.n_users;
-            const int row = is_item ? own_entry - p.n_users : own_entry;
-            T *Wn = (is_item ? (own_buf ? p.V0 : p.V1) : (own_buf ? p.U0 : p.U1)) + (size_t)row * k;
-            T *c1 = (is_item ? p.c1V : p.c1U) + (size_t)row * k, *c2 = (is_item ? p.c2V : p.c2U) + (size_t)row * k;
-#pragma unroll
-            for (int c = 0; c < KI; ++c) {
-                if (!cok[c]) continue;
-                const size_t at = (size_t)(c * LPR + li) * VEC;
-                Ch m1, m2, out;
-                if (p.sgd_mode != MI355REC_SGD) m1 = *reinterpret_cast<const Ch *>(c1 + at);
-                if (p.sgd_mode == MI355REC_ADAM) m2 = *reinterpret_cast<const Ch *>(c2 + at);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const T gm = mean_of(acc[c].v[e], p.inv_batch);
-                    const T step = adapt_cell(p, gm, m1.v[e], m2.v[e], pw1, pw2);
-                    out.v[e] = moved(own[c].v[e], p.lr, step);
-                }
-                *reinterpret_cast<Ch *>(Wn + at) = out;
-                if (p.sgd_mode != MI355REC_SGD) *reinterpret_cast<Ch *>(c1 + at) = m1;
-                if (p.sgd_mode == MI355REC_ADAM) *reinterpret_cast<Ch *>(c2 + at) = m2;
-            }
-            if (bias && li == 0) {
-                T *bn = is_item ? (own_buf ? p.bi0 : p.bi1) : (own_buf ? p.bu0 : p.bu1);
-                T *b1 = is_item ? p.c1_bi : p.c1_bu, *b2 = is_item ? p.c2_bi : p.c2_bu;
-                const T step = adapt(p, bias_acc * p.inv_batch, b1, b2, (size_t)row, pw1, pw2);
-                bn[row] = own_bias + p.lr * step;
-            }
-        }
-        if (p.ticks) tk4 = stamp();      // own row written
-        const int also = BPR && (len == 1 || pair) ? (rec_first.w >> 5) & 3 : 0;
-        if (BPR && also) {
-            // The item rows this single-sample user task took over (mf_sched_sort_kernel): the arithmetic their own tasks would
-            // have done -- gradient of one sample, mean over batch_size, optimiser, one store of the next row version.  In a
-            // single task every group of the wavefront holds the same record, rows and sigmoid (positions past the end of the
-            // list are clamped to the last record), so the rows are dealt to the groups: row e (1 positive, 2 negative item) to
-            // group e % G; in a pair task every group looks after its own sample.
-            // (`rows` still holds the first record's rows: these lists run one iteration and load nothing else)
-#pragma unroll
-            for (int e = 1; e <= 2; ++e) {
-                if (!(also & e) || !(pair || g == e % G)) continue;
-                const int item = e == 1 ? rec_first.y : rec_first.z;
-                const int cur = (rec_first.w >> (e == 1 ? 3 : 4)) & 1;               // buffer of the version just read
-                T *Wn = (cur ? p.V0 : p.V1) + (size_t)item * k;
-                T *c1 = p.c1V + (size_t)item * k, *c2 = p.c2V + (size_t)item * k;
-#pragma unroll
-                for (int c = 0; c < KI; ++c) {
-                    if (!cok[c]) continue;
-                    const size_t at = (size_t)(c * LPR + li) * VEC;
-                    Ch m1, m2, out;
-                    if (p.sgd_mode != MI355REC_SGD) m1 = *reinterpret_cast<const Ch *>(c1 + at);
-                    if (p.sgd_mode == MI355REC_ADAM) m2 = *reinterpret_cast<const Ch *>(c2 + at);
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        const T a = rows.A[c].v[v], b = rows.B[c].v[v], cc = rows.C[c].v[v];
-                        const T gr = e == 1 ? grad_term(sg_first, a, p.positive_reg, b) : grad_term(sg_first, -a, p.negative_reg, cc);   // .pyx:632-639
-                        const T gm = mean_of((T)0 + gr, p.inv_batch);
-                        const T step = adapt_cell(p, gm, m1.v[v], m2.v[v], pw1, pw2);
-                        out.v[v] = moved(e == 1 ? b : cc, p.lr, step);
-                    }
-                    *reinterpret_cast<Ch *>(Wn + at) = out;
-                    if (p.sgd_mode != MI355REC_SGD) *reinterpret_cast<Ch *>(c1 + at) = m1;
-                    if (p.sgd_mode == MI355REC_ADAM) *reinterpret_cast<Ch *>(c2 + at) = m2;
-                }
-            }
-        }
-    }
-    if (p.ticks) tk5 = stamp();          // item rows the task took over written
-    if (bias) {   // the batch's global-bias terms: per workgroup through LDS, then one atomic on one of 16 addresses
-        if (lane == 0) s_mu[threadIdx.x >> 6] = mu_term;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const T sum = (s_mu[0] + s_mu[1]) + (s_mu[2] + s_mu[3]);
-            if (sum != (T)0) atomicAdd(&p.mu_acc[(batch_local % 3) * MU_SLOTS + (wg & (MU_SLOTS - 1))], sum);
-        }
-    }
-    if (p.ticks && lane == 0 && wv < p.tasks_per_batch) {
-        unsigned long long *o = p.ticks + (size_t)wv * 8;
-        o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = stamp(); o[5] = (unsigned long long)(h0.y & LEN_MASK);
-        o[6] = tk4; o[7] = tk5;
-    }
-}
-
-// PLAIN_SGD: the instance for sgd_mode == "sgd" (the reference's default, the headline): every branch on the optimiser is decided at
-// compile time.  The update of the item rows a pair task took over ran through 1 600 instructions of optimiser cases -- 1 730 cycles
-// of the 6 500 a wavefront lives (MI355REC_MF_TICKS, round 4).
-template <int ALGO, class T, int VEC, int LPR, int KI, bool PLAIN_SGD>
-__global__ __launch_bounds__(256) void mf_batch_kernel(const MfParams<T> p, const int batch_local) {
-    // (an assumption about the argument, not a modified copy: a copy that is passed on by reference lands in scratch memory)
-    if constexpr (PLAIN_SGD) __builtin_assume(p.sgd_mode == MI355REC_SGD);
-    // Every kernel argument the start of the kernel needs is requested in ONE batch of scalar loads: left to itself the compiler
-    // fetched them piecewise as the code came to need them -- three waits for a cold kernarg segment before FunkSVD's header load
-    // was even issued, one for BPR's.
-    asm volatile("" ::"s"(p.tasks), "s"(p.tasks_per_batch), "s"(p.wg_base), "s"(p.wg_stride), "s"(p.ticks), "s"(p.use_bias), "s"(p.sgd_mode),
-                 "s"(p.state), "s"(p.mu_state), "s"(p.mu_acc), "s"(p.k), "s"(p.U0), "s"(p.U1), "s"(p.V0), "s"(p.V1), "s"(p.recs));
-    // (here and not in the body: the group launch below reads its parameters from a table in memory, where holding them all in
-    // scalar registers from the start costs occupancy)
-    // (Measured and rejected, round 4: a launch over a third of the slots with a loop over the slots in use, as the group launch does --
-    // BPR 198 against 196 M samples/s, FunkSVD, whose slots are nearly all in use, 102 against 161 M.)
-    mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, blockIdx.x);
-}
-
-// REPLICA-BATCHED launch: mini-batch `batch_local` of R independent models in one grid (blockIdx.y = model).  A single model's
-// epoch is a chain of dependent mini-batches of ~3 MB each -- a launch fills a tenth of the chip, and concurrent replicas on R
-// streams still pay one dispatch per model and mini-batch at the command processor.  Here the chain keeps its length but every
-// link carries R mini-batches.  The models share nothing but the kernel instance (algorithm, storage type, lanes per row) and the
-// number of task slots per mini-batch: factors, hyper-parameters, seeds, optimiser, even k within the instance's range are per
-// model (the table row is the model's MfParams, read through the scalar cache: wave-uniform address, nothing stored before it).
-// Pointers that arrive as kernel arguments are known to point to global memory; pointers read from a table are generic ("flat")
-// to the compiler, which then gathers with flat_load and cannot use the scalar cache for the task header.  The
-// assumption below (neither LDS nor scratch) is what the address-space inference needs to use global_load / s_load again.
-template <class P> __device__ __forceinline__ P *as_global(P *q) {
-    const unsigned long long bits = (unsigned long long)q;
-    return (P *)(__attribute__((address_space(1))) P *)bits;
-}
-template <class T> __device__ __forceinline__ void globalize(MfParams<T> &p) {
-    p.indptr = as_global(p.indptr); p.indices = as_global(p.indices); p.data = as_global(p.data);
-    p.U0 = as_global(p.U0); p.U1 = as_global(p.U1); p.V0 = as_global(p.V0); p.V1 = as_global(p.V1);
-    p.bu0 = as_global(p.bu0); p.bu1 = as_global(p.bu1); p.bi0 = as_global(p.bi0); p.bi1 = as_global(p.bi1);
-    p.c1U = as_global(p.c1U); p.c2U = as_global(p.c2U); p.c1V = as_global(p.c1V); p.c2V = as_global(p.c2V);
-    p.c1_bu = as_global(p.c1_bu); p.c2_bu = as_global(p.c2_bu); p.c1_bi = as_global(p.c1_bi); p.c2_bi = as_global(p.c2_bi);
-    p.mu_state = as_global(p.mu_state); p.mu_acc = as_global(p.mu_acc);
-    p.loss_slots = as_global(p.loss_slots); p.state = as_global(p.state);
-    p.su = as_global(p.su); p.si = as_global(p.si); p.sj = as_global(p.sj); p.sr = as_global(p.sr);
-    p.tasks = as_global(p.tasks); p.recs = as_global(p.recs); p.ticks = as_global(p.ticks); p.used = as_global(p.used);
-    p.slot_recs = as_global(p.slot_recs);
-}
-
-template <int ALGO, class T, int VEC, int LPR, int KI, bool PLAIN_SGD>
-__global__ __launch_bounds__(256, (PLAIN_SGD && ALGO == MI355REC_MF_BPR && sizeof(T) == 4 && LPR == 32) ? 6 : 1) void mf_group_batch_kernel(const MfParams<T> *__restrict__ table, const int batch_local) {
-    MfParams<T> p = table[blockIdx.y];
-    globalize(p);
-    if constexpr (PLAIN_SGD) __builtin_assume(p.sgd_mode == MI355REC_SGD);       // (every member runs plain sgd: see mf_batch_kernel)
-    // the grid covers a third of a mini-batch's header slots; with fused / paired tasks fewer than that are in use as a rule
-    // (the in-LDS schedule files the count), and a workgroup that finds more walks on: no wavefront is launched for an empty slot
-    const int used = p.used ? p.used[batch_local] : p.tasks_per_batch;
-    for (int wg = blockIdx.x; wg * 4 < used; wg += gridDim.x) mf_batch_body<ALGO, T, VEC, LPR, KI>(p, batch_local, wg);
-}
-// Sampler and schedule of every member in ONE launch each (model on the last grid dimension): as 4 x R small launches on R
-// streams they took a third of a 32-model epoch.
-__device__ __forceinline__ void globalize(FastSchedParams &f) {
-    f.su = as_global(f.su); f.si = as_global(f.si); f.sj = as_global(f.sj); f.sr = as_global(f.sr);
-    f.touched = as_global(f.touched); f.par = as_global(f.par); f.sorted_slot = as_global(f.sorted_slot); f.qtask = as_global(f.qtask);
-    f.used = as_global(f.used); f.tasks = as_global(f.tasks); f.recs = as_global(f.recs); f.slot_recs = as_global(f.slot_recs);
-}
-template <int ALGO, class T>
-__global__ __launch_bounds__(256) void mf_group_sample_kernel(const MfParams<T> *__restrict__ table) {
-    MfParams<T> p = table[blockIdx.y];
-    globalize(p);
-    mf_sample_body<ALGO, T>(p);
-}
-template <class T>
-__global__ void mf_group_epoch_advance_kernel(const MfParams<T> *table, const int n_models) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < n_models) table[m].state->epoch += 1;
-}
-__global__ __launch_bounds__(SCHED_THREADS) void mf_group_sched_sort_kernel(const FastSchedParams *__restrict__ table) {
-    FastSchedParams f = table[blockIdx.y];
-    globalize(f);
-    mf_sched_sort_body(f, blockIdx.x);
-}
-__global__ __launch_bounds__(256) void mf_group_sched_emit_kernel(const FastSchedParams *__restrict__ table) {
-    FastSchedParams f = table[blockIdx.z];
-    globalize(f);
-    mf_sched_emit_body(f);
-}
-__global__ __launch_bounds__(256) void mf_group_sched_finish_kernel(const FastSchedParams *__restrict__ table) {
-    FastSchedParams f = table[blockIdx.y];
-    globalize(f);
-    mf_sched_finish_body(f);
-}
-
-// Any k (odd k, k > 64 lanes x 2 chunks): one task per wavefront, one sample at a time, rows re-read for the update.
-template <int ALGO, class T>
-__global__ __launch_bounds__(256) void mf_batch_generic_kernel(const MfParams<T> p, const int batch_local) {
-    constexpr bool BPR = ALGO == MI355REC_MF_BPR;
-    constexpr int KMAX_REG = 8;    // k <= 512 keeps the own-row gradient in registers, larger k is rejected at create
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((blockIdx.x * p.wg_stride + p.wg_base) * 4 + (threadIdx.x >> 6));
-    const TaskHeader *hp = p.tasks + ((size_t)batch_local * p.tasks_per_batch + min(wv, p.tasks_per_batch - 1));
-    const int4 h0 = *reinterpret_cast<const int4 *>(hp);
-    const bool active = (h0.y & LEN_MASK) != 0 && wv < p.tasks_per_batch;
-    const bool bias = !BPR && p.use_bias;
-    __shared__ T s_mu[4];
-    T mu_term = (T)0;
-    if (active || bias) {
-        const long long gb = p.state->batch_base + batch_local;
-        T mu_eff = (T)0;
-        if (bias) mu_eff = global_bias_at(p, gb, batch_local, wv == 0, lane);
-        if (active) {
-            const int entry = h0.x, len = h0.y & LEN_MASK, own_par = (unsigned)h0.y >> 31, start = h0.z;
-            const int k = p.k;
-            T pw1, pw2;
-            adam_powers(p, gb + 1, pw1, pw2);
-            T acc[KMAX_REG];
-#pragma unroll
-            for (int c = 0; c < KMAX_REG; ++c) acc[c] = (T)0;
-            T bias_acc = (T)0;
-            double loss = 0.0;
-            for (int idx = 0; idx < len; ++idx) {
-                const int4 rec = idx == 0 ? hp->rec0 : p.recs[start + idx];
-                const int role = rec.w & 3;
-                const T *Wu = ((rec.w >> 2) & 1 ? p.U1 : p.U0) + (size_t)rec.x * k;
-                const T *Hi = ((rec.w >> 3) & 1 ? p.V1 : p.V0) + (size_t)rec.y * k;
-                const T *Hj = ((rec.w >> 4) & 1 ? p.V1 : p.V0) + (size_t)(BPR ? rec.z : 0) * k;
-                T dot = (T)0;
-                for (int f = lane; f < k; f += 64) dot += BPR ? Wu[f] * (Hi[f] - Hj[f]) : Wu[f] * Hi[f];
-                dot = wave_sum(dot);
-                if (BPR) {
-                    const T sg = sigmoid_of_minus(dot);
-                    if (role == ROLE_U) loss += (double)dot * (double)dot;
-#pragma unroll
-                    for (int c = 0; c < KMAX_REG; ++c) {
-                        const int f = lane + 64 * c;
-                        if (f < k) {
-                            const T a = Wu[f], b = Hi[f], cc = Hj[f];
-                            acc[c] += role == ROLE_U ? sg * (b - cc) - p.user_reg * a
-                                                     : (role == ROLE_I ? sg * a - p.positive_reg * b : sg * (-a) - p.negative_reg * cc);
-                        }
-                    }
-                } else {
-                    T bu_v = (T)0, bi_v = (T)0;
-                    if (bias) {
-                        bu_v = ((rec.w >> 2) & 1 ? p.bu1 : p.bu0)[rec.x];
-                        bi_v = ((rec.w >> 3) & 1 ? p.bi1 : p.bi0)[rec.y];
-                    }
-                    const T err = __int_as_float(rec.z) - (dot + (bias ? mu_eff + bu_v + bi_v : (T)0));
-                    if (role == ROLE_U) {
-                        loss += (double)err * (double)err;
-                        if (bias) mu_term += err - p.bias_reg * mu_eff;
-                    }
-                    if (bias) bias_acc += err - p.bias_reg * (role == ROLE_U ? bu_v : bi_v);
-#pragma unroll
-                    for (int c = 0; c < KMAX_REG; ++c) {
-                        const int f = lane + 64 * c;
-                        if (f < k) {
-                            const T a = Wu[f], b = Hi[f];
-                            acc[c] += role == ROLE_U ? err * b - p.user_reg * a : err * a - p.positive_reg * b;
-                        }
-                    }
-                }
-            }
-            if (lane == 0 && loss != 0.0) p.loss_slots[wv * 4] += loss;
-            const bool is_item = entry >= p.n_users;
-            const int row = is_item ? entry - p.n_users : entry;
-            const T *Wo = (is_item ? (own_par ? p.V1 : p.V0) : (own_par ? p.U1 : p.U0)) + (size_t)row * k;
-            T *Wn = (is_item ? (own_par ? p.V0 : p.V1) : (own_par ? p.U0 : p.U1)) + (size_t)row * k;
-            T *c1 = is_item ? p.c1V : p.c1U, *c2 = is_item ? p.c2V : p.c2U;
-#pragma unroll
-            for (int c = 0; c < KMAX_REG; ++c) {
-                const int f = lane + 64 * c;
-                if (f < k) {
-                    const T step = adapt(p, acc[c] * p.inv_batch, c1, c2, (size_t)row * k + f, pw1, pw2);
-                    Wn[f] = Wo[f] + p.lr * step;
-                }
-            }
-            if (bias && lane == 0) {
-                const T *bo = is_item ? (own_par ? p.bi1 : p.bi0) : (own_par ? p.bu1 : p.bu0);
-                T *bn = is_item ? (own_par ? p.bi0 : p.bi1) : (own_par ? p.bu0 : p.bu1);
-                T *b1 = is_item ? p.c1_bi : p.c1_bu, *b2 = is_item ? p.c2_bi : p.c2_bu;
-                const T step = adapt(p, bias_acc * p.inv_batch, b1, b2, (size_t)row, pw1, pw2);
-                bn[row] = bo[row] + p.lr * step;
-            }
-            mu_term = lane == 0 ? mu_term : (T)0;     // every lane computed the same terms
-        }
-    }
-    if (bias) {
-        if (lane == 0) s_mu[threadIdx.x >> 6] = mu_term;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const T sum = (s_mu[0] + s_mu[1]) + (s_mu[2] + s_mu[3]);
-            if (sum != (T)0) atomicAdd(&p.mu_acc[(batch_local % 3) * MU_SLOTS + (blockIdx.x & (MU_SLOTS - 1))], sum);
-        }
-    }
-}
-
-// Current version of every row as float32 (the getters of .pyx:685-702), and the global bias after the last batch.
-// ---- exact multi-GPU mini-batches -----------------------------------------------------------
-// Every rank holds the same factors and the same schedule; the workgroups (4 task slots: a split list's quarters stay together) of
-// a mini-batch are dealt round-robin to the ranks -- headers are packed at the front of a batch's slots, so contiguous shares
-// would leave the last ranks idle -- and the rows the tasks of rank r own get their new version on rank r only.  PACK copies
-// them into the rank's exchange slab (slab row = 4 * (workgroup / world) + slot % 4); after the all-gather the other ranks'
-// slabs are copied into the same rows (!PACK), and every rank holds bit-identical factors again.  One wavefront per slot.
-template <class T, bool PACK>
-__global__ __launch_bounds__(256) void mf_shard_rows_kernel(const MfParams<T> p, const int batch_local, const int rank, const int world,
-                                                            const int slots_per_rank, T *slab) {
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slot >= p.tasks_per_batch) return;
-    const int wg = slot >> 2, owner = wg % world;
-    if ((owner == rank) != PACK) return;
-    const TaskHeader *hd = p.tasks + ((size_t)batch_local * p.tasks_per_batch + slot);
-    const int meta = hd->meta;
-    if ((meta & LEN_MASK) == 0) return;                                           // empty slot
-    if ((meta & META_WIDE) && ((meta >> 28) & 3) != 0) return;                    // quarters 1..3 of a wide list do not write
-    const int entry = hd->entry, own_par = (unsigned)meta >> 31;
-    const bool is_item = entry >= p.n_users;
-    const int row = is_item ? entry - p.n_users : entry;
-    T *Wn = (is_item ? (own_par ? p.V0 : p.V1) : (own_par ? p.U0 : p.U1)) + (size_t)row * p.k;
-    // slab layout: [rank][slot within the rank][k]; PACK addresses the rank's own slab, !PACK the gathered one
-    const int local = (wg / world) * 4 + (slot & 3);
-    T *at = slab + ((size_t)(PACK ? 0 : owner) * slots_per_rank + local) * p.k;
-    for (int e = lane; e < p.k; e += 64) {
-        if (PACK) at[e] = Wn[e];
-        else Wn[e] = at[e];
-    }
-}
-
-template <class T, class O>
-__global__ __launch_bounds__(256) void mf_gather_rows_kernel(const T *b0, const T *b1, const unsigned char *par, long long n_rows,
-                                                             int k, O *out) {
-    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (t >= n_rows * k) return;
-    const long long row = t / k;
-    out[t] = (O)(par[row] ? b1[t] : b0[t]);
-}
-template <class T, class O>
-__global__ void mf_final_mu_kernel(const MfParams<T> p, O *out) {
-    const int lane = threadIdx.x & 63;
-    const T mu = global_bias_at(p, p.state->batch_base, 0, false, lane);      // (between streams: the ring stands at a stream's start)
-    if (threadIdx.x == 0) out[0] = (O)mu;
-}
-
-// AsySVD (.pyx:393-541): batch_size is 1 and every step rewrites all the Y rows of the sampled user's profile, which
-// nearly every other profile shares -- consecutive steps are one dependent chain, executed strictly in order by ONE 1024-thread
-// workgroup (16 wavefronts across the profile rows, lanes across the factors).  p.U0 is the n_items x k matrix Y
-// ("USER_factors" in the reference), p.V0 the item factors X; nothing is double-buffered here.
-// What a step may not overlap with its predecessor is the Y / X / bias traffic; everything else is SOFTWARE-PIPELINED one step
-// ahead: the next step's sample, its CSR bounds and the profile ids of its first rows are loaded while the current step reduces
-// and updates (they come from read-only arrays), the first ASY_ROWS rows of each wavefront stay in registers between the gather
-// and the update, and the loads of a step are issued from clamped addresses in one batch (a load inside a conditional is waited
-// for where its branch ends).  Per step that leaves: one gather round trip (L2), two LDS reductions, the scalar part, the stores.
-constexpr int ASY_KMAX = 256;
-constexpr int ASY_CELLS = 12;    // factors per lane that stay in registers between the gather and the update: C chunks of 64 factors x R rows
-// C = chunks of 64 factors a row needs (1: k <= 64, 2: k <= 128, 4: k <= 256); R = ASY_CELLS / C profile rows per wavefront stay
-// in registers (192 / 96 / 48 rows per step: the mean ML-1M profile has 166; 16 cells spill at float64)
-template <class T, int C>
-__global__ __launch_bounds__(1024) void mf_asy_kernel(const MfParams<T> p, const long long first, const int count) {
-    constexpr int R = ASY_CELLS / C;
-    __shared__ T s_part[16][ASY_KMAX];
-    __shared__ T s_acc[ASY_KMAX], s_xi[ASY_KMAX];
-    __shared__ T s_err, s_pw1, s_pw2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = p.k;
-    T *const Ymat = p.U0, *const Xmat = p.V0, *const bu = p.bu0, *const bi = p.bi0;
-    double b1p = 0.0, b2p = 0.0, loss = 0.0;
-    if (tid == 0) {
-        b1p = p.state->beta_1_power;
-        b2p = p.state->beta_2_power;
-        loss = p.state->asy_loss;
-    }
-    // this lane's factors of a row: f = lane + 64 c; fc = the same clamped into the row (always a valid address)
-    int fc[C];
-    bool fok[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        fok[c] = lane + 64 * c < k;
-        fc[c] = min(lane + 64 * c, k - 1);
-    }
-    // the first step's sample, bounds and first row ids
-    int u = 0, i = 0, rs = 0, re = 1, rowid[R];
-    T rating = (T)0;
-#pragma unroll
-    for (int m = 0; m < R; ++m) rowid[m] = -1;
-    if (count > 0) {
-        u = p.su[first];
-        i = p.si[first];
-        rating = (T)p.sr[first];
-        rs = p.indptr[u];
-        re = p.indptr[u + 1];
-#pragma unroll
-        for (int m = 0; m < R; ++m) {
-            const int q = rs + wave + 16 * m;
-            const int id = p.indices[min(q, re - 1)];
-            rowid[m] = q < re ? id : -1;
-        }
-    }
-    for (int s = 0; s < count; ++s) {
-        // ---- gathers of this step, one batch: its first rows of Y, X[i], the biases (lane 0 of wavefront 0)
-        T *X = Xmat + (size_t)i * k;
-        T yv[R][C];
-#pragma unroll
-        for (int m = 0; m < R; ++m) {
-            const T *Y = Ymat + (size_t)max(rowid[m], 0) * k;
-#pragma unroll
-            for (int c = 0; c < C; ++c) yv[m][c] = Y[fc[c]];
-        }
-        const T xi_mine = X[min(tid, k - 1)];
-        T mu_v = (T)0, bu_v = (T)0, bi_v = (T)0;
-        if (p.use_bias) {           // (uniform addresses: every lane may load them)
-            mu_v = p.asy_mu[0];
-            bu_v = bu[u];
-            bi_v = bi[i];
-        }
-        // ---- the NEXT step's sample (read-only stream)
-        const long long tn = first + s + (s + 1 < count ? 1 : 0);
-        const int u_n = p.su[tn], i_n = p.si[tn];
-        const T rating_n = (T)p.sr[tn];
-        // user vector: sum of the Y rows of the profile / sqrt(profile length)   (.pyx:424-441)
-        T part[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) part[c] = (T)0;
-#pragma unroll
-        for (int m = 0; m < R; ++m)
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                yv[m][c] = rowid[m] >= 0 && fok[c] ? yv[m][c] : (T)0;
-                part[c] += yv[m][c];
-            }
-        for (int q = rs + wave + 16 * R; q < re; q += 16) {          // profiles longer than 64 rows
-            const T *Y = Ymat + (size_t)p.indices[q] * k;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const T v = Y[fc[c]];
-                part[c] += fok[c] ? v : (T)0;
-            }
-        }
-        if (tid < k) s_xi[tid] = xi_mine;
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-            if (fok[c]) s_part[wave][lane + 64 * c] = part[c];
-        // (the next step's CSR bounds: requested before the barrier, they arrive during the reduction)
-        const int rs_n = p.indptr[u_n], re_n = p.indptr[u_n + 1];
-        __syncthreads();
-        if (tid < k) {
-            T a = (T)0;
-            for (int w = 0; w < 16; ++w) a += s_part[w][tid];
-            s_acc[tid] = a / root((T)(re - rs));
-        }
-        __syncthreads();
-        if (wave == 0) {
-            T dot = (T)0;
-            for (int f = lane; f < k; f += 64) dot += s_acc[f] * s_xi[f];
-            dot = wave_sum(dot);
-            if (lane == 0) {
-                T pred = dot;
-                if (p.use_bias) pred += mu_v + bu_v + bi_v;
-                const T err = rating - pred;
-                loss += (double)err * (double)err;
-                const T pw1 = (T)(1.0 - b1p), pw2 = (T)(1.0 - b2p);
-                if (p.use_bias) {       // global, item, user bias -- in that order (.pyx:458-490)
-                    T g = adapt(p, err - p.bias_reg * mu_v, p.asy_c_mu, p.asy_c_mu + 1, 0, pw1, pw2);
-                    p.asy_mu[0] = mu_v + p.lr * g;
-                    g = adapt(p, err - p.bias_reg * bi_v, p.c1_bi, p.c2_bi, (size_t)i, pw1, pw2);
-                    bi[i] = bi_v + p.lr * g;
-                    g = adapt(p, err - p.bias_reg * bu_v, p.c1_bu, p.c2_bu, (size_t)u, pw1, pw2);
-                    bu[u] = bu_v + p.lr * g;
-                }
-                s_err = err;
-                s_pw1 = pw1;
-                s_pw2 = pw2;
-                if (p.sgd_mode == MI355REC_ADAM) {
-                    b1p *= p.beta_1_d;
-                    b2p *= p.beta_2_d;
-                }
-            }
-        }
-        // the next step's first row ids (its bounds have arrived)
-        int rowid_n[R];
-#pragma unroll
-        for (int m = 0; m < R; ++m) {
-            const int q = rs_n + wave + 16 * m;
-            const int id = p.indices[min(q, max(re_n - 1, rs_n))];
-            rowid_n[m] = q < re_n ? id : -1;
-        }
-        __syncthreads();
-        const T err = s_err, pw1 = s_pw1, pw2 = s_pw2;
-        // every Y row of the profile moves against the OLD X[i]   (.pyx:493-511)
-#pragma unroll
-        for (int m = 0; m < R; ++m) {
-            if (rowid[m] < 0) continue;
-            const size_t row = (size_t)rowid[m];
-            T *Y = Ymat + row * k;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                if (!fok[c]) continue;
-                const int f = lane + 64 * c;
-                const T w = yv[m][c];
-                const T g = adapt(p, err * s_xi[f] - p.user_reg * w, p.c1U, p.c2U, row * k + f, pw1, pw2);
-                Y[f] = w + p.lr * g;
-            }
-        }
-        for (int q = rs + wave + 16 * R; q < re; q += 16) {
-            const size_t row = (size_t)p.indices[q];
-            T *Y = Ymat + row * k;
-            for (int f = lane; f < k; f += 64) {
-                const T w = Y[f];
-                const T g = adapt(p, err * s_xi[f] - p.user_reg * w, p.c1U, p.c2U, row * k + f, pw1, pw2);
-                Y[f] = w + p.lr * g;
-            }
-        }
-        // X[i] moves against the user vector formed BEFORE the Y update   (.pyx:514-531)
-        if (tid < k) {
-            const T h = s_xi[tid];
-            const T g = adapt(p, err * s_acc[tid] - p.item_reg * h, p.c1V, p.c2V, (size_t)i * k + tid, pw1, pw2);
-            X[tid] = h + p.lr * g;
-        }
-        __threadfence_block();
-        __syncthreads();
-        u = u_n;
-        i = i_n;
-        rating = rating_n;
-        rs = rs_n;
-        re = re_n;
-#pragma unroll
-        for (int m = 0; m < R; ++m) rowid[m] = rowid_n[m];
-    }
-    if (tid == 0) {
-        p.state->beta_1_power = b1p;
-        p.state->beta_2_power = b2p;
-        p.state->asy_loss = loss;
-    }
-}
-
-}  // namespace
-}  // namespace mi355rec
 
 using namespace mi355rec;
 
