@@ -249,7 +249,7 @@ int mi355rec_mf_get_last_samples(mi355rec_mf_t h, int32_t *u, int32_t *i, int32_
 int mi355rec_mf_set_profiling(mi355rec_mf_t h, int32_t max_timed_launches);
 /* Diagnostics (handles created with MI355REC_MF_TICKS=1 in the environment): shader-clock stamps of every wavefront of the
  * LAST mini-batch run, 8 words per task slot {entry, header arrived, first rows arrived, list done, exit, list length,
- * workgroup, XCD}.  *n receives the number of words available (0 when the handle was created without the variable). */
+ * own row written, taken-over item rows written}.  *n receives the number of words available (0 when the handle was created without the variable). */
 int mi355rec_mf_get_phase_ticks(mi355rec_mf_t h, uint64_t *out, int64_t cap, int64_t *n);
 int mi355rec_mf_get_stats(mi355rec_mf_t h, mi355rec_stats *stats);
 void mi355rec_mf_destroy(mi355rec_mf_t h);

@@ -177,6 +177,33 @@ def test_native_sampler_is_a_valid_reference_sampler(gpu):
     np.testing.assert_array_equal(again.last_epoch_samples()[0], u)
 
 
+def test_sampler_grid_larger_than_the_device_draws_one_epoch(gpu):
+    """the sampler read the epoch counter that its own launch advanced -- workgroups dispatched after workgroup 0 had
+    retired drew from the NEXT epoch (a launch of 78 k workgroups is not resident at once).  The counter is advanced by a kernel of
+    its own now.  FunkSVD at the ML-20M shape (20 M samples per epoch): two handles with one seed draw the same stream, the stream
+    of epoch 2 differs from epoch 1 everywhere it should, and a handle that runs epochs 1 and 2 in ONE call ends on epoch 2's
+    stream."""
+    X = named_urm("ml20m", "real")
+    kw = dict(n_factors=8, algorithm_name="FUNK_SVD", batch_size=1000, random_seed=123, sgd_mode="sgd", learning_rate=1e-3,
+              use_bias=False, negative_interactions_quota=0.0)
+    a = MatrixFactorization_MI355X_Epoch(X, **kw)
+    b = MatrixFactorization_MI355X_Epoch(X, **kw)
+    a.epochIteration_Cython()
+    u1, i1, r1 = a.last_epoch_samples()
+    b.epochIteration_Cython()
+    for x, y in zip((u1, i1, r1), b.last_epoch_samples()):
+        np.testing.assert_array_equal(x, y)
+    a.epochIteration_Cython()
+    u2, i2, r2 = a.last_epoch_samples()
+    assert (u2 != u1).mean() > 0.99                                     # (two independent uniform draws of 138 493 users)
+    c = MatrixFactorization_MI355X_Epoch(X, **kw)
+    c.epochIteration_Cython(2)
+    for x, y in zip((u2, i2, r2), c.last_epoch_samples()):
+        np.testing.assert_array_equal(x, y)
+    for m in (a, b, c):
+        m.close()
+
+
 @pytest.mark.parametrize("algorithm", ["MF_BPR", "FUNK_SVD"])
 def test_native_epoch_equals_oracle_on_the_device_stream(gpu, algorithm):
     X = named_urm("ml1m", "real" if algorithm == "FUNK_SVD" else "binary", scale=0.2)
