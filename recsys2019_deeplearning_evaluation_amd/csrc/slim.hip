@@ -22,10 +22,12 @@
 //                     write-through store: a reader that knows which step wrote the cell last (`pred`, from a sort of the
 //                     stream's (cell, step) pairs) polls THE CELL until the tag matches -- one round trip per link instead of
 //                     done-flag poll + gather + drain + flag store, and no step ever drains its stores.  The per-item
-//                     optimiser cells travel the same way (two granules per float64).
+//                     optimiser cells travel the same way (two granules per float64).  Steps with profiles of more than 256
+//                     entries are run by a whole workgroup (all their granules in flight at once), the others by a wavefront.
+// The sample stream of epoch e + 1 is drawn and scheduled on a second stream while the kernel of epoch e runs (StreamSet x 2).
 // Steps are claimed from an in-order queue, so a waiting step only ever waits for steps that are already running: no deadlock
 // whatever the residency (the owners of the dense store are the exception: they are leased to one launch at a time, see
-// run_stream).  Exact sequential semantics (1e-5 element-wise against the float64 oracle for all four optimisers, both stores,
+// OwnerLease).  Exact sequential semantics (1e-5 element-wise against the float64 oracle for all four optimisers, both stores,
 // at the full BASELINE config-3 shape).  4-byte gathers / scatters, no dense contraction: no MFMA.
 #include "common.h"
 #include "sampling.cuh"
