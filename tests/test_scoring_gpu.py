@@ -192,3 +192,42 @@ def test_scorer_cache_follows_the_model_and_the_urm(gpu):
         _, host_scores = RB.BaseRecommender.recommend(knn, users, cutoff=10, return_scores=True)
         fin = np.isfinite(host_scores)
         assert np.abs(dev_scores[fin] - host_scores[fin]).max() < 1e-5 * max(1e-30, np.abs(host_scores[fin]).max())
+
+
+@pytest.mark.parametrize("tag", ["plain", "bias", "restricted", "bias_restricted"])
+def test_reference_generated_fixture(gpu, tag):
+    """tests/golden/scoring.npz holds what the REFERENCE's own BaseMatrixFactorizationRecommender._compute_item_score and
+    BaseRecommender.recommend return (tests/golden/make_scoring_fixture.py, run where /root/reference exists): scores after the
+    seen-item filter and ranked lists, incl. a user who has seen nothing and one with fewer unseen items than the cut-off.
+    float64 reference against the device's float32 MFMA scores: 1e-5 of the score scale; rankings equal wherever the reference's
+    neighbouring scores are further apart than that."""
+    import os
+    import scipy.sparse as sps
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scoring.npz"))
+    X = sps.csr_matrix((np.ones(len(z["indices"]), np.float32), z["indices"], z["indptr"]), shape=tuple(z["shape"]))
+    bias = (z["bu"], z["bi"], float(z["mu"])) if "bias" in tag else ()
+    sc = MI355XScorer(z["U"], z["V"], X, *bias)
+    allowed = None
+    if "restricted" in tag:
+        allowed = np.zeros(X.shape[1], np.uint8)
+        allowed[z["allowed"]] = 1
+    cutoff = int(z["cutoff"])
+    ranked, scores = sc.recommend(z["users"], cutoff, remove_seen=True, allowed_items=allowed, return_scores=True)
+    want_scores, want_ranked = z["scores_" + tag], z["ranked_" + tag]
+    finite = np.isfinite(want_scores)
+    assert (np.isfinite(scores) == finite).all()
+    scale = np.abs(want_scores[finite]).max()
+    tol = 1e-5 * scale
+    assert np.abs(scores[finite] - want_scores[finite]).max() < tol
+    for r in range(len(z["users"])):
+        want = want_ranked[r][want_ranked[r] >= 0]
+        got = ranked[r][ranked[r] >= 0]
+        assert len(got) == len(want)
+        _check_ranking(ranked[r], want_scores[r], cutoff, tol)
+        # positions whose reference score is separated from both neighbours by more than the tolerance must hold the same item
+        ws = want_scores[r][want]
+        clear = np.ones(len(want), bool)
+        clear[1:] &= (ws[:-1] - ws[1:]) > 2 * tol
+        clear[:-1] &= (ws[:-1] - ws[1:]) > 2 * tol
+        np.testing.assert_array_equal(got[clear], want[clear])
+    sc.close()
