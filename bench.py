@@ -337,14 +337,14 @@ def hbm_block(kernel, st, seconds, note=None):
     return out
 
 
-def other_paths(urm, args):
+def other_paths(urm, args, out=None):
     """The remaining rows of SURVEY.md section 8 on the same URM shape, one short run each (N = 1 only): one roofline block per
     path.  Throughputs come from the handle's own stream events (call_ms); fractions are ALGORITHMIC work / time against the
-    MI355X peaks."""
+    MI355X peaks.  Fills `out` as it goes: what was measured before a failure stays."""
     import numpy as np
     from recsys2019_deeplearning_evaluation_amd import (IALS_MI355X_Epoch, MatrixFactorization_MI355X_Epoch,
                                                         SLIM_BPR_MI355X_Epoch)
-    out = {}
+    out = {} if out is None else out
 
     def mf_run(tag, epochs, note=None, **kw):
         m = MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, learning_rate=1e-3, init_std_dev=0.1, random_seed=7, **kw)
@@ -982,10 +982,11 @@ def main():
 
     note("ials section done")
     if rank == 0 and world == 1 and not args.no_extras:
+        out["extra"]["paths"] = {}
         try:
-            out["extra"]["paths"] = other_paths(urm, args)
-        except Exception as exc:                       # the headline line must survive a failure in the side measurements
-            out["extra"]["paths_error"] = repr(exc)
+            other_paths(urm, args, out["extra"]["paths"])
+        except Exception as exc:                       # the headline line must survive a failure in the side measurements, and so
+            out["extra"]["paths_error"] = repr(exc)    # must the paths measured before it
     note("other paths done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline_bpr(urm, args.cpu_seconds)
