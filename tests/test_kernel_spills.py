@@ -32,3 +32,72 @@ def test_ials_row_kernel_spills_are_per_row_not_in_the_mfma_loops(tmp_path):
     for slots in (1, 2, 4, 6, 8, 10):
         small = audit(asm, "ials_row_kernelILi%dE" % slots, "v_mfma")
         assert len(small) == 1 and not next(iter(small.values()))["scratch"], slots
+
+
+def _kernel_text(asm_path, mangled_fragment):
+    """The instructions of the one kernel whose mangled name holds the fragment (label .. s_endpgm), comments dropped."""
+    lines = open(asm_path).read().split("\n")
+    starts = [n for n, ln in enumerate(lines) if ln.split(";")[0].strip().endswith(":") and mangled_fragment in ln.split(";")[0]
+              and not ln.startswith(("\t", " ", "."))]
+    assert len(starts) == 1, (mangled_fragment, len(starts))
+    body = []
+    for ln in lines[starts[0] + 1:]:
+        text = ln.split(";")[0].strip()
+        if text:
+            body.append(text)
+        if text.startswith("s_endpgm"):
+            break
+    return body
+
+
+def _resource(asm_path, mangled_fragment, key):
+    """`; key: value` from the kernel's resource comment block (VGPRs, ScratchSize, Occupancy ...)."""
+    text = open(asm_path).read()
+    at = text.index(".amdhsa_kernel", text.index(mangled_fragment))
+    import re
+    m = re.search(r";\s*%s:\s*(\d+)" % re.escape(key), text[at:at + 20000])
+    assert m, key
+    return int(m.group(1))
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_mini_batch_kernel_prologue_and_plain_sgd_instances(tmp_path):
+    """What the round-4 speed-up of the mini-batch chain rests on, checked on the assembly (no GPU): the plain-sgd instances carry no
+    optimiser arithmetic (no square root) and no scratch memory; every kernel argument the prologue needs is
+    loaded before the header is asked for (at most two waits on scalar loads in front of the first vector load), and the header, a pair
+    task's slot records and -- FunkSVD -- the batch index and the global-bias ring entry are all requested before the first wait on
+    a vector load."""
+    asm = str(tmp_path / "mf.s")
+    src = os.path.join(ROOT, "recsys2019_deeplearning_evaluation_amd", "csrc", "mf.hip")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-S", "--cuda-device-only",
+                    src, "-o", asm], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for algo, min_loads in ((0, 3), (1, 5)):             # BPR: header (2 x 16 B) + slot record; FunkSVD: + batch index, ring state, ring terms
+        name = "15mf_batch_kernelILi%dEfLi4ELi32ELi1ELb1EE" % algo
+        body = _kernel_text(asm, name)
+        first_vload = next(n for n, t in enumerate(body) if t.startswith("global_load"))
+        first_vwait = next(n for n, t in enumerate(body) if t.startswith("s_waitcnt vmcnt"))
+        scalar_waits = sum(1 for t in body[:first_vload] if t.startswith("s_waitcnt lgkmcnt"))
+        assert scalar_waits <= 3, (algo, scalar_waits)                      # (one of them belongs to the optional clock stamp)
+        loads_before_wait = sum(1 for t in body[first_vload:first_vwait] if t.startswith("global_load"))
+        assert loads_before_wait >= min_loads, (algo, loads_before_wait)
+        assert _resource(asm, name, "ScratchSize") == 0
+    plain = _kernel_text(asm, "15mf_batch_kernelILi0EfLi4ELi32ELi1ELb1EE")
+    general = _kernel_text(asm, "15mf_batch_kernelILi0EfLi4ELi32ELi1ELb0EE")
+    assert not any(t.startswith("v_sqrt_f32") for t in plain)           # (the sigmoid keeps its one division)
+    assert any(t.startswith("v_sqrt_f32") for t in general)
+    assert len(plain) * 2 < len(general)
+    # the replica-batched plain-sgd instance: no scratch, at most 80 registers (6 wavefronts per SIMD) would be wasted on spills
+    assert _resource(asm, "21mf_group_batch_kernelILi0EfLi4ELi32ELi1ELb1EE", "ScratchSize") == 0
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_slim_dataflow_kernels_fit_their_launch_shape(tmp_path):
+    """1024-thread workgroups leave 128 vector registers per lane: the SLIM dataflow kernels must fit without scratch memory (a spilled
+    granule would put a memory round trip inside a chain link)."""
+    asm = str(tmp_path / "slim.s")
+    src = os.path.join(ROOT, "recsys2019_deeplearning_evaluation_amd", "csrc", "slim.hip")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-S", "--cuda-device-only",
+                    src, "-o", asm], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for name in ("slim_sym_flow_kernel", "slim_dense_flow_kernelIdE", "slim_dense_flow_kernelIfE"):
+        assert _resource(asm, name, "ScratchSize") == 0, name
+        assert _resource(asm, name, "NumVgprs") <= 128, name
