@@ -3,7 +3,9 @@
 seconds) on an ML-20M-shaped synthetic URM (138 493 x 26 744, ~20 M interactions), k=128, batch 1000.
 
   python bench.py --gpus N --steps K --warmup W [--workload ml20m|ml1m|netflix]
-  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+  N > 1:  either as above -- bench.py then starts the N ranks itself (launch_ranks: one process per GPU, refuses to run when fewer
+          than N devices are visible) -- or under python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+          127.0.0.1 ... bench.py --gpus N ... (WORLD_SIZE must then equal N).
 
 A "step" is one reference epoch of MatrixFactorization_BPR_Cython (n_users // batch_size + 1 = 139 mini-batches of
 1000 samples drawn on the device, MatrixFactorization_Cython_Epoch.pyx:583).  Inputs (URM, factors) are resident
@@ -602,6 +604,69 @@ def other_paths(urm, args, out=None):
     return out
 
 
+def visible_devices():
+    """HIP devices this process could bind, counted in a child process (the launcher itself never creates a HIP context).
+    BENCH_ASSUME_DEVICES overrides the count -- for the launcher's own CPU tests (tests/test_bench_launcher.py) only."""
+    import subprocess
+    if os.environ.get("BENCH_ASSUME_DEVICES"):
+        return int(os.environ["BENCH_ASSUME_DEVICES"])
+    code = ("import sys; sys.path.insert(0, %r); from recsys2019_deeplearning_evaluation_amd import _native; "
+            "_native.load(); print(_native.device_count())" % ROOT)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise SystemExit("bench.py: cannot count the HIP devices (%s)" % (res.stderr.strip().splitlines() or ["no output"])[-1])
+    return int(res.stdout.strip().splitlines()[-1])
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here -- one process per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment exactly as torch.distributed.run would set them -- relay
+    rank 0's JSON line (it inherits this process's stdout), and fail if any rank fails.  Never falls back to fewer GPUs: asking for
+    more ranks than there are devices is an error, so a line that says n_gpus = N was produced by N devices (the communicator census
+    inside every rank is the second check).  Returns the exit code of the job."""
+    import socket
+    import subprocess
+    n = args.gpus
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"          # dry run of the N > 1 path on one device (gloo transport)
+    have = visible_devices()
+    if have < (1 if share else n):
+        print("bench.py: --gpus %d needs %d HIP devices, %d visible; refusing to run on fewer" % (n, n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sock:                              # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    children = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_LAUNCHED_BY="bench.py")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = subprocess.PIPE if rank == 0 else subprocess.DEVNULL       # one JSON line on stdout: rank 0's
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, text=True))
+
+    def relay(stream):
+        # rank 0's JSON line goes to stdout; anything a library prints there (gloo's connection banner) goes to stderr
+        for line in stream:
+            print(line, end="", file=sys.stdout if line.lstrip().startswith("{") else sys.stderr, flush=True)
+    pump = threading.Thread(target=relay, args=(children[0].stdout,), daemon=True)
+    pump.start()
+    code = 0
+    pending = dict(enumerate(children))
+    while pending:
+        for rank, child in list(pending.items()):
+            rc = child.poll()
+            if rc is None:
+                continue
+            del pending[rank]
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 1
+                print("bench.py: rank %d exited with code %d; stopping the other ranks" % (rank, rc), file=sys.stderr)
+                for other in pending.values():                 # exactly the processes started above
+                    other.terminate()
+        time.sleep(0.05)
+    pump.join(timeout=10)
+    return code
+
+
 class Net:
     """Barrier + max-over-ranks over whichever transport the run uses (torch.distributed or RCCL through ctypes)."""
 
@@ -622,7 +687,8 @@ class Net:
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-        torch.cuda.set_device(self.local_rank)
+        if backend == "nccl" or torch.cuda.is_available():
+            torch.cuda.set_device(self.local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
         else:
@@ -650,6 +716,11 @@ class Net:
             self.dist.barrier()
         elif self.comm is not None:
             self._gather_double(0.0)
+
+    def barrier_host(self):
+        """Barrier that never touches a device (the launch-only check)."""
+        if self.dist is not None:
+            self.dist.barrier()
 
     def max(self, x):
         if self.dist is not None:
@@ -898,10 +969,28 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args))                   # the ranks come back through main() with WORLD_SIZE set
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
     import faulthandler
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)      # a stall leaves its stack in the log
+    if os.environ.get("BENCH_LAUNCH_ONLY") == "1" and os.environ.get("BENCH_TEST_BREAK_RANK") == os.environ.get("RANK"):
+        raise SystemExit(3)                            # (launcher test: a rank that dies before the rendezvous)
     net = Net(args)
     rank, world = net.rank, net.world
+    if os.environ.get("BENCH_LAUNCH_ONLY") == "1":
+        # launcher + communicator check without a device (tests/test_bench_launcher.py): census, one line, no measurement
+        census = net.census()
+        net.barrier_host()
+        if rank == 0:
+            print(json.dumps({"launch_only": True, "n_gpus": world, "communicator": census, "launched_by": os.environ.get("BENCH_LAUNCHED_BY", "external")}))
+        net.close()
+        faulthandler.cancel_dump_traceback_later()
+        return
     import numpy as np  # noqa: F401
     from recsys2019_deeplearning_evaluation_amd import MatrixFactorization_MI355X_Epoch, _native
     _native.load()
@@ -951,7 +1040,8 @@ def main():
     mf.close()
 
     note("headline: %.1f M samples/s" % (value / 1e6))
-    extra = {"bpr_loss_per_sample": st["loss"] / max(1, st["n_units"]), "bpr_stream_ms": st["call_ms"], "communicator": census}
+    extra = {"bpr_loss_per_sample": st["loss"] / max(1, st["n_units"]), "bpr_stream_ms": st["call_ms"], "communicator": census,
+             "launched_by": os.environ.get("BENCH_LAUNCHED_BY", "external launcher" if world > 1 else "single process")}
     costs = None
     if not args.no_sim:
         costs = itemknn_section(urm, net, args, extra)

@@ -173,6 +173,12 @@ int mi355rec_sim_schedule_info(mi355rec_sim_t h, int32_t *n_items, int32_t *n_sp
  * double array (Compute_Similarity_Cython.pyx:363; chosen when no such scale exists, or with MI355REC_SIM_F64_SUMS=1 in the
  * environment at create time).  Diagnostics for the parity tests. */
 int mi355rec_sim_accumulator_info(mi355rec_sim_t h, int32_t *kind, double *fixed_scale);
+/* Selection path of the last compute call (diagnostics for the parity tests): columns whose top-K was found threshold-first
+ * (per-thread maxima -> K-th largest maximum -> exact division of the survivors only; csrc/sim.hip), the survivors those columns
+ * ranked in total, and columns that went back to the full normalise + radix select after their scan (more survivors than the
+ * candidate buffer holds).  Columns with fewer than topK positive cells, accumulator tiles, 8-byte cells, topK == 0 and the
+ * Euclidean cell map always take the full path and are counted nowhere.  MI355REC_SIM_FAST_TOPK=0 switches the first path off. */
+int mi355rec_sim_selection_info(mi355rec_sim_t h, int64_t *threshold_first_columns, int64_t *candidates, int64_t *fallbacks);
 int mi355rec_sim_sync(mi355rec_sim_t h);
 int mi355rec_sim_get_stats(mi355rec_sim_t h, mi355rec_stats *stats);
 void mi355rec_sim_destroy(mi355rec_sim_t h);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "mi355rec_sim_column_costs": (C.c_int, [_vp, _vp]),
     "mi355rec_sim_schedule_info": (C.c_int, [_vp, _vp, _vp, _vp]),
     "mi355rec_sim_accumulator_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_f64)]),
+    "mi355rec_sim_selection_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "mi355rec_sim_sync": (C.c_int, [_vp]),
     "mi355rec_sim_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "mi355rec_sim_destroy": (None, [_vp]),

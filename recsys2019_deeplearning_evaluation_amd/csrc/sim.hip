@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <type_traits>
 #include <numeric>
 
 namespace mi355rec {
@@ -63,6 +64,8 @@ struct SimParams {
     uint32_t *part_buf;     // [part slots][n_cols_pad] partial accumulators of split columns
     unsigned *part_count;   // arrival counters, indexed by the first part slot of a split column
     unsigned long long *phase_ticks;   // diagnostics (MI355REC_SIM_PHASES=1): 100 MHz ticks per phase, summed over workgroups
+    int fast_topk;          // 1: threshold-first selection (fast_column_topk) where it applies; 0 (MI355REC_SIM_FAST_TOPK=0): always the full normalise + radix select
+    unsigned long long *fast_stats;    // [0] columns finished by the fast path, [1] their candidates, [2] columns that fell back
     unsigned *queue;
     int *out_idx;
     float *out_val;
@@ -99,6 +102,23 @@ __device__ __forceinline__ float euclidean_cell(const SimParams &p, float dot, f
     if (p.euclid_mode == MI355REC_EUCLID_EXP) f = expf(d);                     // :186-187
     else if (p.euclid_mode == MI355REC_EUCLID_LOG) f = logf(__fadd_rn(d, 1.f));  // :192-193
     return __fdiv_rn(1.f, __fadd_rn(__fadd_rn(f, p.shrink), 1e-9f));
+}
+
+// The denominator of `normalise` for the modes that divide by a per-cell quantity, evaluated with one or two fused operations: used
+// only to ORDER cells (fast_column_topk); every value that is emitted comes from `normalise` itself.
+//   dmode 0: normalize (cosine / asymmetric)  1: jaccard  2: dice  3: tversky
+struct DenomConsts {
+    float s6;        // shrink + 1e-6
+    float ncs;       // norm_c + s6
+    float tv_v;      // tversky: 1 - alpha - beta
+    float tv_c;      // tversky: alpha * norm_c + s6
+};
+template <int DMODE>
+__device__ __forceinline__ float approx_denominator(const SimParams &p, const DenomConsts &k, float v, float norm_c, float norm_j) {
+    if (DMODE == 0) return __builtin_fmaf(norm_c, norm_j, k.s6);
+    if (DMODE == 1) return (k.ncs + norm_j) - v;
+    if (DMODE == 2) return k.ncs + norm_j;
+    return __builtin_fmaf(v, k.tv_v, __builtin_fmaf(p.tversky_beta, norm_j, k.tv_c));
 }
 
 // float64 -> int64 by the "magic number" addition: for |x| < 2^51, bits(x + 1.5 * 2^52) - bits(1.5 * 2^52) = round-to-nearest-even(x)
@@ -417,7 +437,135 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             if (CELL32) acc[c - tile_base] = 0.f;
             else acc_d[c - tile_base] = 0.0;
         }
+        if (CELL32 && p.fast_topk && tid < 256) aux[tid] = 0u;      // the histogram of block_kth_largest_prefix16 (the wavefront tables are dead)
         __syncthreads();
+
+        // ---- threshold-first top-K (4-byte cells, one tile, topK > 0, a positive denominator) ----
+        // The full path below divides every cell (IEEE division: ~10 VALU operations), counts signs and key ranges, and then
+        // scans the 26 744 cells of an ML-20M column two or three more times for the radix select: 17.8 of the ~19 us a column costs
+        // besides its accumulation.  Only the K winners need their exact value.  So: (A) every thread takes the maximum of
+        // v * rcp(denominator) over its own cells (approximate: a few ulp) -- the K-th largest of these THREADS maxima is a lower
+        // bound T0 on the K-th largest cell of the column, and a tight one (the winners of a column are spread over the threads);
+        // (B) one more scan compares v with Tf * denominator, Tf = T0 (1 - 2^-19): no division, and the margin (32 ulp) covers the
+        // rounding of both approximations (<= 4 ulp each), so every cell whose EXACT value reaches the exact K-th largest value
+        // passes -- ties included; (C) the survivors (~1.05 K) are divided exactly (`normalise`, the same instructions as below),
+        // ranked by (value, lowest index first) and the first K emitted.  The result is identical to the full path's, bit for bit
+        // (tests/test_sim_gpu.py::test_fast_topk_equals_full_selection).  Fewer than K positive thread maxima (sparse columns) or
+        // more survivors than the candidate buffer holds (masses of equal values): the full path runs, the accumulator is untouched.
+        if (CELL32 && p.fast_topk) {
+            const bool asym = p.normalize && p.kind == MI355REC_SIM_ASYMMETRIC;
+            const float norm_c = asym ? p.norm_alpha[c] : p.norm[c];
+            const float4 *nj4 = reinterpret_cast<const float4 *>(asym ? p.norm_1ma : p.norm);
+            const uint32_t K = (uint32_t)p.topK;
+            // 0-3: approx_denominator; 4: / shrink; 5: the sums themselves
+            const int dmode = p.normalize ? 0 : p.kind == MI355REC_SIM_JACCARD ? 1 : p.kind == MI355REC_SIM_DICE ? 2
+                              : p.kind == MI355REC_SIM_TVERSKY ? 3 : p.shrink != 0.f ? 4 : 5;
+            auto with_mode = [&](auto &&f) {
+                switch (dmode) {
+                    case 0: f(std::integral_constant<int, 0>{}); break;
+                    case 1: f(std::integral_constant<int, 1>{}); break;
+                    case 2: f(std::integral_constant<int, 2>{}); break;
+                    case 3: f(std::integral_constant<int, 3>{}); break;
+                    case 4: f(std::integral_constant<int, 4>{}); break;
+                    default: f(std::integral_constant<int, 5>{}); break;
+                }
+            };
+            constexpr int NPF = 8;                          // MAX_TILE / 4 / 1024 (512-thread tiles are narrower)
+            constexpr int CAND_MAX = AUX_WORDS / 2;
+            const int n_quads = p.n_cols_pad / 4, n_quads_valid = (n_tile + 3) >> 2;
+            float4 npf[NPF];
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) {
+                const int w = tid + i * THREADS;
+                npf[i] = nj4[w < n_quads_valid ? w : 0];
+            }
+            DenomConsts k;
+            k.s6 = p.shrink + 1e-6f;
+            k.ncs = norm_c + k.s6;
+            k.tv_v = 1.f - p.tversky_alpha - p.tversky_beta;
+            k.tv_c = __builtin_fmaf(p.tversky_alpha, norm_c, k.s6);
+            auto cell_value = [&](unsigned q) { return UNIT ? (float)q : (float)(int)q * p.int_inv; };
+            const uint4 *acc4 = reinterpret_cast<const uint4 *>(acc);
+            // (A) thread maxima of the approximate values
+            float m = 0.f;
+            with_mode([&](auto dm) {
+                constexpr int DM = decltype(dm)::value;
+                const float uniform_scale = DM == 4 ? 1.f / p.shrink : 1.f;
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) {
+                    const int w = tid + i * THREADS;
+                    if (w < n_quads) {
+                        const uint4 qu = acc4[w];
+                        const float vv[4] = {cell_value(qu.x), cell_value(qu.y), cell_value(qu.z), cell_value(qu.w)};
+                        const float nn[4] = {npf[i].x, npf[i].y, npf[i].z, npf[i].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float q = DM <= 3 ? vv[e] * __builtin_amdgcn_rcpf(approx_denominator<DM>(p, k, vv[e], norm_c, nn[e]))
+                                                    : vv[e] * uniform_scale;
+                            m = fmaxf(m, q);
+                        }
+                    }
+                }
+            });
+            const uint32_t p16 = block_kth_largest_prefix16<THREADS>(float_key(m), K, aux, sc);
+            mark(3);
+            bool done = p16 > (ZERO_KEY >> 16);                    // else: fewer than K threads hold a positive cell
+            if (done) {
+                if (tid == 0 && tile == 0) request_next();
+                const float Tf = key_float(p16 << 16) * 0.99999809265136719f;        // 1 - 2^-19
+                // (B) cells that can reach the top K -> exact value -> candidate list
+                uint64_t *cand = reinterpret_cast<uint64_t *>(aux);
+                if (tid == 0) sc.out_count = 0;
+                uint32_t mine = 0;          // bit 4 i + e: cell e of this thread's quad i passes
+                with_mode([&](auto dm) {
+                    constexpr int DM = decltype(dm)::value;
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) {
+                        const int w = tid + i * THREADS;
+                        if (w < n_quads) {
+                            const uint4 qu = acc4[w];
+                            const float vv[4] = {cell_value(qu.x), cell_value(qu.y), cell_value(qu.z), cell_value(qu.w)};
+                            const float nn[4] = {npf[i].x, npf[i].y, npf[i].z, npf[i].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float bar = DM <= 3 ? Tf * approx_denominator<DM>(p, k, vv[e], norm_c, nn[e]) : (DM == 4 ? Tf * p.shrink : Tf);
+                                mine |= (uint32_t)(vv[e] >= bar) << (4 * i + e);
+                            }
+                        }
+                    }
+                });
+                // (C) the survivors (a few per wavefront): exact value, candidate list
+                while (mine) {
+                    const int b = __ffs((int)mine) - 1;
+                    mine &= mine - 1u;
+                    const int j = 4 * (tid + (b >> 2) * THREADS) + (b & 3);
+                    const float x = normalise(p, cell_value(reinterpret_cast<const unsigned *>(acc)[j]), norm_c, reinterpret_cast<const float *>(nj4)[j]);
+                    const uint32_t at = atomicAdd(&s_ncand, 1u);
+                    if (at < (uint32_t)CAND_MAX) cand[at] = ((uint64_t)float_key(x) << 32) | (uint32_t)(~(uint32_t)j);
+                }
+                __syncthreads();
+                const uint32_t n_cand = s_ncand;
+                if (n_cand > (uint32_t)CAND_MAX || n_cand < K) {         // (n_cand < K cannot happen: at least K cells passed (A)'s bar)
+                    __syncthreads();
+                    if (tid == 0) s_ncand = 0;
+                    if (p.fast_stats && tid == 0) atomicAdd(&p.fast_stats[2], 1ull);
+                    done = false;
+                } else {
+                    if (p.fast_stats && tid == 0) {
+                        atomicAdd(&p.fast_stats[0], 1ull);
+                        atomicAdd(&p.fast_stats[1], (unsigned long long)n_cand);
+                    }
+                    // rank, emit
+                    block_rank_emit<THREADS>(cand, (int)n_cand, p.topK, K, 0u, sc, p.out_idx + out_base, p.out_val + out_base);
+                }
+            }
+            if (done) {
+                if (tid == 0 && tile == 0) file_next();
+                __syncthreads();
+                mark(4);
+                continue;
+            }
+        }
 
         // ---- normalisation (.pyx:473-504), in place; count signs for the selection ----
         uint32_t npos = 0, nneg = 0, kmin = 0xFFFFFFFFu, kmax = 0u;   // key range of the positive cells
@@ -1037,6 +1185,7 @@ struct mi355rec_sim {
     DeviceBuffer<uint32_t> part_buf;
     DeviceBuffer<unsigned> part_count;
     DeviceBuffer<unsigned long long> phase_ticks;
+    DeviceBuffer<unsigned long long> selection_counts;   // [0] columns finished by the threshold-first selection, [1] their candidates, [2] fall-backs after its scan
     DeviceBuffer<int> csr_key, csr_key_sorted, csr_pos, csr_pos_sorted, csr_indptr, csr_indices;   // mi355rec_sim_compute_csr
     DeviceBuffer<float> csr_data;
     DeviceBuffer<char> csr_sort_tmp;
@@ -1383,6 +1532,18 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
         if (!h->phase_ticks.ptr) h->phase_ticks.alloc(8);
         MI_HIP(hipMemsetAsync(h->phase_ticks.ptr, 0, 8 * sizeof(unsigned long long), h->stream));
         p.phase_ticks = h->phase_ticks.ptr;
+    }
+    if (!h->selection_counts.ptr) h->selection_counts.alloc(4);
+    MI_HIP(hipMemsetAsync(h->selection_counts.ptr, 0, 4 * sizeof(unsigned long long), h->stream));
+    p.fast_stats = h->selection_counts.ptr;
+    // threshold-first selection (fast_column_topk in the kernel): positive denominators only (the set-based modes and tversky's
+    // alpha / beta inside the range the approximation's error bound was derived for), K well below the number of thread maxima
+    {
+        const char *sw = getenv("MI355REC_SIM_FAST_TOPK");
+        const bool tversky_ok = h->cfg.similarity != MI355REC_SIM_TVERSKY ||
+                                (h->cfg.tversky_alpha >= 0.f && h->cfg.tversky_alpha <= 4.f && h->cfg.tversky_beta >= 0.f && h->cfg.tversky_beta <= 4.f);
+        p.fast_topk = !(sw && atoi(sw) == 0) && unit_kernel && h->n_tiles == 1 && p.topK > 0 && 4 * p.topK <= threads &&
+                      h->cfg.similarity != MI355REC_SIM_EUCLIDEAN && h->cfg.shrink >= 0 && tversky_ok;
     }
     p.fixed_scale = unit_kernel ? 0.0 : h->fixed_scale;
     p.int_scale = h->int_shift >= 0 ? (float)(1 << (2 * h->int_shift)) : 1.f;
@@ -1810,11 +1971,13 @@ extern "C" int mi355rec_sim_compute(mi355rec_sim_t h, int32_t start_col, int32_t
         MI_HIP(hipStreamSynchronize(h->stream));
         read_timers(h);
         if (h->phase_ticks.ptr && getenv("MI355REC_SIM_PHASES")) {
-            unsigned long long t[8];
+            unsigned long long t[12];
             h->phase_ticks.download(t, 8, h->stream);
+            h->selection_counts.download(t + 8, 4, h->stream);
             MI_HIP(hipStreamSynchronize(h->stream));
-            fprintf(stderr, "[mi355rec sim phases, workgroup-ms] fetch+clear %.2f  accumulate %.2f  split-merge %.2f  normalise %.2f  topk %.2f  (kernel %.3f ms)\n",
-                    t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, h->stats.kernel_ms);
+            fprintf(stderr, "[mi355rec sim phases, workgroup-ms] fetch+clear %.2f  accumulate %.2f  split-merge %.2f  normalise %.2f  topk %.2f  (kernel %.3f ms)"
+                            "  threshold-first columns %llu (candidates %.1f per column), full-selection fall-backs after the scan %llu\n",
+                    t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, h->stats.kernel_ms, t[8], t[8] ? (double)t[9] / (double)t[8] : 0.0, t[10]);
         }
     });
 }
@@ -1908,6 +2071,21 @@ extern "C" int mi355rec_sim_schedule_info(mi355rec_sim_t h, int32_t *n_items, in
         *n_items = (int32_t)h->items_host.size();
         *n_split_columns = h->n_split_columns;
         *n_parts = h->n_part_items;
+    });
+}
+
+extern "C" int mi355rec_sim_selection_info(mi355rec_sim_t h, int64_t *threshold_first_columns, int64_t *candidates, int64_t *fallbacks) {
+    return guarded([&] {
+        MI_REQUIRE(h && threshold_first_columns && candidates && fallbacks, "NULL argument");
+        unsigned long long t[4] = {0, 0, 0, 0};
+        if (h->selection_counts.ptr) {
+            ensure_device();
+            h->selection_counts.download(t, 4, h->stream);
+            MI_HIP(hipStreamSynchronize(h->stream));
+        }
+        *threshold_first_columns = (int64_t)t[0];
+        *candidates = (int64_t)t[1];
+        *fallbacks = (int64_t)t[2];
     });
 }
 

@@ -131,6 +131,116 @@ __device__ void bitonic_sort_desc(uint64_t *a, int P) {
 }
 
 
+// Ranks the `ncand` candidates (key << 32 | ~index) in LDS and writes those that fall inside the top K of [positives, the
+// `nzero` competing zeros, negatives] straight to their output slot (value-descending, ties towards the lower index), then pads
+// the tail with (-1, 0).  Counting rank (every candidate counts the candidates above it: keys carry the index, so ranks are a
+// permutation) up to 1024 candidates, a bitonic sort above that.  sc.out_count must be 0 on entry (barrier in between).
+template <int THREADS>
+__device__ void block_rank_emit(uint64_t *cand, int ncand, int topK, uint32_t K, uint32_t nzero, SelectScratch &sc, int *out_idx,
+                                float *out_val, int idx_offset = 0, const int *idx_map = nullptr) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    // rank r (0 = largest) is emitted when it falls inside the top K of [positives, the competing zeros, negatives]
+    auto emit = [&](uint64_t e, int r) {
+        const uint32_t key = (uint32_t)(e >> 32);
+        const bool ok = (uint32_t)r + (key < ZERO_KEY ? nzero : 0u) < K;
+        if (ok) {
+            int idx = (int)(~(uint32_t)(e & 0xFFFFFFFFull));
+            idx = idx_map ? idx_map[idx] : idx + idx_offset;
+            out_idx[r] = idx;
+            if (out_val) out_val[r] = key_float(key);
+        }
+        return ok;
+    };
+    uint32_t emitted = 0;
+    if (ncand <= 1024) {
+        // counting rank: G lanes share one candidate (G a power of two <= 64, G * ncand <= THREADS when possible)
+        int G = 1;
+        while (G < 64 && 2 * G * ncand <= THREADS) G <<= 1;
+        const int per_round = THREADS / G, part = tid & (G - 1);
+        for (int c0 = 0; c0 < ncand; c0 += per_round) {
+            const int c = c0 + tid / G;
+            const bool live = c < ncand;
+            const uint64_t mine = live ? cand[c] : 0ull;
+            int r = 0;
+            if (live)
+                for (int i = part; i < ncand; i += G) r += cand[i] > mine;
+            for (int off = 1; off < G; off <<= 1) r += __shfl_xor(r, off);
+            if (live && part == 0) emitted += emit(mine, r);
+        }
+    } else {
+        int P = 2048;
+        while (P < ncand) P <<= 1;
+        for (int t = ncand + tid; t < P; t += THREADS) cand[t] = 0ull;
+        __syncthreads();
+        bitonic_sort_desc<THREADS>(cand, P);
+        for (int t = tid; t < min(ncand, topK); t += THREADS) emitted += emit(cand[t], t);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) emitted += __shfl_down(emitted, off);
+    if (lane == 0 && emitted) atomicAdd(&sc.out_count, emitted);
+    __syncthreads();
+    for (int t = (int)sc.out_count + tid; t < topK; t += THREADS) {
+        out_idx[t] = -1;
+        if (out_val) out_val[t] = 0.f;
+    }
+    __syncthreads();   // sc and aux may be re-used by the caller's next column
+}
+
+// The 16 leading bits of the K-th largest (1-based) of the THREADS keys the threads of the block hold, one each: returns P such that
+// at least K keys are >= P << 16 and fewer than K are >= (P + 1) << 16.  Two 8-bit passes over a 256-bin histogram `hist` (LDS,
+// all zero on entry and on exit).  Keys of one column's maxima share sign and most exponent bits, so the first pass would send
+// nearly every lane of a wavefront to the same bin: the lanes of up to three distinct digits are counted with one atomic per
+// digit (ballot), whoever is left adds for itself.
+template <int THREADS>
+__device__ uint32_t block_kth_largest_prefix16(uint32_t key, uint32_t K, uint32_t *hist, SelectScratch &sc) {
+    static_assert(THREADS >= 256, "the bins are scanned by the first 256 threads");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t prefix = 0, want = K;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int shift = 24 - 8 * pass;
+        bool pending = pass == 0 || (key >> 24) == prefix;
+        const uint32_t digit = (key >> shift) & 255u;
+        for (int it = 0; it < 3; ++it) {
+            const unsigned long long todo = __ballot(pending);
+            if (!todo) break;
+            const int first = __ffsll((long long)todo) - 1;
+            const uint32_t d = (uint32_t)__shfl((int)digit, first);
+            const unsigned long long same = __ballot(pending && digit == d);
+            if (lane == first) atomicAdd(&hist[d], (uint32_t)__popcll(same));
+            pending = pending && digit != d;
+        }
+        if (pending) atomicAdd(&hist[digit], 1u);
+        __syncthreads();
+        uint32_t cnt = 0, suffix = 0;
+        if (tid < 256) {
+            cnt = hist[tid];
+            hist[tid] = 0;                                              // ready for the next pass / the next column
+            suffix = cnt;  // inclusive suffix sum inside the wave (towards higher bins)
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t t = __shfl_down(suffix, off);
+                if (lane + off < 64) suffix += t;
+            }
+            if (lane == 0) sc.wave_tot[wave] = suffix;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            for (int w = wave + 1; w < 4; ++w) suffix += sc.wave_tot[w];
+            const uint32_t above = suffix - cnt;
+            if (suffix >= want && above < want) {
+                sc.digit = tid;
+                sc.want = want - above;
+            }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | sc.digit;
+        want = sc.want;
+    }
+    __syncthreads();     // sc is rewritten by the caller's next selection
+    return prefix;
+}
+
 // Which cells take part in a top-K.
 //   TOPK_ZEROS_COMPETE : the K largest cells of the whole array are taken, zeros included, and zeros are then dropped
 //                        (Compute_Similarity_Cython.pyx:523-555, Triangular_Matrix.get_scipy_csr :1384-1404)
@@ -229,51 +339,7 @@ __device__ void block_topk_emit(const float *acc, int n, int topK, uint32_t npos
     }
     __syncthreads();
     const int ncand = min((int)*ncand_shared, CAND_MAX);
-    // rank r (0 = largest) is emitted when it falls inside the top K of [positives, the competing zeros, negatives]
-    auto emit = [&](uint64_t e, int r) {
-        const uint32_t key = (uint32_t)(e >> 32);
-        const bool ok = (uint32_t)r + ((zeros_compete && key < ZERO_KEY) ? nzero : 0u) < K;
-        if (ok) {
-            int idx = (int)(~(uint32_t)(e & 0xFFFFFFFFull));
-            idx = idx_map ? idx_map[idx] : idx + idx_offset;
-            out_idx[r] = idx;
-            if (out_val) out_val[r] = key_float(key);
-        }
-        return ok;
-    };
-    uint32_t emitted = 0;
-    if (ncand <= 1024) {
-        // counting rank: G lanes share one candidate (G a power of two <= 64, G * ncand <= THREADS when possible)
-        int G = 1;
-        while (G < 64 && 2 * G * ncand <= THREADS) G <<= 1;
-        const int per_round = THREADS / G, part = tid & (G - 1);
-        for (int c0 = 0; c0 < ncand; c0 += per_round) {
-            const int c = c0 + tid / G;
-            const bool live = c < ncand;
-            const uint64_t mine = live ? cand[c] : 0ull;
-            int r = 0;
-            if (live)
-                for (int i = part; i < ncand; i += G) r += cand[i] > mine;
-            for (int off = 1; off < G; off <<= 1) r += __shfl_xor(r, off);
-            if (live && part == 0) emitted += emit(mine, r);
-        }
-    } else {
-        int P = 2048;
-        while (P < ncand) P <<= 1;
-        for (int t = ncand + tid; t < P; t += THREADS) cand[t] = 0ull;
-        __syncthreads();
-        bitonic_sort_desc<THREADS>(cand, P);
-        for (int t = tid; t < min(ncand, topK); t += THREADS) emitted += emit(cand[t], t);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) emitted += __shfl_down(emitted, off);
-    if (lane == 0 && emitted) atomicAdd(&sc.out_count, emitted);
-    __syncthreads();
-    for (int t = (int)sc.out_count + tid; t < topK; t += THREADS) {
-        out_idx[t] = -1;
-        if (out_val) out_val[t] = 0.f;
-    }
-    __syncthreads();   // sc and aux may be re-used by the caller's next column
+    block_rank_emit<THREADS>(cand, ncand, topK, K, zeros_compete ? nzero : 0u, sc, out_idx, out_val, idx_offset, idx_map);
 }
 
 }  // namespace mi355rec

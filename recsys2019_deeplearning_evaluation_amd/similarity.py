@@ -161,6 +161,12 @@ class Compute_Similarity_MI355X:
         N.check(self._lib.mi355rec_sim_accumulator_info(self._h, C.byref(kind), C.byref(scale)))
         return ("uint32", "int64-fixed", "float64", "int32-exact")[kind.value], scale.value
 
+    def selection_info(self):
+        """(columns selected threshold-first, their candidates in total, fall-backs to the full selection) of the last compute call."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        N.check(self._lib.mi355rec_sim_selection_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def stats(self):
         st = N.Stats()
         N.check(self._lib.mi355rec_sim_get_stats(self._h, C.byref(st)))

@@ -650,3 +650,68 @@ def test_quantised_ratings_use_exact_int32_sums(gpu, step, similarity, monkeypat
             other = Compute_Similarity_MI355X(M, **dict(kw, **extra))
             assert other.accumulator_info()[0] in ("int64-fixed", "float64")
             other.close()
+
+
+def _slabs_both_selections(X, monkeypatch, **kw):
+    """(idx, val) of the threshold-first selection and of the full normalise + radix select, and the first one's counters."""
+    out = []
+    for switch in ("1", "0"):
+        monkeypatch.setenv("MI355REC_SIM_FAST_TOPK", switch)
+        dev = Compute_Similarity_MI355X(X, **kw)
+        idx, val, _ = dev.compute_slabs()
+        out.append((idx.copy(), val.copy(), dev.selection_info()))
+        dev.close()
+    monkeypatch.delenv("MI355REC_SIM_FAST_TOPK")
+    assert out[1][2] == (0, 0, 0)                # switched off: no column is counted
+    return out[0], out[1]
+
+
+@pytest.mark.parametrize("similarity,extra", [("cosine", dict(shrink=0)), ("cosine", dict(shrink=10)), ("asymmetric", dict(shrink=5, asymmetric_alpha=0.3)),
+                                              ("jaccard", dict(shrink=0)), ("dice", dict(shrink=3)), ("tversky", dict(shrink=1, tversky_alpha=0.7, tversky_beta=1.5)),
+                                              ("cosine", dict(shrink=20, normalize=False)), ("cosine", dict(shrink=0, normalize=False))])
+@pytest.mark.parametrize("values", ["binary", "stars"])
+def test_threshold_first_topk_equals_full_selection(gpu, similarity, extra, values, monkeypatch):
+    """The threshold-first selection (thread maxima of approximate values -> K-th largest maximum -> exact division of the survivors)
+    emits what the full path emits, bit for bit -- indices, order and values -- for every denominator, on counts and on exact
+    int32 sums, for dense columns (1024-thread instance: 12 000 columns) and K from 1 to THREADS / 4."""
+    X = synthetic_urm(9000, 12000, 1_500_000, min_len=5, max_len=3000, seed=77, values="binary")
+    if values == "stars":
+        rng = np.random.default_rng(5)
+        X.data[:] = rng.integers(1, 11, X.nnz) * 0.5                   # half stars: exact int32 sums
+    for topK in (1, 100, 256):
+        (idx, val, info), (idx0, val0, _) = _slabs_both_selections(X, monkeypatch, topK=topK, similarity=similarity, **extra)
+        np.testing.assert_array_equal(idx, idx0)
+        np.testing.assert_array_equal(val, val0)
+        assert info[0] > 0.9 * X.shape[1], info                  # nearly every column of this matrix has K positive thread maxima
+        assert info[2] == 0, info
+        assert info[1] < 4 * max(topK, 16) * info[0], info       # the bound is tight: a few candidates beyond K per column
+    orc = O.OracleSimilarity(X, topK=0, similarity=similarity, **extra)
+    for c in range(0, X.shape[1], 997):
+        check_topk_against_dense(idx[c], val[c], orc.column(c)[0], 256, RTOL)
+
+
+def test_threshold_first_topk_small_instance_and_sparse_columns(gpu, monkeypatch):
+    """512-thread instance (narrow matrix), columns with fewer than K positive cells (they take the full path), K at the limit."""
+    X = named_urm("ml1m", "binary", scale=0.5)
+    for topK in (5, 128):
+        (idx, val, info), (idx0, val0, _) = _slabs_both_selections(X, monkeypatch, topK=topK, shrink=2)
+        np.testing.assert_array_equal(idx, idx0)
+        np.testing.assert_array_equal(val, val0)
+        assert info[0] > 0, info
+    Xs = synthetic_urm(400, 3000, 6000, min_len=1, max_len=40, seed=3, values="binary")      # nearly every column has < K neighbours
+    (idx, val, info), (idx0, val0, _) = _slabs_both_selections(Xs, monkeypatch, topK=50, shrink=0)
+    np.testing.assert_array_equal(idx, idx0)
+    np.testing.assert_array_equal(val, val0)
+    assert info[0] < 0.2 * Xs.shape[1], info
+
+
+def test_threshold_first_topk_falls_back_on_masses_of_equal_values(gpu, monkeypatch):
+    """Every user holds every item: all cells of a column are equal, every one of them passes the bar -- more survivors than the
+    candidate buffer holds (4 096), so the column is selected by the full path (lowest ids win the tie) and counted as a fall-back."""
+    n_items = 12000
+    X = sps.csr_matrix(np.ones((40, n_items), dtype=np.float32))
+    (idx, val, info), (idx0, val0, _) = _slabs_both_selections(X, monkeypatch, topK=10, shrink=0)
+    np.testing.assert_array_equal(idx, idx0)
+    np.testing.assert_array_equal(val, val0)
+    assert info[2] == n_items and info[0] == 0, info
+    assert (idx[5] == [0, 1, 2, 3, 4, 6, 7, 8, 9, 10]).all()
