@@ -30,6 +30,7 @@ namespace {
 
 constexpr int MAX_TILE = 32256;      // uint32 count cells of the LDS accumulator: 4 B * (32256 + 4) + 32 KiB selection scratch + statics <= 160 KiB
 constexpr int MAX_TILE_F64 = 16128;  // float64 cells (real-valued data): 8 B * (16128 + 4) + 32 KiB
+constexpr int NORM_PAD = 1024 + 4;     // zeros behind the norm arrays: the threshold-first selection reads whole rounds of 1024 cells
 constexpr int F64_CELLS_PER_THREAD = 16;   // >= MAX_TILE_F64 / 1024 (and the 512-thread launches have <= 5116 cells)
 
 struct SimParams {
@@ -104,21 +105,28 @@ __device__ __forceinline__ float euclidean_cell(const SimParams &p, float dot, f
     return __fdiv_rn(1.f, __fadd_rn(__fadd_rn(f, p.shrink), 1e-9f));
 }
 
-// The denominator of `normalise` for the modes that divide by a per-cell quantity, evaluated with one or two fused operations: used
-// only to ORDER cells (fast_column_topk); every value that is emitted comes from `normalise` itself.
-//   dmode 0: normalize (cosine / asymmetric)  1: jaccard  2: dice  3: tversky
-struct DenomConsts {
-    float s6;        // shrink + 1e-6
-    float ncs;       // norm_c + s6
-    float tv_v;      // tversky: 1 - alpha - beta
-    float tv_c;      // tversky: alpha * norm_c + s6
+// The denominator of `normalise` in ONE form for every mode, d = a * norm_j + (c * v + b), evaluated with two fused operations: used only
+// to ORDER cells (the threshold-first selection); every value that is emitted comes from `normalise` itself.
+//   normalize (cosine, asymmetric ...)   a = norm_c   b = shrink + 1e-6             c = 0
+//   jaccard                              a = 1        b = norm_c + shrink + 1e-6    c = -1
+//   dice                                 a = 1        b = norm_c + shrink + 1e-6    c = 0
+//   tversky                              a = beta     b = alpha norm_c + shrink + 1e-6   c = 1 - alpha - beta
+//   shrink only                          a = 0        b = shrink                    c = 0
+//   none                                 a = 0        b = 1                         c = 0      (v * rcp(1) = v)
+struct DenomForm {
+    float a, b, c;
 };
-template <int DMODE>
-__device__ __forceinline__ float approx_denominator(const SimParams &p, const DenomConsts &k, float v, float norm_c, float norm_j) {
-    if (DMODE == 0) return __builtin_fmaf(norm_c, norm_j, k.s6);
-    if (DMODE == 1) return (k.ncs + norm_j) - v;
-    if (DMODE == 2) return k.ncs + norm_j;
-    return __builtin_fmaf(v, k.tv_v, __builtin_fmaf(p.tversky_beta, norm_j, k.tv_c));
+__device__ __forceinline__ DenomForm denominator_form(const SimParams &p, float norm_c) {
+    const float s6 = p.shrink + 1e-6f;
+    if (p.normalize) return {norm_c, s6, 0.f};
+    if (p.kind == MI355REC_SIM_JACCARD) return {1.f, norm_c + s6, -1.f};
+    if (p.kind == MI355REC_SIM_DICE) return {1.f, norm_c + s6, 0.f};
+    if (p.kind == MI355REC_SIM_TVERSKY) return {p.tversky_beta, __builtin_fmaf(p.tversky_alpha, norm_c, s6), 1.f - p.tversky_alpha - p.tversky_beta};
+    if (p.shrink != 0.f) return {0.f, p.shrink, 0.f};
+    return {0.f, 1.f, 0.f};
+}
+__device__ __forceinline__ float approx_denominator(const DenomForm &f, float v, float norm_j) {
+    return __builtin_fmaf(f.a, norm_j, __builtin_fmaf(f.c, v, f.b));
 }
 
 // float64 -> int64 by the "magic number" addition: for |x| < 2^51, bits(x + 1.5 * 2^52) - bits(1.5 * 2^52) = round-to-nearest-even(x)
@@ -437,7 +445,12 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             if (CELL32) acc[c - tile_base] = 0.f;
             else acc_d[c - tile_base] = 0.0;
         }
-        if (CELL32 && p.fast_topk && tid < 256) aux[tid] = 0u;      // the histogram of block_kth_largest_prefix16 (the wavefront tables are dead)
+        if (CELL32 && p.fast_topk) {
+            // the histogram of block_kth_largest_prefix16 (256 words; the wavefront tables are dead) and, with the spare cells (they
+            // absorbed the padding entries), the zeros the last round of the selection's scans reads behind the tile
+            for (int w = tid; w < 1024; w += THREADS) aux[w] = 0u;
+            if (tid < 4) acc[p.n_cols_pad + tid] = 0.f;
+        }
         __syncthreads();
 
         // ---- threshold-first top-K (4-byte cells, one tile, topK > 0, a positive denominator) ----
@@ -451,97 +464,82 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         // passes -- ties included; (C) the survivors (~1.05 K) are divided exactly (`normalise`, the same instructions as below),
         // ranked by (value, lowest index first) and the first K emitted.  The result is identical to the full path's, bit for bit
         // (tests/test_sim_gpu.py::test_fast_topk_equals_full_selection).  Fewer than K positive thread maxima (sparse columns) or
-        // more survivors than the candidate buffer holds (masses of equal values): the full path runs, the accumulator is untouched.
+        // more survivors than the candidate buffer holds (2 048: masses of equal values): the full path runs, the accumulator is untouched.
         if (CELL32 && p.fast_topk) {
             const bool asym = p.normalize && p.kind == MI355REC_SIM_ASYMMETRIC;
             const float norm_c = asym ? p.norm_alpha[c] : p.norm[c];
             const float4 *nj4 = reinterpret_cast<const float4 *>(asym ? p.norm_1ma : p.norm);
             const uint32_t K = (uint32_t)p.topK;
-            // 0-3: approx_denominator; 4: / shrink; 5: the sums themselves
-            const int dmode = p.normalize ? 0 : p.kind == MI355REC_SIM_JACCARD ? 1 : p.kind == MI355REC_SIM_DICE ? 2
-                              : p.kind == MI355REC_SIM_TVERSKY ? 3 : p.shrink != 0.f ? 4 : 5;
-            auto with_mode = [&](auto &&f) {
-                switch (dmode) {
-                    case 0: f(std::integral_constant<int, 0>{}); break;
-                    case 1: f(std::integral_constant<int, 1>{}); break;
-                    case 2: f(std::integral_constant<int, 2>{}); break;
-                    case 3: f(std::integral_constant<int, 3>{}); break;
-                    case 4: f(std::integral_constant<int, 4>{}); break;
-                    default: f(std::integral_constant<int, 5>{}); break;
-                }
-            };
-            constexpr int NPF = 8;                          // MAX_TILE / 4 / 1024 (512-thread tiles are narrower)
-            constexpr int CAND_MAX = AUX_WORDS / 2;
-            const int n_quads = p.n_cols_pad / 4, n_quads_valid = (n_tile + 3) >> 2;
-            float4 npf[NPF];
-#pragma unroll
-            for (int i = 0; i < NPF; ++i) {
-                const int w = tid + i * THREADS;
-                npf[i] = nj4[w < n_quads_valid ? w : 0];
-            }
-            DenomConsts k;
-            k.s6 = p.shrink + 1e-6f;
-            k.ncs = norm_c + k.s6;
-            k.tv_v = 1.f - p.tversky_alpha - p.tversky_beta;
-            k.tv_c = __builtin_fmaf(p.tversky_alpha, norm_c, k.s6);
+            // Thread t owns the cells t, t + THREADS, t + 2 THREADS, ...: neighbouring ids -- whose values are often neighbours too
+            // (ids ordered by popularity or by age) -- sit in different threads, so a run of large cells is a run of large thread maxima.
+            // (With four adjacent cells per thread the bound was loose: 262 survivors per column for K = 100.)  Cells and norms are
+            // fetched in rounds of THREADS: ds_read_b32 at one address register + a constant offset; the norms with buffer loads (one
+            // offset register, the round in the scalar offset, zeros beyond the array) -- nothing per cell is kept between the two
+            // scans: 32 norms per thread do not fit next to the kernel's state in the 128 registers of a 1024-thread workgroup (they
+            // went to scratch and came back one dependent reload per cell).  The round that straddles the end of the tile reads the
+            // spare cells and the first words of the selection scratch: all zero (cleared above; the histogram is zero again when
+            // block_kth_largest_prefix16 returns), and a zero cell neither raises a maximum nor passes the bar.
+            constexpr int CPT = (MAX_TILE + 1023) / 1024;      // rounds (512-thread tiles are narrower than half of MAX_TILE)
+            constexpr int CAND_MAX = AUX_WORDS / 4;            // survivors: ids in the upper half of the scratch, (value, id) pairs in the lower half
+            const float *nj = reinterpret_cast<const float *>(nj4);
+            const __amdgpu_buffer_rsrc_t nj_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(nj), 0, n_tile * 4, 0x00020000);
+            int tid_o = tid;                                   // (opaque: or the 32 addresses are computed before the persistent loop and parked in scratch)
+            asm volatile("" : "+v"(tid_o));
+            const unsigned *own = reinterpret_cast<const unsigned *>(acc) + tid_o;
+            const int n_rounds = (p.n_cols_pad + THREADS - 1) / THREADS;
+            const DenomForm form = denominator_form(p, norm_c);
             auto cell_value = [&](unsigned q) { return UNIT ? (float)q : (float)(int)q * p.int_inv; };
-            const uint4 *acc4 = reinterpret_cast<const uint4 *>(acc);
+            constexpr int BATCH = 8;
             // (A) thread maxima of the approximate values
             float m = 0.f;
-            with_mode([&](auto dm) {
-                constexpr int DM = decltype(dm)::value;
-                const float uniform_scale = DM == 4 ? 1.f / p.shrink : 1.f;
 #pragma unroll
-                for (int i = 0; i < NPF; ++i) {
-                    const int w = tid + i * THREADS;
-                    if (w < n_quads) {
-                        const uint4 qu = acc4[w];
-                        const float vv[4] = {cell_value(qu.x), cell_value(qu.y), cell_value(qu.z), cell_value(qu.w)};
-                        const float nn[4] = {npf[i].x, npf[i].y, npf[i].z, npf[i].w};
+            for (int b = 0; b < CPT; b += BATCH) {
+                if (b >= n_rounds) break;                              // (block-uniform)
+                float nrm[BATCH];
+                unsigned cnt[BATCH];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float q = DM <= 3 ? vv[e] * __builtin_amdgcn_rcpf(approx_denominator<DM>(p, k, vv[e], norm_c, nn[e]))
-                                                    : vv[e] * uniform_scale;
-                            m = fmaxf(m, q);
-                        }
-                    }
+                for (int i = 0; i < BATCH; ++i) {
+                    nrm[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(nj_rsrc, tid_o * 4, (b + i) * THREADS * 4, 0));
+                    cnt[i] = own[(b + i) * THREADS];
                 }
-            });
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    const float v = cell_value(cnt[i]);
+                    m = fmaxf(m, v * __builtin_amdgcn_rcpf(approx_denominator(form, v, nrm[i])));
+                }
+            }
             const uint32_t p16 = block_kth_largest_prefix16<THREADS>(float_key(m), K, aux, sc);
             mark(3);
             bool done = p16 > (ZERO_KEY >> 16);                    // else: fewer than K threads hold a positive cell
             if (done) {
                 if (tid == 0 && tile == 0) request_next();
                 const float Tf = key_float(p16 << 16) * 0.99999809265136719f;        // 1 - 2^-19
-                // (B) cells that can reach the top K -> exact value -> candidate list
+                // (B) cells that can reach the top K -> list of cell ids (upper half of the scratch; the candidates go to the lower half)
                 uint64_t *cand = reinterpret_cast<uint64_t *>(aux);
+                uint32_t *survivor = aux + AUX_WORDS / 2;
                 if (tid == 0) sc.out_count = 0;
-                uint32_t mine = 0;          // bit 4 i + e: cell e of this thread's quad i passes
-                with_mode([&](auto dm) {
-                    constexpr int DM = decltype(dm)::value;
+                uint32_t mine = 0;          // bit i: this thread's cell i passes
 #pragma unroll
-                    for (int i = 0; i < NPF; ++i) {
-                        const int w = tid + i * THREADS;
-                        if (w < n_quads) {
-                            const uint4 qu = acc4[w];
-                            const float vv[4] = {cell_value(qu.x), cell_value(qu.y), cell_value(qu.z), cell_value(qu.w)};
-                            const float nn[4] = {npf[i].x, npf[i].y, npf[i].z, npf[i].w};
+                for (int b = 0; b < CPT; b += BATCH) {
+                    if (b >= n_rounds) break;
+                    float nrm[BATCH];
+                    unsigned cnt[BATCH];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float bar = DM <= 3 ? Tf * approx_denominator<DM>(p, k, vv[e], norm_c, nn[e]) : (DM == 4 ? Tf * p.shrink : Tf);
-                                mine |= (uint32_t)(vv[e] >= bar) << (4 * i + e);
-                            }
-                        }
+                    for (int i = 0; i < BATCH; ++i) {
+                        nrm[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(nj_rsrc, tid_o * 4, (b + i) * THREADS * 4, 0));
+                        cnt[i] = own[(b + i) * THREADS];
                     }
-                });
-                // (C) the survivors (a few per wavefront): exact value, candidate list
-                while (mine) {
-                    const int b = __ffs((int)mine) - 1;
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i) {
+                        const float v = cell_value(cnt[i]);
+                        mine |= (uint32_t)(v >= Tf * approx_denominator(form, v, nrm[i])) << (b + i);        // (Tf and the denominators are positive: a zero cell never passes)
+                    }
+                }
+                while (mine) {              // (a few lanes per wavefront)
+                    const int i = __ffs((int)mine) - 1;
                     mine &= mine - 1u;
-                    const int j = 4 * (tid + (b >> 2) * THREADS) + (b & 3);
-                    const float x = normalise(p, cell_value(reinterpret_cast<const unsigned *>(acc)[j]), norm_c, reinterpret_cast<const float *>(nj4)[j]);
                     const uint32_t at = atomicAdd(&s_ncand, 1u);
-                    if (at < (uint32_t)CAND_MAX) cand[at] = ((uint64_t)float_key(x) << 32) | (uint32_t)(~(uint32_t)j);
+                    if (at < (uint32_t)CAND_MAX) survivor[at] = (uint32_t)(tid_o + i * THREADS);
                 }
                 __syncthreads();
                 const uint32_t n_cand = s_ncand;
@@ -555,7 +553,13 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                         atomicAdd(&p.fast_stats[0], 1ull);
                         atomicAdd(&p.fast_stats[1], (unsigned long long)n_cand);
                     }
-                    // rank, emit
+                    // (C) the survivors' exact values (one survivor per thread, in place), rank, emit
+                    for (uint32_t t = tid; t < n_cand; t += THREADS) {
+                        const uint32_t j = survivor[t];
+                        const float x = normalise(p, cell_value(acc_u[j]), norm_c, nj[j]);
+                        cand[t] = ((uint64_t)float_key(x) << 32) | (uint32_t)(~j);
+                    }
+                    __syncthreads();
                     block_rank_emit<THREADS>(cand, (int)n_cand, p.topK, K, 0u, sc, p.out_idx + out_base, p.out_val + out_base);
                 }
             }
@@ -1811,12 +1815,12 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         else
             hipLaunchKernelGGL(column_sumsq_f32_kernel, dim3(div_up(n_cols, 64)), dim3(64), 0, s, h->csc_ptr.ptr, h->csc_val.ptr, n_cols,
                                cfg->norm_sum_order, sumsq.ptr);
-        h->norm.alloc_zero((size_t)n_cols + 4, s);
+        h->norm.alloc_zero((size_t)n_cols + NORM_PAD, s);
         const bool asym = cfg->similarity == MI355REC_SIM_ASYMMETRIC;
-        if (euclid) h->norm_alpha.alloc_zero((size_t)n_cols + 4, s);     // sums of squares
+        if (euclid) h->norm_alpha.alloc_zero((size_t)n_cols + NORM_PAD, s);     // sums of squares
         if (asym) {
-            h->norm_alpha.alloc_zero((size_t)n_cols + 4, s);
-            h->norm_1ma.alloc_zero((size_t)n_cols + 4, s);
+            h->norm_alpha.alloc_zero((size_t)n_cols + NORM_PAD, s);
+            h->norm_1ma.alloc_zero((size_t)n_cols + NORM_PAD, s);
         }
         hipLaunchKernelGGL(norms_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, s, sumsq.ptr, n_cols, (int)set_based,
                            (int)asym, (int)euclid, cfg->asymmetric_alpha, h->norm.ptr, h->norm_alpha.ptr, h->norm_1ma.ptr);

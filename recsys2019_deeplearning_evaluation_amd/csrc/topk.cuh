@@ -162,8 +162,10 @@ __device__ void block_rank_emit(uint64_t *cand, int ncand, int topK, uint32_t K,
             const bool live = c < ncand;
             const uint64_t mine = live ? cand[c] : 0ull;
             int r = 0;
-            if (live)
+            if (live) {
+#pragma unroll 8
                 for (int i = part; i < ncand; i += G) r += cand[i] > mine;
+            }
             for (int off = 1; off < G; off <<= 1) r += __shfl_xor(r, off);
             if (live && part == 0) emitted += emit(mine, r);
         }
