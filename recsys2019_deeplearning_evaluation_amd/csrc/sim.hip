@@ -485,29 +485,32 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             const __amdgpu_buffer_rsrc_t nj_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(nj), 0, n_tile * 4, 0x00020000);
             int tid_o = tid;                                   // (opaque: or the 32 addresses are computed before the persistent loop and parked in scratch)
             asm volatile("" : "+v"(tid_o));
-            const unsigned *own = reinterpret_cast<const unsigned *>(acc) + tid_o;
             const int n_rounds = (p.n_cols_pad + THREADS - 1) / THREADS;
             const DenomForm form = denominator_form(p, norm_c);
             auto cell_value = [&](unsigned q) { return UNIT ? (float)q : (float)(int)q * p.int_inv; };
             constexpr int BATCH = 8;
+            // one batch of rounds: BATCH norms and BATCH cells requested together, then handed to `use(round, value, norm)`.  Rounds behind
+            // the tile (the batch is not cut short) and the lanes of the last round that lie behind it read the first spare cell: zero.
+            const unsigned cell_at = (unsigned)tid_o * 4u, cell_end = (unsigned)p.n_cols_pad * 4u;      // byte offsets into the accumulator
+            auto scan_cells = [&](auto &&use) {
+#pragma unroll
+                for (int b = 0; b < CPT; b += BATCH) {
+                    if (b >= n_rounds) break;                              // (block-uniform)
+                    float nrm[BATCH];
+                    unsigned cnt[BATCH];
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i) {
+                        nrm[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(nj_rsrc, tid_o * 4, (b + i) * THREADS * 4, 0));
+                        cnt[i] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(acc) + min(cell_at + (unsigned)(b + i) * (THREADS * 4u), cell_end));
+                    }
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i) use(b + i, cell_value(cnt[i]), nrm[i]);
+                }
+            };
             // (A) thread maxima of the approximate values
             float m = 0.f;
-#pragma unroll
-            for (int b = 0; b < CPT; b += BATCH) {
-                if (b >= n_rounds) break;                              // (block-uniform)
-                float nrm[BATCH];
-                unsigned cnt[BATCH];
-#pragma unroll
-                for (int i = 0; i < BATCH; ++i) {
-                    nrm[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(nj_rsrc, tid_o * 4, (b + i) * THREADS * 4, 0));
-                    cnt[i] = own[(b + i) * THREADS];
-                }
-#pragma unroll
-                for (int i = 0; i < BATCH; ++i) {
-                    const float v = cell_value(cnt[i]);
-                    m = fmaxf(m, v * __builtin_amdgcn_rcpf(approx_denominator(form, v, nrm[i])));
-                }
-            }
+            scan_cells([&](int, float v, float norm_j) { m = fmaxf(m, v * __builtin_amdgcn_rcpf(approx_denominator(form, v, norm_j))); });
+            mark(5);
             const uint32_t p16 = block_kth_largest_prefix16<THREADS>(float_key(m), K, aux, sc);
             mark(3);
             bool done = p16 > (ZERO_KEY >> 16);                    // else: fewer than K threads hold a positive cell
@@ -519,22 +522,9 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                 uint32_t *survivor = aux + AUX_WORDS / 2;
                 if (tid == 0) sc.out_count = 0;
                 uint32_t mine = 0;          // bit i: this thread's cell i passes
-#pragma unroll
-                for (int b = 0; b < CPT; b += BATCH) {
-                    if (b >= n_rounds) break;
-                    float nrm[BATCH];
-                    unsigned cnt[BATCH];
-#pragma unroll
-                    for (int i = 0; i < BATCH; ++i) {
-                        nrm[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(nj_rsrc, tid_o * 4, (b + i) * THREADS * 4, 0));
-                        cnt[i] = own[(b + i) * THREADS];
-                    }
-#pragma unroll
-                    for (int i = 0; i < BATCH; ++i) {
-                        const float v = cell_value(cnt[i]);
-                        mine |= (uint32_t)(v >= Tf * approx_denominator(form, v, nrm[i])) << (b + i);        // (Tf and the denominators are positive: a zero cell never passes)
-                    }
-                }
+                scan_cells([&](int round, float v, float norm_j) {
+                    mine |= (uint32_t)(v >= Tf * approx_denominator(form, v, norm_j)) << round;       // (Tf and the denominators are positive: a zero cell never passes)
+                });
                 while (mine) {              // (a few lanes per wavefront)
                     const int i = __ffs((int)mine) - 1;
                     mine &= mine - 1u;
@@ -542,11 +532,13 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                     if (at < (uint32_t)CAND_MAX) survivor[at] = (uint32_t)(tid_o + i * THREADS);
                 }
                 __syncthreads();
+                mark(6);
                 const uint32_t n_cand = s_ncand;
                 if (n_cand > (uint32_t)CAND_MAX || n_cand < K) {         // (n_cand < K cannot happen: at least K cells passed (A)'s bar)
                     __syncthreads();
                     if (tid == 0) s_ncand = 0;
                     if (p.fast_stats && tid == 0) atomicAdd(&p.fast_stats[2], 1ull);
+                    if (p.fast_stats && tid == 0 && n_cand > (uint32_t)CAND_MAX) atomicAdd(&p.fast_stats[3], 1ull);
                     done = false;
                 } else {
                     if (p.fast_stats && tid == 0) {
@@ -1980,8 +1972,10 @@ extern "C" int mi355rec_sim_compute(mi355rec_sim_t h, int32_t start_col, int32_t
             h->selection_counts.download(t + 8, 4, h->stream);
             MI_HIP(hipStreamSynchronize(h->stream));
             fprintf(stderr, "[mi355rec sim phases, workgroup-ms] fetch+clear %.2f  accumulate %.2f  split-merge %.2f  normalise %.2f  topk %.2f  (kernel %.3f ms)"
-                            "  threshold-first columns %llu (candidates %.1f per column), full-selection fall-backs after the scan %llu\n",
-                    t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, h->stats.kernel_ms, t[8], t[8] ? (double)t[9] / (double)t[8] : 0.0, t[10]);
+                            "  threshold-first: maxima scan %.2f  (K-th maximum under `normalise`)  survivor scan %.2f  (exact values + rank + emit under `topk`)"
+                            "  columns %llu (candidates %.1f per column), full-selection fall-backs after the scan %llu (%llu: buffer full)\n",
+                    t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, h->stats.kernel_ms, t[5] * 1e-5, t[6] * 1e-5, t[8],
+                    t[8] ? (double)t[9] / (double)t[8] : 0.0, t[10], t[11]);
         }
     });
 }
