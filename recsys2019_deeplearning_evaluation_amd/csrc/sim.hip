@@ -464,7 +464,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         // passes -- ties included; (C) the survivors (~1.05 K) are divided exactly (`normalise`, the same instructions as below),
         // ranked by (value, lowest index first) and the first K emitted.  The result is identical to the full path's, bit for bit
         // (tests/test_sim_gpu.py::test_fast_topk_equals_full_selection).  Fewer than K positive thread maxima (sparse columns) or
-        // more survivors than the candidate buffer holds (2 048: masses of equal values): the full path runs, the accumulator is untouched.
+        // more survivors than the candidate buffer holds (4 096: masses of equal values): the full path runs, the accumulator is untouched.
         if (CELL32 && p.fast_topk) {
             const bool asym = p.normalize && p.kind == MI355REC_SIM_ASYMMETRIC;
             const float norm_c = asym ? p.norm_alpha[c] : p.norm[c];
@@ -480,7 +480,8 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             // spare cells and the first words of the selection scratch: all zero (cleared above; the histogram is zero again when
             // block_kth_largest_prefix16 returns), and a zero cell neither raises a maximum nor passes the bar.
             constexpr int CPT = (MAX_TILE + 1023) / 1024;      // rounds (512-thread tiles are narrower than half of MAX_TILE)
-            constexpr int CAND_MAX = AUX_WORDS / 4;            // survivors: ids in the upper half of the scratch, (value, id) pairs in the lower half
+            constexpr int CAND_MAX = AUX_WORDS / 2;            // 8-byte entries: (norm, id) of a survivor, then its (value key, ~id)
+            constexpr int BATCH = 8;
             const float *nj = reinterpret_cast<const float *>(nj4);
             const __amdgpu_buffer_rsrc_t nj_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(nj), 0, n_tile * 4, 0x00020000);
             int tid_o = tid;                                   // (opaque: or the 32 addresses are computed before the persistent loop and parked in scratch)
@@ -488,23 +489,29 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             const int n_rounds = (p.n_cols_pad + THREADS - 1) / THREADS;
             const DenomForm form = denominator_form(p, norm_c);
             auto cell_value = [&](unsigned q) { return UNIT ? (float)q : (float)(int)q * p.int_inv; };
-            constexpr int BATCH = 8;
-            // one batch of rounds: BATCH norms and BATCH cells requested together, then handed to `use(round, value, norm)`.  Rounds behind
-            // the tile (the batch is not cut short) and the lanes of the last round that lie behind it read the first spare cell: zero.
+            // one batch of rounds: BATCH cells, and the norms of the NEXT batch requested before the current one is worked on (an L2 round
+            // trip per batch otherwise: four of them were most of a scan), then `use(round, value, norm)`.  Rounds behind the tile (a
+            // batch is not cut short) and the lanes of the last round that lie behind it read the first spare cell: zero.
             const unsigned cell_at = (unsigned)tid_o * 4u, cell_end = (unsigned)p.n_cols_pad * 4u;      // byte offsets into the accumulator
-            auto scan_cells = [&](auto &&use) {
+            auto request_norms = [&](int b, float (&dst)[BATCH]) {
 #pragma unroll
-                for (int b = 0; b < CPT; b += BATCH) {
+                for (int i = 0; i < BATCH; ++i)
+                    dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(nj_rsrc, tid_o * 4, (b + i) * THREADS * 4, 0));
+            };
+            auto scan_cells = [&](auto &&use) {
+                float nrm[2][BATCH];
+                request_norms(0, nrm[0]);
+#pragma unroll
+                for (int bi = 0; bi < CPT / BATCH; ++bi) {
+                    const int b = bi * BATCH;
                     if (b >= n_rounds) break;                              // (block-uniform)
-                    float nrm[BATCH];
+                    if (b + BATCH < n_rounds) request_norms(b + BATCH, nrm[(bi + 1) & 1]);
                     unsigned cnt[BATCH];
 #pragma unroll
-                    for (int i = 0; i < BATCH; ++i) {
-                        nrm[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(nj_rsrc, tid_o * 4, (b + i) * THREADS * 4, 0));
+                    for (int i = 0; i < BATCH; ++i)
                         cnt[i] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(acc) + min(cell_at + (unsigned)(b + i) * (THREADS * 4u), cell_end));
-                    }
 #pragma unroll
-                    for (int i = 0; i < BATCH; ++i) use(b + i, cell_value(cnt[i]), nrm[i]);
+                    for (int i = 0; i < BATCH; ++i) use(b + i, cell_value(cnt[i]), nrm[bi & 1][i]);
                 }
             };
             // (A) thread maxima of the approximate values
@@ -517,20 +524,15 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             if (done) {
                 if (tid == 0 && tile == 0) request_next();
                 const float Tf = key_float(p16 << 16) * 0.99999809265136719f;        // 1 - 2^-19
-                // (B) cells that can reach the top K -> list of cell ids (upper half of the scratch; the candidates go to the lower half)
+                // (B) cells that can reach the top K -> list of (neighbour norm, cell id)
                 uint64_t *cand = reinterpret_cast<uint64_t *>(aux);
-                uint32_t *survivor = aux + AUX_WORDS / 2;
                 if (tid == 0) sc.out_count = 0;
-                uint32_t mine = 0;          // bit i: this thread's cell i passes
                 scan_cells([&](int round, float v, float norm_j) {
-                    mine |= (uint32_t)(v >= Tf * approx_denominator(form, v, norm_j)) << round;       // (Tf and the denominators are positive: a zero cell never passes)
+                    if (v >= Tf * approx_denominator(form, v, norm_j)) {          // (Tf and the denominators are positive: a zero cell never passes)
+                        const uint32_t at = atomicAdd(&s_ncand, 1u);
+                        if (at < (uint32_t)CAND_MAX) cand[at] = ((uint64_t)__float_as_uint(norm_j) << 32) | (uint32_t)(tid_o + round * THREADS);
+                    }
                 });
-                while (mine) {              // (a few lanes per wavefront)
-                    const int i = __ffs((int)mine) - 1;
-                    mine &= mine - 1u;
-                    const uint32_t at = atomicAdd(&s_ncand, 1u);
-                    if (at < (uint32_t)CAND_MAX) survivor[at] = (uint32_t)(tid_o + i * THREADS);
-                }
                 __syncthreads();
                 mark(6);
                 const uint32_t n_cand = s_ncand;
@@ -547,8 +549,9 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                     }
                     // (C) the survivors' exact values (one survivor per thread, in place), rank, emit
                     for (uint32_t t = tid; t < n_cand; t += THREADS) {
-                        const uint32_t j = survivor[t];
-                        const float x = normalise(p, cell_value(acc_u[j]), norm_c, nj[j]);
+                        const uint64_t e = cand[t];
+                        const uint32_t j = (uint32_t)e;
+                        const float x = normalise(p, cell_value(acc_u[j]), norm_c, __uint_as_float((uint32_t)(e >> 32)));
                         cand[t] = ((uint64_t)float_key(x) << 32) | (uint32_t)(~j);
                     }
                     __syncthreads();
