@@ -864,6 +864,19 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
     sim = Compute_Similarity_MI355X(urm, topK=TOPK, shrink=0, normalize=True, similarity="cosine")
     sim.synchronize()
     create_s = time.perf_counter() - t_c
+    # the same constructor from a URM that is already in HBM (uploaded once per search, ResidentURM): the `fit` of the bench
+    # contract (inputs resident when the timed region starts); the PCIe-inclusive figure stays next to it
+    from recsys2019_deeplearning_evaluation_amd import ResidentURM
+    resident = ResidentURM(urm)
+    create_resident_s = None
+    for _ in range(3):
+        sim.close()
+        t_c = time.perf_counter()
+        sim = Compute_Similarity_MI355X(urm, topK=TOPK, shrink=0, normalize=True, similarity="cosine", resident=resident)
+        sim.synchronize()
+        dt = time.perf_counter() - t_c
+        create_resident_s = dt if create_resident_s is None else min(create_resident_s, dt)
+    resident.close()
     costs = sim.column_costs()
     job = ShardedSimilarityBuild(sim, net.dist, rank, world, net.comm)       # partition + buffers once, outside the timed region
     my_columns = job.columns[rank]
@@ -886,7 +899,9 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
     block = {
         "cosine_build_s": best, "definition": "kernel on this rank's columns (interleaved partition: equal counts, equal cost) + one "
                                               "all-gather; full (n_cols x topK) result resident on every rank's device (max over ranks, best of 3)",
-        "create_s": create_s, "fit_s": create_s + best, "download_to_host_rank0_s": download_s,
+        "create_s": create_resident_s, "fit_s": create_resident_s + best,
+        "fit_definition": "constructor from the device-resident URM (ResidentURM: uploaded once per search) + build; Python host code included",
+        "create_incl_pcie_upload_s": create_s, "fit_incl_pcie_upload_s": create_s + best, "download_to_host_rank0_s": download_s,
         "topK": TOPK, "columns_this_rank": int(len(my_columns)), "kernel_ms_this_rank": kernel_ms,
         "exchange_bytes_per_rank": job.exchange_bytes_per_rank(),
         "transport": "none" if world == 1 else ("rccl-ctypes" if net.comm is not None else "torch." + net.dist.get_backend()),
@@ -962,7 +977,8 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
     block["shape"] = "%dx%d nnz=%d" % (urm.shape[0], urm.shape[1], urm.nnz)
     extra[key] = block
     if key == "itemknn":     # flat aliases kept for continuity with round 1's line
-        extra.update({"itemknn_cosine_build_s": best, "itemknn_create_s": create_s, "itemknn_fit_s": create_s + best,
+        extra.update({"itemknn_cosine_build_s": best, "itemknn_create_s": create_resident_s, "itemknn_fit_s": create_resident_s + best,
+                      "itemknn_fit_incl_pcie_upload_s": create_s + best,
                       "itemknn_kernel_ms_this_rank": kernel_ms, "itemknn_frac_of_lds_atomic_peak": pair_rate / LDS_ATOMIC_PEAK})
     return costs
 
@@ -1103,7 +1119,8 @@ def main():
             table[name].update({"cpu_reference_fixture_value": fx.get("value"), "cpu_reference_fixture_kind": fx.get("kind")})
     if "itemknn" in out["extra"]:
         ik = out["extra"]["itemknn"]
-        table["itemknn_cosine_top100"] = {"value": ik.get("fit_s"), "unit": "s (constructor incl. PCIe upload + build)", "build_s": ik.get("cosine_build_s"),
+        table["itemknn_cosine_top100"] = {"value": ik.get("fit_s"), "unit": "s (constructor from the HBM-resident URM + build)", "build_s": ik.get("cosine_build_s"),
+                                          "fit_incl_pcie_upload_s": ik.get("fit_incl_pcie_upload_s"),
                                           "bound": "lds-atomics", "frac": ik.get("roofline", {}).get("frac"),
                                           "cpu_value": (ik.get("cpu_baseline") or {}).get("value"), "cpu_kind": (ik.get("cpu_baseline") or {}).get("kind")}
     out["paths"] = table

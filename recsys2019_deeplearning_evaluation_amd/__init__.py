@@ -5,6 +5,7 @@ Hot path only: Compute_Similarity (ItemKNN build), BPR-MF 
 IALS solve step.  Python host code + ctypes C-ABI (include/mi355rec.h) + hand-written HIP kernels (csrc/).
 Nothing here imports torch; torch.distributed is only used by `sharding` for the multi-GPU gather.
 """
+from ._native import ResidentURM  # noqa: F401
 from .similarity import Compute_Similarity, Compute_Similarity_MI355X, Compute_Similarity_Euclidean_MI355X  # noqa: F401
 from .knn import ItemKNNCFRecommender, UserKNNCFRecommender  # noqa: F401
 from .matrix_factorization import (MatrixFactorization_MI355X_Epoch, MatrixFactorization_BPR_MI355X,  # noqa: F401
@@ -17,5 +18,5 @@ from .graph_based import P3alphaRecommender, RP3betaRecommender  # noqa: F401,E4
 from .ease_r import EASE_R_Recommender  # noqa: F401,E402
 from .ials import IALS_MI355X_Epoch, IALSRecommender  # noqa: F401,E402
 
-__all__ = ["EASE_R_Recommender", "P3alphaRecommender", "RP3betaRecommender", "MI355XScorer", "MI355XSparseScorer", "GpuScoringMixin", "GpuSimilarityScoringMixin", "SLIM_BPR_MI355X_Epoch", "SLIM_BPR_MI355X", "IALS_MI355X_Epoch", "IALSRecommender", "Compute_Similarity", "Compute_Similarity_MI355X", "Compute_Similarity_Euclidean_MI355X", "ItemKNNCFRecommender", "UserKNNCFRecommender",
+__all__ = ["ResidentURM", "EASE_R_Recommender", "P3alphaRecommender", "RP3betaRecommender", "MI355XScorer", "MI355XSparseScorer", "GpuScoringMixin", "GpuSimilarityScoringMixin", "SLIM_BPR_MI355X_Epoch", "SLIM_BPR_MI355X", "IALS_MI355X_Epoch", "IALSRecommender", "Compute_Similarity", "Compute_Similarity_MI355X", "Compute_Similarity_Euclidean_MI355X", "ItemKNNCFRecommender", "UserKNNCFRecommender",
            "MatrixFactorization_MI355X_Epoch", "MatrixFactorization_MI355X_Group", "MatrixFactorization_BPR_MI355X", "MatrixFactorization_FunkSVD_MI355X", "MatrixFactorization_AsySVD_MI355X"]

@@ -76,6 +76,7 @@ SIGNATURES = {
     "mi355rec_device_memcpy": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int]),
     "mi355rec_device_synchronize": (C.c_int, []),
     "mi355rec_sim_create": (C.c_int, [C.POINTER(_vp), C.POINTER(SimConfig), _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mi355rec_sim_create_resident": (C.c_int, [C.POINTER(_vp), C.POINTER(SimConfig), _i32, _i32, _vp, _vp, _vp, _vp]),
     "mi355rec_sim_get_weighted_values": (C.c_int, [_vp, _vp]),
     "mi355rec_sim_compute_part_device": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355rec_sim_compute_part_chunk_device": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -245,3 +246,66 @@ class DeviceArray:
             self.close()
         except Exception:
             pass
+
+
+class ResidentURM:
+    """A CSR matrix (int32 structure, float32 values, sorted indices) uploaded ONCE to the calling process's GPU.  Similarity
+    builds started from it (`Compute_Similarity_MI355X(..., resident=...)`, `ItemKNNCFRecommender.fit(..., resident_urm=...)`)
+    copy the arrays at HBM speed instead of paying the PCIe upload in every fit -- the reference's hyper-parameter search runs
+    hundreds of fits on the same URM_train (ParameterTuning/SearchAbstractClass.py:253-262)."""
+
+    def __init__(self, matrix):
+        import scipy.sparse as sps
+        csr = sps.csr_matrix(matrix, dtype=np.float32)
+        if not csr.has_sorted_indices:
+            csr = csr.sorted_indices()
+        self.shape = csr.shape
+        self.nnz = int(csr.nnz)
+        self._fingerprint = self.fingerprint_of(csr)
+        self._buffers = self._buffers_of(csr)
+        self._host = csr                         # (keeps the buffers alive: their addresses identify the matrix)
+        self._full = None
+        self.indptr, self.indices, self.data = DeviceArray(len(csr.indptr)), DeviceArray(max(1, self.nnz)), DeviceArray(max(1, self.nnz))
+        lib = load()
+        for dev, host in ((self.indptr, as_i32(csr.indptr)), (self.indices, as_i32(csr.indices)), (self.data, as_f32(csr.data))):
+            if len(host):
+                check(lib.mi355rec_device_memcpy(dev.ptr, ptr(host), 4 * len(host), 1))
+
+    @staticmethod
+    def fingerprint_of(csr):
+        """Shape, nnz and a checksum of the row pointers and of a sample (every nnz / 65536-th entry) of indices and values."""
+        import zlib
+        return (csr.shape, int(csr.nnz), zlib.crc32(np.ascontiguousarray(csr.indptr, np.int32).tobytes()),
+                zlib.crc32(np.ascontiguousarray(csr.data, np.float32)[:: max(1, csr.nnz // 65536)].tobytes()),
+                zlib.crc32(np.ascontiguousarray(csr.indices, np.int32)[:: max(1, csr.nnz // 65536)].tobytes()))
+
+    @staticmethod
+    def _buffers_of(csr):
+        return tuple(a.__array_interface__["data"][0] for a in (csr.indptr, csr.indices, csr.data))
+
+    @staticmethod
+    def _full_checksum(csr):
+        import zlib
+        return (zlib.crc32(np.ascontiguousarray(csr.indices, np.int32).tobytes()), zlib.crc32(np.ascontiguousarray(csr.data, np.float32).tobytes()))
+
+    def matches(self, csr, thorough=None):
+        """Is `csr` the uploaded matrix?  Always compared: shape, nnz, every row pointer and a sample (every nnz / 65536-th entry) of
+        indices and values -- a fraction of a millisecond, enough to catch another data set, another split, a re-weighted or a
+        filtered matrix.  thorough=True (or MI355REC_RESIDENT_VERIFY=full in the environment) also compares a checksum of EVERY
+        index and value unless `csr` is made of the very buffers that were uploaded: ~0.1 s at ML-20M size, more than ten fits, so
+        it is not the default -- the caller's contract is that the resident copy is a copy of the matrix it fits on (the
+        recommenders copy URM_train in their constructor, BaseRecommender.py:29, so buffer identity cannot be the test)."""
+        import os
+        if self.fingerprint_of(csr) != self._fingerprint:
+            return False
+        if thorough is None:
+            thorough = os.environ.get("MI355REC_RESIDENT_VERIFY", "") == "full"
+        if not thorough or self._buffers_of(csr) == self._buffers:
+            return True
+        if self._full is None:
+            self._full = self._full_checksum(self._host)
+        return self._full_checksum(csr) == self._full
+
+    def close(self):
+        for a in (self.indptr, self.indices, self.data):
+            a.close()

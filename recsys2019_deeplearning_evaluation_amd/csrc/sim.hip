@@ -1590,9 +1590,10 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
 
 }  // namespace
 
-extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, int32_t n_rows, int32_t n_cols,
-                                   const int32_t *csr_indptr, const int32_t *csr_indices, const float *csr_data,
-                                   const float *row_weights) {
+// `resident`: the three CSR arrays are device memory (mi355rec_sim_create_resident) -- copied at HBM speed instead of over PCIe
+static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, int32_t n_rows, int32_t n_cols,
+                           const int32_t *csr_indptr, const int32_t *csr_indices, const float *csr_data,
+                           const float *row_weights, bool resident) {
     return guarded([&] {
         MI_REQUIRE(out && cfg && csr_indptr && csr_indices && csr_data, "NULL argument");
         MI_REQUIRE(n_rows > 0 && n_cols > 0, "empty matrix (%d x %d)", n_rows, n_cols);
@@ -1619,8 +1620,11 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         if (set_based) h->cfg.normalize = 0;  // .pyx:124-135
         h->n_rows = n_rows;
         h->n_cols = n_cols;
-        h->nnz = (size_t)csr_indptr[n_rows];
-        MI_REQUIRE(h->nnz > 0, "matrix has no stored values");
+        int32_t nnz_in = 0;
+        if (resident) MI_HIP(hipMemcpy(&nnz_in, csr_indptr + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost));
+        else nnz_in = csr_indptr[n_rows];
+        h->nnz = (size_t)nnz_in;
+        MI_REQUIRE(nnz_in > 0, "matrix has no stored values");
         MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->timer.init();
         h->call_timer.init();
@@ -1636,14 +1640,17 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
             fprintf(stderr, "[sim create] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_phase).count());
             t_phase = now;
         };
-        h->csr_ptr.upload(csr_indptr, (size_t)n_rows + 1, s);
+        // (the handle keeps its own copy either way: the values are re-weighted / centred in place and the arrays are padded)
+        const hipMemcpyKind in_kind = resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        h->csr_ptr.alloc((size_t)n_rows + 1);
+        MI_HIP(hipMemcpyAsync(h->csr_ptr.ptr, csr_indptr, ((size_t)n_rows + 1) * sizeof(int), in_kind, s));
         // padding: the column kernel reads the profiles in aligned 16-byte chunks, a whole lane group at a time
         h->csr_idx.alloc_zero(nnz + 520, s);
         h->csr_val.alloc_zero(nnz + 520, s);
-        MI_HIP(hipMemcpyAsync(h->csr_idx.ptr, csr_indices, nnz * sizeof(int), hipMemcpyHostToDevice, s));
-        MI_HIP(hipMemcpyAsync(h->csr_val.ptr, csr_data, nnz * sizeof(float), hipMemcpyHostToDevice, s));
+        MI_HIP(hipMemcpyAsync(h->csr_idx.ptr, csr_indices, nnz * sizeof(int), in_kind, s));
+        MI_HIP(hipMemcpyAsync(h->csr_val.ptr, csr_data, nnz * sizeof(float), in_kind, s));
         if (row_weights) h->row_w.upload(row_weights, n_rows, s);
-        phase("allocate + upload (PCIe)");
+        phase(resident ? "allocate + copy of the resident URM" : "allocate + upload (PCIe)");
         // CSR -> CSC (.pyx:203-207), on the device: stable radix sort of the cell positions by column; the values are gathered
         // into column order further down, after their pre-processing.  (Measured and rejected: the sort on a second stream behind the
         // upload of the values -- it needs the structure only --: the upload of pageable memory and the sort's kernels got into each
@@ -1891,6 +1898,18 @@ extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_confi
         phase("fixed-point check + cost order (host)");
         *out = h.release();
     });
+}
+
+extern "C" int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, int32_t n_rows, int32_t n_cols,
+                                   const int32_t *csr_indptr, const int32_t *csr_indices, const float *csr_data,
+                                   const float *row_weights) {
+    return sim_create_from(out, cfg, n_rows, n_cols, csr_indptr, csr_indices, csr_data, row_weights, false);
+}
+
+extern "C" int mi355rec_sim_create_resident(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, int32_t n_rows, int32_t n_cols,
+                                            const int32_t *d_csr_indptr, const int32_t *d_csr_indices, const float *d_csr_data,
+                                            const float *row_weights) {
+    return sim_create_from(out, cfg, n_rows, n_cols, d_csr_indptr, d_csr_indices, d_csr_data, row_weights, true);
 }
 
 extern "C" int mi355rec_sim_compute_device(mi355rec_sim_t h, int32_t start_col, int32_t end_col, int32_t *d_nbr_idx,

@@ -29,12 +29,17 @@ class _ItemKNNLogic(_KNNCFMixin):
     def __init__(self, URM_train, verbose=True):
         super(_ItemKNNLogic, self).__init__(URM_train, verbose=verbose)
 
-    def fit(self, topK=50, shrink=100, similarity="cosine", normalize=True, feature_weighting="none", **similarity_args):
+    def fit(self, topK=50, shrink=100, similarity="cosine", normalize=True, feature_weighting="none", resident_urm=None,
+            **similarity_args):
+        """resident_urm (not an argument of the reference): a `ResidentURM` of this URM_train, uploaded once for a whole search --
+        the build then starts from the device copy (the constructor verifies that it holds the same matrix)."""
         self.topK = topK
         self.shrink = shrink
         self._check_weighting(feature_weighting)
+        if resident_urm is not None:
+            similarity_args["resident"] = resident_urm
         # okapi_BM_25(URM.T).T / TF_IDF(URM.T).T (ItemKNNCFRecommender.py:40-48): documents = items = columns of the URM
-        builder = Compute_Similarity(self.URM_train.astype(np.float32), shrink=shrink, topK=topK, normalize=normalize,
+        builder = Compute_Similarity(self.URM_train.astype(np.float32, copy=False), shrink=shrink, topK=topK, normalize=normalize,
                                      similarity=similarity, feature_weighting=feature_weighting, weighting_documents="columns",
                                      **similarity_args)
         if feature_weighting != "none":

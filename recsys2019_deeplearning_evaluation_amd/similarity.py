@@ -37,10 +37,12 @@ class Compute_Similarity_MI355X:
     def __init__(self, dataMatrix, topK=100, shrink=0, normalize=True, asymmetric_alpha=0.5, tversky_alpha=1.0,
                  tversky_beta=1.0, similarity="cosine", row_weights=None, unit_column_side=False,
                  normalize_avg_row=False, similarity_from_distance_mode="lin", feature_weighting="none",
-                 weighting_documents="columns", K1=1.2, B=0.75):
+                 weighting_documents="columns", K1=1.2, B=0.75, resident=None):
         """feature_weighting ("none" / "BM25" / "TF-IDF"), weighting_documents ("columns" / "rows"), K1, B: the re-weighting the
         KNN recommenders apply to the matrix before the build (Base/IR_feature_weighting.py), as a device pre-pass on the
-        uploaded values; `weighted_matrix()` hands the re-weighted matrix back.  Not arguments of the reference class."""
+        uploaded values; `weighted_matrix()` hands the re-weighted matrix back.  resident: a `_native.ResidentURM` holding THIS
+        dataMatrix on the device (checked): the constructor copies it there instead of uploading it.  Not arguments of the
+        reference class."""
         if similarity not in self.SIMILARITY_VALUES and similarity != "euclidean":
             raise ValueError("Cosine_Similarity: value for parameter 'mode' not recognized."
                              " Allowed values are: 'cosine', 'pearson', 'adjusted', 'asymmetric', 'jaccard', 'tanimoto',"
@@ -78,8 +80,14 @@ class Compute_Similarity_MI355X:
         self._weighted_structure = (csr.indptr, csr.indices, csr.shape) if feature_weighting != "none" else None
         self._lib = N.load()
         self._h = C.c_void_p()
-        N.check(self._lib.mi355rec_sim_create(C.byref(self._h), C.byref(cfg), self.n_rows, self.n_columns,
-                                              N.ptr(indptr), N.ptr(indices), N.ptr(data), N.ptr(rw)))
+        if resident is not None:
+            if not resident.matches(csr):
+                raise ValueError("Compute_Similarity_MI355X: `resident` does not hold this dataMatrix (shape, nnz or contents differ)")
+            N.check(self._lib.mi355rec_sim_create_resident(C.byref(self._h), C.byref(cfg), self.n_rows, self.n_columns,
+                                                           resident.indptr.ptr, resident.indices.ptr, resident.data.ptr, N.ptr(rw)))
+        else:
+            N.check(self._lib.mi355rec_sim_create(C.byref(self._h), C.byref(cfg), self.n_rows, self.n_columns,
+                                                  N.ptr(indptr), N.ptr(indices), N.ptr(data), N.ptr(rw)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -244,6 +252,7 @@ class Compute_Similarity:
             dataMatrix = sps.csr_matrix(dataMatrix)
         if similarity == "euclidean":
             args.pop("similarity", None)
+            args.pop("resident", None)              # (the Euclidean front-end uploads its own, squared, copy)
             self.compute_similarity_object = Compute_Similarity_Euclidean_MI355X(dataMatrix, **args)
         else:
             self.compute_similarity_object = Compute_Similarity_MI355X(dataMatrix, **args)

@@ -220,3 +220,17 @@ def test_interleaved_parts_are_equal_in_count_and_cost():
     assert max(widths) > 2 * (len(cost) // 8)                       # equal-cost contiguous ranges are very unequal in width
     # ties in the cost keep the column order (stable), as the device's cost order does
     np.testing.assert_array_equal(interleaved_parts(np.ones(10, np.int64), 2)[0], [0, 3, 4, 7, 8])
+
+
+def test_resident_urm_fingerprint_tells_matrices_apart():
+    """ResidentURM.matches (the check behind `resident=`): same matrix -> same fingerprint; a changed value, index or shape -> not."""
+    from recsys2019_deeplearning_evaluation_amd._native import ResidentURM
+    from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
+    X = named_urm("ml1m", "real", scale=0.2)
+    f = ResidentURM.fingerprint_of(X)
+    assert ResidentURM.fingerprint_of(X.copy()) == f
+    Y = X.copy(); Y.data[0] += 1.0
+    assert ResidentURM.fingerprint_of(Y) != f
+    Z = X.copy(); Z.indices[0], Z.indices[1] = Z.indices[1], Z.indices[0]
+    assert ResidentURM.fingerprint_of(Z) != f
+    assert ResidentURM.fingerprint_of(X[:-1]) != f

@@ -715,3 +715,31 @@ def test_threshold_first_topk_falls_back_on_masses_of_equal_values(gpu, monkeypa
     np.testing.assert_array_equal(val, val0)
     assert info[2] == n_items and info[0] == 0, info
     assert (idx[5] == [0, 1, 2, 3, 4, 6, 7, 8, 9, 10]).all()
+
+
+def test_resident_urm_build_equals_host_build(gpu):
+    """mi355rec_sim_create_resident: the constructor that copies a URM already in HBM gives the same handle as the one that
+    uploads it -- identical slabs, with feature weighting too (the handle re-weights its own copy, the resident one stays as it
+    was and serves the next fit) -- and refuses a resident copy of a different matrix."""
+    from recsys2019_deeplearning_evaluation_amd import ResidentURM
+    X = named_urm("ml1m", "real", scale=0.4)
+    res = ResidentURM(X)
+    for kw in (dict(topK=20, shrink=3), dict(topK=20, shrink=3, feature_weighting="BM25"), dict(topK=0, similarity="jaccard")):
+        out = []
+        for resident in (None, res):
+            dev = Compute_Similarity_MI355X(X, resident=resident, **kw)
+            out.append(dev.compute_similarity())
+            dev.close()
+        assert (out[0] != out[1]).nnz == 0 if sps.issparse(out[0]) else np.array_equal(out[0], out[1])
+    other = X.copy()
+    other.data[0] += 1.0                                    # (entry 0 is always part of the sample)
+    with pytest.raises(ValueError, match="does not hold this dataMatrix"):
+        Compute_Similarity_MI355X(other, topK=5, resident=res)
+    other = X.copy()
+    other.data[7] += 1.0                                    # not sampled: only the full comparison sees it
+    assert res.matches(other) and not res.matches(other, thorough=True) and res.matches(X.copy(), thorough=True)
+    rec, rec_res = ItemKNNCFRecommender(X, verbose=False), ItemKNNCFRecommender(X, verbose=False)
+    rec.fit(topK=10, shrink=1)
+    rec_res.fit(topK=10, shrink=1, resident_urm=res)
+    assert (rec.W_sparse != rec_res.W_sparse).nnz == 0
+    res.close()
