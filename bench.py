@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-sim", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each CPU baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the other hot paths (FunkSVD, SLIM-BPR, IALS, scoring, replicas)")
+    ap.add_argument("--no-paths", action="store_true", help="skip the other hot paths but keep the emulated 8-way ItemKNN build")
     ap.add_argument("--no-ials", action="store_true", help="skip the row-sharded IALS epoch (BASELINE config 5)")
     ap.add_argument("--no-netflix", action="store_true", help="N > 1: skip the Netflix-shape ItemKNN build (BASELINE config 4)")
     return ap.parse_args()
@@ -1087,7 +1088,7 @@ def main():
            "roofline": roofline, "extra": extra}
 
     note("ials section done")
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_paths:
         out["extra"]["paths"] = {}
         try:
             other_paths(urm, args, out["extra"]["paths"])
