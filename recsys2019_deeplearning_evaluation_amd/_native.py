@@ -273,9 +273,9 @@ class ResidentURM:
 
     @staticmethod
     def fingerprint_of(csr):
-        """Shape, nnz and a checksum of the row pointers and of a sample (every nnz / 65536-th entry) of indices and values."""
+        """Shape, nnz and a checksum of a sample of the row pointers (every 8th), indices and values (every nnz / 65536-th entry)."""
         import zlib
-        return (csr.shape, int(csr.nnz), zlib.crc32(np.ascontiguousarray(csr.indptr, np.int32).tobytes()),
+        return (csr.shape, int(csr.nnz), zlib.crc32(np.ascontiguousarray(csr.indptr, np.int32)[::8].tobytes()),
                 zlib.crc32(np.ascontiguousarray(csr.data, np.float32)[:: max(1, csr.nnz // 65536)].tobytes()),
                 zlib.crc32(np.ascontiguousarray(csr.indices, np.int32)[:: max(1, csr.nnz // 65536)].tobytes()))
 
@@ -289,7 +289,7 @@ class ResidentURM:
         return (zlib.crc32(np.ascontiguousarray(csr.indices, np.int32).tobytes()), zlib.crc32(np.ascontiguousarray(csr.data, np.float32).tobytes()))
 
     def matches(self, csr, thorough=None):
-        """Is `csr` the uploaded matrix?  Always compared: shape, nnz, every row pointer and a sample (every nnz / 65536-th entry) of
+        """Is `csr` the uploaded matrix?  Always compared: shape, nnz, every 8th row pointer and a sample (every nnz / 65536-th entry) of
         indices and values -- a fraction of a millisecond, enough to catch another data set, another split, a re-weighted or a
         filtered matrix.  thorough=True (or MI355REC_RESIDENT_VERIFY=full in the environment) also compares a checksum of EVERY
         index and value unless `csr` is made of the very buffers that were uploaded: ~0.1 s at ML-20M size, more than ten fits, so

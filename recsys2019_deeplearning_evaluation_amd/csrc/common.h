@@ -98,16 +98,37 @@ struct DeviceBuffer {
     }
 };
 
+// ---- streams and events of short-lived handles -----------------------------------------------------------------------
+// hipStreamCreate + four hipEventCreate cost 1.8 ms on MI355X / ROCm 7 -- half of a similarity constructor that starts from a
+// resident URM, and a search creates one handle per fit.  Handles take their (non-blocking) stream and their timing events from a
+// per-process pool and hand them back, drained, when they are destroyed; the pool is never torn down (the HIP runtime may be gone
+// before static destructors run).  One pool per process = per device (mi355rec_set_device binds a process to one GPU).
+hipStream_t pooled_stream();
+void pooled_stream_return(hipStream_t s);
+hipEvent_t pooled_event();
+void pooled_event_return(hipEvent_t e);
+
 // ---- event-pair timer on a stream -------------------------------------------------------------------
 struct StreamTimer {
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool pooled = false;
     void init() {
         MI_HIP(hipEventCreate(&t0));
         MI_HIP(hipEventCreate(&t1));
     }
+    void init_pooled() {
+        t0 = pooled_event();
+        t1 = pooled_event();
+        pooled = true;
+    }
     void destroy() {
-        if (t0) (void)hipEventDestroy(t0);
-        if (t1) (void)hipEventDestroy(t1);
+        if (pooled) {
+            if (t0) pooled_event_return(t0);
+            if (t1) pooled_event_return(t1);
+        } else {
+            if (t0) (void)hipEventDestroy(t0);
+            if (t1) (void)hipEventDestroy(t1);
+        }
         t0 = t1 = nullptr;
     }
     void start(hipStream_t s) { MI_HIP(hipEventRecord(t0, s)); }

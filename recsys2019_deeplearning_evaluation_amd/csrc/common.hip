@@ -133,6 +133,69 @@ void device_block_return(void *p, size_t) {
     for (void *q : drop) (void)hipFree(q);
 }
 
+namespace {
+struct HandlePool {
+    std::mutex lock;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> events;
+};
+HandlePool &handle_pool() {
+    static HandlePool *p = new HandlePool();
+    return *p;
+}
+}  // namespace
+
+hipStream_t pooled_stream() {
+    HandlePool &p = handle_pool();
+    {
+        std::lock_guard<std::mutex> g(p.lock);
+        if (!p.streams.empty()) {
+            hipStream_t s = p.streams.back();
+            p.streams.pop_back();
+            return s;
+        }
+    }
+    hipStream_t s = nullptr;
+    MI_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
+
+void pooled_stream_return(hipStream_t s) {
+    if (!s) return;
+    if (hipStreamSynchronize(s) != hipSuccess) {      // a stream that cannot be drained is not handed to anybody else
+        (void)hipGetLastError();
+        (void)hipStreamDestroy(s);
+        return;
+    }
+    HandlePool &p = handle_pool();
+    std::lock_guard<std::mutex> g(p.lock);
+    if (p.streams.size() < 64) p.streams.push_back(s);
+    else (void)hipStreamDestroy(s);
+}
+
+hipEvent_t pooled_event() {
+    HandlePool &p = handle_pool();
+    {
+        std::lock_guard<std::mutex> g(p.lock);
+        if (!p.events.empty()) {
+            hipEvent_t e = p.events.back();
+            p.events.pop_back();
+            return e;
+        }
+    }
+    hipEvent_t e = nullptr;
+    MI_HIP(hipEventCreate(&e));
+    return e;
+}
+
+void pooled_event_return(hipEvent_t e) {
+    if (!e) return;
+    HandlePool &p = handle_pool();
+    std::lock_guard<std::mutex> g(p.lock);
+    if (p.events.size() < 256) p.events.push_back(e);
+    else (void)hipEventDestroy(e);
+}
+
 }  // namespace mi355rec
 
 using namespace mi355rec;

@@ -1221,7 +1221,7 @@ struct mi355rec_sim {
         if (stream) (void)hipStreamSynchronize(stream);
         timer.destroy();
         call_timer.destroy();
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream) pooled_stream_return(stream);
     }
 };
 
@@ -1610,6 +1610,7 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
                            "%d column distances by the %d row weights: operands could not be broadcast together)", n_cols, n_rows);
         }
         MI_REQUIRE(cfg->topK >= 0, "topK must be >= 0");
+        const auto t_enter = std::chrono::steady_clock::now();
         ensure_device();
         std::unique_ptr<mi355rec_sim> h(new mi355rec_sim());
         h->cfg = *cfg;
@@ -1625,14 +1626,14 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         else nnz_in = csr_indptr[n_rows];
         h->nnz = (size_t)nnz_in;
         MI_REQUIRE(nnz_in > 0, "matrix has no stored values");
-        MI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        h->timer.init();
-        h->call_timer.init();
+        h->stream = pooled_stream();
+        h->timer.init_pooled();
+        h->call_timer.init_pooled();
         hipStream_t s = h->stream;
         const size_t nnz = h->nnz;
         // MI355REC_SIM_CREATE_PHASES=1: wall clock of the constructor's phases on stderr (each one drained before the next starts)
         const bool phases = getenv("MI355REC_SIM_CREATE_PHASES") != nullptr;
-        auto t_phase = std::chrono::steady_clock::now();
+        auto t_phase = t_enter;
         auto phase = [&](const char *what) {
             if (!phases) return;
             (void)hipStreamSynchronize(s);
@@ -1642,6 +1643,7 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         };
         // (the handle keeps its own copy either way: the values are re-weighted / centred in place and the arrays are padded)
         const hipMemcpyKind in_kind = resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        phase("device, stream, events, nnz");
         h->csr_ptr.alloc((size_t)n_rows + 1);
         MI_HIP(hipMemcpyAsync(h->csr_ptr.ptr, csr_indptr, ((size_t)n_rows + 1) * sizeof(int), in_kind, s));
         // padding: the column kernel reads the profiles in aligned 16-byte chunks, a whole lane group at a time
