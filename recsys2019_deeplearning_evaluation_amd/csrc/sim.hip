@@ -850,7 +850,7 @@ __global__ void seg_len_kernel(const int *csr_ptr, const int *row_tile_ptr, int 
 // values as they are after pre-processing; padding entries point at the 4 spare accumulator cells and carry 0.
 __global__ void seg_fill_kernel(const int *csr_ptr, const int *row_tile_ptr, const int *csr_idx, const float *csr_val,
                                 const int *seg_ptr, int n_rows, int n_tiles, int tile_w, unsigned short *seg_idx16,
-                                float *seg_val) {
+                                float *seg_val, int group_lanes) {
     const long long k = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (k >= (long long)n_rows * n_tiles) return;
@@ -864,10 +864,24 @@ __global__ void seg_fill_kernel(const int *csr_ptr, const int *row_tile_ptr, con
         b = row_tile_ptr[(size_t)u * (n_tiles + 1) + t + 1];
     }
     const int dst = seg_ptr[k], padded = seg_ptr[k + 1] - dst, len = b - a;
+    // Lane-interleaved order inside every FULL block of 8 G entries (G = lanes per profile in the column kernel, 0 = off): the
+    // kernel's lane g loads the 16-byte chunk g of a block and its e-th ds_add takes the chunk's entry e, so with the entries
+    // stored in row order one instruction carries entries g * 8 + e -- ids at stride 8 of a sorted profile, and where a long
+    // profile is dense (the popular items of a heavy user: ids nearly consecutive) that is 4 distinct LDS banks for 32 lanes.
+    // Stored as chunk g = entries {g, g + G, g + 2 G, ...}, one instruction carries G CONSECUTIVE entries of the profile: consecutive
+    // ids, distinct banks.  The kernel does not care in which order a segment's entries arrive; the tail of a segment (less than a
+    // block) stays in row order, so the chunk-granular end-of-segment test still holds.  Measured at ML-20M shape: accumulation
+    // 659 -> 640 workgroup-ms, kernel 4.02 -> 3.98 ms (the atomic unit itself, not the bank pattern, is what bounds the scatter).
+    const int block = 8 * group_lanes, n_blocked = block > 0 ? (padded / block) * block : 0;
     for (int q = lane; q < padded; q += 64) {
         const bool real = q < len;
-        seg_idx16[dst + q] = (unsigned short)(real ? csr_idx[a + q] - t * tile_w : tile_w + (q & 3));
-        seg_val[dst + q] = real ? csr_val[a + q] : 0.f;
+        int at = q;
+        if (q < n_blocked) {
+            const int k = q % block;
+            at = q - k + (k % group_lanes) * 8 + k / group_lanes;
+        }
+        seg_idx16[dst + at] = (unsigned short)(real ? csr_idx[a + q] - t * tile_w : tile_w + (q & 3));
+        seg_val[dst + at] = real ? csr_val[a + q] : 0.f;
     }
 }
 
@@ -1781,30 +1795,6 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
             hipLaunchKernelGGL(col_center_kernel, dim3(eg), dim3(eb), 0, s, h->csr_idx.ptr, h->csr_val.ptr, nnz, mean.ptr);
             hipLaunchKernelGGL(col_center_csc_kernel, dim3(cg), dim3(256), 0, s, h->csc_ptr.ptr, h->csc_val.ptr, n_cols, mean.ptr);
         }
-        // the profile stream: (row, tile) segments padded to whole 16-byte chunks, from the pre-processed values
-        {
-            const long long n_seg = (long long)n_rows * h->n_tiles;
-            DeviceBuffer<int> len_pad;
-            DeviceBuffer<char> scan_tmp;
-            len_pad.alloc((size_t)n_seg + 1);
-            h->seg_ptr.alloc((size_t)n_seg + 1);
-            hipLaunchKernelGGL(seg_len_kernel, dim3(div_up(n_seg + 1, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->row_tile_ptr.ptr,
-                               n_rows, h->n_tiles, len_pad.ptr);
-            size_t scan_bytes = 0;
-            MI_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, 0, (size_t)(n_seg + 1), rocprim::plus<int>(), s));
-            scan_tmp.alloc(scan_bytes);
-            MI_HIP(rocprim::exclusive_scan(scan_tmp.ptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, 0, (size_t)(n_seg + 1), rocprim::plus<int>(), s));
-            const size_t seg_cap = nnz + 7 * (size_t)n_seg + 520;     // every segment grows by at most 7 entries
-            MI_REQUIRE(seg_cap < (size_t)INT32_MAX, "matrix too large for 32-bit segment offsets");
-            h->seg_idx16.alloc_zero(seg_cap, s);
-            h->seg_val.alloc_zero(seg_cap, s);
-            hipLaunchKernelGGL(seg_fill_kernel, dim3(div_up(n_seg * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->row_tile_ptr.ptr,
-                               h->csr_idx.ptr, h->csr_val.ptr, h->seg_ptr.ptr, n_rows, h->n_tiles, h->tile_w, h->seg_idx16.ptr,
-                               h->seg_val.ptr);
-            MI_HIP(hipGetLastError());
-            MI_HIP(hipStreamSynchronize(s));      // the temporaries above go out of scope
-        }
-        phase("profile stream");
         sumsq.alloc((size_t)n_cols);
         cost.alloc((size_t)n_cols);
         MI_HIP(hipMemsetAsync(cost.ptr, 0, sizeof(long long) * (size_t)n_cols, s));
@@ -1848,6 +1838,44 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         MI_HIP(hipStreamSynchronize(s));
         phase("column costs + norms + downloads");
 
+        // lanes per user profile: sized to the profile length seen from an item (cost-weighted mean)
+        {
+            long long total_cost = 0;
+            for (long long c : h->cost) total_cost += c;
+            const double weighted_len = (double)total_cost / (double)nnz;
+            // each lane covers 8 profile entries per load: G lanes span 8*G entries
+            h->group_lanes = weighted_len >= 1024 ? 64 : (weighted_len >= 320 ? 32 : 16);
+            // the float64 kernel has half the loads in flight per lane (DEPTH 2): narrower groups keep more profiles going
+            if (h->acc_mode() != ACC_COUNTS) h->group_lanes = weighted_len >= 2048 ? 64 : (weighted_len >= 640 ? 32 : 16);
+            if (getenv("MI355REC_SIM_G")) h->group_lanes = atoi(getenv("MI355REC_SIM_G"));
+            MI_REQUIRE(h->group_lanes == 8 || h->group_lanes == 16 || h->group_lanes == 32 || h->group_lanes == 64, "MI355REC_SIM_G must be 8, 16, 32 or 64");
+        }
+        const bool stream_order = !(getenv("MI355REC_SIM_STREAM_ORDER") && atoi(getenv("MI355REC_SIM_STREAM_ORDER")) == 0);
+        // the profile stream: (row, tile) segments padded to whole 16-byte chunks, from the pre-processed values
+        {
+            const long long n_seg = (long long)n_rows * h->n_tiles;
+            DeviceBuffer<int> len_pad;
+            DeviceBuffer<char> scan_tmp;
+            len_pad.alloc((size_t)n_seg + 1);
+            h->seg_ptr.alloc((size_t)n_seg + 1);
+            hipLaunchKernelGGL(seg_len_kernel, dim3(div_up(n_seg + 1, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->row_tile_ptr.ptr,
+                               n_rows, h->n_tiles, len_pad.ptr);
+            size_t scan_bytes = 0;
+            MI_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, 0, (size_t)(n_seg + 1), rocprim::plus<int>(), s));
+            scan_tmp.alloc(scan_bytes);
+            MI_HIP(rocprim::exclusive_scan(scan_tmp.ptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, 0, (size_t)(n_seg + 1), rocprim::plus<int>(), s));
+            const size_t seg_cap = nnz + 7 * (size_t)n_seg + 520;     // every segment grows by at most 7 entries
+            MI_REQUIRE(seg_cap < (size_t)INT32_MAX, "matrix too large for 32-bit segment offsets");
+            h->seg_idx16.alloc_zero(seg_cap, s);
+            h->seg_val.alloc_zero(seg_cap, s);
+            hipLaunchKernelGGL(seg_fill_kernel, dim3(div_up(n_seg * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->row_tile_ptr.ptr,
+                               h->csr_idx.ptr, h->csr_val.ptr, h->seg_ptr.ptr, n_rows, h->n_tiles, h->tile_w, h->seg_idx16.ptr,
+                               h->seg_val.ptr, stream_order ? h->group_lanes : 0);
+            MI_HIP(hipGetLastError());
+            MI_HIP(hipStreamSynchronize(s));      // the temporaries above go out of scope
+        }
+        phase("profile stream");
+
         // Real-valued data: can the column sums be kept as int64 fixed point (ds_add_u64 is 1.8x faster than ds_add_f64)?
         // Every product is at most P = max weight * max |column-side value| * max |value|; a cell sums at most N = longest
         // column of them.  Scale 2^S with P * 2^S <= 2^50 (the float64 rounding trick needs |x| < 2^51) and N * P * 2^S <= 2^62.
@@ -1888,15 +1916,6 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         }
 
         h->queue.alloc(1);
-        // lanes per user profile: sized to the profile length seen from an item (cost-weighted mean)
-        long long total_cost = 0;
-        for (long long c : h->cost) total_cost += c;
-        const double weighted_len = (double)total_cost / (double)nnz;
-        // each lane covers 8 profile entries per load: G lanes span 8*G entries
-        h->group_lanes = weighted_len >= 1024 ? 64 : (weighted_len >= 320 ? 32 : 16);
-        // the float64 kernel has half the loads in flight per lane (DEPTH 2): narrower groups keep more profiles going
-        if (h->acc_mode() != ACC_COUNTS) h->group_lanes = weighted_len >= 2048 ? 64 : (weighted_len >= 640 ? 32 : 16);
-        if (getenv("MI355REC_SIM_G")) h->group_lanes = atoi(getenv("MI355REC_SIM_G"));
         phase("fixed-point check + cost order (host)");
         *out = h.release();
     });
