@@ -36,6 +36,8 @@ struct IalsParams {
     double *part_buf;          // [part slots][SLOTS * 4 * ROW_THREADS] partial augmented Gramians of split rows (accumulator layout)
     unsigned *part_count;      // arrival counters, indexed by the first part slot of a split row
     unsigned *queue;
+    double *systems;           // two-stage epochs: [rows of the batch][SLOTS * 4 * ROW_THREADS] augmented systems (accumulator layout)
+    const int *sys_slot;       // two-stage epochs: slab of every work item's row in `systems`
     unsigned long long *phases;   // optional (MI355REC_IALS_PHASES=1): shader-clock totals of {base, Gramian, Cholesky, back substitution}, rows
 };
 
@@ -134,9 +136,10 @@ __device__ __forceinline__ double swap_sum32(double v) {
 }
 
 // doubles of dynamic LDS the kernel needs for k factors
-static inline size_t ials_lds_doubles(int k) {
+static inline size_t ials_lds_doubles(int k, int stage = 0) {
     const int KT = (k + 1 + 15) / 16, KP = KT * 16;
-    return (size_t)std::max(2 * CHUNK * KP, KT * 16 * TP) + (size_t)KT * 16 * TP + (size_t)KT * 16 + 3 * (size_t)KP;   // staging | panel, Linv, z / x / acc
+    const int first = stage == 2 ? KT * 16 * TP : (stage == 1 ? 2 * CHUNK * KP : std::max(2 * CHUNK * KP, KT * 16 * TP));
+    return (size_t)first + (size_t)KT * 16 * TP + (size_t)KT * 16 + 3 * (size_t)KP;   // staging | panel, Linv, z / x / acc
 }
 
 // 1 / sqrt(d) in full double precision from v_rsq_f64 and two Newton steps (the IEEE sqrt + divide sequences are ~50
@@ -195,8 +198,16 @@ __device__ __forceinline__ int not_invariant(int v) {
     return v;
 }
 
-template <int SLOTS>
+// STAGE 0: the whole row in one workgroup (Gramian, Cholesky, back substitution).
+// Two-stage epochs (the default where it pays, half_step): STAGE 1 builds the augmented systems of a batch of rows and leaves them in
+// HBM in the layout the MFMA accumulators have (512 consecutive doubles per store, 196 KB per row at k = 200); STAGE 2 loads them and
+// solves.  The factorisation is a chain of 13 panels whose diagonal tile is factored and inverted by ONE wavefront (58 % of the
+// Cholesky's cycles, measured) while the matrix pipe idles; the fused kernel holds the tiles AND the Gramian's staging in 256
+// registers, one workgroup per CU, so nothing else can run meanwhile.  The solve alone fits 128 registers: two workgroups per CU, and
+// one row's panel chain hides behind the other's trailing updates -- what the wide register file of a CU is for.
+template <int SLOTS, int STAGE>
 __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams p) {
+    static_assert(STAGE == 0 || STAGE == 1, "the solve stage is ials_solve_kernel");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ short s_tI[MAX_NT], s_tJ[MAX_NT];
     __shared__ int s_row;
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
     double *const ya = lds;                                         // [CHUNK][KP]   A side: (c - 1) y, c in column k
     double *const yb = ya + CHUNK * KP;                             // [CHUNK][KP]   B side: y
     double *const P = lds;                                          // [KT][16][TP]  panel tiles (aliases the staging area)
-    double *const Linv = lds + max(2 * CHUNK * KP, KT * 16 * TP);   // [KT][16][TP]  inverses of the factored diagonal tiles
+    double *const Linv = lds + (STAGE == 1 ? 2 * CHUNK * KP : max(2 * CHUNK * KP, KT * 16 * TP));   // [KT][16][TP]  inverses of the factored diagonal tiles
     double *const zv = Linv + KT * 16 * TP + KT * 16;               // [KP] forward-substituted rhs
     double *const xv = zv + KP;                                     // [KP] solution
     double *const acc = xv + KP;                                    // [KP] sum of L[I][J]^T x_I over the tile rows already solved
@@ -254,6 +265,8 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
 
         // (2a) the first chunk of profile rows is requested before anything else; item ids and confidences run one chunk
         // further ahead than the factor rows they address (two dependent global round trips otherwise)
+        constexpr size_t SYS_DOUBLES = (size_t)SLOTS * 4 * ROW_THREADS;
+        d4 C[SLOTS];
         double pre[2][SPL];
         double pre_c[2], next_c[2];
         int next_item[2];
@@ -283,7 +296,6 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
         fetch_ids(beg + CHUNK);
 
         // (1) B = YtY + reg I                                      (IALSRecommender.py:199)
-        d4 C[SLOTS];
         {
         const int g = not_invariant(lane >> 4), cl = not_invariant(lane & 15);
 #pragma unroll
@@ -378,6 +390,19 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
                 }
         }
         if (p.phases && tid == 0) { asm volatile("" ::"v"(C[0][0])); t2 = ials_stamp(); }
+        if (STAGE == 1) {                                            // hand the system to the solve stage
+            double *dst = p.systems + (size_t)p.sys_slot[slot] * SYS_DOUBLES;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[(size_t)(s * 4 + i) * ROW_THREADS + tid] = C[s][i];
+            if (p.phases && tid == 0) {
+                atomicAdd(&p.phases[0], t1 - t0);
+                atomicAdd(&p.phases[1], t2 - t1);
+                atomicAdd(&p.phases[4], 1ull);
+            }
+            continue;
+        }
 
         // (3) blocked Cholesky of the augmented matrix, panel J = columns 16 J .. 16 J + 15
         for (int J = 0; J < KT; ++J) {
@@ -391,7 +416,10 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
                     for (int i = 0; i < 4; ++i) tile[(4 * i + g) * TP + cl] = C[s][i];
                 }
             __syncthreads();
+            unsigned long long c0 = 0, c1 = 0, c2 = 0;
+            if (p.phases && tid == 0) c0 = ials_stamp();
             if (wave == 0) factor_and_invert_diagonal_tile(P, Linv + J * 16 * TP, lane);
+            if (p.phases && tid == 0) { asm volatile("" ::: "memory"); c1 = ials_stamp(); }
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
@@ -411,6 +439,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
                 }
             }
             __syncthreads();
+            if (p.phases && tid == 0) c2 = ials_stamp();
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s)
                 if (tJs[s] > J) {                                    // trailing update: tile -= X_I X_J'^T
@@ -421,6 +450,13 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) C[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], C[s], 0, 0, 0);
                 }
+            if (p.phases && tid == 0) {
+                asm volatile("" ::"v"(C[0][0]));
+                const unsigned long long c3 = ials_stamp();
+                atomicAdd(&p.phases[5], c1 - c0);
+                atomicAdd(&p.phases[6], c2 - c1);
+                atomicAdd(&p.phases[7], c3 - c2);
+            }
         }
         if (p.phases && tid == 0) { asm volatile("" ::"v"(C[0][0])); t3 = ials_stamp(); }
 
@@ -461,15 +497,174 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
             const unsigned long long t4 = ials_stamp();
             atomicAdd(&p.phases[0], t1 - t0);
             atomicAdd(&p.phases[1], t2 - t1);
+            atomicAdd(&p.phases[4], 1ull);
             atomicAdd(&p.phases[2], t3 - t2);
             atomicAdd(&p.phases[3], t4 - t3);
-            atomicAdd(&p.phases[4], 1ull);
         }
     }
 }
 
 // CSR -> CSC of the confidence matrix on the device (row ids inside a column end up unordered: irrelevant here,
 // the Gramian is a sum).
+// ---- the solve stage of a two-stage epoch ----------------------------------------------------------------------------------
+// One 512-thread workgroup per row, TWO workgroups per CU (128 registers per lane): wavefront 0 is the PANEL wavefront -- it factors
+// and inverts the diagonal tile of every panel and solves the diagonal blocks of the back substitution -- and holds no tile;
+// wavefronts 1..7 hold the lower-triangle tiles (tile t on wavefront 1 + t % 7, slot t / 7: 13 slots = 104 registers at k = 200) and
+// do the matrix-pipe work: panel solves and trailing updates.  The two roles run different code between the same barriers, so the
+// register allocation is the larger of the two, not their sum (tiles 104 + operands; diagonal tile 64 + the inverse) -- in the
+// one-kernel epoch every wavefront carries both.  While one workgroup's panel wavefront works through its 16 pivots, the other
+// workgroup of the CU has the matrix pipe.  Algorithm, order of operations and results: those of ials_row_kernel steps (3), (4).
+constexpr int TILE_WAVES = ROW_WAVES - 1;
+template <int SLOTS>
+__global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsParams p, int gram_slots) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ short s_tI[MAX_NT], s_tJ[MAX_NT];
+    __shared__ int s_row;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k = p.k, KT = (k + 1 + 15) / 16, KP = KT * 16, NT = KT * (KT + 1) / 2;
+    double *const P = lds;                                          // [KT][16][TP]  panel tiles
+    double *const Linv = lds + KT * 16 * TP;                        // [KT][16][TP]  inverses of the factored diagonal tiles
+    double *const zv = Linv + KT * 16 * TP + KT * 16;               // [KP] forward-substituted rhs
+    double *const xv = zv + KP;                                     // [KP] solution
+    double *const acc = xv + KP;                                    // [KP] sum of L[I][J]^T x_I over the tile rows already solved
+    for (int t = tid; t < NT; t += ROW_THREADS) {
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        s_tI[t] = (short)I;
+        s_tJ[t] = (short)(t - I * (I + 1) / 2);
+    }
+    __syncthreads();
+    const int Ik = k >> 4, rk = k & 15;                             // tile row and local row of the rhs row
+    const size_t sys_doubles = (size_t)gram_slots * 4 * ROW_THREADS;
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_row = (int)atomicAdd(p.queue, 1u);
+        __syncthreads();
+        const int slot = s_row;
+        if (slot >= p.n_local) break;
+        const int row = p.items[slot].x;
+        unsigned long long t2 = 0, t3 = 0;
+        if (p.phases && tid == 0) t2 = ials_stamp();
+        if (wave == 0) {
+            // ---- the panel wavefront ----
+            for (int J = 0; J < KT; ++J) {
+                __syncthreads();
+                __syncthreads();                                     // the panel's tiles are in LDS
+                unsigned long long c0 = 0;
+                if (p.phases && tid == 0) c0 = ials_stamp();
+                factor_and_invert_diagonal_tile(P, Linv + J * 16 * TP, lane);
+                if (p.phases && tid == 0) { asm volatile("" ::: "memory"); atomicAdd(&p.phases[5], ials_stamp() - c0); }
+                __syncthreads();
+                __syncthreads();
+            }
+            if (p.phases && tid == 0) t3 = ials_stamp();
+            __syncthreads();
+            __syncthreads();
+            __syncthreads();
+            for (int I = KT - 1; I >= 0; --I) {                      // x_I = L_II^-T (z_I - acc_I): lane c < 16 takes entry c
+                const int c = lane & 15;
+                double t = zv[16 * I + c] - acc[16 * I + c];
+                if (16 * I + c >= k) t = 0.0;                        // the rhs row and the padding are not unknowns
+                double x = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) x += Linv[(I * 16 + m) * TP + c] * lane_bcast(t, m);   // (L^-T)[c][m] = Linv[m][c]
+                if (16 * I + c >= k) x = 0.0;
+                if (lane < 16) xv[16 * I + c] = x;
+                __syncthreads();
+                __syncthreads();
+            }
+        } else {
+            // ---- a tile wavefront ----
+            int tIs[SLOTS], tJs[SLOTS];
+            d4 C[SLOTS];
+            {
+                const double *src = p.systems + (size_t)p.sys_slot[slot] * sys_doubles;
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const int t = (wave - 1) + TILE_WAVES * s;
+                    tIs[s] = t < NT ? __builtin_amdgcn_readfirstlane((int)s_tI[t]) : -1;
+                    tJs[s] = t < NT ? __builtin_amdgcn_readfirstlane((int)s_tJ[t]) : -1;
+                    // stage 1 left tile t in slot t / 8 of its wavefront t % 8
+                    const double *ts = src + (size_t)(t / ROW_WAVES) * 4 * ROW_THREADS + (t % ROW_WAVES) * 64 + lane;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) C[s][i] = t < NT ? ts[(size_t)i * ROW_THREADS] : 0.0;
+                }
+            }
+            for (int J = 0; J < KT; ++J) {
+                const int g = not_invariant(lane >> 4), cl = not_invariant(lane & 15);
+                __syncthreads();                                     // (the previous panel is no longer read)
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s)
+                    if (tJs[s] == J) {
+                        double *tile = P + (tIs[s] - J) * 16 * TP;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) tile[(4 * i + g) * TP + cl] = C[s][i];
+                    }
+                __syncthreads();
+                __syncthreads();                                     // the panel wavefront has factored the diagonal tile
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    if (tJs[s] == J && tIs[s] > J) {                 // X = T L_JJ^-T on the matrix pipe: the owner's registers ARE the result
+                        double *tile = P + (tIs[s] - J) * 16 * TP;
+                        const double *li = Linv + J * 16 * TP;
+                        d4 X = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) X = __builtin_amdgcn_mfma_f64_16x16x4f64(tile[cl * TP + 4 * q + g], li[cl * TP + 4 * q + g], X, 0, 0, 0);
+                        C[s] = X;
+                        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // (the tile is rewritten below: its operand reads must have issued)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) tile[(4 * i + g) * TP + cl] = X[i];
+                    } else if (tJs[s] == J) {                        // the diagonal tile: L_JJ
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) C[s][i] = P[(4 * i + g) * TP + cl];
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s)
+                    if (tJs[s] > J) {                                // trailing update: tile -= X_I X_J'^T
+                        const double *xa = P + ((tIs[s] - J) * 16 + cl) * TP, *xb = P + ((tJs[s] - J) * 16 + cl) * TP;
+                        double av[4], bv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { av[q] = -xa[4 * q + g]; bv[q] = xb[4 * q + g]; }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) C[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], C[s], 0, 0, 0);
+                    }
+            }
+            // (4) back substitution L^T x = z; z is row k of L (the forward substitution came with the factorisation)
+            __syncthreads();
+            for (int f = tid - 64; f < KP; f += ROW_THREADS - 64) { xv[f] = 0.0; acc[f] = 0.0; zv[f] = 0.0; }
+            __syncthreads();
+            const int g = not_invariant(lane >> 4), cl = not_invariant(lane & 15);
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+                if (tIs[s] == Ik && g == (rk & 3)) zv[16 * tJs[s] + cl] = C[s][rk >> 2];
+            __syncthreads();
+            for (int I = KT - 1; I >= 0; --I) {
+                __syncthreads();                                     // the panel wavefront has x_I
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s)
+                    if (tIs[s] == I && tJs[s] < I) {                 // segment J loses L[I][J]^T x_I
+                        double part = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) part += C[s][i] * xv[16 * I + 4 * i + g];
+                        part = swap_sum32(swap_sum16(part));
+                        if (g == 0) atomicAdd(&acc[16 * tJs[s] + cl], part);
+                    }
+                __syncthreads();
+            }
+        }
+        if (tid < k) p.X[(size_t)row * k + tid] = xv[tid];
+        if (p.phases && tid == 0) {
+            const unsigned long long t4 = ials_stamp();
+            atomicAdd(&p.phases[2], t3 - t2);
+            atomicAdd(&p.phases[3], t4 - t3);
+        }
+    }
+}
+
 __global__ void ials_count_kernel(const int *idx, size_t nnz, int *cnt) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x)
         atomicAdd(&cnt[idx[i]], 1);
@@ -524,6 +719,10 @@ struct mi355rec_ials {
     DeviceBuffer<int4> items;
     DeviceBuffer<double> part_buf;
     DeviceBuffer<unsigned> part_count;
+    DeviceBuffer<double> systems;          // two-stage epochs: the augmented systems of one batch of rows
+    DeviceBuffer<int> sys_slot;
+    std::vector<int> sys_slot_host;
+    int n_batches = 0;
     std::vector<int4> items_host;
     int n_split_rows = 0, n_part_items = 0;
     DeviceBuffer<float> u_conf, i_conf;
@@ -573,12 +772,45 @@ void launch_gram(mi355rec_ials *h, const double *Y, int n) {
     }
 }
 
-template <int SLOTS>
-void launch_rows_t(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1) {
-    const size_t lds = sizeof(double) * ials_lds_doubles(h->k);
-    auto kern = ials_row_kernel<SLOTS>;
+template <int SLOTS, int STAGE>
+void launch_rows_ts(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1) {
+    const size_t lds = sizeof(double) * ials_lds_doubles(h->k, STAGE);
+    auto kern = ials_row_kernel<SLOTS, STAGE>;
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(ROW_THREADS), (unsigned)lds, h->stream, e0, e1, 0, p);
+}
+
+template <int SLOTS>
+void launch_rows_t(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1, int stage) {
+    if (stage == 1) launch_rows_ts<SLOTS, 1>(h, p, grid, e0, e1);
+    else launch_rows_ts<SLOTS, 0>(h, p, grid, e0, e1);
+}
+
+template <int SLOTS>
+void launch_solve_t(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1, int gram_slots) {
+    const size_t lds = sizeof(double) * ials_lds_doubles(h->k, 2);
+    auto kern = ials_solve_kernel<SLOTS>;
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(ROW_THREADS), (unsigned)lds, h->stream, e0, e1, 0, p, gram_slots);
+}
+
+// the solve stage holds the tiles on 7 wavefronts: up to 13 slots (k <= 207) fit two workgroups per CU
+constexpr int MAX_SOLVE_SLOTS = 13;
+int solve_slots(int NT) { return (NT + TILE_WAVES - 1) / TILE_WAVES; }
+
+void launch_solve(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1, int gram_slots) {
+    const int KT = (h->k + 1 + 15) / 16, NT = KT * (KT + 1) / 2;
+    switch (solve_slots(NT)) {
+        case 1: launch_solve_t<1>(h, p, grid, e0, e1, gram_slots); break;
+        case 2: launch_solve_t<2>(h, p, grid, e0, e1, gram_slots); break;
+        case 3: case 4: launch_solve_t<4>(h, p, grid, e0, e1, gram_slots); break;
+        case 5: case 6: launch_solve_t<6>(h, p, grid, e0, e1, gram_slots); break;
+        case 7: case 8: launch_solve_t<8>(h, p, grid, e0, e1, gram_slots); break;
+        case 9: case 10: launch_solve_t<10>(h, p, grid, e0, e1, gram_slots); break;
+        case 11: launch_solve_t<11>(h, p, grid, e0, e1, gram_slots); break;
+        case 12: launch_solve_t<12>(h, p, grid, e0, e1, gram_slots); break;
+        default: launch_solve_t<13>(h, p, grid, e0, e1, gram_slots); break;
+    }
 }
 
 // SLOTS of the ials_row_kernel instance launch_rows picks for NT lower-triangle tiles (must mirror its switch)
@@ -589,18 +821,18 @@ int row_slots(int NT) {
     return need == 13 ? 13 : 15;
 }
 
-void launch_rows(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1) {
+void launch_rows(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1, int stage = 0) {
     const int KT = (h->k + 1 + 15) / 16, NT = KT * (KT + 1) / 2;
     switch ((NT + ROW_WAVES - 1) / ROW_WAVES) {          // lower-triangle tiles per wavefront
-        case 1: launch_rows_t<1>(h, p, grid, e0, e1); break;
-        case 2: launch_rows_t<2>(h, p, grid, e0, e1); break;
-        case 3: case 4: launch_rows_t<4>(h, p, grid, e0, e1); break;
-        case 5: case 6: launch_rows_t<6>(h, p, grid, e0, e1); break;
-        case 7: case 8: launch_rows_t<8>(h, p, grid, e0, e1); break;
-        case 9: case 10: launch_rows_t<10>(h, p, grid, e0, e1); break;
-        case 11: case 12: launch_rows_t<12>(h, p, grid, e0, e1); break;
-        case 13: launch_rows_t<13>(h, p, grid, e0, e1); break;
-        default: launch_rows_t<15>(h, p, grid, e0, e1); break;
+        case 1: launch_rows_t<1>(h, p, grid, e0, e1, stage); break;
+        case 2: launch_rows_t<2>(h, p, grid, e0, e1, stage); break;
+        case 3: case 4: launch_rows_t<4>(h, p, grid, e0, e1, stage); break;
+        case 5: case 6: launch_rows_t<6>(h, p, grid, e0, e1, stage); break;
+        case 7: case 8: launch_rows_t<8>(h, p, grid, e0, e1, stage); break;
+        case 9: case 10: launch_rows_t<10>(h, p, grid, e0, e1, stage); break;
+        case 11: case 12: launch_rows_t<12>(h, p, grid, e0, e1, stage); break;
+        case 13: launch_rows_t<13>(h, p, grid, e0, e1, stage); break;
+        default: launch_rows_t<15>(h, p, grid, e0, e1, stage); break;
     }
 }
 
@@ -682,17 +914,82 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
     p.part_count = h->part_count.ptr;
     p.queue = h->queue.ptr;
     p.phases = h->phases.ptr;
-    const int grid = std::min(n_work, grid_cap);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    h->dispatch_timers.next(e0, e1, 1 << 30);
-    launch_rows(h, p, grid, e0, e1);
-    MI_HIP(hipGetLastError());
+    // Two-stage epochs (ials_row_kernel, STAGE 1 / 2): the rows of the half-step, in cost order, in batches whose systems fit the
+    // buffer (MI355REC_IALS_SYSTEM_GIB, default 8: 43 000 rows at k = 200); per batch one launch builds the systems (work items =
+    // the batch's rows and parts, still most expensive first) and one solves them, two workgroups per CU.  Same arithmetic, same
+    // order of every sum as the one-kernel epoch: the factors are bit-identical (tests/test_ials_gpu.py).
+    const char *ts = getenv("MI355REC_IALS_TWO_STAGE");
+    const bool two_stage = (ts ? atoi(ts) != 0 : true) && solve_slots(((h->k + 1 + 15) / 16) * (((h->k + 1 + 15) / 16) + 1) / 2) <= MAX_SOLVE_SLOTS;
+    h->n_batches = 0;
+    if (!two_stage) {
+        const int grid = std::min(n_work, grid_cap);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        h->dispatch_timers.reserve(h->dispatch_timers.used + 1);
+        h->dispatch_timers.next(e0, e1, 1 << 30);
+        launch_rows(h, p, grid, e0, e1);
+        MI_HIP(hipGetLastError());
+    } else {
+        const int KT_ = (h->k + 1 + 15) / 16, NT_ = KT_ * (KT_ + 1) / 2;
+        const size_t sys_doubles = (size_t)row_slots(NT_) * 4 * ROW_THREADS;
+        double gib = 8.0;
+        if (getenv("MI355REC_IALS_SYSTEM_GIB")) gib = std::max(0.001, atof(getenv("MI355REC_IALS_SYSTEM_GIB")));
+        const int per_batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_local, (size_t)(gib * 1073741824.0) / (sys_doubles * sizeof(double))));
+        const int n_batches = (n_local + per_batch - 1) / per_batch;
+        h->n_batches = n_batches;
+        if (h->systems.count < (size_t)per_batch * sys_doubles) h->systems.alloc((size_t)per_batch * sys_doubles);
+        // position of every row in the cost order -> (batch, slab)
+        std::vector<int> pos_of_row((size_t)n_side, -1);
+        for (int i = 0; i < n_local; ++i) pos_of_row[h->staging[i]] = i;
+        // stage-1 items per batch (the sorted list filtered), then one stage-2 item per row
+        std::vector<std::vector<int4>> gram_items((size_t)n_batches);
+        for (const int4 &it : h->items_host) gram_items[(size_t)(pos_of_row[it.x] / per_batch)].push_back(it);
+        std::vector<int4> all;
+        h->sys_slot_host.clear();
+        std::vector<int> gram_off((size_t)n_batches), gram_n((size_t)n_batches), solve_off((size_t)n_batches), solve_n((size_t)n_batches);
+        for (int b = 0; b < n_batches; ++b) {
+            gram_off[b] = (int)all.size();
+            gram_n[b] = (int)gram_items[b].size();
+            for (const int4 &it : gram_items[b]) {
+                all.push_back(it);
+                h->sys_slot_host.push_back(pos_of_row[it.x] % per_batch);
+            }
+            solve_off[b] = (int)all.size();
+            const int r_end = std::min(n_local, (b + 1) * per_batch);
+            solve_n[b] = r_end - b * per_batch;
+            for (int i = b * per_batch; i < r_end; ++i) {
+                all.push_back(make_int4(h->staging[i], 0, 1, 0));
+                h->sys_slot_host.push_back(i % per_batch);
+            }
+        }
+        if (h->items.count < all.size()) h->items.alloc(all.size() + 1024);
+        if (h->sys_slot.count < all.size()) h->sys_slot.alloc(all.size() + 1024);
+        MI_HIP(hipMemcpyAsync(h->items.ptr, all.data(), sizeof(int4) * all.size(), hipMemcpyHostToDevice, h->stream));
+        MI_HIP(hipMemcpyAsync(h->sys_slot.ptr, h->sys_slot_host.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice, h->stream));
+        MI_HIP(hipStreamSynchronize(h->stream));         // (`all` is a local)
+        h->dispatch_timers.reserve(h->dispatch_timers.used + 2 * n_batches);
+        p.systems = h->systems.ptr;
+        for (int b = 0; b < n_batches; ++b) {
+            for (int stage = 1; stage <= 2; ++stage) {
+                p.items = h->items.ptr + (stage == 1 ? gram_off[b] : solve_off[b]);
+                p.sys_slot = h->sys_slot.ptr + (stage == 1 ? gram_off[b] : solve_off[b]);
+                p.n_local = stage == 1 ? gram_n[b] : solve_n[b];
+                MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(unsigned), h->stream));
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                h->dispatch_timers.next(e0, e1, 1 << 30);
+                if (stage == 1) launch_rows(h, p, std::min(p.n_local, grid_cap), e0, e1, 1);
+                else launch_solve(h, p, std::min(p.n_local, 2 * grid_cap), e0, e1, row_slots(NT_));
+                MI_HIP(hipGetLastError());
+            }
+        }
+    }
     if (h->phases.ptr) {
-        unsigned long long ph[5];
+        unsigned long long ph[8];
         MI_HIP(hipMemcpyAsync(ph, h->phases.ptr, sizeof(ph), hipMemcpyDeviceToHost, h->stream));
         MI_HIP(hipStreamSynchronize(h->stream));
-        fprintf(stderr, "[ials phases] %s half: %llu rows; shader cycles per row: base %.0f, Gramian %.0f, Cholesky %.0f, back-substitution %.0f\n",
-                users ? "user" : "item", ph[4], (double)ph[0] / ph[4], (double)ph[1] / ph[4], (double)ph[2] / ph[4], (double)ph[3] / ph[4]);
+        fprintf(stderr, "[ials phases] %s half: %llu rows; shader cycles per row: base %.0f, Gramian %.0f, Cholesky %.0f (diagonal tiles %.0f, panel solves %.0f, "
+                        "trailing updates of wavefront 0 %.0f), back-substitution %.0f\n",
+                users ? "user" : "item", ph[4], (double)ph[0] / ph[4], (double)ph[1] / ph[4], (double)ph[2] / ph[4], (double)ph[5] / ph[4], (double)ph[6] / ph[4],
+                (double)ph[7] / ph[4], (double)ph[3] / ph[4]);
         MI_HIP(hipMemsetAsync(h->phases.ptr, 0, sizeof(ph), h->stream));
     }
     // ALGORITHMIC work, SURVEY.md section 8(d): Gramian 2 * nnz * k^2 flop per pass (+ the k x k base Gramian 2 n k^2),
@@ -771,7 +1068,7 @@ extern "C" int mi355rec_ials_create(mi355rec_ials_t *out, int32_t n_users, int32
         h->V.upload(V0, ni, s);
         h->G.alloc((size_t)h->k * h->k);
         h->queue.alloc(1);
-        if (getenv("MI355REC_IALS_PHASES")) h->phases.alloc_zero(5, s);
+        if (getenv("MI355REC_IALS_PHASES")) h->phases.alloc_zero(8, s);
         h->u_ptr_host.assign(indptr, indptr + n_users + 1);
         h->i_ptr_host.resize((size_t)n_items + 1);
         h->i_ptr.download(h->i_ptr_host.data(), (size_t)n_items + 1, s);
