@@ -38,6 +38,7 @@ struct IalsParams {
     unsigned *queue;
     double *systems;           // two-stage epochs: [rows of the batch][SLOTS * 4 * ROW_THREADS] augmented systems (accumulator layout)
     const int *sys_slot;       // two-stage epochs: slab of every work item's row in `systems`
+    int same_panel_wave;       // diagnostics (MI355REC_IALS_SAME_PANEL_WAVE=1): every workgroup's panel wavefront is wavefront 0
     unsigned long long *phases;   // optional (MI355REC_IALS_PHASES=1): shader-clock totals of {base, Gramian, Cholesky, back substitution}, rows
 };
 
@@ -296,21 +297,31 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
         fetch_ids(beg + CHUNK);
 
         // (1) B = YtY + reg I                                      (IALSRecommender.py:199)
+        // Every lane's 4 x SLOTS cells of G are requested first, unconditionally (clamped addresses), and patched afterwards: with the
+        // load inside the `r < k && c < k` test every cell waited for its own round trip to the L2 (37 k cycles per row, a quarter
+        // of the Gramian stage).
         {
         const int g = not_invariant(lane >> 4), cl = not_invariant(lane & 15);
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
+            const int tI = max(tIs[s], 0), tJ = max(tJs[s], 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) C[s][i] = p.G[(size_t)min(16 * tI + 4 * i + g, k - 1) * k + min(16 * tJ + cl, k - 1)];
+            // (one kernel: four tiles' loads in flight at a time -- its registers are full; the Gramian stage of a two-stage epoch
+            // requests all of them at once)
+            if (STAGE == 0 && (s & 3) == 3) asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                double v = 0.0;
-                if (tIs[s] >= 0 && first_part) {
-                    const int r = 16 * tIs[s] + 4 * i + g, c = 16 * tJs[s] + cl;
-                    if (r < k && c < k) v = p.G[(size_t)r * k + c] + (r == c ? p.reg : 0.0);
-                    else if (r == c) v = r == k ? AUG_DIAG : 1.0;   // identity padding keeps the factorisation well defined
-                }
+                const int r = 16 * tIs[s] + 4 * i + g, c = 16 * tJs[s] + cl;
+                double v = C[s][i];
+                if (r == c) v += p.reg;
+                if (r >= k || c >= k) v = r == c ? (r == k ? AUG_DIAG : 1.0) : 0.0;   // identity padding keeps the factorisation well defined
+                if (tIs[s] < 0 || !first_part) v = 0.0;
                 C[s][i] = v;
             }
-            if ((s & 3) == 3) asm volatile("" ::: "memory");         // four tiles' loads in flight at a time: bounded registers
         }
         }
         if (p.phases && tid == 0) { asm volatile("" ::"v"(C[0][0])); t1 = ials_stamp(); }
@@ -513,7 +524,12 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
 // do the matrix-pipe work: panel solves and trailing updates.  The two roles run different code between the same barriers, so the
 // register allocation is the larger of the two, not their sum (tiles 104 + operands; diagonal tile 64 + the inverse) -- in the
 // one-kernel epoch every wavefront carries both.  While one workgroup's panel wavefront works through its 16 pivots, the other
-// workgroup of the CU has the matrix pipe.  Algorithm, order of operations and results: those of ials_row_kernel steps (3), (4).
+// workgroup of the CU has the matrix pipe.  Algorithm, order of operations and results: those of ials_row_kernel steps (3), (4) --
+// the factors of a two-stage epoch are the one-kernel epoch's bit for bit.
+// Measured and not kept (round 5): the diagonal tile with DPP row broadcasts instead of v_readlane (factor alone 103 k cycles per row
+// against ~80 k; factor + inverse 559 k against 158 k), and no inverse at all -- panel tiles solved by substitution on the tile
+// wavefronts (DPP), back substitution by substitution on the panel wavefront: the Cholesky took 274 k cycles per row against 267 k, the
+// back substitution 60 k against 35 k.
 constexpr int TILE_WAVES = ROW_WAVES - 1;
 template <int SLOTS>
 __global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsParams p, int gram_slots) {
@@ -524,8 +540,8 @@ __global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsPa
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int k = p.k, KT = (k + 1 + 15) / 16, KP = KT * 16, NT = KT * (KT + 1) / 2;
     double *const P = lds;                                          // [KT][16][TP]  panel tiles
-    double *const Linv = lds + KT * 16 * TP;                        // [KT][16][TP]  inverses of the factored diagonal tiles
-    double *const zv = Linv + KT * 16 * TP + KT * 16;               // [KP] forward-substituted rhs
+    double *const Ld = lds + KT * 16 * TP;                          // [KT][16][TP]  inverses of the factored diagonal tiles
+    double *const zv = Ld + KT * 16 * TP + KT * 16;                 // [KP] forward-substituted rhs
     double *const xv = zv + KP;                                     // [KP] solution
     double *const acc = xv + KP;                                    // [KP] sum of L[I][J]^T x_I over the tile rows already solved
     for (int t = tid; t < NT; t += ROW_THREADS) {
@@ -537,6 +553,13 @@ __global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsPa
     __syncthreads();
     const int Ik = k >> 4, rk = k & 15;                             // tile row and local row of the rhs row
     const size_t sys_doubles = (size_t)gram_slots * 4 * ROW_THREADS;
+    // The two workgroups of a CU should not have their panel wavefronts on the same SIMD (both chains would share one issue port:
+    // measured 120 k -> 158 k cycles of diagonal-tile work per row).  Wavefront w of a workgroup sits on SIMD w % 4 and the second
+    // half of the grid is what doubles the CUs up (both observed, neither promised: a wrong guess costs speed only) -- the second
+    // half takes wavefront 2 as its panel wavefront.  Tile wavefronts are numbered 0..6 in the order of the remaining indices.
+    const int panel_wave = 2 * (int)(blockIdx.x >= gridDim.x / 2 && gridDim.x > 1 && !p.same_panel_wave);
+    const bool is_panel = wave == panel_wave;
+    const int tile_wave = wave - (wave > panel_wave);               // 0 .. 6 for the others
 
     for (;;) {
         __syncthreads();
@@ -546,30 +569,31 @@ __global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsPa
         if (slot >= p.n_local) break;
         const int row = p.items[slot].x;
         unsigned long long t2 = 0, t3 = 0;
-        if (p.phases && tid == 0) t2 = ials_stamp();
-        if (wave == 0) {
+        const bool clock = p.phases && is_panel && lane == 0;
+        if (clock) t2 = ials_stamp();
+        if (is_panel) {
             // ---- the panel wavefront ----
             for (int J = 0; J < KT; ++J) {
                 __syncthreads();
                 __syncthreads();                                     // the panel's tiles are in LDS
                 unsigned long long c0 = 0;
-                if (p.phases && tid == 0) c0 = ials_stamp();
-                factor_and_invert_diagonal_tile(P, Linv + J * 16 * TP, lane);
-                if (p.phases && tid == 0) { asm volatile("" ::: "memory"); atomicAdd(&p.phases[5], ials_stamp() - c0); }
+                if (clock) c0 = ials_stamp();
+                factor_and_invert_diagonal_tile(P, Ld + J * 16 * TP, lane);
+                if (clock) { asm volatile("" ::: "memory"); atomicAdd(&p.phases[5], ials_stamp() - c0); }
                 __syncthreads();
                 __syncthreads();
             }
-            if (p.phases && tid == 0) t3 = ials_stamp();
+            if (clock) t3 = ials_stamp();
             __syncthreads();
             __syncthreads();
             __syncthreads();
-            for (int I = KT - 1; I >= 0; --I) {                      // x_I = L_II^-T (z_I - acc_I): lane c < 16 takes entry c
+            for (int I = KT - 1; I >= 0; --I) {                      // x_I = L_II^-T (z_I - acc_I) by substitution: lane c < 16 takes entry c
                 const int c = lane & 15;
                 double t = zv[16 * I + c] - acc[16 * I + c];
                 if (16 * I + c >= k) t = 0.0;                        // the rhs row and the padding are not unknowns
                 double x = 0.0;
 #pragma unroll
-                for (int m = 0; m < 16; ++m) x += Linv[(I * 16 + m) * TP + c] * lane_bcast(t, m);   // (L^-T)[c][m] = Linv[m][c]
+                for (int m = 0; m < 16; ++m) x += Ld[(I * 16 + m) * TP + c] * lane_bcast(t, m);   // (L^-T)[c][m] = Linv[m][c]
                 if (16 * I + c >= k) x = 0.0;
                 if (lane < 16) xv[16 * I + c] = x;
                 __syncthreads();
@@ -583,7 +607,7 @@ __global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsPa
                 const double *src = p.systems + (size_t)p.sys_slot[slot] * sys_doubles;
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) {
-                    const int t = (wave - 1) + TILE_WAVES * s;
+                    const int t = tile_wave + TILE_WAVES * s;
                     tIs[s] = t < NT ? __builtin_amdgcn_readfirstlane((int)s_tI[t]) : -1;
                     tJs[s] = t < NT ? __builtin_amdgcn_readfirstlane((int)s_tJ[t]) : -1;
                     // stage 1 left tile t in slot t / 8 of its wavefront t % 8
@@ -608,7 +632,7 @@ __global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsPa
                 for (int s = 0; s < SLOTS; ++s) {
                     if (tJs[s] == J && tIs[s] > J) {                 // X = T L_JJ^-T on the matrix pipe: the owner's registers ARE the result
                         double *tile = P + (tIs[s] - J) * 16 * TP;
-                        const double *li = Linv + J * 16 * TP;
+                        const double *li = Ld + J * 16 * TP;
                         d4 X = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                         for (int q = 0; q < 4; ++q) X = __builtin_amdgcn_mfma_f64_16x16x4f64(tile[cl * TP + 4 * q + g], li[cl * TP + 4 * q + g], X, 0, 0, 0);
@@ -635,7 +659,7 @@ __global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsPa
             }
             // (4) back substitution L^T x = z; z is row k of L (the forward substitution came with the factorisation)
             __syncthreads();
-            for (int f = tid - 64; f < KP; f += ROW_THREADS - 64) { xv[f] = 0.0; acc[f] = 0.0; zv[f] = 0.0; }
+            for (int f = tile_wave * 64 + lane; f < KP; f += ROW_THREADS - 64) { xv[f] = 0.0; acc[f] = 0.0; zv[f] = 0.0; }
             __syncthreads();
             const int g = not_invariant(lane >> 4), cl = not_invariant(lane & 15);
 #pragma unroll
@@ -657,7 +681,7 @@ __global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsPa
             }
         }
         if (tid < k) p.X[(size_t)row * k + tid] = xv[tid];
-        if (p.phases && tid == 0) {
+        if (clock) {
             const unsigned long long t4 = ials_stamp();
             atomicAdd(&p.phases[2], t3 - t2);
             atomicAdd(&p.phases[3], t4 - t3);
@@ -968,6 +992,7 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
         MI_HIP(hipStreamSynchronize(h->stream));         // (`all` is a local)
         h->dispatch_timers.reserve(h->dispatch_timers.used + 2 * n_batches);
         p.systems = h->systems.ptr;
+        p.same_panel_wave = getenv("MI355REC_IALS_SAME_PANEL_WAVE") != nullptr;
         for (int b = 0; b < n_batches; ++b) {
             for (int stage = 1; stage <= 2; ++stage) {
                 p.items = h->items.ptr + (stage == 1 ? gram_off[b] : solve_off[b]);

@@ -200,3 +200,35 @@ def test_rows_split_over_workgroups_equal_unsplit_rows(gpu, k, monkeypatch):
     Uw, Vw = whole.get_factors()
     assert rel_err(Us, U) < 1e-8 and rel_err(Vs, V) < 1e-8
     assert rel_err(Us, Uw) < 1e-10 and rel_err(Vs, Vw) < 1e-10
+
+
+@pytest.mark.parametrize("k", [8, 48, 200, 207, 208])
+def test_two_stage_epochs_equal_one_kernel_epochs_bit_for_bit(gpu, k, monkeypatch):
+    """The default epoch builds the augmented systems of a batch of rows into HBM (ials_row_kernel, STAGE 1) and solves them with two
+    workgroups per CU (ials_solve_kernel: a panel wavefront + seven tile wavefronts); MI355REC_IALS_TWO_STAGE=0 keeps the whole row in
+    one workgroup.  Same operations in the same order: identical factors -- with rows split over workgroups, with batches of a few rows
+    (MI355REC_IALS_SYSTEM_GIB), and where the solve stage does not apply (k > 207: 14 tiles per tile wavefront) the switch changes
+    nothing."""
+    X = named_urm("ml1m", "real", scale=0.12)
+    Cm = O.oracle_ials_confidence(X, "linear", 3.0)
+    V0 = k ** -0.5 * np.random.default_rng(k).random((X.shape[1], k))
+    monkeypatch.setenv("MI355REC_IALS_PART_ROWS", "64")              # long rows split into parts of 64 profile entries
+    out = {}
+    for label, two_stage, gib in (("one", "0", None), ("two", "1", None), ("two-small-batches", "1", "0.004")):
+        monkeypatch.setenv("MI355REC_IALS_TWO_STAGE", two_stage)
+        if gib:
+            monkeypatch.setenv("MI355REC_IALS_SYSTEM_GIB", gib)
+        else:
+            monkeypatch.delenv("MI355REC_IALS_SYSTEM_GIB", raising=False)
+        dev = IALS_MI355X_Epoch(Cm, k, 1e-2, V0)
+        dev.run_epochs(2)
+        out[label] = dev.get_factors()
+        assert dev.schedule_info()[0] > 0                               # split rows took part
+        dev.close()
+    for label in ("two", "two-small-batches"):
+        assert np.array_equal(out[label][0], out["one"][0]) and np.array_equal(out[label][1], out["one"][1]), label
+    U = np.zeros((X.shape[0], k)); V = V0.copy()
+    Cc = sps.csc_matrix(Cm)
+    for _ in range(2):
+        O.oracle_ials_epoch(Cm, Cc, U, V, 1e-2)
+    assert rel_err(out["two"][0], U) < RTOL and rel_err(out["two"][1], V) < RTOL
