@@ -524,8 +524,9 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
 // do the matrix-pipe work: panel solves and trailing updates.  The two roles run different code between the same barriers, so the
 // register allocation is the larger of the two, not their sum (tiles 104 + operands; diagonal tile 64 + the inverse) -- in the
 // one-kernel epoch every wavefront carries both.  While one workgroup's panel wavefront works through its 16 pivots, the other
-// workgroup of the CU has the matrix pipe.  Algorithm, order of operations and results: those of ials_row_kernel steps (3), (4) --
-// the factors of a two-stage epoch are the one-kernel epoch's bit for bit.
+// workgroup of the CU has the matrix pipe.  Algorithm and order of operations: those of ials_row_kernel steps (3), (4); the factors
+// of a two-stage epoch agree with the one-kernel epoch's to 1e-12 (two compilations of the same expressions; the back substitution's
+// LDS atomics add in arrival order in both).
 // Measured and not kept (round 5): the diagonal tile with DPP row broadcasts instead of v_readlane (factor alone 103 k cycles per row
 // against ~80 k; factor + inverse 559 k against 158 k), and no inverse at all -- panel tiles solved by substitution on the tile
 // wavefronts (DPP), back substitution by substitution on the panel wavefront: the Cholesky took 274 k cycles per row against 267 k, the
@@ -940,8 +941,8 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
     p.phases = h->phases.ptr;
     // Two-stage epochs (ials_row_kernel, STAGE 1 / 2): the rows of the half-step, in cost order, in batches whose systems fit the
     // buffer (MI355REC_IALS_SYSTEM_GIB, default 8: 43 000 rows at k = 200); per batch one launch builds the systems (work items =
-    // the batch's rows and parts, still most expensive first) and one solves them, two workgroups per CU.  Same arithmetic, same
-    // order of every sum as the one-kernel epoch: the factors are bit-identical (tests/test_ials_gpu.py).
+    // the batch's rows and parts, still most expensive first) and one solves them, two workgroups per CU.  Same arithmetic as the
+    // one-kernel epoch (tests/test_ials_gpu.py::test_two_stage_epochs_equal_one_kernel_epochs: 1e-12).
     const char *ts = getenv("MI355REC_IALS_TWO_STAGE");
     const bool two_stage = (ts ? atoi(ts) != 0 : true) && solve_slots(((h->k + 1 + 15) / 16) * (((h->k + 1 + 15) / 16) + 1) / 2) <= MAX_SOLVE_SLOTS;
     h->n_batches = 0;

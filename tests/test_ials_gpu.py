@@ -203,12 +203,12 @@ def test_rows_split_over_workgroups_equal_unsplit_rows(gpu, k, monkeypatch):
 
 
 @pytest.mark.parametrize("k", [8, 48, 200, 207, 208])
-def test_two_stage_epochs_equal_one_kernel_epochs_bit_for_bit(gpu, k, monkeypatch):
+def test_two_stage_epochs_equal_one_kernel_epochs(gpu, k, monkeypatch):
     """The default epoch builds the augmented systems of a batch of rows into HBM (ials_row_kernel, STAGE 1) and solves them with two
     workgroups per CU (ials_solve_kernel: a panel wavefront + seven tile wavefronts); MI355REC_IALS_TWO_STAGE=0 keeps the whole row in
-    one workgroup.  Same operations in the same order: identical factors -- with rows split over workgroups, with batches of a few rows
-    (MI355REC_IALS_SYSTEM_GIB), and where the solve stage does not apply (k > 207: 14 tiles per tile wavefront) the switch changes
-    nothing."""
+    one workgroup.  The same operations on the same systems: the factors agree to 1e-12 (not bit for bit -- two compilations of the
+    expressions, and Y^T Y itself is summed with atomics in arrival order in every epoch) -- with rows split over workgroups, with batches of a few rows
+    (MI355REC_IALS_SYSTEM_GIB); where the solve stage does not apply (k > 207: 14 tiles per tile wavefront) the switch changes nothing."""
     X = named_urm("ml1m", "real", scale=0.12)
     Cm = O.oracle_ials_confidence(X, "linear", 3.0)
     V0 = k ** -0.5 * np.random.default_rng(k).random((X.shape[1], k))
@@ -225,8 +225,8 @@ def test_two_stage_epochs_equal_one_kernel_epochs_bit_for_bit(gpu, k, monkeypatc
         out[label] = dev.get_factors()
         assert dev.schedule_info()[0] > 0                               # split rows took part
         dev.close()
-    for label in ("two", "two-small-batches"):
-        assert np.array_equal(out[label][0], out["one"][0]) and np.array_equal(out[label][1], out["one"][1]), label
+    assert rel_err(out["two"][0], out["one"][0]) < 1e-12 and rel_err(out["two"][1], out["one"][1]) < 1e-12
+    assert rel_err(out["two-small-batches"][0], out["two"][0]) < 1e-12 and rel_err(out["two-small-batches"][1], out["two"][1]) < 1e-12
     U = np.zeros((X.shape[0], k)); V = V0.copy()
     Cc = sps.csc_matrix(Cm)
     for _ in range(2):
