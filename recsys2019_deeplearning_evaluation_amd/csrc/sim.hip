@@ -1339,14 +1339,18 @@ __global__ void wide_iota_kernel(int *ids, unsigned *offsets, int n_rows, int n_
         offsets[r] = (unsigned)(r * n_cols);
 }
 
-void run_columns_wide_topk(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, int n_parts) {
+// n_parts > 0: rows [part_first, part_first + part_count) of interleaved part `start` only (a sharded build computes its part in pieces)
+void run_columns_wide_topk(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, float *d_val, int n_parts, int part_first = 0,
+                           int part_count = 0x7fffffff) {
     const int topK = h->cfg.topK, n_cols = h->n_cols;
     // rows of the output, in output order: a contiguous range, or one interleaved part (whose rows the kernel places by out_slot)
     int n_local = end - start;
     if (n_parts > 0) {
         n_local = 0;
         for (long long pos = 0; pos < n_cols; ++pos) n_local += part_of_position(pos, n_parts) == start;
+        n_local = std::max(0, std::min(part_count, n_local - part_first));
     }
+    if (n_local == 0) return;
     // 4 GiB per float buffer (MI355REC_SIM_WIDE_CELLS: a smaller bound, for tests of the block walk)
     const size_t cells_cap = getenv("MI355REC_SIM_WIDE_CELLS") ? (size_t)std::max(1ll, atoll(getenv("MI355REC_SIM_WIDE_CELLS"))) : (size_t)1 << 30;
     int block = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_local, cells_cap / (size_t)n_cols));
@@ -1373,7 +1377,7 @@ void run_columns_wide_topk(mi355rec_sim *h, int32_t start, int32_t end, int *d_i
         for (int done = 0; done < n_local; done += block) {
             const int here = std::min(block, n_local - done);
             h->cfg.topK = 0;
-            if (n_parts > 0) run_columns_lds(h, start, 0, nullptr, nullptr, dense.ptr, n_parts, done, here);
+            if (n_parts > 0) run_columns_lds(h, start, 0, nullptr, nullptr, dense.ptr, n_parts, part_first + done, here);
             else run_columns_lds(h, start + done, start + done + here, nullptr, nullptr, dense.ptr, 0);
             h->cfg = saved;
             MI_HIP(hipStreamSynchronize(s));
@@ -1961,11 +1965,13 @@ extern "C" int mi355rec_sim_compute_part_chunk_device(mi355rec_sim_t h, int32_t 
         MI_REQUIRE(n_parts >= 1 && part >= 0 && part < n_parts, "part %d of %d", part, n_parts);
         MI_REQUIRE(slot_first >= 0 && slot_count >= 0, "rows %d + %d of a part", slot_first, slot_count);
         if (h->cfg.topK == 0) fail(MI355REC_E_INVALID, "topK == 0: use mi355rec_sim_compute_dense");
-        if (h->wide_topk) fail(MI355REC_E_UNSUPPORTED, "topK beyond the in-LDS selection: build the part in one piece (mi355rec_sim_compute_part_device)");
         ensure_device();
         if (slot_count == 0) return;
         h->wide_kernel_ms = -1.0;
-        run_columns_lds(h, part, 0, d_nbr_idx, d_nbr_val, nullptr, n_parts, slot_first, slot_count);
+        // (topK beyond the in-LDS selection, or more per-tile candidates than the merge buffer holds: dense columns + segmented sort,
+        // walking the same rows of the part)
+        if (h->wide_topk) run_columns_wide_topk(h, part, 0, d_nbr_idx, d_nbr_val, n_parts, slot_first, slot_count);
+        else run_columns_lds(h, part, 0, d_nbr_idx, d_nbr_val, nullptr, n_parts, slot_first, slot_count);
     });
 }
 

@@ -190,8 +190,8 @@ class ShardedSimilarityBuild:
             self.widest = max(e - s for s, e in self.ranges)
         if chunks is None:
             chunks = 4 if world > 1 else 1
-        if getattr(similarity_object, "TopK", 0) > 4096:           # beyond the in-LDS selection a part is built in one piece
-            chunks = 1
+        # (topK beyond the in-LDS selection -- more than 4096 neighbours, or accumulator tiles x topK beyond the merge buffer -- is built
+        # dense + sorted; mi355rec_sim_compute_part_chunk_device walks the same rows of the part there too, so pieces work either way)
         self.rows = chunk_bounds(self.widest, chunks)
         self.slab_words = 2 * self.widest * self.topK
         self.local = DeviceArray(self.slab_words)

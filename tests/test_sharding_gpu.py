@@ -149,6 +149,42 @@ def test_interleaved_parts_with_topk_beyond_the_lds_selection(gpu, monkeypatch):
     buf.close(); sim.close()
 
 
+def test_part_pieces_with_topk_beyond_the_lds_selection(gpu, monkeypatch, n=4500, topK=4200, cells=100):
+    """The sharded build computes a rank's part in 4 pieces by default (ShardedSimilarityBuild.rows); a handle whose top-K goes through
+    dense columns + the segmented sort -- topK > 4096 candidates, or a wide catalogue whose accumulator tiles x topK exceed the merge
+    buffer -- must serve those pieces too (round 4 raised MI355REC_E_UNSUPPORTED there):
+    pieces of 3 interleaved parts, walked in blocks of a few columns, against the single build."""
+    import numpy as np
+    from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_MI355X
+    from recsys2019_deeplearning_evaluation_amd._native import DeviceArray
+    from recsys2019_deeplearning_evaluation_amd.sharding import chunk_bounds
+    from recsys2019_deeplearning_evaluation_amd.synthetic import synthetic_urm
+    G = 3
+    X = synthetic_urm(500, n, 6 * n, 3, 400, seed=23, values="binary", zipf_exponent=0.5)
+    sim = Compute_Similarity_MI355X(X, topK=topK, shrink=1)
+    full_idx, full_val, _ = sim.compute_slabs()
+    monkeypatch.setenv("MI355REC_SIM_WIDE_CELLS", str(cells * n))
+    widest = -(-n // G)
+    pieces = chunk_bounds(widest, 4)
+    idx = np.full((n, topK), -7, np.int32); val = np.zeros((n, topK), np.float32)
+    for r in range(G):
+        cols = sim.part_columns(r, G)
+        for r0, r1 in pieces:
+            count = max(0, min(r1, len(cols)) - r0)
+            if count == 0:
+                continue
+            buf = DeviceArray(2 * (r1 - r0) * topK)
+            sim.compute_part_chunk_device(r, G, r0, count, buf.address(), buf.address((r1 - r0) * topK))
+            sim.synchronize()
+            host = buf.to_host().reshape(2, r1 - r0, topK)
+            idx[cols[r0:r0 + count]] = host[0, :count]
+            val[cols[r0:r0 + count]] = host[1, :count].view(np.float32)
+            buf.close()
+    np.testing.assert_array_equal(idx, full_idx)
+    np.testing.assert_array_equal(val, full_val)
+    sim.close()
+
+
 @pytest.mark.parametrize("world,batch_size,k", [(1, 1000, 128), (4, 1000, 128), (8, 4096, 64), (3, 37, 20), (2, 2000, 8)])
 def test_exact_multi_gpu_bpr_emulated_on_one_gpu(gpu, world, batch_size, k):
     """SURVEY 8(e)'s exact mode: `world` identical replicas in ONE process stand for the ranks; every mini-batch each runs its share of
