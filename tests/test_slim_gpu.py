@@ -363,3 +363,21 @@ def test_sparse_store_rows_with_more_nodes_than_the_lds_select_holds(gpu, mode, 
         dev.replay_samples(*orc.recorded())
         _csr_parity(dev.get_S(), orc.get_S(), "%s round %d" % (mode, round_))
     dev.close()
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+@pytest.mark.parametrize("mode", ["adagrad", "adam"])
+def test_many_epochs_do_not_drift_from_the_float64_oracle(gpu, symmetric, mode):
+    """the hot paths take the sigmoid and the adaptive step through v_exp_f32 / v_rcp_f32 / v_sqrt_f32 (relative error of a
+    step ~2e-7), owned rows live in LDS as float32 and the symmetric store keeps float32 cells -- the short replays above cannot show
+    whether that compounds.  120 epochs (72 600 steps on 370 items: the busiest rows take ~10 000 steps each) of the same stream
+    against the strictly sequential float64 oracle, the usual element-wise bar."""
+    X = named_urm("ml1m", "binary", scale=0.1)           # 604 x 370
+    orc, dev, (u, i, j) = _replay(X, 120, symmetric=symmetric, random_seed=29, sgd_mode=mode, learning_rate=0.01,
+                                  li_reg=0.003, lj_reg=0.005)
+    assert len(u) == 120 * (X.shape[0] + 1)
+    S = dev.get_S_dense()
+    assert_factor_parity(S, orc.get_S_dense(), mode, "S")
+    if not symmetric:
+        assert dev.schedule_info()[0] > 0                   # rows were owned (LDS-resident) during the run
+    dev.close()
