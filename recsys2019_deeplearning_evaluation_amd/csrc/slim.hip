@@ -30,6 +30,11 @@
 // OwnerLease).  Exact sequential semantics (1e-5 element-wise against the float64 oracle for all four optimisers, both stores,
 // at the full BASELINE config-3 shape).  4-byte gathers / scatters, no dense contraction: no MFMA.
 #include "common.h"
+
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+#include <mutex>
 #include "sampling.cuh"
 #include "topk.cuh"
 #include "wave.cuh"
@@ -1607,11 +1612,59 @@ void sort_pairs(mi355rec_slim *h, unsigned long long *keys_out, int *vals_out, s
 // compute unit; a launch takes what it is allowed (all of them, or MI355REC_SLIM_CUS of them when several models train side by
 // side) and sizes its grid by what it got.  A launch that gets fewer than 32 slots runs every step from the in-order queue, which
 // makes progress under any residency.
+// ... of ONE process: workgroups of another process's persistent kernel are as much in the owners' way as another thread's.  The
+// reference's search trains its candidates in a multiprocessing.Pool (ParameterTuning/run_parameter_search.py:498-503): two fits on
+// one GPU each used to launch one owner workgroup per compute unit, neither set became resident, and both aborted after the 5 s spin
+// budget with S half-updated.  Owners therefore also need the device's OWNER GATE: an advisory file lock (flock, released by the
+// kernel when its holder dies) on a per-user, per-device file; the process that holds it runs owners, everybody else runs every
+// step from the in-order queue -- slower, never stuck.  Taken with the first lease of a process, given back with the last.
+struct OwnerGate {
+    std::mutex lock;
+    int fd = -1, holders = 0;
+    bool acquire() {
+        std::lock_guard<std::mutex> g(lock);
+        if (holders > 0) { ++holders; return true; }
+        if (getenv("MI355REC_SLIM_NO_OWNER_GATE")) { ++holders; return true; }
+        int dev = 0;
+        char bus[64] = "unknown";
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev);
+        for (char *c = bus; *c; ++c)
+            if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+        const char *dir = getenv("MI355REC_LOCK_DIR") ? getenv("MI355REC_LOCK_DIR") : "/tmp";
+        char path[512];
+        snprintf(path, sizeof(path), "%s/mi355rec_slim_owners_%u_%s.lock", dir, (unsigned)getuid(), bus);
+        const int f = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        if (f < 0) return false;                       // no lock file, no owners: the queue-only mode is always correct
+        if (flock(f, LOCK_EX | LOCK_NB) != 0) {
+            close(f);
+            return false;                              // another process trains with owners on this device
+        }
+        fd = f;
+        holders = 1;
+        return true;
+    }
+    void release() {
+        std::lock_guard<std::mutex> g(lock);
+        if (holders > 0 && --holders == 0 && fd >= 0) {
+            (void)flock(fd, LOCK_UN);
+            close(fd);
+            fd = -1;
+        }
+    }
+};
+OwnerGate &owner_gate() {
+    static OwnerGate *g = new OwnerGate();
+    return *g;
+}
+
 std::atomic<int> g_owner_slots{-1};
 struct OwnerLease {
     int slots = 0;
+    bool gated = false;
     void take(bool wanted, int want) {
         if (!wanted) return;
+        if (!owner_gate().acquire()) return;           // (slots stays 0: queue-only launch)
+        gated = true;
         int expected = -1;
         g_owner_slots.compare_exchange_strong(expected, multiprocessor_count());      // first use: one slot per compute unit
         int have = g_owner_slots.load();
@@ -1623,6 +1676,8 @@ struct OwnerLease {
     void give_back() {
         if (slots) g_owner_slots.fetch_add(slots);
         slots = 0;
+        if (gated) owner_gate().release();
+        gated = false;
     }
     ~OwnerLease() { give_back(); }
 };
