@@ -443,3 +443,34 @@ def test_two_processes_train_dense_slim_on_one_device(gpu, tmp_path):
     # never both with owners in the same call would be the strict statement; what can be observed per process is that the work was done
     # in both modes or by both processes without an abort -- and that owners were used at all on this device
     assert max(o.max() for o in owned) > 0, owned
+
+
+def test_owner_gate_held_elsewhere_means_queue_only(gpu, tmp_path, monkeypatch):
+    """The gate itself, deterministically: while somebody else (here: a second open file description in this process, which flock
+    treats like another process) holds the device's lock file, a dense replay runs without owned rows; before and after, with them.
+    The three calls together still match the oracle."""
+    import fcntl
+    import glob
+    monkeypatch.setenv("MI355REC_LOCK_DIR", str(tmp_path))
+    X = named_urm("ml1m", "binary", scale=0.3)
+    kw = dict(symmetric=False, random_seed=7, sgd_mode="adagrad", learning_rate=0.01, li_reg=0.003, lj_reg=0.005)
+    orc = O.OracleSLIM(X, topK=False, final_model_sparse_weights=False, **kw)
+    orc.record_samples(10 ** 7)
+    for _ in range(6):
+        orc.epochIteration_Cython()
+    u, i, j = orc.recorded()
+    n = len(u) // 3
+    dev = SLIM_BPR_MI355X_Epoch(X, topK=False, final_model_sparse_weights=False, **kw)
+    dev.replay_samples(u[:n], i[:n], j[:n])
+    assert dev.schedule_info()[0] > 0
+    files = glob.glob(str(tmp_path / "mi355rec_slim_owners_*.lock"))
+    assert len(files) == 1, files
+    with open(files[0], "r+") as other:
+        fcntl.flock(other, fcntl.LOCK_EX | fcntl.LOCK_NB)        # free between calls: the library gives the gate back with the last lease
+        dev.replay_samples(u[n:2 * n], i[n:2 * n], j[n:2 * n])
+        assert dev.schedule_info()[0] == 0
+        fcntl.flock(other, fcntl.LOCK_UN)
+    dev.replay_samples(u[2 * n:], i[2 * n:], j[2 * n:])
+    assert dev.schedule_info()[0] > 0
+    assert_factor_parity(dev.get_S_dense(), orc.get_S_dense(), "adagrad", "S")
+    dev.close()
