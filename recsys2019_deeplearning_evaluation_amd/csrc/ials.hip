@@ -530,7 +530,8 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
 // Measured and not kept (round 5): the diagonal tile with DPP row broadcasts instead of v_readlane (factor alone 103 k cycles per row
 // against ~80 k; factor + inverse 559 k against 158 k), and no inverse at all -- panel tiles solved by substitution on the tile
 // wavefronts (DPP), back substitution by substitution on the panel wavefront: the Cholesky took 274 k cycles per row against 267 k, the
-// back substitution 60 k against 35 k.
+// back substitution 60 k against 35 k; the columns of L through LDS (broadcast reads) instead of SGPRs: diagonal tiles 317 k cycles per
+// row against 158 k (the panel wavefront's share of the 128 registers is small: its rows went to scratch).
 constexpr int TILE_WAVES = ROW_WAVES - 1;
 template <int SLOTS>
 __global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsParams p, int gram_slots) {
