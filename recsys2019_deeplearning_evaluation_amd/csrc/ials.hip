@@ -179,8 +179,14 @@ __device__ __forceinline__ void factor_and_invert_diagonal_tile(double *P, doubl
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         x[m] *= lane_bcast(my_inv, m);
+        // (The broadcasts of column m of L depend on nothing the loop computes, and left to itself the compiler reads all 120 of
+        // them into SGPRs up front -- twice as many as there are, so they are parked in VGPR lanes: 200 v_writelane + as many
+        // v_readlane per tile on the one chain every other wavefront of the workgroup waits for.  Tying the column to x[m] keeps
+        // each broadcast next to its use.)
+        double am = a[m];
+        asm volatile("" : "+v"(am) : "v"(x[m]));
 #pragma unroll
-        for (int rr = m + 1; rr < 16; ++rr) x[rr] -= lane_bcast(a[m], rr) * x[m];
+        for (int rr = m + 1; rr < 16; ++rr) x[rr] -= lane_bcast(am, rr) * x[m];
     }
     if (lane < 16) {
 #pragma unroll
@@ -580,6 +586,7 @@ __global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsPa
                 __syncthreads();                                     // the panel's tiles are in LDS
                 unsigned long long c0 = 0;
                 if (clock) c0 = ials_stamp();
+                // (s_setprio 3 around it -- the chain everybody waits for first at the issue port -- changes nothing: measured)
                 factor_and_invert_diagonal_tile(P, Ld + J * 16 * TP, lane);
                 if (clock) { asm volatile("" ::: "memory"); atomicAdd(&p.phases[5], ials_stamp() - c0); }
                 __syncthreads();
