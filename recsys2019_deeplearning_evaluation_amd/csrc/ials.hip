@@ -212,9 +212,15 @@ __device__ __forceinline__ int not_invariant(int v) {
 // Cholesky's cycles, measured) while the matrix pipe idles; the fused kernel holds the tiles AND the Gramian's staging in 256
 // registers, one workgroup per CU, so nothing else can run meanwhile.  The solve alone fits 128 registers: two workgroups per CU, and
 // one row's panel chain hides behind the other's trailing updates -- what the wide register file of a CU is for.
-template <int SLOTS, int STAGE>
-__global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams p) {
+// THREADS: 512 for the one-kernel epoch (256 registers per lane: tiles + staging of a whole row); the Gramian stage of a two-stage epoch
+// runs 1024 threads -- sixteen wavefronts with half the tiles each (6 slots at k = 200), four per SIMD instead of two: the row's
+// profile is staged once, and while two wavefronts of a SIMD wait at the chunk's barriers or for their operands the other two feed the
+// matrix pipe (with two per SIMD the Gramian reached 47 % of it).
+template <int SLOTS, int STAGE, int THREADS>
+__global__ __launch_bounds__(THREADS) void ials_row_kernel(const IalsParams p) {
     static_assert(STAGE == 0 || STAGE == 1, "the solve stage is ials_solve_kernel");
+    static_assert(THREADS == 512 || THREADS == 1024, "CHUNK profile rows are staged by THREADS / 64 wavefronts");
+    constexpr int WAVES = THREADS / 64, RPW = CHUNK / WAVES;      // profile rows a wavefront stages per chunk
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ short s_tI[MAX_NT], s_tJ[MAX_NT];
     __shared__ int s_row;
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
     double *const xv = zv + KP;                                     // [KP] solution
     double *const acc = xv + KP;                                    // [KP] sum of L[I][J]^T x_I over the tile rows already solved
 
-    for (int t = tid; t < NT; t += ROW_THREADS) {                   // tile t = I (I + 1) / 2 + J of the lower triangle
+    for (int t = tid; t < NT; t += THREADS) {                   // tile t = I (I + 1) / 2 + J of the lower triangle
         int I = 0;
         while ((I + 1) * (I + 2) / 2 <= t) ++I;
         s_tI[t] = (short)I;
@@ -239,12 +245,12 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
     int tIs[SLOTS], tJs[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        const int t = wave + ROW_WAVES * s;
+        const int t = wave + WAVES * s;
         tIs[s] = t < NT ? __builtin_amdgcn_readfirstlane((int)s_tI[t]) : -1;
         tJs[s] = t < NT ? __builtin_amdgcn_readfirstlane((int)s_tJ[t]) : -1;
     }
     const int Ik = k >> 4, rk = k & 15;                             // tile row and local row of the rhs row
-    // staging roles: wavefront w fetches profile rows 2 w and 2 w + 1 of a chunk, lanes across the factors (4 x 64 >= 224 + 1)
+    // staging roles: wavefront w fetches profile rows RPW w .. RPW w + RPW - 1 of a chunk, lanes across the factors (4 x 64 >= 224 + 1)
     constexpr int SPL = 4;
 
     for (;;) {
@@ -272,22 +278,22 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
 
         // (2a) the first chunk of profile rows is requested before anything else; item ids and confidences run one chunk
         // further ahead than the factor rows they address (two dependent global round trips otherwise)
-        constexpr size_t SYS_DOUBLES = (size_t)SLOTS * 4 * ROW_THREADS;
+        constexpr size_t SYS_DOUBLES = (size_t)SLOTS * 4 * THREADS;
         d4 C[SLOTS];
-        double pre[2][SPL];
-        double pre_c[2], next_c[2];
-        int next_item[2];
+        double pre[RPW][SPL];
+        double pre_c[RPW], next_c[RPW];
+        int next_item[RPW];
         auto fetch_ids = [&](int base) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = base + 2 * wave + h;
+            for (int h = 0; h < RPW; ++h) {
+                const int r = base + RPW * wave + h;
                 next_item[h] = r < end ? p.idx[r] : -1;
                 next_c[h] = r < end ? (double)p.conf[r] : 0.0;
             }
         };
         auto fetch_rows = [&]() {                                    // rows of the ids fetched last
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < RPW; ++h) {
                 const bool ok = next_item[h] >= 0;
                 pre_c[h] = next_c[h];
                 const double *src = p.Y + (size_t)(ok ? next_item[h] : 0) * k;
@@ -338,8 +344,8 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
             const int nr = min(CHUNK, end - base);
             __syncthreads();                                         // the previous chunk has been consumed
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = 2 * wave + h;
+            for (int h = 0; h < RPW; ++h) {
+                const int r = RPW * wave + h;
                 const double c = pre_c[h];
 #pragma unroll
                 for (int q = 0; q < SPL; ++q) {
@@ -374,13 +380,13 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
             }
         }
         if (item.z > 1) {
-            constexpr size_t PART_DOUBLES = (size_t)SLOTS * 4 * ROW_THREADS;
+            constexpr size_t PART_DOUBLES = (size_t)SLOTS * 4 * THREADS;
             {
                 double *dst = p.part_buf + (size_t)(item.w + item.y) * PART_DOUBLES;
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dst[(size_t)(s * 4 + i) * ROW_THREADS + tid] = C[s][i];
+                    for (int i = 0; i < 4; ++i) dst[(size_t)(s * 4 + i) * THREADS + tid] = C[s][i];
             }
             // every wavefront waits for its own stores; ONE thread then makes them visible device-wide (agent-scope release) and
             // counts the arrival; the last arriver acquires on behalf of the workgroup (same protocol as the similarity kernel's
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     double v = 0.0;
-                    for (int q = 0; q < item.z; ++q) v += src[(size_t)q * PART_DOUBLES + (size_t)(s * 4 + i) * ROW_THREADS + tid];
+                    for (int q = 0; q < item.z; ++q) v += src[(size_t)q * PART_DOUBLES + (size_t)(s * 4 + i) * THREADS + tid];
                     C[s][i] = v;
                 }
         }
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dst[(size_t)(s * 4 + i) * ROW_THREADS + tid] = C[s][i];
+                for (int i = 0; i < 4; ++i) dst[(size_t)(s * 4 + i) * THREADS + tid] = C[s][i];
             if (p.phases && tid == 0) {
                 atomicAdd(&p.phases[0], t1 - t0);
                 atomicAdd(&p.phases[1], t2 - t1);
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
 
         // (4) back substitution L^T x = z; z is row k of L (the forward substitution came with the factorisation)
         __syncthreads();
-        for (int f = tid; f < KP; f += ROW_THREADS) { xv[f] = 0.0; acc[f] = 0.0; zv[f] = 0.0; }
+        for (int f = tid; f < KP; f += THREADS) { xv[f] = 0.0; acc[f] = 0.0; zv[f] = 0.0; }
         __syncthreads();
         const int g = not_invariant(lane >> 4), cl = not_invariant(lane & 15);
 #pragma unroll
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ials_row_kernel(const IalsParams 
 // row against 158 k (the panel wavefront's share of the 128 registers is small: its rows went to scratch).
 constexpr int TILE_WAVES = ROW_WAVES - 1;
 template <int SLOTS>
-__global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsParams p, int gram_slots) {
+__global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsParams p, int gram_slots, int gram_threads) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ short s_tI[MAX_NT], s_tJ[MAX_NT];
     __shared__ int s_row;
@@ -560,7 +566,8 @@ __global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsPa
     }
     __syncthreads();
     const int Ik = k >> 4, rk = k & 15;                             // tile row and local row of the rhs row
-    const size_t sys_doubles = (size_t)gram_slots * 4 * ROW_THREADS;
+    const size_t sys_doubles = (size_t)gram_slots * 4 * gram_threads;      // (the Gramian stage's workgroup wrote the slab)
+    const int gram_waves = gram_threads / 64;
     // The two workgroups of a CU should not have their panel wavefronts on the same SIMD (both chains would share one issue port:
     // measured 120 k -> 158 k cycles of diagonal-tile work per row).  Wavefront w of a workgroup sits on SIMD w % 4 and the second
     // half of the grid is what doubles the CUs up (both observed, neither promised: a wrong guess costs speed only) -- the second
@@ -619,10 +626,10 @@ __global__ __launch_bounds__(ROW_THREADS, 4) void ials_solve_kernel(const IalsPa
                     const int t = tile_wave + TILE_WAVES * s;
                     tIs[s] = t < NT ? __builtin_amdgcn_readfirstlane((int)s_tI[t]) : -1;
                     tJs[s] = t < NT ? __builtin_amdgcn_readfirstlane((int)s_tJ[t]) : -1;
-                    // stage 1 left tile t in slot t / 8 of its wavefront t % 8
-                    const double *ts = src + (size_t)(t / ROW_WAVES) * 4 * ROW_THREADS + (t % ROW_WAVES) * 64 + lane;
+                    // stage 1 left tile t in slot t / W of its wavefront t % W (W wavefronts)
+                    const double *ts = src + (size_t)(t / gram_waves) * 4 * gram_threads + (t % gram_waves) * 64 + lane;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) C[s][i] = t < NT ? ts[(size_t)i * ROW_THREADS] : 0.0;
+                    for (int i = 0; i < 4; ++i) C[s][i] = t < NT ? ts[(size_t)i * gram_threads] : 0.0;
                 }
             }
             for (int J = 0; J < KT; ++J) {
@@ -805,18 +812,34 @@ void launch_gram(mi355rec_ials *h, const double *Y, int n) {
     }
 }
 
-template <int SLOTS, int STAGE>
+template <int SLOTS, int STAGE, int THREADS>
 void launch_rows_ts(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1) {
     const size_t lds = sizeof(double) * ials_lds_doubles(h->k, STAGE);
-    auto kern = ials_row_kernel<SLOTS, STAGE>;
+    auto kern = ials_row_kernel<SLOTS, STAGE, THREADS>;
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(ROW_THREADS), (unsigned)lds, h->stream, e0, e1, 0, p);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), (unsigned)lds, h->stream, e0, e1, 0, p);
 }
 
 template <int SLOTS>
-void launch_rows_t(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1, int stage) {
-    if (stage == 1) launch_rows_ts<SLOTS, 1>(h, p, grid, e0, e1);
-    else launch_rows_ts<SLOTS, 0>(h, p, grid, e0, e1);
+void launch_rows_t(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1, int) {
+    launch_rows_ts<SLOTS, 0, ROW_THREADS>(h, p, grid, e0, e1);
+}
+
+// The Gramian stage of a two-stage epoch: 1024 threads, tiles over sixteen wavefronts
+constexpr int GRAM_THREADS = 1024, GRAM_WAVES = GRAM_THREADS / 64;
+int gram_slots_of(int NT) { return (NT + GRAM_WAVES - 1) / GRAM_WAVES; }
+void launch_gram_stage(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1) {
+    const int KT = (h->k + 1 + 15) / 16, NT = KT * (KT + 1) / 2;
+    switch (gram_slots_of(NT)) {
+        case 1: launch_rows_ts<1, 1, GRAM_THREADS>(h, p, grid, e0, e1); break;
+        case 2: launch_rows_ts<2, 1, GRAM_THREADS>(h, p, grid, e0, e1); break;
+        case 3: launch_rows_ts<3, 1, GRAM_THREADS>(h, p, grid, e0, e1); break;
+        case 4: launch_rows_ts<4, 1, GRAM_THREADS>(h, p, grid, e0, e1); break;
+        case 5: launch_rows_ts<5, 1, GRAM_THREADS>(h, p, grid, e0, e1); break;
+        case 6: launch_rows_ts<6, 1, GRAM_THREADS>(h, p, grid, e0, e1); break;
+        case 7: launch_rows_ts<7, 1, GRAM_THREADS>(h, p, grid, e0, e1); break;
+        default: launch_rows_ts<8, 1, GRAM_THREADS>(h, p, grid, e0, e1); break;
+    }
 }
 
 template <int SLOTS>
@@ -824,7 +847,7 @@ void launch_solve_t(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t 
     const size_t lds = sizeof(double) * ials_lds_doubles(h->k, 2);
     auto kern = ials_solve_kernel<SLOTS>;
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(ROW_THREADS), (unsigned)lds, h->stream, e0, e1, 0, p, gram_slots);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(ROW_THREADS), (unsigned)lds, h->stream, e0, e1, 0, p, gram_slots, (int)GRAM_THREADS);
 }
 
 // the solve stage holds the tiles on 7 wavefronts: up to 13 slots (k <= 207) fit two workgroups per CU
@@ -869,6 +892,12 @@ void launch_rows(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0,
     }
 }
 
+// doubles of one row's augmented system (or of one part of a split row) as the kernel that builds it lays it out
+size_t slab_doubles(const mi355rec_ials *h, bool two_stage) {
+    const int KT = (h->k + 1 + 15) / 16, NT = KT * (KT + 1) / 2;
+    return two_stage ? (size_t)gram_slots_of(NT) * 4 * GRAM_THREADS : (size_t)row_slots(NT) * 4 * ROW_THREADS;
+}
+
 // Two-stage epochs: on unless MI355REC_IALS_TWO_STAGE=0 or the solve stage's 13 tile slots do not cover k (k > 207).
 bool two_stage_epochs(const mi355rec_ials *h) {
     const char *ts = getenv("MI355REC_IALS_TWO_STAGE");
@@ -878,8 +907,7 @@ bool two_stage_epochs(const mi355rec_ials *h) {
 
 // Rows whose systems the buffer holds at a time: MI355REC_IALS_SYSTEM_GIB (default 8) worth of slabs, at most the longer side.
 int rows_per_batch(const mi355rec_ials *h) {
-    const int KT = (h->k + 1 + 15) / 16, NT = KT * (KT + 1) / 2;
-    const size_t sys_bytes = (size_t)row_slots(NT) * 4 * ROW_THREADS * sizeof(double);
+    const size_t sys_bytes = slab_doubles(h, true) * sizeof(double);
     double gib = 8.0;
     if (getenv("MI355REC_IALS_SYSTEM_GIB")) gib = std::max(0.001, atof(getenv("MI355REC_IALS_SYSTEM_GIB")));
     const size_t longest = (size_t)std::max(h->n_users, h->n_items);
@@ -943,8 +971,7 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
     MI_HIP(hipMemcpyAsync(h->items.ptr, h->items_host.data(), sizeof(int4) * n_work, hipMemcpyHostToDevice, h->stream));
     MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(unsigned), h->stream));
     if (part_slots) {
-        const int KT_ = (h->k + 1 + 15) / 16, NT_ = KT_ * (KT_ + 1) / 2;
-        const size_t part_doubles = (size_t)row_slots(NT_) * 4 * ROW_THREADS;
+        const size_t part_doubles = slab_doubles(h, two_stage_epochs(h));
         if (h->part_buf.count < (size_t)part_slots * part_doubles) h->part_buf.alloc((size_t)part_slots * part_doubles);
         if (h->part_count.count < (size_t)part_slots) h->part_count.alloc((size_t)part_slots);
         MI_HIP(hipMemsetAsync(h->part_count.ptr, 0, sizeof(unsigned) * part_slots, h->stream));
@@ -979,7 +1006,7 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
         MI_HIP(hipGetLastError());
     } else {
         const int KT_ = (h->k + 1 + 15) / 16, NT_ = KT_ * (KT_ + 1) / 2;
-        const size_t sys_doubles = (size_t)row_slots(NT_) * 4 * ROW_THREADS;
+        const size_t sys_doubles = slab_doubles(h, true);
         const int per_batch = std::min(std::max(1, n_local), rows_per_batch(h));
         const int n_batches = (n_local + per_batch - 1) / per_batch;
         h->n_batches = n_batches;
@@ -1024,8 +1051,8 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
                 MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(unsigned), h->stream));
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 h->dispatch_timers.next(e0, e1, 1 << 30);
-                if (stage == 1) launch_rows(h, p, std::min(p.n_local, grid_cap), e0, e1, 1);
-                else launch_solve(h, p, std::min(p.n_local, 2 * grid_cap), e0, e1, row_slots(NT_));
+                if (stage == 1) launch_gram_stage(h, p, std::min(p.n_local, grid_cap), e0, e1);
+                else launch_solve(h, p, std::min(p.n_local, 2 * grid_cap), e0, e1, gram_slots_of(NT_));
                 MI_HIP(hipGetLastError());
             }
         }
@@ -1054,8 +1081,7 @@ void begin_call(mi355rec_ials *h) {
     // (the buffer of the two-stage epochs is allocated here, before the call's clock starts: 8 GiB of hipMalloc took 0.4 s of the
     // first epoch's "call_ms" when half_step did it)
     if (two_stage_epochs(h)) {
-        const int KT = (h->k + 1 + 15) / 16, NT = KT * (KT + 1) / 2;
-        const size_t need = (size_t)rows_per_batch(h) * row_slots(NT) * 4 * ROW_THREADS;
+        const size_t need = (size_t)rows_per_batch(h) * slab_doubles(h, true);
         if (h->systems.count < need) h->systems.alloc(need);
     }
     h->dispatch_timers.reset();
