@@ -215,7 +215,8 @@ __device__ __forceinline__ int not_invariant(int v) {
 // THREADS: 512 for the one-kernel epoch (256 registers per lane: tiles + staging of a whole row); the Gramian stage of a two-stage epoch
 // runs 1024 threads -- sixteen wavefronts with half the tiles each (6 slots at k = 200), four per SIMD instead of two: the row's
 // profile is staged once, and while two wavefronts of a SIMD wait at the chunk's barriers or for their operands the other two feed the
-// matrix pipe (with two per SIMD the Gramian reached 47 % of it).
+// matrix pipe (with two per SIMD the Gramian reached 47 % of it).  (Measured and not kept: two chunks staged in LDS, chunk n + 1 written
+// while chunk n is multiplied, one barrier per chunk -- 161 k cycles per user row against 99 k.)
 template <int SLOTS, int STAGE, int THREADS>
 __global__ __launch_bounds__(THREADS) void ials_row_kernel(const IalsParams p) {
     static_assert(STAGE == 0 || STAGE == 1, "the solve stage is ials_solve_kernel");
