@@ -2014,9 +2014,22 @@ void run_epochs_typed(mi355rec_slim *h, int n_epochs) {
             launch_stream<T>(h, st, n, 0, L);
             // ... and while it runs: the next epoch's stream, into the other set (kept for the next call if this was the last)
             StreamSet &nx = h->set[h->cur];
-            draw_epoch<T>(h, nx, epoch + 1, n, h->side);
-            schedule_stream(h, nx, n, 0, h->side);
-            nx.epoch = epoch + 1;
+            try {
+                draw_epoch<T>(h, nx, epoch + 1, n, h->side);
+                schedule_stream(h, nx, n, 0, h->side);
+                nx.epoch = epoch + 1;
+            } catch (...) {
+                // The look-ahead failed (allocation, a HIP error) while this epoch's kernel is in flight: finish the epoch first --
+                // drain, return the lease, advance the counters (S has moved) -- and drop the half-made set; only then report
+                // (the lease went back with owners still resident and the epoch would have been applied twice).
+                nx.epoch = -1;
+                nx.n = 0;
+                finish_stream(h, L, n);
+                h->cur ^= 1;
+                h->epochs_done += 1;
+                h->last_native = true;
+                throw;
+            }
             finish_stream(h, L, n);
         }
         h->cur ^= 1;
