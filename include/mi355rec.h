@@ -42,6 +42,11 @@ int mi355rec_device_malloc(void **out, uint64_t bytes);
 int mi355rec_device_free(void *p);
 int mi355rec_device_memcpy(void *dst, const void *src, uint64_t bytes, int to_device);
 int mi355rec_device_synchronize(void);
+/* Device blocks that handles have released stay in a per-process cache (hipFree drains the device and costs 0.2 - 0.5 ms per block: a
+ * dozen temporaries made up a third of a similarity constructor); at most MI355REC_POOL_BYTES of them (default 8 GiB of the device's 288, 0: no cache).
+ * mi355rec_device_trim gives every cached block back to the driver -- for a process that shares the device with another allocator
+ * (PyTorch, RCCL) and is done with a phase of fits; *freed_bytes (nullable) receives what was returned. */
+int mi355rec_device_trim(uint64_t *freed_bytes);
 /* Number of visible HIP devices (0 and MI355REC_OK when none). */
 int mi355rec_device_count(int *count);
 /* Select the device used by handles created afterwards in this process (one process per GPU: LOCAL_RANK). */

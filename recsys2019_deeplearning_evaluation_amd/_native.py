@@ -75,6 +75,7 @@ SIGNATURES = {
     "mi355rec_device_free": (C.c_int, [_vp]),
     "mi355rec_device_memcpy": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int]),
     "mi355rec_device_synchronize": (C.c_int, []),
+    "mi355rec_device_trim": (C.c_int, [C.POINTER(C.c_uint64)]),
     "mi355rec_sim_create": (C.c_int, [C.POINTER(_vp), C.POINTER(SimConfig), _i32, _i32, _vp, _vp, _vp, _vp]),
     "mi355rec_sim_create_resident": (C.c_int, [C.POINTER(_vp), C.POINTER(SimConfig), _i32, _i32, _vp, _vp, _vp, _vp]),
     "mi355rec_sim_get_weighted_values": (C.c_int, [_vp, _vp]),
@@ -214,6 +215,14 @@ def as_f32(a):
 
 def as_f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def trim_device_cache():
+    """Give the library's cache of released device blocks back to the driver (a process that shares the GPU with PyTorch / RCCL calls
+    this between phases of fits); returns the bytes freed."""
+    freed = C.c_uint64(0)
+    check(load().mi355rec_device_trim(C.byref(freed)))
+    return int(freed.value)
 
 
 class DeviceArray:

@@ -62,8 +62,8 @@ int multiprocessor_count();
 // Blocks go back to a small per-process cache instead of hipFree (which drains the device and costs 0.2 - 0.5 ms per block: a dozen
 // temporaries made up a third of the similarity constructor): device_block() hands out a cached block of at least -- and at most
 // twice -- the size asked for, or calls hipMalloc.  Like hipFree, returning a block waits for the device first (the block may be
-// handed to another stream next).  Blocks above 1 GiB are not cached; the cache holds at most MI355REC_POOL_BYTES (default 8 GiB,
-// 0 switches it off).
+// handed to another stream next).  Blocks above 1 GiB are not cached; the cache holds at most MI355REC_POOL_BYTES (default 8 GiB of
+// the 288, 0 switches it off); mi355rec_device_trim empties it.
 void *device_block(size_t bytes);
 void device_block_return(void *p, size_t bytes);
 

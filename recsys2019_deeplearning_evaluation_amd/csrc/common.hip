@@ -256,6 +256,23 @@ extern "C" int mi355rec_device_memcpy(void *dst, const void *src, uint64_t bytes
     });
 }
 
+extern "C" int mi355rec_device_trim(uint64_t *freed_bytes) {
+    return guarded([&] {
+        BlockCache &c = block_cache();
+        std::vector<void *> drop;
+        size_t bytes = 0;
+        {
+            std::lock_guard<std::mutex> g(c.lock);
+            for (auto &kv : c.free_blocks) drop.push_back(kv.second);
+            bytes = c.cached;
+            c.free_blocks.clear();
+            c.cached = 0;
+        }
+        for (void *q : drop) (void)hipFree(q);
+        if (freed_bytes) *freed_bytes = (uint64_t)bytes;
+    });
+}
+
 extern "C" int mi355rec_device_synchronize(void) {
     return guarded([&] {
         ensure_device();

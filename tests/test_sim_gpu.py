@@ -743,3 +743,18 @@ def test_resident_urm_build_equals_host_build(gpu):
     rec_res.fit(topK=10, shrink=1, resident_urm=res)
     assert (rec.W_sparse != rec_res.W_sparse).nnz == 0
     res.close()
+
+
+def test_device_cache_trim(gpu):
+    """mi355rec_device_trim: the blocks a closed handle left in the library's cache go back to the driver (a process that shares the
+    device with another allocator calls it between phases); builds afterwards work as before."""
+    from recsys2019_deeplearning_evaluation_amd import _native as N
+    X = named_urm("ml1m", "binary", scale=0.5)
+    dev = Compute_Similarity_MI355X(X, topK=10)
+    before = dev.compute_similarity()
+    dev.close()
+    assert N.trim_device_cache() > 0                     # the constructor's temporaries and the handle's arrays were cached
+    assert N.trim_device_cache() == 0
+    dev = Compute_Similarity_MI355X(X, topK=10)
+    assert (dev.compute_similarity() != before).nnz == 0
+    dev.close()
