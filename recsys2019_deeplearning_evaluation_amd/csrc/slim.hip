@@ -1643,6 +1643,33 @@ struct OwnerGate {
         holders = 1;
         return true;
     }
+    // Blocking variant for the symmetric store's launch, which has no queue-only mode to fall back to: its long-profile workgroups wait
+    // for steps that only its short-profile workgroups run, so TWO such kernels on one device (two handles in threads, two processes)
+    // may leave each other's short workgroups non-resident and spin into the 5 s budget.  Symmetric launches of a device
+    // therefore run one at a time: `serial` inside the process, the file lock across processes (held from launch to finish).
+    std::mutex serial;
+    bool acquire_blocking() {
+        serial.lock();
+        std::lock_guard<std::mutex> g(lock);
+        if (holders > 0 || getenv("MI355REC_SLIM_NO_OWNER_GATE")) { ++holders; return true; }
+        int dev = 0;
+        char bus[64] = "unknown";
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev);
+        for (char *c = bus; *c; ++c)
+            if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+        const char *dir = getenv("MI355REC_LOCK_DIR") ? getenv("MI355REC_LOCK_DIR") : "/tmp";
+        char path[512];
+        snprintf(path, sizeof(path), "%s/mi355rec_slim_owners_%u_%s.lock", dir, (unsigned)getuid(), bus);
+        const int f = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        if (f >= 0 && flock(f, LOCK_EX) == 0) fd = f;          // (no lock file: in-process serialisation only)
+        else if (f >= 0) close(f);
+        holders = 1;
+        return true;
+    }
+    void release_blocking() {
+        release();
+        serial.unlock();
+    }
     void release() {
         std::lock_guard<std::mutex> g(lock);
         if (holders > 0 && --holders == 0 && fd >= 0) {
@@ -1795,7 +1822,12 @@ void schedule_stream(mi355rec_slim *h, StreamSet &st, int n, int first, hipStrea
 
 struct Launched {
     OwnerLease lease;
-    bool dense = false, profile = false;
+    bool dense = false, profile = false, serial = false;
+    void end_serial() {
+        if (serial) owner_gate().release_blocking();
+        serial = false;
+    }
+    ~Launched() { end_serial(); }
 };
 
 // The dataflow kernel of a scheduled stream, enqueued on the handle's main stream.
@@ -1838,6 +1870,7 @@ void launch_stream(mi355rec_slim *h, StreamSet &st, int n, int first, Launched &
             const int long_wgs = std::min(n_long, std::max(1, std::min(most - 1, env_int("MI355REC_SLIM_SYM_LONG_WGS", most / 4))));
             const int grid = long_wgs + std::max(1, std::min(div_up(st.n_short, FLOW_WAVES), most - long_wgs));
             h->dispatch_timers.next(e0, e1, 1 << 30);
+            L.serial = owner_gate().acquire_blocking();              // one symmetric dataflow kernel per device at a time
             hipExtLaunchKernelGGL(slim_sym_flow_kernel, dim3(grid), dim3(FLOW_THREADS), 0, s, e0, e1, 0, p, long_wgs);
         }
     } else {
@@ -1897,6 +1930,7 @@ void finish_stream(mi355rec_slim *h, Launched &L, int n) {
     if (L.dense) MI_HIP(hipMemcpyAsync(counters, h->counters.ptr, sizeof(counters), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
     L.lease.give_back();
+    L.end_serial();
     if (L.dense) {
         h->last_owners = counters[0];
         h->last_cold = counters[1];

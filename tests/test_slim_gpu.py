@@ -474,3 +474,39 @@ def test_owner_gate_held_elsewhere_means_queue_only(gpu, tmp_path, monkeypatch):
     assert dev.schedule_info()[0] > 0
     assert_factor_parity(dev.get_S_dense(), orc.get_S_dense(), "adagrad", "S")
     dev.close()
+
+
+def test_two_symmetric_handles_train_concurrently(gpu):
+    """The symmetric store's dataflow kernel has no queue-only mode: its long-profile workgroups wait for steps only its short-profile
+    workgroups run, so two such kernels competing for the device could keep each other's short workgroups out.  Symmetric
+    launches of a device run one at a time (in-process mutex + the device's lock file): two threads, each replaying its own stream
+    on its own handle in several calls, both finish and both match the oracle."""
+    import threading
+    X = named_urm("ml1m", "binary", scale=0.2)
+    results, errors = {}, []
+
+    def work(tag, seed):
+        try:
+            kw = dict(symmetric=True, random_seed=seed, sgd_mode="adagrad", learning_rate=0.01, li_reg=0.003, lj_reg=0.005)
+            orc = O.OracleSLIM(X, topK=False, final_model_sparse_weights=False, **kw)
+            orc.record_samples(10 ** 7)
+            for _ in range(6):
+                orc.epochIteration_Cython()
+            u, i, j = orc.recorded()
+            dev = SLIM_BPR_MI355X_Epoch(X, topK=False, final_model_sparse_weights=False, **kw)
+            n = len(u) // 6
+            for part in range(6):
+                dev.replay_samples(u[part * n:(part + 1) * n], i[part * n:(part + 1) * n], j[part * n:(part + 1) * n])
+            results[tag] = (dev.get_S_dense(), orc.get_S_dense())
+            dev.close()
+        except Exception as exc:           # noqa: BLE001 (reported below, in the main thread)
+            errors.append((tag, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(t, 40 + t)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for tag in range(2):
+        assert_factor_parity(results[tag][0], results[tag][1], "adagrad", "S (thread %d)" % tag)
