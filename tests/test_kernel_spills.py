@@ -20,7 +20,7 @@ def test_ials_row_kernel_spills_are_per_row_not_in_the_mfma_loops(tmp_path):
     src = os.path.join(ROOT, "recsys2019_deeplearning_evaluation_amd", "csrc", "ials.hip")
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-S", "--cuda-device-only",
                     src, "-o", asm], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    found = audit(asm, "ials_row_kernelILi12E", "v_mfma")
+    found = audit(asm, "ials_row_kernelILi12ELi0ELi512E", "v_mfma")          # the one-kernel epoch at k = 200: <SLOTS 12, STAGE 0, 512 threads>
     assert len(found) == 1
     k = next(iter(found.values()))
     mfma_depths = set(k["hot"])
@@ -30,8 +30,20 @@ def test_ials_row_kernel_spills_are_per_row_not_in_the_mfma_loops(tmp_path):
     assert max(scratch_depths, default=0) <= 1
     # the instances below 12 slots do not spill at all
     for slots in (1, 2, 4, 6, 8, 10):
-        small = audit(asm, "ials_row_kernelILi%dE" % slots, "v_mfma")
+        small = audit(asm, "ials_row_kernelILi%dELi0ELi512E" % slots, "v_mfma")
         assert len(small) == 1 and not next(iter(small.values()))["scratch"], slots
+    # round 5, two-stage epochs.  The Gramian stage (1024 threads = 128 registers per lane, 6 tile slots at k = 200) has no scratch at
+    # all; the solve stage must fit 128 registers (two workgroups per CU is the point of it) and keeps what it spills out of the
+    # blocks that hold its MFMAs' operand loads: at most a handful of reloads per panel, none deeper.
+    gram = audit(asm, "ials_row_kernelILi6ELi1ELi1024E", "v_mfma")
+    assert len(gram) == 1 and not next(iter(gram.values()))["scratch"], gram
+    assert _resource(asm, "ials_row_kernelILi6ELi1ELi1024E", "NumVgprs") <= 128
+    solve = audit(asm, "ials_solve_kernelILi13E", "v_mfma")
+    assert len(solve) == 1
+    sk = next(iter(solve.values()))
+    assert _resource(asm, "ials_solve_kernelILi13E", "NumVgprs") <= 128
+    assert _resource(asm, "ials_solve_kernelILi13E", "Occupancy") >= 4           # 4 wavefronts per SIMD = two 512-thread workgroups per CU
+    assert max((d for (_, d) in sk["scratch"]), default=0) <= 2 and sum(n for (kind, d), n in sk["scratch"].items() if d == 2) <= 32, sk["scratch"]
 
 
 def _kernel_text(asm_path, mangled_fragment):
