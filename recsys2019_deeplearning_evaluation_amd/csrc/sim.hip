@@ -465,7 +465,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         // ranked by (value, lowest index first) and the first K emitted.  The result is identical to the full path's, bit for bit
         // (tests/test_sim_gpu.py::test_fast_topk_equals_full_selection).  Fewer than K positive thread maxima (sparse columns) or
         // more survivors than the candidate buffer holds (4 096: masses of equal values): the full path runs, the accumulator is untouched.
-        if (CELL32 && p.fast_topk) {
+        if (CELL32 && p.fast_topk && !(item.z == 1 && item.w == 1)) {          // (.w == 1: a light column, see the schedule)
             const bool asym = p.normalize && p.kind == MI355REC_SIM_ASYMMETRIC;
             const float norm_c = asym ? p.norm_alpha[c] : p.norm[c];
             const float4 *nj4 = reinterpret_cast<const float4 *>(asym ? p.norm_1ma : p.norm);
@@ -1481,7 +1481,11 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
             ++n_split;
         } else {
             keyed.emplace_back(h->cost[c], (int)h->items_host.size());
-            h->items_host.push_back(make_int4(c, 0, 1, 0));
+            // .w of an unsplit column: 1 = LIGHT -- fewer than 16 K pair-adds cannot leave K positive thread maxima behind (real
+            // catalogues: half of ML-20M's items have fewer than 20 ratings), so the threshold-first selection would scan the
+            // accumulator twice only to hand the column to the full path, which is quick on such columns anyway (all-zero quads
+            // are skipped, nothing to select among fewer than K positives)
+            h->items_host.push_back(make_int4(c, 0, 1, h->cost[c] < 16ll * std::max(1, h->cfg.topK) ? 1 : 0));
         }
     }
     if (n_split) {

@@ -698,11 +698,16 @@ def test_threshold_first_topk_small_instance_and_sparse_columns(gpu, monkeypatch
         np.testing.assert_array_equal(idx, idx0)
         np.testing.assert_array_equal(val, val0)
         assert info[0] > 0, info
-    Xs = synthetic_urm(400, 3000, 6000, min_len=1, max_len=40, seed=3, values="binary")      # nearly every column has < K neighbours
+    Xs = synthetic_urm(400, 3000, 6000, min_len=1, max_len=40, seed=3, values="binary")      # every column has < K neighbours
     (idx, val, info), (idx0, val0, _) = _slabs_both_selections(Xs, monkeypatch, topK=50, shrink=0)
     np.testing.assert_array_equal(idx, idx0)
     np.testing.assert_array_equal(val, val0)
-    assert 0 < info[0] < 0.5 * Xs.shape[1], info
+    assert info == (0, 0, 0), info                    # light columns (< 16 K pair-adds) are scheduled straight onto the full path
+    Xm = synthetic_urm(2500, 3000, 60000, min_len=2, max_len=300, seed=4, values="binary")   # in between: some columns reach K positive maxima
+    (idx, val, info), (idx0, val0, _) = _slabs_both_selections(Xm, monkeypatch, topK=50, shrink=0)
+    np.testing.assert_array_equal(idx, idx0)
+    np.testing.assert_array_equal(val, val0)
+    assert 0 < info[0] < Xm.shape[1], info
 
 
 def test_threshold_first_topk_falls_back_on_masses_of_equal_values(gpu, monkeypatch):
