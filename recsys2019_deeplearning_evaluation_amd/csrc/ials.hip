@@ -22,6 +22,10 @@ namespace mi355rec {
 namespace {
 
 constexpr int CHUNK = 16;   // profile rows staged per LDS round
+#ifndef MI355REC_IALS_GRAM_CHUNK
+#define MI355REC_IALS_GRAM_CHUNK 32
+#endif
+constexpr int GRAM_CHUNK = MI355REC_IALS_GRAM_CHUNK;   // ... by the Gramian stage of a two-stage epoch
 
 struct IalsParams {
     int k;
@@ -139,7 +143,7 @@ __device__ __forceinline__ double swap_sum32(double v) {
 // doubles of dynamic LDS the kernel needs for k factors
 static inline size_t ials_lds_doubles(int k, int stage = 0) {
     const int KT = (k + 1 + 15) / 16, KP = KT * 16;
-    const int first = stage == 2 ? KT * 16 * TP : (stage == 1 ? 2 * CHUNK * KP : std::max(2 * CHUNK * KP, KT * 16 * TP));
+    const int first = stage == 2 ? KT * 16 * TP : (stage == 1 ? 2 * GRAM_CHUNK * KP : std::max(2 * CHUNK * KP, KT * 16 * TP));
     return (size_t)first + (size_t)KT * 16 * TP + (size_t)KT * 16 + 3 * (size_t)KP;   // staging | panel, Linv, z / x / acc
 }
 
@@ -221,6 +225,8 @@ template <int SLOTS, int STAGE, int THREADS>
 __global__ __launch_bounds__(THREADS) void ials_row_kernel(const IalsParams p) {
     static_assert(STAGE == 0 || STAGE == 1, "the solve stage is ials_solve_kernel");
     static_assert(THREADS == 512 || THREADS == 1024, "CHUNK profile rows are staged by THREADS / 64 wavefronts");
+    // profile rows staged per LDS round: 16; the Gramian stage (which has the LDS to itself) takes GRAM_CHUNK -- half as many barriers per row
+    constexpr int CHUNK = STAGE == 1 ? GRAM_CHUNK : mi355rec::CHUNK;
     constexpr int WAVES = THREADS / 64, RPW = CHUNK / WAVES;      // profile rows a wavefront stages per chunk
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ short s_tI[MAX_NT], s_tJ[MAX_NT];
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(THREADS) void ials_row_kernel(const IalsParams p) {
     double *const ya = lds;                                         // [CHUNK][KP]   A side: (c - 1) y, c in column k
     double *const yb = ya + CHUNK * KP;                             // [CHUNK][KP]   B side: y
     double *const P = lds;                                          // [KT][16][TP]  panel tiles (aliases the staging area)
-    double *const Linv = lds + (STAGE == 1 ? 2 * CHUNK * KP : max(2 * CHUNK * KP, KT * 16 * TP));   // [KT][16][TP]  inverses of the factored diagonal tiles
+    double *const Linv = lds + (STAGE == 1 ? 2 * GRAM_CHUNK * KP : max(2 * CHUNK * KP, KT * 16 * TP));   // [KT][16][TP]  inverses of the factored diagonal tiles
     double *const zv = Linv + KT * 16 * TP + KT * 16;               // [KP] forward-substituted rhs
     double *const xv = zv + KP;                                     // [KP] solution
     double *const acc = xv + KP;                                    // [KP] sum of L[I][J]^T x_I over the tile rows already solved

@@ -32,11 +32,13 @@ def test_ials_row_kernel_spills_are_per_row_not_in_the_mfma_loops(tmp_path):
     for slots in (1, 2, 4, 6, 8, 10):
         small = audit(asm, "ials_row_kernelILi%dELi0ELi512E" % slots, "v_mfma")
         assert len(small) == 1 and not next(iter(small.values()))["scratch"], slots
-    # round 5, two-stage epochs.  The Gramian stage (1024 threads = 128 registers per lane, 6 tile slots at k = 200) has no scratch at
-    # all; the solve stage must fit 128 registers (two workgroups per CU is the point of it) and keeps what it spills out of the
+    # round 5, two-stage epochs.  The Gramian stage (1024 threads = 128 registers per lane, 6 tile slots at k = 200, 32 profile rows
+    # staged per round) keeps its few spilled words at row level, never in a block with an MFMA; the solve stage must fit 128 registers (two workgroups per CU is the point of it) and keeps what it spills out of the
     # blocks that hold its MFMAs' operand loads: at most a handful of reloads per panel, none deeper.
     gram = audit(asm, "ials_row_kernelILi6ELi1ELi1024E", "v_mfma")
-    assert len(gram) == 1 and not next(iter(gram.values()))["scratch"], gram
+    assert len(gram) == 1
+    gk = next(iter(gram.values()))
+    assert max((d for (_, d) in gk["scratch"]), default=0) <= 1 and min(gk["hot"]) >= 2, (gk["scratch"], gk["hot"])
     assert _resource(asm, "ials_row_kernelILi6ELi1ELi1024E", "NumVgprs") <= 128
     solve = audit(asm, "ials_solve_kernelILi13E", "v_mfma")
     assert len(solve) == 1
