@@ -13,6 +13,7 @@
 //                    the kernel: augmented system in 16 x 16 register tiles, Gramian and trailing updates as MFMAs, blocked
 //                    Cholesky with an in-register diagonal-tile factorisation, back substitution through the tile inverses.
 #include "common.h"
+#include "ials_diag.cuh"
 
 #include <algorithm>
 #include <memory>
@@ -114,17 +115,10 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *Y, int n, int k
 // Round 1 kept 32 x 32 register tiles on the FP64 vector pipe with one barrier per column: VALU-issue bound in the
 // factorisation (2240 cycles per column: 28 multiply-adds among ~180 instructions on 16 wavefronts) and staging-latency bound
 // in the Gramian (1440 cycles per profile row); measured 832 k cycles per user row at ML-20M shape, k = 200.
-typedef double d4 __attribute__((ext_vector_type(4)));
-constexpr int TP = 17;                   // padded row length of a 16 x 16 tile staged in LDS (conflict-free operand reads)
 constexpr int MAX_KT = 15, MAX_NT = MAX_KT * (MAX_KT + 1) / 2;
 constexpr int ROW_THREADS = 512, ROW_WAVES = ROW_THREADS / 64;   // 2 wavefronts per SIMD: 256 VGPRs for the tiles of a wavefront
 constexpr double AUG_DIAG = 1e200;       // diagonal of the rhs row: keeps the last pivot positive, never used
 
-__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
-    const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_readlane((int)b, src_lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
-}
 __device__ __forceinline__ double swap_sum16(double v) {
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
     auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
@@ -145,60 +139,6 @@ static inline size_t ials_lds_doubles(int k, int stage = 0) {
     const int KT = (k + 1 + 15) / 16, KP = KT * 16;
     const int first = stage == 2 ? KT * 16 * TP : (stage == 1 ? 2 * GRAM_CHUNK * KP : std::max(2 * CHUNK * KP, KT * 16 * TP));
     return (size_t)first + (size_t)KT * 16 * TP + (size_t)KT * 16 + 3 * (size_t)KP;   // staging | panel, Linv, z / x / acc
-}
-
-// 1 / sqrt(d) in full double precision from v_rsq_f64 and two Newton steps (the IEEE sqrt + divide sequences are ~50
-// instructions on the critical path of every pivot)
-__device__ __forceinline__ double fast_rsqrt(double d) {
-    double y = __builtin_amdgcn_rsq(d);
-    y = y * (1.5 - 0.5 * d * y * y);
-    y = y * (1.5 - 0.5 * d * y * y);
-    return y;
-}
-
-// The 16 x 16 diagonal tile of a panel (row-major in LDS, TP doubles per row) -> its Cholesky factor in place (upper part
-// cleared) and the inverse of that factor in `inv_tile`.  One wavefront, no barriers inside.
-__device__ __forceinline__ void factor_and_invert_diagonal_tile(double *P, double *inv_tile, int lane) {
-    const int r = lane & 15;
-    double a[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = P[r * TP + c];
-    double my_inv = 0.0;
-    // right-looking, all in registers: lane r holds row r; the pivot and the scaled column travel between lanes as v_readlane
-    // broadcasts (no LDS round trip on the dependent chain: 128 cycles per column when they did)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double d = lane_bcast(a[j], j);
-        const double inv = fast_rsqrt(d);
-        const double lj = r > j ? a[j] * inv : (r == j ? d * inv : 0.0);     // L[r][j]
-        a[j] = lj;
-        if (r == j) my_inv = inv;
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) a[c] -= lj * lane_bcast(lj, c);      // only cells with c <= r are ever used
-    }
-    // the inverse, lane c computes column c: x starts as e_c; once x_m is final every later entry loses L[rr][m] x_m
-    double x[16];
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) x[rr] = r == rr ? 1.0 : 0.0;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        x[m] *= lane_bcast(my_inv, m);
-        // (The broadcasts of column m of L depend on nothing the loop computes, and left to itself the compiler reads all 120 of
-        // them into SGPRs up front -- twice as many as there are, so they are parked in VGPR lanes: 200 v_writelane + as many
-        // v_readlane per tile on the one chain every other wavefront of the workgroup waits for.  Tying the column to x[m] keeps
-        // each broadcast next to its use.)
-        double am = a[m];
-        asm volatile("" : "+v"(am) : "v"(x[m]));
-#pragma unroll
-        for (int rr = m + 1; rr < 16; ++rr) x[rr] -= lane_bcast(am, rr) * x[m];
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            P[r * TP + c] = c <= r ? a[c] : 0.0;                               // L_JJ, upper part cleared
-            inv_tile[c * TP + r] = x[c];                                       // inverse[c][column r]
-        }
-    }
 }
 
 // The tile coordinates of a wavefront never change, so the compiler hoists every per-tile address computation (4 global
