@@ -895,6 +895,17 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
     idx, val = job.download() if rank == 0 else (None, None)
     download_s = time.perf_counter() - t2
     sst = sim.stats()
+    # the bound of the accumulation, measured on THIS device in THIS run (the round-1 microbenchmark figure is the fall-back)
+    global LDS_ATOMIC_PEAK
+    peak_source = "profiles/r1_lds_atomics_microbench.txt (21.6 lane-adds per ns and CU x 256)"
+    try:
+        from recsys2019_deeplearning_evaluation_amd import _native as _N
+        measured = _N.lds_atomic_rate()
+        if measured > 0:
+            LDS_ATOMIC_PEAK = measured
+            peak_source = "mi355rec_lds_atomic_rate in this run: ds_add_u32 on uniformly random cells, one 1024-thread workgroup per CU"
+    except Exception as exc:
+        peak_source += "; live measurement failed: %r" % (exc,)
     pairs = float(np.asarray(costs, dtype=np.float64)[my_columns].sum())
     pair_rate = pairs / (kernel_ms * 1e-3)
     alg_gbps = sst["algorithmic_bytes"] / (sst["kernel_ms"] * 1e-3) / 1e9
@@ -909,7 +920,7 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
         "transport": "none" if world == 1 else ("rccl-ctypes" if net.comm is not None else "torch." + net.dist.get_backend()),
         "nnz_out": int((idx >= 0).sum()) if idx is not None else None,
         "roofline": {"bound": "lds-atomics", "kernel": "sim_column_kernel", "achieved": pair_rate, "peak": LDS_ATOMIC_PEAK,
-                     "unit": "pair-adds/s", "frac": pair_rate / LDS_ATOMIC_PEAK, "pairs_this_rank": pairs,
+                     "unit": "pair-adds/s", "frac": pair_rate / LDS_ATOMIC_PEAK, "peak_source": peak_source, "pairs_this_rank": pairs,
                      "stream_GBps": 2.0 * pairs / (kernel_ms * 1e-3) / 1e9,
                      "survey_8d_algorithmic_GBps": alg_gbps, "survey_8d_algorithmic_over_hbm_peak": alg_gbps / HBM_PEAK_GBPS,
                      "note": "SURVEY 8(d)'s byte model (8 B per co-occurrence pair) exceeds the HBM peak because the kernel streams "

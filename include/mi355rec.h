@@ -194,6 +194,10 @@ int mi355rec_sim_accumulator_info(mi355rec_sim_t h, int32_t *kind, double *fixed
  * Euclidean cell map always take the full path and are counted nowhere.  MI355REC_SIM_FAST_TOPK=0 switches the first path off. */
 int mi355rec_sim_selection_info(mi355rec_sim_t h, int64_t *threshold_first_columns, int64_t *candidates, int64_t *fallbacks);
 int mi355rec_sim_sync(mi355rec_sim_t h);
+/* The rate the column kernel's accumulation is priced against (bench.py's `roofline.peak` of the ItemKNN build), measured on the device at
+ * hand: ds_add_u32 lane-adds per second of the whole device on uniformly random cells of a 128 KiB LDS array, one 1024-thread workgroup
+ * per CU (the loop of scripts/micro/lds_atomics.hip).  ~10 ms. */
+int mi355rec_lds_atomic_rate(double *lane_adds_per_second);
 int mi355rec_sim_get_stats(mi355rec_sim_t h, mi355rec_stats *stats);
 void mi355rec_sim_destroy(mi355rec_sim_t h);
 

@@ -90,6 +90,7 @@ SIGNATURES = {
     "mi355rec_sim_schedule_info": (C.c_int, [_vp, _vp, _vp, _vp]),
     "mi355rec_sim_accumulator_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_f64)]),
     "mi355rec_sim_selection_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "mi355rec_lds_atomic_rate": (C.c_int, [C.POINTER(_f64)]),
     "mi355rec_sim_sync": (C.c_int, [_vp]),
     "mi355rec_sim_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "mi355rec_sim_destroy": (None, [_vp]),
@@ -215,6 +216,13 @@ def as_f32(a):
 
 def as_f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def lds_atomic_rate():
+    """ds_add_u32 lane-adds per second of the whole device on uniformly random LDS cells (the similarity build's roofline peak)."""
+    rate = C.c_double(0.0)
+    check(load().mi355rec_lds_atomic_rate(C.byref(rate)))
+    return float(rate.value)
 
 
 def trim_device_cache():

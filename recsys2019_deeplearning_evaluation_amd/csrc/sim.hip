@@ -2149,6 +2149,57 @@ extern "C" int mi355rec_sim_accumulator_info(mi355rec_sim_t h, int32_t *kind, do
     });
 }
 
+// ---- the bound the column kernel is priced against, measured on the device at hand -----------------------------------------
+// ds_add_u32 lane-adds per second of the whole device: one 1024-thread workgroup per CU adding to pseudo-random cells of a 128 KiB LDS
+// array (uniformly random addresses: the bank conflicts of a random scatter are part of the figure; scripts/micro/lds_atomics.hip is
+// the same loop stand-alone, 21.6 lane-adds per ns and CU in round 1).
+namespace {
+__global__ __launch_bounds__(1024) void lds_atomic_rate_kernel(int iters, unsigned *sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned rate_cells[];
+    constexpr unsigned CELLS = 128 * 1024 / sizeof(unsigned);
+    for (unsigned i = threadIdx.x; i < CELLS; i += 1024) rate_cells[i] = 0u;
+    __syncthreads();
+    unsigned s = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 1u;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s = s * 1664525u + 1013904223u;
+            atomicAdd(&rate_cells[(s >> 8) % CELLS], s & 7u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sink[blockIdx.x] = rate_cells[blockIdx.x % CELLS];
+}
+}  // namespace
+
+extern "C" int mi355rec_lds_atomic_rate(double *lane_adds_per_second) {
+    return guarded([&] {
+        MI_REQUIRE(lane_adds_per_second, "NULL argument");
+        ensure_device();
+        const int cus = multiprocessor_count(), iters = 2048;
+        DeviceBuffer<unsigned> sink;
+        sink.alloc((size_t)cus);
+        auto kern = lds_atomic_rate_kernel;
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        hipEvent_t a = pooled_event(), b = pooled_event();
+        hipLaunchKernelGGL(kern, dim3(cus), dim3(1024), 128 * 1024, 0, 64, sink.ptr);             // warm-up
+        double best = 0.0;
+        for (int rep = 0; rep < 3; ++rep) {
+            MI_HIP(hipEventRecord(a, 0));
+            hipLaunchKernelGGL(kern, dim3(cus), dim3(1024), 128 * 1024, 0, iters, sink.ptr);
+            MI_HIP(hipEventRecord(b, 0));
+            MI_HIP(hipEventSynchronize(b));
+            float ms = 0.f;
+            MI_HIP(hipEventElapsedTime(&ms, a, b));
+            if (ms > 0.f) best = std::max(best, (double)cus * 1024.0 * iters * 8.0 / (ms * 1e-3));
+        }
+        MI_HIP(hipGetLastError());
+        pooled_event_return(a);
+        pooled_event_return(b);
+        *lane_adds_per_second = best;
+    });
+}
+
 extern "C" int mi355rec_sim_sync(mi355rec_sim_t h) {
     return guarded([&] {
         MI_REQUIRE(h, "NULL handle");

@@ -763,3 +763,11 @@ def test_device_cache_trim(gpu):
     dev = Compute_Similarity_MI355X(X, topK=10)
     assert (dev.compute_similarity() != before).nnz == 0
     dev.close()
+
+
+def test_lds_atomic_rate_is_measured(gpu):
+    """mi355rec_lds_atomic_rate: the peak bench.py prices the column kernel against, measured on the device at hand -- within a factor of
+    two of round 1's microbenchmark (21.6 lane-adds per ns and CU)."""
+    from recsys2019_deeplearning_evaluation_amd import _native as N
+    rate = N.lds_atomic_rate()
+    assert 0.5 * 21.6e9 * 256 < rate < 2.0 * 21.6e9 * 256, rate
