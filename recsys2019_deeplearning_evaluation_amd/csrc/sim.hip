@@ -28,6 +28,11 @@
 namespace mi355rec {
 namespace {
 
+// chunks a lane group keeps in flight in the counts instance (round 5: 6 and 8 measured at ML-20M shape: 4.19 / 4.27 ms against 3.99-4.15:
+// the stream is not what the accumulation waits for)
+#ifndef SIM_DEPTH_UNIT
+#define SIM_DEPTH_UNIT 4
+#endif
 constexpr int MAX_TILE = 32256;      // uint32 count cells of the LDS accumulator: 4 B * (32256 + 4) + 32 KiB selection scratch + statics <= 160 KiB
 constexpr int MAX_TILE_F64 = 16128;  // float64 cells (real-valued data): 8 B * (16128 + 4) + 32 KiB
 constexpr int NORM_PAD = 1024 + 4;     // zeros behind the norm arrays: the threshold-first selection reads whole rounds of 1024 cells
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         // inside 62 bits and every product's rounding below 1e-7 of the smallest normalised result (p.fixed_scale > 0):
         // x * scale is rounded to an integer by adding 1.5 * 2^52 in float64 (one fma) and subtracting that constant's bits;
         // integer sums are exact and independent of the order of the adds.
-        constexpr int DEPTH = UNIT ? 4 : 2;
+        constexpr int DEPTH = UNIT ? SIM_DEPTH_UNIT : 2;
         unsigned *acc_u = reinterpret_cast<unsigned *>(acc);
         double *acc_d = reinterpret_cast<double *>(acc);
         unsigned long long *acc_q = reinterpret_cast<unsigned long long *>(acc);
