@@ -53,6 +53,7 @@ struct SimParams {
     const int *seg_ptr;                // [n_rows * n_tiles + 1], multiples of 8
     const unsigned short *seg_idx16;
     const float *seg_val;
+    const short *seg_val16;            // ACC_INT32: the stored values times 2^s as 16-bit integers (same entry order as seg_idx16); seg_val is absent then
     int tile_w, n_tiles;               // accumulator tile width and count (1 when n_cols fits the LDS)
     int *cand_idx;                     // n_tiles > 1: per-workgroup scratch [n_tiles * topK] of per-tile candidates
     float *cand_val;
@@ -65,6 +66,7 @@ struct SimParams {
     int n_items, start_col;
     const int *out_slot;    // interleaved parts: output row of every column of the call (NULL: column - start_col)
     float int_scale, int_inv;   // ACC_INT32: 4^s (both factors of a product carry 2^s) and its inverse
+    float int_half;             // ACC_INT32: 2^s
     double fixed_scale;     // real-valued data: > 0 = the accumulator holds int64 fixed-point sums, products scaled by this power of two
     double fixed_inv;       //                   (1 / fixed_scale); 0 = float64 sums
     uint32_t *part_buf;     // [part slots][n_cols_pad] partial accumulators of split columns
@@ -287,13 +289,15 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         // inside 62 bits and every product's rounding below 1e-7 of the smallest normalised result (p.fixed_scale > 0):
         // x * scale is rounded to an integer by adding 1.5 * 2^52 in float64 (one fma) and subtracting that constant's bits;
         // integer sums are exact and independent of the order of the adds.
-        constexpr int DEPTH = UNIT ? SIM_DEPTH_UNIT : 2;
+        // (exact int32 sums: ids and values are one 16-byte chunk each per lane -- three of them in flight)
+        constexpr int DEPTH = UNIT ? SIM_DEPTH_UNIT : (MODE == ACC_INT32 ? 3 : 2);
         unsigned *acc_u = reinterpret_cast<unsigned *>(acc);
         double *acc_d = reinterpret_cast<double *>(acc);
         unsigned long long *acc_q = reinterpret_cast<unsigned long long *>(acc);
         const bool fixed_point = MODE == ACC_WIDE && p.fixed_scale > 0.0;
         const uint4 *idx8 = reinterpret_cast<const uint4 *>(p.seg_idx16);
         const float4 *val4 = reinterpret_cast<const float4 *>(p.seg_val);
+        const uint4 *val8 = reinterpret_cast<const uint4 *>(p.seg_val16);
         int *tab = reinterpret_cast<int *>(aux) + wave * 192;       // [64] x {rs, re, weight}
         for (int base = wbeg; base < wend; base += 64) {
             const int n_here = min(64, wend - base);
@@ -335,7 +339,9 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                 c_re[d] = f_have ? f_re : 0;
                 c_r[d] = f_r;
                 ids[d] = idx8[at >> 3];
-                if (!UNIT) {
+                if (MODE == ACC_INT32) {
+                    vlo[d] = __builtin_bit_cast(float4, val8[at >> 3]);       // eight int16 values
+                } else if (!UNIT) {
                     vlo[d] = val4[at >> 2];
                     vhi[d] = val4[(at >> 2) + 1];
                 }
@@ -354,12 +360,17 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                     const float vv[8] = {vlo[d].x, vlo[d].y, vlo[d].z, vlo[d].w, vhi[d].x, vhi[d].y, vhi[d].z, vhi[d].w};
                     const double rd = (double)c_r[d];
                     if (MODE == ACC_INT32) {
-                        // (column value * 2^s) * (row value * 2^s): integers below 2^24, exact in float32, then an integer add
-                        const float rs = c_r[d] * p.int_scale;
+                        // (column value * 2^s) * (row value * 2^s): two integers of at most 12 bits -- the row side comes from the stream
+                        // as int16 (a third of the bytes of ids + float32 values: the stream, not the atomics, was what made this
+                        // instance twice as slow as the counts), one 24-bit multiply, an integer add
+                        const int ri = __float2int_rn(c_r[d] * p.int_half);
+                        const uint4 vq = __builtin_bit_cast(uint4, vlo[d]);
+                        const unsigned vw[4] = {vq.x, vq.y, vq.z, vq.w};
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const unsigned j = (e & 1) ? (ww[e >> 1] >> 16) : (ww[e >> 1] & 0xFFFFu);
-                            atomicAdd(&acc_u[j], (unsigned)__float2int_rn(rs * vv[e]));
+                            const int v = (e & 1) ? (int)vw[e >> 1] >> 16 : (int)(short)(vw[e >> 1] & 0xFFFFu);
+                            atomicAdd(&acc_u[j], (unsigned)__mul24(ri, v));
                         }
                     } else if (MODE == ACC_WIDE && fixed_point) {
                         const double rs = rd * p.fixed_scale;
@@ -855,7 +866,7 @@ __global__ void seg_len_kernel(const int *csr_ptr, const int *row_tile_ptr, int 
 // values as they are after pre-processing; padding entries point at the 4 spare accumulator cells and carry 0.
 __global__ void seg_fill_kernel(const int *csr_ptr, const int *row_tile_ptr, const int *csr_idx, const float *csr_val,
                                 const int *seg_ptr, int n_rows, int n_tiles, int tile_w, unsigned short *seg_idx16,
-                                float *seg_val, int group_lanes) {
+                                float *seg_val, int group_lanes, short *seg_val16, float int_half) {
     const long long k = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (k >= (long long)n_rows * n_tiles) return;
@@ -886,7 +897,8 @@ __global__ void seg_fill_kernel(const int *csr_ptr, const int *row_tile_ptr, con
             at = q - k + (k % group_lanes) * 8 + k / group_lanes;
         }
         seg_idx16[dst + at] = (unsigned short)(real ? csr_idx[a + q] - t * tile_w : tile_w + (q & 3));
-        seg_val[dst + at] = real ? csr_val[a + q] : 0.f;
+        if (seg_val16) seg_val16[dst + at] = real ? (short)__float2int_rn(csr_val[a + q] * int_half) : (short)0;     // exact: the value grid was checked
+        else seg_val[dst + at] = real ? csr_val[a + q] : 0.f;
     }
 }
 
@@ -1214,6 +1226,7 @@ struct mi355rec_sim {
     DeviceBuffer<unsigned short> seg_idx16;
     DeviceBuffer<int> seg_ptr;
     DeviceBuffer<float> seg_val;
+    DeviceBuffer<short> seg_val16;
     DeviceBuffer<int> row_tile_ptr, cand_idx;
     DeviceBuffer<float> cand_val;
     int tile_w = 0, n_tiles = 1;
@@ -1542,6 +1555,7 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     p.seg_ptr = h->seg_ptr.ptr;
     p.seg_idx16 = h->seg_idx16.ptr;
     p.seg_val = h->seg_val.ptr;
+    p.seg_val16 = h->seg_val16.ptr;
     p.csc_ptr = h->csc_ptr.ptr;
     p.csc_idx = h->csc_idx.ptr;
     p.csc_val = h->csc_val.ptr;
@@ -1573,6 +1587,7 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     }
     p.fixed_scale = unit_kernel ? 0.0 : h->fixed_scale;
     p.int_scale = h->int_shift >= 0 ? (float)(1 << (2 * h->int_shift)) : 1.f;
+    p.int_half = h->int_shift >= 0 ? (float)(1 << h->int_shift) : 1.f;
     p.int_inv = 1.f / p.int_scale;
     p.fixed_inv = p.fixed_scale > 0.0 ? 1.0 / p.fixed_scale : 0.0;
     p.start_col = start;
@@ -1880,10 +1895,12 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
             const size_t seg_cap = nnz + 7 * (size_t)n_seg + 520;     // every segment grows by at most 7 entries
             MI_REQUIRE(seg_cap < (size_t)INT32_MAX, "matrix too large for 32-bit segment offsets");
             h->seg_idx16.alloc_zero(seg_cap, s);
-            h->seg_val.alloc_zero(seg_cap, s);
+            const bool int16_values = h->acc_mode() == ACC_INT32;      // (ids + int16 values: 4 B per entry instead of 6)
+            if (int16_values) h->seg_val16.alloc_zero(seg_cap, s);
+            else h->seg_val.alloc_zero(seg_cap, s);
             hipLaunchKernelGGL(seg_fill_kernel, dim3(div_up(n_seg * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->row_tile_ptr.ptr,
                                h->csr_idx.ptr, h->csr_val.ptr, h->seg_ptr.ptr, n_rows, h->n_tiles, h->tile_w, h->seg_idx16.ptr,
-                               h->seg_val.ptr, stream_order ? h->group_lanes : 0);
+                               h->seg_val.ptr, stream_order ? h->group_lanes : 0, h->seg_val16.ptr, (float)(1 << std::max(0, h->int_shift)));
             MI_HIP(hipGetLastError());
             MI_HIP(hipStreamSynchronize(s));      // the temporaries above go out of scope
         }
