@@ -290,11 +290,12 @@ class ResidentURM:
 
     @staticmethod
     def fingerprint_of(csr):
-        """Shape, nnz and a checksum of a sample of the row pointers (every 8th), indices and values (every nnz / 65536-th entry)."""
+        """Shape, nnz and a checksum of a sample of the row pointers (every 64th: each one counts ALL the entries before it), indices and values (every nnz / 8192-th entry:
+        a strided sample is one cache miss per entry, 65 536 of them per array cost 0.5 ms of every constructor)."""
         import zlib
-        return (csr.shape, int(csr.nnz), zlib.crc32(np.ascontiguousarray(csr.indptr, np.int32)[::8].tobytes()),
-                zlib.crc32(np.ascontiguousarray(csr.data, np.float32)[:: max(1, csr.nnz // 65536)].tobytes()),
-                zlib.crc32(np.ascontiguousarray(csr.indices, np.int32)[:: max(1, csr.nnz // 65536)].tobytes()))
+        return (csr.shape, int(csr.nnz), zlib.crc32(np.ascontiguousarray(csr.indptr, np.int32)[::64].tobytes()),
+                zlib.crc32(np.ascontiguousarray(csr.data, np.float32)[:: max(1, csr.nnz // 8192)].tobytes()),
+                zlib.crc32(np.ascontiguousarray(csr.indices, np.int32)[:: max(1, csr.nnz // 8192)].tobytes()))
 
     @staticmethod
     def _buffers_of(csr):
@@ -306,7 +307,7 @@ class ResidentURM:
         return (zlib.crc32(np.ascontiguousarray(csr.indices, np.int32).tobytes()), zlib.crc32(np.ascontiguousarray(csr.data, np.float32).tobytes()))
 
     def matches(self, csr, thorough=None):
-        """Is `csr` the uploaded matrix?  Always compared: shape, nnz, every 8th row pointer and a sample (every nnz / 65536-th entry) of
+        """Is `csr` the uploaded matrix?  Always compared: shape, nnz, every 64th row pointer and a sample (every nnz / 8192-th entry) of
         indices and values -- a fraction of a millisecond, enough to catch another data set, another split, a re-weighted or a
         filtered matrix.  thorough=True (or MI355REC_RESIDENT_VERIFY=full in the environment) also compares a checksum of EVERY
         index and value unless `csr` is made of the very buffers that were uploaded: ~0.1 s at ML-20M size, more than ten fits, so

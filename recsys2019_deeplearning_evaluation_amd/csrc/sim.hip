@@ -782,12 +782,14 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
 
 // ---------------------------------------- set-up kernels -------------------------------------------
 
-// Which of the scales 2^0 .. 2^3 turn every value into an integer (bit s of out[0] is SET when one does not), and max |value|.
-__global__ void value_grid_kernel(const float *x, size_t n, unsigned *out) {
-    unsigned bad = 0, top = 0;
+// One pass over the stored values: out[0] bit s SET when some value times 2^s (s = 0..3) is not an integer, out[1] the bits of
+// max |value|, out[2] non-zero when some value is not exactly 1.
+__global__ void value_scan_kernel(const float *x, size_t n, unsigned *out) {
+    unsigned bad = 0, top = 0, not_unit = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = x[i];
         top = max(top, __float_as_uint(fabsf(v)));
+        not_unit |= v != 1.0f;
 #pragma unroll
         for (int sh = 0; sh <= 3; ++sh) {
             const float t = v * (float)(1 << sh);
@@ -795,7 +797,8 @@ __global__ void value_grid_kernel(const float *x, size_t n, unsigned *out) {
         }
     }
     if (bad) atomicOr(&out[0], bad);
-    atomicMax(&out[1], top);
+    if (top) atomicMax(&out[1], top);
+    if (not_unit) atomicOr(&out[2], 1u);
 }
 
 __global__ void fill_kernel(float *x, size_t n, float v) {
@@ -930,22 +933,29 @@ __global__ void csc_ptr_kernel(const int *sorted_cols, size_t nnz, int n_cols, i
     csc_ptr[c] = (int)lo;
 }
 
-// Row id of every stored cell (one wave per row), and the identity permutation 0..nnz-1.
-__global__ void expand_rows_kernel(const int *ptr, int n_rows, int *row_of, int *pos) {
+// Row id of every stored cell (one wave per row): the payload of the CSR -> CSC sort for all-ones data.
+__global__ void expand_rows_kernel(const int *ptr, int n_rows, int *row_of) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= n_rows) return;
-    for (int q = ptr[wave] + lane; q < ptr[wave + 1]; q += 64) {
-        row_of[q] = wave;
-        pos[q] = q;
-    }
+    for (int q = ptr[wave] + lane; q < ptr[wave + 1]; q += 64) row_of[q] = wave;
 }
 
-// CSC view from the stable (column-key) sort permutation: users inside a column stay in ascending order.
-__global__ void gather_csc_kernel(const int *perm, const int *row_of, const float *val, size_t nnz, int *csc_idx, float *csc_val) {
+// Payload of the CSR -> CSC sort for valued data: (row id, value bits) of every stored cell in one 8-byte word, so that the sort
+// itself carries the cells into column order (a sorted permutation + a gather of rows and values through it spent 0.7 ms on its
+// 2 x 20 M random 4-byte reads at the ML-20M shape).
+__global__ void expand_cells_kernel(const int *ptr, const float *val, int n_rows, unsigned long long *cell) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_rows) return;
+    for (int q = ptr[wave] + lane; q < ptr[wave + 1]; q += 64)
+        cell[q] = (unsigned long long)(unsigned)wave | ((unsigned long long)__float_as_uint(val[q]) << 32);
+}
+
+// CSC view from the sorted cells: users inside a column stay in ascending order (the sort is stable).
+__global__ void split_cells_kernel(const unsigned long long *cell, size_t nnz, int *csc_idx, float *csc_val) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x) {
-        const int q = perm[i];
-        csc_idx[i] = row_of[q];
-        csc_val[i] = val[q];
+        const unsigned long long c = cell[i];
+        csc_idx[i] = (int)(unsigned)c;
+        csc_val[i] = __uint_as_float((unsigned)(c >> 32));
     }
 }
 
@@ -1154,13 +1164,6 @@ __global__ void absmax_kernel(const float *val, size_t nnz, unsigned *out) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
-}
-
-__global__ void minmax_kernel(const float *val, size_t nnz, int *not_unit) {
-    int bad = 0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x)
-        bad |= val[i] != 1.0f;
-    if (bad) atomicOr(not_unit, 1);
 }
 
 // CSR assembly of the result (.pyx:603-605: row = neighbour, column = source item) -- sort keys: the neighbour id of
@@ -1695,30 +1698,6 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         MI_HIP(hipMemcpyAsync(h->csr_val.ptr, csr_data, nnz * sizeof(float), in_kind, s));
         if (row_weights) h->row_w.upload(row_weights, n_rows, s);
         phase(resident ? "allocate + copy of the resident URM" : "allocate + upload (PCIe)");
-        // CSR -> CSC (.pyx:203-207), on the device: stable radix sort of the cell positions by column; the values are gathered
-        // into column order further down, after their pre-processing.  (Measured and rejected: the sort on a second stream behind the
-        // upload of the values -- it needs the structure only --: the upload of pageable memory and the sort's kernels got into each
-        // other's way, 5.96 ms for the two against 2.92 + 1.16 ms one after the other.)
-        DeviceBuffer<int> row_of, pos_in, pos_out, key_out;
-        DeviceBuffer<char> sort_tmp;
-        {
-            h->csc_ptr.alloc((size_t)n_cols + 1);
-            row_of.alloc(nnz);
-            pos_in.alloc(nnz);
-            pos_out.alloc(nnz);
-            key_out.alloc(nnz);
-            int key_bits = 1;
-            while ((1ll << key_bits) < (long long)n_cols) ++key_bits;
-            size_t tmp_bytes = 0;
-            MI_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, pos_in.ptr, pos_out.ptr,
-                                                      (int)nnz, 0, key_bits, s));
-            sort_tmp.alloc(tmp_bytes);
-            hipLaunchKernelGGL(expand_rows_kernel, dim3(div_up((int64_t)n_rows * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr, n_rows,
-                               row_of.ptr, pos_in.ptr);
-            MI_HIP(rocprim::radix_sort_pairs(sort_tmp.ptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, pos_in.ptr, pos_out.ptr,
-                                                      (int)nnz, 0, key_bits, s));
-            hipLaunchKernelGGL(csc_ptr_kernel, dim3(div_up(n_cols + 1, 256)), dim3(256), 0, s, key_out.ptr, nnz, n_cols, h->csc_ptr.ptr);
-        }
         const int eb = 256, eg = std::min<size_t>((nnz + eb - 1) / eb, 4096);
 
         // optional pre-pass: BM25 / TF-IDF on the stored values (what the KNN recommenders do to the matrix before the build)
@@ -1751,35 +1730,27 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         // All-ones data (implicit URMs, every set-based similarity) takes the integer-count kernel, which never reads
         // the value arrays; mean-centred data never qualifies.
         h->unit_values = set_based;
-        if (!set_based && cfg->similarity != MI355REC_SIM_ADJUSTED && cfg->similarity != MI355REC_SIM_PEARSON) {
-            DeviceBuffer<int> not_unit;
-            not_unit.alloc_zero(1, s);
-            hipLaunchKernelGGL(minmax_kernel, dim3(eg), dim3(eb), 0, s, h->csr_val.ptr, nnz, not_unit.ptr);
-            MI_HIP(hipGetLastError());
-            int nu = 1;
-            not_unit.download(&nu, 1, s);
-            MI_HIP(hipStreamSynchronize(s));
-            h->unit_values = (nu == 0);
-        }
         // Quantised values (star ratings, half stars, counts): if every stored value times 2^s (s <= 3) is an integer of at most
         // 2048 and n_rows products of that size cannot overflow an int32, the column sums are exact integers (ACC_INT32).  Not for
-        // mean-centred data (adjusted / pearson centre the values later) nor with row weights.
-        if (!h->unit_values && !row_weights && cfg->similarity != MI355REC_SIM_ADJUSTED && cfg->similarity != MI355REC_SIM_PEARSON &&
-            !getenv("MI355REC_SIM_F64_SUMS") && !getenv("MI355REC_SIM_NO_INT32")) {
-            DeviceBuffer<unsigned> grid_info;          // [0] bit s set: some value times 2^s is not an integer; [1] bits of max |value|
-            grid_info.alloc_zero(2, s);
-            hipLaunchKernelGGL(value_grid_kernel, dim3(eg), dim3(eb), 0, s, h->csr_val.ptr, nnz, grid_info.ptr);
+        // mean-centred data (adjusted / pearson centre the values later) nor with row weights.  One pass answers both questions.
+        if (!set_based && cfg->similarity != MI355REC_SIM_ADJUSTED && cfg->similarity != MI355REC_SIM_PEARSON) {
+            DeviceBuffer<unsigned> scan;          // [0] bit s set: some value times 2^s is not an integer; [1] bits of max |value|; [2] not all ones
+            scan.alloc_zero(3, s);
+            hipLaunchKernelGGL(value_scan_kernel, dim3(eg), dim3(eb), 0, s, h->csr_val.ptr, nnz, scan.ptr);
             MI_HIP(hipGetLastError());
-            unsigned info[2] = {0xFu, 0u};
-            grid_info.download(info, 2, s);
+            unsigned info[3] = {0xFu, 0u, 1u};
+            scan.download(info, 3, s);
             MI_HIP(hipStreamSynchronize(s));
-            float vmax_f;
-            memcpy(&vmax_f, &info[1], sizeof(float));
-            for (int sh = 0; sh <= 3; ++sh) {
-                const double m = (double)vmax_f * (double)(1 << sh);
-                if (!((info[0] >> sh) & 1u) && m <= 2048.0 && (double)n_rows * m * m < 2147483648.0) {
-                    h->int_shift = sh;
-                    break;
+            h->unit_values = (info[2] == 0);
+            if (!h->unit_values && !row_weights && !getenv("MI355REC_SIM_F64_SUMS") && !getenv("MI355REC_SIM_NO_INT32")) {
+                float vmax_f;
+                memcpy(&vmax_f, &info[1], sizeof(float));
+                for (int sh = 0; sh <= 3; ++sh) {
+                    const double m = (double)vmax_f * (double)(1 << sh);
+                    if (!((info[0] >> sh) & 1u) && m <= 2048.0 && (double)n_rows * m * m < 2147483648.0) {
+                        h->int_shift = sh;
+                        break;
+                    }
                 }
             }
         }
@@ -1811,10 +1782,45 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
             hipLaunchKernelGGL(row_tile_ptr_kernel, dim3(div_up((int64_t)n_rows * (h->n_tiles + 1), 256)), dim3(256), 0, s,
                                h->csr_ptr.ptr, h->csr_idx.ptr, n_rows, h->tile_w, h->n_tiles, h->row_tile_ptr.ptr);
         }
-        hipLaunchKernelGGL(gather_csc_kernel, dim3(eg), dim3(eb), 0, s, pos_out.ptr, row_of.ptr, h->csr_val.ptr, nnz,
-                           h->csc_idx.ptr, h->csc_val.ptr);
+        // CSR -> CSC (.pyx:203-207), on the device: stable radix sort of the pre-processed cells by column.  All-ones data sorts the
+        // row ids alone (the values of the column view are a fill); valued data sorts (row id, value) words and splits them.
+        // (Measured and rejected: the sort on a second stream behind the upload of the values -- the upload of pageable memory and
+        // the sort's kernels got into each other's way, 5.96 ms for the two against 2.92 + 1.16 ms one after the other.)
+        DeviceBuffer<int> key_out, row_of;
+        DeviceBuffer<unsigned long long> cell_in, cell_out;
+        DeviceBuffer<char> sort_tmp;
+        {
+            h->csc_ptr.alloc((size_t)n_cols + 1);
+            key_out.alloc(nnz);
+            int key_bits = 1;
+            while ((1ll << key_bits) < (long long)n_cols) ++key_bits;
+            size_t tmp_bytes = 0;
+            const int rg = div_up((int64_t)n_rows * 64, 256);
+            if (h->unit_values) {
+                row_of.alloc(nnz);
+                hipLaunchKernelGGL(expand_rows_kernel, dim3(rg), dim3(256), 0, s, h->csr_ptr.ptr, n_rows, row_of.ptr);
+                MI_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, row_of.ptr, h->csc_idx.ptr,
+                                                          (int)nnz, 0, key_bits, s));
+                sort_tmp.alloc(tmp_bytes);
+                MI_HIP(rocprim::radix_sort_pairs(sort_tmp.ptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, row_of.ptr, h->csc_idx.ptr,
+                                                          (int)nnz, 0, key_bits, s));
+                hipLaunchKernelGGL(fill_kernel, dim3(eg), dim3(eb), 0, s, h->csc_val.ptr, nnz, 1.0f);
+            } else {
+                cell_in.alloc(nnz);
+                cell_out.alloc(nnz);
+                hipLaunchKernelGGL(expand_cells_kernel, dim3(rg), dim3(256), 0, s, h->csr_ptr.ptr, h->csr_val.ptr, n_rows, cell_in.ptr);
+                MI_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, cell_in.ptr, cell_out.ptr,
+                                                          (int)nnz, 0, key_bits, s));
+                sort_tmp.alloc(tmp_bytes);
+                MI_HIP(rocprim::radix_sort_pairs(sort_tmp.ptr, tmp_bytes, h->csr_idx.ptr, key_out.ptr, cell_in.ptr, cell_out.ptr,
+                                                          (int)nnz, 0, key_bits, s));
+                hipLaunchKernelGGL(split_cells_kernel, dim3(eg), dim3(eb), 0, s, cell_out.ptr, nnz, h->csc_idx.ptr, h->csc_val.ptr);
+            }
+            hipLaunchKernelGGL(csc_ptr_kernel, dim3(div_up(n_cols + 1, 256)), dim3(256), 0, s, key_out.ptr, nnz, n_cols, h->csc_ptr.ptr);
+            MI_HIP(hipGetLastError());
+        }
 
-        phase("CSR -> CSC (allocations, radix sort, gather)");
+        phase("CSR -> CSC (allocations, radix sort of the cells)");
         const int cg = div_up((int64_t)n_cols * 64, 256);
         if (cfg->similarity == MI355REC_SIM_PEARSON) {
             mean.alloc((size_t)n_cols);
