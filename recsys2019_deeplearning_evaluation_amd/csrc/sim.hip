@@ -796,9 +796,18 @@ __global__ void value_scan_kernel(const float *x, size_t n, unsigned *out) {
             if (!(t == rintf(t))) bad |= 1u << sh;       // (NaN / inf never qualify)
         }
     }
-    if (bad) atomicOr(&out[0], bad);
-    if (top) atomicMax(&out[1], top);
-    if (not_unit) atomicOr(&out[2], 1u);
+    // one atomic per wavefront and word (a million threads on one address each cost 0.15 ms)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bad |= (unsigned)__shfl_xor((int)bad, off);
+        top = max(top, (unsigned)__shfl_xor((int)top, off));
+        not_unit |= (unsigned)__shfl_xor((int)not_unit, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad) atomicOr(&out[0], bad);
+        if (top) atomicMax(&out[1], top);
+        if (not_unit) atomicOr(&out[2], 1u);
+    }
 }
 
 __global__ void fill_kernel(float *x, size_t n, float v) {
@@ -891,17 +900,39 @@ __global__ void seg_fill_kernel(const int *csr_ptr, const int *row_tile_ptr, con
     // ids, distinct banks.  The kernel does not care in which order a segment's entries arrive; the tail of a segment (less than a
     // block) stays in row order, so the chunk-granular end-of-segment test still holds.  Measured at ML-20M shape: accumulation
     // 659 -> 640 workgroup-ms, kernel 4.02 -> 3.98 ms (the atomic unit itself, not the bank pattern, is what bounds the scatter).
+    // One lane per 16-byte chunk of the stream (8 entries): the row-order entries first, first + step, ... are read (neighbouring
+    // lanes on neighbouring entries inside a block), packed and stored as ONE aligned 16-byte word per lane -- 2-byte stores
+    // at a stride of 16 bytes took 0.18 ms for the 40 MB of ids.  The counts kernel never reads values: none are written for it.
     const int block = 8 * group_lanes, n_blocked = block > 0 ? (padded / block) * block : 0;
-    for (int q = lane; q < padded; q += 64) {
-        const bool real = q < len;
-        int at = q;
-        if (q < n_blocked) {
-            const int k = q % block;
-            at = q - k + (k % group_lanes) * 8 + k / group_lanes;
+    const int n_chunks = padded >> 3, tile_base = t * tile_w;
+    uint4 *idx_out = reinterpret_cast<uint4 *>(seg_idx16 + dst);
+    for (int c = lane; c < n_chunks; c += 64) {
+        int first = c * 8, step = 1;
+        if (first < n_blocked) {
+            const int blk = c / group_lanes;
+            first = blk * block + (c - blk * group_lanes);
+            step = group_lanes;
         }
-        seg_idx16[dst + at] = (unsigned short)(real ? csr_idx[a + q] - t * tile_w : tile_w + (q & 3));
-        if (seg_val16) seg_val16[dst + at] = real ? (short)__float2int_rn(csr_val[a + q] * int_half) : (short)0;     // exact: the value grid was checked
-        else seg_val[dst + at] = real ? csr_val[a + q] : 0.f;
+        unsigned id[8];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int q = first + e * step;
+            const bool real = q < len;
+            id[e] = (unsigned)(real ? csr_idx[a + q] - tile_base : tile_w + (q & 3)) & 0xFFFFu;
+            v[e] = (real && (seg_val || seg_val16)) ? csr_val[a + q] : 0.f;
+        }
+        idx_out[c] = make_uint4(id[0] | (id[1] << 16), id[2] | (id[3] << 16), id[4] | (id[5] << 16), id[6] | (id[7] << 16));
+        if (seg_val16) {
+            unsigned h[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (unsigned)__float2int_rn(v[e] * int_half) & 0xFFFFu;     // exact: the value grid was checked
+            reinterpret_cast<uint4 *>(seg_val16 + dst)[c] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        } else if (seg_val) {
+            float4 *val_out = reinterpret_cast<float4 *>(seg_val + dst);
+            val_out[2 * c] = make_float4(v[0], v[1], v[2], v[3]);
+            val_out[2 * c + 1] = make_float4(v[4], v[5], v[6], v[7]);
+        }
     }
 }
 
@@ -1692,8 +1723,10 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         h->csr_ptr.alloc((size_t)n_rows + 1);
         MI_HIP(hipMemcpyAsync(h->csr_ptr.ptr, csr_indptr, ((size_t)n_rows + 1) * sizeof(int), in_kind, s));
         // padding: the column kernel reads the profiles in aligned 16-byte chunks, a whole lane group at a time
-        h->csr_idx.alloc_zero(nnz + 520, s);
-        h->csr_val.alloc_zero(nnz + 520, s);
+        h->csr_idx.alloc(nnz + 520);                 // (only the padding needs the zeros)
+        h->csr_val.alloc(nnz + 520);
+        MI_HIP(hipMemsetAsync(h->csr_idx.ptr + nnz, 0, 520 * sizeof(int), s));
+        MI_HIP(hipMemsetAsync(h->csr_val.ptr + nnz, 0, 520 * sizeof(float), s));
         MI_HIP(hipMemcpyAsync(h->csr_idx.ptr, csr_indices, nnz * sizeof(int), in_kind, s));
         MI_HIP(hipMemcpyAsync(h->csr_val.ptr, csr_data, nnz * sizeof(float), in_kind, s));
         if (row_weights) h->row_w.upload(row_weights, n_rows, s);
@@ -1860,9 +1893,11 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         cost_sorted.alloc((size_t)n_cols); col_ids.alloc((size_t)n_cols); col_order.alloc((size_t)n_cols);
         hipLaunchKernelGGL(iota_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, s, col_ids.ptr, n_cols);
         size_t order_bytes = 0;
-        MI_HIP(rocprim::radix_sort_pairs_desc(nullptr, order_bytes, cost.ptr, cost_sorted.ptr, col_ids.ptr, col_order.ptr, (size_t)n_cols, 0, 64, s));
+        int cost_bits = 1;                          // a column's cost counts every stored cell at most once: cost <= nnz
+        while ((1ull << cost_bits) <= (unsigned long long)nnz) ++cost_bits;
+        MI_HIP(rocprim::radix_sort_pairs_desc(nullptr, order_bytes, cost.ptr, cost_sorted.ptr, col_ids.ptr, col_order.ptr, (size_t)n_cols, 0, cost_bits, s));
         order_tmp.alloc(order_bytes + 16);
-        MI_HIP(rocprim::radix_sort_pairs_desc(order_tmp.ptr, order_bytes, cost.ptr, cost_sorted.ptr, col_ids.ptr, col_order.ptr, (size_t)n_cols, 0, 64, s));
+        MI_HIP(rocprim::radix_sort_pairs_desc(order_tmp.ptr, order_bytes, cost.ptr, cost_sorted.ptr, col_ids.ptr, col_order.ptr, (size_t)n_cols, 0, cost_bits, s));
         h->cost_order.resize(n_cols);
         col_order.download(h->cost_order.data(), (size_t)n_cols, s);
         h->cost.resize(n_cols);
@@ -1903,7 +1938,7 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
             h->seg_idx16.alloc_zero(seg_cap, s);
             const bool int16_values = h->acc_mode() == ACC_INT32;      // (ids + int16 values: 4 B per entry instead of 6)
             if (int16_values) h->seg_val16.alloc_zero(seg_cap, s);
-            else h->seg_val.alloc_zero(seg_cap, s);
+            else if (h->acc_mode() != ACC_COUNTS) h->seg_val.alloc_zero(seg_cap, s);     // (the counts kernel reads ids only)
             hipLaunchKernelGGL(seg_fill_kernel, dim3(div_up(n_seg * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->row_tile_ptr.ptr,
                                h->csr_idx.ptr, h->csr_val.ptr, h->seg_ptr.ptr, n_rows, h->n_tiles, h->tile_w, h->seg_idx16.ptr,
                                h->seg_val.ptr, stream_order ? h->group_lanes : 0, h->seg_val16.ptr, (float)(1 << std::max(0, h->int_shift)));
