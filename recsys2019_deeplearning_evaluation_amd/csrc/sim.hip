@@ -534,6 +534,13 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             float m = 0.f;
             scan_cells([&](int, float v, float norm_j) { m = fmaxf(m, v * __builtin_amdgcn_rcpf(approx_denominator(form, v, norm_j))); });
             mark(5);
+            if (p.phase_ticks) {          // (diagnostics only: the wait for the slowest wavefront of the scan, apart from the selection)
+                __syncthreads();
+                mark(7);
+            }
+            // (block_kth_largest_bin12 -- one 12-bit pass, three barriers, 4 060 cycles against 5 960 in scripts/micro/kth_select.hip --
+            // was measured here: the phase went from 91 to 63 workgroup-ms, its 12 % more survivors cost 4 of them back, and the
+            // un-instrumented kernel was 0.08-0.11 ms SLOWER in both sessions: the two-pass 16-bit prefix stays)
             const uint32_t p16 = block_kth_largest_prefix16<THREADS>(float_key(m), K, aux, sc);
             mark(3);
             bool done = p16 > (ZERO_KEY >> 16);                    // else: fewer than K threads hold a positive cell
@@ -2089,9 +2096,9 @@ extern "C" int mi355rec_sim_compute(mi355rec_sim_t h, int32_t start_col, int32_t
             MI_HIP(hipStreamSynchronize(h->stream));
             fprintf(stderr, "[mi355rec sim phases, workgroup-ms] fetch+clear %.2f  accumulate %.2f  split-merge %.2f  normalise %.2f  topk %.2f  (kernel %.3f ms)"
                             "  threshold-first: maxima scan %.2f  (K-th maximum under `normalise`)  survivor scan %.2f  (exact values + rank + emit under `topk`)"
-                            "  columns %llu (candidates %.1f per column), full-selection fall-backs after the scan %llu (%llu: buffer full)\n",
+                            "  columns %llu (candidates %.1f per column), full-selection fall-backs after the scan %llu (%llu: buffer full); wait for the scan's slowest wavefront %.2f (instrumented runs only)\n",
                     t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, h->stats.kernel_ms, t[5] * 1e-5, t[6] * 1e-5, t[8],
-                    t[8] ? (double)t[9] / (double)t[8] : 0.0, t[10], t[11]);
+                    t[8] ? (double)t[9] / (double)t[8] : 0.0, t[10], t[11], t[7] * 1e-5);
         }
     });
 }

@@ -26,6 +26,7 @@ __device__ __forceinline__ float key_float(uint32_t k) {
 
 struct SelectScratch {
     uint32_t wave_tot[4];
+    uint32_t wave_tot16[16];
     uint32_t digit, want, bin_count, out_count;
 };
 
@@ -241,6 +242,81 @@ __device__ uint32_t block_kth_largest_prefix16(uint32_t key, uint32_t K, uint32_
     }
     __syncthreads();     // sc is rewritten by the caller's next selection
     return prefix;
+}
+
+// Suffix sums inside a wavefront without LDS traffic: lane l gets v[l] + v[l + 1] + ... + v[63].  Four DPP additions inside the rows
+// of 16 lanes (row_shl:n reads lane l + n of the same row, lanes past the row's end contribute 0), then the totals of the rows above
+// through v_readlane.  (__shfl_down goes through the LDS crossbar: ~100 cycles per step, six steps.)
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t row_suffix_sum(uint32_t v) {
+    v += dpp_u32<0x101>(v);   // row_shl:1
+    v += dpp_u32<0x102>(v);   // row_shl:2
+    v += dpp_u32<0x104>(v);   // row_shl:4
+    v += dpp_u32<0x108>(v);   // row_shl:8
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_suffix_sum(uint32_t v) {
+    const uint32_t s = row_suffix_sum(v);
+    const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)s, 16), t2 = (uint32_t)__builtin_amdgcn_readlane((int)s, 32),
+                   t3 = (uint32_t)__builtin_amdgcn_readlane((int)s, 48);
+    const int row = (threadIdx.x & 63) >> 4;
+    return s + (row == 0 ? t1 + t2 + t3 : (row == 1 ? t2 + t3 : (row == 2 ? t3 : 0u)));
+}
+
+// A lower bound on the K-th largest (1-based) of the THREADS keys the threads of the block hold, one each, all >= ZERO_KEY: the
+// return value P (a 16-bit prefix like block_kth_largest_prefix16's) is the lower edge of the 12-bit bin -- 8 exponent bits and the
+// 4 leading mantissa bits of a non-negative float -- that holds the K-th largest key, so at least K keys are >= P << 16; P ==
+// ZERO_KEY >> 16 when fewer than K keys are above the zero bin.  ONE pass over a 4 096-bin histogram `hist` (LDS, all zero on
+// entry, left dirty) and three barriers: every wavefront sums its 4096 / WAVES bins (suffix sums by DPP) and publishes its total;
+// from the totals every wavefront finds -- for itself, no further exchange -- the wavefront whose bins hold the K-th key, re-reads
+// those bins and locates the bin.  block_kth_largest_prefix16 spends 6 000 cycles per call on its seven barriers, ballot rounds and
+// LDS-crossbar shuffles (scripts/micro/kth_select.hip); the bound here is up to 1/16 below the exact key instead of 2^-7 -- a caller
+// that filters cells with it lets a few more through (114 instead of 102 per column of the ML-20M shape at K = 100).
+template <int THREADS>
+__device__ uint32_t block_kth_largest_bin12(uint32_t key, uint32_t K, uint32_t *hist, SelectScratch &sc) {
+    static_assert(THREADS >= 256 && THREADS <= 1024 && 4096 % THREADS == 0, "one lane sums 4096 / THREADS bins");
+    constexpr int WAVES = THREADS / 64, BPL = 4096 / THREADS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t bin = (key >> 19) & 0xFFFu;
+    const unsigned long long zeros = __ballot(bin == 0u);           // threads without a positive cell: one atomic for all of them
+    if (bin != 0u) atomicAdd(&hist[bin], 1u);
+    else if (lane == __ffsll((long long)zeros) - 1) atomicAdd(&hist[0], (uint32_t)__popcll(zeros));
+    __syncthreads();
+    auto lane_bins = [&](int w, uint32_t (&c)[BPL]) {          // the BPL bins of this lane in wavefront w's stretch, and their sum
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < BPL; ++i) {
+            c[i] = hist[(w * 64 + lane) * BPL + i];
+            sum += c[i];
+        }
+        return sum;
+    };
+    uint32_t c[BPL];
+    const uint32_t mine = lane_bins(wave, c);
+    const uint32_t total = wave_suffix_sum(mine);           // lane 0: all keys in this wavefront's bins
+    if (lane == 0) sc.wave_tot16[wave] = total;
+    __syncthreads();
+    // which wavefront's stretch holds the K-th largest key (stretches of higher wavefronts hold larger keys)
+    const uint32_t tot = lane < WAVES ? sc.wave_tot16[lane] : 0u;
+    const uint32_t tsuf = row_suffix_sum(tot);              // (WAVES <= 16: one row)
+    const unsigned long long hit_w = __ballot(lane < WAVES && tsuf >= K && tsuf - tot < K);      // exactly one: THREADS >= K keys in all
+    const int W = __ffsll((long long)hit_w) - 1;
+    const uint32_t above_w = (uint32_t)__builtin_amdgcn_readlane((int)(tsuf - tot), W);
+    const uint32_t its = lane_bins(W, c);
+    const uint32_t suf = wave_suffix_sum(its) + above_w;    // keys in the bins of this lane and above
+    const unsigned long long hit_l = __ballot(suf >= K && suf - its < K);
+    const int L = __ffsll((long long)hit_l) - 1;
+    uint32_t above = suf - its;
+    int b = BPL - 1;
+    for (; b > 0; --b) {
+        if (above + c[b] >= K) break;
+        above += c[b];
+    }
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((W * 64 + lane) * BPL + b, L);
+    __syncthreads();     // the caller re-uses the bins (candidate list) and sc
+    return 0x8000u | (d << 3);
 }
 
 // Which cells take part in a top-K.

@@ -7,7 +7,10 @@ from bench import load_urm, TOPK
 from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_MI355X
 urm = load_urm(sys.argv[1] if len(sys.argv) > 1 else "ml20m")
 real = urm.copy(); real.data = (1 + (np.arange(real.nnz) % 5)).astype(np.float32)
-for name, X in (("binary (ds_add_u32 counts)", urm), ("integer ratings 1..5 (exact int32 sums)", real)):
+cases = (("binary (ds_add_u32 counts)", urm), ("integer ratings 1..5 (exact int32 sums)", real))
+if os.environ.get("SIM_PHASES_BINARY_ONLY"):
+    cases = cases[:1]
+for name, X in cases:
     s = Compute_Similarity_MI355X(X, topK=TOPK, shrink=0, normalize=True, similarity="cosine")
     s.compute_slabs()
     for fast in ("1", "0"):
