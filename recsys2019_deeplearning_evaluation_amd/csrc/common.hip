@@ -253,6 +253,10 @@ extern "C" int mi355rec_device_memcpy(void *dst, const void *src, uint64_t bytes
         ensure_device();
         MI_REQUIRE(to_device >= 0 && to_device <= 2, "to_device must be 0, 1 or 2");
         MI_HIP(hipMemcpy(dst, src, (size_t)bytes, to_device == 2 ? hipMemcpyDeviceToDevice : (to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost)));
+        // A device-to-device hipMemcpy is queued on the null stream and may return before it has run; the handles' streams are
+        // non-blocking, so a kernel launched next on one of them would not wait for it (seen once in ~10 suite runs as a stale exchange
+        // slab in tests/test_sharding_gpu.py::test_exact_multi_gpu_bpr_emulated_on_one_gpu).  Every entry point of this library blocks.
+        if (to_device == 2) MI_HIP(hipStreamSynchronize(nullptr));
     });
 }
 

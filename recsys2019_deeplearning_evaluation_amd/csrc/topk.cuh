@@ -26,7 +26,6 @@ __device__ __forceinline__ float key_float(uint32_t k) {
 
 struct SelectScratch {
     uint32_t wave_tot[4];
-    uint32_t wave_tot16[16];
     uint32_t digit, want, bin_count, out_count;
 };
 
@@ -268,8 +267,8 @@ __device__ __forceinline__ uint32_t wave_suffix_sum(uint32_t v) {
 // A lower bound on the K-th largest (1-based) of the THREADS keys the threads of the block hold, one each, all >= ZERO_KEY: the
 // return value P (a 16-bit prefix like block_kth_largest_prefix16's) is the lower edge of the 12-bit bin -- 8 exponent bits and the
 // 4 leading mantissa bits of a non-negative float -- that holds the K-th largest key, so at least K keys are >= P << 16; P ==
-// ZERO_KEY >> 16 when fewer than K keys are above the zero bin.  ONE pass over a 4 096-bin histogram `hist` (LDS, all zero on
-// entry, left dirty) and three barriers: every wavefront sums its 4096 / WAVES bins (suffix sums by DPP) and publishes its total;
+// ZERO_KEY >> 16 when fewer than K keys are above the zero bin.  ONE pass over a 4 096-bin histogram `hist` (LDS, 4 112 words, the first 4 096 all zero
+// on entry; left dirty) and three barriers: every wavefront sums its 4096 / WAVES bins (suffix sums by DPP) and publishes its total;
 // from the totals every wavefront finds -- for itself, no further exchange -- the wavefront whose bins hold the K-th key, re-reads
 // those bins and locates the bin.  block_kth_largest_prefix16 spends 6 000 cycles per call on its seven barriers, ballot rounds and
 // LDS-crossbar shuffles (scripts/micro/kth_select.hip); the bound here is up to 1/16 below the exact key instead of 2^-7 -- a caller
@@ -296,10 +295,10 @@ __device__ uint32_t block_kth_largest_bin12(uint32_t key, uint32_t K, uint32_t *
     uint32_t c[BPL];
     const uint32_t mine = lane_bins(wave, c);
     const uint32_t total = wave_suffix_sum(mine);           // lane 0: all keys in this wavefront's bins
-    if (lane == 0) sc.wave_tot16[wave] = total;
+    if (lane == 0) hist[4096 + wave] = total;          // (the words behind the bins: plain stores, nothing assumed about them)
     __syncthreads();
     // which wavefront's stretch holds the K-th largest key (stretches of higher wavefronts hold larger keys)
-    const uint32_t tot = lane < WAVES ? sc.wave_tot16[lane] : 0u;
+    const uint32_t tot = lane < WAVES ? hist[4096 + lane] : 0u;
     const uint32_t tsuf = row_suffix_sum(tot);              // (WAVES <= 16: one row)
     const unsigned long long hit_w = __ballot(lane < WAVES && tsuf >= K && tsuf - tot < K);      // exactly one: THREADS >= K keys in all
     const int W = __ffsll((long long)hit_w) - 1;
