@@ -328,7 +328,9 @@ def cpu_baseline_ials(conf, k, reg, V0, seconds):
             limit.unregister() if hasattr(limit, "unregister") else None
     return {"value": t_used * full / max(done, 1.0), "unit": "s/epoch", "cores": 1, "kind": "port",
             "sample": "%d rows (users and items at random) = %.3f %% of an epoch's 2 L k^2 + 2 k^3 flops in %.1f s, NumPy on one BLAS thread; "
-                      "epoch extrapolated by that cost" % (n_rows, 100.0 * done / full, t_used)}
+                      "epoch extrapolated by that cost.  kind 'port': oracle._ials_update_row, the NumPy restatement of IALSRecommender._update_row, "
+                      "timed on THIS host in THIS run; the reference class itself cannot travel to the GPU box -- its own figure is the committed "
+                      "fixture `cpu_baseline_reference_fixture`, timed on a DIFFERENT host" % (n_rows, 100.0 * done / full, t_used)}
 
 
 def hbm_block(kernel, st, seconds, note=None):
@@ -340,14 +342,26 @@ def hbm_block(kernel, st, seconds, note=None):
     return out
 
 
-def other_paths(urm, args, out=None):
+def other_paths(urm, args, out=None, cpu_jobs=None):
     """The remaining rows of SURVEY.md section 8 on the same URM shape, one short run each (N = 1 only): one roofline block per
     path.  Throughputs come from the handle's own stream events (call_ms); fractions are ALGORITHMIC work / time against the
-    MI355X peaks.  Fills `out` as it goes: what was measured before a failure stays."""
+    MI355X peaks.  Fills `out` as it goes: what was measured before a failure stays.  The CPU baseline leg of
+    a path is NOT run here: it is appended to `cpu_jobs` as a closure that fills the path's block, and main() runs those one after
+    the other once every GPU measurement is done and the URM-generating child process has exited (a leg that shares the host with
+    another busy process would flatter the GPU)."""
     import numpy as np
     from recsys2019_deeplearning_evaluation_amd import (IALS_MI355X_Epoch, MatrixFactorization_MI355X_Epoch,
                                                         SLIM_BPR_MI355X_Epoch)
     out = {} if out is None else out
+    cpu_jobs = [] if cpu_jobs is None else cpu_jobs
+
+    def later(tag, leg, ratio):
+        """ratio(block, baseline) -> the GPU / CPU speed-up of that path's own unit"""
+        def job():
+            blk = out[tag]
+            blk["cpu_baseline"] = leg()
+            blk["speedup_vs_cpu_baseline"] = ratio(blk, blk["cpu_baseline"]["value"])
+        cpu_jobs.append((tag, job))
 
     def mf_run(tag, epochs, note=None, **kw):
         m = MatrixFactorization_MI355X_Epoch(urm, n_factors=K_FACTORS, learning_rate=1e-3, init_std_dev=0.1, random_seed=7, **kw)
@@ -365,9 +379,10 @@ def other_paths(urm, args, out=None):
     mf_run("funk_svd_k128_batch1000_bias", 1, "20 001 mini-batches per epoch, in-LDS schedule 256 mini-batches at a time", algorithm_name="FUNK_SVD",
            batch_size=BATCH, sgd_mode="sgd", use_bias=True, negative_interactions_quota=0.0)
     if cpu:
-        out["funk_svd_k128_batch1000_bias"]["cpu_baseline"] = cpu_baseline_funk(urm, args.cpu_seconds)
-        out["funk_svd_k128_batch1000_bias"]["speedup_vs_cpu_baseline"] = (
-            out["funk_svd_k128_batch1000_bias"]["samples_per_s"] / out["funk_svd_k128_batch1000_bias"]["cpu_baseline"]["value"])
+        later("funk_svd_k128_batch1000_bias", lambda: cpu_baseline_funk(urm, args.cpu_seconds), lambda b, c: b["samples_per_s"] / c)
+    # the reference's own arithmetic type (MatrixFactorization_Cython_Epoch.pyx:65: double): the same headline epoch with float64 factors
+    mf_run("bpr_mf_k128_batch1000_fp64", 50, "float64 factors, plain sgd: the reference's arithmetic width; 48 k B algorithmic per sample",
+           algorithm_name="MF_BPR", batch_size=BATCH, sgd_mode="sgd", precision="fp64")
 
     note("paths: 32-model group")
     # REPLICA-BATCHED launches: 32 independent models (own factors, seed, sample stream), mini-batch b of all of them in ONE grid
@@ -492,8 +507,8 @@ def other_paths(urm, args, out=None):
         out["slim_bpr_%s" % ("symmetric" if symmetric else "dense")] = blk
         sl.close()
         if cpu:
-            blk["cpu_baseline"] = cpu_baseline_slim(urm, symmetric, args.cpu_seconds)
-            blk["speedup_vs_cpu_baseline"] = blk["samples_per_s"] / blk["cpu_baseline"]["value"]
+            later("slim_bpr_%s" % ("symmetric" if symmetric else "dense"), lambda symmetric=symmetric: cpu_baseline_slim(urm, symmetric, args.cpu_seconds),
+                  lambda b, c: b["samples_per_s"] / c)
 
     note("paths: slim, 4 models side by side")
     # R independent SLIM models on R streams (how the reference's search runs every SGD path: run_parameter_search.py:498-503); the
@@ -567,8 +582,7 @@ def other_paths(urm, args, out=None):
                         "row_kernel_ms": st["kernel_ms"]}
     ia.close()
     if cpu:
-        out["ials_k200"]["cpu_baseline"] = cpu_baseline_ials(conf, k, 1e-3, V0, args.cpu_seconds)
-        out["ials_k200"]["speedup_vs_cpu_baseline"] = out["ials_k200"]["cpu_baseline"]["value"] / out["ials_k200"]["seconds_per_epoch"]
+        later("ials_k200", lambda: cpu_baseline_ials(conf, k, 1e-3, V0, args.cpu_seconds), lambda b, c: c / b["seconds_per_epoch"])
     # the REFERENCE's own _update_row timed where /root/reference exists (tests/golden/make_ials_reference_timing.py): a committed fixture,
     # from another host than this run's -- next to, not instead of, the same-run port above
     try:
@@ -576,7 +590,8 @@ def other_paths(urm, args, out=None):
             fx = json.load(f)
         out["ials_k200"]["cpu_baseline_reference_fixture"] = {
             "value": fx["seconds_per_epoch_extrapolated"], "unit": "s/epoch", "cores": fx["blas_threads"], "kind": "reference-fixture",
-            "sample": "%d rows = %.2f %% of an epoch's flops in %.1f s on %s (%s)" % (fx["rows_timed"], 100 * fx["fraction_of_an_epochs_flops"], fx["seconds"],
+            "sample": "NOT this run and NOT this host: the reference's IALSRecommender._update_row, %d rows = %.2f %% of an epoch's flops in %.1f s on %s (%s); "
+                      "committed fixture tests/golden/ials_reference_timing.json" % (fx["rows_timed"], 100 * fx["fraction_of_an_epochs_flops"], fx["seconds"],
                                                                                    fx["cpu"], fx["generated"])}
     except Exception:
         pass
@@ -601,9 +616,188 @@ def other_paths(urm, args, out=None):
                                "note": "ML-1M shape (6 040 x 3 706, 1 000 209 interactions); algorithmic bytes = 16 k L_u + 8 k per step"}
     asy.close()
     if cpu:
-        out["asy_svd_ml1m_k64"]["cpu_baseline"] = cpu_baseline_asy(x1m, ka, args.cpu_seconds)
-        out["asy_svd_ml1m_k64"]["speedup_vs_cpu_baseline"] = out["asy_svd_ml1m_k64"]["samples_per_s"] / out["asy_svd_ml1m_k64"]["cpu_baseline"]["value"]
+        later("asy_svd_ml1m_k64", lambda: cpu_baseline_asy(x1m, ka, args.cpu_seconds), lambda b, c: b["samples_per_s"] / c)
     return out
+
+
+class HoldoutEvaluator:
+    """What Base/Evaluation/Evaluator.py:EvaluatorHoldout does per validation, restated for the bench's end-to-end row: every user
+    with a held-out item, in blocks of 1000 (Evaluator.py:406-408), recommender.recommend(block, cutoff, remove_seen_flag=True),
+    PRECISION / RECALL / MAP at the cutoff on the host.  Keeps its own wall clock (`seconds`, `calls`)."""
+
+    def __init__(self, URM_test, cutoff=10):
+        import numpy as np
+        self.URM_test = URM_test.tocsr()
+        self.cutoff = cutoff
+        self.users = np.flatnonzero(np.diff(self.URM_test.indptr) > 0).astype(np.int64)
+        self.seconds, self.calls = 0.0, 0
+
+    def evaluateRecommender(self, recommender):
+        import numpy as np
+        t0 = time.perf_counter()
+        X, c = self.URM_test, self.cutoff
+        hits_sum = recall_sum = map_sum = 0.0
+        for at in range(0, len(self.users), 1000):
+            block = self.users[at:at + 1000]
+            lists = recommender.recommend(block, cutoff=c, remove_seen_flag=True)
+            for u, rec in zip(block, lists):
+                rel = X.indices[X.indptr[u]:X.indptr[u + 1]]
+                hit = np.isin(np.asarray(rec[:c]), rel, assume_unique=True)
+                n_hit = float(hit.sum())
+                hits_sum += n_hit / c
+                recall_sum += n_hit / len(rel)
+                if n_hit:
+                    map_sum += float((hit * np.cumsum(hit) / (1.0 + np.arange(len(hit)))).sum()) / min(len(rel), c)
+        n = max(1, len(self.users))
+        res = {c: {"PRECISION": hits_sum / n, "RECALL": recall_sum / n, "MAP": map_sum / n}}
+        self.seconds += time.perf_counter() - t0
+        self.calls += 1
+        return res, "CUTOFF: %d - PRECISION: %.6f, RECALL: %.6f, MAP: %.6f" % (c, res[c]["PRECISION"], res[c]["RECALL"], res[c]["MAP"])
+
+
+def holdout_split(urm, seed=5):
+    """Leave one random interaction out per user with at least two (train, test) -- the shape of the suite's own validation splits."""
+    import numpy as np
+    import scipy.sparse as sps
+    rng = np.random.default_rng(seed)
+    lens = np.diff(urm.indptr)
+    pick = urm.indptr[:-1] + (rng.random(len(lens)) * np.maximum(lens, 1)).astype(np.int64)
+    pick = pick[lens >= 2]
+    keep = np.ones(urm.nnz, bool)
+    keep[pick] = False
+    rows = np.repeat(np.arange(urm.shape[0]), lens)
+    train = sps.csr_matrix((urm.data[keep], (rows[keep], urm.indices[keep])), shape=urm.shape, dtype=np.float32)
+    test = sps.csr_matrix((urm.data[pick], (rows[pick], urm.indices[pick])), shape=urm.shape, dtype=np.float32)
+    train.sort_indices()
+    return train, test
+
+
+def fit_rows(urm, out):
+    """Whole-`fit()` wall time THROUGH the recommender classes -- the only kind of number the reference publishes (BASELINE.md
+    section 1) and what "drops into the evaluation harness" costs end to end:
+      ItemKNNCFRecommender(urm).fit(topK=100, shrink=0)  (KNN/ItemKNNCFRecommender.py:31-54): PCIe upload, device constructor, build,
+        download, host CSR assembly into W_sparse;
+      MatrixFactorization_BPR_MI355X(train).fit(epochs=50, validation_every_n=5, evaluator_object=...)
+        (MatrixFactorization_Cython.py:37-143, Incremental_Training_Early_Stopping.py:91-192): one blocking call per epoch, and per
+        validation the factor download (_prepare_model_for_validation) + the evaluator's recommend() blocks on the device scorer."""
+    import numpy as np
+    from recsys2019_deeplearning_evaluation_amd import ItemKNNCFRecommender, MatrixFactorization_BPR_MI355X
+    rec = ItemKNNCFRecommender(urm, verbose=False)
+    walls = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        rec.fit(topK=TOPK, shrink=0)
+        walls.append(time.perf_counter() - t0)
+    st = rec.similarity_stats
+    out["itemknn_recommender_fit"] = {
+        "value": min(walls[1:]), "unit": "s", "first_call_s": walls[0], "repeats_s": walls[1:], "W_sparse_nnz": int(rec.W_sparse.nnz),
+        "kernel_ms": st.get("kernel_ms"), "definition": "ItemKNNCFRecommender(urm).fit(topK=100, shrink=0) wall: upload + constructor + build + "
+        "download + W_sparse (scipy CSR) assembly; best of 3 after one warm-up call"}
+    del rec
+
+    train, test = holdout_split(urm)
+    ev = HoldoutEvaluator(test, cutoff=10)
+
+    class Timed(MatrixFactorization_BPR_MI355X):
+        t_epoch = t_prepare = 0.0
+
+        def _run_epoch(self, num_epoch):
+            t0 = time.perf_counter()
+            super()._run_epoch(num_epoch)
+            Timed.t_epoch += time.perf_counter() - t0
+
+        def _prepare_model_for_validation(self):
+            t0 = time.perf_counter()
+            super()._prepare_model_for_validation()
+            Timed.t_prepare += time.perf_counter() - t0
+
+    epochs, every = 50, 5
+    m = Timed(train, verbose=False)
+    t0 = time.perf_counter()
+    m.fit(epochs=epochs, batch_size=BATCH, num_factors=K_FACTORS, learning_rate=1e-3, sgd_mode="sgd", random_seed=42,
+          validation_every_n=every, stop_on_validation=False, validation_metric="MAP", evaluator_object=ev)
+    wall = time.perf_counter() - t0
+    per_epoch = (train.shape[0] // BATCH + 1) * BATCH
+    out["bpr_mf_recommender_fit_50_epochs_validation_every_5"] = {
+        "value": wall / epochs, "unit": "s/epoch", "fit_wall_s": wall, "epochs": epochs, "validations": ev.calls,
+        "train_s": Timed.t_epoch, "factor_download_s": Timed.t_prepare, "evaluate_s": ev.seconds,
+        "evaluated_users_per_validation": int(len(ev.users)), "train_samples_per_s": epochs * per_epoch / max(Timed.t_epoch, 1e-9),
+        "end_to_end_samples_per_s": epochs * per_epoch / wall, "best_MAP": m.best_validation_metric,
+        "definition": "MatrixFactorization_BPR_MI355X(train).fit(epochs=50, batch 1000, k=128, validation_every_n=5, MAP@10 on a leave-one-out "
+                      "split, every test user) wall / 50: constructor, one blocking epoch call per epoch, factor download + device-scored "
+                      "recommend() blocks per validation"}
+    return out
+
+
+DRIVER_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+               "config")
+EXTRA_FILE = "bench_extra.json"
+
+
+def _sig(x, digits=5):
+    """Numbers of the compact line carry 5 significant digits (the full-precision record is the extra file)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (digits, x))
+
+
+def _slim(d, keys):
+    return {k: _sig(d[k]) for k in keys if d.get(k) is not None}
+
+
+def compact_line(out):
+    """The ONE line of stdout: the driver's keys, `roofline` and `cpu_baseline` of the headline kernel, and one short row per other
+    hot path (value, unit, bound, fraction of that bound, CPU figure of the same run) -- no notes, no per-piece arrays.  Everything
+    else the run measured is in EXTRA_FILE (and, as one earlier line, on stderr).  Stays far below 8 KB whatever the sections hold
+    (tests/test_bench_line.py builds it from a recorded run)."""
+    line = {k: _sig(out[k]) for k in DRIVER_KEYS if k in out}
+    line["roofline"] = _slim(out.get("roofline", {}), ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
+                                                      "algorithmic_bytes_per_launch", "timed_launches"))
+    line["roofline"].setdefault("traffic", None)
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = _slim(out["cpu_baseline"], ("value", "unit", "cores", "kind", "host_cpu_count"))
+        line["cpu_baseline"]["sample"] = str(out["cpu_baseline"].get("sample", ""))[:160]
+    extra = out.get("extra", {})
+    for key in ("itemknn", "itemknn_netflix_config4"):
+        blk = extra.get(key)
+        if isinstance(blk, dict) and blk.get("cosine_build_s") is not None:
+            line[key + "_build_s"] = _sig(blk["cosine_build_s"])
+    if isinstance(extra.get("ials"), dict) and extra["ials"].get("seconds_per_epoch") is not None:
+        line["ials_k200_sharded_epoch_s"] = _sig(extra["ials"]["seconds_per_epoch"])
+    if "speedup_vs_cpu_baseline" in extra:
+        line["speedup_vs_cpu_baseline"] = _sig(extra["speedup_vs_cpu_baseline"])
+    rows = {}
+    for name, row in out.get("paths", {}).items():
+        if row.get("value") is None:
+            continue
+        rows[name] = _slim(row, ("value", "unit", "bound", "frac", "cpu_value", "cpu_kind", "build_s", "fit_resident_s", "predicted_8_gpu_one_ring"))
+        if isinstance(rows[name].get("bound"), str):
+            rows[name]["bound"] = rows[name]["bound"].split(" ")[0]
+    line["paths"] = rows
+    for key in ("paths_error", "ials_error", "fit_rows_error", "cpu_legs_error"):
+        if key in extra:
+            line[key] = str(extra[key])[:120]
+    line["extra_file"] = EXTRA_FILE
+    return line
+
+
+def emit(out):
+    """Full record -> EXTRA_FILE next to bench.py (and under gpurun_out/ when that scratch directory exists) and one stderr line;
+    compact record -> the one stdout line."""
+    full = json.dumps(out)
+    for folder in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(folder):
+            try:
+                with open(os.path.join(folder, EXTRA_FILE), "w") as f:
+                    f.write(full + "\n")
+            except OSError:
+                pass
+    print("[bench extra] " + full, file=sys.stderr, flush=True)
+    line = json.dumps(compact_line(out))
+    assert len(line) < 8192, "the stdout line must stay short enough for the driver to parse (%d bytes)" % len(line)
+    print(line, flush=True)
 
 
 def visible_devices():
@@ -886,45 +1080,56 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
     for rep in range(4):
         net.barrier()
         t1 = time.perf_counter()
-        job.build()                              # kernel on this rank's columns + the all-gather: result resident on every device
+        k_ms = job.build()                       # kernel on this rank's columns + the all-gather: result resident on every device
         net.barrier()
         dt = net.max(time.perf_counter() - t1)
         if rep > 0 and (best is None or dt < best):       # the first repetition warms the communicator up
-            best, kernel_ms = dt, sim.stats()["kernel_ms"]
+            best, kernel_ms = dt, k_ms                    # (k_ms: the column kernel's time summed over ALL pieces of this rank's build)
     t2 = time.perf_counter()
     idx, val = job.download() if rank == 0 else (None, None)
     download_s = time.perf_counter() - t2
     sst = sim.stats()
     # the bound of the accumulation, measured on THIS device in THIS run (the round-1 microbenchmark figure is the fall-back)
     global LDS_ATOMIC_PEAK
+    fixed_peak = 21.6e9 * 256
     peak_source = "profiles/r1_lds_atomics_microbench.txt (21.6 lane-adds per ns and CU x 256)"
     try:
         from recsys2019_deeplearning_evaluation_amd import _native as _N
         measured = _N.lds_atomic_rate()
-        if measured > 0:
+        if measured > fixed_peak:                      # the stricter (higher) of the two peaks is the one the fraction is taken of
             LDS_ATOMIC_PEAK = measured
             peak_source = "mi355rec_lds_atomic_rate in this run: ds_add_u32 on uniformly random cells, one 1024-thread workgroup per CU"
+        else:
+            LDS_ATOMIC_PEAK = fixed_peak
+            peak_source += "; live measurement in this run was lower (%.3e)" % measured
     except Exception as exc:
         peak_source += "; live measurement failed: %r" % (exc,)
     pairs = float(np.asarray(costs, dtype=np.float64)[my_columns].sum())
     pair_rate = pairs / (kernel_ms * 1e-3)
-    alg_gbps = sst["algorithmic_bytes"] / (sst["kernel_ms"] * 1e-3) / 1e9
+    alg_gbps = 8.0 * pairs / (kernel_ms * 1e-3) / 1e9
     block = {
         "cosine_build_s": best, "definition": "kernel on this rank's columns (interleaved partition: equal counts, equal cost) + one "
                                               "all-gather; full (n_cols x topK) result resident on every rank's device (max over ranks, best of 3)",
-        "create_s": create_resident_s, "fit_s": create_resident_s + best,
-        "fit_definition": "constructor from the device-resident URM (ResidentURM: uploaded once per search) + build; Python host code included",
-        "create_incl_pcie_upload_s": create_s, "fit_incl_pcie_upload_s": create_s + best, "download_to_host_rank0_s": download_s,
+        "create_s": create_s, "fit_s": create_s + best,
+        "fit_definition": "constructor from the HOST URM (PCIe upload + device set-up) + build: the same meaning as in rounds 1-4; Python host code included",
+        "create_incl_pcie_upload_s": create_s, "fit_incl_pcie_upload_s": create_s + best,
+        "create_resident_s": create_resident_s, "fit_resident_s": create_resident_s + best,
+        "fit_resident_definition": "constructor from the device-resident URM (ResidentURM: uploaded once per search; best of 3) + build",
+        "download_to_host_rank0_s": download_s,
         "topK": TOPK, "columns_this_rank": int(len(my_columns)), "kernel_ms_this_rank": kernel_ms,
         "exchange_bytes_per_rank": job.exchange_bytes_per_rank(),
         "transport": "none" if world == 1 else ("rccl-ctypes" if net.comm is not None else "torch." + net.dist.get_backend()),
         "nnz_out": int((idx >= 0).sum()) if idx is not None else None,
         "roofline": {"bound": "lds-atomics", "kernel": "sim_column_kernel", "achieved": pair_rate, "peak": LDS_ATOMIC_PEAK,
                      "unit": "pair-adds/s", "frac": pair_rate / LDS_ATOMIC_PEAK, "peak_source": peak_source, "pairs_this_rank": pairs,
+                     "peak_fixed_round1": fixed_peak, "frac_of_fixed_round1_peak": pair_rate / fixed_peak,
                      "stream_GBps": 2.0 * pairs / (kernel_ms * 1e-3) / 1e9,
                      "survey_8d_algorithmic_GBps": alg_gbps, "survey_8d_algorithmic_over_hbm_peak": alg_gbps / HBM_PEAK_GBPS,
                      "note": "SURVEY 8(d)'s byte model (8 B per co-occurrence pair) exceeds the HBM peak because the kernel streams "
                              "2-byte ids from L2/MALL; the bound that holds is the LDS atomic rate"}}
+    if not (0.0 < block["roofline"]["frac"] <= 1.0):
+        # a fraction above 1 means the timed kernel is not the work that was divided by it: never print such a block
+        block["roofline"] = {"error": "refused: frac %.3f outside (0, 1] (kernel_ms %.4f for %.3e pairs)" % (block["roofline"]["frac"], kernel_ms, pairs)}
     if world == 1 and not args.no_extras:
         # the 8-GPU build of BASELINE config 4, one part after the other on this GPU: kernel time per part (measured), the
         # gathered buffer assembled with device copies (measured: what the last ring step leaves behind), and the exchange
@@ -990,9 +1195,9 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
     block["shape"] = "%dx%d nnz=%d" % (urm.shape[0], urm.shape[1], urm.nnz)
     extra[key] = block
     if key == "itemknn":     # flat aliases kept for continuity with round 1's line
-        extra.update({"itemknn_cosine_build_s": best, "itemknn_create_s": create_resident_s, "itemknn_fit_s": create_resident_s + best,
-                      "itemknn_fit_incl_pcie_upload_s": create_s + best,
-                      "itemknn_kernel_ms_this_rank": kernel_ms, "itemknn_frac_of_lds_atomic_peak": pair_rate / LDS_ATOMIC_PEAK})
+        extra.update({"itemknn_cosine_build_s": best, "itemknn_create_s": create_s, "itemknn_fit_s": create_s + best,
+                      "itemknn_create_resident_s": create_resident_s, "itemknn_fit_resident_s": create_resident_s + best,
+                      "itemknn_kernel_ms_this_rank": kernel_ms, "itemknn_frac_of_lds_atomic_peak": block["roofline"].get("frac")})
     return costs
 
 
@@ -1109,13 +1314,19 @@ def main():
            "roofline": roofline, "extra": extra}
 
     note("ials section done")
+    cpu_jobs = []
     if rank == 0 and world == 1 and not args.no_extras and not args.no_paths:
         out["extra"]["paths"] = {}
         try:
-            other_paths(urm, args, out["extra"]["paths"])
+            other_paths(urm, args, out["extra"]["paths"], cpu_jobs)
         except Exception as exc:                       # the headline line must survive a failure in the side measurements, and so
             out["extra"]["paths_error"] = repr(exc)    # must the paths measured before it
-    note("other paths done")
+        note("other paths done")
+        try:
+            fit_rows(urm, out["extra"]["paths"])
+        except Exception as exc:
+            out["extra"]["fit_rows_error"] = repr(exc)
+        note("recommender fit() rows done")
     if netflix_child is not None:
         try:
             netflix_child.wait(timeout=float(os.environ.get("BENCH_NETFLIX_WAIT_S", "90")))
@@ -1129,9 +1340,12 @@ def main():
         except Exception as exc:                        # the headline line must survive: the section is reported as skipped
             try:
                 netflix_child.kill()
+                netflix_child.wait(timeout=10)
             except Exception:
                 pass
             out["extra"]["itemknn_netflix_config4"] = {"skipped": repr(exc)}
+    # ---- CPU baseline legs: the LAST thing the run does -- every GPU measurement is finished and the generator child has exited
+    # (or was killed), so each leg has the host to itself, one after the other
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline_bpr(urm, args.cpu_seconds)
         base["host_cpu_count"] = os.cpu_count()
@@ -1139,15 +1353,34 @@ def main():
         out["extra"]["speedup_vs_cpu_baseline"] = value / base["value"]
         if costs is not None:
             sb = cpu_baseline_sim(urm, costs, args.cpu_seconds)
-            out["extra"]["itemknn"]["cpu_baseline"] = sb
-            out["extra"]["itemknn"]["speedup_vs_cpu_baseline"] = sb["value"] / out["extra"]["itemknn"]["cosine_build_s"]
-            out["extra"]["itemknn"]["fit_speedup_vs_cpu_baseline"] = sb["value"] / out["extra"]["itemknn"]["fit_s"]
+            ik = out["extra"]["itemknn"]
+            ik["cpu_baseline"] = sb
+            ik["speedup_vs_cpu_baseline"] = sb["value"] / ik["cosine_build_s"]
+            ik["fit_speedup_vs_cpu_baseline"] = sb["value"] / ik["fit_s"]                 # (upload-inclusive fit)
+            ik["fit_resident_speedup_vs_cpu_baseline"] = sb["value"] / ik["fit_resident_s"]
+            rf = out["extra"].get("paths", {}).get("itemknn_recommender_fit")
+            if rf:
+                rf["cpu_baseline"] = sb
+                rf["speedup_vs_cpu_baseline"] = sb["value"] / rf["value"]
+        for tag, job in cpu_jobs:
+            note("cpu leg: %s" % tag)
+            try:
+                job()
+            except Exception as exc:
+                out["extra"].setdefault("cpu_legs_error", "")
+                out["extra"]["cpu_legs_error"] += "%s: %r; " % (tag, exc)
     # one compact row per path at the TOP level (value, unit, fraction of the bound, CPU baseline of the same run)
     table = {"bpr_mf_k128_batch1000_one_model": {"value": value, "unit": "samples/s", "bound": "hbm", "frac": roofline["frac"],
                                                  "cpu_value": out.get("cpu_baseline", {}).get("value"), "cpu_kind": out.get("cpu_baseline", {}).get("kind")}}
     for name, blk in out["extra"].get("paths", {}).items():
         if not isinstance(blk, dict):
             continue
+        if "value" in blk and "unit" in blk and "definition" in blk:          # (the end-to-end fit() rows)
+            table[name] = {"value": blk["value"], "unit": blk["unit"], "bound": "end-to-end", "cpu_value": (blk.get("cpu_baseline") or {}).get("value"),
+                           "cpu_kind": (blk.get("cpu_baseline") or {}).get("kind")}
+            continue
+        if "samples_per_s" not in blk and "users_per_s" not in blk and "seconds_per_epoch" not in blk:
+            continue                                                             # (a block without a rate: modelled figures only)
         val = blk.get("samples_per_s", blk.get("users_per_s", blk.get("seconds_per_epoch")))
         table[name] = {"value": val, "unit": "samples/s" if "samples_per_s" in blk else ("users/s" if "users_per_s" in blk else "s/epoch"),
                        "bound": blk.get("bound"), "frac": blk.get("frac"), "cpu_value": (blk.get("cpu_baseline") or {}).get("value"),
@@ -1157,15 +1390,16 @@ def main():
             table[name].update({"cpu_reference_fixture_value": fx.get("value"), "cpu_reference_fixture_kind": fx.get("kind")})
     if "itemknn" in out["extra"]:
         ik = out["extra"]["itemknn"]
-        table["itemknn_cosine_top100"] = {"value": ik.get("fit_s"), "unit": "s (constructor from the HBM-resident URM + build)", "build_s": ik.get("cosine_build_s"),
-                                          "fit_incl_pcie_upload_s": ik.get("fit_incl_pcie_upload_s"),
+        table["itemknn_cosine_top100"] = {"value": ik.get("fit_incl_pcie_upload_s"), "unit": "s (upload + constructor + build)", "build_s": ik.get("cosine_build_s"),
+                                          "fit_resident_s": ik.get("fit_resident_s"),
                                           "bound": "lds-atomics", "frac": ik.get("roofline", {}).get("frac"),
                                           "cpu_value": (ik.get("cpu_baseline") or {}).get("value"), "cpu_kind": (ik.get("cpu_baseline") or {}).get("kind")}
     nf = out["extra"].get("itemknn_netflix_config4")
     if isinstance(nf, dict) and "fit_s" in nf:
         e8 = nf.get("emulated_8_way", {})
         table["itemknn_cosine_top100_netflix_shape_config4"] = {
-            "value": nf.get("fit_s"), "unit": "s (constructor from the HBM-resident URM + build)", "build_s": nf.get("cosine_build_s"),
+            "value": nf.get("fit_incl_pcie_upload_s"), "unit": "s (upload + constructor + build)", "build_s": nf.get("cosine_build_s"),
+            "fit_resident_s": nf.get("fit_resident_s"), "predicted_8_gpu_one_ring": (e8.get("predicted_build_speedup") or {}).get("one_ring"),
             "bound": "lds-atomics", "frac": nf.get("roofline", {}).get("frac"),
             "emulated_8_way_kernel_speedup": e8.get("kernel_speedup_vs_1gpu"),
             "predicted_8_gpu_build_speedup": e8.get("predicted_build_speedup"),
@@ -1175,7 +1409,7 @@ def main():
     note("done")
     faulthandler.cancel_dump_traceback_later()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     net.close()
 
 

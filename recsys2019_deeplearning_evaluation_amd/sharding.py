@@ -209,7 +209,7 @@ class ShardedSimilarityBuild:
         mine = len(self.columns[self.rank])
         count = max(0, min(r1, mine) - r0)
         if count == 0:
-            return
+            return False
         at = self.gather.offsets[c]
         d_idx, d_val = self.local.address(at), self.local.address(at + (r1 - r0) * self.topK)
         if self.partition == "interleaved":
@@ -221,15 +221,21 @@ class ShardedSimilarityBuild:
             s, e = self.ranges[self.rank]
             a, b = s + r0, s + r0 + count
             self.sim.compute_slabs_device(a if a > 0 else None, b if b < self.n else None, d_idx, d_val)
+        return True
 
     def build(self):
         """Kernel on this rank's columns, piece by piece, each piece's all-gather behind the next piece's kernel; afterwards the
-        gathered slabs are valid on this device.  Blocking."""
+        gathered slabs are valid on this device.  Blocking.  Returns the column kernel's milliseconds summed over the pieces (the
+        similarity object's stats() only ever hold the LAST launch: a caller that divides this rank's work by a kernel time needs the sum)."""
+        kernel_ms = 0.0
         for c in range(len(self.rows)):
-            self._build_piece(c)
-            self.sim.synchronize()
+            if self._build_piece(c):
+                self.sim.synchronize()
+                kernel_ms += float(self.sim.stats()["kernel_ms"])
             self.gather.start(c)
         self.gather.finish()
+        self.kernel_ms = kernel_ms
+        return kernel_ms
 
     def download(self):
         """(idx, val) NumPy arrays for ALL columns."""
