@@ -636,18 +636,24 @@ class HoldoutEvaluator:
         import numpy as np
         t0 = time.perf_counter()
         X, c = self.URM_test, self.cutoff
+        n_items = X.shape[1]
         hits_sum = recall_sum = map_sum = 0.0
+        rank_weight = 1.0 / (1.0 + np.arange(c))
         for at in range(0, len(self.users), 1000):
             block = self.users[at:at + 1000]
             lists = recommender.recommend(block, cutoff=c, remove_seen_flag=True)
-            for u, rec in zip(block, lists):
-                rel = X.indices[X.indptr[u]:X.indptr[u + 1]]
-                hit = np.isin(np.asarray(rec[:c]), rel, assume_unique=True)
-                n_hit = float(hit.sum())
-                hits_sum += n_hit / c
-                recall_sum += n_hit / len(rel)
-                if n_hit:
-                    map_sum += float((hit * np.cumsum(hit) / (1.0 + np.arange(len(hit)))).sum()) / min(len(rel), c)
+            rec = np.full((len(block), c), -1, np.int64)
+            for r, row in enumerate(lists):
+                rec[r, :min(c, len(row))] = row[:c]
+            # is_relevant for the whole block at once: (row, item) pairs as single keys
+            n_rel = (X.indptr[block + 1] - X.indptr[block]).astype(np.int64)
+            rows = np.repeat(np.arange(len(block), dtype=np.int64), n_rel)
+            cols = np.concatenate([X.indices[X.indptr[u]:X.indptr[u + 1]] for u in block]) if len(block) else np.zeros(0, np.int64)
+            hit = np.isin(np.arange(len(block), dtype=np.int64)[:, None] * n_items + rec, rows * n_items + cols) & (rec >= 0)
+            n_hit = hit.sum(1).astype(np.float64)
+            hits_sum += float((n_hit / c).sum())
+            recall_sum += float((n_hit / n_rel).sum())
+            map_sum += float(((hit * np.cumsum(hit, 1) * rank_weight).sum(1) / np.minimum(n_rel, c)).sum())
         n = max(1, len(self.users))
         res = {c: {"PRECISION": hits_sum / n, "RECALL": recall_sum / n, "MAP": map_sum / n}}
         self.seconds += time.perf_counter() - t0

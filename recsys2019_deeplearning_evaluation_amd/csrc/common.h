@@ -80,6 +80,10 @@ struct DeviceBuffer {
         ptr = nullptr;
         count = 0;
     }
+    void swap(DeviceBuffer &other) {
+        std::swap(ptr, other.ptr);
+        std::swap(count, other.count);
+    }
     void alloc(size_t n) {
         release();
         if (n) ptr = static_cast<T *>(device_block(n * sizeof(T)));

@@ -59,6 +59,12 @@ struct SimParams {
     float *cand_val;
     const int *csc_ptr, *csc_idx;
     const float *csc_val;
+    // Walk lists (built by the constructor, build_walk_lists): per column, what the accumulation walks -- one entry per SLICE of a user's
+    // profile segment (at most WALK_SLICE chunks of 8 entries), longest slices first.  walk8: {first entry, end entry} of the slice in
+    // the profile stream (all-ones data: no weight); walk16: {first, end, bits of the column-side value times the row weight, 0}.
+    // With accumulator tiles (n_tiles > 1) an entry is a whole user: .x = the row, whose per-tile segment bounds come from seg_ptr.
+    const uint2 *walk8;
+    const uint4 *walk16;
     const float *row_w;
     const float *norm, *norm_alpha, *norm_1ma;
     const int4 *items;  // work items of this call, most expensive first: {column, part, n_parts, first part slot}
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         if (slot >= p.n_items) break;
         const int4 item = s_item;
         const int c = item.x;
-        int cbeg = s_range.x, cend = s_range.y;
+        const int cbeg = s_range.x, cend = s_range.y;    // the column's walk list
         int4 nx_item = make_int4(0, 0, 0, 0);
         int2 nx_range = make_int2(0, 0);
         auto request_next = [&]() {          // (B) thread 0
@@ -208,11 +214,8 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             s_range = nx_range;
             nx_slot = -1;
         };
-        if (item.z > 1) {   // a heavy column split over several workgroups: this one walks users [cbeg, cend) of it
-            const int per = (((cend - cbeg + item.z - 1) / item.z) + 63) & ~63;
-            cbeg = min(cend, cbeg + item.y * per);
-            cend = min(cend, cbeg + per);
-        }
+        // (a heavy column split over several workgroups, item.z > 1: this one is part item.y, whose wavefronts take their stripes of
+        // the walk list like the wavefronts of any other part -- see the dealing below)
         const size_t out_base = (size_t)(p.out_slot ? p.out_slot[c] : c - p.start_col) * p.topK;
         int *wg_cand_idx = p.cand_idx + (size_t)blockIdx.x * p.n_tiles * p.topK;
         float *wg_cand_val = p.cand_val + (size_t)blockIdx.x * p.n_tiles * p.topK;
@@ -232,41 +235,68 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             s_kmax = 0u;
         }
 
-        // The column's users are dealt to the wavefronts in equal contiguous runs (a column with few users -- the long
-        // tail: most columns have far fewer than WAVES x 64 of them -- still keeps every wavefront busy).
+        // The column's walk list (slices of user profiles, longest first) is dealt to the wavefronts in stripes: units of GPW consecutive
+        // entries -- one per lane group -- go to the NV = WAVES x parts "virtual wavefronts" of the column in serpentine order (every
+        // other stripe reversed), so every wavefront of every part sees the same mix of lengths; entry q of virtual wavefront vw is
+        //     cbeg + ((q / GPW) * NV + pos) * GPW + q % GPW,     pos = vw or NV - 1 - vw by the parity of the stripe q / GPW.
+        // Consecutive entries of the sorted list have (nearly) the same number of chunks: the GPW groups of a wavefront finish their
+        // entries of a round together and the wavefronts of a column finish together -- with the CSC's row order and whole profiles
+        // one heavy user kept its lane group busy while the others idled (42 of 64 lanes per ds_add at ML-20M shape, scripts/analysis/
+        // sim_lane_census.py; 59 with this dealing).
         constexpr int WAVES = THREADS / 64, GPW = 64 / G;
         const int wave = tid >> 6, sub = lane / G;
-        const int per_wave = (cend - cbeg + WAVES - 1) / WAVES;
-        const int wbeg = min(cend, cbeg + wave * per_wave), wend = min(cend, wbeg + per_wave);
-        // User ids / weights and CSR bounds are the only dependent loads of the stream.  They run two rounds (of 64
-        // users per wavefront) ahead: ids of round r+2 and bounds of round r+1 are requested while round r streams,
-        // and the first round's ids are requested before the accumulator is cleared.
-        auto load_user = [&](int q, int &u, float &cv) {
-            if (q < wend) {
-                u = p.csc_idx[q];
-                cv = (UNIT || p.unit_col) ? 1.f : p.csc_val[q];
+        const int NV = WAVES * item.z, vw = item.y * WAVES + wave;
+        auto entry_of = [&](int q) {                   // position in the column's walk list of this wavefront's q-th entry
+            const int stripe = q / GPW, pos = (stripe & 1) ? NV - 1 - vw : vw;
+            return cbeg + (stripe * NV + pos) * GPW + (q % GPW);
+        };
+        // Walk entries (and, with accumulator tiles, the CSR bounds behind them) are the only dependent loads of the stream.  They
+        // run two rounds (of 64 entries per wavefront) ahead: entries of round r+2 and bounds of round r+1 are requested while round r
+        // streams, and the first round's entries are requested before the accumulator is cleared.
+        auto load_user = [&](int q, int &ex, int &ey, float &cv) {
+            const int at = entry_of(q);
+            if (at < cend) {
+                if (UNIT) {
+                    const uint2 e = p.walk8[at];
+                    ex = (int)e.x;
+                    ey = (int)e.y;
+                    cv = 1.f;
+                } else {
+                    const uint4 e = p.walk16[at];
+                    ex = (int)e.x;
+                    ey = (int)e.y;
+                    cv = __uint_as_float(e.z);
+                }
+            } else {
+                ex = 0;
+                ey = -1;                               // (marks a lane without an entry)
             }
         };
-        auto load_bounds = [&](bool valid, int u, float cv, int &rs, int &re, float &r) {
-            if (valid) {
-                const int *sp = p.seg_ptr + ((size_t)u * p.n_tiles + tile);
+        auto load_bounds = [&](int ex, int ey, float cv, int &rs, int &re, float &r) {
+            r = cv;
+            if (p.n_tiles == 1) {
+                rs = ex;
+                re = ey;
+            } else if (ey >= 0) {                      // accumulator tiles: .x is the row
+                const int *sp = p.seg_ptr + ((size_t)ex * p.n_tiles + tile);
                 rs = sp[0];
                 re = sp[1];
-                r = cv;
-                if (MODE == ACC_WIDE && p.row_w) r *= p.row_w[u];
+            } else {
+                rs = 0;
+                re = -1;
             }
         };
-        int u_first = 0, u_next = 0, t_rs = 0, t_re = 0;
+        int x_first = 0, y_first = -1, x_next = 0, y_next = -1, t_rs = 0, t_re = -1;
         float cv_first = 1.f, cv_next = 1.f, t_r = 0.f;
-        load_user(wbeg + lane, u_first, cv_first);
-        load_user(wbeg + 64 + lane, u_next, cv_next);
+        load_user(lane, x_first, y_first, cv_first);
+        load_user(64 + lane, x_next, y_next, cv_next);
 
         // ---- clear this_item_weights (.pyx:365-370) ----
         {
             float4 *a4 = reinterpret_cast<float4 *>(acc);
             for (int w = tid; w < p.acc_words / 4; w += THREADS) a4[w] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        load_bounds(wbeg + lane < wend, u_first, cv_first, t_rs, t_re, t_r);
+        load_bounds(x_first, y_first, cv_first, t_rs, t_re, t_r);
         __syncthreads();
         mark(0);
 
@@ -298,16 +328,13 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         const uint4 *idx8 = reinterpret_cast<const uint4 *>(p.seg_idx16);
         const float4 *val4 = reinterpret_cast<const float4 *>(p.seg_val);
         const uint4 *val8 = reinterpret_cast<const uint4 *>(p.seg_val16);
-        int *tab = reinterpret_cast<int *>(aux) + wave * 192;       // [64] x {rs, re, weight}
-        for (int base = wbeg; base < wend; base += 64) {
-            const int n_here = min(64, wend - base);
-            if (lane < n_here) {
-                tab[lane * 3] = t_rs;
-                tab[lane * 3 + 1] = t_re;
-                tab[lane * 3 + 2] = __float_as_int(t_r);
-            }
-            load_bounds(base + 64 + lane < wend, u_next, cv_next, t_rs, t_re, t_r);     // for the next round
-            load_user(base + 128 + lane, u_next, cv_next);                             // for the round after
+        int4 *tab = reinterpret_cast<int4 *>(aux) + wave * 64;       // [64] x {rs, re, weight, -}: one 16-byte read per entry
+        for (int base = 0; entry_of(base) < cend; base += 64) {
+            const bool have = t_re >= 0;                 // (a prefix of the lanes: entry_of grows with q)
+            const int n_here = __popcll(__ballot(have));
+            if (have) tab[lane] = make_int4(t_rs, t_re, __float_as_int(t_r), 0);
+            load_bounds(x_next, y_next, cv_next, t_rs, t_re, t_r);                     // for the next round
+            load_user(base + 128 + lane, x_next, y_next, cv_next);                    // for the round after
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -321,9 +348,10 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                     m += GPW;
                     f_have = m < n_here;
                     if (f_have) {
-                        f_t = tab[m * 3];
-                        f_re = tab[m * 3 + 1];
-                        f_r = __int_as_float(tab[m * 3 + 2]);
+                        const int4 e = tab[m];
+                        f_t = e.x;
+                        f_re = e.y;
+                        f_r = __int_as_float(e.z);
                     }
                 } while (f_have && f_t >= f_re);      // empty segments exist only with accumulator tiles
             };
@@ -551,7 +579,9 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                 uint64_t *cand = reinterpret_cast<uint64_t *>(aux);
                 if (tid == 0) sc.out_count = 0;
                 scan_cells([&](int round, float v, float norm_j) {
-                    if (v >= Tf * approx_denominator(form, v, norm_j)) {          // (Tf and the denominators are positive: a zero cell never passes)
+                    // (v > 0 is tested on its own: the rounds of a batch that lie behind the tile read zero CELLS by construction, but their
+                    // NORMS rest on the buffer range check covering the scalar offset -- a zero cell must not pass on a stale norm)
+                    if (v > 0.f && v >= Tf * approx_denominator(form, v, norm_j)) {
                         const uint32_t at = atomicAdd(&s_ncand, 1u);
                         if (at < (uint32_t)CAND_MAX) cand[at] = ((uint64_t)__float_as_uint(norm_j) << 32) | (uint32_t)(tid_o + round * THREADS);
                     }
@@ -1139,6 +1169,83 @@ __global__ void norms_kernel(const double *sumsq, int n_cols, int set_based, int
     }
 }
 
+// ---- walk lists: what the column kernel's accumulation walks (see SimParams::walk8) ------------------------------------------------
+// A user's profile segment is cut into slices of at most WALK_SLICE chunks (of 8 entries); the slices of ALL rows are ordered by
+// descending length once (a few hundred thousand of them), the (column, slice) pairs are generated in that order from the CSR rows
+// and a STABLE sort by column leaves every column's slices longest first.
+constexpr int WALK_SLICE = 128;
+
+// slices per row (tiled accumulators: the row itself is the entry -- its segments differ per tile)
+__global__ void walk_row_slices_kernel(const int *csr_ptr, const int *seg_ptr, int n_rows, int tiled, int *n_slices) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_rows) return;
+    const int len = csr_ptr[u + 1] - csr_ptr[u];
+    int n = 0;
+    if (len > 0) n = tiled ? 1 : ((seg_ptr[u + 1] - seg_ptr[u]) / 8 + WALK_SLICE - 1) / WALK_SLICE;
+    n_slices[u] = n;
+}
+
+// one record per slice: key = its chunks (tiled: the row's chunks over all tiles, clamped), value = row | slice << 32
+__global__ void walk_slice_records_kernel(const int *csr_ptr, const int *seg_ptr, const int *slice_off, int n_rows, int tiled, int n_tiles,
+                                          unsigned *key, unsigned long long *rec) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_rows) return;
+    const int at = slice_off[u], n = slice_off[u + 1] - at;
+    if (n == 0) return;
+    if (tiled) {
+        const int chunks = (seg_ptr[(size_t)(u + 1) * n_tiles] - seg_ptr[(size_t)u * n_tiles]) / 8;
+        key[at] = (unsigned)min(chunks / 4, 255);
+        rec[at] = (unsigned long long)(unsigned)u;
+        return;
+    }
+    const int chunks = (seg_ptr[u + 1] - seg_ptr[u]) / 8;
+    for (int j = 0; j < n; ++j) {
+        key[at + j] = (unsigned)min(WALK_SLICE, chunks - j * WALK_SLICE);
+        rec[at + j] = (unsigned long long)(unsigned)u | ((unsigned long long)j << 32);
+    }
+}
+
+__global__ void walk_record_lengths_kernel(const unsigned long long *rec, const int *csr_ptr, int n_rec, int *len) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rec) {
+        const int u = (int)(unsigned)rec[r];
+        len[r] = csr_ptr[u + 1] - csr_ptr[u];
+    }
+    if (r == n_rec) len[r] = 0;
+}
+
+// One workgroup per slice record (in sorted order): its (column, entry) pairs, one per stored cell of the row.  WIDE: 16-byte entries
+// with the column-side value of the cell (times the row's weight), else 8-byte entries.
+template <bool WIDE>
+__global__ __launch_bounds__(256) void walk_generate_kernel(const unsigned long long *rec, const int *out_off, const int *csr_ptr, const int *csr_idx,
+                                                            const float *csr_val, const int *seg_ptr, const float *row_w, int unit_col, int tiled,
+                                                            int *key, void *entries) {
+    const int r = blockIdx.x;
+    const unsigned long long rc = rec[r];
+    const int u = (int)(unsigned)rc, j = (int)(rc >> 32);
+    const int a = csr_ptr[u], len = csr_ptr[u + 1] - a, at = out_off[r];
+    unsigned ex, ey;
+    if (tiled) {
+        ex = (unsigned)u;
+        ey = 0u;
+    } else {
+        const int s0 = seg_ptr[u], s1 = seg_ptr[u + 1];
+        ex = (unsigned)(s0 + j * WALK_SLICE * 8);
+        ey = (unsigned)min(s1, s0 + (j + 1) * WALK_SLICE * 8);
+    }
+    const float w = row_w ? row_w[u] : 1.f;
+    for (int i = threadIdx.x; i < len; i += 256) {
+        key[at + i] = csr_idx[a + i];
+        if (WIDE) {
+            float cv = unit_col ? 1.f : csr_val[a + i];
+            if (row_w) cv *= w;
+            reinterpret_cast<uint4 *>(entries)[at + i] = make_uint4(ex, ey, __float_as_uint(cv), 0u);
+        } else {
+            reinterpret_cast<uint2 *>(entries)[at + i] = make_uint2(ex, ey);
+        }
+    }
+}
+
 // ---- BM25 / TF-IDF re-weighting of the stored values (Base/IR_feature_weighting.py:13-75) ---------------------------------
 // Per row and per column of the CSR: the sum of the stored values and their number; one wavefront per row, the column side
 // through atomics (20 M cells at ML-20M shape: a few hundred microseconds, once per build).  float64 throughout -- the
@@ -1279,6 +1386,9 @@ struct mi355rec_sim {
     DeviceBuffer<float> out_val;
     std::vector<long long> cost;   // host copy
     std::vector<int> csc_ptr_host;
+    DeviceBuffer<uint2> walk8;          // walk lists of the column kernel (all-ones data), see SimParams::walk8
+    DeviceBuffer<uint4> walk16;         //   ... with the column-side weight
+    std::vector<int> walk_ptr_host;     // [n_cols + 1] a column's entries in the walk arrays
     std::vector<int> cost_order;   // all columns, most expensive first
     int group_lanes = 64;
     double fixed_scale = 0.0;      // real-valued data: power-of-two scale of the int64 fixed-point accumulator (0: float64 sums)
@@ -1527,7 +1637,7 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     int part_slots = 0, n_split = 0;
     for (int c : h->cost_order) {
         if (!in_call(c)) continue;
-        const int n_c = h->csc_ptr_host[c + 1] - h->csc_ptr_host[c];
+        const int n_c = h->walk_ptr_host[c + 1] - h->walk_ptr_host[c];      // entries of the column's walk list
         long long parts = 1;
         if (h->n_tiles == 1 && h->cost[c] > limit)
             parts = std::max<long long>(1, std::min<long long>({(h->cost[c] + limit - 1) / limit, (long long)n_c / min_part_users, 64ll}));
@@ -1563,7 +1673,7 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     h->ranges_host.resize((size_t)n_items);
     for (int i = 0; i < n_items; ++i) {
         const int c = h->items_host[i].x;
-        h->ranges_host[i] = make_int2(h->csc_ptr_host[c], h->csc_ptr_host[c + 1]);
+        h->ranges_host[i] = make_int2(h->walk_ptr_host[c], h->walk_ptr_host[c + 1]);
     }
     MI_HIP(hipMemcpyAsync(h->items.ptr, h->items_host.data(), sizeof(int4) * n_items, hipMemcpyHostToDevice, h->stream));
     MI_HIP(hipMemcpyAsync(h->item_range.ptr, h->ranges_host.data(), sizeof(int2) * n_items, hipMemcpyHostToDevice, h->stream));
@@ -1600,6 +1710,8 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     p.csc_ptr = h->csc_ptr.ptr;
     p.csc_idx = h->csc_idx.ptr;
     p.csc_val = h->csc_val.ptr;
+    p.walk8 = h->walk8.ptr;
+    p.walk16 = h->walk16.ptr;
     p.row_w = h->row_w.ptr;
     p.norm = h->norm.ptr;
     p.norm_alpha = h->norm_alpha.ptr;
@@ -1811,6 +1923,111 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
                                h->csr_val.ptr, n_rows, row_mean.ptr);
         }
 
+        const bool stream_order = !(getenv("MI355REC_SIM_STREAM_ORDER") && atoi(getenv("MI355REC_SIM_STREAM_ORDER")) == 0);
+        const long long n_seg = (long long)n_rows * h->n_tiles;
+        // the profile stream: (row, tile) segments padded to whole 16-byte chunks, from the pre-processed values.  Its offsets
+        // (build_seg_ptr) depend on the row lengths alone; its contents (fill_stream) on the pre-processed values and on group_lanes
+        auto build_seg_ptr = [&]() {
+            DeviceBuffer<int> len_pad;
+            DeviceBuffer<char> scan_tmp;
+            len_pad.alloc((size_t)n_seg + 1);
+            h->seg_ptr.alloc((size_t)n_seg + 1);
+            hipLaunchKernelGGL(seg_len_kernel, dim3(div_up(n_seg + 1, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->row_tile_ptr.ptr,
+                               n_rows, h->n_tiles, len_pad.ptr);
+            size_t scan_bytes = 0;
+            MI_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, 0, (size_t)(n_seg + 1), rocprim::plus<int>(), s));
+            scan_tmp.alloc(scan_bytes);
+            MI_HIP(rocprim::exclusive_scan(scan_tmp.ptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, 0, (size_t)(n_seg + 1), rocprim::plus<int>(), s));
+        };
+        auto fill_stream = [&]() {
+            const size_t seg_cap = nnz + 7 * (size_t)n_seg + 520;     // every segment grows by at most 7 entries
+            MI_REQUIRE(seg_cap < (size_t)INT32_MAX, "matrix too large for 32-bit segment offsets");
+            h->seg_idx16.alloc_zero(seg_cap, s);
+            const bool int16_values = h->acc_mode() == ACC_INT32;      // (ids + int16 values: 4 B per entry instead of 6)
+            if (int16_values) h->seg_val16.alloc_zero(seg_cap, s);
+            else if (h->acc_mode() != ACC_COUNTS) h->seg_val.alloc_zero(seg_cap, s);     // (the counts kernel reads ids only)
+            hipLaunchKernelGGL(seg_fill_kernel, dim3(div_up(n_seg * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->row_tile_ptr.ptr,
+                               h->csr_idx.ptr, h->csr_val.ptr, h->seg_ptr.ptr, n_rows, h->n_tiles, h->tile_w, h->seg_idx16.ptr,
+                               h->seg_val.ptr, stream_order ? h->group_lanes : 0, h->seg_val16.ptr, (float)(1 << std::max(0, h->int_shift)));
+            MI_HIP(hipGetLastError());
+            MI_HIP(hipStreamSynchronize(s));      // the temporaries above go out of scope
+        };
+        // the walk lists (what the column kernel's accumulation walks instead of the CSC arrays): slices of the profile segments,
+        // every column's longest first.
+        auto build_walk = [&]() {
+            const int tiled = h->n_tiles > 1;
+            const bool wide = h->acc_mode() != ACC_COUNTS;
+            DeviceBuffer<int> n_slices, slice_off, rec_len, out_off, key_in, key_sorted, walk_ptr;
+            DeviceBuffer<unsigned> rec_key, rec_key_sorted;
+            DeviceBuffer<unsigned long long> rec, rec_sorted;
+            DeviceBuffer<char> tmp;
+            n_slices.alloc((size_t)n_rows + 1);
+            slice_off.alloc((size_t)n_rows + 1);
+            MI_HIP(hipMemsetAsync(n_slices.ptr + n_rows, 0, sizeof(int), s));
+            hipLaunchKernelGGL(walk_row_slices_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->seg_ptr.ptr, n_rows, tiled, n_slices.ptr);
+            size_t bytes = 0;
+            MI_HIP(rocprim::exclusive_scan(nullptr, bytes, n_slices.ptr, slice_off.ptr, 0, (size_t)n_rows + 1, rocprim::plus<int>(), s));
+            tmp.alloc(bytes + 16);
+            MI_HIP(rocprim::exclusive_scan(tmp.ptr, bytes, n_slices.ptr, slice_off.ptr, 0, (size_t)n_rows + 1, rocprim::plus<int>(), s));
+            int n_rec = 0;
+            MI_HIP(hipMemcpyAsync(&n_rec, slice_off.ptr + n_rows, sizeof(int), hipMemcpyDeviceToHost, s));
+            MI_HIP(hipStreamSynchronize(s));
+            MI_REQUIRE(n_rec > 0, "matrix has no stored values");
+            rec_key.alloc((size_t)n_rec); rec_key_sorted.alloc((size_t)n_rec);
+            rec.alloc((size_t)n_rec); rec_sorted.alloc((size_t)n_rec);
+            hipLaunchKernelGGL(walk_slice_records_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->seg_ptr.ptr, slice_off.ptr, n_rows,
+                               tiled, h->n_tiles, rec_key.ptr, rec.ptr);
+            bytes = 0;
+            MI_HIP(rocprim::radix_sort_pairs_desc(nullptr, bytes, rec_key.ptr, rec_key_sorted.ptr, rec.ptr, rec_sorted.ptr, (size_t)n_rec, 0, 8, s));
+            DeviceBuffer<char> tmp2;
+            tmp2.alloc(bytes + 16);
+            MI_HIP(rocprim::radix_sort_pairs_desc(tmp2.ptr, bytes, rec_key.ptr, rec_key_sorted.ptr, rec.ptr, rec_sorted.ptr, (size_t)n_rec, 0, 8, s));
+            rec_len.alloc((size_t)n_rec + 1);
+            out_off.alloc((size_t)n_rec + 1);
+            hipLaunchKernelGGL(walk_record_lengths_kernel, dim3(div_up(n_rec + 1, 256)), dim3(256), 0, s, rec_sorted.ptr, h->csr_ptr.ptr, n_rec, rec_len.ptr);
+            bytes = 0;
+            MI_HIP(rocprim::exclusive_scan(nullptr, bytes, rec_len.ptr, out_off.ptr, 0, (size_t)n_rec + 1, rocprim::plus<int>(), s));
+            DeviceBuffer<char> tmp3;
+            tmp3.alloc(bytes + 16);
+            MI_HIP(rocprim::exclusive_scan(tmp3.ptr, bytes, rec_len.ptr, out_off.ptr, 0, (size_t)n_rec + 1, rocprim::plus<int>(), s));
+            int n_walk = 0;
+            MI_HIP(hipMemcpyAsync(&n_walk, out_off.ptr + n_rec, sizeof(int), hipMemcpyDeviceToHost, s));
+            MI_HIP(hipStreamSynchronize(s));
+            MI_REQUIRE(n_walk > 0 && (size_t)n_walk >= nnz, "walk list: %d entries for %zu stored values", n_walk, nnz);
+            key_in.alloc((size_t)n_walk); key_sorted.alloc((size_t)n_walk);
+            walk_ptr.alloc((size_t)n_cols + 1);
+            int key_bits = 1;
+            while ((1ll << key_bits) < (long long)n_cols) ++key_bits;
+            DeviceBuffer<char> tmp4;
+            if (wide) {
+                DeviceBuffer<uint4> gen;
+                gen.alloc((size_t)n_walk);
+                h->walk16.alloc((size_t)n_walk);
+                hipLaunchKernelGGL(walk_generate_kernel<true>, dim3(n_rec), dim3(256), 0, s, rec_sorted.ptr, out_off.ptr, h->csr_ptr.ptr, h->csr_idx.ptr,
+                                   h->csr_val.ptr, h->seg_ptr.ptr, h->row_w.ptr, (int)cfg->unit_column_side, tiled, key_in.ptr, (void *)gen.ptr);
+                bytes = 0;
+                MI_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key_in.ptr, key_sorted.ptr, gen.ptr, h->walk16.ptr, (size_t)n_walk, 0, key_bits, s));
+                tmp4.alloc(bytes + 16);
+                MI_HIP(rocprim::radix_sort_pairs(tmp4.ptr, bytes, key_in.ptr, key_sorted.ptr, gen.ptr, h->walk16.ptr, (size_t)n_walk, 0, key_bits, s));
+                MI_HIP(hipStreamSynchronize(s));       // (gen goes out of scope)
+            } else {
+                DeviceBuffer<uint2> gen;
+                gen.alloc((size_t)n_walk);
+                h->walk8.alloc((size_t)n_walk);
+                hipLaunchKernelGGL(walk_generate_kernel<false>, dim3(n_rec), dim3(256), 0, s, rec_sorted.ptr, out_off.ptr, h->csr_ptr.ptr, h->csr_idx.ptr,
+                                   h->csr_val.ptr, h->seg_ptr.ptr, h->row_w.ptr, (int)cfg->unit_column_side, tiled, key_in.ptr, (void *)gen.ptr);
+                bytes = 0;
+                MI_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key_in.ptr, key_sorted.ptr, gen.ptr, h->walk8.ptr, (size_t)n_walk, 0, key_bits, s));
+                tmp4.alloc(bytes + 16);
+                MI_HIP(rocprim::radix_sort_pairs(tmp4.ptr, bytes, key_in.ptr, key_sorted.ptr, gen.ptr, h->walk8.ptr, (size_t)n_walk, 0, key_bits, s));
+                MI_HIP(hipStreamSynchronize(s));
+            }
+            hipLaunchKernelGGL(csc_ptr_kernel, dim3(div_up(n_cols + 1, 256)), dim3(256), 0, s, key_sorted.ptr, (size_t)n_walk, n_cols, walk_ptr.ptr);
+            MI_HIP(hipGetLastError());
+            h->walk_ptr_host.resize((size_t)n_cols + 1);
+            walk_ptr.download(h->walk_ptr_host.data(), (size_t)n_cols + 1, s);
+            MI_HIP(hipStreamSynchronize(s));
+        };
         // gather the pre-processed values into the column order
         DeviceBuffer<float> mean;
         DeviceBuffer<double> sumsq;
@@ -1926,33 +2143,11 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
             if (getenv("MI355REC_SIM_G")) h->group_lanes = atoi(getenv("MI355REC_SIM_G"));
             MI_REQUIRE(h->group_lanes == 8 || h->group_lanes == 16 || h->group_lanes == 32 || h->group_lanes == 64, "MI355REC_SIM_G must be 8, 16, 32 or 64");
         }
-        const bool stream_order = !(getenv("MI355REC_SIM_STREAM_ORDER") && atoi(getenv("MI355REC_SIM_STREAM_ORDER")) == 0);
-        // the profile stream: (row, tile) segments padded to whole 16-byte chunks, from the pre-processed values
-        {
-            const long long n_seg = (long long)n_rows * h->n_tiles;
-            DeviceBuffer<int> len_pad;
-            DeviceBuffer<char> scan_tmp;
-            len_pad.alloc((size_t)n_seg + 1);
-            h->seg_ptr.alloc((size_t)n_seg + 1);
-            hipLaunchKernelGGL(seg_len_kernel, dim3(div_up(n_seg + 1, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->row_tile_ptr.ptr,
-                               n_rows, h->n_tiles, len_pad.ptr);
-            size_t scan_bytes = 0;
-            MI_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, 0, (size_t)(n_seg + 1), rocprim::plus<int>(), s));
-            scan_tmp.alloc(scan_bytes);
-            MI_HIP(rocprim::exclusive_scan(scan_tmp.ptr, scan_bytes, len_pad.ptr, h->seg_ptr.ptr, 0, (size_t)(n_seg + 1), rocprim::plus<int>(), s));
-            const size_t seg_cap = nnz + 7 * (size_t)n_seg + 520;     // every segment grows by at most 7 entries
-            MI_REQUIRE(seg_cap < (size_t)INT32_MAX, "matrix too large for 32-bit segment offsets");
-            h->seg_idx16.alloc_zero(seg_cap, s);
-            const bool int16_values = h->acc_mode() == ACC_INT32;      // (ids + int16 values: 4 B per entry instead of 6)
-            if (int16_values) h->seg_val16.alloc_zero(seg_cap, s);
-            else if (h->acc_mode() != ACC_COUNTS) h->seg_val.alloc_zero(seg_cap, s);     // (the counts kernel reads ids only)
-            hipLaunchKernelGGL(seg_fill_kernel, dim3(div_up(n_seg * 64, 256)), dim3(256), 0, s, h->csr_ptr.ptr, h->row_tile_ptr.ptr,
-                               h->csr_idx.ptr, h->csr_val.ptr, h->seg_ptr.ptr, n_rows, h->n_tiles, h->tile_w, h->seg_idx16.ptr,
-                               h->seg_val.ptr, stream_order ? h->group_lanes : 0, h->seg_val16.ptr, (float)(1 << std::max(0, h->int_shift)));
-            MI_HIP(hipGetLastError());
-            MI_HIP(hipStreamSynchronize(s));      // the temporaries above go out of scope
-        }
+        build_seg_ptr();
+        fill_stream();
         phase("profile stream");
+        build_walk();
+        phase("walk lists");
 
         // Real-valued data: can the column sums be kept as int64 fixed point (ds_add_u64 is 1.8x faster than ds_add_f64)?
         // Every product is at most P = max weight * max |column-side value| * max |value|; a cell sums at most N = longest
@@ -1993,6 +2188,9 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
             }
         }
 
+        // the column view has served (norms, costs, value range): the accumulation walks the lists above
+        h->csc_idx.release();
+        h->csc_val.release();
         h->queue.alloc(1);
         phase("fixed-point check + cost order (host)");
         *out = h.release();

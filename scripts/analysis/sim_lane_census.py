@@ -32,16 +32,35 @@ def census(urm, G, order="row", deal="runs", waves=16, dynamic=False, sample=Non
         k = chunks_of[users]
         if order == "len":
             k = np.sort(k)[::-1]
+        elif order == "steps":                      # descending number of steps ceil(k / G): what a counting sort on the device gives
+            k = k[np.argsort(-(-(-k // G)), kind="stable")]
         elif order == "lenclass":                   # 2 classes per octave, stable inside a class
             cls = np.floor(2 * np.log2(np.maximum(k, 1))).astype(np.int64)
             k = k[np.argsort(-cls, kind="stable")]
+        if deal == "dyn":                           # wavefronts take the next 64 users of the column from a shared counter when they finish a round
+            load = np.zeros(waves, np.int64)
+            for r in range(0, n, 64):
+                kr = k[r:r + 64]
+                sr = -(-kr // G)
+                pad = (-len(sr)) % GPW
+                t = np.concatenate([sr, np.zeros(pad, np.int64)]).reshape(-1, GPW).sum(0).max()
+                load[np.argmin(load)] += int(t)
+                tot_chunks += int(kr.sum())
+            tot_steps += int(load.sum())
+            wave_steps_sum += int(load.sum())
+            wave_steps_max += waves * int(load.max())
+            continue
         if deal == "runs":
             per = -(-n // waves)
             lists = [k[w * per:(w + 1) * per] for w in range(waves)]
-        else:                                       # round-robin in units of `deal` users
-            unit = int(deal)
+        else:                                       # round-robin in units of `deal` users ("s" suffix: serpentine, every other stripe reversed)
+            serp = str(deal).endswith("s")
+            unit = int(str(deal).rstrip("s"))
             idx = np.arange(n)
             owner = (idx // unit) % waves
+            if serp:
+                stripe = idx // (unit * waves)
+                owner = np.where(stripe % 2 == 1, waves - 1 - owner, owner)
             lists = [k[owner == w] for w in range(waves)]
         col_wave = []
         for kw in lists:
@@ -74,9 +93,9 @@ if __name__ == "__main__":
     # cost-weighted sample of columns (the census of all 26 744 takes minutes in Python)
     sample = rng.choice(urm.shape[1], size=1500, replace=False, p=cost / cost.sum())
     print("%s: weighted mean profile %.0f entries" % (name, cost.sum() / urm.nnz))
-    for G in (64, 32, 16, 8):
-        for order, deal, dyn in (("row", "runs", False), ("row", "runs", True), ("len", "1", False), ("len", str(64 // G), False),
-                                 ("lenclass", str(64 // G), False), ("len", "64", False)):
+    for G in (32, 16, 8, 4):
+        for order, deal, dyn in (("row", "runs", False), ("len", str(64 // G), False), ("steps", str(64 // G), False), ("steps", str(64 // G) + "s", False),
+                                 ("steps", "dyn", False), ("row", "dyn", False)):
             lanes, wave_bal, steps = census(urm, G, order, deal, dynamic=dyn, sample=sample)
             print("G=%2d order=%-8s deal=%-4s dynamic=%d : %.1f lanes per ds_add, wave balance %.3f, steps x waves %.3e (rel. cost %.3f)" % (
                 G, order, deal, dyn, lanes, wave_bal, steps, steps / wave_bal))
