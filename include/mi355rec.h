@@ -139,7 +139,8 @@ int mi355rec_sim_create(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, int
  * row_weights stays a host array): the handle copies the three arrays at HBM speed instead of uploading 8 B per stored value over
  * PCIe -- 2.9 of the 6.7 ms the constructor takes at ML-20M shape.  The reference's hyper-parameter search fits hundreds of models
  * on one URM_train (ParameterTuning/SearchAbstractClass.py:253-262, one `fit` per configuration): the matrix is uploaded once
- * (`ResidentURM` in the Python front-end) and every ItemKNN / P3alpha / RP3beta fit starts from the resident copy.  The caller keeps
+ * (`ResidentURM` in the Python front-end) and every ItemKNN fit starts from the resident copy (P3alpha / RP3beta build from a
+ * row-normalised, re-weighted matrix of their own and upload that).  The caller keeps
  * ownership of the arrays; they are not modified and may be freed as soon as the call returns. */
 int mi355rec_sim_create_resident(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, int32_t n_rows, int32_t n_cols,
                                  const int32_t *d_csr_indptr, const int32_t *d_csr_indices, const float *d_csr_data,

@@ -61,11 +61,26 @@ int multiprocessor_count();
 // ---- device memory ---------------------------------------------------------------------------------
 // Blocks go back to a small per-process cache instead of hipFree (which drains the device and costs 0.2 - 0.5 ms per block: a dozen
 // temporaries made up a third of the similarity constructor): device_block() hands out a cached block of at least -- and at most
-// twice -- the size asked for, or calls hipMalloc.  Like hipFree, returning a block waits for the device first (the block may be
-// handed to another stream next).  Blocks above 1 GiB are not cached; the cache holds at most MI355REC_POOL_BYTES (default 8 GiB of
+// twice -- the size asked for, or calls hipMalloc.  Like hipFree, returning a block waits first (the block may be handed to another
+// stream next): for the streams of the calling thread's ReleaseScope, or -- outside any scope -- for the whole device.  Blocks above 1 GiB are not cached; the cache holds at most MI355REC_POOL_BYTES (default 8 GiB of
 // the 288, 0 switches it off); mi355rec_device_trim empties it.
 void *device_block(size_t bytes);
 void device_block_return(void *p, size_t bytes);
+
+// The device-wide wait of a returned block stands in for "every stream that touched the block is drained".  A handle knows those
+// streams: while a ReleaseScope is alive on the calling thread, returned blocks wait for the scope's streams ONLY -- so closing one
+// handle (or the temporaries of its constructor) no longer waits for another handle's persistent kernel, nor for handles that run
+// in other threads.  Outside any scope the device-wide wait stays.  Scopes nest (the innermost one counts).
+struct ReleaseScope {
+    hipStream_t streams[3];
+    ReleaseScope *outer;
+    explicit ReleaseScope(hipStream_t a, hipStream_t b = nullptr, hipStream_t c = nullptr);
+    ~ReleaseScope();
+    // a handle's destructor has drained `s` and is about to destroy it (or hand it back to the pool): no scope of this thread waits for it again
+    static void forget(hipStream_t s);
+    ReleaseScope(const ReleaseScope &) = delete;
+    ReleaseScope &operator=(const ReleaseScope &) = delete;
+};
 
 template <class T>
 struct DeviceBuffer {

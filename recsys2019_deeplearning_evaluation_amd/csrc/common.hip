@@ -101,6 +101,17 @@ void *device_block(size_t bytes) {
     return p;
 }
 
+namespace {
+thread_local ReleaseScope *t_release_scope = nullptr;
+}
+ReleaseScope::ReleaseScope(hipStream_t a, hipStream_t b, hipStream_t c) : streams{a, b, c}, outer(t_release_scope) { t_release_scope = this; }
+ReleaseScope::~ReleaseScope() { t_release_scope = outer; }
+void ReleaseScope::forget(hipStream_t s) {
+    for (ReleaseScope *sc = t_release_scope; sc; sc = sc->outer)
+        for (hipStream_t &st : sc->streams)
+            if (st == s) st = nullptr;
+}
+
 void device_block_return(void *p, size_t) {
     if (!p) return;
     BlockCache &c = block_cache();
@@ -117,7 +128,12 @@ void device_block_return(void *p, size_t) {
         (void)hipFree(p);
         return;
     }
-    (void)hipDeviceSynchronize();                    // what hipFree would have waited for
+    if (const ReleaseScope *scope = t_release_scope) {   // the owner's streams: nothing else can hold work on the block
+        for (hipStream_t st : scope->streams)
+            if (st) (void)hipStreamSynchronize(st);
+    } else {
+        (void)hipDeviceSynchronize();                // what hipFree would have waited for
+    }
     std::vector<void *> drop;
     {
         std::lock_guard<std::mutex> g(c.lock);

@@ -53,11 +53,13 @@ __device__ __forceinline__ unsigned long long ials_stamp() {
     return t;
 }
 
-// G += Y[rows]^T Y[rows]; 256 threads as a 16 x 16 grid, thread owns G[ty + 16a][tx + 16b].
+// G += Y[rows]^T Y[rows]; 256 threads as a 16 x 16 grid, thread owns G[ty + 16 (a0 + a)][tx + 16 (b0 + b)], a, b < KT16: the
+// whole matrix in one launch (a0 = b0 = 0, KT16 = tiles per side; up to 14 x 14 cells = 392 registers per thread), or -- 15 and 16
+// tiles per side, k > 224 -- one launch per 8 x 8 quadrant.
 template <int KT16>
-__global__ __launch_bounds__(256) void gram_kernel(const double *Y, int n, int k, double *G) {
+__global__ __launch_bounds__(256) void gram_kernel(const double *Y, int n, int k, double *G, int a0, int b0) {
     __shared__ double ys[8][256];
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int tid = threadIdx.x, ty = tid >> 4 | a0 << 4, tx = (tid & 15) | b0 << 4;
     double acc[KT16][KT16];
 #pragma unroll
     for (int a = 0; a < KT16; ++a)
@@ -77,8 +79,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *Y, int n, int k
             double ya[KT16], yb[KT16];
 #pragma unroll
             for (int a = 0; a < KT16; ++a) {
-                ya[a] = ys[r][ty + 16 * a];
-                yb[a] = ys[r][tx + 16 * a];
+                ya[a] = ys[r][(ty + 16 * a) & 255];        // (tiles past the 16th do not exist: masked at the end)
+                yb[a] = ys[r][(tx + 16 * a) & 255];
             }
 #pragma unroll
             for (int a = 0; a < KT16; ++a)
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *Y, int n, int k
 #pragma unroll
         for (int b = 0; b < KT16; ++b) {
             const int r = ty + 16 * a, c = tx + 16 * b;
-            if (r < k && c < k) atomicAdd(&G[(size_t)r * k + c], acc[a][b]);
+            if (r < k && c < k && r < 256 && c < 256) atomicAdd(&G[(size_t)r * k + c], acc[a][b]);
         }
 }
 
@@ -710,6 +712,7 @@ struct mi355rec_ials {
     DeviceBuffer<int> sys_slot;
     std::vector<int> sys_slot_host;
     int n_batches = 0;
+    double system_gib = 0.0;             // size of the two-stage epochs' systems buffer (0: not decided yet, see rows_per_batch)
     std::vector<int4> items_host;
     int n_split_rows = 0, n_part_items = 0;
     DeviceBuffer<float> u_conf, i_conf;
@@ -727,6 +730,7 @@ struct mi355rec_ials {
         if (stream) (void)hipStreamSynchronize(stream);
         call_timer.destroy();
         dispatch_timers.destroy();
+        ReleaseScope::forget(stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -735,7 +739,7 @@ namespace {
 
 template <int KT16>
 void launch_gram_t(mi355rec_ials *h, const double *Y, int n, int grid) {
-    hipLaunchKernelGGL(gram_kernel<KT16>, dim3(grid), dim3(256), 0, h->stream, Y, n, h->k, h->G.ptr);
+    hipLaunchKernelGGL(gram_kernel<KT16>, dim3(grid), dim3(256), 0, h->stream, Y, n, h->k, h->G.ptr, 0, 0);
 }
 
 void launch_gram(mi355rec_ials *h, const double *Y, int n) {
@@ -755,7 +759,12 @@ void launch_gram(mi355rec_ials *h, const double *Y, int n) {
         case 11: launch_gram_t<11>(h, Y, n, grid); break;
         case 12: launch_gram_t<12>(h, Y, n, grid); break;
         case 13: launch_gram_t<13>(h, Y, n, grid); break;
-        default: launch_gram_t<14>(h, Y, n, grid); break;
+        case 14: launch_gram_t<14>(h, Y, n, grid); break;
+        default:        // 15 or 16 tiles per side: four quadrants of 8 x 8 tiles
+            for (int a0 = 0; a0 < 16; a0 += 8)
+                for (int b0 = 0; b0 < 16; b0 += 8)
+                    hipLaunchKernelGGL(gram_kernel<8>, dim3(grid), dim3(256), 0, h->stream, Y, n, h->k, h->G.ptr, a0, b0);
+            break;
     }
 }
 
@@ -821,7 +830,7 @@ int row_slots(int NT) {
     const int need = (NT + ROW_WAVES - 1) / ROW_WAVES;
     if (need <= 2) return need;
     if (need <= 12) return (need + 1) / 2 * 2;
-    return need == 13 ? 13 : 15;
+    return need == 13 ? 13 : (need <= 15 ? 15 : 17);
 }
 
 void launch_rows(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0, hipEvent_t e1, int stage = 0) {
@@ -835,7 +844,8 @@ void launch_rows(mi355rec_ials *h, const IalsParams &p, int grid, hipEvent_t e0,
         case 9: case 10: launch_rows_t<10>(h, p, grid, e0, e1, stage); break;
         case 11: case 12: launch_rows_t<12>(h, p, grid, e0, e1, stage); break;
         case 13: launch_rows_t<13>(h, p, grid, e0, e1, stage); break;
-        default: launch_rows_t<15>(h, p, grid, e0, e1, stage); break;
+        case 14: case 15: launch_rows_t<15>(h, p, grid, e0, e1, stage); break;
+        default: launch_rows_t<17>(h, p, grid, e0, e1, stage); break;      // 16 x 16 tiles: k <= 255
     }
 }
 
@@ -852,13 +862,40 @@ bool two_stage_epochs(const mi355rec_ials *h) {
     return (ts ? atoi(ts) != 0 : true) && solve_slots(KT * (KT + 1) / 2) <= MAX_SOLVE_SLOTS;
 }
 
-// Rows whose systems the buffer holds at a time: MI355REC_IALS_SYSTEM_GIB (default 8) worth of slabs, at most the longer side.
-int rows_per_batch(const mi355rec_ials *h) {
+// Rows whose systems the buffer holds at a time: MI355REC_IALS_SYSTEM_GIB worth of slabs (default: 8, but never more than a quarter
+// of the memory the device has free when the handle first asks -- several handles on one device, or a device shared with PyTorch /
+// RCCL, each take a share instead of 8 GiB), at most the longer side.  A buffer that cannot be had is halved (ensure_systems).
+int rows_per_batch(mi355rec_ials *h) {
     const size_t sys_bytes = slab_doubles(h, true) * sizeof(double);
-    double gib = 8.0;
-    if (getenv("MI355REC_IALS_SYSTEM_GIB")) gib = std::max(0.001, atof(getenv("MI355REC_IALS_SYSTEM_GIB")));
+    if (h->system_gib <= 0.0) {
+        double gib = 8.0;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) gib = std::min(gib, (double)free_b / 4.0 / 1073741824.0);
+        else (void)hipGetLastError();
+        if (getenv("MI355REC_IALS_SYSTEM_GIB")) gib = atof(getenv("MI355REC_IALS_SYSTEM_GIB"));
+        h->system_gib = std::max(0.001, gib);
+    }
     const size_t longest = (size_t)std::max(h->n_users, h->n_items);
-    return (int)std::max<size_t>(1, std::min<size_t>(longest, (size_t)(gib * 1073741824.0) / sys_bytes));
+    return (int)std::max<size_t>(1, std::min<size_t>(longest, (size_t)(h->system_gib * 1073741824.0) / sys_bytes));
+}
+
+// The systems buffer for half-steps of up to `rows` rows: min(rows, rows_per_batch) slabs.  Blocks above 1 GiB bypass the block cache,
+// so this is a real hipMalloc -- done once per handle (and again only if a larger half-step arrives).  If the device cannot give it,
+// the batch is halved (more, smaller batches: same results) down to 64 slabs; below that the caller falls back to the one-kernel epoch.
+bool ensure_systems(mi355rec_ials *h, int rows) {
+    const size_t slab = slab_doubles(h, true);
+    for (;;) {
+        const int per_batch = std::min(std::max(1, rows), rows_per_batch(h));
+        if (h->systems.count >= (size_t)per_batch * slab) return true;
+        try {
+            h->systems.alloc((size_t)per_batch * slab);
+            return true;
+        } catch (const Error &) {
+            (void)hipGetLastError();
+            if (per_batch <= 64) return false;
+            h->system_gib = std::max(0.001, 0.5 * (double)per_batch * (double)slab * sizeof(double) / 1073741824.0);
+        }
+    }
 }
 
 // Solve the rows [r0, r1) of one side.
@@ -942,7 +979,7 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
     // buffer (MI355REC_IALS_SYSTEM_GIB, default 8: 43 000 rows at k = 200); per batch one launch builds the systems (work items =
     // the batch's rows and parts, still most expensive first) and one solves them, two workgroups per CU.  Same arithmetic as the
     // one-kernel epoch (tests/test_ials_gpu.py::test_two_stage_epochs_equal_one_kernel_epochs: 1e-12).
-    const bool two_stage = two_stage_epochs(h);
+    const bool two_stage = two_stage_epochs(h) && ensure_systems(h, n_local);      // (no memory for 64 systems: the one-kernel epoch)
     h->n_batches = 0;
     if (!two_stage) {
         const int grid = std::min(n_work, grid_cap);
@@ -954,10 +991,9 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
     } else {
         const int KT_ = (h->k + 1 + 15) / 16, NT_ = KT_ * (KT_ + 1) / 2;
         const size_t sys_doubles = slab_doubles(h, true);
-        const int per_batch = std::min(std::max(1, n_local), rows_per_batch(h));
+        const int per_batch = (int)std::min<size_t>((size_t)std::min(std::max(1, n_local), rows_per_batch(h)), h->systems.count / sys_doubles);
         const int n_batches = (n_local + per_batch - 1) / per_batch;
         h->n_batches = n_batches;
-        if (h->systems.count < (size_t)per_batch * sys_doubles) h->systems.alloc((size_t)per_batch * sys_doubles);
         // position of every row in the cost order -> (batch, slab)
         std::vector<int> pos_of_row((size_t)n_side, -1);
         for (int i = 0; i < n_local; ++i) pos_of_row[h->staging[i]] = i;
@@ -1024,13 +1060,11 @@ void half_step(mi355rec_ials *h, bool users, int r0, int r1) {
     h->launches_acc += 1;
 }
 
-void begin_call(mi355rec_ials *h) {
+// `rows`: the longest half-step the call will run
+void begin_call(mi355rec_ials *h, int rows) {
     // (the buffer of the two-stage epochs is allocated here, before the call's clock starts: 8 GiB of hipMalloc took 0.4 s of the
     // first epoch's "call_ms" when half_step did it)
-    if (two_stage_epochs(h)) {
-        const size_t need = (size_t)rows_per_batch(h) * slab_doubles(h, true);
-        if (h->systems.count < need) h->systems.alloc(need);
-    }
+    if (two_stage_epochs(h)) (void)ensure_systems(h, rows);
     h->dispatch_timers.reset();
     h->flops_acc = h->bytes_acc = 0;
     h->rows_acc = h->launches_acc = 0;
@@ -1060,8 +1094,8 @@ extern "C" int mi355rec_ials_create(mi355rec_ials_t *out, int32_t n_users, int32
         MI_REQUIRE(out && indptr && indices && confidence && V0, "NULL argument");
         MI_REQUIRE(n_users > 0 && n_items > 0, "empty URM");
         MI_REQUIRE(n_factors >= 1, "num_factors must be >= 1");
-        if (n_factors > 224)   // 15 x 15 tiles of 16 (the rhs row included): 8 tiles per wavefront; the search space stops at 200
-            fail(MI355REC_E_UNSUPPORTED, "num_factors = %d: the register-resident solver covers num_factors <= 224", n_factors);
+        if (n_factors > 255)   // 16 x 16 tiles of 16 (the rhs row included): 17 tiles per wavefront; the search space stops at 200
+            fail(MI355REC_E_UNSUPPORTED, "num_factors = %d: the register-resident solver covers num_factors <= 255", n_factors);
         ensure_device();
         std::unique_ptr<mi355rec_ials> h(new mi355rec_ials());
         h->n_users = n_users;
@@ -1118,8 +1152,9 @@ extern "C" int mi355rec_ials_run_epochs(mi355rec_ials_t h, int32_t n_epochs) {
         MI_REQUIRE(h, "NULL handle");
         MI_REQUIRE(n_epochs >= 0, "n_epochs must be >= 0");
         ensure_device();
+        ReleaseScope scope(h->stream);
         h->dispatch_timers.reserve(2 * std::max(1, n_epochs));
-        begin_call(h);
+        begin_call(h, std::max(h->n_users, h->n_items));
         for (int e = 0; e < n_epochs; ++e) {
             half_step(h, true, 0, h->n_users);      // fit user factors against V     (IALSRecommender.py:141-152)
             half_step(h, false, 0, h->n_items);     // then item factors against the UPDATED U (:156-166)
@@ -1132,8 +1167,9 @@ extern "C" int mi355rec_ials_user_half(mi355rec_ials_t h, int32_t u0, int32_t u1
     return guarded([&] {
         MI_REQUIRE(h, "NULL handle");
         ensure_device();
+        ReleaseScope scope(h->stream);
         h->dispatch_timers.reserve(2);
-        begin_call(h);
+        begin_call(h, std::max(0, u1 - u0));
         half_step(h, true, u0, u1);
         end_call(h, false);
     });
@@ -1143,8 +1179,9 @@ extern "C" int mi355rec_ials_item_half(mi355rec_ials_t h, int32_t i0, int32_t i1
     return guarded([&] {
         MI_REQUIRE(h, "NULL handle");
         ensure_device();
+        ReleaseScope scope(h->stream);
         h->dispatch_timers.reserve(2);
-        begin_call(h);
+        begin_call(h, std::max(0, i1 - i0));
         half_step(h, false, i0, i1);
         end_call(h, false);
     });
@@ -1198,4 +1235,8 @@ extern "C" int mi355rec_ials_get_stats(mi355rec_ials_t h, mi355rec_stats *stats)
     });
 }
 
-extern "C" void mi355rec_ials_destroy(mi355rec_ials_t h) { delete h; }
+extern "C" void mi355rec_ials_destroy(mi355rec_ials_t h) {
+    if (!h) return;
+    ReleaseScope scope(h->stream);
+    delete h;
+}

@@ -106,6 +106,7 @@ struct mi355rec_mf {
         drop_graphs();
         timer.destroy();
         dispatch_timers.destroy();
+        ReleaseScope::forget(stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -726,6 +727,7 @@ extern "C" int mi355rec_mf_run_epochs(mi355rec_mf_t h, int32_t n_epochs) {
         MI_REQUIRE(h, "NULL handle");
         MI_REQUIRE(n_epochs >= 0, "n_epochs must be >= 0");
         ensure_device();
+        ReleaseScope scope(h->stream);
         if (h->f64) run_epochs_typed<double>(h, n_epochs); else run_epochs_typed<float>(h, n_epochs);
     });
 }
@@ -903,6 +905,7 @@ struct mi355rec_mf_group {
         dispatch_timers.destroy();
         if (fork) (void)hipEventDestroy(fork);
         for (auto e : join) (void)hipEventDestroy(e);
+        ReleaseScope::forget(stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -1151,7 +1154,11 @@ extern "C" int mi355rec_mf_group_get_stats(mi355rec_mf_group_t g, mi355rec_stats
     });
 }
 
-extern "C" void mi355rec_mf_group_destroy(mi355rec_mf_group_t g) { delete g; }
+extern "C" void mi355rec_mf_group_destroy(mi355rec_mf_group_t g) {
+    if (!g) return;
+    ReleaseScope scope(g->stream);
+    delete g;
+}
 
 extern "C" int mi355rec_mf_get_factors(mi355rec_mf_t h, float *U, float *V, float *bu, float *bi, float *mu) {
     return guarded([&] {
@@ -1214,4 +1221,8 @@ extern "C" int mi355rec_mf_get_stats(mi355rec_mf_t h, mi355rec_stats *stats) {
     });
 }
 
-extern "C" void mi355rec_mf_destroy(mi355rec_mf_t h) { delete h; }
+extern "C" void mi355rec_mf_destroy(mi355rec_mf_t h) {
+    if (!h) return;
+    ReleaseScope scope(h->stream);       // (a group's launches on the group's stream have been waited for by the call that made them)
+    delete h;
+}

@@ -274,6 +274,7 @@ struct mi355rec_scorer {
         if (stream) (void)hipStreamSynchronize(stream);
         gemm_timer.destroy();
         call_timer.destroy();
+        ReleaseScope::forget(stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -387,7 +388,11 @@ extern "C" int mi355rec_scorer_get_stats(mi355rec_scorer_t h, mi355rec_stats *st
     });
 }
 
-extern "C" void mi355rec_scorer_destroy(mi355rec_scorer_t h) { delete h; }
+extern "C" void mi355rec_scorer_destroy(mi355rec_scorer_t h) {
+    if (!h) return;
+    ReleaseScope scope(h->stream);
+    delete h;
+}
 
 // ------------------------------------------------------------------------------------------------------
 // Similarity-model scoring: scores[u] = A[u, :] . B with A and B sparse (CSR).
@@ -480,6 +485,7 @@ struct mi355rec_spscorer {
     ~mi355rec_spscorer() {
         if (stream) (void)hipStreamSynchronize(stream);
         timer.destroy();
+        ReleaseScope::forget(stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -565,4 +571,8 @@ extern "C" int mi355rec_spscorer_get_stats(mi355rec_spscorer_t h, mi355rec_stats
     });
 }
 
-extern "C" void mi355rec_spscorer_destroy(mi355rec_spscorer_t h) { delete h; }
+extern "C" void mi355rec_spscorer_destroy(mi355rec_spscorer_t h) {
+    if (!h) return;
+    ReleaseScope scope(h->stream);
+    delete h;
+}

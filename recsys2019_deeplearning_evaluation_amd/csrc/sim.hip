@@ -59,11 +59,14 @@ struct SimParams {
     float *cand_val;
     const int *csc_ptr, *csc_idx;
     const float *csc_val;
-    // Walk lists (built by the constructor, build_walk_lists): per column, what the accumulation walks -- one entry per SLICE of a user's
-    // profile segment (at most WALK_SLICE chunks of 8 entries), longest slices first.  walk8: {first entry, end entry} of the slice in
-    // the profile stream (all-ones data: no weight); walk16: {first, end, bits of the column-side value times the row weight, 0}.
-    // With accumulator tiles (n_tiles > 1) an entry is a whole user: .x = the row, whose per-tile segment bounds come from seg_ptr.
-    const uint2 *walk8;
+    // Walk lists (built by the constructor, build_walk): per column, what the accumulation walks -- one entry per SLICE of a user's
+    // profile segment (at most WALK_SLICE chunks of 8 entries), longest slices first.  All-ones data: walk4 = the slice's number, whose
+    // {first entry, end entry} in the profile stream are walk_tab[number] (a 4-byte entry: this list IS the column view of all-ones data,
+    // sorted once); valued data: walk16 = {first, end, bits of the column-side value times the row weight, 0}.
+    // With accumulator tiles (n_tiles > 1) an entry is a whole user: the row (walk4 / walk16.x), whose per-tile segment bounds come
+    // from seg_ptr.
+    const int *walk4;
+    const uint2 *walk_tab;
     const uint4 *walk16;
     const float *row_w;
     const float *norm, *norm_alpha, *norm_1ma;
@@ -154,23 +157,59 @@ constexpr long long FIXED_MAGIC_BITS = 0x4338000000000000ll;
 //               counts, and one accumulator tile where 8-byte cells need two (26 744 columns at ML-20M shape);
 //   ACC_WIDE    any other real-valued data (or row weights): int64 fixed-point or float64 sums in 8-byte cells.
 enum { ACC_COUNTS = 0, ACC_INT32 = 1, ACC_WIDE = 2 };
+struct alignas(16) SimShared {
+    int4 item;
+    int2 range;
+    int col, last;
+    uint32_t npos, nneg, ncand, kmin, kmax;
+    SelectScratch sc;
+};
+// LDS byte address of the cell whose id is half `HI` of the packed id pair `w` (the accumulator starts at LDS address 0)
+template <int HI, int SHIFT>
+__device__ __forceinline__ unsigned lds_cell_address(unsigned w) {
+    unsigned a;
+    if (HI) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a) : "v"((unsigned)SHIFT), "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a) : "v"((unsigned)SHIFT), "v"(w));
+    return a;
+}
+typedef __attribute__((address_space(3))) unsigned lds_u32_t;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
+typedef __attribute__((address_space(3))) double lds_f64_t;
+__device__ __forceinline__ void lds_add_u32(unsigned byte_address, unsigned v) {
+    __hip_atomic_fetch_add((lds_u32_t *)(size_t)byte_address, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add_u64(unsigned byte_address, unsigned long long v) {
+    __hip_atomic_fetch_add((lds_u64_t *)(size_t)byte_address, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add_f64(unsigned byte_address, double v) {
+    __hip_atomic_fetch_add((lds_f64_t *)(size_t)byte_address, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int THREADS, int G, int MODE>
 __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) {
     constexpr bool UNIT = MODE == ACC_COUNTS;        // no values
     constexpr bool CELL32 = MODE != ACC_WIDE;        // 4-byte integer cells
+    // LDS: [accumulator | selection scratch | the workgroup's few shared scalars].  The kernel has NO static LDS, so the accumulator
+    // starts at LDS address 0 and a cell's address is its id times the cell size -- one SDWA shift per entry instead of extract + shift
+    // + base (lds_cell_address; checked once below).
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *acc = smem;
     uint32_t *aux = reinterpret_cast<uint32_t *>(smem + p.acc_words);
-    __shared__ SelectScratch sc;
-    __shared__ int s_col, s_last;
-    __shared__ int4 s_item;
-    __shared__ int2 s_range;
-    __shared__ uint32_t s_npos, s_nneg, s_ncand, s_kmin, s_kmax;
+    SimShared &shared = *reinterpret_cast<SimShared *>(aux + AUX_WORDS);
+    SelectScratch &sc = shared.sc;
+    int &s_col = shared.col, &s_last = shared.last;
+    int4 &s_item = shared.item;
+    int2 &s_range = shared.range;
+    uint32_t &s_npos = shared.npos, &s_nneg = shared.nneg, &s_ncand = shared.ncand, &s_kmin = shared.kmin, &s_kmax = shared.kmax;
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) float *)smem != 0u) __builtin_trap();
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int gl = tid % G;
 
     unsigned long long t_prev = p.phase_ticks ? wall_clock64() : 0ull;
+    // (diagnostics: [8] earliest start, [9] latest end, [10] sum of the workgroups' own spans, [11] longest single work item, [12] its column)
+    const unsigned long long t_start = t_prev;
+    if (p.phase_ticks && tid == 0) atomicMin(&p.phase_ticks[8], t_start);
     auto mark = [&](int phase) {
         if (p.phase_ticks && tid == 0) {
             const unsigned long long now = wall_clock64();
@@ -193,11 +232,21 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         nx_slot = -1;
     };
     if (tid == 0) pull_now();
+    // (Measured and rejected, round 6: requesting the next column's first walk entries while the current column's survivors are ranked.
+    // Every __syncthreads waits for ALL outstanding loads of the wavefront, so the requests were simply waited for at the next barrier
+    // of the selection -- its phase grew by what the loop head saved, 3.85 ms against 3.81.)
     for (;;) {
         __syncthreads();
         const int slot = s_col;
         if (slot >= p.n_items) break;
         const int4 item = s_item;
+        const unsigned long long t_item = p.phase_ticks ? wall_clock64() : 0ull;
+        auto item_done = [&]() {
+            if (p.phase_ticks && tid == 0) {
+                const unsigned long long span = wall_clock64() - t_item;
+                if (span > atomicMax(&p.phase_ticks[11], span)) p.phase_ticks[12] = (unsigned long long)item.x;
+            }
+        };
         const int c = item.x;
         const int cbeg = s_range.x, cend = s_range.y;    // the column's walk list
         int4 nx_item = make_int4(0, 0, 0, 0);
@@ -246,20 +295,19 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         constexpr int WAVES = THREADS / 64, GPW = 64 / G;
         const int wave = tid >> 6, sub = lane / G;
         const int NV = WAVES * item.z, vw = item.y * WAVES + wave;
-        auto entry_of = [&](int q) {                   // position in the column's walk list of this wavefront's q-th entry
-            const int stripe = q / GPW, pos = (stripe & 1) ? NV - 1 - vw : vw;
-            return cbeg + (stripe * NV + pos) * GPW + (q % GPW);
+        auto entry_in = [&](int first, int nv, int v, int q) {       // position in a column's walk list of the q-th entry of its virtual wavefront v of nv
+            const int stripe = q / GPW, pos = (stripe & 1) ? nv - 1 - v : v;
+            return first + (stripe * nv + pos) * GPW + (q % GPW);
         };
+        auto entry_of = [&](int q) { return entry_in(cbeg, NV, vw, q); };
         // Walk entries (and, with accumulator tiles, the CSR bounds behind them) are the only dependent loads of the stream.  They
         // run two rounds (of 64 entries per wavefront) ahead: entries of round r+2 and bounds of round r+1 are requested while round r
         // streams, and the first round's entries are requested before the accumulator is cleared.
-        auto load_user = [&](int q, int &ex, int &ey, float &cv) {
-            const int at = entry_of(q);
-            if (at < cend) {
+        auto load_entry = [&](int at, int end, int &ex, int &ey, float &cv) {
+            if (at < end) {
                 if (UNIT) {
-                    const uint2 e = p.walk8[at];
-                    ex = (int)e.x;
-                    ey = (int)e.y;
+                    ex = p.walk4[at];
+                    ey = 0;
                     cv = 1.f;
                 } else {
                     const uint4 e = p.walk16[at];
@@ -272,9 +320,15 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                 ey = -1;                               // (marks a lane without an entry)
             }
         };
+        auto load_user = [&](int q, int &ex, int &ey, float &cv) { load_entry(entry_of(q), cend, ex, ey, cv); };
         auto load_bounds = [&](int ex, int ey, float cv, int &rs, int &re, float &r) {
             r = cv;
             if (p.n_tiles == 1) {
+                if (UNIT && ey >= 0) {                 // the slice's bounds: one more (L2-resident) look-up, a round ahead like the tiles' bounds
+                    const uint2 e = p.walk_tab[ex];
+                    ex = (int)e.x;
+                    ey = (int)e.y;
+                }
                 rs = ex;
                 re = ey;
             } else if (ey >= 0) {                      // accumulator tiles: .x is the row
@@ -323,9 +377,10 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         constexpr int DEPTH = UNIT ? SIM_DEPTH_UNIT : (MODE == ACC_INT32 ? 3 : 2);
         unsigned *acc_u = reinterpret_cast<unsigned *>(acc);
         double *acc_d = reinterpret_cast<double *>(acc);
-        unsigned long long *acc_q = reinterpret_cast<unsigned long long *>(acc);
         const bool fixed_point = MODE == ACC_WIDE && p.fixed_scale > 0.0;
-        const uint4 *idx8 = reinterpret_cast<const uint4 *>(p.seg_idx16);
+        // (the id stream through a buffer descriptor: a 32-bit byte offset per load instead of 64-bit address arithmetic; the stream holds
+        // fewer than 2^31 entries of 2 bytes -- checked by the constructor -- so the descriptor's 32-bit size covers it)
+        const __amdgpu_buffer_rsrc_t idx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.seg_idx16), 0, (int)0xFFFFFFF0u, 0x00020000);
         const float4 *val4 = reinterpret_cast<const float4 *>(p.seg_val);
         const uint4 *val8 = reinterpret_cast<const uint4 *>(p.seg_val16);
         int4 *tab = reinterpret_cast<int4 *>(aux) + wave * 64;       // [64] x {rs, re, weight, -}: one 16-byte read per entry
@@ -366,7 +421,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                 c_t[d] = at;
                 c_re[d] = f_have ? f_re : 0;
                 c_r[d] = f_r;
-                ids[d] = idx8[at >> 3];
+                ids[d] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(idx_rsrc, at * 2, 0, 0));
                 if (MODE == ACC_INT32) {
                     vlo[d] = __builtin_bit_cast(float4, val8[at >> 3]);       // eight int16 values
                 } else if (!UNIT) {
@@ -396,24 +451,23 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                         const unsigned vw[4] = {vq.x, vq.y, vq.z, vq.w};
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const unsigned j = (e & 1) ? (ww[e >> 1] >> 16) : (ww[e >> 1] & 0xFFFFu);
+                            const unsigned at = (e & 1) ? lds_cell_address<1, 2>(ww[e >> 1]) : lds_cell_address<0, 2>(ww[e >> 1]);
                             const int v = (e & 1) ? (int)vw[e >> 1] >> 16 : (int)(short)(vw[e >> 1] & 0xFFFFu);
-                            atomicAdd(&acc_u[j], (unsigned)__mul24(ri, v));
+                            lds_add_u32(at, (unsigned)__mul24(ri, v));
                         }
                     } else if (MODE == ACC_WIDE && fixed_point) {
                         const double rs = rd * p.fixed_scale;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const unsigned j = (e & 1) ? (ww[e >> 1] >> 16) : (ww[e >> 1] & 0xFFFFu);
+                            const unsigned at = (e & 1) ? lds_cell_address<1, 3>(ww[e >> 1]) : lds_cell_address<0, 3>(ww[e >> 1]);
                             const double q = __builtin_fma(rs, (double)vv[e], FIXED_MAGIC);
-                            atomicAdd(&acc_q[j], (unsigned long long)(__double_as_longlong(q) - FIXED_MAGIC_BITS));
+                            lds_add_u64(at, (unsigned long long)(__double_as_longlong(q) - FIXED_MAGIC_BITS));
                         }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const unsigned j = (e & 1) ? (ww[e >> 1] >> 16) : (ww[e >> 1] & 0xFFFFu);
-                            if (UNIT) atomicAdd(&acc_u[j], 1u);
-                            else atomicAdd(&acc_d[j], rd * (double)vv[e]);
+                            if (UNIT) lds_add_u32((e & 1) ? lds_cell_address<1, 2>(ww[e >> 1]) : lds_cell_address<0, 2>(ww[e >> 1]), 1u);
+                            else lds_add_f64((e & 1) ? lds_cell_address<1, 3>(ww[e >> 1]) : lds_cell_address<0, 3>(ww[e >> 1]), rd * (double)vv[e]);
                         }
                     }
                 }
@@ -814,6 +868,12 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
                                      (long long)p.n_cols - total_nonzero);
             __syncthreads();
         }
+        item_done();
+    }
+    if (p.phase_ticks && tid == 0) {
+        const unsigned long long t_end = wall_clock64();
+        atomicMax(&p.phase_ticks[9], t_end);
+        atomicAdd(&p.phase_ticks[10], t_end - t_start);
     }
 }
 
@@ -1031,7 +1091,11 @@ __global__ void split_cells_kernel(const unsigned long long *cell, size_t nnz, i
 // the column-ordered arrays (one wavefront per column spent 1.2 ms on the longest column of the ML-20M shape alone).  `col_of` is the
 // sorted key array of the CSR -> CSC sort.  Runs of one column are summed in registers, one atomic per run and wavefront; the few
 // cells of a stretch of 64 that spans several columns add themselves.
+// COUNTED (the walk list of all-ones data as the column view: `csc_idx` = slice numbers, `csr_ptr` = scan of the rows' lengths filed
+// under their FIRST slice): bits 40.. of the sum count the entries with a non-zero length = the column's users.
 constexpr int COST_CHUNK = 4096;
+constexpr int COST_COUNT_SHIFT = 40;
+template <bool COUNTED>
 __global__ __launch_bounds__(256) void column_cost_kernel(const int *col_of, const int *csc_idx, const int *csr_ptr, size_t nnz,
                                                           unsigned long long *cost) {
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
@@ -1050,7 +1114,8 @@ __global__ __launch_bounds__(256) void column_cost_kernel(const int *col_of, con
         const bool live = q < last;
         const int col = live ? col_of[q] : -1;
         const int u = live ? csc_idx[q] : 0;
-        const unsigned long long len = live ? (unsigned long long)(csr_ptr[u + 1] - csr_ptr[u]) : 0ull;
+        unsigned long long len = live ? (unsigned long long)(csr_ptr[u + 1] - csr_ptr[u]) : 0ull;
+        if (COUNTED && len) len |= 1ull << COST_COUNT_SHIFT;
         const int col0 = __builtin_amdgcn_readfirstlane(col);
         if (__all(!live || col == col0)) {
             if (col0 != cur) {
@@ -1205,17 +1270,40 @@ __global__ void walk_slice_records_kernel(const int *csr_ptr, const int *seg_ptr
     }
 }
 
-__global__ void walk_record_lengths_kernel(const unsigned long long *rec, const int *csr_ptr, int n_rec, int *len) {
+// per record (sorted order): the cells it emits (= the row's length), the row's length filed under its first slice only (what a
+// column's cost and user count are summed from), and the slice's bounds in the profile stream
+__global__ void walk_record_lengths_kernel(const unsigned long long *rec, const int *csr_ptr, const int *seg_ptr, int n_rec, int tiled,
+                                           int *len, int *first_len, uint2 *tab) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n_rec) {
-        const int u = (int)(unsigned)rec[r];
-        len[r] = csr_ptr[u + 1] - csr_ptr[u];
+        const unsigned long long rc = rec[r];
+        const int u = (int)(unsigned)rc, j = (int)(rc >> 32);
+        const int n = csr_ptr[u + 1] - csr_ptr[u];
+        len[r] = n;
+        first_len[r] = j == 0 ? n : 0;
+        if (!tiled) {
+            const int s0 = seg_ptr[u], s1 = seg_ptr[u + 1];
+            tab[r] = make_uint2((unsigned)(s0 + j * WALK_SLICE * 8), (unsigned)min(s1, s0 + (j + 1) * WALK_SLICE * 8));
+        }
     }
-    if (r == n_rec) len[r] = 0;
+    if (r == n_rec) {
+        len[r] = 0;
+        first_len[r] = 0;
+    }
+}
+
+// the packed sums of column_cost_kernel<true>: cost, users (as the column's sum of squares and as an int)
+__global__ void walk_unpack_cost_kernel(const unsigned long long *packed, int n_cols, long long *cost, double *sumsq, int *count) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cols) return;
+    const unsigned long long v = packed[c];
+    cost[c] = (long long)(v & ((1ull << COST_COUNT_SHIFT) - 1ull));
+    sumsq[c] = (double)(v >> COST_COUNT_SHIFT);
+    count[c] = (int)(v >> COST_COUNT_SHIFT);
 }
 
 // One workgroup per slice record (in sorted order): its (column, entry) pairs, one per stored cell of the row.  WIDE: 16-byte entries
-// with the column-side value of the cell (times the row's weight), else 8-byte entries.
+// with the column-side value of the cell (times the row's weight), else 4-byte entries: the record's number (tiled: the row).
 template <bool WIDE>
 __global__ __launch_bounds__(256) void walk_generate_kernel(const unsigned long long *rec, const int *out_off, const int *csr_ptr, const int *csr_idx,
                                                             const float *csr_val, const int *seg_ptr, const float *row_w, int unit_col, int tiled,
@@ -1224,11 +1312,8 @@ __global__ __launch_bounds__(256) void walk_generate_kernel(const unsigned long 
     const unsigned long long rc = rec[r];
     const int u = (int)(unsigned)rc, j = (int)(rc >> 32);
     const int a = csr_ptr[u], len = csr_ptr[u + 1] - a, at = out_off[r];
-    unsigned ex, ey;
-    if (tiled) {
-        ex = (unsigned)u;
-        ey = 0u;
-    } else {
+    unsigned ex = (unsigned)u, ey = 0u;
+    if (!tiled && WIDE) {
         const int s0 = seg_ptr[u], s1 = seg_ptr[u + 1];
         ex = (unsigned)(s0 + j * WALK_SLICE * 8);
         ey = (unsigned)min(s1, s0 + (j + 1) * WALK_SLICE * 8);
@@ -1241,7 +1326,7 @@ __global__ __launch_bounds__(256) void walk_generate_kernel(const unsigned long 
             if (row_w) cv *= w;
             reinterpret_cast<uint4 *>(entries)[at + i] = make_uint4(ex, ey, __float_as_uint(cv), 0u);
         } else {
-            reinterpret_cast<uint2 *>(entries)[at + i] = make_uint2(ex, ey);
+            reinterpret_cast<int *>(entries)[at + i] = tiled ? u : r;
         }
     }
 }
@@ -1386,8 +1471,9 @@ struct mi355rec_sim {
     DeviceBuffer<float> out_val;
     std::vector<long long> cost;   // host copy
     std::vector<int> csc_ptr_host;
-    DeviceBuffer<uint2> walk8;          // walk lists of the column kernel (all-ones data), see SimParams::walk8
-    DeviceBuffer<uint4> walk16;         //   ... with the column-side weight
+    DeviceBuffer<int> walk4;            // walk lists of the column kernel (all-ones data), see SimParams::walk4
+    DeviceBuffer<uint2> walk_tab;       //   ... and the bounds of the slices they name
+    DeviceBuffer<uint4> walk16;         // walk lists with the column-side weight (valued data)
     std::vector<int> walk_ptr_host;     // [n_cols + 1] a column's entries in the walk arrays
     std::vector<int> cost_order;   // all columns, most expensive first
     int group_lanes = 64;
@@ -1404,6 +1490,7 @@ struct mi355rec_sim {
         if (stream) (void)hipStreamSynchronize(stream);
         timer.destroy();
         call_timer.destroy();
+        ReleaseScope::forget(stream);
         if (stream) pooled_stream_return(stream);
     }
 };
@@ -1607,7 +1694,7 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     auto in_call = [&](int c) { return n_parts > 0 ? slot_host[c] >= 0 : (c >= start && c < end); };
     const bool unit_kernel = h->acc_mode() != ACC_WIDE;          // 4-byte cells
     const int acc_words = (h->tile_w + 4) * (unit_kernel ? 1 : 2);
-    const size_t lds = (size_t)acc_words * 4 + (size_t)AUX_WORDS * 4;
+    const size_t lds = (size_t)acc_words * 4 + (size_t)AUX_WORDS * 4 + sizeof(SimShared);
     const int cus = multiprocessor_count();
     int threads = 1024, max_grid = cus;   // one 16-wave workgroup per CU when the accumulator owns the LDS
     if (lds <= 72 * 1024) {
@@ -1710,7 +1797,8 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     p.csc_ptr = h->csc_ptr.ptr;
     p.csc_idx = h->csc_idx.ptr;
     p.csc_val = h->csc_val.ptr;
-    p.walk8 = h->walk8.ptr;
+    p.walk4 = h->walk4.ptr;
+    p.walk_tab = h->walk_tab.ptr;
     p.walk16 = h->walk16.ptr;
     p.row_w = h->row_w.ptr;
     p.norm = h->norm.ptr;
@@ -1722,8 +1810,9 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     p.part_buf = h->part_buf.ptr;
     p.part_count = h->part_count.ptr;
     if (getenv("MI355REC_SIM_PHASES")) {
-        if (!h->phase_ticks.ptr) h->phase_ticks.alloc(8);
-        MI_HIP(hipMemsetAsync(h->phase_ticks.ptr, 0, 8 * sizeof(unsigned long long), h->stream));
+        if (!h->phase_ticks.ptr) h->phase_ticks.alloc(16);
+        MI_HIP(hipMemsetAsync(h->phase_ticks.ptr, 0, 16 * sizeof(unsigned long long), h->stream));
+        MI_HIP(hipMemsetAsync(h->phase_ticks.ptr + 8, 0xFF, sizeof(unsigned long long), h->stream));      // [8]: a minimum
         p.phase_ticks = h->phase_ticks.ptr;
     }
     if (!h->selection_counts.ptr) h->selection_counts.alloc(4);
@@ -1822,6 +1911,7 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         h->nnz = (size_t)nnz_in;
         MI_REQUIRE(nnz_in > 0, "matrix has no stored values");
         h->stream = pooled_stream();
+        ReleaseScope scope(h->stream);          // the constructor's temporaries wait for this stream, not for the device
         h->timer.init_pooled();
         h->call_timer.init_pooled();
         hipStream_t s = h->stream;
@@ -1953,11 +2043,15 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
             MI_HIP(hipStreamSynchronize(s));      // the temporaries above go out of scope
         };
         // the walk lists (what the column kernel's accumulation walks instead of the CSC arrays): slices of the profile segments,
-        // every column's longest first.
+        // every column's longest first.  All-ones data: 4-byte entries (slice numbers) -- the sorted list is the column view itself,
+        // `walk_keys` (its sorted column keys) and `walk_len_ptr` (scan of the rows' lengths by first slice) are what the columns'
+        // costs and user counts are then summed from, and no CSC is ever built (walk_only).
+        DeviceBuffer<int> walk_keys, walk_len_ptr;
+        int n_walk_entries = 0;
         auto build_walk = [&]() {
             const int tiled = h->n_tiles > 1;
             const bool wide = h->acc_mode() != ACC_COUNTS;
-            DeviceBuffer<int> n_slices, slice_off, rec_len, out_off, key_in, key_sorted, walk_ptr;
+            DeviceBuffer<int> n_slices, slice_off, rec_len, first_len, out_off, key_in, key_sorted, walk_ptr;
             DeviceBuffer<unsigned> rec_key, rec_key_sorted;
             DeviceBuffer<unsigned long long> rec, rec_sorted;
             DeviceBuffer<char> tmp;
@@ -1983,13 +2077,21 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
             tmp2.alloc(bytes + 16);
             MI_HIP(rocprim::radix_sort_pairs_desc(tmp2.ptr, bytes, rec_key.ptr, rec_key_sorted.ptr, rec.ptr, rec_sorted.ptr, (size_t)n_rec, 0, 8, s));
             rec_len.alloc((size_t)n_rec + 1);
+            first_len.alloc((size_t)n_rec + 1);
             out_off.alloc((size_t)n_rec + 1);
-            hipLaunchKernelGGL(walk_record_lengths_kernel, dim3(div_up(n_rec + 1, 256)), dim3(256), 0, s, rec_sorted.ptr, h->csr_ptr.ptr, n_rec, rec_len.ptr);
+            if (!wide && !tiled) h->walk_tab.alloc((size_t)n_rec);
+            hipLaunchKernelGGL(walk_record_lengths_kernel, dim3(div_up(n_rec + 1, 256)), dim3(256), 0, s, rec_sorted.ptr, h->csr_ptr.ptr, h->seg_ptr.ptr,
+                               n_rec, (int)(wide || tiled), rec_len.ptr, first_len.ptr, h->walk_tab.ptr);
             bytes = 0;
             MI_HIP(rocprim::exclusive_scan(nullptr, bytes, rec_len.ptr, out_off.ptr, 0, (size_t)n_rec + 1, rocprim::plus<int>(), s));
             DeviceBuffer<char> tmp3;
             tmp3.alloc(bytes + 16);
             MI_HIP(rocprim::exclusive_scan(tmp3.ptr, bytes, rec_len.ptr, out_off.ptr, 0, (size_t)n_rec + 1, rocprim::plus<int>(), s));
+            if (!wide && !tiled) {         // (tiled: the entries are rows, whose lengths the CSR pointers give)
+                walk_len_ptr.alloc((size_t)n_rec + 1);
+                bytes = tmp3.count;
+                MI_HIP(rocprim::exclusive_scan(tmp3.ptr, bytes, first_len.ptr, walk_len_ptr.ptr, 0, (size_t)n_rec + 1, rocprim::plus<int>(), s));
+            }
             int n_walk = 0;
             MI_HIP(hipMemcpyAsync(&n_walk, out_off.ptr + n_rec, sizeof(int), hipMemcpyDeviceToHost, s));
             MI_HIP(hipStreamSynchronize(s));
@@ -2011,15 +2113,15 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
                 MI_HIP(rocprim::radix_sort_pairs(tmp4.ptr, bytes, key_in.ptr, key_sorted.ptr, gen.ptr, h->walk16.ptr, (size_t)n_walk, 0, key_bits, s));
                 MI_HIP(hipStreamSynchronize(s));       // (gen goes out of scope)
             } else {
-                DeviceBuffer<uint2> gen;
+                DeviceBuffer<int> gen;
                 gen.alloc((size_t)n_walk);
-                h->walk8.alloc((size_t)n_walk);
+                h->walk4.alloc((size_t)n_walk);
                 hipLaunchKernelGGL(walk_generate_kernel<false>, dim3(n_rec), dim3(256), 0, s, rec_sorted.ptr, out_off.ptr, h->csr_ptr.ptr, h->csr_idx.ptr,
                                    h->csr_val.ptr, h->seg_ptr.ptr, h->row_w.ptr, (int)cfg->unit_column_side, tiled, key_in.ptr, (void *)gen.ptr);
                 bytes = 0;
-                MI_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key_in.ptr, key_sorted.ptr, gen.ptr, h->walk8.ptr, (size_t)n_walk, 0, key_bits, s));
+                MI_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key_in.ptr, key_sorted.ptr, gen.ptr, h->walk4.ptr, (size_t)n_walk, 0, key_bits, s));
                 tmp4.alloc(bytes + 16);
-                MI_HIP(rocprim::radix_sort_pairs(tmp4.ptr, bytes, key_in.ptr, key_sorted.ptr, gen.ptr, h->walk8.ptr, (size_t)n_walk, 0, key_bits, s));
+                MI_HIP(rocprim::radix_sort_pairs(tmp4.ptr, bytes, key_in.ptr, key_sorted.ptr, gen.ptr, h->walk4.ptr, (size_t)n_walk, 0, key_bits, s));
                 MI_HIP(hipStreamSynchronize(s));
             }
             hipLaunchKernelGGL(csc_ptr_kernel, dim3(div_up(n_cols + 1, 256)), dim3(256), 0, s, key_sorted.ptr, (size_t)n_walk, n_cols, walk_ptr.ptr);
@@ -2027,13 +2129,19 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
             h->walk_ptr_host.resize((size_t)n_cols + 1);
             walk_ptr.download(h->walk_ptr_host.data(), (size_t)n_cols + 1, s);
             MI_HIP(hipStreamSynchronize(s));
+            n_walk_entries = n_walk;
+            walk_keys.swap(key_sorted);
         };
         // gather the pre-processed values into the column order
         DeviceBuffer<float> mean;
         DeviceBuffer<double> sumsq;
         DeviceBuffer<long long> cost;
-        h->csc_idx.alloc(nnz);
-        h->csc_val.alloc(nnz);
+        // all-ones data: the walk list is the column view (one sort of 4-byte entries instead of the CSC's sort + the list's)
+        const bool walk_only = h->acc_mode() == ACC_COUNTS && n_rows < (1 << 23) && !getenv("MI355REC_SIM_WALK_WITH_CSC");
+        if (!walk_only) {
+            h->csc_idx.alloc(nnz);
+            h->csc_val.alloc(nnz);
+        }
         if (h->n_tiles > 1) {
             h->row_tile_ptr.alloc((size_t)n_rows * (h->n_tiles + 1));
             hipLaunchKernelGGL(row_tile_ptr_kernel, dim3(div_up((int64_t)n_rows * (h->n_tiles + 1), 256)), dim3(256), 0, s,
@@ -2046,7 +2154,10 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         DeviceBuffer<int> key_out, row_of;
         DeviceBuffer<unsigned long long> cell_in, cell_out;
         DeviceBuffer<char> sort_tmp;
-        {
+        if (walk_only) {
+            build_seg_ptr();
+            build_walk();
+        } else {
             h->csc_ptr.alloc((size_t)n_cols + 1);
             key_out.alloc(nnz);
             int key_bits = 1;
@@ -2077,7 +2188,7 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
             MI_HIP(hipGetLastError());
         }
 
-        phase("CSR -> CSC (allocations, radix sort of the cells)");
+        phase(walk_only ? "walk lists = the column view (slices, radix sort of the entries)" : "CSR -> CSC (allocations, radix sort of the cells)");
         const int cg = div_up((int64_t)n_cols * 64, 256);
         if (cfg->similarity == MI355REC_SIM_PEARSON) {
             mean.alloc((size_t)n_cols);
@@ -2089,10 +2200,23 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         sumsq.alloc((size_t)n_cols);
         cost.alloc((size_t)n_cols);
         MI_HIP(hipMemsetAsync(cost.ptr, 0, sizeof(long long) * (size_t)n_cols, s));
-        hipLaunchKernelGGL(column_cost_kernel, dim3(div_up((int64_t)div_up((int64_t)nnz, COST_CHUNK) * 64, 256)), dim3(256), 0, s, key_out.ptr,
+        DeviceBuffer<int> user_count;
+        DeviceBuffer<unsigned long long> packed;
+        if (walk_only) {
+            // cost and users of every column from the sorted entries: the rows' lengths filed under their first slices (tiled: rows)
+            const size_t n_walk = (size_t)n_walk_entries;
+            packed.alloc_zero((size_t)n_cols, s);
+            user_count.alloc((size_t)n_cols);
+            hipLaunchKernelGGL(column_cost_kernel<true>, dim3(div_up((int64_t)div_up((int64_t)n_walk, COST_CHUNK) * 64, 256)), dim3(256), 0, s, walk_keys.ptr,
+                               h->walk4.ptr, h->n_tiles > 1 ? h->csr_ptr.ptr : walk_len_ptr.ptr, n_walk, packed.ptr);
+            hipLaunchKernelGGL(walk_unpack_cost_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, s, packed.ptr, n_cols, cost.ptr, sumsq.ptr, user_count.ptr);
+        } else
+        hipLaunchKernelGGL(column_cost_kernel<false>, dim3(div_up((int64_t)div_up((int64_t)nnz, COST_CHUNK) * 64, 256)), dim3(256), 0, s, key_out.ptr,
                            h->csc_idx.ptr, h->csr_ptr.ptr, nnz, reinterpret_cast<unsigned long long *>(cost.ptr));
         MI_REQUIRE(cfg->norm_sum_order == 0 || cfg->norm_sum_order == 1, "norm_sum_order must be 0 (CSR order) or 1 (CSC order)");
-        if (h->unit_values && n_rows < (1 << 24))
+        if (walk_only) {
+            // (sumsq = the users counted above)
+        } else if (h->unit_values && n_rows < (1 << 24))
             hipLaunchKernelGGL(column_count_sumsq_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, s, h->csc_ptr.ptr, n_cols, sumsq.ptr);
         else if (cfg->norm_sum_order == 0)
             hipLaunchKernelGGL(column_sumsq_f32_rowwise_kernel, dim3(div_up((int64_t)n_cols * 64, 256)), dim3(256), 0, s, h->csc_ptr.ptr,
@@ -2127,8 +2251,16 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         h->cost.resize(n_cols);
         cost.download(h->cost.data(), n_cols, s);
         h->csc_ptr_host.resize((size_t)n_cols + 1);
-        h->csc_ptr.download(h->csc_ptr_host.data(), (size_t)n_cols + 1, s);
-        MI_HIP(hipStreamSynchronize(s));
+        if (walk_only) {
+            user_count.download(h->csc_ptr_host.data() + 1, (size_t)n_cols, s);
+            MI_HIP(hipStreamSynchronize(s));
+            h->csc_ptr_host[0] = 0;
+            for (int c = 0; c < n_cols; ++c) h->csc_ptr_host[c + 1] += h->csc_ptr_host[c];
+            MI_REQUIRE((size_t)h->csc_ptr_host[n_cols] == nnz, "walk lists: %d users counted for %zu stored values", h->csc_ptr_host[n_cols], nnz);
+        } else {
+            h->csc_ptr.download(h->csc_ptr_host.data(), (size_t)n_cols + 1, s);
+            MI_HIP(hipStreamSynchronize(s));
+        }
         phase("column costs + norms + downloads");
 
         // lanes per user profile: sized to the profile length seen from an item (cost-weighted mean)
@@ -2137,17 +2269,23 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
             for (long long c : h->cost) total_cost += c;
             const double weighted_len = (double)total_cost / (double)nnz;
             // each lane covers 8 profile entries per load: G lanes span 8*G entries
-            h->group_lanes = weighted_len >= 1024 ? 64 : (weighted_len >= 320 ? 32 : 16);
-            // the float64 kernel has half the loads in flight per lane (DEPTH 2): narrower groups keep more profiles going
-            if (h->acc_mode() != ACC_COUNTS) h->group_lanes = weighted_len >= 2048 ? 64 : (weighted_len >= 640 ? 32 : 16);
+            // (with the walk lists a lane group never sees more than WALK_SLICE chunks at once and the groups of a round get slices of
+            // the same length: 8 lanes per slice are fastest at every shape measured -- ML-20M shape 3.76 ms against 3.77 / 3.91 / 4.48 with
+            // 16 / 32 / 64, Netflix shape 15.7 against 16.2 / 17.8 with 16 / 32, star ratings 5.16 against 5.31 / 5.88 / 7.39)
+            (void)weighted_len;
+            h->group_lanes = 8;
+            // the float64 kernel has half the loads in flight per lane (DEPTH 2)
+            if (h->acc_mode() == ACC_WIDE) h->group_lanes = 16;
             if (getenv("MI355REC_SIM_G")) h->group_lanes = atoi(getenv("MI355REC_SIM_G"));
             MI_REQUIRE(h->group_lanes == 8 || h->group_lanes == 16 || h->group_lanes == 32 || h->group_lanes == 64, "MI355REC_SIM_G must be 8, 16, 32 or 64");
         }
-        build_seg_ptr();
+        if (!walk_only) build_seg_ptr();
         fill_stream();
         phase("profile stream");
-        build_walk();
-        phase("walk lists");
+        if (!walk_only) {
+            build_walk();
+            phase("walk lists");
+        }
 
         // Real-valued data: can the column sums be kept as int64 fixed point (ds_add_u64 is 1.8x faster than ds_add_f64)?
         // Every product is at most P = max weight * max |column-side value| * max |value|; a cell sums at most N = longest
@@ -2216,6 +2354,7 @@ extern "C" int mi355rec_sim_compute_device(mi355rec_sim_t h, int32_t start_col, 
         MI_REQUIRE(h->cfg.topK > 0, "topK == 0: use mi355rec_sim_compute_dense");
         ensure_device();
         clamp_range(h, start_col, end_col);
+        ReleaseScope scope(h->stream);
         run_columns(h, start_col, end_col, d_nbr_idx, d_nbr_val, nullptr);
     });
 }
@@ -2277,6 +2416,7 @@ extern "C" int mi355rec_sim_compute(mi355rec_sim_t h, int32_t start_col, int32_t
         MI_REQUIRE(h->cfg.topK > 0, "topK == 0: use mi355rec_sim_compute_dense");
         ensure_device();
         clamp_range(h, start_col, end_col);
+        ReleaseScope scope(h->stream);
         const size_t n = (size_t)(end_col - start_col) * h->cfg.topK;
         if (h->out_idx.count < n) {
             h->out_idx.alloc(n);
@@ -2288,10 +2428,13 @@ extern "C" int mi355rec_sim_compute(mi355rec_sim_t h, int32_t start_col, int32_t
         MI_HIP(hipStreamSynchronize(h->stream));
         read_timers(h);
         if (h->phase_ticks.ptr && getenv("MI355REC_SIM_PHASES")) {
-            unsigned long long t[12];
-            h->phase_ticks.download(t, 8, h->stream);
+            unsigned long long t[12], w[16];
+            h->phase_ticks.download(w, 16, h->stream);
             h->selection_counts.download(t + 8, 4, h->stream);
             MI_HIP(hipStreamSynchronize(h->stream));
+            memcpy(t, w, 8 * sizeof(unsigned long long));
+            fprintf(stderr, "[mi355rec sim spans] first start to last end %.3f ms; workgroups' own spans %.2f workgroup-ms; longest work item %.3f ms (column %llu)\n",
+                    (double)(w[9] - w[8]) * 1e-5, (double)w[10] * 1e-5, (double)w[11] * 1e-5, w[12]);
             fprintf(stderr, "[mi355rec sim phases, workgroup-ms] fetch+clear %.2f  accumulate %.2f  split-merge %.2f  normalise %.2f  topk %.2f  (kernel %.3f ms)"
                             "  threshold-first: maxima scan %.2f  (K-th maximum under `normalise`)  survivor scan %.2f  (exact values + rank + emit under `topk`)"
                             "  columns %llu (candidates %.1f per column), full-selection fall-backs after the scan %llu (%llu: buffer full); wait for the scan's slowest wavefront %.2f (instrumented runs only)\n",
@@ -2308,6 +2451,7 @@ extern "C" int mi355rec_sim_compute_csr(mi355rec_sim_t h, int32_t start_col, int
         MI_REQUIRE(h->cfg.topK > 0, "topK == 0: use mi355rec_sim_compute_dense");
         ensure_device();
         clamp_range(h, start_col, end_col);
+        ReleaseScope scope(h->stream);
         const size_t n = (size_t)(end_col - start_col) * h->cfg.topK;
         MI_REQUIRE(n < (size_t)INT32_MAX, "result too large for 32-bit CSR offsets");
         if (h->out_idx.count < n) {
@@ -2353,6 +2497,7 @@ extern "C" int mi355rec_sim_compute_dense(mi355rec_sim_t h, int32_t start_col, i
         MI_REQUIRE(h && W, "NULL argument");
         ensure_device();
         clamp_range(h, start_col, end_col);
+        ReleaseScope scope(h->stream);
         const int n_local = end_col - start_col;
         MI_REQUIRE(ld >= n_local, "ld (%lld) < number of columns (%d)", (long long)ld, n_local);
         mi355rec_sim_config saved = h->cfg;
@@ -2483,4 +2628,8 @@ extern "C" int mi355rec_sim_get_stats(mi355rec_sim_t h, mi355rec_stats *stats) {
     });
 }
 
-extern "C" void mi355rec_sim_destroy(mi355rec_sim_t h) { delete h; }
+extern "C" void mi355rec_sim_destroy(mi355rec_sim_t h) {
+    if (!h) return;
+    ReleaseScope scope(h->stream);
+    delete h;
+}

@@ -43,6 +43,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
+#include <chrono>
 #include <memory>
 #include <type_traits>
 
@@ -1497,6 +1499,8 @@ struct mi355rec_slim {
         if (side) (void)hipStreamSynchronize(side);
         call_timer.destroy();
         dispatch_timers.destroy();
+        ReleaseScope::forget(side);
+        ReleaseScope::forget(stream);
         if (side) (void)hipStreamDestroy(side);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -1621,19 +1625,26 @@ void sort_pairs(mi355rec_slim *h, unsigned long long *keys_out, int *vals_out, s
 struct OwnerGate {
     std::mutex lock;
     int fd = -1, holders = 0;
-    bool acquire() {
-        std::lock_guard<std::mutex> g(lock);
-        if (holders > 0) { ++holders; return true; }
-        if (getenv("MI355REC_SLIM_NO_OWNER_GATE")) { ++holders; return true; }
+    // The device's lock file: per user and per PCI bus id, in MI355REC_LOCK_DIR, else XDG_RUNTIME_DIR (a directory only the user can
+    // write), else /tmp; never through a symbolic link (the name is predictable).  -1: no lock file.
+    static int open_lock_file() {
         int dev = 0;
         char bus[64] = "unknown";
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev);
         for (char *c = bus; *c; ++c)
             if (*c == ':' || *c == '.' || *c == '/') *c = '_';
-        const char *dir = getenv("MI355REC_LOCK_DIR") ? getenv("MI355REC_LOCK_DIR") : "/tmp";
+        const char *dir = getenv("MI355REC_LOCK_DIR");
+        if (!dir || !*dir) dir = getenv("XDG_RUNTIME_DIR");
+        if (!dir || !*dir) dir = "/tmp";
         char path[512];
         snprintf(path, sizeof(path), "%s/mi355rec_slim_owners_%u_%s.lock", dir, (unsigned)getuid(), bus);
-        const int f = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        return open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
+    }
+    bool acquire() {
+        std::lock_guard<std::mutex> g(lock);
+        if (holders > 0) { ++holders; return true; }
+        if (getenv("MI355REC_SLIM_NO_OWNER_GATE")) { ++holders; return true; }
+        const int f = open_lock_file();
         if (f < 0) return false;                       // no lock file, no owners: the queue-only mode is always correct
         if (flock(f, LOCK_EX | LOCK_NB) != 0) {
             close(f);
@@ -1647,22 +1658,40 @@ struct OwnerGate {
     // for steps that only its short-profile workgroups run, so TWO such kernels on one device (two handles in threads, two processes)
     // may leave each other's short workgroups non-resident and spin into the 5 s budget.  Symmetric launches of a device
     // therefore run one at a time: `serial` inside the process, the file lock across processes (held from launch to finish).
+    // The file lock is polled (LOCK_NB) OUTSIDE the gate's mutex against a deadline (MI355REC_SLIM_GATE_WAIT_S, default 600 s): a
+    // process that hangs with the lock held makes this launch fail with a message, not block for ever -- and never blocks the
+    // acquire / release of the dense store's launches of this process.
     std::mutex serial;
     bool acquire_blocking() {
         serial.lock();
+        {
+            std::lock_guard<std::mutex> g(lock);
+            if (holders > 0 || getenv("MI355REC_SLIM_NO_OWNER_GATE")) { ++holders; return true; }
+        }
+        const int f = open_lock_file();
+        bool locked = false;
+        if (f >= 0) {
+            const double wait_s = getenv("MI355REC_SLIM_GATE_WAIT_S") ? atof(getenv("MI355REC_SLIM_GATE_WAIT_S")) : 600.0;
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(wait_s);
+            for (;;) {
+                if (flock(f, LOCK_EX | LOCK_NB) == 0) { locked = true; break; }
+                if (errno != EWOULDBLOCK && errno != EINTR) break;          // (no usable lock file: in-process serialisation only)
+                if (std::chrono::steady_clock::now() >= deadline) {
+                    close(f);
+                    serial.unlock();
+                    fail(MI355REC_E_HIP, "SLIM-BPR (symmetric store): another process has held this device's launch lock for more than %.0f s", wait_s);
+                }
+                usleep(2000);
+            }
+            if (!locked) close(f);
+        }
         std::lock_guard<std::mutex> g(lock);
-        if (holders > 0 || getenv("MI355REC_SLIM_NO_OWNER_GATE")) { ++holders; return true; }
-        int dev = 0;
-        char bus[64] = "unknown";
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev);
-        for (char *c = bus; *c; ++c)
-            if (*c == ':' || *c == '.' || *c == '/') *c = '_';
-        const char *dir = getenv("MI355REC_LOCK_DIR") ? getenv("MI355REC_LOCK_DIR") : "/tmp";
-        char path[512];
-        snprintf(path, sizeof(path), "%s/mi355rec_slim_owners_%u_%s.lock", dir, (unsigned)getuid(), bus);
-        const int f = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
-        if (f >= 0 && flock(f, LOCK_EX) == 0) fd = f;          // (no lock file: in-process serialisation only)
-        else if (f >= 0) close(f);
+        if (holders > 0) {                                 // (a dense launch of this process took the gate meanwhile: its lock serves)
+            if (locked) { (void)flock(f, LOCK_UN); close(f); }
+            ++holders;
+            return true;
+        }
+        if (locked) fd = f;
         holders = 1;
         return true;
     }
@@ -1823,17 +1852,24 @@ void schedule_stream(mi355rec_slim *h, StreamSet &st, int n, int first, hipStrea
 struct Launched {
     OwnerLease lease;
     bool dense = false, profile = false, serial = false;
+    hipStream_t stream = nullptr;          // set once the dataflow kernel is enqueued
     void end_serial() {
         if (serial) owner_gate().release_blocking();
         serial = false;
     }
-    ~Launched() { end_serial(); }
+    // (error paths end here with the kernel possibly still running: it is waited for BEFORE the gate and the leased compute units go
+    // back -- finish_stream has already drained the stream on the regular path, where this costs nothing)
+    ~Launched() {
+        if (stream && (serial || lease.slots > 0)) (void)hipStreamSynchronize(stream);
+        end_serial();
+    }
 };
 
 // The dataflow kernel of a scheduled stream, enqueued on the handle's main stream.
 template <class T>
 void launch_stream(mi355rec_slim *h, StreamSet &st, int n, int first, Launched &L) {
     hipStream_t s = h->stream;
+    L.stream = s;
     SlimParams<T> p{};
     const bool sym = h->cfg.symmetric != 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -2176,6 +2212,7 @@ extern "C" int mi355rec_slim_run_epochs(mi355rec_slim_t h, int32_t n_epochs) {
         MI_REQUIRE(h, "NULL handle");
         MI_REQUIRE(n_epochs >= 0, "n_epochs must be >= 0");
         ensure_device();
+        ReleaseScope scope(h->stream, h->side);
         if (h->f64) run_epochs_typed<double>(h, n_epochs); else run_epochs_typed<float>(h, n_epochs);
     });
 }
@@ -2186,6 +2223,7 @@ extern "C" int mi355rec_slim_run_samples(mi355rec_slim_t h, const int32_t *u, co
         MI_REQUIRE(n >= 0 && n < (1ll << 30), "n out of range");
         ensure_device();
         if (n == 0) return;
+        ReleaseScope scope(h->stream, h->side);
         StreamSet &st = h->set[h->cur ^ 1];                  // (a stream scheduled ahead for the next native epoch, if any, is given up)
         ensure_set_capacity(h, st, (size_t)n);
         st.epoch = -1;
@@ -2277,4 +2315,8 @@ extern "C" int mi355rec_slim_schedule_info(mi355rec_slim_t h, int32_t *n_owned_r
     });
 }
 
-extern "C" void mi355rec_slim_destroy(mi355rec_slim_t h) { delete h; }
+extern "C" void mi355rec_slim_destroy(mi355rec_slim_t h) {
+    if (!h) return;
+    ReleaseScope scope(h->stream, h->side);
+    delete h;
+}

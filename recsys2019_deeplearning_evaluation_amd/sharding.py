@@ -446,10 +446,19 @@ class ShardedIALSEpoch:
             self.recv.close()
 
 
+# What a row's solve (Cholesky + substitutions + the per-row set-up) costs next to the Gramian of its profile, in profile entries per
+# factor: the flop counts alone say k / 3 entries, but the solve stage runs at a fifth of the Gramian stage's rate.
+# Fitted to the eight measured item ranges of the ML-20M shape at k = 200 (profiles/r6_ials_ranges.txt): t = 1.53e-6 ms per entry
+# + 2.74e-4 ms per row = 180 entries per row; with k / 3 the tail range (9 136 short rows) took 5.83 ms against 4.27 ms for the head.
+IALS_ROW_ENTRIES_PER_FACTOR = 0.9
+
+
 def ials_row_ranges(confidence_csr, world, num_factors):
-    """Cost-balanced user and item ranges: cost(row) = L * k^2 (Gramian) + k^3 / 3 (factorisation)."""
+    """Cost-balanced user and item ranges: cost(row) = (L + 0.9 k) * k^2 -- the Gramian of the row's L profile entries plus its solve,
+    priced in entries (IALS_ROW_ENTRIES_PER_FACTOR)."""
     import scipy.sparse as sps
     k = float(num_factors)
+    fixed = IALS_ROW_ENTRIES_PER_FACTOR * k
     lu = np.diff(confidence_csr.indptr).astype(np.float64)
     li = np.diff(sps.csc_matrix(confidence_csr).indptr).astype(np.float64)
-    return (balanced_column_ranges(lu * k * k + k ** 3 / 3.0, world), balanced_column_ranges(li * k * k + k ** 3 / 3.0, world))
+    return (balanced_column_ranges((lu + fixed) * k * k, world), balanced_column_ranges((li + fixed) * k * k, world))

@@ -36,7 +36,7 @@ def test_golden_fixture(gpu):
         assert rel_err(rec.ITEM_factors, z["V_%d" % n]) < RTOL
 
 
-@pytest.mark.parametrize("k", [1, 5, 32, 33, 64, 100, 160, 161, 200, 224])
+@pytest.mark.parametrize("k", [1, 5, 32, 33, 64, 100, 160, 161, 200, 224, 225, 240, 255])
 def test_factor_counts(gpu, k):
     X = named_urm("ml1m", "real", scale=0.08)
     Cm = O.oracle_ials_confidence(X, "linear", 2.0)

@@ -741,8 +741,11 @@ def test_resident_urm_build_equals_host_build(gpu):
     with pytest.raises(ValueError, match="does not hold this dataMatrix"):
         Compute_Similarity_MI355X(other, topK=5, resident=res)
     other = X.copy()
-    other.data[7] += 1.0                                    # not sampled: only the full comparison sees it
-    assert res.matches(other) and not res.matches(other, thorough=True) and res.matches(X.copy(), thorough=True)
+    other.data[7] += 1.0                                    # not in the fixed sample: the full comparison of a first presentation sees it
+    assert not res.matches(other) and not res.matches(other, thorough=True) and res.matches(X.copy(), thorough=True)
+    same = X.copy()
+    assert res.matches(same) and res._verified[res._buffers_of(same)] is True      # ... and the verdict is kept for these buffers
+    assert res.matches(same)
     rec, rec_res = ItemKNNCFRecommender(X, verbose=False), ItemKNNCFRecommender(X, verbose=False)
     rec.fit(topK=10, shrink=1)
     rec_res.fit(topK=10, shrink=1, resident_urm=res)
@@ -771,3 +774,49 @@ def test_lds_atomic_rate_is_measured(gpu):
     from recsys2019_deeplearning_evaluation_amd import _native as N
     rate = N.lds_atomic_rate()
     assert 0.5 * 21.6e9 * 256 < rate < 2.0 * 21.6e9 * 256, rate
+
+
+def test_closing_a_handle_does_not_wait_for_another_handles_kernels(gpu):
+    """Blocks that go back to the library's cache wait for the streams of the handle that owned them (csrc/common.h ReleaseScope), not for
+    the device: while one thread trains an IALS model (hundreds of milliseconds of kernels on its own stream), another thread builds
+    and closes small similarity handles -- each constructor + build + close stays far below the time the IALS call has left, and the
+    builds are as correct as ever."""
+    import threading
+    import time
+    from recsys2019_deeplearning_evaluation_amd import IALS_MI355X_Epoch
+    big = named_urm("ml20m", "binary", scale=0.35)
+    conf = big.copy()
+    conf.data = (1.0 + conf.data).astype(np.float32)
+    k = 128
+    ia = IALS_MI355X_Epoch(conf, k, 1e-3, k ** -0.5 * np.random.default_rng(0).random((big.shape[1], k)))
+    ia.run_epochs(1)
+    t0 = time.perf_counter()
+    ia.run_epochs(1)
+    epoch_s = time.perf_counter() - t0
+    n_epochs = max(4, int(np.ceil(1.0 / max(epoch_s, 1e-3))))           # about a second of kernels
+    X = named_urm("ml1m", "binary", scale=0.3)
+    want = Compute_Similarity_MI355X(X, topK=10).compute_similarity()
+    spans, running = [], threading.Event()
+
+    def train():
+        running.set()
+        ia.run_epochs(n_epochs)
+        running.clear()
+
+    th = threading.Thread(target=train)
+    th.start()
+    running.wait(10)
+    time.sleep(0.05)
+    while running.is_set() and len(spans) < 200:
+        t1 = time.perf_counter()
+        dev = Compute_Similarity_MI355X(X, topK=10)
+        got = dev.compute_similarity()
+        dev.close()
+        spans.append(time.perf_counter() - t1)
+        assert (got != want).nnz == 0
+    th.join(120)
+    ia.close()
+    total = n_epochs * epoch_s
+    assert len(spans) >= 3, (len(spans), total)
+    # with the device-wide wait every close() lasted until the IALS call ended: one or two handles per call
+    assert np.median(spans) < 0.2 * total, (np.median(spans), total, len(spans))
