@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355rec.so")
+# (MI355REC_LIB: another build of the same library, for measurements of compile-time variants -- scripts/sim_depth_sweep.sh)
+LIB_PATH = os.environ.get("MI355REC_LIB") or os.path.join(_HERE, "libmi355rec.so")
 
 E_INVALID, E_HIP, E_NO_DEVICE, E_UNSUPPORTED, E_NUMERIC = -1, -2, -3, -4, -5
 

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *Y, int n, int k
 // Round 1 kept 32 x 32 register tiles on the FP64 vector pipe with one barrier per column: VALU-issue bound in the
 // factorisation (2240 cycles per column: 28 multiply-adds among ~180 instructions on 16 wavefronts) and staging-latency bound
 // in the Gramian (1440 cycles per profile row); measured 832 k cycles per user row at ML-20M shape, k = 200.
-constexpr int MAX_KT = 15, MAX_NT = MAX_KT * (MAX_KT + 1) / 2;
+constexpr int MAX_KT = 16, MAX_NT = MAX_KT * (MAX_KT + 1) / 2;
 constexpr int ROW_THREADS = 512, ROW_WAVES = ROW_THREADS / 64;   // 2 wavefronts per SIMD: 256 VGPRs for the tiles of a wavefront
 constexpr double AUG_DIAG = 1e200;       // diagonal of the rhs row: keeps the last pivot positive, never used
 

@@ -892,6 +892,20 @@ struct mi355rec_mf_group {
     DeviceBuffer<FastSchedParams> sched_table;   // valid when every member is on the in-LDS schedule (all_fast)
     std::vector<FastSchedParams> host_sched_table;
     bool all_fast = false;
+    // Look-ahead schedule (all_fast): the sampler, sort, emit and finish launches of epoch e + 1 -- 38 % of a group epoch, and they read
+    // nothing the mini-batch kernels write -- run on `side` while the mini-batch launches of epoch e run on `stream`.  What the
+    // mini-batch kernels READ of a schedule (task headers, records, pair records, slots in use) exists twice per member: set A is the
+    // member's own, set B belongs to the group; the tables below are the A tables with the four pointers swapped.
+    struct SetB {
+        DeviceBuffer<TaskHeader> tasks;
+        DeviceBuffer<int4> recs, slot_recs;
+        DeviceBuffer<int> used;
+    };
+    std::vector<std::unique_ptr<SetB>> set_b;
+    DeviceBuffer<unsigned char> table_b;
+    DeviceBuffer<FastSchedParams> sched_table_b;
+    hipStream_t side = nullptr;
+    hipEvent_t ahead_fork = nullptr, ahead_join = nullptr;
     hipEvent_t fork = nullptr;
     std::vector<hipEvent_t> join;
     hipGraphExec_t graph = nullptr;
@@ -900,6 +914,11 @@ struct mi355rec_mf_group {
 
     ~mi355rec_mf_group() {
         if (stream) (void)hipStreamSynchronize(stream);
+        if (side) (void)hipStreamSynchronize(side);
+        if (ahead_fork) (void)hipEventDestroy(ahead_fork);
+        if (ahead_join) (void)hipEventDestroy(ahead_join);
+        ReleaseScope::forget(side);
+        if (side) (void)hipStreamDestroy(side);
         if (graph) (void)hipGraphExecDestroy(graph);
         timer.destroy();
         dispatch_timers.destroy();
@@ -1046,15 +1065,73 @@ void group_run_epochs_typed(mi355rec_mf_group *g, int n_epochs) {
     }
     g->dispatch_timers.reset();
     const long long timed_epochs = g->max_timed > 0 ? std::min<long long>(n_epochs, (g->max_timed + nb - 1) / nb) : 0;
-    bool use_graph = nb <= GRAPH_SEGMENT && n_epochs - timed_epochs > 0 && !getenv("MI355REC_NO_GRAPH");
+    const bool ahead = g->all_fast && n_epochs > 1 && !getenv("MI355REC_MF_GROUP_NO_LOOKAHEAD");
+    bool use_graph = !ahead && nb <= GRAPH_SEGMENT && n_epochs - timed_epochs > 0 && !getenv("MI355REC_NO_GRAPH");
     if (use_graph) {
         group_ensure_graph<T>(g);
         use_graph = g->graph != nullptr;
     }
+    if (ahead) {
+        // set B and its tables (once per group, again when a member's buffers moved)
+        bool fresh = g->set_b.size() != (size_t)R;
+        for (int m = 0; m < R && !fresh; ++m) {
+            const mi355rec_mf *h = g->members[m];
+            const mi355rec_mf_group::SetB &b = *g->set_b[m];
+            fresh = b.tasks.count != h->tasks.count || b.recs.count != h->recs.count || b.slot_recs.count != h->slot_recs.count || b.used.count != h->used.count;
+        }
+        if (fresh) {
+            MI_HIP(hipStreamSynchronize(g->stream));
+            if (!g->side) MI_HIP(hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking));
+            if (!g->ahead_fork) MI_HIP(hipEventCreateWithFlags(&g->ahead_fork, hipEventDisableTiming));
+            if (!g->ahead_join) MI_HIP(hipEventCreateWithFlags(&g->ahead_join, hipEventDisableTiming));
+            g->set_b.clear();
+            for (int m = 0; m < R; ++m) {
+                mi355rec_mf *h = g->members[m];
+                std::unique_ptr<mi355rec_mf_group::SetB> b(new mi355rec_mf_group::SetB());
+                b->tasks.alloc_zero(h->tasks.count, g->stream);
+                b->recs.alloc(h->recs.count);
+                b->slot_recs.alloc_zero(h->slot_recs.count, g->stream);
+                b->used.alloc(h->used.count);
+                g->set_b.push_back(std::move(b));
+            }
+        }
+        std::vector<unsigned char> table_b = table;
+        std::vector<FastSchedParams> sched_b = sched;
+        for (int m = 0; m < R; ++m) {
+            MfParams<T> pb;
+            memcpy(&pb, table_b.data() + sizeof(MfParams<T>) * (size_t)m, sizeof(pb));
+            const mi355rec_mf_group::SetB &b = *g->set_b[m];
+            pb.tasks = b.tasks.ptr; pb.recs = b.recs.ptr; pb.slot_recs = b.slot_recs.ptr; pb.used = b.used.ptr;
+            memcpy(table_b.data() + sizeof(MfParams<T>) * (size_t)m, &pb, sizeof(pb));
+            sched_b[m].tasks = b.tasks.ptr; sched_b[m].recs = b.recs.ptr; sched_b[m].slot_recs = b.slot_recs.ptr; sched_b[m].used = b.used.ptr;
+        }
+        if (g->table_b.count < table_b.size()) g->table_b.alloc(table_b.size());
+        if (g->sched_table_b.count < sched_b.size()) g->sched_table_b.alloc(sched_b.size());
+        MI_HIP(hipMemcpyAsync(g->table_b.ptr, table_b.data(), table_b.size(), hipMemcpyHostToDevice, g->stream));
+        MI_HIP(hipMemcpyAsync(g->sched_table_b.ptr, sched_b.data(), sizeof(FastSchedParams) * sched_b.size(), hipMemcpyHostToDevice, g->stream));
+        MI_HIP(hipStreamSynchronize(g->stream));           // (the two vectors are locals)
+    }
     g->timer.start(g->stream);
-    for (long long e = 0; e < n_epochs; ++e) {
-        if (e < timed_epochs || !use_graph) group_enqueue_epoch<T>(g, e < timed_epochs);
-        else MI_HIP(hipGraphLaunch(g->graph, g->stream));
+    if (ahead) {
+        const MfParams<T> *tab[2] = {reinterpret_cast<const MfParams<T> *>(g->table.ptr), reinterpret_cast<const MfParams<T> *>(g->table_b.ptr)};
+        const FastSchedParams *sch[2] = {g->sched_table.ptr, g->sched_table_b.ptr};
+        group_enqueue_schedule<T>(g, tab[0], sch[0], g->stream);                   // the call's first epoch: nothing to hide it behind
+        for (long long e = 0; e < n_epochs; ++e) {
+            const int cur = (int)(e & 1);
+            if (e + 1 < n_epochs) {
+                MI_HIP(hipEventRecord(g->ahead_fork, g->stream));                   // (behind epoch e's schedule and epoch e - 1's mini-batches)
+                MI_HIP(hipStreamWaitEvent(g->side, g->ahead_fork, 0));
+                group_enqueue_schedule<T>(g, tab[cur ^ 1], sch[cur ^ 1], g->side);
+                MI_HIP(hipEventRecord(g->ahead_join, g->side));
+            }
+            group_enqueue_batches<T>(g, tab[cur], e < timed_epochs);
+            if (e + 1 < n_epochs) MI_HIP(hipStreamWaitEvent(g->stream, g->ahead_join, 0));
+        }
+    } else {
+        for (long long e = 0; e < n_epochs; ++e) {
+            if (e < timed_epochs || !use_graph) group_enqueue_epoch<T>(g, e < timed_epochs);
+            else MI_HIP(hipGraphLaunch(g->graph, g->stream));
+        }
     }
     g->timer.stop(g->stream);
     MI_HIP(hipGetLastError());

@@ -82,6 +82,12 @@ struct SimParams {
     unsigned *part_count;   // arrival counters, indexed by the first part slot of a split column
     unsigned long long *phase_ticks;   // diagnostics (MI355REC_SIM_PHASES=1): 100 MHz ticks per phase, summed over workgroups
     int fast_topk;          // 1: threshold-first selection (fast_column_topk) where it applies; 0 (MI355REC_SIM_FAST_TOPK=0): always the full normalise + radix select
+    // packed-counts launch + the 32-bit launch behind it (run_columns_lds): the second launch's work list is its own items followed by
+    // the columns the packed kernel hands over; *retry_count = its length (read once at kernel start when n_items_dev is set)
+    int *retry_count;
+    int4 *retry_items;
+    int2 *retry_ranges;
+    const int *n_items_dev;
     unsigned long long *fast_stats;    // [0] columns finished by the fast path, [1] their candidates, [2] columns that fell back
     unsigned *queue;
     int *out_idx;
@@ -186,7 +192,7 @@ __device__ __forceinline__ void lds_add_f64(unsigned byte_address, double v) {
 }
 
 template <int THREADS, int G, int MODE>
-__global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) {
+__global__ __launch_bounds__(THREADS, 4) void sim_column_kernel(const SimParams p) {
     constexpr bool UNIT = MODE == ACC_COUNTS;        // no values
     constexpr bool CELL32 = MODE != ACC_WIDE;        // 4-byte integer cells
     // LDS: [accumulator | selection scratch | the workgroup's few shared scalars].  The kernel has NO static LDS, so the accumulator
@@ -221,11 +227,13 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
     // atomic after the accumulation (A), requests the item's descriptor one phase later (B) and files both in LDS after the
     // top-K (C), where the loop head finds them -- without it every column starts with three dependent round trips (queue ->
     // descriptor -> CSC bounds: 2-3 us of ~20).  None of this state is live during the accumulation (the register peak).
+    // (behind a packed-counts launch the list has grown by the columns that kernel handed over: its length is read from the device)
+    const int n_items = p.n_items_dev ? *p.n_items_dev : p.n_items;
     int nx_slot = -1;                        // thread 0 only
     auto pull_now = [&]() {                  // thread 0, synchronous: the first item, and after a split column's part that does not finish the column
         const int sl = nx_slot >= 0 ? nx_slot : (int)atomicAdd(p.queue, 1u);
         s_col = sl;
-        if (sl < p.n_items) {
+        if (sl < n_items) {
             s_item = p.items[sl];
             s_range = p.item_range[sl];
         }
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
     for (;;) {
         __syncthreads();
         const int slot = s_col;
-        if (slot >= p.n_items) break;
+        if (slot >= n_items) break;
         const int4 item = s_item;
         const unsigned long long t_item = p.phase_ticks ? wall_clock64() : 0ull;
         auto item_done = [&]() {
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         int4 nx_item = make_int4(0, 0, 0, 0);
         int2 nx_range = make_int2(0, 0);
         auto request_next = [&]() {          // (B) thread 0
-            if (nx_slot < p.n_items) {
+            if (nx_slot < n_items) {
                 nx_item = p.items[nx_slot];
                 nx_range = p.item_range[nx_slot];
             }
@@ -384,15 +392,81 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         const float4 *val4 = reinterpret_cast<const float4 *>(p.seg_val);
         const uint4 *val8 = reinterpret_cast<const uint4 *>(p.seg_val16);
         int4 *tab = reinterpret_cast<int4 *>(aux) + wave * 64;       // [64] x {rs, re, weight, -}: one 16-byte read per entry
+        // All-ones data, one tile (the headline instance): the same walk with the bookkeeping pared down -- measured in round 6, the
+        // loop is bound by instruction ISSUE (61 instructions per 8 atomics: with one atomic per chunk instead of eight the phase
+        // still took 75 % of its time; deeper prefetch made it slower; where the stream comes from makes no difference), not by
+        // the LDS unit.  The table holds {first, end} pairs (128 per wavefront, the upper half stays {0, 0}: a group that has run
+        // out of entries reads an empty slice and stays where it is); per step a group checks whether its slice is used up, READS ITS
+        // NEXT TABLE ENTRY UNCONDITIONALLY (no branch) and applies it after the eight atomics of the oldest chunk have been issued
+        // -- the read is older than they are, so the wait for it does not drain them --, then fetches: ~33 instructions per step.
+        const bool lean = UNIT && p.n_tiles == 1;
+        int2 *tab2 = reinterpret_cast<int2 *>(aux) + wave * 128;
+        if (lean) tab2[64 + lane] = make_int2(0, 0);
         for (int base = 0; entry_of(base) < cend; base += 64) {
             const bool have = t_re >= 0;                 // (a prefix of the lanes: entry_of grows with q)
             const int n_here = __popcll(__ballot(have));
-            if (have) tab[lane] = make_int4(t_rs, t_re, __float_as_int(t_r), 0);
+            if (lean) tab2[lane] = have ? make_int2(t_rs, t_re) : make_int2(0, 0);
+            else if (have) tab[lane] = make_int4(t_rs, t_re, __float_as_int(t_r), 0);
             load_bounds(x_next, y_next, cv_next, t_rs, t_re, t_r);                     // for the next round
             load_user(base + 128 + lane, x_next, y_next, cv_next);                    // for the round after
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lean) {
+                const int g8 = 8 * gl;
+                int m = sub;
+                int f_t, f_re;
+                {
+                    const int2 e = tab2[m];
+                    f_t = e.x;
+                    f_re = e.y;
+                }
+                uint4 ids[DEPTH];
+                bool ok[DEPTH];
+                auto fetch = [&](int d) {
+                    const int at = f_t + g8;
+                    ok[d] = at < f_re;
+                    ids[d] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(idx_rsrc, at * 2, 0, 0));
+                    f_t += 8 * G;
+                };
+                auto step = [&](int d) {
+                    const bool done = f_t >= f_re;           // (group-uniform: the slice is used up)
+                    m = min(m + (done ? GPW : 0), 127);
+                    const int2 e = tab2[m];                  // requested before the atomics below, needed after them
+                    if (ok[d]) {
+                        const unsigned ww[4] = {ids[d].x, ids[d].y, ids[d].z, ids[d].w};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            lds_add_u32((q & 1) ? lds_cell_address<1, 2>(ww[q >> 1]) : lds_cell_address<0, 2>(ww[q >> 1]), 1u);
+                    }
+                    f_t = done ? e.x : f_t;
+                    f_re = done ? e.y : f_re;
+                    fetch(d);
+                };
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    if (d) {
+                        const bool done = f_t >= f_re;
+                        m = min(m + (done ? GPW : 0), 127);
+                        const int2 e = tab2[m];
+                        f_t = done ? e.x : f_t;
+                        f_re = done ? e.y : f_re;
+                    }
+                    fetch(d);
+                }
+                for (;;) {
+                    bool any = false;
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) {
+                        any |= ok[d];
+                        step(d);
+                    }
+                    if (__ballot(any) == 0ull) break;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // the table is rewritten by the next round
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
 
             // fetch cursor of this lane group
             int m = sub - GPW, f_t = 0, f_re = 0;
@@ -487,6 +561,25 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
         __syncthreads();
         mark(1);
         if (tid == 0 && tile == 0) nx_slot = (int)atomicAdd(p.queue, 1u);       // next work item: requested now, looked at later
+        if (UNIT && item.w < 0) {
+            // A column with 65 536 users or more behind a packed-counts launch: its parts (each fewer users than that) were accumulated
+            // there, two 16-bit counts per word, and published; this item -- {column, 0, 1, -(1 + first slot)} with the EMPTY walk list
+            // [parts, parts) -- adds them up into 32-bit cells and selects.
+            const int n_words = p.n_cols_pad / 2;
+            const uint32_t *src = p.part_buf + (size_t)(-(item.w + 1)) * p.n_cols_pad;
+            for (int w = tid; w < n_words; w += THREADS) {
+                unsigned lo = 0u, hi = 0u;
+                for (int q = 0; q < cbeg; ++q) {
+                    const unsigned v = src[(size_t)q * p.n_cols_pad + w];
+                    lo += v & 0xFFFFu;
+                    hi += v >> 16;
+                }
+                acc_u[2 * w] = lo;
+                acc_u[2 * w + 1] = hi;
+            }
+            __syncthreads();
+            mark(2);
+        }
         if (item.z > 1) {
             const int pub_words = CELL32 ? p.n_cols_pad : 2 * p.n_cols_pad;
             // Split column: publish this part's accumulator; the workgroup that arrives last adds the parts up (in
@@ -579,7 +672,7 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             // block_kth_largest_prefix16 returns), and a zero cell neither raises a maximum nor passes the bar.
             constexpr int CPT = (MAX_TILE + 1023) / 1024;      // rounds (512-thread tiles are narrower than half of MAX_TILE)
             constexpr int CAND_MAX = AUX_WORDS / 2;            // 8-byte entries: (norm, id) of a survivor, then its (value key, ~id)
-            constexpr int BATCH = 8;
+            constexpr int BATCH = 16, HALF = 8;
             const float *nj = reinterpret_cast<const float *>(nj4);
             const __amdgpu_buffer_rsrc_t nj_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(nj), 0, n_tile * 4, 0x00020000);
             int tid_o = tid;                                   // (opaque: or the 32 addresses are computed before the persistent loop and parked in scratch)
@@ -587,29 +680,35 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             const int n_rounds = (p.n_cols_pad + THREADS - 1) / THREADS;
             const DenomForm form = denominator_form(p, norm_c);
             auto cell_value = [&](unsigned q) { return UNIT ? (float)q : (float)(int)q * p.int_inv; };
-            // one batch of rounds: BATCH cells, and the norms of the NEXT batch requested before the current one is worked on (an L2 round
-            // trip per batch otherwise: four of them were most of a scan), then `use(round, value, norm)`.  Rounds behind the tile (a
-            // batch is not cut short) and the lanes of the last round that lie behind it read the first spare cell: zero.
+            // one batch of rounds: the norms of BATCH cells are requested together, the cells are read from LDS while they are on their
+            // way, then `use(round, value, norm)`.  Rounds behind the tile (a batch is not cut short) and the lanes of the last round
+            // that lie behind it read the first spare cell: zero.
             const unsigned cell_at = (unsigned)tid_o * 4u, cell_end = (unsigned)p.n_cols_pad * 4u;      // byte offsets into the accumulator
             auto request_norms = [&](int b, float (&dst)[BATCH]) {
 #pragma unroll
                 for (int i = 0; i < BATCH; ++i)
                     dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(nj_rsrc, tid_o * 4, (b + i) * THREADS * 4, 0));
             };
+            // (sixteen norms per request and thread, nothing requested ahead: a scan of an ML-20M column is two L2 round trips instead of
+            // the four that eight double-buffered norms made it -- working on eight cells never hid the next request's latency; the same
+            // 24 registers: sixteen norms + eight cells)
             auto scan_cells = [&](auto &&use) {
-                float nrm[2][BATCH];
-                request_norms(0, nrm[0]);
 #pragma unroll
                 for (int bi = 0; bi < CPT / BATCH; ++bi) {
                     const int b = bi * BATCH;
                     if (b >= n_rounds) break;                              // (block-uniform)
-                    if (b + BATCH < n_rounds) request_norms(b + BATCH, nrm[(bi + 1) & 1]);
-                    unsigned cnt[BATCH];
+                    float nrm[BATCH];
+                    request_norms(b, nrm);
 #pragma unroll
-                    for (int i = 0; i < BATCH; ++i)
-                        cnt[i] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(acc) + min(cell_at + (unsigned)(b + i) * (THREADS * 4u), cell_end));
+                    for (int hf = 0; hf < BATCH / HALF; ++hf) {
+                        unsigned cnt[HALF];
 #pragma unroll
-                    for (int i = 0; i < BATCH; ++i) use(b + i, cell_value(cnt[i]), nrm[bi & 1][i]);
+                        for (int i = 0; i < HALF; ++i)
+                            cnt[i] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(acc) +
+                                                                         min(cell_at + (unsigned)(b + hf * HALF + i) * (THREADS * 4u), cell_end));
+#pragma unroll
+                        for (int i = 0; i < HALF; ++i) use(b + hf * HALF + i, cell_value(cnt[i]), nrm[hf * HALF + i]);
+                    }
                 }
             };
             // (A) thread maxima of the approximate values
@@ -869,6 +968,332 @@ __global__ __launch_bounds__(THREADS) void sim_column_kernel(const SimParams p) 
             __syncthreads();
         }
         item_done();
+    }
+    if (p.phase_ticks && tid == 0) {
+        const unsigned long long t_end = wall_clock64();
+        atomicMax(&p.phase_ticks[9], t_end);
+        atomicAdd(&p.phase_ticks[10], t_end - t_start);
+    }
+}
+
+// ---------------------------------------- packed counts: two workgroups per CU ----------------------------------------
+// The column kernel above keeps one workgroup per CU: a 32-bit cell per neighbour takes most of the LDS at ML-20M / Netflix shape, and a
+// column's phases run one after the other -- accumulation (LDS atomics, the stream), then four latency-bound selection phases during
+// which the atomic unit idles; measured in round 6, neither phase comes near a hardware limit of its own (profiles/r6_sim_phases.txt).
+// Two co-resident workgroups interleave them.  They fit because, for all-ones data, a cell (c, j) never exceeds the number of users of
+// column c: a column with fewer than 65 536 users needs 16 bits per cell.  This kernel packs two neighbours per LDS word -- neighbour
+// j lives in half j & 1 of word j >> 1 and is incremented by 1 or 65 536 with the same 32-bit atomic; a half cannot carry into the other
+// -- so an ML-20M column takes 53 KiB, two 512-thread workgroups share a CU, and the same id stream, walk lists and threshold-first
+// selection serve (thread maxima over the words' two cells each, exact values of the survivors, rank, emit: bit-identical output).
+// NOT handled here, by the host's choice of work items: columns with 65 536 users or more, columns that the schedule would split,
+// light columns -- the 32-bit kernel runs them in a second launch, together with the columns whose threshold-first selection does
+// not go through (fewer than K positive thread maxima, more survivors than the buffer holds): this kernel appends those to the
+// second launch's work list (p.retry_count / p.retry_items), the accumulator is simply abandoned.
+constexpr double PACKED_MAX_PAIRS_PER_COLUMN = 2.0e6;
+constexpr int PACKED_PART_ENTRIES = 49152;      // walk entries (>= users) of one part of a column with 65 536 users or more: its counts stay below 2^16
+constexpr int PACKED_AUX_WORDS = 4096;          // 16 KiB: the wavefront tables (8 x 1 KiB), then histogram / candidates (2 048 x 8 B)
+template <int THREADS, int G>
+__global__ __launch_bounds__(THREADS, 4) void sim_packed_kernel(const SimParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned *accw = reinterpret_cast<unsigned *>(smem);                       // [acc_words] two 16-bit counts per word (+ spare words)
+    uint32_t *aux = reinterpret_cast<uint32_t *>(smem) + p.acc_words;
+    SimShared &shared = *reinterpret_cast<SimShared *>(aux + PACKED_AUX_WORDS);
+    SelectScratch &sc = shared.sc;
+    int &s_col = shared.col;
+    int4 &s_item = shared.item;
+    int2 &s_range = shared.range;
+    uint32_t &s_ncand = shared.ncand;
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) float *)smem != 0u) __builtin_trap();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int gl = tid % G;
+    constexpr int WAVES = THREADS / 64, GPW = 64 / G, DEPTH = SIM_DEPTH_UNIT;
+    const int wave = tid >> 6, sub = lane / G;
+    const int n_words = p.n_cols_pad / 2;                                       // words that hold neighbours (n_cols_pad is a multiple of 4)
+
+    unsigned long long t_prev = p.phase_ticks ? wall_clock64() : 0ull;
+    const unsigned long long t_start = t_prev;
+    if (p.phase_ticks && tid == 0) atomicMin(&p.phase_ticks[8], t_start);
+    auto mark = [&](int phase) {
+        if (p.phase_ticks && tid == 0) {
+            const unsigned long long now = wall_clock64();
+            atomicAdd(&p.phase_ticks[phase], now - t_prev);
+            t_prev = now;
+        }
+    };
+    int nx_slot = -1;                        // thread 0 only (the next work item is pulled early, see sim_column_kernel)
+    if (tid == 0) {
+        const int sl = (int)atomicAdd(p.queue, 1u);
+        s_col = sl;
+        if (sl < p.n_items) {
+            s_item = p.items[sl];
+            s_range = p.item_range[sl];
+        }
+    }
+    const __amdgpu_buffer_rsrc_t idx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.seg_idx16), 0, (int)0xFFFFFFF0u, 0x00020000);
+    for (;;) {
+        __syncthreads();
+        const int slot = s_col;
+        if (slot >= p.n_items) break;
+        const int4 item = s_item;
+        const unsigned long long t_item = p.phase_ticks ? wall_clock64() : 0ull;
+        const int c = item.x;
+        const int cbeg = s_range.x, cend = s_range.y;
+        int4 nx_item = make_int4(0, 0, 0, 0);
+        int2 nx_range = make_int2(0, 0);
+        const size_t out_base = (size_t)(p.out_slot ? p.out_slot[c] : c - p.start_col) * p.topK;
+
+        // the wavefront's stripes of the column's walk list (serpentine over the WAVES x parts virtual wavefronts, as in sim_column_kernel)
+        const int n_parts = item.z & 0xFFFF;
+        const bool parts_only = (item.z >> 16) != 0;        // a column of 65 536 users or more: the 32-bit launch adds its parts up
+        const int NV = WAVES * n_parts, vw = item.y * WAVES + wave;
+        auto entry_of = [&](int q) {
+            const int stripe = q / GPW, pos = (stripe & 1) ? NV - 1 - vw : vw;
+            return cbeg + (stripe * NV + pos) * GPW + (q % GPW);
+        };
+        auto load_user = [&](int q, int &ex) {
+            const int at = entry_of(q);
+            ex = at < cend ? p.walk4[at] : -1;
+        };
+        auto load_bounds = [&](int ex, int &rs, int &re) {
+            if (ex >= 0) {
+                const uint2 e = p.walk_tab[ex];
+                rs = (int)e.x;
+                re = (int)e.y;
+            } else {
+                rs = 0;
+                re = -1;
+            }
+        };
+        int x_first, x_next, t_rs, t_re;
+        load_user(lane, x_first);
+        load_user(64 + lane, x_next);
+        {
+            uint4 *a4 = reinterpret_cast<uint4 *>(accw);
+            for (int w = tid; w < p.acc_words / 4; w += THREADS) a4[w] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        load_bounds(x_first, t_rs, t_re);
+        __syncthreads();
+        mark(0);
+
+        // ---- accumulation: the lean walk of sim_column_kernel, the increment chosen by the id's lowest bit ----
+        int2 *tab2 = reinterpret_cast<int2 *>(aux) + wave * 128;
+        tab2[64 + lane] = make_int2(0, 0);
+        for (int base = 0; entry_of(base) < cend; base += 64) {
+            tab2[lane] = t_re >= 0 ? make_int2(t_rs, t_re) : make_int2(0, 0);
+            load_bounds(x_next, t_rs, t_re);
+            load_user(base + 128 + lane, x_next);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int g8 = 8 * gl;
+            int m = sub, f_t, f_re;
+            {
+                const int2 e = tab2[m];
+                f_t = e.x;
+                f_re = e.y;
+            }
+            uint4 ids[DEPTH];
+            bool ok[DEPTH];
+            auto fetch = [&](int d) {
+                const int at = f_t + g8;
+                ok[d] = at < f_re;
+                ids[d] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(idx_rsrc, at * 2, 0, 0));
+                f_t += 8 * G;
+            };
+            auto add_pair = [&](unsigned w) {                 // the two ids of one stream word
+                const unsigned a0 = lds_cell_address<0, 1>(w) & 0xFFFFFFFCu, a1 = lds_cell_address<1, 1>(w) & 0xFFFFFFFCu;
+                lds_add_u32(a0, (w & 1u) ? 0x10000u : 1u);
+                lds_add_u32(a1, (w & 0x10000u) ? 0x10000u : 1u);
+            };
+            auto step = [&](int d) {
+                const bool done = f_t >= f_re;
+                m = min(m + (done ? GPW : 0), 127);
+                const int2 e = tab2[m];
+                if (ok[d]) {
+                    add_pair(ids[d].x);
+                    add_pair(ids[d].y);
+                    add_pair(ids[d].z);
+                    add_pair(ids[d].w);
+                }
+                f_t = done ? e.x : f_t;
+                f_re = done ? e.y : f_re;
+                fetch(d);
+            };
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (d) {
+                    const bool done = f_t >= f_re;
+                    m = min(m + (done ? GPW : 0), 127);
+                    const int2 e = tab2[m];
+                    f_t = done ? e.x : f_t;
+                    f_re = done ? e.y : f_re;
+                }
+                fetch(d);
+            }
+            for (;;) {
+                bool any = false;
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    any |= ok[d];
+                    step(d);
+                }
+                if (__ballot(any) == 0ull) break;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        mark(1);
+        if (tid == 0) nx_slot = (int)atomicAdd(p.queue, 1u);
+        if (n_parts > 1 || parts_only) {
+            // Split column (see sim_column_kernel): publish the part's words; the workgroup that arrives last adds the parts up -- the sums
+            // stay below 65 536 per half, the column has fewer users than that -- and carries on with the column.  (parts_only: nobody
+            // here adds anything up.)
+            const int pub_words = n_words;
+            {
+                uint4 *dst = reinterpret_cast<uint4 *>(p.part_buf + (size_t)(item.w + item.y) * p.n_cols_pad);
+                const uint4 *src = reinterpret_cast<const uint4 *>(accw);
+                for (int w = tid; w < pub_words / 4; w += THREADS) dst[w] = src[w];
+                if (tid < (pub_words & 3)) p.part_buf[(size_t)(item.w + item.y) * p.n_cols_pad + (pub_words & ~3) + tid] = accw[(pub_words & ~3) + tid];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __threadfence();
+                shared.last = parts_only ? 0 : (atomicAdd(&p.part_count[item.w], 1u) == (unsigned)(n_parts - 1));
+                if (shared.last) __threadfence();
+            }
+            __syncthreads();
+            if (!shared.last) {
+                mark(2);
+                if (tid == 0) {          // (synchronous: nothing of this item is left to hide the requests behind)
+                    s_col = nx_slot;
+                    if (nx_slot < p.n_items) {
+                        s_item = p.items[nx_slot];
+                        s_range = p.item_range[nx_slot];
+                    }
+                    nx_slot = -1;
+                }
+                continue;
+            }
+            const uint32_t *src = p.part_buf + (size_t)item.w * p.n_cols_pad;
+            for (int w = tid; w < pub_words; w += THREADS) {
+                uint32_t a = src[w];
+                for (int q = 1; q < n_parts; ++q) a += src[(size_t)q * p.n_cols_pad + w];
+                accw[w] = a;
+            }
+            __syncthreads();
+            mark(2);
+        }
+        // the diagonal was accumulated like any other cell; the spare words absorbed the padding entries; the wavefront tables are dead:
+        // zero the histogram of block_kth_largest_prefix16 and what the scans read behind the last word
+        if (tid == 0) accw[c >> 1] &= (c & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+        for (int w = tid; w < 1024; w += THREADS) aux[w] = 0u;
+        if (tid < p.acc_words - n_words) accw[n_words + tid] = 0u;
+        if (tid == 0) s_ncand = 0;
+        __syncthreads();
+
+        // ---- threshold-first top-K over the words (see sim_column_kernel for the argument): thread t owns words t, t + THREADS, ... ----
+        bool done = false;
+        {
+            const bool asym = p.normalize && p.kind == MI355REC_SIM_ASYMMETRIC;
+            const float norm_c = asym ? p.norm_alpha[c] : p.norm[c];
+            const float *nj = asym ? p.norm_1ma : p.norm;
+            const uint32_t K = (uint32_t)p.topK;
+            constexpr int CPT = (MAX_TILE / 2 + THREADS - 1) / THREADS;     // rounds of THREADS words
+            constexpr int CAND_MAX = PACKED_AUX_WORDS / 2;
+            constexpr int BATCH = 8;                                        // words: sixteen cells and norms
+            const __amdgpu_buffer_rsrc_t nj_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(nj), 0, p.n_cols_pad * 4, 0x00020000);
+            int tid_o = tid;
+            asm volatile("" : "+v"(tid_o));
+            const int n_rounds = (n_words + THREADS - 1) / THREADS;
+            const DenomForm form = denominator_form(p, norm_c);
+            const unsigned word_at = (unsigned)tid_o * 4u, word_end = (unsigned)n_words * 4u;      // byte offsets (behind the last word: a zeroed spare word)
+            auto scan_words = [&](auto &&use) {
+#pragma unroll
+                for (int bi = 0; bi < CPT / BATCH; ++bi) {
+                    const int b = bi * BATCH;
+                    if (b >= n_rounds) break;
+                    float2 nrm[BATCH];
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i)
+                        nrm[i] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(nj_rsrc, tid_o * 8, (b + i) * THREADS * 8, 0));
+                    unsigned wd[BATCH];
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i)
+                        wd[i] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(accw) + min(word_at + (unsigned)(b + i) * (THREADS * 4u), word_end));
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i) {
+                        use(b + i, 0, (float)(wd[i] & 0xFFFFu), nrm[i].x);
+                        use(b + i, 1, (float)(wd[i] >> 16), nrm[i].y);
+                    }
+                }
+            };
+            float mx = 0.f;
+            scan_words([&](int, int, float v, float norm_j) { mx = fmaxf(mx, v * __builtin_amdgcn_rcpf(approx_denominator(form, v, norm_j))); });
+            mark(5);
+            const uint32_t p16 = block_kth_largest_prefix16<THREADS>(float_key(mx), K, aux, sc);
+            mark(3);
+            done = p16 > (ZERO_KEY >> 16);
+            if (done) {
+                if (tid == 0 && nx_slot < p.n_items) {
+                    nx_item = p.items[nx_slot];
+                    nx_range = p.item_range[nx_slot];
+                }
+                const float Tf = key_float(p16 << 16) * 0.99999809265136719f;
+                uint64_t *cand = reinterpret_cast<uint64_t *>(aux);
+                if (tid == 0) sc.out_count = 0;
+                scan_words([&](int round, int half, float v, float norm_j) {
+                    if (v > 0.f && v >= Tf * approx_denominator(form, v, norm_j)) {
+                        const uint32_t at = atomicAdd(&s_ncand, 1u);
+                        if (at < (uint32_t)CAND_MAX) cand[at] = ((uint64_t)__float_as_uint(norm_j) << 32) | (uint32_t)(2 * (tid_o + round * THREADS) + half);
+                    }
+                });
+                __syncthreads();
+                mark(6);
+                const uint32_t n_cand = s_ncand;
+                if (n_cand > (uint32_t)CAND_MAX || n_cand < K) {
+                    done = false;
+                } else {
+                    if (p.fast_stats && tid == 0) {
+                        atomicAdd(&p.fast_stats[0], 1ull);
+                        atomicAdd(&p.fast_stats[1], (unsigned long long)n_cand);
+                    }
+                    for (uint32_t t = tid; t < n_cand; t += THREADS) {
+                        const uint64_t e = cand[t];
+                        const uint32_t j = (uint32_t)e;
+                        const unsigned wv = accw[j >> 1];
+                        const float x = normalise(p, (float)((j & 1u) ? wv >> 16 : wv & 0xFFFFu), norm_c, __uint_as_float((uint32_t)(e >> 32)));
+                        cand[t] = ((uint64_t)float_key(x) << 32) | (uint32_t)(~j);
+                    }
+                    __syncthreads();
+                    block_rank_emit<THREADS>(cand, (int)n_cand, p.topK, K, 0u, sc, p.out_idx + out_base, p.out_val + out_base);
+                }
+            }
+        }
+        if (!done) {        // the 32-bit kernel's launch takes the column over (whole, whatever path failed here)
+            if (tid == 0) {
+                if (nx_slot < p.n_items && nx_item.z == 0) {          // (the descriptor of the next item was not asked for yet)
+                    nx_item = p.items[nx_slot];
+                    nx_range = p.item_range[nx_slot];
+                }
+                const int k = atomicAdd(p.retry_count, 1);
+                p.retry_items[k] = make_int4(c, 0, 1, 0);
+                p.retry_ranges[k] = make_int2(cbeg, cend);
+            }
+        }
+        if (tid == 0) {
+            s_col = nx_slot;
+            s_item = nx_item;
+            s_range = nx_range;
+            nx_slot = -1;
+            if (p.phase_ticks) {
+                const unsigned long long span = wall_clock64() - t_item;
+                if (span > atomicMax(&p.phase_ticks[11], span)) p.phase_ticks[12] = (unsigned long long)c;
+            }
+        }
+        __syncthreads();
+        mark(4);
     }
     if (p.phase_ticks && tid == 0) {
         const unsigned long long t_end = wall_clock64();
@@ -1498,10 +1923,10 @@ struct mi355rec_sim {
 namespace {
 
 template <int THREADS, int G>
-void launch_sim(mi355rec_sim *h, const SimParams &p, int grid, size_t lds) {
+void launch_sim(mi355rec_sim *h, const SimParams &p, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
     auto go = [&](auto k) {
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipExtLaunchKernelGGL(k, dim3(grid), dim3(THREADS), (unsigned)lds, h->stream, h->timer.t0, h->timer.t1, 0, p);
+        hipExtLaunchKernelGGL(k, dim3(grid), dim3(THREADS), (unsigned)lds, h->stream, e0, e1, 0, p);
     };
     switch (h->acc_mode()) {
         case ACC_COUNTS: go(sim_column_kernel<THREADS, G, ACC_COUNTS>); break;
@@ -1512,13 +1937,28 @@ void launch_sim(mi355rec_sim *h, const SimParams &p, int grid, size_t lds) {
 }
 
 template <int THREADS>
-void launch_sim_g(mi355rec_sim *h, const SimParams &p, int grid, size_t lds) {
+void launch_sim_g(mi355rec_sim *h, const SimParams &p, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
     switch (h->group_lanes) {
-        case 8: launch_sim<THREADS, 8>(h, p, grid, lds); break;
-        case 16: launch_sim<THREADS, 16>(h, p, grid, lds); break;
-        case 32: launch_sim<THREADS, 32>(h, p, grid, lds); break;
-        default: launch_sim<THREADS, 64>(h, p, grid, lds); break;
+        case 4: launch_sim<THREADS, 4>(h, p, grid, lds, e0, e1); break;
+        case 8: launch_sim<THREADS, 8>(h, p, grid, lds, e0, e1); break;
+        case 16: launch_sim<THREADS, 16>(h, p, grid, lds, e0, e1); break;
+        case 32: launch_sim<THREADS, 32>(h, p, grid, lds, e0, e1); break;
+        default: launch_sim<THREADS, 64>(h, p, grid, lds, e0, e1); break;
     }
+}
+
+// the packed-counts kernel (all-ones data, one tile, 512 threads, two workgroups per CU)
+void launch_packed(mi355rec_sim *h, const SimParams &p, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
+    auto go = [&](auto k) {
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipExtLaunchKernelGGL(k, dim3(grid), dim3(512), (unsigned)lds, h->stream, e0, e1, 0, p);
+    };
+    switch (h->group_lanes) {
+        case 4: go(sim_packed_kernel<512, 4>); break;
+        case 16: go(sim_packed_kernel<512, 16>); break;
+        default: go(sim_packed_kernel<512, 8>); break;
+    }
+    MI_HIP(hipGetLastError());
 }
 
 void clamp_range(const mi355rec_sim *h, int32_t &s, int32_t &e) {
@@ -1697,7 +2137,7 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     const size_t lds = (size_t)acc_words * 4 + (size_t)AUX_WORDS * 4 + sizeof(SimShared);
     const int cus = multiprocessor_count();
     int threads = 1024, max_grid = cus;   // one 16-wave workgroup per CU when the accumulator owns the LDS
-    if (lds <= 72 * 1024) {
+    if (lds <= 72 * 1024 && !getenv("MI355REC_SIM_ONE_WG_PER_CU")) {       // (the variable: measurements of one 16-wave workgroup against several 8-wave ones)
         const int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (lds + 1024))));
         threads = 512;
         max_grid = cus * per_cu;
@@ -1716,14 +2156,91 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
         }
     int min_part_users = 4 * threads;
     if (getenv("MI355REC_SIM_MIN_PART_USERS")) min_part_users = std::max(64, atoi(getenv("MI355REC_SIM_MIN_PART_USERS")));
-    const long long limit = std::max<long long>(1, cost_sum / ((long long)max_grid * 2));
+    // threshold-first selection (fast_column_topk in the kernel): positive denominators only (the set-based modes and tversky's
+    // alpha / beta inside the range the approximation's error bound was derived for), K well below the number of thread maxima
+    auto fast_topk_for = [&](int n_threads) {
+        const char *sw = getenv("MI355REC_SIM_FAST_TOPK");
+        const bool tversky_ok = h->cfg.similarity != MI355REC_SIM_TVERSKY ||
+                                (h->cfg.tversky_alpha >= 0.f && h->cfg.tversky_alpha <= 4.f && h->cfg.tversky_beta >= 0.f && h->cfg.tversky_beta <= 4.f);
+        return !(sw && atoi(sw) == 0) && unit_kernel && h->n_tiles == 1 && h->cfg.topK > 0 && 4 * h->cfg.topK <= n_threads &&
+               h->cfg.similarity != MI355REC_SIM_EUCLIDEAN && h->cfg.shrink >= 0 && tversky_ok;
+    };
+    // The packed-counts kernel (sim_packed_kernel: two 512-thread workgroups per CU) takes the columns it can: all-ones data, one
+    // tile, the threshold-first selection applicable, fewer than 65 536 users, not light, cheap enough not to be split over its grid.
+    // Everything else -- and whatever that kernel hands over -- goes to the 32-bit kernel's launch behind it.
+    const int packed_words = ((h->tile_w / 2 + 2) + 3) & ~3;
+    const size_t lds_packed = (size_t)packed_words * 4 + (size_t)PACKED_AUX_WORDS * 4 + sizeof(SimShared);
+    // ... and only where a column's fixed phases weigh something next to its accumulation: below PACKED_MAX_PAIRS_PER_COLUMN
+    // pair-adds per column of the call (ML-20M shape: 0.29 M, kernel 3.80 -> 3.03-3.10 ms; 138 493 x 9 000 with the same stored
+    // values: 0.87 M, 2.44 -> 2.09-2.17 ms; Netflix shape: 3.0 M, accumulation 92 % of the kernel, 16.5 -> 17.0 ms: not packed).
+    // MI355REC_SIM_PACKED=1 / 0 forces it on (where it applies) / off.
+    const char *packed_env = getenv("MI355REC_SIM_PACKED");
+    const bool packed_pays = packed_env ? atoi(packed_env) != 0 : (double)cost_sum < PACKED_MAX_PAIRS_PER_COLUMN * (double)std::max(1, n_local);
+    const bool packed = h->acc_mode() == ACC_COUNTS && h->n_tiles == 1 && !d_dense && threads == 1024 && fast_topk_for(512) &&
+                        2 * (lds_packed + 1024) <= 160 * 1024 && (h->group_lanes == 4 || h->group_lanes == 8 || h->group_lanes == 16) &&
+                        packed_pays && !getenv("MI355REC_SIM_NO_PACKED");
+    const int packed_grid = 2 * cus;
+    std::vector<int4> packed_items, merge_items;       // merge_items: 32-bit launch, columns whose packed parts it adds up
+    std::vector<int> merge_parts;
+    std::vector<char> is_packed;
+    long long legacy_cost = 0, packed_cost = 0;
+    int part_slots = 0, n_split = 0;
+    const bool heavy_parts = !(getenv("MI355REC_SIM_PACKED_HEAVY") && atoi(getenv("MI355REC_SIM_PACKED_HEAVY")) == 0);
+    if (packed) {
+        is_packed.assign((size_t)h->n_cols, 0);
+        for (int c : h->cost_order) {
+            if (!in_call(c)) continue;
+            // (columns of 65 536 users or more: accumulated there in parts of fewer users each, added up by the 32-bit launch; more
+            // than 64 such parts: left to the 32-bit kernel)
+            const int n_c = h->walk_ptr_host[c + 1] - h->walk_ptr_host[c];
+            const bool many = h->csc_ptr_host[c + 1] - h->csc_ptr_host[c] >= 65536;
+            if ((many ? heavy_parts && n_c <= 64 * PACKED_PART_ENTRIES : true) && h->cost[c] >= 16ll * std::max(1, h->cfg.topK)) {
+                is_packed[(size_t)c] = 1;
+                packed_cost += h->cost[c];
+            } else {
+                legacy_cost += h->cost[c];
+            }
+        }
+        // its heavy columns are split like the 32-bit kernel's: a part is at most 1/4 of a workgroup's fair share (its workgroups have
+        // 8 wavefronts: an unsplit column of 1/2 share kept one of them busy for a third of the launch)
+        const long long plimit = std::max<long long>(1, packed_cost / ((long long)packed_grid * 4));
+        std::vector<std::pair<long long, int>> pkeyed;
+        for (int c : h->cost_order) {
+            if (!in_call(c) || !is_packed[(size_t)c]) continue;
+            const int n_c = h->walk_ptr_host[c + 1] - h->walk_ptr_host[c];
+            const bool many_users = h->csc_ptr_host[c + 1] - h->csc_ptr_host[c] >= 65536;
+            long long parts = 1;
+            if (h->cost[c] > plimit) parts = std::max<long long>(1, std::min<long long>({(h->cost[c] + plimit - 1) / plimit, (long long)n_c / (4 * 512), 64ll}));
+            if (many_users) parts = std::max<long long>(parts, (n_c + PACKED_PART_ENTRIES - 1) / PACKED_PART_ENTRIES);
+            for (int q = 0; q < (int)parts; ++q) {
+                pkeyed.emplace_back(h->cost[c] / parts, (int)packed_items.size());
+                packed_items.push_back(make_int4(c, q, (int)parts | (many_users ? 1 << 16 : 0), parts > 1 || many_users ? part_slots : 0));
+            }
+            if (many_users) merge_items.push_back(make_int4(c, 0, 1, -(1 + part_slots)));
+            if (many_users) merge_parts.push_back((int)parts);
+            if (parts > 1 || many_users) {
+                part_slots += (int)parts;
+                ++n_split;
+            }
+        }
+        if (n_split) {
+            std::stable_sort(pkeyed.begin(), pkeyed.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+            std::vector<int4> sorted(pkeyed.size());
+            for (size_t i = 0; i < pkeyed.size(); ++i) sorted[i] = packed_items[pkeyed[i].second];
+            packed_items.swap(sorted);
+        }
+    }
+    const int n_packed = (int)packed_items.size();
+    const int n_split_packed = n_split;
+    // (the 32-bit launch behind a packed one splits ITS columns -- the heaviest of the call -- over its whole grid)
+    const long long limit = std::max<long long>(1, (n_packed ? legacy_cost : cost_sum) / ((long long)max_grid * 2));
     h->items_host.clear();
     h->items_host.reserve((size_t)n_local + 8 * (size_t)max_grid);
     std::vector<std::pair<long long, int>> keyed;   // (item cost, index into items_host)
     keyed.reserve(h->items_host.capacity());
-    int part_slots = 0, n_split = 0;
     for (int c : h->cost_order) {
         if (!in_call(c)) continue;
+        if (n_packed && is_packed[(size_t)c]) continue;
         const int n_c = h->walk_ptr_host[c + 1] - h->walk_ptr_host[c];      // entries of the column's walk list
         long long parts = 1;
         if (h->n_tiles == 1 && h->cost[c] > limit)
@@ -1744,27 +2261,36 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
             h->items_host.push_back(make_int4(c, 0, 1, h->cost[c] < 16ll * std::max(1, h->cfg.topK) ? 1 : 0));
         }
     }
-    if (n_split) {
+    if (n_split > n_split_packed) {
         std::stable_sort(keyed.begin(), keyed.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
         std::vector<int4> sorted(keyed.size());
         for (size_t i = 0; i < keyed.size(); ++i) sorted[i] = h->items_host[keyed[i].second];
         h->items_host.swap(sorted);
     }
+    h->items_host.insert(h->items_host.end(), merge_items.begin(), merge_items.end());        // (cheap: nothing to accumulate)
+    // device layout of the work lists: [the packed kernel's items | the 32-bit kernel's items | room for every packed item handed over]
+    const int n_legacy = (int)h->items_host.size();
+    h->items_host.insert(h->items_host.begin(), packed_items.begin(), packed_items.end());
     const int n_items = (int)h->items_host.size();
     h->n_split_columns = n_split;
     h->n_part_items = part_slots;
-    if (h->items.count < (size_t)n_items) {
-        h->items.alloc((size_t)n_items + 1024);
-        h->item_range.alloc((size_t)n_items + 1024);
+    if (h->items.count < (size_t)n_items + (size_t)n_packed) {
+        h->items.alloc((size_t)n_items + (size_t)n_packed + 1024);
+        h->item_range.alloc((size_t)n_items + (size_t)n_packed + 1024);
     }
     h->ranges_host.resize((size_t)n_items);
     for (int i = 0; i < n_items; ++i) {
         const int c = h->items_host[i].x;
         h->ranges_host[i] = make_int2(h->walk_ptr_host[c], h->walk_ptr_host[c + 1]);
+        if (i >= n_packed && h->items_host[i].w < 0) {            // a column added up from packed parts: the empty list [parts, parts)
+            const int parts = merge_parts[(size_t)(i - (n_items - (int)merge_items.size()))];
+            h->ranges_host[i] = make_int2(parts, parts);
+        }
     }
     MI_HIP(hipMemcpyAsync(h->items.ptr, h->items_host.data(), sizeof(int4) * n_items, hipMemcpyHostToDevice, h->stream));
     MI_HIP(hipMemcpyAsync(h->item_range.ptr, h->ranges_host.data(), sizeof(int2) * n_items, hipMemcpyHostToDevice, h->stream));
-    MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(unsigned), h->stream));
+    MI_HIP(hipMemsetAsync(h->queue.ptr, 0, 4 * sizeof(unsigned), h->stream));           // [0] the 32-bit launch's queue, [1] the packed launch's, [2] items of the 32-bit launch
+    if (n_packed) MI_HIP(hipMemcpyAsync(h->queue.ptr + 2, &n_legacy, sizeof(int), hipMemcpyHostToDevice, h->stream));
     if (part_slots) {
         const size_t pub_words = (size_t)h->tile_w * (unit_kernel ? 1 : 2);
         if (h->part_buf.count < (size_t)part_slots * pub_words) h->part_buf.alloc((size_t)part_slots * pub_words);
@@ -1804,9 +2330,9 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     p.norm = h->norm.ptr;
     p.norm_alpha = h->norm_alpha.ptr;
     p.norm_1ma = h->norm_1ma.ptr;
-    p.items = h->items.ptr;
-    p.item_range = h->item_range.ptr;
-    p.n_items = n_items;
+    p.items = h->items.ptr + n_packed;
+    p.item_range = h->item_range.ptr + n_packed;
+    p.n_items = n_legacy;
     p.part_buf = h->part_buf.ptr;
     p.part_count = h->part_count.ptr;
     if (getenv("MI355REC_SIM_PHASES")) {
@@ -1818,15 +2344,7 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     if (!h->selection_counts.ptr) h->selection_counts.alloc(4);
     MI_HIP(hipMemsetAsync(h->selection_counts.ptr, 0, 4 * sizeof(unsigned long long), h->stream));
     p.fast_stats = h->selection_counts.ptr;
-    // threshold-first selection (fast_column_topk in the kernel): positive denominators only (the set-based modes and tversky's
-    // alpha / beta inside the range the approximation's error bound was derived for), K well below the number of thread maxima
-    {
-        const char *sw = getenv("MI355REC_SIM_FAST_TOPK");
-        const bool tversky_ok = h->cfg.similarity != MI355REC_SIM_TVERSKY ||
-                                (h->cfg.tversky_alpha >= 0.f && h->cfg.tversky_alpha <= 4.f && h->cfg.tversky_beta >= 0.f && h->cfg.tversky_beta <= 4.f);
-        p.fast_topk = !(sw && atoi(sw) == 0) && unit_kernel && h->n_tiles == 1 && p.topK > 0 && 4 * p.topK <= threads &&
-                      h->cfg.similarity != MI355REC_SIM_EUCLIDEAN && h->cfg.shrink >= 0 && tversky_ok;
-    }
+    p.fast_topk = fast_topk_for(threads);
     p.fixed_scale = unit_kernel ? 0.0 : h->fixed_scale;
     p.int_scale = h->int_shift >= 0 ? (float)(1 << (2 * h->int_shift)) : 1.f;
     p.int_half = h->int_shift >= 0 ? (float)(1 << h->int_shift) : 1.f;
@@ -1845,7 +2363,7 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     p.out_val = d_val;
     p.out_dense = d_dense;
 
-    const int grid = std::min(n_items, max_grid);
+    const int grid = n_packed ? max_grid : std::min(n_legacy, max_grid);      // (behind a packed launch the list may grow)
     if (h->n_tiles > 1 && p.topK > 0) {
         const size_t need = (size_t)grid * h->n_tiles * p.topK;
         if (h->cand_idx.count < need) {
@@ -1856,11 +2374,27 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     p.cand_idx = h->cand_idx.ptr;
     p.cand_val = h->cand_val.ptr;
     h->call_timer.start(h->stream);
-    if (threads == 1024) launch_sim_g<1024>(h, p, grid, lds);
-    else launch_sim_g<512>(h, p, grid, lds);
+    if (n_packed) {
+        SimParams q = p;
+        q.items = h->items.ptr;
+        q.item_range = h->item_range.ptr;
+        q.n_items = n_packed;
+        q.acc_words = packed_words;
+        q.queue = h->queue.ptr + 1;
+        q.retry_count = reinterpret_cast<int *>(h->queue.ptr + 2);
+        q.retry_items = h->items.ptr + n_packed;
+        q.retry_ranges = h->item_range.ptr + n_packed;
+        launch_packed(h, q, std::min(n_packed, packed_grid), lds_packed, h->timer.t0, nullptr);
+        p.n_items_dev = reinterpret_cast<const int *>(h->queue.ptr + 2);
+        launch_sim_g<1024>(h, p, grid, lds, nullptr, h->timer.t1);
+    } else if (threads == 1024) {
+        launch_sim_g<1024>(h, p, grid, lds, h->timer.t0, h->timer.t1);
+    } else {
+        launch_sim_g<512>(h, p, grid, lds, h->timer.t0, h->timer.t1);
+    }
     h->call_timer.stop(h->stream);
 
-    h->stats.n_launches = 1;
+    h->stats.n_launches = n_packed ? 2 : 1;
     h->stats.n_timed = 1;
     h->stats.n_units = n_local;
     // ALGORITHMIC bytes, SURVEY.md section 8(d): per column c, its CSC column (8 B x n_c) + the CSR row of each of its users
@@ -2274,10 +2808,13 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
             // 16 / 32 / 64, Netflix shape 15.7 against 16.2 / 17.8 with 16 / 32, star ratings 5.16 against 5.31 / 5.88 / 7.39)
             (void)weighted_len;
             h->group_lanes = 8;
+            // (where the packed-counts kernel will run -- see run_columns_lds -- sixteen: 3.03 against 3.10 ms at ML-20M shape)
+            if (h->acc_mode() == ACC_COUNTS && h->n_tiles == 1 && (double)total_cost < PACKED_MAX_PAIRS_PER_COLUMN * (double)n_cols) h->group_lanes = 16;
             // the float64 kernel has half the loads in flight per lane (DEPTH 2)
             if (h->acc_mode() == ACC_WIDE) h->group_lanes = 16;
             if (getenv("MI355REC_SIM_G")) h->group_lanes = atoi(getenv("MI355REC_SIM_G"));
-            MI_REQUIRE(h->group_lanes == 8 || h->group_lanes == 16 || h->group_lanes == 32 || h->group_lanes == 64, "MI355REC_SIM_G must be 8, 16, 32 or 64");
+            MI_REQUIRE(h->group_lanes == 4 || h->group_lanes == 8 || h->group_lanes == 16 || h->group_lanes == 32 || h->group_lanes == 64,
+                       "MI355REC_SIM_G must be 4, 8, 16, 32 or 64");
         }
         if (!walk_only) build_seg_ptr();
         fill_stream();
@@ -2329,7 +2866,7 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         // the column view has served (norms, costs, value range): the accumulation walks the lists above
         h->csc_idx.release();
         h->csc_val.release();
-        h->queue.alloc(1);
+        h->queue.alloc(4);
         phase("fixed-point check + cost order (host)");
         *out = h.release();
     });

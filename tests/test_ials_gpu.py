@@ -98,7 +98,7 @@ def test_cold_rows_are_left_alone_and_halves_compose(gpu):
 def test_too_many_factors_is_refused_not_miscomputed(gpu):
     X = named_urm("ml1m", "binary", scale=0.05)
     with pytest.raises(NotImplementedError):
-        IALS_MI355X_Epoch(O.oracle_ials_confidence(X), 225, 1e-3, np.zeros((X.shape[1], 225)))
+        IALS_MI355X_Epoch(O.oracle_ials_confidence(X), 256, 1e-3, np.zeros((X.shape[1], 256)))
 
 
 def test_recommender_surface(gpu):

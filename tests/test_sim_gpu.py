@@ -820,3 +820,23 @@ def test_closing_a_handle_does_not_wait_for_another_handles_kernels(gpu):
     assert len(spans) >= 3, (len(spans), total)
     # with the device-wide wait every close() lasted until the IALS call ended: one or two handles per call
     assert np.median(spans) < 0.2 * total, (np.median(spans), total, len(spans))
+
+
+def test_packed_counts_kernel_equals_the_one_launch_build(gpu, monkeypatch):
+    """sim_packed_kernel (all-ones data: two 16-bit counts per LDS word, two workgroups per CU, the 32-bit kernel's launch behind it for
+    what it hands over) against the one-launch build, bit for bit -- on a URM whose most popular items have MORE than 65 535 users (their
+    columns are accumulated in parts and added up by the second launch), with split columns and light columns, three denominator forms."""
+    X = synthetic_urm(200000, 12000, 12000000, 5, 400, seed=7)
+    assert X[:, 0].nnz >= 65536 and X[:, 11999].nnz < 200
+    for kw in (dict(topK=50, shrink=0), dict(topK=100, shrink=5, similarity="jaccard"), dict(topK=120, shrink=0, similarity="asymmetric", asymmetric_alpha=0.3)):
+        out = {}
+        for packed in ("1", "0"):
+            monkeypatch.setenv("MI355REC_SIM_PACKED", packed)
+            dev = Compute_Similarity_MI355X(X, **kw)
+            idx, val, _ = dev.compute_slabs()
+            out[packed] = (idx, val, dev.stats()["n_launches"])
+            dev.close()
+        assert out["1"][2] == 2 and out["0"][2] == 1, (out["1"][2], out["0"][2])
+        np.testing.assert_array_equal(out["1"][0], out["0"][0])
+        np.testing.assert_array_equal(out["1"][1], out["0"][1])
+    monkeypatch.delenv("MI355REC_SIM_PACKED")
