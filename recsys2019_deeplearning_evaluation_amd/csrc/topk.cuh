@@ -193,26 +193,31 @@ __device__ void block_rank_emit(uint64_t *cand, int ncand, int topK, uint32_t K,
 // all zero on entry and on exit).  Keys of one column's maxima share sign and most exponent bits, so the first pass would send
 // nearly every lane of a wavefront to the same bin: the lanes of up to three distinct digits are counted with one atomic per
 // digit (ballot), whoever is left adds for itself.
-template <int THREADS>
-__device__ uint32_t block_kth_largest_prefix16(uint32_t key, uint32_t K, uint32_t *hist, SelectScratch &sc) {
+// KEYS = 2: every thread holds two keys (the K-th largest of the 2 x THREADS keys is looked for).
+template <int THREADS, int KEYS = 1>
+__device__ uint32_t block_kth_largest_prefix16(uint32_t key, uint32_t K, uint32_t *hist, SelectScratch &sc, uint32_t key_b = 0u) {
     static_assert(THREADS >= 256, "the bins are scanned by the first 256 threads");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t prefix = 0, want = K;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int shift = 24 - 8 * pass;
-        bool pending = pass == 0 || (key >> 24) == prefix;
-        const uint32_t digit = (key >> shift) & 255u;
-        for (int it = 0; it < 3; ++it) {
-            const unsigned long long todo = __ballot(pending);
-            if (!todo) break;
-            const int first = __ffsll((long long)todo) - 1;
-            const uint32_t d = (uint32_t)__shfl((int)digit, first);
-            const unsigned long long same = __ballot(pending && digit == d);
-            if (lane == first) atomicAdd(&hist[d], (uint32_t)__popcll(same));
-            pending = pending && digit != d;
+#pragma unroll
+        for (int which = 0; which < KEYS; ++which) {
+            const uint32_t k = which ? key_b : key;
+            bool pending = pass == 0 || (k >> 24) == prefix;
+            const uint32_t digit = (k >> shift) & 255u;
+            for (int it = 0; it < 3; ++it) {
+                const unsigned long long todo = __ballot(pending);
+                if (!todo) break;
+                const int first = __ffsll((long long)todo) - 1;
+                const uint32_t d = (uint32_t)__shfl((int)digit, first);
+                const unsigned long long same = __ballot(pending && digit == d);
+                if (lane == first) atomicAdd(&hist[d], (uint32_t)__popcll(same));
+                pending = pending && digit != d;
+            }
+            if (pending) atomicAdd(&hist[digit], 1u);
         }
-        if (pending) atomicAdd(&hist[digit], 1u);
         __syncthreads();
         uint32_t cnt = 0, suffix = 0;
         if (tid < 256) {

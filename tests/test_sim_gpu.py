@@ -827,8 +827,10 @@ def test_packed_counts_kernel_equals_the_one_launch_build(gpu, monkeypatch):
     what it hands over) against the one-launch build, bit for bit -- on a URM whose most popular items have MORE than 65 535 users (their
     columns are accumulated in parts and added up by the second launch), with split columns and light columns, three denominator forms."""
     X = synthetic_urm(200000, 12000, 12000000, 5, 400, seed=7)
-    assert X[:, 0].nnz >= 65536 and X[:, 11999].nnz < 200
-    for kw in (dict(topK=50, shrink=0), dict(topK=100, shrink=5, similarity="jaccard"), dict(topK=120, shrink=0, similarity="asymmetric", asymmetric_alpha=0.3)):
+    assert X[:, 0].nnz >= 65536 and X[:, 11999].nnz < 2000
+    for kw in (dict(topK=50, shrink=0), dict(topK=100, shrink=5, similarity="jaccard"), dict(topK=120, shrink=0, similarity="asymmetric", asymmetric_alpha=0.3),
+               dict(topK=1, shrink=2, similarity="dice"), dict(topK=128, shrink=0, similarity="tversky", tversky_alpha=0.7, tversky_beta=1.3),
+               dict(topK=10, shrink=3, normalize=False), dict(topK=64, shrink=0, normalize=False)):
         out = {}
         for packed in ("1", "0"):
             monkeypatch.setenv("MI355REC_SIM_PACKED", packed)
