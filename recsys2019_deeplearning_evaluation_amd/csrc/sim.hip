@@ -2488,6 +2488,20 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         if (row_weights) h->row_w.upload(row_weights, n_rows, s);
         phase(resident ? "allocate + copy of the resident URM" : "allocate + upload (PCIe)");
         const int eb = 256, eg = std::min<size_t>((nnz + eb - 1) / eb, 4096);
+        // One pass over the values as they came in: the reference's dispatcher asserts that they are finite (Compute_Similarity.py:34-36,
+        // np.isfinite over the whole array: 9 of the 18 ms of an ItemKNN fit at ML-20M shape when the front-end did it on the host) -- the
+        // largest |value|'s bits say so here -- and, where nothing re-writes the values before the build, the same pass answers "all
+        // ones?" and "which 2^s grid?" below.
+        unsigned info0[3] = {0xFu, 0u, 1u};
+        {
+            DeviceBuffer<unsigned> scan;
+            scan.alloc_zero(3, s);
+            hipLaunchKernelGGL(value_scan_kernel, dim3(eg), dim3(eb), 0, s, h->csr_val.ptr, nnz, scan.ptr);
+            MI_HIP(hipGetLastError());
+            scan.download(info0, 3, s);
+            MI_HIP(hipStreamSynchronize(s));
+            if (info0[1] >= 0x7F800000u) fail(MI355REC_E_INVALID, "Compute_Similarity: Data matrix contains non finite values");
+        }
 
         // optional pre-pass: BM25 / TF-IDF on the stored values (what the KNN recommenders do to the matrix before the build)
         if (cfg->feature_weighting != MI355REC_WEIGHT_NONE) {
@@ -2523,13 +2537,17 @@ static int sim_create_from(mi355rec_sim_t *out, const mi355rec_sim_config *cfg, 
         // 2048 and n_rows products of that size cannot overflow an int32, the column sums are exact integers (ACC_INT32).  Not for
         // mean-centred data (adjusted / pearson centre the values later) nor with row weights.  One pass answers both questions.
         if (!set_based && cfg->similarity != MI355REC_SIM_ADJUSTED && cfg->similarity != MI355REC_SIM_PEARSON) {
-            DeviceBuffer<unsigned> scan;          // [0] bit s set: some value times 2^s is not an integer; [1] bits of max |value|; [2] not all ones
-            scan.alloc_zero(3, s);
-            hipLaunchKernelGGL(value_scan_kernel, dim3(eg), dim3(eb), 0, s, h->csr_val.ptr, nnz, scan.ptr);
-            MI_HIP(hipGetLastError());
-            unsigned info[3] = {0xFu, 0u, 1u};
-            scan.download(info, 3, s);
-            MI_HIP(hipStreamSynchronize(s));
+            // [0] bit s set: some value times 2^s is not an integer; [1] bits of max |value|; [2] not all ones
+            unsigned info[3] = {info0[0], info0[1], info0[2]};
+            if (cfg->feature_weighting != MI355REC_WEIGHT_NONE) {          // (the weighting has re-written the values: look again)
+                DeviceBuffer<unsigned> scan;
+                scan.alloc_zero(3, s);
+                hipLaunchKernelGGL(value_scan_kernel, dim3(eg), dim3(eb), 0, s, h->csr_val.ptr, nnz, scan.ptr);
+                MI_HIP(hipGetLastError());
+                info[0] = 0xFu; info[1] = 0u; info[2] = 1u;
+                scan.download(info, 3, s);
+                MI_HIP(hipStreamSynchronize(s));
+            }
             h->unit_values = (info[2] == 0);
             if (!h->unit_values && !row_weights && !getenv("MI355REC_SIM_F64_SUMS") && !getenv("MI355REC_SIM_NO_INT32")) {
                 float vmax_f;

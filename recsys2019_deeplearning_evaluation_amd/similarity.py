@@ -235,9 +235,14 @@ class Compute_Similarity:
     the reference (:59-62); "python" raises NotImplementedError instead of silently running on the CPU."""
 
     def __init__(self, dataMatrix, use_implementation="density", similarity=None, **args):
-        assert np.all(np.isfinite(dataMatrix.data)), \
-            "Compute_Similarity: Data matrix contains {} non finite values".format(
-                np.sum(np.logical_not(np.isfinite(dataMatrix.data))))
+        # (the reference asserts np.isfinite over the whole data array here, Compute_Similarity.py:34-36: two host passes over 80 MB at
+        # ML-20M shape, half of an ItemKNN fit on this path.  The library's constructor finds non-finite values in the pass over the
+        # uploaded values it makes anyway and refuses; the count for the reference's message is then taken on the host.)
+        def non_finite():
+            return AssertionError("Compute_Similarity: Data matrix contains {} non finite values".format(
+                np.sum(np.logical_not(np.isfinite(dataMatrix.data)))))
+        if similarity == "euclidean" and not np.all(np.isfinite(dataMatrix.data)):        # (that front-end squares the values first)
+            raise non_finite()
         assert similarity == "euclidean" or not (dataMatrix.shape[0] == 1 and dataMatrix.nnz == dataMatrix.shape[1]), \
             "Compute_Similarity: data has only 1 feature (shape: {}) with dense values," \
             " vector and set based similarities are not defined on 1-dimensional dense data," \
@@ -255,7 +260,12 @@ class Compute_Similarity:
             args.pop("resident", None)              # (the Euclidean front-end uploads its own, squared, copy)
             self.compute_similarity_object = Compute_Similarity_Euclidean_MI355X(dataMatrix, **args)
         else:
-            self.compute_similarity_object = Compute_Similarity_MI355X(dataMatrix, **args)
+            try:
+                self.compute_similarity_object = Compute_Similarity_MI355X(dataMatrix, **args)
+            except ValueError as exc:
+                if "non finite" in str(exc):
+                    raise non_finite() from None
+                raise
 
     def compute_similarity(self, **args):
         return self.compute_similarity_object.compute_similarity(**args)

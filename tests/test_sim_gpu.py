@@ -842,3 +842,17 @@ def test_packed_counts_kernel_equals_the_one_launch_build(gpu, monkeypatch):
         np.testing.assert_array_equal(out["1"][0], out["0"][0])
         np.testing.assert_array_equal(out["1"][1], out["0"][1])
     monkeypatch.delenv("MI355REC_SIM_PACKED")
+
+
+def test_non_finite_values_are_refused_like_the_reference_dispatcher(gpu):
+    """Compute_Similarity.py:34-36 asserts np.isfinite over the data array; here the library's constructor finds non-finite values in its
+    own pass over the uploaded values (the host no longer scans 80 MB twice per fit) and the dispatcher raises the reference's message."""
+    X = named_urm("ml1m", "real", scale=0.2)
+    for bad in (np.nan, np.inf, -np.inf):
+        Y = X.copy()
+        Y.data[[3, 77]] = bad
+        with pytest.raises(AssertionError, match="Data matrix contains 2 non finite values"):
+            Compute_Similarity(Y, topK=5, shrink=0)
+        with pytest.raises(ValueError, match="non finite"):
+            Compute_Similarity_MI355X(Y, topK=5, shrink=0, similarity="jaccard")
+    Compute_Similarity(X, topK=5, shrink=0).compute_similarity()
