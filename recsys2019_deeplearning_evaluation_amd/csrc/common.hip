@@ -139,12 +139,17 @@ void device_block_return(void *p, size_t) {
         std::lock_guard<std::mutex> g(c.lock);
         c.free_blocks.emplace(bytes, p);
         c.cached += bytes;
-        while (c.cached > c.limit && !c.free_blocks.empty()) {       // largest first
-            auto last = std::prev(c.free_blocks.end());
-            drop.push_back(last->second);
-            c.cached -= last->first;
-            c.free_blocks.erase(last);
-        }
+        // Over the limit: give back down to HALF of it, largest first.  (Stopping at the limit left a cache that a search had once filled
+        // -- 32 MF models: 8 GiB of factor and schedule buffers -- sitting exactly there: every block returned afterwards pushed another
+        // one out, and a hipFree waits for the device.  The similarity constructor's twenty temporaries cost 5 ms more in such a
+        // process: ItemKNN fit 14 ms at the end of bench.py against 8.8 ms in a fresh one.)
+        if (c.cached > c.limit)
+            while (c.cached > c.limit / 2 && !c.free_blocks.empty()) {
+                auto last = std::prev(c.free_blocks.end());
+                drop.push_back(last->second);
+                c.cached -= last->first;
+                c.free_blocks.erase(last);
+            }
     }
     for (void *q : drop) (void)hipFree(q);
 }

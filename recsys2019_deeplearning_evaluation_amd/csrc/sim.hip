@@ -392,13 +392,14 @@ __global__ __launch_bounds__(THREADS, 4) void sim_column_kernel(const SimParams 
         const float4 *val4 = reinterpret_cast<const float4 *>(p.seg_val);
         const uint4 *val8 = reinterpret_cast<const uint4 *>(p.seg_val16);
         int4 *tab = reinterpret_cast<int4 *>(aux) + wave * 64;       // [64] x {rs, re, weight, -}: one 16-byte read per entry
-        // All-ones data, one tile (the headline instance): the same walk with the bookkeeping pared down -- measured in round 6, the
-        // loop is bound by instruction ISSUE (61 instructions per 8 atomics: with one atomic per chunk instead of eight the phase
-        // still took 75 % of its time; deeper prefetch made it slower; where the stream comes from makes no difference), not by
-        // the LDS unit.  The table holds {first, end} pairs (128 per wavefront, the upper half stays {0, 0}: a group that has run
-        // out of entries reads an empty slice and stays where it is); per step a group checks whether its slice is used up, READS ITS
-        // NEXT TABLE ENTRY UNCONDITIONALLY (no branch) and applies it after the eight atomics of the oldest chunk have been issued
-        // -- the read is older than they are, so the wait for it does not drain them --, then fetches: ~33 instructions per step.
+        // All-ones data, one tile (the headline instance): the same walk with the bookkeeping pared down.  The table holds {first, end}
+        // pairs (128 per wavefront, the upper half stays {0, 0}: a group that has run out of entries reads an empty slice and stays where
+        // it is); per step a group checks whether its slice is used up, READS ITS NEXT TABLE ENTRY UNCONDITIONALLY (no branch, no nested
+        // loop, no count of pending chunks) and applies it after the eight atomics of the oldest chunk, then fetches: 36 instructions
+        // per step where the general loop below has 61.  Measured in round 6: the phase takes the same time either way (524 against
+        // 518 workgroup-ms at ML-20M shape) -- like prefetch depth, the stream's origin and the atomics' count, the instruction count
+        // is not what it waits for; kept because sim_packed_kernel shares the loop and it is the
+        // simpler code.
         const bool lean = UNIT && p.n_tiles == 1;
         int2 *tab2 = reinterpret_cast<int2 *>(aux) + wave * 128;
         if (lean) tab2[64 + lane] = make_int2(0, 0);

@@ -234,3 +234,23 @@ def test_resident_urm_fingerprint_tells_matrices_apart():
     Z = X.copy(); Z.indices[0], Z.indices[1] = Z.indices[1], Z.indices[0]
     assert ResidentURM.fingerprint_of(Z) != f
     assert ResidentURM.fingerprint_of(X[:-1]) != f
+
+
+def test_ials_row_ranges_price_a_row_at_its_solve_as_well_as_its_profile():
+    """sharding.ials_row_ranges: cost(row) = (L + 0.9 k) k^2 (fitted to measured ranges, profiles/r6_ials_ranges.txt).  The ranges
+    cover every row once, and on a popularity-skewed matrix the tail range (many short rows) carries FEWER stored values than the
+    head range (few long rows) by about the rows' solve cost -- with the flop-count model (k / 3 entries per row) it carried as
+    many and ran 36 % longer."""
+    import scipy.sparse as sps
+    from recsys2019_deeplearning_evaluation_amd.sharding import ials_row_ranges, IALS_ROW_ENTRIES_PER_FACTOR
+    from recsys2019_deeplearning_evaluation_amd.synthetic import synthetic_urm
+    X = synthetic_urm(3000, 2000, 90000, 2, 400, seed=11)
+    k, world = 40, 4
+    ur, ir = ials_row_ranges(X, world, k)
+    for ranges, n in ((ur, X.shape[0]), (ir, X.shape[1])):
+        assert ranges[0][0] == 0 and ranges[-1][1] == n and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    li = np.diff(sps.csc_matrix(X).indptr).astype(np.float64)
+    cost = [(li[s:e].sum() + IALS_ROW_ENTRIES_PER_FACTOR * k * (e - s)) for s, e in ir]
+    assert max(cost) / min(cost) < 1.15, cost
+    nnz = [li[s:e].sum() for s, e in ir]
+    assert nnz[-1] < nnz[0]                      # the tail range holds more rows and therefore fewer values
