@@ -57,13 +57,36 @@ def similarityMatrixTopK(item_weights, k=100, verbose=False):
         keep = vals != 0
         cols = np.broadcast_to(np.arange(n)[None, :], top.shape)
         return sps.csc_matrix((vals[keep], (top[keep], cols[keep])), shape=(n, n), dtype=np.float32)
-    W = check_matrix(item_weights, "csc", dtype=np.float32).copy()
+    W = check_matrix(item_weights, "csc", dtype=np.float32)
+    if W is item_weights:                      # (a conversion has made a new matrix already: zeros are eliminated in place below)
+        W = W.copy()
     W.eliminate_zeros()
     counts = np.diff(W.indptr)
     keep = np.ones(W.nnz, dtype=bool)
-    for c in np.flatnonzero(counts > k):
-        a, b = W.indptr[c], W.indptr[c + 1]
-        keep[a + np.argsort(W.data[a:b], kind="stable")[:b - a - k]] = False
+    # Over-full columns, ranked together: a stable ascending sort of a column drops its first len - k entries -- i.e. keeps every
+    # entry above the k-th largest value T and, of the entries equal to T, the LAST ones (highest rows).  One argsort call per column
+    # was 9 000 calls and 0.09 s at ML-20M size (every validation of a SLIM fit pays it); here the columns are padded into a few
+    # 2-D blocks by length (powers of two: at most twice the entries), T comes from one argpartition per block and the tie rule
+    # from a reversed cumulative count.
+    full = np.flatnonzero(counts > k)
+    if len(full):
+        lengths = counts[full]
+        bucket = np.ceil(np.log2(lengths)).astype(np.int64)
+        for b in np.unique(bucket):
+            cols = full[bucket == b]
+            width = int(counts[cols].max())
+            starts, lens = W.indptr[cols].astype(np.int64), counts[cols].astype(np.int64)
+            pos = starts[:, None] + np.arange(width, dtype=np.int64)[None, :]
+            real = np.arange(width)[None, :] < lens[:, None]
+            vals = np.where(real, W.data[np.minimum(pos, W.nnz - 1)], -np.inf)
+            kth = -np.partition(-vals, k - 1, axis=1)[:, k - 1]                      # the k-th largest value of every column
+            above = vals > kth[:, None]
+            tied = real & (vals == kth[:, None])
+            wanted = k - above.sum(axis=1)                                            # how many of the tied entries belong to the top k
+            from_end = np.cumsum(tied[:, ::-1], axis=1)[:, ::-1]                      # (a tied entry's rank among the tied ones, counted from the end)
+            kept = above | (tied & (from_end <= wanted[:, None]))
+            drop = real & ~kept
+            keep[pos[drop]] = False
     indptr = np.concatenate([[0], np.cumsum(np.minimum(counts, k))])
     return sps.csc_matrix((W.data[keep], W.indices[keep], indptr), shape=(n, n), dtype=np.float32)
 
