@@ -732,6 +732,38 @@ def fit_rows(urm, out):
         "definition": "MatrixFactorization_BPR_MI355X(train).fit(epochs=50, batch 1000, k=128, validation_every_n=5, MAP@10 on a leave-one-out "
                       "split, every test user) wall / 50: constructor, one blocking epoch call per epoch, factor download + device-scored "
                       "recommend() blocks per validation"}
+
+    # SLIM-BPR (BASELINE config 3) through its recommender: per validation the fit loop asks for get_S() AND W_sparse =
+    # similarityMatrixTopK(get_S(), topK) (SLIM_BPR_Cython.py:186-197) -- both selections run on the device (mi355rec_slim_get_W_csr)
+    from recsys2019_deeplearning_evaluation_amd import SLIM_BPR_MI355X
+    ev2 = HoldoutEvaluator(test, cutoff=10)
+
+    class TimedSlim(SLIM_BPR_MI355X):
+        t_epoch = t_prepare = 0.0
+
+        def _run_epoch(self, num_epoch):
+            t0 = time.perf_counter()
+            super()._run_epoch(num_epoch)
+            TimedSlim.t_epoch += time.perf_counter() - t0
+
+        def _prepare_model_for_validation(self):
+            t0 = time.perf_counter()
+            super()._prepare_model_for_validation()
+            TimedSlim.t_prepare += time.perf_counter() - t0
+
+    epochs, every = 30, 10
+    sl = TimedSlim(train, verbose=False)
+    t0 = time.perf_counter()
+    sl.fit(epochs=epochs, symmetric=False, topK=TOPK, sgd_mode="adagrad", learning_rate=1e-4, random_seed=42,
+           validation_every_n=every, stop_on_validation=False, validation_metric="MAP", evaluator_object=ev2)
+    wall = time.perf_counter() - t0
+    out["slim_bpr_recommender_fit_30_epochs_validation_every_10"] = {
+        "value": wall / epochs, "unit": "s/epoch", "fit_wall_s": wall, "epochs": epochs, "validations": ev2.calls,
+        "train_s": TimedSlim.t_epoch, "get_S_and_W_s": TimedSlim.t_prepare, "evaluate_s": ev2.seconds,
+        "train_samples_per_s": epochs * (train.shape[0] + 1) / max(TimedSlim.t_epoch, 1e-9), "W_sparse_nnz": int(sl.W_sparse.nnz),
+        "definition": "SLIM_BPR_MI355X(train).fit(epochs=30, dense store, topK=100, adagrad, validation_every_n=10, MAP@10 on the same split) "
+                      "wall / 30: constructor, one blocking epoch call per epoch, per validation get_S + the column top-K of W_sparse (device) "
+                      "+ the evaluator's recommend() blocks on the sparse device scorer"}
     return out
 
 

@@ -335,6 +335,13 @@ int mi355rec_slim_get_last_samples(mi355rec_slim_t h, int32_t *u, int32_t *i, in
 /* get_S: diagonal zeroed, per-ROW top-K (.pyx:343-391): nbr_idx/nbr_val[(row) * topK ...], descending,
  * (-1, 0) padded, zeros never emitted. */
 int mi355rec_slim_get_S_topk(mi355rec_slim_t h, int32_t topK, int32_t *nbr_idx, float *nbr_val);
+/* W_sparse = similarityMatrixTopK(get_S(), k = topK) (SLIM_BPR_Cython.py:186-197 at every validation; Base/Recommender_utils.py:55-122): of
+ * the per-row selection above, every COLUMN keeps its topK largest non-zero cells (of equal values the highest rows, as the reference's
+ * stable ascending sort leaves them), returned as canonical CSR (indptr [n_items + 1], indices / data with room for n_items * topK
+ * entries, *nnz = how many were written).  nbr_idx / nbr_val (optional, may be NULL): the row slabs of mi355rec_slim_get_S_topk from
+ * the same pass.  n_items <= 65 535. */
+int mi355rec_slim_get_W_csr(mi355rec_slim_t h, int32_t topK, int32_t *nbr_idx, float *nbr_val, int32_t *indptr, int32_t *indices,
+                            float *data, int64_t *nnz);
 /* get_S of the sparse store with topK > 0 (.pyx:343-352, 381-382): the diagonal becomes a node holding zero, every row keeps
  * its TopK largest nodes (the model changes, as in the reference), and the surviving NON-ZERO nodes of row r are listed in
  * column order in nbr_idx/nbr_val[r * topK ...], (-1, 0) padded (from_linked_list_to_python_list :862-875). */

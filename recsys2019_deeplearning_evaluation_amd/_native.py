@@ -119,6 +119,7 @@ SIGNATURES = {
     "mi355rec_slim_run_samples": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
     "mi355rec_slim_get_last_samples": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     "mi355rec_slim_get_S_topk": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "mi355rec_slim_get_W_csr": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int64)]),
     "mi355rec_slim_get_S_sparse": (C.c_int, [_vp, _vp, _vp]),
     "mi355rec_slim_get_S_dense": (C.c_int, [_vp, _vp]),
     "mi355rec_slim_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),

@@ -2109,14 +2109,122 @@ void run_epochs_typed(mi355rec_slim *h, int n_epochs) {
     end_call(h, (long long)n * n_epochs, sum_profile);
 }
 
+// W = similarityMatrixTopK(get_S(), k) on the device (Base/Recommender_utils.py:55-122 applied to the per-row selection of .pyx:343-391;
+// SLIM_BPR_Cython.py:186-197 does this at every validation, and on the host the column step alone -- 9 000 over-full columns ranked one
+// by one -- was 0.09 s at ML-20M size against 2 ms for the epoch it follows).  From the (row, K) slabs: one radix sort of the non-zero
+// entries by (column, value descending, row descending) ranks every column -- the host function's stable ascending sort drops the first
+// len - k entries of a column, i.e. of equal values it keeps the HIGHEST rows --, entries ranked below k are dropped, a second sort by
+// (row, column) puts the survivors into canonical CSR order.  Items are 16-bit here (n_items <= 65 535), like everywhere on this path.
+__global__ void slim_w_rank_keys_kernel(const int *idx, const float *val, size_t n_slots, int topK, unsigned long long *key, int *slot) {
+    const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (q >= n_slots) return;
+    const int col = idx[q];
+    const float v = val[q];
+    slot[q] = (int)q;
+    if (col < 0 || v == 0.f) {
+        key[q] = ~0ull;                                   // (padding and zeros sort behind every column)
+        return;
+    }
+    const unsigned row = (unsigned)(q / (size_t)topK);
+    key[q] = ((unsigned long long)(unsigned)col << 48) | ((unsigned long long)(~float_key(v)) << 16) | (unsigned long long)(0xFFFFu - row);
+}
+// position of every column's first entry in the ranked order (binary search on the column field; n_items + 1 entries, the last = the
+// number of real entries)
+__global__ void slim_w_col_start_kernel(const unsigned long long *ranked, size_t n_slots, int n_items, int *start) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_items) return;
+    size_t lo = 0, hi = n_slots;
+    while (lo < hi) {
+        const size_t mid = (lo + hi) >> 1;
+        const unsigned long long k = ranked[mid];
+        const bool before = k != ~0ull && (int)(k >> 48) < c;
+        if (before) lo = mid + 1; else hi = mid;
+    }
+    start[c] = (int)lo;
+}
+// the survivors' (row, column) keys and values, in ranked order; everything else sorts behind them
+__global__ void slim_w_keep_kernel(const unsigned long long *ranked, const int *slot, const int *col_start, const float *val, size_t n_slots, int topK,
+                                   int k_cols, unsigned *key2, float *val2) {
+    const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (q >= n_slots) return;
+    const unsigned long long k = ranked[q];
+    key2[q] = ~0u;
+    val2[q] = 0.f;
+    if (k == ~0ull) return;
+    const int col = (int)(k >> 48);
+    if ((int)q - col_start[col] >= k_cols) return;
+    const int s = slot[q];
+    key2[q] = ((unsigned)(s / topK) << 16) | (unsigned)col;
+    val2[q] = val[s];
+}
+__global__ void slim_w_csr_kernel(const unsigned *key2, size_t n_slots, int n_items, int *indptr, int *indices) {
+    const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (q < n_slots && key2[q] != ~0u) indices[q] = (int)(key2[q] & 0xFFFFu);
+    if (q <= (size_t)n_items) {                          // first entry whose row is >= q
+        size_t lo = 0, hi = n_slots;
+        while (lo < hi) {
+            const size_t mid = (lo + hi) >> 1;
+            const bool before = key2[mid] != ~0u && (key2[mid] >> 16) < (unsigned)q;
+            if (before) lo = mid + 1; else hi = mid;
+        }
+        indptr[q] = (int)lo;
+    }
+}
+
 template <class T>
-void get_topk_typed(mi355rec_slim *h, int topK, int *nbr_idx, float *nbr_val) {
+void topk_slabs_on_device(mi355rec_slim *h, int topK, DeviceBuffer<int> &d_idx, DeviceBuffer<float> &d_val);
+
+template <class T>
+void get_w_csr_typed(mi355rec_slim *h, int topK, int *nbr_idx, float *nbr_val, int *indptr, int *indices, float *data, long long *nnz) {
+    MI_REQUIRE(h->n_items <= 65535, "n_items = %d: the device-side column selection packs items into 16 bits", h->n_items);
+    hipStream_t s = h->stream;
+    DeviceBuffer<int> d_idx, slot, slot_sorted, col_start, d_indptr, d_indices;
+    DeviceBuffer<float> d_val, val2, val2_sorted;
+    DeviceBuffer<unsigned long long> key, key_sorted;
+    DeviceBuffer<unsigned> key2, key2_sorted;
+    DeviceBuffer<unsigned char> tmp;
+    topk_slabs_on_device<T>(h, topK, d_idx, d_val);
+    const size_t n_slots = (size_t)h->n_items * topK;
+    MI_REQUIRE(n_slots < (size_t)INT32_MAX, "too many slab entries");
+    key.alloc(n_slots); key_sorted.alloc(n_slots); slot.alloc(n_slots); slot_sorted.alloc(n_slots);
+    const unsigned grid = (unsigned)((n_slots + 255) / 256);
+    hipLaunchKernelGGL(slim_w_rank_keys_kernel, dim3(grid), dim3(256), 0, s, d_idx.ptr, d_val.ptr, n_slots, topK, key.ptr, slot.ptr);
+    size_t bytes = 0;
+    MI_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key.ptr, key_sorted.ptr, slot.ptr, slot_sorted.ptr, n_slots, 0, 64, s));
+    tmp.alloc(bytes + 16);
+    MI_HIP(rocprim::radix_sort_pairs(tmp.ptr, bytes, key.ptr, key_sorted.ptr, slot.ptr, slot_sorted.ptr, n_slots, 0, 64, s));
+    col_start.alloc((size_t)h->n_items + 1);
+    hipLaunchKernelGGL(slim_w_col_start_kernel, dim3((unsigned)((h->n_items + 256) / 256)), dim3(256), 0, s, key_sorted.ptr, n_slots, h->n_items, col_start.ptr);
+    key2.alloc(n_slots); key2_sorted.alloc(n_slots); val2.alloc(n_slots); val2_sorted.alloc(n_slots);
+    hipLaunchKernelGGL(slim_w_keep_kernel, dim3(grid), dim3(256), 0, s, key_sorted.ptr, slot_sorted.ptr, col_start.ptr, d_val.ptr, n_slots, topK, topK,
+                       key2.ptr, val2.ptr);
+    size_t bytes2 = 0;
+    MI_HIP(rocprim::radix_sort_pairs(nullptr, bytes2, key2.ptr, key2_sorted.ptr, val2.ptr, val2_sorted.ptr, n_slots, 0, 32, s));
+    if (bytes2 + 16 > tmp.count) tmp.alloc(bytes2 + 16);
+    MI_HIP(rocprim::radix_sort_pairs(tmp.ptr, bytes2, key2.ptr, key2_sorted.ptr, val2.ptr, val2_sorted.ptr, n_slots, 0, 32, s));
+    d_indptr.alloc((size_t)h->n_items + 1); d_indices.alloc(n_slots);
+    hipLaunchKernelGGL(slim_w_csr_kernel, dim3(std::max(grid, (unsigned)((h->n_items + 256) / 256))), dim3(256), 0, s, key2_sorted.ptr, n_slots, h->n_items,
+                       d_indptr.ptr, d_indices.ptr);
+    MI_HIP(hipGetLastError());
+    d_indptr.download(indptr, (size_t)h->n_items + 1, s);
+    MI_HIP(hipStreamSynchronize(s));
+    const size_t n_kept = (size_t)indptr[h->n_items];
+    *nnz = (long long)n_kept;
+    if (n_kept) {
+        d_indices.download(indices, n_kept, s);
+        val2_sorted.download(data, n_kept, s);
+    }
+    if (nbr_idx) d_idx.download(nbr_idx, n_slots, s);
+    if (nbr_val) d_val.download(nbr_val, n_slots, s);
+    MI_HIP(hipStreamSynchronize(s));
+}
+
+template <class T>
+void topk_slabs_on_device(mi355rec_slim *h, int topK, DeviceBuffer<int> &d_idx, DeviceBuffer<float> &d_val) {
     const int n_pad = (h->n_items + 3) & ~3;
     const size_t lds = (size_t)n_pad * 4 + (size_t)AUX_WORDS * 4;
     if (lds + 2048 > 160 * 1024)
         fail(MI355REC_E_UNSUPPORTED, "n_items = %d: a row of S does not fit the 160 KiB LDS for the top-K selection", h->n_items);
-    DeviceBuffer<int> d_idx;
-    DeviceBuffer<float> d_val;
     const size_t n_out = (size_t)h->n_items * topK;
     d_idx.alloc(n_out);
     d_val.alloc(n_out);
@@ -2128,6 +2236,14 @@ void get_topk_typed(mi355rec_slim *h, int topK, int *nbr_idx, float *nbr_val) {
     hipLaunchKernelGGL(k, dim3(std::min(h->n_items, multiprocessor_count() * per_cu)), dim3(1024), lds, h->stream, p, topK,
                        n_pad, d_idx.ptr, d_val.ptr);
     MI_HIP(hipGetLastError());
+}
+
+template <class T>
+void get_topk_typed(mi355rec_slim *h, int topK, int *nbr_idx, float *nbr_val) {
+    DeviceBuffer<int> d_idx;
+    DeviceBuffer<float> d_val;
+    topk_slabs_on_device<T>(h, topK, d_idx, d_val);
+    const size_t n_out = (size_t)h->n_items * topK;
     d_idx.download(nbr_idx, n_out, h->stream);
     d_val.download(nbr_val, n_out, h->stream);
     MI_HIP(hipStreamSynchronize(h->stream));
@@ -2267,6 +2383,22 @@ extern "C" int mi355rec_slim_get_S_topk(mi355rec_slim_t h, int32_t topK, int32_t
         topK = std::min(topK, h->n_items);
         if (topK > MAX_TOPK) fail(MI355REC_E_UNSUPPORTED, "topK = %d exceeds the in-LDS selection limit of %d", topK, MAX_TOPK);
         if (h->f64) get_topk_typed<double>(h, topK, nbr_idx, nbr_val); else get_topk_typed<float>(h, topK, nbr_idx, nbr_val);
+    });
+}
+
+extern "C" int mi355rec_slim_get_W_csr(mi355rec_slim_t h, int32_t topK, int32_t *nbr_idx, float *nbr_val, int32_t *indptr, int32_t *indices,
+                                       float *data, int64_t *nnz) {
+    return guarded([&] {
+        MI_REQUIRE(h && indptr && indices && data && nnz, "NULL argument");
+        MI_REQUIRE(topK >= 1, "topK must be >= 1");
+        ensure_device();
+        ReleaseScope scope(h->stream, h->side);
+        topK = std::min(topK, h->n_items);
+        if (topK > MAX_TOPK) fail(MI355REC_E_UNSUPPORTED, "topK = %d exceeds the in-LDS selection limit of %d", topK, MAX_TOPK);
+        long long n = 0;
+        if (h->f64) get_w_csr_typed<double>(h, topK, nbr_idx, nbr_val, indptr, indices, data, &n);
+        else get_w_csr_typed<float>(h, topK, nbr_idx, nbr_val, indptr, indices, data, &n);
+        *nnz = (int64_t)n;
     });
 }
 

@@ -11,6 +11,7 @@ SEMANTICS run on the same dense device array (cells know whether they "have a no
 As in the reference wrapper the epoch object is always driven with batch_size = 1 (SLIM_BPR_Cython.py:140).
 """
 import ctypes as C
+import os
 import sys
 
 import numpy as np
@@ -115,6 +116,24 @@ class SLIM_BPR_MI355X_Epoch:
         N.check(self._lib.mi355rec_slim_get_S_topk(self._h, k, N.ptr(idx), N.ptr(val)))
         return idx, val
 
+    def selects_rows(self):
+        """Does get_S() return the per-row top-K selection as a csr_matrix (rather than the dense array, the whole matrix or the
+        sparse store's own selection)?"""
+        return bool(self.topK) and not self.train_with_sparse_weights and (self.symmetric or self.final_model_sparse_weights)
+
+    def get_S_and_W(self):
+        """(get_S(), similarityMatrixTopK(get_S(), k=topK) as canonical csr float32) in ONE device pass (mi355rec_slim_get_W_csr): what
+        SLIM_BPR_Cython.py:186-197 computes at every validation.  Only where get_S() is the per-row selection (selects_rows())."""
+        assert self.selects_rows() and self.n_items <= 65535
+        k = min(int(self.topK), self.n_items)
+        idx = np.empty((self.n_items, k), np.int32); val = np.empty((self.n_items, k), np.float32)
+        indptr = np.empty(self.n_items + 1, np.int32); indices = np.empty(self.n_items * k, np.int32); data = np.empty(self.n_items * k, np.float32)
+        nnz = C.c_int64(0)
+        N.check(self._lib.mi355rec_slim_get_W_csr(self._h, k, N.ptr(idx), N.ptr(val), N.ptr(indptr), N.ptr(indices), N.ptr(data), C.byref(nnz)))
+        W = sps.csr_matrix((data[:nnz.value], indices[:nnz.value], indptr), shape=(self.n_items, self.n_items))
+        W.has_sorted_indices = True
+        return rows_slabs_to_csr(idx, val, self.n_items), W
+
     def get_S(self):
         """Same return convention as the reference (.pyx:343-391): csr with per-row top-K, or the dense array when
         final_model_sparse_weights is False on the dense store, or the full matrix as csr when topK is False."""
@@ -202,7 +221,13 @@ class _SLIMLogic:
         self.epoch_kernel.epochIteration_Cython()
 
     def get_S_incremental_and_set_W(self):
-        self.S_incremental = self.epoch_kernel.get_S()
+        kernel = self.epoch_kernel
+        if getattr(kernel, "selects_rows", None) and kernel.selects_rows() and kernel.n_items <= 65535 and \
+                os.environ.get("MI355REC_SLIM_HOST_TOPK") != "1":
+            # the column selection of .py:196 next to the row selection, on the device (0.09 s per validation on the host at ML-20M size)
+            self.S_incremental, self.W_sparse = kernel.get_S_and_W()
+            return
+        self.S_incremental = kernel.get_S()
         if self.train_with_sparse_weights or not self.topK:          # .py:193-195: the tree's get_S has selected already
             self.W_sparse = self.S_incremental
         else:

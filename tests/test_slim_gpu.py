@@ -510,3 +510,38 @@ def test_two_symmetric_handles_train_concurrently(gpu):
     assert not errors, errors
     for tag in range(2):
         assert_factor_parity(results[tag][0], results[tag][1], "adagrad", "S (thread %d)" % tag)
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_device_column_selection_equals_similarityMatrixTopK(gpu, symmetric):
+    """mi355rec_slim_get_W_csr: W_sparse = similarityMatrixTopK(get_S(), k) (SLIM_BPR_Cython.py:186-197) computed next to the row
+    selection on the device -- identical, cell for cell, to the host function on the same S: after ONE epoch (most touched cells hold one
+    of a few values: masses of ties at the k-th rank of the popular columns) and after several; small k so that most columns are over-full."""
+    from recsys2019_deeplearning_evaluation_amd.recommender_base import similarityMatrixTopK, check_matrix
+    X = named_urm("ml1m", "binary", scale=0.35)
+    for topK, sgd_mode, lr in ((5, "sgd", 0.05), (20, "adagrad", 0.05)):
+        dev = SLIM_BPR_MI355X_Epoch(X, symmetric=symmetric, topK=topK, final_model_sparse_weights=True, sgd_mode=sgd_mode, learning_rate=lr,
+                                    random_seed=13)
+        for epochs in (1, 3):
+            dev.epochIteration_Cython(epochs)
+            S, W = dev.get_S_and_W()
+            S_host = dev.get_S()
+            assert (S != S_host).nnz == 0
+            W_host = check_matrix(similarityMatrixTopK(S_host, k=topK), format="csr")
+            W_host.sort_indices()
+            assert W.dtype == np.float32 and W.has_canonical_format
+            assert np.array_equal(W.indptr, W_host.indptr) and np.array_equal(W.indices, W_host.indices) and np.array_equal(W.data, W_host.data)
+            assert (np.diff(W.tocsc().indptr) == topK).sum() > 10           # (over-full columns were cut)
+        dev.close()
+    # ... and through the recommender: the same W_sparse with the host function switched back on
+    import os
+    rec = SLIM_BPR_MI355X(X, verbose=False)
+    kw = dict(epochs=2, symmetric=symmetric, topK=10, sgd_mode="adagrad", learning_rate=0.05, random_seed=3)
+    rec.fit(**kw)
+    os.environ["MI355REC_SLIM_HOST_TOPK"] = "1"
+    try:
+        ref = SLIM_BPR_MI355X(X, verbose=False)
+        ref.fit(**kw)
+    finally:
+        del os.environ["MI355REC_SLIM_HOST_TOPK"]
+    assert (rec.W_sparse != ref.W_sparse).nnz == 0 and (rec.S_incremental != ref.S_incremental).nnz == 0
