@@ -1112,7 +1112,9 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
         create_resident_s = dt if create_resident_s is None else min(create_resident_s, dt)
     resident.close()
     costs = sim.column_costs()
-    job = ShardedSimilarityBuild(sim, net.dist, rank, world, net.comm)       # partition + buffers once, outside the timed region
+    # partition + buffers once, outside the timed region.  BENCH_SIM_EXCHANGE=gather: only rank 0 receives (north_star's wording; the default
+    # all-gather leaves the result on every rank, which is what this block's `definition` has said since round 1)
+    job = ShardedSimilarityBuild(sim, net.dist, rank, world, net.comm, exchange=os.environ.get("BENCH_SIM_EXCHANGE", "allgather"))
     my_columns = job.columns[rank]
     best, kernel_ms = None, None
     for rep in range(4):
@@ -1156,6 +1158,8 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
         "download_to_host_rank0_s": download_s,
         "topK": TOPK, "columns_this_rank": int(len(my_columns)), "kernel_ms_this_rank": kernel_ms,
         "exchange_bytes_per_rank": job.exchange_bytes_per_rank(),
+        "exchange": "none" if world == 1 else ("%s of %d cost-sized pieces, %s" % ("gather to rank 0" if job.root is not None else "all-gather", len(job.rows),
+                                                "6-byte cells (float32 value + 16-bit id)" if job.packed else "8-byte cells")),
         "transport": "none" if world == 1 else ("rccl-ctypes" if net.comm is not None else "torch." + net.dist.get_backend()),
         "nnz_out": int((idx >= 0).sum()) if idx is not None else None,
         "roofline": {"bound": "lds-atomics", "kernel": "sim_packed_kernel + sim_column_kernel (one timed region: the packed-counts launch and the 32-bit launch behind it)",
@@ -1178,10 +1182,21 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
         widest8 = -(-n_items // G)
         slab_words = 2 * widest8 * TOPK
         local8, gathered8 = DeviceArray(slab_words), DeviceArray(G * slab_words)
-        from recsys2019_deeplearning_evaluation_amd.sharding import chunk_bounds
+        from recsys2019_deeplearning_evaluation_amd.sharding import cost_sized_pieces, chunk_bounds, packed_words, piece_order, FIXED_PAIRS_PER_CELL
         per_part, per_piece = [], []
         t_copy = 0.0
-        pieces = chunk_bounds(widest8, 4)                # what ShardedSimilarityBuild does at world > 1: 4 pieces per part
+        # what ShardedSimilarityBuild does at world > 1: 4 pieces per part sized by cost (the cheap rows in equal-cost pieces first, the small
+        # head of the most expensive columns last: only the last piece's exchange is exposed), each packed into 6-byte cells (n_items <=
+        # 65 535) by a small kernel behind the piece's column kernel
+        cols0 = sim.part_columns(0, G)
+        row_cost = np.zeros(widest8)
+        row_cost[:len(cols0)] = np.asarray(costs, np.float64)[cols0] + FIXED_PAIRS_PER_CELL * n_items
+        pieces_in_row_order = cost_sized_pieces(row_cost, 4)
+        pieces = [pieces_in_row_order[c] for c in piece_order(pieces_in_row_order)]     # in BUILD order: cheapest rows first, the small head last
+        pieces_by_count = chunk_bounds(widest8, 4)
+        can_pack = n_items <= 65535
+        packed8 = DeviceArray(packed_words(widest8 * TOPK) + 4)
+        pack_ms = []
         for r in range(G):
             sim.compute_part_device(r, G, local8.address(), local8.address(widest8 * TOPK))
             sim.synchronize()
@@ -1196,17 +1211,25 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
                 if cnt:
                     sim.compute_part_chunk_device(r, G, r0, cnt, local8.address(2 * r0 * TOPK), local8.address(2 * r0 * TOPK + (r1 - r0) * TOPK))
                     sim.synchronize()
-                    row.append(sim.stats()["kernel_ms"])
+                    k_ms = sim.stats()["kernel_ms"]
+                    if can_pack:                          # (wall time of the pack launch, blocking: an upper bound of what it adds to a piece)
+                        t3 = time.perf_counter()
+                        sim.pack_slab_device(local8.address(2 * r0 * TOPK), local8.address(2 * r0 * TOPK + (r1 - r0) * TOPK), (r1 - r0) * TOPK, packed8.address())
+                        sim.synchronize()
+                        pack_ms.append((time.perf_counter() - t3) * 1e3)
+                        k_ms += pack_ms[-1]
+                    row.append(k_ms)
                 else:
                     row.append(0.0)
             per_piece.append(row)
-        slab = 4 * slab_words
+        cell_bytes = 6 if can_pack else 8
+        slab = cell_bytes * widest8 * TOPK
         ring_of = lambda nbytes: (G - 1) * nbytes / 50e9 * 1e3 + 0.05     # ONE ring over one xGMI link direction (~50 GB/s effective) + launch latency
         direct_of = lambda nbytes: nbytes / 50e9 * 1e3 + 0.05             # all 7 links at once (every peer is one hop away on the xGMI mesh)
         ring_ms, direct_ms = ring_of(slab), direct_of(slab)
 
         def overlapped(row, gather_of):
-            """kernel of piece c + 1 hides the all-gather of piece c; what sticks out is added (the last piece's gather always does)"""
+            """kernel of piece c + 1 hides the exchange of piece c; what sticks out is added (the last piece's exchange always does)"""
             t = 0.0
             for c, k_ms in enumerate(row):
                 g_prev = gather_of(slab * (pieces[c - 1][1] - pieces[c - 1][0]) / widest8) if c else 0.0
@@ -1217,17 +1240,26 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
             "partition": "interleaved (serpentine deal of the cost order): %d columns and 1/8 of the cost per part" % widest8,
             "kernel_ms_per_part": per_part, "slowest_part_ms": max(per_part),
             "kernel_speedup_vs_1gpu": kernel_ms / max(per_part),
-            "slab_MB_per_rank": slab / 1e6,
+            "cell_bytes": cell_bytes, "slab_MB_per_rank": slab / 1e6, "slab_MB_per_rank_8_byte_cells": 8 * widest8 * TOPK / 1e6,
             "slab_MB_per_rank_with_contiguous_ranges": 8 * max(b - a for a, b in ranges8) * TOPK / 1e6,
             "device_copy_of_8_slabs_ms": t_copy * 1e3,
+            "pieces_rows_in_build_order": [b - a for a, b in pieces], "pieces_first_row_in_build_order": [a for a, b in pieces],
+            "pieces_rows_by_count_until_round_5": [b - a for a, b in pieces_by_count],
+            "pack_kernel_wall_ms_per_piece": (sum(pack_ms) / len(pack_ms)) if pack_ms else None,
             "modelled_allgather_ms": {"one_ring_50GBps_per_link": ring_ms, "seven_links_at_once": direct_ms},
+            "modelled_gather_to_root_ms": direct_ms,
             "predicted_build_speedup_one_exchange_at_the_end": {"one_ring": (best * 1e3) / (max(per_part) + ring_ms),
                                                                 "seven_links": (best * 1e3) / (max(per_part) + direct_ms)},
             "kernel_ms_per_piece": per_piece,
             "predicted_build_speedup": {"one_ring": (best * 1e3) / max(overlapped(row, ring_of) for row in per_piece),
-                                        "seven_links": (best * 1e3) / max(overlapped(row, direct_of) for row in per_piece)},
-            "exchange": "4 pieces per part, the all-gather of a finished piece behind the kernel of the next one (ShardedSimilarityBuild)",
-            "note": "parts run one after the other on ONE GPU; the exchange is modelled from its size (7 x %.2f MB), unmeasured on hardware" % (slab / 1e6)}
+                                        "seven_links": (best * 1e3) / max(overlapped(row, direct_of) for row in per_piece),
+                                        "gather_to_root": (best * 1e3) / max(overlapped(row, direct_of) for row in per_piece)},
+            "exchange": "4 cost-sized pieces per part built cheapest rows first (kernel_ms_per_piece is in that order), %d-byte cells, the exchange of a finished piece behind the kernel of the next one "
+                        "(ShardedSimilarityBuild); all-gather = every rank ends with W (one ring, or all seven links at once); gather_to_root = only "
+                        "rank 0 does (exchange='gather': each peer sends over its own link, the model of 'seven_links')" % cell_bytes,
+            "note": "parts run one after the other on ONE GPU; the exchange is modelled from its size (7 x %.2f MB), unmeasured on hardware; kernel_ms_per_piece "
+                    "includes the blocking wall time of the piece's pack launch" % (slab / 1e6)}
+        packed8.close()
         local8.close(); gathered8.close()
     job.close()
     sim.close()

@@ -154,6 +154,12 @@ int mi355rec_sim_compute_part_device(mi355rec_sim_t h, int32_t part, int32_t n_p
  * in: a sharded build computes its part in chunks so that the all-gather of a finished chunk travels while the next one is built. */
 int mi355rec_sim_compute_part_chunk_device(mi355rec_sim_t h, int32_t part, int32_t n_parts, int32_t slot_first, int32_t slot_count,
                                            int32_t *d_nbr_idx, float *d_nbr_val);
+/* The exchange format of the sharded build when n_cols <= 65 535 (6 bytes per neighbour instead of 8): n_cells float32 values followed by
+ * n_cells 16-bit neighbour ids (0xFFFF = the -1 of an empty slot), padded to a multiple of 4 bytes -- n_cells + (n_cells + 1) / 2 words.
+ * pack: from the (idx, val) slabs a compute_*_device call filled; unpack: back into such slabs.  Asynchronous on the handle's stream.
+ * What travels is what Compute_Similarity_Cython.pyx:593-607 would assemble into W_sparse on one process. */
+int mi355rec_sim_pack_slab_device(mi355rec_sim_t h, const int32_t *d_nbr_idx, const float *d_nbr_val, int64_t n_cells, void *d_packed);
+int mi355rec_sim_unpack_slab_device(mi355rec_sim_t h, const void *d_packed, int64_t n_cells, int32_t *d_nbr_idx, float *d_nbr_val);
 /* The columns of a part in output-row order (columns may be NULL: only the count). */
 int mi355rec_sim_part_columns(mi355rec_sim_t h, int32_t part, int32_t n_parts, int32_t *columns, int32_t *n_columns);
 /* The re-weighted stored values (feature_weighting != NONE), in the order of the csr_data passed to mi355rec_sim_create: what the

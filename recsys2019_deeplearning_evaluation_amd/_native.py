@@ -82,6 +82,8 @@ SIGNATURES = {
     "mi355rec_sim_get_weighted_values": (C.c_int, [_vp, _vp]),
     "mi355rec_sim_compute_part_device": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355rec_sim_compute_part_chunk_device": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mi355rec_sim_pack_slab_device": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "mi355rec_sim_unpack_slab_device": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "mi355rec_sim_part_columns": (C.c_int, [_vp, _i32, _i32, _vp, C.POINTER(_i32)]),
     "mi355rec_sim_compute": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mi355rec_sim_compute_device": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),

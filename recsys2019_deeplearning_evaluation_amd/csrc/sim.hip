@@ -990,7 +990,10 @@ __global__ __launch_bounds__(THREADS, 4) void sim_column_kernel(const SimParams 
 // light columns -- the 32-bit kernel runs them in a second launch, together with the columns whose threshold-first selection does
 // not go through (fewer than K positive thread maxima, more survivors than the buffer holds): this kernel appends those to the
 // second launch's work list (p.retry_count / p.retry_items), the accumulator is simply abandoned.
-constexpr double PACKED_MAX_PAIRS_PER_COLUMN = 2.0e6;
+// (2.0e6 until pieces of a multi-GPU part were measured on their own: the 512 most expensive columns of an 8-way part of the ML-20M
+// shape, 1.07 M pair-adds per column, took 0.51 ms packed against 0.23 ms on the 32-bit kernel -- a few long columns and nothing to
+// interleave them with --, columns [0, 4096) of the whole shape, 1.05 M, 1.51 against 1.45 ms; at 0.87 M and below packed wins)
+constexpr double PACKED_MAX_PAIRS_PER_COLUMN = 1.0e6;
 constexpr int PACKED_PART_ENTRIES = 49152;      // walk entries (>= users) of one part of a column with 65 536 users or more: its counts stay below 2^16
 constexpr int PACKED_AUX_WORDS = 4096;          // 16 KiB: the wavefront tables (8 x 1 KiB), then histogram / candidates (2 048 x 8 B)
 template <int THREADS, int G>
@@ -2186,7 +2189,8 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
     const size_t lds_packed = (size_t)packed_words * 4 + (size_t)PACKED_AUX_WORDS * 4 + sizeof(SimShared);
     // ... and only where a column's fixed phases weigh something next to its accumulation: below PACKED_MAX_PAIRS_PER_COLUMN
     // pair-adds per column of the call (ML-20M shape: 0.29 M, kernel 3.80 -> 3.03-3.10 ms; 138 493 x 9 000 with the same stored
-    // values: 0.87 M, 2.44 -> 2.09-2.17 ms; Netflix shape: 3.0 M, accumulation 92 % of the kernel, 16.5 -> 17.0 ms: not packed).
+    // values: 0.87 M, 2.44 -> 2.09-2.17 ms; Netflix shape: 3.0 M, accumulation 92 % of the kernel, 16.5 -> 17.0 ms: not packed; the
+    // head of an 8-way part, 1.07 M: 0.51 against 0.23 ms: not packed).
     // MI355REC_SIM_PACKED=1 / 0 forces it on (where it applies) / off.
     const char *packed_env = getenv("MI355REC_SIM_PACKED");
     const bool packed_pays = packed_env ? atoi(packed_env) != 0 : (double)cost_sum < PACKED_MAX_PAIRS_PER_COLUMN * (double)std::max(1, n_local);
@@ -2952,6 +2956,59 @@ extern "C" int mi355rec_sim_compute_part_chunk_device(mi355rec_sim_t h, int32_t 
         // walking the same rows of the part)
         if (h->wide_topk) run_columns_wide_topk(h, part, 0, d_nbr_idx, d_nbr_val, n_parts, slot_first, slot_count);
         else run_columns_lds(h, part, 0, d_nbr_idx, d_nbr_val, nullptr, n_parts, slot_first, slot_count);
+    });
+}
+
+// The 6-byte cells of the sharded build's exchange (n_cols <= 65 535): n_cells float32 values, then n_cells 16-bit neighbour ids
+// (0xFFFF = the empty slot's -1), the whole padded to 4-byte words.  Two cells per thread: one packed id word per store.
+__global__ void sim_pack_slab_kernel(const int *idx, const float *val, long long n_cells, float *out_val, unsigned *out_ids) {
+    const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;          // pair number
+    const long long q = 2 * p;
+    if (q >= n_cells) return;
+    const bool two = q + 1 < n_cells;
+    const unsigned lo = (unsigned)idx[q] & 0xFFFFu, hi = two ? ((unsigned)idx[q + 1] & 0xFFFFu) : 0xFFFFu;
+    out_val[q] = val[q];
+    if (two) out_val[q + 1] = val[q + 1];
+    out_ids[p] = lo | (hi << 16);
+}
+__global__ void sim_unpack_slab_kernel(const float *in_val, const unsigned *in_ids, long long n_cells, int *idx, float *val) {
+    const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long q = 2 * p;
+    if (q >= n_cells) return;
+    const unsigned w = in_ids[p];
+    const unsigned lo = w & 0xFFFFu, hi = w >> 16;
+    idx[q] = lo == 0xFFFFu ? -1 : (int)lo;
+    val[q] = in_val[q];
+    if (q + 1 < n_cells) {
+        idx[q + 1] = hi == 0xFFFFu ? -1 : (int)hi;
+        val[q + 1] = in_val[q + 1];
+    }
+}
+
+extern "C" int mi355rec_sim_pack_slab_device(mi355rec_sim_t h, const int32_t *d_nbr_idx, const float *d_nbr_val, int64_t n_cells, void *d_packed) {
+    return guarded([&] {
+        MI_REQUIRE(h && d_nbr_idx && d_nbr_val && d_packed, "NULL argument");
+        MI_REQUIRE(n_cells >= 0, "n_cells = %lld", (long long)n_cells);
+        MI_REQUIRE(h->n_cols <= 65535, "n_cols = %d: neighbour ids do not fit 16 bits", h->n_cols);
+        ensure_device();
+        if (n_cells == 0) return;
+        const long long pairs = (n_cells + 1) / 2;
+        hipLaunchKernelGGL(sim_pack_slab_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, d_nbr_idx, d_nbr_val, (long long)n_cells,
+                           (float *)d_packed, (unsigned *)d_packed + n_cells);
+        MI_HIP(hipGetLastError());
+    });
+}
+
+extern "C" int mi355rec_sim_unpack_slab_device(mi355rec_sim_t h, const void *d_packed, int64_t n_cells, int32_t *d_nbr_idx, float *d_nbr_val) {
+    return guarded([&] {
+        MI_REQUIRE(h && d_nbr_idx && d_nbr_val && d_packed, "NULL argument");
+        MI_REQUIRE(n_cells >= 0, "n_cells = %lld", (long long)n_cells);
+        ensure_device();
+        if (n_cells == 0) return;
+        const long long pairs = (n_cells + 1) / 2;
+        hipLaunchKernelGGL(sim_unpack_slab_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, (const float *)d_packed,
+                           (const unsigned *)d_packed + n_cells, (long long)n_cells, d_nbr_idx, d_nbr_val);
+        MI_HIP(hipGetLastError());
     });
 }
 

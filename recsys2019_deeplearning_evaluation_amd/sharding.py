@@ -89,20 +89,86 @@ def chunk_bounds(n_rows, chunks):
     return [(min(c * step, n_rows), min((c + 1) * step, n_rows)) for c in range(chunks)]
 
 
-def assemble_gathered_pieces(host_words, world, rows, topK, columns, n_columns):
-    """The piece-major gathered buffer of a sharded similarity build (piece c: `[world][2][rows_c][topK]` words, pieces one after the
-    other) as (idx, val) arrays for all columns; `columns[r]` are rank r's columns in the order of its output rows."""
+def cost_sized_pieces(row_costs, chunks, min_rows=512):
+    """Row ranges of a part's output rows for the piece-wise exchange, sized by COST instead of by count, and the order to build them in.
+
+    row_costs[q] = build cost of output row q (the rows of an interleaved part are in descending cost order).  Measured at ML-20M shape,
+    8 parts (bench.py emulated_8_way, round 6): the 512 most expensive columns of a part take 0.23 ms on their own -- their heaviest
+    columns bound them -- against 0.30 ms for the other 2 831 together, so equal COUNTS, heaviest first, made the first of four pieces as
+    long as the whole part in one go (0.52 of 0.55 ms) and every later exchange stick out behind a short kernel.  Only the exchange of
+    the piece built LAST is exposed, and an exchange takes time in proportion to its rows: the piece built last is therefore the head --
+    the fewest rows the device can still be filled with, max(min_rows, n / (2 chunks)), two workgroups per CU -- and the rows behind it
+    are cut into chunks - 1 pieces of equal cost (each at least min_rows rows) that are built FIRST, cheapest rows first, their many-row
+    exchanges behind the next, more expensive piece's kernel.  Returns the ranges in ROW order (piece 0 = the head); build and exchange
+    them in `reversed` order (`piece_order`).  Every rank computes the same bounds from the same costs.  Falls back to equal counts for
+    parts too small to cut."""
+    row_costs = np.asarray(row_costs, dtype=np.float64)
+    n, chunks = len(row_costs), max(1, int(chunks))
+    if chunks == 1 or n < (chunks + 1) * min_rows:
+        return chunk_bounds(n, chunks)
+    head = max(int(min_rows), n // (2 * chunks))
+    prefix = np.concatenate([[0.0], np.cumsum(row_costs[head:] + 1.0)])
+    bounds = [0, head]
+    for p in range(1, chunks - 1):
+        # (an equal share of what is LEFT: a piece that the minimum made larger than its share does not starve the last ones)
+        done = bounds[-1] - head
+        cut = head + int(np.searchsorted(prefix, prefix[done] + (prefix[-1] - prefix[done]) / (chunks - p), side="left"))
+        cut = max(cut, bounds[-1] + min_rows)
+        cut = min(cut, n - (chunks - 1 - p) * min_rows)
+        bounds.append(cut)
+    bounds.append(n)
+    return [(bounds[i], bounds[i + 1]) for i in range(chunks)]
+
+
+def piece_order(rows):
+    """The order pieces are built and exchanged in: last rows (the cheapest columns of an interleaved part) first, the head last."""
+    return list(range(len(rows) - 1, -1, -1))
+
+
+def packed_words(n_cells):
+    """4-byte words of n_cells packed (float32 value, 16-bit id) cells: mi355rec_sim_pack_slab_device's layout."""
+    return int(n_cells) + (int(n_cells) + 1) // 2
+
+
+def unpack_cells(words, n_cells):
+    """(idx int32, val float32) of one packed block (host side of mi355rec_sim_unpack_slab_device)."""
+    val = words[:n_cells].view(np.float32)
+    ids = words[n_cells:packed_words(n_cells)].view(np.uint16)[:n_cells].astype(np.int32)
+    ids[ids == 0xFFFF] = -1
+    return ids, val
+
+
+def pack_cells(idx, val):
+    """Host restatement of mi355rec_sim_pack_slab_device (CPU-side tests and stand-ins): int32 words."""
+    idx = np.ascontiguousarray(idx, np.int32).reshape(-1)
+    n = idx.size
+    ids = np.full(2 * ((n + 1) // 2), 0xFFFF, np.uint16)
+    ids[:n] = (idx & 0xFFFF).astype(np.uint16)
+    return np.concatenate([np.ascontiguousarray(val, np.float32).reshape(-1).view(np.int32), ids.view(np.int32)])
+
+
+def assemble_gathered_pieces(host_words, world, rows, topK, columns, n_columns, packed=False):
+    """The piece-major gathered buffer of a sharded similarity build (piece c: `[world][2][rows_c][topK]` words -- or, packed,
+    `[world][packed_words(rows_c * topK)]` -- pieces one after the other) as (idx, val) arrays for all columns; `columns[r]` are rank
+    r's columns in the order of its output rows."""
     idx = np.empty((n_columns, topK), np.int32)
     val = np.empty((n_columns, topK), np.int32)
     at = 0
     for r0, r1 in rows:
-        words = 2 * (r1 - r0) * topK
+        cells = (r1 - r0) * topK
+        words = packed_words(cells) if packed else 2 * cells
         for r, cols in enumerate(columns):
             have = max(0, min(r1, len(cols)) - r0)
             if have:
-                piece = host_words[at + r * words:at + (r + 1) * words].reshape(2, r1 - r0, topK)
-                idx[cols[r0:r0 + have]] = piece[0, :have]
-                val[cols[r0:r0 + have]] = piece[1, :have]
+                block = host_words[at + r * words:at + (r + 1) * words]
+                if packed:
+                    p_idx, p_val = unpack_cells(block, cells)
+                    idx[cols[r0:r0 + have]] = p_idx.reshape(r1 - r0, topK)[:have]
+                    val[cols[r0:r0 + have]] = p_val.view(np.int32).reshape(r1 - r0, topK)[:have]
+                else:
+                    piece = block.reshape(2, r1 - r0, topK)
+                    idx[cols[r0:r0 + have]] = piece[0, :have]
+                    val[cols[r0:r0 + have]] = piece[1, :have]
         at += world * words
     return idx, val.view(np.float32)
 
@@ -114,26 +180,51 @@ class ChunkedAllGather:
     offset world * sum(words[:c]) -- every piece is one ordinary all-gather into a contiguous block.  start(c) returns at once where
     the transport can (RCCL through ctypes: the collective is enqueued on the null stream, which the library's non-blocking streams
     do not wait for; torch.distributed "nccl": async_op on RCCL's own stream); gloo stages through host memory and blocks (CPU-side
-    tests).  The caller has synchronised the stream that produced piece c before start(c)."""
+    tests).  The caller has synchronised the stream that produced piece c before start(c).
 
-    def __init__(self, send, recv, words, world, dist=None, comm=None):
+    root = r: a GATHER to rank r instead (the step the reference's single process does when it assembles W_sparse,
+    Compute_Similarity_Cython.pyx:593-607 -- only the process that builds the model needs every column): the other ranks send their
+    piece to r over their own link (on the xGMI mesh every peer is one hop away, so the G - 1 transfers run side by side instead of
+    making G - 1 steps round a ring); only rank r's receive buffer is filled (recv may be None elsewhere)."""
+
+    def __init__(self, send, recv, words, world, dist=None, comm=None, root=None, rank=0, as_tensor=None):
         self.send, self.recv, self.words, self.world, self.dist, self.comm = send, recv, list(words), world, dist, comm
+        self.root, self.rank = root, rank
+        # (as_tensor(address, n_words): the CPU-side tests hand in host buffers; the default views device memory of libmi355rec.so)
+        tensor = as_tensor or (lambda address, n_words: device_tensor(address, (n_words,), "<i4"))
         self.offsets = [int(o) for o in np.concatenate([[0], np.cumsum(self.words)])]
         self.pending = []
+        receives = root is None or rank == root
         if dist is not None:
             self.on_host = dist.get_backend() == "gloo"
-            self.t_send = [device_tensor(send.address(self.offsets[c]), (w,), "<i4") if w else None for c, w in enumerate(self.words)]
-            self.t_recv = [device_tensor(recv.address(world * self.offsets[c]), (world * w,), "<i4") if w else None for c, w in enumerate(self.words)]
+            self.t_send = [tensor(send.address(self.offsets[c]), w) if w else None for c, w in enumerate(self.words)]
+            self.t_recv = [tensor(recv.address(world * self.offsets[c]), world * w) if w and receives else None for c, w in enumerate(self.words)]
 
     def start(self, c):
         w = self.words[c]
         if not w or self.world == 1:
             return
         if self.comm is not None:
-            self.comm.all_gather_words_async(self.send.address(self.offsets[c]), self.recv.address(self.world * self.offsets[c]), w)
+            if self.root is None:
+                self.comm.all_gather_words_async(self.send.address(self.offsets[c]), self.recv.address(self.world * self.offsets[c]), w)
+            else:
+                self.comm.gather_words_async(self.send.address(self.offsets[c]),
+                                             self.recv.address(self.world * self.offsets[c]) if self.rank == self.root else 0, w, self.root)
             return
         import torch
-        if self.on_host:
+        if self.root is not None:
+            mine = self.t_send[c].cpu() if self.on_host else self.t_send[c]
+            parts = None
+            if self.rank == self.root:
+                whole = torch.empty(self.world * w, dtype=torch.int32) if self.on_host else self.t_recv[c]
+                parts = list(whole.view(self.world, w).unbind(0))
+            work = self.dist.gather(mine, parts, dst=self.root, async_op=not self.on_host)
+            if self.on_host:
+                if self.rank == self.root:
+                    self.t_recv[c].copy_(whole)
+            else:
+                self.pending.append(work)
+        elif self.on_host:
             mine = self.t_send[c].cpu()
             parts = [torch.empty_like(mine) for _ in range(self.world)]
             self.dist.all_gather(parts, mine)
@@ -151,7 +242,8 @@ class ChunkedAllGather:
         for work in self.pending:
             work.wait()
         self.pending = []
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
 
 class ShardedSimilarityBuild:
@@ -162,101 +254,139 @@ class ShardedSimilarityBuild:
     ranges of partition="ranges", the reference's own start_col/end_col seam, are up to 2.6 x wider than the average at
     Netflix shape because unpopular columns are cheap).
 
-    The rank's `widest` output rows are built in `chunks` pieces (default 4 when world > 1): the all-gather of a finished piece
-    overlaps the kernel of the next one, so only the LAST piece's exchange is exposed (the one-ring model of the 8-GPU ML-20M
-    build: kernel 0.63 ms + 0.42 / 4 ms instead of + 0.42 ms).  Device layout, piece-major: piece c of the rank's slab is
-    `[2][rows_c][topK]` 4-byte words -- neighbour ids, then the similarity values (float32 bits) -- which the column kernel fills
-    directly (its two output pointers are the two halves); the gathered buffer holds, piece after piece, `[world][2][rows_c][topK]`.
-    `build()` returns when the full result is resident on this rank's device -- the same definition at world == 1 (no exchange) --
-    and `download()` copies it to the host, which only a caller that needs NumPy arrays pays.
+    The rank's `widest` output rows are built in `chunks` pieces (default 4 when world > 1): the exchange of a finished piece
+    overlaps the kernel of the next one, so only the exchange of the piece built LAST is exposed.  With the interleaved partition the
+    pieces are sized by cost and built cheapest rows first (`cost_sized_pieces`: a small head of the most expensive columns, built
+    last, behind equal-cost pieces of the other rows), with contiguous ranges by count.
+
+    What travels (`pack`, default: whenever n_columns <= 65 535): 6-byte cells -- piece c of the send slab is the float32 values of
+    its rows followed by their 16-bit neighbour ids (`mi355rec_sim_pack_slab_device`, one small kernel behind the piece's column
+    kernel) -- instead of the `[2][rows_c][topK]` 4-byte words the column kernel writes (which travel as they are when pack=False:
+    its two output pointers are then the two halves of the piece).  The gathered buffer holds, piece after piece, `[world][piece]`.
+
+    exchange="allgather" (default): every rank ends with every column (a recommender object per rank can score its users).
+    exchange="gather": only rank `root` (0) does -- the step the reference's one process performs when it assembles W_sparse
+    (Compute_Similarity_Cython.pyx:593-607); the others' `download()` returns None.  On the xGMI mesh the G - 1 sends run side by
+    side on their own links, where a ring all-gather makes G - 1 steps.
+
+    `build()` returns when the result is resident on the receiving rank's (ranks') device -- the same definition at world == 1 (no
+    exchange) -- and `download()` copies it to the host, which only a caller that needs NumPy arrays pays.
     Buffers belong to libmi355rec.so (raw device allocations); the transport is either
       `comm`: an rccl_direct.RcclCommunicator (RCCL through ctypes, no PyTorch in the process), or
       `dist`: torch.distributed ("nccl" = RCCL: device to device over xGMI; "gloo": staged through host memory, CPU-side tests)."""
 
-    def __init__(self, similarity_object, dist=None, rank=0, world=1, comm=None, partition="interleaved", chunks=None):
+    def __init__(self, similarity_object, dist=None, rank=0, world=1, comm=None, partition="interleaved", chunks=None, exchange="allgather",
+                 pack=None, root=0):
         from ._native import DeviceArray
         self.sim, self.dist, self.comm, self.rank, self.world = similarity_object, dist, comm, rank, world
         assert world == 1 or (dist is None) != (comm is None), "exactly one transport: torch.distributed (dist) or RcclCommunicator (comm)"
-        assert partition in ("interleaved", "ranges")
+        assert partition in ("interleaved", "ranges") and exchange in ("allgather", "gather")
         self.topK, self.n = similarity_object.TopK, similarity_object.n_columns
         self.partition = partition if world > 1 else "ranges"
+        self.root = int(root) if (exchange == "gather" and world > 1) else None
+        self.receives = self.root is None or rank == self.root
+        self.packed = bool(world > 1 and self.n <= 65535 and (pack is None or pack))
+        assert not (pack and self.n > 65535), "pack=True needs n_columns <= 65 535 (16-bit neighbour ids)"
+        if chunks is None:
+            chunks = 4 if world > 1 else 1
         if self.partition == "interleaved":
             self.columns = [similarity_object.part_columns(r, world) for r in range(world)]
             self.ranges = None
             self.widest = max(len(c) for c in self.columns)
+            # (the same bounds on every rank: part 0's rows, the most expensive column of every serpentine group among them)
+            cost = np.asarray(similarity_object.column_costs(), np.float64) + FIXED_PAIRS_PER_CELL * self.n
+            row_cost = np.zeros(self.widest)
+            row_cost[:len(self.columns[0])] = cost[self.columns[0]]
+            self.rows = cost_sized_pieces(row_cost, chunks)
         else:
             self.ranges = similarity_column_ranges(similarity_object, world) if world > 1 else [(0, self.n)]
             self.columns = [np.arange(s, e, dtype=np.int32) for s, e in self.ranges]
             self.widest = max(e - s for s, e in self.ranges)
-        if chunks is None:
-            chunks = 4 if world > 1 else 1
+            self.rows = chunk_bounds(self.widest, chunks)
         # (topK beyond the in-LDS selection -- more than 4096 neighbours, or accumulator tiles x topK beyond the merge buffer -- is built
         # dense + sorted; mi355rec_sim_compute_part_chunk_device walks the same rows of the part there too, so pieces work either way)
-        self.rows = chunk_bounds(self.widest, chunks)
-        self.slab_words = 2 * self.widest * self.topK
-        self.local = DeviceArray(self.slab_words)
-        # rows beyond this rank's columns are never written by the kernel but travel in the all-gather: (-1, 0.0) like empty slots
+        self.work_words = 2 * self.widest * self.topK
+        self.work_offsets = [2 * r0 * self.topK for r0, _ in self.rows]
+        self.work = DeviceArray(self.work_words)
+        # rows beyond this rank's columns are never written by the kernel but travel in the exchange: (-1, 0.0) like empty slots
         from . import _native as N
         fill = np.concatenate([np.concatenate([np.full((r1 - r0) * self.topK, -1, np.int32), np.zeros((r1 - r0) * self.topK, np.int32)])
                                for r0, r1 in self.rows])
-        N.check(N.load().mi355rec_device_memcpy(self.local.ptr, N.ptr(fill), 4 * self.slab_words, 1))
-        self.gathered = DeviceArray(world * self.slab_words) if world > 1 else self.local
-        self._host = np.empty(world * self.slab_words, np.int32)
-        self.gather = ChunkedAllGather(self.local, self.gathered, [2 * (r1 - r0) * self.topK for r0, r1 in self.rows], world, dist, comm)
+        N.check(N.load().mi355rec_device_memcpy(self.work.ptr, N.ptr(fill), 4 * self.work_words, 1))
+        piece_words = [packed_words((r1 - r0) * self.topK) if self.packed else 2 * (r1 - r0) * self.topK for r0, r1 in self.rows]
+        self.slab_words = int(sum(piece_words))
+        self.local = DeviceArray(self.slab_words) if self.packed else self.work
+        if world == 1:
+            self.gathered = self.local
+        else:
+            self.gathered = DeviceArray(world * self.slab_words) if self.receives else None
+        self._host = np.empty(world * self.slab_words, np.int32) if self.receives else None
+        self.gather = ChunkedAllGather(self.local, self.gathered, piece_words, world, dist, comm, root=self.root, rank=rank)
 
     def _build_piece(self, c):
         r0, r1 = self.rows[c]
         mine = len(self.columns[self.rank])
         count = max(0, min(r1, mine) - r0)
-        if count == 0:
-            return False
-        at = self.gather.offsets[c]
-        d_idx, d_val = self.local.address(at), self.local.address(at + (r1 - r0) * self.topK)
-        if self.partition == "interleaved":
-            if len(self.rows) == 1:
-                self.sim.compute_part_device(self.rank, self.world, d_idx, d_val)
+        at = self.work_offsets[c]
+        d_idx, d_val = self.work.address(at), self.work.address(at + (r1 - r0) * self.topK)
+        if count:
+            if self.partition == "interleaved":
+                if len(self.rows) == 1:
+                    self.sim.compute_part_device(self.rank, self.world, d_idx, d_val)
+                else:
+                    self.sim.compute_part_chunk_device(self.rank, self.world, r0, count, d_idx, d_val)
             else:
-                self.sim.compute_part_chunk_device(self.rank, self.world, r0, count, d_idx, d_val)
-        else:
-            s, e = self.ranges[self.rank]
-            a, b = s + r0, s + r0 + count
-            self.sim.compute_slabs_device(a if a > 0 else None, b if b < self.n else None, d_idx, d_val)
-        return True
+                s, e = self.ranges[self.rank]
+                a, b = s + r0, s + r0 + count
+                self.sim.compute_slabs_device(a if a > 0 else None, b if b < self.n else None, d_idx, d_val)
+        if self.packed and r1 > r0:
+            # (also for a piece this rank has no column in: its empty rows travel like everybody's)
+            self.sim.pack_slab_device(d_idx, d_val, (r1 - r0) * self.topK, self.local.address(self.gather.offsets[c]))
+            return True
+        return count > 0
 
     def build(self):
-        """Kernel on this rank's columns, piece by piece, each piece's all-gather behind the next piece's kernel; afterwards the
-        gathered slabs are valid on this device.  Blocking.  Returns the column kernel's milliseconds summed over the pieces (the
-        similarity object's stats() only ever hold the LAST launch: a caller that divides this rank's work by a kernel time needs the sum)."""
+        """Kernel on this rank's columns, piece by piece, each piece's exchange behind the next piece's kernel; afterwards the
+        gathered slabs are valid on the receiving device(s).  Blocking.  Returns the column kernel's milliseconds summed over the pieces
+        (the similarity object's stats() only ever hold the LAST launch: a caller that divides this rank's work by a kernel time needs
+        the sum)."""
         kernel_ms = 0.0
-        for c in range(len(self.rows)):
+        mine = len(self.columns[self.rank])
+        for c in piece_order(self.rows):
             if self._build_piece(c):
                 self.sim.synchronize()
-                kernel_ms += float(self.sim.stats()["kernel_ms"])
+                if min(self.rows[c][1], mine) > self.rows[c][0]:
+                    kernel_ms += float(self.sim.stats()["kernel_ms"])
             self.gather.start(c)
         self.gather.finish()
         self.kernel_ms = kernel_ms
         return kernel_ms
 
     def download(self):
-        """(idx, val) NumPy arrays for ALL columns."""
-        return assemble_gathered_pieces(self.gathered.to_host(self._host), self.world, self.rows, self.topK, self.columns, self.n)
+        """(idx, val) NumPy arrays for ALL columns (None on a rank that the gather does not deliver to)."""
+        if not self.receives:
+            return None
+        return assemble_gathered_pieces(self.gathered.to_host(self._host), self.world, self.rows, self.topK, self.columns, self.n, self.packed)
 
     def exchange_bytes_per_rank(self):
         return 0 if self.world == 1 else 4 * self.slab_words
 
     def close(self):
-        self.local.close()
-        if self.gathered is not self.local:
+        self.work.close()
+        if self.local is not self.work:
+            self.local.close()
+        if self.gathered is not None and self.gathered is not self.local:
             self.gathered.close()
 
 
-def sharded_similarity_build(similarity_object, dist=None, rank=0, world=1, comm=None, partition="interleaved"):
+def sharded_similarity_build(similarity_object, dist=None, rank=0, world=1, comm=None, partition="interleaved", **how):
     """Column-sharded build with a Compute_Similarity_MI355X object: returns (idx, val) numpy arrays for ALL
-    columns on every rank.  With world == 1 this is the plain single-GPU build."""
+    columns on every rank (exchange="gather": on rank 0, None elsewhere).  With world == 1 this is the plain single-GPU build.
+    `how`: chunks / exchange / pack / root of ShardedSimilarityBuild."""
     if world == 1:
         idx, val, _ = similarity_object.compute_slabs()
         return idx, val
-    job = ShardedSimilarityBuild(similarity_object, dist, rank, world, comm, partition)
+    job = ShardedSimilarityBuild(similarity_object, dist, rank, world, comm, partition, **how)
     job.build()
     out = job.download()
     job.close()

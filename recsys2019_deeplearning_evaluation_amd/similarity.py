@@ -142,6 +142,13 @@ class Compute_Similarity_MI355X:
         N.check(self._lib.mi355rec_sim_compute_part_chunk_device(self._h, int(part), int(n_parts), int(slot_first), int(slot_count),
                                                                  C.c_void_p(d_idx_ptr), C.c_void_p(d_val_ptr)))
 
+    def pack_slab_device(self, d_idx_ptr, d_val_ptr, n_cells, d_packed_ptr):
+        """(idx, val) device slabs of n_cells cells -> the 6-byte exchange cells (values, then 16-bit ids); asynchronous on the handle's stream."""
+        N.check(self._lib.mi355rec_sim_pack_slab_device(self._h, C.c_void_p(d_idx_ptr), C.c_void_p(d_val_ptr), int(n_cells), C.c_void_p(d_packed_ptr)))
+
+    def unpack_slab_device(self, d_packed_ptr, n_cells, d_idx_ptr, d_val_ptr):
+        N.check(self._lib.mi355rec_sim_unpack_slab_device(self._h, C.c_void_p(d_packed_ptr), int(n_cells), C.c_void_p(d_idx_ptr), C.c_void_p(d_val_ptr)))
+
     def part_columns(self, part, n_parts):
         n = C.c_int32()
         N.check(self._lib.mi355rec_sim_part_columns(self._h, int(part), int(n_parts), None, C.byref(n)))

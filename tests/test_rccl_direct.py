@@ -44,7 +44,7 @@ def test_unique_id_travels_whole():
 def test_librccl_exports_what_the_binding_uses():
     lib = rccl_direct._load_rccl()
     for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclCommDestroy", "ncclGetErrorString", "ncclCommCount",
-                 "ncclCommUserRank"):
+                 "ncclCommUserRank", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd"):
         assert hasattr(lib, name)
     assert rccl_direct._UniqueId.__dict__ is not None and rccl_direct.NCCL_UNIQUE_ID_BYTES == 128
 

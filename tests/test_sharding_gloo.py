@@ -64,6 +64,33 @@ for chunks in (1, 3, 4, widest + 5):
         gathered.append(out)
     got_idx, got_val = assemble_gathered_pieces(torch.cat(gathered).numpy(), world, rows, 12, parts, X.shape[1])
     assert np.array_equal(got_idx, ref_idx) and np.array_equal(got_val, ref_val), "pieces (%%d) rank %%d mismatch" %% (chunks, rank)
+# the exchange as ShardedSimilarityBuild runs it: cost-sized pieces, 6-byte packed cells (values + 16-bit ids), all-gather or gather
+# to a root, through ChunkedAllGather itself (host buffers stand in for the device slabs)
+import ctypes as C
+from recsys2019_deeplearning_evaluation_amd.sharding import ChunkedAllGather, cost_sized_pieces, pack_cells, packed_words, piece_order
+class HostWords:
+    def __init__(self, n): self.a = np.zeros(n, np.int32)
+    def address(self, word_offset=0): return self.a.ctypes.data + 4 * int(word_offset)
+as_tensor = lambda address, n: torch.from_numpy(np.ctypeslib.as_array((C.c_int32 * n).from_address(address)))
+row_cost = np.zeros(widest); row_cost[:len(parts[0])] = cost[parts[0]]
+for rows in (cost_sized_pieces(row_cost, 3, min_rows=10), chunk_bounds(widest, 4)):
+    for packed in (True, False):
+        words = [packed_words((r1 - r0) * 12) if packed else 2 * (r1 - r0) * 12 for r0, r1 in rows]
+        for root in (None, 0, 1):
+            send, recv = HostWords(sum(words)), HostWords(world * sum(words))
+            recv.a[:] = 12345
+            gather = ChunkedAllGather(send, recv, words, world, dist, None, root=root, rank=rank, as_tensor=as_tensor)
+            for c in piece_order(rows):
+                r0, r1 = rows[c]
+                piece = mine[:, r0:r1, :].numpy()
+                send.a[gather.offsets[c]:gather.offsets[c + 1]] = pack_cells(piece[0], piece[1].view(np.float32)) if packed else piece.reshape(-1)
+                gather.start(c)
+            gather.finish()
+            if root is None or root == rank:
+                got_idx, got_val = assemble_gathered_pieces(recv.a, world, rows, 12, parts, X.shape[1], packed)
+                assert np.array_equal(got_idx, ref_idx) and np.array_equal(got_val, ref_val), "exchange (packed %%s, root %%s) rank %%d mismatch" %% (packed, root, rank)
+            else:
+                assert (recv.a == 12345).all(), "a gather to rank %%d wrote on rank %%d" %% (root, rank)
 dist.barrier()
 if rank == 0:
     print("SHARDING_OK", ranges)
@@ -182,3 +209,28 @@ def test_exact_bpr_mode_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "SHARDED_BPR_OK" in outs[0]
+
+
+def test_cost_sized_pieces_and_packed_cells():
+    """Host pieces of the sharded build's exchange: piece bounds sized by cost (equal-cost pieces, a small last one, every row once, the same
+    on every rank) and the 6-byte cell format (values, then 16-bit ids with 0xFFFF for the empty slot's -1)."""
+    from recsys2019_deeplearning_evaluation_amd.sharding import cost_sized_pieces, chunk_bounds, pack_cells, unpack_cells, packed_words, piece_order
+    rng = np.random.default_rng(5)
+    cost = 1.6e5 + 9e5 * np.exp(-np.arange(3343) / 700.0)                  # a part of the ML-20M shape: 3343 rows in descending cost order
+    rows = cost_sized_pieces(cost, 4)
+    assert rows[0][0] == 0 and rows[-1][1] == len(cost) and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    sizes = [b - a for a, b in rows]
+    assert sizes[0] == max(512, len(cost) // 8) and min(sizes) >= 512   # the head: the fewest rows, built (and exchanged) last
+    piece_cost = [cost[a:b].sum() for a, b in rows]
+    assert max(piece_cost[1:]) <= 1.25 * min(piece_cost[1:])
+    assert sizes[1] < sizes[2] < sizes[3]                               # (expensive rows first: fewer of them per piece)
+    assert piece_order(rows) == [3, 2, 1, 0]
+    assert cost_sized_pieces(cost[:1500], 4) == chunk_bounds(1500, 4)   # too small to cut by cost
+    assert cost_sized_pieces(cost, 1) == [(0, len(cost))]
+    for n in (0, 1, 2, 7, 100):
+        idx = rng.integers(-1, 65535, n).astype(np.int32)
+        val = rng.random(n).astype(np.float32)
+        words = pack_cells(idx, val)
+        assert words.dtype == np.int32 and len(words) == packed_words(n)
+        got_idx, got_val = unpack_cells(words, n)
+        assert np.array_equal(got_idx, idx) and np.array_equal(got_val, val)

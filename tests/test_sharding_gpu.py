@@ -29,8 +29,14 @@ X = named_urm("ml1m", "binary", scale=0.2)
 sim = Compute_Similarity_MI355X(X, topK=30, shrink=2, similarity="jaccard")
 full_idx, full_val, _ = sim.compute_slabs()
 for partition in ("interleaved", "ranges"):
-    idx, val = sharded_similarity_build(sim, dist, rank, world, partition=partition)
-    assert np.array_equal(idx, full_idx) and np.array_equal(val, full_val), "sharded similarity (%%s) differs on rank %%d" %% (partition, rank)
+    # default: 6-byte packed cells in cost-sized pieces, all-gather; then the 8-byte words, and both as a gather to rank 0 / rank 1
+    for how in (dict(), dict(pack=False), dict(exchange="gather"), dict(exchange="gather", pack=False, chunks=3, root=1), dict(chunks=1)):
+        out = sharded_similarity_build(sim, dist, rank, world, partition=partition, **how)
+        if how.get("exchange") == "gather" and rank != how.get("root", 0):
+            assert out is None
+            continue
+        idx, val = out
+        assert np.array_equal(idx, full_idx) and np.array_equal(val, full_val), "sharded similarity (%%s, %%s) differs on rank %%d" %% (partition, how, rank)
 ranges = balanced_column_ranges(sim.column_costs(), world)
 assert ranges[0][1] < X.shape[1] // 2, "cost balancing must give the popular (low-index) columns the shorter range"
 
@@ -85,6 +91,40 @@ def test_two_ranks_share_one_gpu(gpu, tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "SHARDED_GPU_OK" in outs[0]
+
+
+def test_packed_exchange_cells_on_the_device(gpu):
+    """mi355rec_sim_pack_slab_device / unpack: the 6-byte cells of the sharded build's exchange equal the host restatement
+    (sharding.pack_cells), for even and odd cell counts, and unpack gives the slabs back with -1 in the empty slots."""
+    import numpy as np
+    from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_MI355X, _native as N
+    from recsys2019_deeplearning_evaluation_amd._native import DeviceArray
+    from recsys2019_deeplearning_evaluation_amd.sharding import pack_cells, packed_words, ShardedSimilarityBuild
+    from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
+    X = named_urm("ml1m", "binary", scale=0.3)
+    topK = 7
+    sim = Compute_Similarity_MI355X(X, topK=topK, shrink=0)
+    idx, val, _ = sim.compute_slabs()
+    built_idx, built_val = idx.copy(), val.copy()
+    idx[::5, -2:] = -1; val[::5, -2:] = 0.0                    # (columns with fewer than topK neighbours: empty slots travel too)
+    for rows in (len(idx), 331, 1, 0):
+        cells = rows * topK
+        slab = np.concatenate([idx[:rows].reshape(-1), val[:rows].reshape(-1).view(np.int32)])
+        work, packed, back = DeviceArray(max(2 * cells, 1)), DeviceArray(max(packed_words(cells), 1)), DeviceArray(max(2 * cells, 1))
+        if cells:
+            N.check(N.load().mi355rec_device_memcpy(work.ptr, N.ptr(slab), 4 * len(slab), 1))
+        sim.pack_slab_device(work.address(), work.address(cells), cells, packed.address())
+        sim.unpack_slab_device(packed.address(), cells, back.address(), back.address(cells))
+        sim.synchronize()
+        assert np.array_equal(packed.to_host()[:packed_words(cells)], pack_cells(idx[:rows], val[:rows]))
+        assert np.array_equal(back.to_host()[:2 * cells], slab)
+        work.close(); packed.close(); back.close()
+    # world == 1: the sharded object is the plain build (nothing packed, nothing exchanged)
+    job = ShardedSimilarityBuild(sim)
+    job.build()
+    got_idx, got_val = job.download()
+    assert np.array_equal(got_idx, built_idx) and np.array_equal(got_val, built_val) and job.exchange_bytes_per_rank() == 0 and not job.packed
+    job.close(); sim.close()
 
 
 def test_interleaved_parts_on_one_gpu(gpu):
