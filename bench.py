@@ -1236,6 +1236,9 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
                 t += max(k_ms, g_prev)
             return t + gather_of(slab * (pieces[-1][1] - pieces[-1][0]) / widest8)
         ranges8 = similarity_column_ranges(sim, 8)
+        from recsys2019_deeplearning_evaluation_amd.sharding import default_chunks
+        part_pairs = (float(np.asarray(costs, np.float64).sum()) + FIXED_PAIRS_PER_CELL * float(n_items) ** 2) / G
+        chunks_allgather, chunks_gather = default_chunks(part_pairs, slab, G, "allgather"), default_chunks(part_pairs, slab, G, "gather")
         block["emulated_8_way"] = {
             "partition": "interleaved (serpentine deal of the cost order): %d columns and 1/8 of the cost per part" % widest8,
             "kernel_ms_per_part": per_part, "slowest_part_ms": max(per_part),
@@ -1251,9 +1254,14 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
             "predicted_build_speedup_one_exchange_at_the_end": {"one_ring": (best * 1e3) / (max(per_part) + ring_ms),
                                                                 "seven_links": (best * 1e3) / (max(per_part) + direct_ms)},
             "kernel_ms_per_piece": per_piece,
-            "predicted_build_speedup": {"one_ring": (best * 1e3) / max(overlapped(row, ring_of) for row in per_piece),
-                                        "seven_links": (best * 1e3) / max(overlapped(row, direct_of) for row in per_piece),
-                                        "gather_to_root": (best * 1e3) / max(overlapped(row, direct_of) for row in per_piece)},
+            "predicted_build_speedup_in_4_pieces": {"one_ring": (best * 1e3) / max(overlapped(row, ring_of) for row in per_piece),
+                                                    "seven_links": (best * 1e3) / max(overlapped(row, direct_of) for row in per_piece)},
+            # what the library does by default (sharding.default_chunks: pieces only where the modelled exchange is long next to the kernel)
+            "default_chunks": {"allgather": chunks_allgather, "gather_to_root": chunks_gather},
+            "predicted_build_speedup": {
+                "one_ring": (best * 1e3) / (max(overlapped(row, ring_of) for row in per_piece) if chunks_allgather > 1 else max(per_part) + ring_ms),
+                "seven_links": (best * 1e3) / (max(overlapped(row, direct_of) for row in per_piece) if chunks_allgather > 1 else max(per_part) + direct_ms),
+                "gather_to_root": (best * 1e3) / (max(overlapped(row, direct_of) for row in per_piece) if chunks_gather > 1 else max(per_part) + direct_ms)},
             "exchange": "4 cost-sized pieces per part built cheapest rows first (kernel_ms_per_piece is in that order), %d-byte cells, the exchange of a finished piece behind the kernel of the next one "
                         "(ShardedSimilarityBuild); all-gather = every rank ends with W (one ring, or all seven links at once); gather_to_root = only "
                         "rank 0 does (exchange='gather': each peer sends over its own link, the model of 'seven_links')" % cell_bytes,

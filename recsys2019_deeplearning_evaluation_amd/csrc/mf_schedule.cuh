@@ -136,6 +136,8 @@ constexpr int FAST_MAX_BATCHES = 256, FAST_MAX_SLOTS = 8192;
 struct FastSchedParams {
     long long n_samples;
     int per, n_users, n_entries, batch_size, tasks_per_batch, slot_bits, np, words, group;
+    int fill_all;                 // 1: every header slot past the last one in use is zeroed (the one-model kernel launches a wavefront per slot);
+                                  // 0: only up to the next multiple of 4 (the group kernel walks the slots in use, a workgroup of four wavefronts at a time)
     int mid_bytes;                // LDS bytes between the keys and the once-touched flags (run starts + header slots, or the sort's scratch)
     int entry_bits;               // bits of a row id (users, then items) + 1: the padding keys' all-ones field sorts last
     int fuse;                     // BPR: a sample whose user row is touched once in the batch takes over its other once-touched rows
@@ -143,7 +145,7 @@ struct FastSchedParams {
     const float *sr;
     unsigned *touched;            // [n_entries][words]: bit b of row x = mini-batch b of this stream touches x
     unsigned char *par;           // [n_entries]: buffer of every row's current version at stream start
-    int *sorted_slot;             // [n_batches][tasks_per_batch]: batch-local incidence ids in (row, id) order
+    int *sorted_slot;             // [n_batches][tasks_per_batch]: per batch-local incidence (sample * per + role) its position in (row, id) order | also << 16
     int *qtask;                   // per sorted position: batch-local slot of its task's (first) header | wide << 30
     int *used;                    // [n_batches]: header slots in use
     TaskHeader *tasks;
@@ -289,7 +291,8 @@ __device__ __forceinline__ void mf_sched_sort_body(const FastSchedParams &s, con
     }
     const int used = 4 * n_wide + (total - n_wide - n_abs);
     if (tid == 0) s.used[b] = used;
-    for (int slot = used + tid; slot < s.tasks_per_batch; slot += SCHED_THREADS)
+    const int fill_end = s.fill_all ? s.tasks_per_batch : min(s.tasks_per_batch, (used + 3) & ~3);
+    for (int slot = used + tid; slot < fill_end; slot += SCHED_THREADS)
         *reinterpret_cast<int4 *>(out + slot) = make_int4(0, 0, 0, 0);          // no samples: the slot's wavefront idles
     __syncthreads();
     for (int q = tid; q < m; q += SCHED_THREADS) {
@@ -304,7 +307,9 @@ __device__ __forceinline__ void mf_sched_sort_body(const FastSchedParams &s, con
             const int smp = inc / s.per;
             if (inc == smp * s.per) also = (single[inc + 1] ? 1 : 0) | (s.per == 3 && single[inc + 2] ? 2 : 0);
         }
-        s.sorted_slot[(size_t)b * s.tasks_per_batch + q] = inc | (also << 16);
+        // (by INCIDENCE: the emit kernel runs one thread per sample, which looks its three incidences' sorted positions up; a scattered
+        // 4-byte store into the mini-batch's 12 KB here, three coalesced loads there)
+        s.sorted_slot[(size_t)b * s.tasks_per_batch + inc] = q | (also << 16);
         s.qtask[(size_t)b * s.tasks_per_batch + q] = tpos[lo];
     }
 }
@@ -318,48 +323,58 @@ __device__ __forceinline__ int version_parity(const FastSchedParams &s, int entr
     return (s.par[entry] + cnt) & 1;
 }
 
+// One thread per SAMPLE (until round 6: per incidence -- every sample's ids were then fetched by three threads at three unrelated
+// sorted positions and the version parities of its three rows evaluated three times over: 1.08 GB fetched per 32-model epoch).  The
+// sample's ids come in coalesced, each row's parity is evaluated once, and the record goes to the sample's three sorted positions.
 __device__ __forceinline__ void mf_sched_emit_body(const FastSchedParams &s) {
-    const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y, smp = blockIdx.x * 256 + threadIdx.x;
     const long long first = (long long)b * s.batch_size;
     const int n_in = (int)min((long long)s.batch_size, s.n_samples - first);
-    if (q >= n_in * s.per) return;
-    const size_t at = (size_t)b * s.tasks_per_batch + q;
-    const int slot_word = s.sorted_slot[at];
-    const int slot = slot_word & 0xffff, also = slot_word >> 16;
-    const int smp = slot / s.per, role = slot - smp * s.per;
+    if (smp >= n_in) return;
+    const size_t base = (size_t)b * s.tasks_per_batch;
     const long long t = first + smp;
     const int u = s.su[t], i = s.si[t], j = s.per == 3 ? s.sj[t] : 0;
+    const int third = s.per == 3 ? j : __float_as_int(s.sr[t]);
+    int where[3];
+#pragma unroll
+    for (int role = 0; role < 3; ++role) where[role] = role < s.per ? s.sorted_slot[base + (size_t)smp * s.per + role] : 0;
     const int pu = version_parity(s, u, b), pi = version_parity(s, s.n_users + i, b);
     const int pj = s.per == 3 ? version_parity(s, s.n_users + j, b) : 0;
-    const int4 rec = make_int4(u, i, s.per == 3 ? j : __float_as_int(s.sr[t]), role | (pu << 2) | (pi << 3) | (pj << 4) | (also << 5));
-    s.recs[at] = rec;
-    const int tp = s.qtask[at];
-    if (tp == SLOT_ABSORBED) {
-        // a sample of a PAIR task other than its first (pairs are aligned blocks of `group` sorted positions, the header belongs to the
-        // first): its record also goes where the mini-batch kernel finds it without having seen the header -- by header slot
-        const int q0 = q - q % s.group;
-        if (s.fuse && q0 != q) {
-            const int tp0 = s.qtask[(size_t)b * s.tasks_per_batch + q0];
-            if (tp0 != SLOT_ABSORBED && !(tp0 & META_WIDE)) {
-                const TaskHeader *lead = s.tasks + (size_t)b * s.tasks_per_batch + tp0;
-                if (lead->pad == 1 && lead->start == (int)((size_t)b * s.tasks_per_batch + q0))
-                    s.slot_recs[((size_t)b * s.tasks_per_batch + tp0) * 3 + (q - q0 - 1)] = rec;
+    const int par_bits = (pu << 2) | (pi << 3) | (pj << 4);
+#pragma unroll
+    for (int role = 0; role < 3; ++role) {
+        if (role >= s.per) break;
+        const int q = where[role] & 0xffff, also = where[role] >> 16;
+        const size_t at = base + q;
+        const int4 rec = make_int4(u, i, third, role | par_bits | (also << 5));
+        s.recs[at] = rec;
+        const int tp = s.qtask[at];
+        if (tp == SLOT_ABSORBED) {
+            // a sample of a PAIR task other than its first (pairs are aligned blocks of `group` sorted positions, the header belongs to the
+            // first): its record also goes where the mini-batch kernel finds it without having seen the header -- by header slot
+            const int q0 = q - q % s.group;
+            if (s.fuse && q0 != q) {
+                const int tp0 = s.qtask[base + q0];
+                if (tp0 != SLOT_ABSORBED && !(tp0 & META_WIDE)) {
+                    const TaskHeader *lead = s.tasks + base + tp0;
+                    if (lead->pad == 1 && lead->start == (int)(base + q0)) s.slot_recs[(base + tp0) * 3 + (q - q0 - 1)] = rec;
+                }
             }
+            continue;
         }
-        return;
-    }
-    TaskHeader *hd = s.tasks + (size_t)b * s.tasks_per_batch + (tp & (META_WIDE - 1));
-    const int off = (int)(at - (size_t)hd->start);
-    const int own = role == 0 ? pu : (role == 1 ? pi : pj);
-    int part = -1;
-    if (tp & META_WIDE) {           // quarter k of a wide list starts at position k * group
-        if (off % s.group == 0 && off / s.group < 4) part = off / s.group;      // (quarters past the end of the list stay empty)
-    } else if (off == 0) {
-        part = 0;
-    }
-    if (part >= 0) {
-        hd[part].rec0 = rec;
-        hd[part].meta |= own << 31;
+        TaskHeader *hd = s.tasks + base + (tp & (META_WIDE - 1));
+        const int off = (int)(at - (size_t)hd->start);
+        const int own = role == 0 ? pu : (role == 1 ? pi : pj);
+        int part = -1;
+        if (tp & META_WIDE) {           // quarter k of a wide list starts at position k * group
+            if (off % s.group == 0 && off / s.group < 4) part = off / s.group;      // (quarters past the end of the list stay empty)
+        } else if (off == 0) {
+            part = 0;
+        }
+        if (part >= 0) {
+            hd[part].rec0 = rec;
+            hd[part].meta |= own << 31;
+        }
     }
 }
 

@@ -125,6 +125,27 @@ def piece_order(rows):
     return list(range(len(rows) - 1, -1, -1))
 
 
+# What the piece-wise exchange is decided on: the column kernel's rate on a part of a multi-GPU build (pair-adds per second; ML-20M shape,
+# 8 parts: 0.98e9 pairs in 0.46-0.55 ms, Netflix shape 6.8e9 in 2.2 ms) and the per-link rate the exchange is modelled with.
+PART_PAIRS_PER_SECOND = 2.5e12
+LINK_BYTES_PER_SECOND = 50e9
+
+
+def default_chunks(part_pairs, slab_bytes, world, exchange):
+    """Pieces per part: 4 where the exchange is long next to the kernel that could hide it, else 1.
+
+    Building a part in pieces costs kernel time (ML-20M shape, 8 parts: 0.60 ms in four pieces against 0.54 ms in one go; Netflix shape,
+    equal counts: 2.6 against 2.16 ms), so it only pays where the exchange it hides is longer than that: a ring all-gather moves
+    (world - 1) slabs over one link (0.33 ms against 0.54 ms of kernel at ML-20M shape: pieces; 0.24 against 2.2 ms at Netflix shape:
+    one go), a gather to one rank a single slab per link (0.09 ms: one go at both shapes)."""
+    if world <= 1:
+        return 1
+    steps = (world - 1) if exchange == "allgather" else 1
+    exchange_s = steps * float(slab_bytes) / LINK_BYTES_PER_SECOND
+    kernel_s = float(part_pairs) / PART_PAIRS_PER_SECOND
+    return 4 if exchange_s > 0.3 * kernel_s else 1
+
+
 def packed_words(n_cells):
     """4-byte words of n_cells packed (float32 value, 16-bit id) cells: mi355rec_sim_pack_slab_device's layout."""
     return int(n_cells) + (int(n_cells) + 1) // 2
@@ -254,7 +275,8 @@ class ShardedSimilarityBuild:
     ranges of partition="ranges", the reference's own start_col/end_col seam, are up to 2.6 x wider than the average at
     Netflix shape because unpopular columns are cheap).
 
-    The rank's `widest` output rows are built in `chunks` pieces (default 4 when world > 1): the exchange of a finished piece
+    The rank's `widest` output rows are built in `chunks` pieces (default: 4 where the modelled exchange is long next to the part's
+    kernel, else 1 -- `default_chunks`): the exchange of a finished piece
     overlaps the kernel of the next one, so only the exchange of the piece built LAST is exposed.  With the interleaved partition the
     pieces are sized by cost and built cheapest rows first (`cost_sized_pieces`: a small head of the most expensive columns, built
     last, behind equal-cost pieces of the other rows), with contiguous ranges by count.
@@ -288,7 +310,9 @@ class ShardedSimilarityBuild:
         self.packed = bool(world > 1 and self.n <= 65535 and (pack is None or pack))
         assert not (pack and self.n > 65535), "pack=True needs n_columns <= 65 535 (16-bit neighbour ids)"
         if chunks is None:
-            chunks = 4 if world > 1 else 1
+            cost_all = np.asarray(similarity_object.column_costs(), np.float64)
+            chunks = default_chunks((cost_all.sum() + FIXED_PAIRS_PER_CELL * float(self.n) ** 2) / world,
+                                    (6 if self.packed else 8) * -(-self.n // world) * self.topK, world, exchange)
         if self.partition == "interleaved":
             self.columns = [similarity_object.part_columns(r, world) for r in range(world)]
             self.ranges = None

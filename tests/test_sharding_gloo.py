@@ -234,3 +234,14 @@ def test_cost_sized_pieces_and_packed_cells():
         assert words.dtype == np.int32 and len(words) == packed_words(n)
         got_idx, got_val = unpack_cells(words, n)
         assert np.array_equal(got_idx, idx) and np.array_equal(got_val, val)
+
+
+def test_pieces_only_where_the_exchange_is_long_next_to_the_kernel():
+    """sharding.default_chunks at the two BASELINE shapes, 8 ranks, topK 100 (pair counts of bench.py's synthetic URMs): a ring all-gather at
+    ML-20M shape is built in pieces, everything else in one go."""
+    from recsys2019_deeplearning_evaluation_amd.sharding import default_chunks, FIXED_PAIRS_PER_CELL
+    ml20m = ((7.82e9 + FIXED_PAIRS_PER_CELL * 26744.0 ** 2) / 8, 6 * 3343 * 100)
+    netflix = ((54.09e9 + FIXED_PAIRS_PER_CELL * 17770.0 ** 2) / 8, 6 * 2222 * 100)
+    assert default_chunks(*ml20m, 8, "allgather") == 4 and default_chunks(*ml20m, 8, "gather") == 1
+    assert default_chunks(*netflix, 8, "allgather") == 1 and default_chunks(*netflix, 8, "gather") == 1
+    assert default_chunks(*ml20m, 1, "allgather") == 1
