@@ -1489,6 +1489,7 @@ struct mi355rec_slim {
     size_t launch_capacity = 0;
     DeviceBuffer<unsigned long long> prof;              // MI355REC_SLIM_PROF=1: phase clocks of the last launch
     long long steps_done = 0, epochs_done = 0;
+    bool aborted = false;                               // a launch gave up on a hand-off: S holds part of an epoch, every later call refuses
     unsigned tag_base = 0;                              // symmetric store: tags handed out so far
     int last_owners = 0, last_cold = 0;                 // owned rows / steps on rows in HBM of the last dense launch (diagnostics)
     std::vector<double> h_loss;
@@ -1879,6 +1880,11 @@ void launch_stream(mi355rec_slim *h, StreamSet &st, int n, int first, Launched &
         MI_HIP(hipMemsetAsync(h->prof.ptr, 0, sizeof(unsigned long long) * h->prof.count, s));
     }
     MI_HIP(hipMemsetAsync(h->queue.ptr, 0, sizeof(int) * 4, s));
+    if (getenv("MI355REC_SLIM_INJECT_ABORT")) {                      // (test hook: the abort flag is up before the first step polls it)
+        const int one = 1;
+        MI_HIP(hipMemcpyAsync(h->queue.ptr + 1, &one, sizeof(int), hipMemcpyHostToDevice, s));
+        MI_HIP(hipStreamSynchronize(s));
+    }
     if (!flow_supported(h)) {
         if constexpr (std::is_same<T, double>::value) {
             fill_params(h, st, p);
@@ -1971,7 +1977,13 @@ void finish_stream(mi355rec_slim *h, Launched &L, int n) {
         h->last_owners = counters[0];
         h->last_cold = counters[1];
     }
-    if (flags[1]) fail(MI355REC_E_HIP, "SLIM-BPR: a hand-off between steps did not arrive (dataflow kernel aborted)");
+    if (flags[1]) {
+        // Steps of the epoch have been applied, others not, and nothing records which: the model is neither the one before the call nor a
+        // trained one.  There is no copy to roll back to (S is n_items^2 cells), so the handle says so from now on instead of training on.
+        h->aborted = true;
+        fail(MI355REC_E_HIP, "SLIM-BPR: a hand-off between steps did not arrive (dataflow kernel aborted); S holds part of an epoch -- this handle "
+                             "refuses further calls, create a new one");
+    }
     if (L.profile) {
         std::vector<unsigned long long> c(h->prof.count);
         MI_HIP(hipMemcpy(c.data(), h->prof.ptr, sizeof(unsigned long long) * c.size(), hipMemcpyDeviceToHost));
@@ -2036,7 +2048,12 @@ void run_epoch_stream(mi355rec_slim *h, StreamSet &st, int n, double &sum_profil
     }
 }
 
+void require_consistent(const mi355rec_slim *h) {
+    if (h->aborted) fail(MI355REC_E_HIP, "SLIM-BPR: an earlier call on this handle was aborted inside an epoch; its model is inconsistent -- create a new handle");
+}
+
 void begin_call(mi355rec_slim *h) {
+    require_consistent(h);
     MI_HIP(hipMemsetAsync(h->loss_slots.ptr, 0, sizeof(double) * LOSS_SLOTS, h->stream));
     h->dispatch_timers.reset();
     h->stats = mi355rec_stats{};
@@ -2378,6 +2395,7 @@ extern "C" int mi355rec_slim_get_last_samples(mi355rec_slim_t h, int32_t *u, int
 extern "C" int mi355rec_slim_get_S_topk(mi355rec_slim_t h, int32_t topK, int32_t *nbr_idx, float *nbr_val) {
     return guarded([&] {
         MI_REQUIRE(h && nbr_idx && nbr_val, "NULL argument");
+        require_consistent(h);
         MI_REQUIRE(topK >= 1, "topK must be >= 1 (use mi355rec_slim_get_S_dense for the full matrix)");
         ensure_device();
         topK = std::min(topK, h->n_items);
@@ -2390,6 +2408,7 @@ extern "C" int mi355rec_slim_get_W_csr(mi355rec_slim_t h, int32_t topK, int32_t 
                                        float *data, int64_t *nnz) {
     return guarded([&] {
         MI_REQUIRE(h && indptr && indices && data && nnz, "NULL argument");
+        require_consistent(h);
         MI_REQUIRE(topK >= 1, "topK must be >= 1");
         ensure_device();
         ReleaseScope scope(h->stream, h->side);
@@ -2405,6 +2424,7 @@ extern "C" int mi355rec_slim_get_W_csr(mi355rec_slim_t h, int32_t topK, int32_t 
 extern "C" int mi355rec_slim_get_S_sparse(mi355rec_slim_t h, int32_t *nbr_idx, float *nbr_val) {
     return guarded([&] {
         MI_REQUIRE(h && nbr_idx && nbr_val, "NULL argument");
+        require_consistent(h);
         MI_REQUIRE(h->cfg.train_with_sparse_weights && h->cfg.topK >= 1, "handle was not created with train_with_sparse_weights and topK >= 1");
         ensure_device();
         const int width = h->cfg.topK;
@@ -2427,6 +2447,7 @@ extern "C" int mi355rec_slim_get_S_sparse(mi355rec_slim_t h, int32_t *nbr_idx, f
 extern "C" int mi355rec_slim_get_S_dense(mi355rec_slim_t h, float *S) {
     return guarded([&] {
         MI_REQUIRE(h && S, "NULL argument");
+        require_consistent(h);
         ensure_device();
         if (h->f64) get_dense_typed<double>(h, S); else get_dense_typed<float>(h, S);
     });

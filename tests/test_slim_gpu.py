@@ -545,3 +545,28 @@ def test_device_column_selection_equals_similarityMatrixTopK(gpu, symmetric):
     finally:
         del os.environ["MI355REC_SLIM_HOST_TOPK"]
     assert (rec.W_sparse != ref.W_sparse).nnz == 0 and (rec.S_incremental != ref.S_incremental).nnz == 0
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_a_handle_whose_epoch_was_aborted_refuses_further_calls(gpu, monkeypatch, symmetric):
+    """A dataflow launch that gives up on a hand-off leaves S with part of an epoch applied and no record of which part (there is no copy
+    of the n_items^2 cells to roll back to): the call fails, and from then on the handle refuses to train on or to hand the model out --
+    it does not continue silently.  The abort flag is raised through the library's test hook before the first step looks at it."""
+    from recsys2019_deeplearning_evaluation_amd._native import NativeLibraryError
+    X = named_urm("ml1m", "binary", scale=0.2)
+    dev = SLIM_BPR_MI355X_Epoch(X, symmetric=symmetric, topK=10, final_model_sparse_weights=True, sgd_mode="adagrad", learning_rate=0.05, random_seed=5)
+    dev.epochIteration_Cython(1)
+    assert dev.get_S().nnz > 0
+    monkeypatch.setenv("MI355REC_SLIM_INJECT_ABORT", "1")
+    with pytest.raises(NativeLibraryError, match="aborted"):
+        dev.epochIteration_Cython(1)
+    monkeypatch.delenv("MI355REC_SLIM_INJECT_ABORT")
+    for call in (lambda: dev.epochIteration_Cython(1), dev.get_S, lambda: dev.get_S_slabs(10)):
+        with pytest.raises(NativeLibraryError, match="inconsistent"):
+            call()
+    dev.close()
+    # a fresh handle on the same device trains as if nothing had happened
+    again = SLIM_BPR_MI355X_Epoch(X, symmetric=symmetric, topK=10, final_model_sparse_weights=True, sgd_mode="adagrad", learning_rate=0.05, random_seed=5)
+    again.epochIteration_Cython(2)
+    assert again.get_S().nnz > 0
+    again.close()
