@@ -2219,6 +2219,29 @@ void run_columns_lds(mi355rec_sim *h, int32_t start, int32_t end, int *d_idx, fl
                 legacy_cost += h->cost[c];
             }
         }
+        // HEAVY columns gain nothing from the packed launch -- what it offers is a second workgroup's accumulation beside a column's
+        // selection phases, and a heavy column is nearly all accumulation, on workgroups of 8 wavefronts instead of 16 (the 8 heaviest
+        // columns of an 8-way part of the ML-20M shape: 0.37 ms packed against 0.125 ms; 504 columns of 0.93 M pair-adds: 0.245 against
+        // 0.204 ms; 715 of 0.26 M: 0.102 against 0.115 ms -- packed wins).  Heavy = more than a quarter of a packed workgroup's fair share
+        // of the call, and at least 0.5 M pair-adds.  Where such columns are a large share of the call (a part of an 8-way build: 60 %
+        // of its pair-adds; the whole shape: 14 %, where a second launch of that size only adds a tail -- measured 3.05 against 3.00 ms)
+        // they go to the 32-bit launch behind this one: slowest part of 8 0.56 -> 0.45-0.47 ms, identical output.
+        // MI355REC_SIM_PACKED_DEMOTE=0 / 1 forces it off / on.
+        {
+            const long long heavy = std::max<long long>(500000, packed_cost / ((long long)packed_grid * 4));
+            long long heavy_cost = 0;
+            for (int c : h->cost_order)
+                if (in_call(c) && is_packed[(size_t)c] && h->cost[c] > heavy) heavy_cost += h->cost[c];
+            const char *dm = getenv("MI355REC_SIM_PACKED_DEMOTE");
+            const bool demote = dm ? atoi(dm) != 0 : (double)heavy_cost >= 0.4 * (double)packed_cost;
+            if (demote)
+                for (int c : h->cost_order) {
+                    if (!in_call(c) || !is_packed[(size_t)c] || h->cost[c] <= heavy) continue;
+                    is_packed[(size_t)c] = 0;
+                    packed_cost -= h->cost[c];
+                    legacy_cost += h->cost[c];
+                }
+        }
         // its heavy columns are split like the 32-bit kernel's: a part is at most 1/4 of a workgroup's fair share (its workgroups have
         // 8 wavefronts: an unsplit column of 1/2 share kept one of them busy for a third of the launch)
         const long long plimit = std::max<long long>(1, packed_cost / ((long long)packed_grid * 4));
