@@ -134,9 +134,9 @@ LINK_BYTES_PER_SECOND = 50e9
 def default_chunks(part_pairs, slab_bytes, world, exchange):
     """Pieces per part: 4 where the exchange is long next to the kernel that could hide it, else 1.
 
-    Building a part in pieces costs kernel time (ML-20M shape, 8 parts: 0.60 ms in four pieces against 0.54 ms in one go; Netflix shape,
+    Building a part in pieces costs kernel time (ML-20M shape, 8 parts: 0.58 ms in four pieces against 0.47 ms in one go; Netflix shape,
     equal counts: 2.6 against 2.16 ms), so it only pays where the exchange it hides is longer than that: a ring all-gather moves
-    (world - 1) slabs over one link (0.33 ms against 0.54 ms of kernel at ML-20M shape: pieces; 0.24 against 2.2 ms at Netflix shape:
+    (world - 1) slabs over one link (0.33 ms against 0.47 ms of kernel at ML-20M shape: pieces; 0.24 against 2.2 ms at Netflix shape:
     one go), a gather to one rank a single slab per link (0.09 ms: one go at both shapes)."""
     if world <= 1:
         return 1
