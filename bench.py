@@ -810,7 +810,7 @@ def compact_line(out):
     for name, row in out.get("paths", {}).items():
         if row.get("value") is None:
             continue
-        rows[name] = _slim(row, ("value", "unit", "bound", "frac", "cpu_value", "cpu_kind", "build_s", "fit_resident_s", "predicted_8_gpu_one_ring"))
+        rows[name] = _slim(row, ("value", "unit", "bound", "frac", "cpu_value", "cpu_kind", "build_s", "fit_resident_s", "build_gather_to_rank0_s", "predicted_8_gpu_one_ring"))
         if isinstance(rows[name].get("bound"), str):
             rows[name]["bound"] = rows[name]["bound"].split(" ")[0]
     line["paths"] = rows
@@ -1128,6 +1128,28 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
     t2 = time.perf_counter()
     idx, val = job.download() if rank == 0 else (None, None)
     download_s = time.perf_counter() - t2
+    # north_star's wording of the exchange -- "a final RCCL gather": only rank 0 ends with every column (sharding exchange="gather": each
+    # peer sends its slab over its own xGMI link) -- timed next to the all-gather above, whichever of the two this block's headline figure is
+    other_s = other_err = None
+    other_kind = "allgather" if job.root is not None else "gather"
+    if world > 1 and os.environ.get("BENCH_SIM_BOTH_EXCHANGES", "1") != "0":
+        try:
+            job2 = ShardedSimilarityBuild(sim, net.dist, rank, world, net.comm, exchange=other_kind)
+            for rep in range(3):
+                net.barrier()
+                t1 = time.perf_counter()
+                job2.build()
+                net.barrier()
+                dt = net.max(time.perf_counter() - t1)
+                if rep > 0 and (other_s is None or dt < other_s):
+                    other_s = dt
+            if rank == 0 and idx is not None:
+                idx2, val2 = job2.download()
+                if not (np.array_equal(idx2, idx) and np.array_equal(val2, val)):
+                    other_err = "the two exchanges assembled different results"
+            job2.close()
+        except Exception as exc:                      # (recorded, not fatal: the all-gather figure above stands)
+            other_err = repr(exc)
     sst = sim.stats()
     # the bound of the accumulation, measured on THIS device in THIS run (the round-1 microbenchmark figure is the fall-back)
     global LDS_ATOMIC_PEAK
@@ -1158,6 +1180,8 @@ def itemknn_section(urm, net, args, extra, key="itemknn"):
         "download_to_host_rank0_s": download_s,
         "topK": TOPK, "columns_this_rank": int(len(my_columns)), "kernel_ms_this_rank": kernel_ms,
         "exchange_bytes_per_rank": job.exchange_bytes_per_rank(),
+        "cosine_build_other_exchange_s": other_s, "other_exchange": None if world == 1 else ("gather to rank 0" if other_kind == "gather" else "all-gather"),
+        "other_exchange_error": other_err,
         "exchange": "none" if world == 1 else ("%s of %d cost-sized pieces, %s" % ("gather to rank 0" if job.root is not None else "all-gather", len(job.rows),
                                                 "6-byte cells (float32 value + 16-bit id)" if job.packed else "8-byte cells")),
         "transport": "none" if world == 1 else ("rccl-ctypes" if net.comm is not None else "torch." + net.dist.get_backend()),
@@ -1470,7 +1494,7 @@ def main():
     if "itemknn" in out["extra"]:
         ik = out["extra"]["itemknn"]
         table["itemknn_cosine_top100"] = {"value": ik.get("fit_incl_pcie_upload_s"), "unit": "s (upload + constructor + build)", "build_s": ik.get("cosine_build_s"),
-                                          "fit_resident_s": ik.get("fit_resident_s"),
+                                          "fit_resident_s": ik.get("fit_resident_s"), "build_gather_to_rank0_s": ik.get("cosine_build_other_exchange_s"),
                                           "bound": "lds-atomics", "frac": ik.get("roofline", {}).get("frac"),
                                           "cpu_value": (ik.get("cpu_baseline") or {}).get("value"), "cpu_kind": (ik.get("cpu_baseline") or {}).get("kind")}
     nf = out["extra"].get("itemknn_netflix_config4")
@@ -1478,7 +1502,8 @@ def main():
         e8 = nf.get("emulated_8_way", {})
         table["itemknn_cosine_top100_netflix_shape_config4"] = {
             "value": nf.get("fit_incl_pcie_upload_s"), "unit": "s (upload + constructor + build)", "build_s": nf.get("cosine_build_s"),
-            "fit_resident_s": nf.get("fit_resident_s"), "predicted_8_gpu_one_ring": (e8.get("predicted_build_speedup") or {}).get("one_ring"),
+            "fit_resident_s": nf.get("fit_resident_s"), "build_gather_to_rank0_s": nf.get("cosine_build_other_exchange_s"),
+            "predicted_8_gpu_one_ring": (e8.get("predicted_build_speedup") or {}).get("one_ring"),
             "bound": "lds-atomics", "frac": nf.get("roofline", {}).get("frac"),
             "emulated_8_way_kernel_speedup": e8.get("kernel_speedup_vs_1gpu"),
             "predicted_8_gpu_build_speedup": e8.get("predicted_build_speedup"),
