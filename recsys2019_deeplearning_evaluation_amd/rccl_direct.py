@@ -177,20 +177,17 @@ class RcclCommunicator:
 
     def gather_words_async(self, send_address, recv_address, n_words, root):
         """recv[r * n_words : (r + 1) * n_words] on rank `root` = rank r's send[0 : n_words]; nothing is written elsewhere (recv_address is
-        ignored there).  One group of point-to-point transfers: every other rank sends to the root over its own xGMI link, the root
-        posts world - 1 receives and copies its own piece on the device.  Enqueued only (null stream), like all_gather_words_async."""
+        ignored there).  One group of point-to-point transfers: every rank sends to the root over its own xGMI link, the root posts
+        `world` receives -- its own piece included (a send to oneself inside the group of its receive, the pattern of an all-to-all):
+        nothing here blocks the host.  Enqueued only (null stream), like all_gather_words_async."""
         self._check(self._lib.ncclGroupStart(), "ncclGroupStart")
         try:
             if self.rank == root:
                 for r in range(self.world):
-                    if r != root:
-                        self._check(self._lib.ncclRecv(C.c_void_p(recv_address + 4 * r * n_words), n_words, NCCL_INT32, r, self._comm, None), "ncclRecv")
-            else:
-                self._check(self._lib.ncclSend(C.c_void_p(send_address), n_words, NCCL_INT32, root, self._comm, None), "ncclSend")
+                    self._check(self._lib.ncclRecv(C.c_void_p(recv_address + 4 * r * n_words), n_words, NCCL_INT32, r, self._comm, None), "ncclRecv")
+            self._check(self._lib.ncclSend(C.c_void_p(send_address), n_words, NCCL_INT32, root, self._comm, None), "ncclSend")
         finally:
             self._check(self._lib.ncclGroupEnd(), "ncclGroupEnd")
-        if self.rank == root:
-            N.check(N.load().mi355rec_device_memcpy(C.c_void_p(recv_address + 4 * root * n_words), C.c_void_p(send_address), 4 * n_words, 2))
 
     def synchronize(self):
         N.check(N.load().mi355rec_device_synchronize())

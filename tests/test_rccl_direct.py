@@ -94,6 +94,12 @@ N.check(N.load().mi355rec_device_memcpy(a.ptr, N.ptr(src), 4000, 1))
 comm.all_gather_words(a.address(), b.address(), 1000)
 assert (b.to_host() == src).all()
 print("RCCL single-rank all-gather ran: ncclCommCount = %%d" %% comm.count())
+# the gather of the sharded similarity build: one group of ncclSend / ncclRecv, the root's own piece as a send to itself
+c = N.DeviceArray(1000)
+comm.gather_words_async(a.address(250), c.address(), 750, 0)
+comm.synchronize()
+assert (c.to_host()[:750] == src[250:]).all()
+print("RCCL single-rank gather (send / recv group) ran")
 comm.close()
 """
 
@@ -118,6 +124,7 @@ def test_single_rank_rccl_communicator_all_gather(gpu):
             ln[-160:] for ln in (r.stdout + r.stderr).strip().splitlines()[-6:]))
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     assert "RCCL single-rank all-gather ran: ncclCommCount = 1" in r.stdout
+    assert "RCCL single-rank gather (send / recv group) ran" in r.stdout
 
 
 @pytest.mark.gpu
