@@ -127,6 +127,52 @@ def test_packed_exchange_cells_on_the_device(gpu):
     job.close(); sim.close()
 
 
+def test_parts_at_ml20m_shape_with_heavy_columns_routed_to_the_32_bit_launch(gpu, monkeypatch):
+    """At the ML-20M shape the heavy columns of an 8-way part are 60 % of its pair-adds: the packed-counts call hands them to the 32-bit launch
+    behind it (sim.hip, run_columns_lds: MI355REC_SIM_PACKED_DEMOTE).  Parts 0 and 7 built with that rule (the default), with it forced
+    off, and without the packed kernel at all are identical cell for cell -- whole and in the pieces the sharded build cuts them into --
+    and the schedule shows that the rule fired (fewer split columns in the packed call); the whole-shape build does not use it."""
+    import numpy as np
+    from recsys2019_deeplearning_evaluation_amd import Compute_Similarity_MI355X
+    from recsys2019_deeplearning_evaluation_amd._native import DeviceArray
+    from recsys2019_deeplearning_evaluation_amd.sharding import cost_sized_pieces, FIXED_PAIRS_PER_CELL
+    from recsys2019_deeplearning_evaluation_amd.synthetic import named_urm
+    X = named_urm("ml20m", "binary")
+    n, G, topK = X.shape[1], 8, 100
+    w = -(-n // G)
+    buf = DeviceArray(2 * w * topK)
+    results, schedules = {}, {}
+    for tag, env in (("rule", {}), ("rule off", {"MI355REC_SIM_PACKED_DEMOTE": "0"}), ("32-bit only", {"MI355REC_SIM_PACKED": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sim = Compute_Similarity_MI355X(X, topK=topK, shrink=0, normalize=True, similarity="cosine")
+        out = []
+        for part in (0, 7):
+            sim.compute_part_device(part, G, buf.address(), buf.address(w * topK))
+            sim.synchronize()
+            out.append(buf.to_host().copy())
+            schedules[(tag, part)] = sim.schedule_info()
+        cost = np.asarray(sim.column_costs(), np.float64)
+        cols0 = sim.part_columns(0, G)
+        row_cost = np.zeros(w); row_cost[:len(cols0)] = cost[cols0] + FIXED_PAIRS_PER_CELL * n
+        for r0, r1 in cost_sized_pieces(row_cost, 4):
+            cnt = min(r1, len(cols0)) - r0
+            sim.compute_part_chunk_device(0, G, r0, cnt, buf.address(), buf.address(cnt * topK))
+            sim.synchronize()
+            out.append(buf.to_host()[:2 * cnt * topK].copy())
+        results[tag] = out
+        sim.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    for tag in ("rule off", "32-bit only"):
+        assert len(results[tag]) == len(results["rule"])
+        for a, b in zip(results["rule"], results[tag]):
+            assert np.array_equal(a, b), "parts differ between the heavy-column rule and '%s'" % tag
+    # (work items, split columns, parts): with the rule the packed call splits nothing heavy, the 32-bit launch's own limit applies
+    assert schedules[("rule", 0)] != schedules[("rule off", 0)] and schedules[("rule", 0)][1] < schedules[("rule off", 0)][1]
+    buf.close()
+
+
 def test_interleaved_parts_on_one_gpu(gpu):
     """The 8-way interleaved partition, part after part on one device: equal counts, equal cost, and the parts put together are the
     single build bit for bit; the host restatement of the partition (sharding.interleaved_parts) names the same columns."""
