@@ -397,6 +397,16 @@ __device__ __forceinline__ bool wave_wait_mail(const SlimParams<T> &p, unsigned 
     }
 }
 
+// A `volatile T *` into LDS that has lost its address space on the way (a function argument, the address of a __shared__ member) is
+// read and written with flat_load / flat_store ... sc0 sc1, each behind an s_waitcnt vmcnt(0): the access goes down the vector-memory
+// path, waits for every outstanding global load of the wavefront, and takes several hundred cycles -- found in round 6 on the turn word
+// and the optimiser cells of an owned row, i.e. four such round trips inside every turn of the busiest row's chain.  The low 32 bits of
+// a generic address inside the shared aperture are the LDS offset: through this cast the same accesses are ds_read / ds_write.
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(3))) volatile T *as_lds(volatile T *q) {
+    return (__attribute__((address_space(3))) volatile T *)(uintptr_t)(unsigned)(unsigned long long)q;
+}
+
 __device__ __forceinline__ unsigned long long shader_clock() {   // not reordered against memory operations
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -406,14 +416,9 @@ __device__ __forceinline__ unsigned long long shader_clock() {   // not reordere
 // Next step of the in-order queue for this wavefront (NO_STEP: the queue is empty or the launch is being abandoned).  The chunks are
 // fetched in the order of their generations, so what a workgroup holds is always a prefix of what it will hold: a step it has not
 // handed out yet can only be waited for by steps it has not handed out either.
-template <class T>
-__device__ __forceinline__ int claim_step(const SlimParams<T> &p, LocalQueue *lq, const int lane) {
-    int k = 0;
-    if (lane == 0) k = atomicAdd(&lq->next, 1);
-    k = __builtin_amdgcn_readfirstlane(k);
+template <class T, class ReadyPtr, class BasesPtr>
+__device__ __forceinline__ int claim_step_on(const SlimParams<T> &p, const int lane, const int k, ReadyPtr ready, BasesPtr bases) {
     const int gen = k / LQ_CHUNK, off = k % LQ_CHUNK;
-    volatile int *ready = &lq->ready;
-    volatile int *bases = lq->base;
     SpinGuard sg;
     unsigned spins = 0;
     if (off == 0) {
@@ -436,6 +441,18 @@ __device__ __forceinline__ int claim_step(const SlimParams<T> &p, LocalQueue *lq
         return NO_STEP;
     }
     return base >= NO_STEP - LQ_CHUNK ? NO_STEP : base + off;
+}
+// LDS_POLLS: the queue's two LDS words read and written as ds_read / ds_write (as_lds) instead of through the generic volatile pointers'
+// flat_load ... sc0 sc1.  The dense store's cold steps want it (a poll comes back four times as fast, a claimed step starts sooner:
+// epoch 1.77 -> 1.58-1.63 ms); the symmetric store's wavefronts, which ALL pass through here and are bound by the chain behind it,
+// do not (10.4 -> 11.1 ms: the faster polls take issue slots from the wavefronts that work) -- both measured in round 6.
+template <bool LDS_POLLS, class T>
+__device__ __forceinline__ int claim_step(const SlimParams<T> &p, LocalQueue *lq, const int lane) {
+    int k = 0;
+    if (lane == 0) k = atomicAdd(&lq->next, 1);
+    k = __builtin_amdgcn_readfirstlane(k);
+    if constexpr (LDS_POLLS) return claim_step_on(p, lane, k, as_lds((volatile int *)&lq->ready), as_lds((volatile int *)lq->base));
+    else return claim_step_on(p, lane, k, (volatile int *)&lq->ready, (volatile int *)lq->base);
 }
 
 // The sigmoid and the optimiser step of an OWNED row's step sit on the critical path of the whole epoch (the turn of the busiest
@@ -592,8 +609,10 @@ __device__ __forceinline__ void cold_step(const SlimParams<T> &p, const StepDesc
 constexpr int OWN_IDS = 16;
 
 template <class T>
-__device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, float *row, volatile int *turn, volatile double *oc,
+__device__ __forceinline__ void owned_row(const SlimParams<T> &p, const int h, float *row, volatile int *turn_generic, volatile double *oc_generic,
                                           const int lane, const int wave) {
+    auto turn = as_lds(turn_generic);
+    auto oc = as_lds(oc_generic);
     const int item = p.hot_item[h], first = p.lst_begin[h], len = p.lst_len[h];
     const size_t n = (size_t)p.n_items;
     const float lr = (float)p.lr, li_reg = (float)p.li_reg, lj_reg = (float)p.lj_reg;
@@ -816,7 +835,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void slim_dense_flow_kernel(const Sli
     __syncthreads();
     const int n_cold = *p.n_cold;
     for (;;) {          // in-order queue: everything a step can wait for is already running
-        const int q = claim_step(p, &s_queue, lane);
+        const int q = claim_step<true>(p, &s_queue, lane);
         if (q >= n_cold) break;
         cold_step(p, p.cold_desc[q], lane);
     }
@@ -1101,7 +1120,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void slim_sym_flow_kernel(const SlimP
         }
     }
     for (;;) {          // in-order queue: everything a step can wait for is already running
-        const int q = claim_step(p, &s_queue, lane);
+        const int q = claim_step<false>(p, &s_queue, lane);
         if (q >= p.n_short) break;
         sym_step(p, p.order[q], lane);
     }

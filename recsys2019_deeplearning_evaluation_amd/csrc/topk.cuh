@@ -14,6 +14,18 @@ constexpr uint32_t ZERO_KEY = 0x80000000u;
 constexpr int AUX_WORDS = 8192;  // 32 KiB: 256 bins x 32 bank replicas, later re-used as the candidate buffer
 constexpr int MAX_TOPK = 4096;   // AUX_WORDS * 4 B / 8 B per candidate
 
+// The selection routines below work on LDS arrays, but block_topk_emit is big enough to stay an out-of-line function, and inside an
+// out-of-line function a `float *` is a generic pointer: every access to the accumulator, the histogram and the scratch words was a
+// flat_load / flat_store / flat_atomic (117 of them, found in round 6) -- the vector-memory path to LDS, several times the latency of
+// ds_read / ds_write and tied to the wavefront's outstanding global loads.  The low 32 bits of a generic address inside the shared
+// aperture are the LDS offset: the routines take LDS-typed pointers, the public entry points cast once.
+#define MI355REC_LDS __attribute__((address_space(3)))
+template <class T> __device__ __forceinline__ MI355REC_LDS T *lds_of(T *q) { return (MI355REC_LDS T *)(uintptr_t)(unsigned)(unsigned long long)q; }
+typedef float lds_f4 __attribute__((ext_vector_type(4)));      // (HIP's float4 class has no constructor from an address-space-qualified lvalue)
+__device__ __forceinline__ uint32_t lds_add(MI355REC_LDS uint32_t *q, uint32_t v) {
+    return __hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // Order-preserving map float -> uint32 (larger float <=> larger key); +0.0 maps to ZERO_KEY.
 __device__ __forceinline__ uint32_t float_key(float v) {
     uint32_t b = __float_as_uint(v);
@@ -42,8 +54,8 @@ struct SelectScratch {
 // `vals` (LDS, readable up to the next multiple of 4) is scanned four cells per thread and step; kf(j, v, key) maps
 // cell j with value v to its key and says whether it takes part.
 template <int THREADS, class KeyFn>
-__device__ bool block_select(KeyFn kf, const float *vals, int n, uint32_t want, uint32_t virt_key, uint32_t virt_cnt, uint32_t *hist,
-                             SelectScratch &sc, uint32_t key_lo, uint32_t key_hi, uint32_t cap, uint32_t &T,
+__device__ bool block_select(KeyFn kf, MI355REC_LDS const float *vals, int n, uint32_t want, uint32_t virt_key, uint32_t virt_cnt,
+                             MI355REC_LDS uint32_t *hist, MI355REC_LDS SelectScratch &sc, uint32_t key_lo, uint32_t key_hi, uint32_t cap, uint32_t &T,
                              uint32_t &need_eq, uint32_t &eq_total) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t want0 = want;
@@ -55,14 +67,14 @@ __device__ bool block_select(KeyFn kf, const float *vals, int n, uint32_t want, 
         const int width = min(8, remaining), shift = remaining - width;
         const uint32_t mask = (1u << width) - 1u;
         for (int w = tid; w < (n + 3) / 4; w += THREADS) {
-            const float4 q = reinterpret_cast<const float4 *>(vals)[w];
+            const lds_f4 q = ((MI355REC_LDS const lds_f4 *)vals)[w];
             const float vv[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int j = 4 * w + e;
                 uint32_t key;
                 if (j < n && kf(j, vv[e], key) && (uint32_t)((uint64_t)key >> remaining) == prefix)
-                    atomicAdd(&hist[((key >> shift) & mask) * 32 + (lane & 31)], 1u);
+                    lds_add(&hist[((key >> shift) & mask) * 32 + (lane & 31)], 1u);
             }
         }
         __syncthreads();
@@ -111,7 +123,7 @@ __device__ bool block_select(KeyFn kf, const float *vals, int n, uint32_t want, 
 }
 
 template <int THREADS>
-__device__ void bitonic_sort_desc(uint64_t *a, int P) {
+__device__ void bitonic_sort_desc(MI355REC_LDS uint64_t *a, int P) {
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = threadIdx.x; t < P; t += THREADS) {
@@ -136,8 +148,8 @@ __device__ void bitonic_sort_desc(uint64_t *a, int P) {
 // the tail with (-1, 0).  Counting rank (every candidate counts the candidates above it: keys carry the index, so ranks are a
 // permutation) up to 1024 candidates, a bitonic sort above that.  sc.out_count must be 0 on entry (barrier in between).
 template <int THREADS>
-__device__ void block_rank_emit(uint64_t *cand, int ncand, int topK, uint32_t K, uint32_t nzero, SelectScratch &sc, int *out_idx,
-                                float *out_val, int idx_offset = 0, const int *idx_map = nullptr) {
+__device__ void block_rank_emit_lds(MI355REC_LDS uint64_t *cand, int ncand, int topK, uint32_t K, uint32_t nzero, MI355REC_LDS SelectScratch &sc, int *out_idx,
+                                    float *out_val, int idx_offset = 0, const int *idx_map = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63;
     // rank r (0 = largest) is emitted when it falls inside the top K of [positives, the competing zeros, negatives]
     auto emit = [&](uint64_t e, int r) {
@@ -179,13 +191,18 @@ __device__ void block_rank_emit(uint64_t *cand, int ncand, int topK, uint32_t K,
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) emitted += __shfl_down(emitted, off);
-    if (lane == 0 && emitted) atomicAdd(&sc.out_count, emitted);
+    if (lane == 0 && emitted) lds_add(&sc.out_count, emitted);
     __syncthreads();
     for (int t = (int)sc.out_count + tid; t < topK; t += THREADS) {
         out_idx[t] = -1;
         if (out_val) out_val[t] = 0.f;
     }
     __syncthreads();   // sc and aux may be re-used by the caller's next column
+}
+template <int THREADS>
+__device__ __forceinline__ void block_rank_emit(uint64_t *cand, int ncand, int topK, uint32_t K, uint32_t nzero, SelectScratch &sc, int *out_idx,
+                                                float *out_val, int idx_offset = 0, const int *idx_map = nullptr) {
+    block_rank_emit_lds<THREADS>(lds_of(cand), ncand, topK, K, nzero, *lds_of(&sc), out_idx, out_val, idx_offset, idx_map);
 }
 
 // The 16 leading bits of the K-th largest (1-based) of the THREADS keys the threads of the block hold, one each: returns P such that
@@ -351,6 +368,9 @@ __device__ void block_topk_emit(const float *acc, int n, int topK, uint32_t npos
                                 int idx_offset = 0, const int *idx_map = nullptr, long long zero_count = -1,
                                 uint32_t key_lo = 0u, uint32_t key_hi = 0xFFFFFFFFu) {
     const int tid = threadIdx.x, lane = tid & 63;
+    MI355REC_LDS const float *const acc_l = lds_of(acc);
+    MI355REC_LDS uint32_t *const aux_l = lds_of(aux), *const ncand_l = lds_of(ncand_shared);
+    MI355REC_LDS SelectScratch &sc_l = *lds_of(&sc);
     const bool zeros_compete = mode == TOPK_ZEROS_COMPETE;
     const uint32_t nzero = zeros_compete ? (zero_count >= 0 ? (uint32_t)zero_count : (uint32_t)n - npos - nneg) : 0u;
     uint32_t K = (uint32_t)topK;
@@ -361,7 +381,7 @@ __device__ void block_topk_emit(const float *acc, int n, int topK, uint32_t npos
     }
     const uint32_t cap = (uint32_t)min(AUX_WORDS / 2, max(256, 2 * topK));
     uint32_t T = ZERO_KEY, need_eq = 0, eq_total = 0;
-    if (tid == 0) sc.out_count = 0;
+    if (tid == 0) sc_l.out_count = 0;
     // all positives fit and no negative can displace a zero: nothing to select
     bool take_all = zeros_compete ? (npos <= K && (nneg == 0 || npos + nzero >= K)) : (npos + nneg <= K);
     if (!zeros_compete && take_all) T = 0u;                      // every candidate key is > 0
@@ -375,7 +395,7 @@ __device__ void block_topk_emit(const float *acc, int n, int topK, uint32_t npos
         superset = true;                                         // few enough positives: rank them all
         T = max(key_lo, ZERO_KEY + 1u);                          // positives only
     } else if (!take_all) {
-        superset = block_select<THREADS>(value_key, acc, n, K, ZERO_KEY, nzero, aux, sc, key_lo, key_hi, cap, T, need_eq, eq_total);
+        superset = block_select<THREADS>(value_key, acc_l, n, K, ZERO_KEY, nzero, aux_l, sc_l, key_lo, key_hi, cap, T, need_eq, eq_total);
         if (!superset && zeros_compete && T == ZERO_KEY) need_eq = 0;          // zeros are never emitted
     }
     uint32_t T2 = 0;  // tie-break on the index when more cells equal T than fit: lowest index wins
@@ -386,17 +406,17 @@ __device__ void block_topk_emit(const float *acc, int n, int topK, uint32_t npos
             key = ~(uint32_t)j;
             return candidate(v) && float_key(v) == T;
         };
-        block_select<THREADS>(index_key, acc, n, need_eq, 0u, 0u, aux, sc, 0u, 0xFFFFFFFFu, 0u, T2, dummy_need, dummy_tot);
+        block_select<THREADS>(index_key, acc_l, n, need_eq, 0u, 0u, aux_l, sc_l, 0u, 0xFFFFFFFFu, 0u, T2, dummy_need, dummy_tot);
     }
     __syncthreads();
     // ---- candidates -> aux as (key << 32 | ~index); slots are handed out per wavefront (one LDS atomic per wave) ----
-    uint64_t *cand = reinterpret_cast<uint64_t *>(aux);
+    MI355REC_LDS uint64_t *cand = (MI355REC_LDS uint64_t *)aux_l;
     constexpr int CAND_MAX = AUX_WORDS / 2;
     for (int w0 = 0; w0 < (n + 3) / 4; w0 += THREADS) {
         const int w = w0 + tid;
         float vv[4] = {0.f, 0.f, 0.f, 0.f};
         if (4 * w < n) {
-            const float4 q = reinterpret_cast<const float4 *>(acc)[w];
+            const lds_f4 q = ((MI355REC_LDS const lds_f4 *)acc_l)[w];
             vv[0] = q.x; vv[1] = q.y; vv[2] = q.z; vv[3] = q.w;
         }
 #pragma unroll
@@ -410,7 +430,7 @@ __device__ void block_topk_emit(const float *acc, int n, int topK, uint32_t npos
             if (m) {
                 const int leader = __ffsll((long long)m) - 1;
                 uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(ncand_shared, (uint32_t)__popcll(m));
+                if (lane == leader) base = lds_add(ncand_l, (uint32_t)__popcll(m));
                 base = __shfl(base, leader);
                 if (take) {
                     const uint32_t slot_c = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -420,8 +440,8 @@ __device__ void block_topk_emit(const float *acc, int n, int topK, uint32_t npos
         }
     }
     __syncthreads();
-    const int ncand = min((int)*ncand_shared, CAND_MAX);
-    block_rank_emit<THREADS>(cand, ncand, topK, K, zeros_compete ? nzero : 0u, sc, out_idx, out_val, idx_offset, idx_map);
+    const int ncand = min((int)*ncand_l, CAND_MAX);
+    block_rank_emit_lds<THREADS>(cand, ncand, topK, K, zeros_compete ? nzero : 0u, sc_l, out_idx, out_val, idx_offset, idx_map);
 }
 
 }  // namespace mi355rec
