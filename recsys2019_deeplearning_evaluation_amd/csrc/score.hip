@@ -173,17 +173,59 @@ __global__ __launch_bounds__(THREADS) void score_rank_kernel(const RankParams p)
         __syncthreads();
     }
     uint32_t nfin = 0;
+    float tmax = -INFINITY;         // this thread's largest score (threshold-first selection below)
     for (int j = tid; j < p.n_items; j += THREADS) {
         const float v = acc[j];
         nfin += v > -INFINITY;
+        tmax = fmaxf(tmax, v);
         if (p.write_back) row[j] = v;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nfin += __shfl_down(nfin, off);
     if (lane == 0 && nfin) atomicAdd(&s_nfinite, nfin);
+    for (int w = tid; w < 256; w += THREADS) aux[w] = 0;           // (the bins of block_kth_largest_prefix16)
     __syncthreads();
-    block_topk_emit<THREADS>(acc, p.n_items, p.cutoff, s_nfinite, 0u, TOPK_FINITE, aux, sc, &s_ncand,
-                             p.ranked + (size_t)b * p.cutoff, nullptr);
+    int *out = p.ranked + (size_t)b * p.cutoff;
+    // THRESHOLD-FIRST (round 6; the similarity build's selection, csrc/sim.hip): the cutoff largest scores are all >= the cutoff-th
+    // largest of the THREADS thread maxima (the cutoff largest maxima are cutoff different cells), so one 16-bit radix select over
+    // THREADS keys gives a bound, one pass over the row collects the cells at or above it -- a few times `cutoff` of them -- and those
+    // are ranked exactly (ties towards the lower item, as before).  The full radix select over the row (block_topk_emit: two or three
+    // passes of LDS atomics over n_items cells) remains for rows with fewer finite scores than the cutoff, cut-offs that are not small
+    // next to the number of maxima, and a candidate list that overflows.
+    if (s_nfinite >= (uint32_t)p.cutoff && 4 * p.cutoff <= THREADS) {
+        const uint32_t prefix = block_kth_largest_prefix16<THREADS>(float_key(tmax), (uint32_t)p.cutoff, aux, sc);
+        const uint32_t T = prefix << 16;
+        if (tid == 0) sc.out_count = 0;
+        uint64_t *cand = reinterpret_cast<uint64_t *>(aux);
+        constexpr int CAND_MAX = AUX_WORDS / 2;
+        for (int j0 = 0; j0 < p.n_items; j0 += THREADS) {
+            const int j = j0 + tid;
+            const float v = j < p.n_items ? acc[j] : -INFINITY;
+            const uint32_t key = float_key(v);
+            const bool take = v > -INFINITY && key >= T;
+            const unsigned long long m = __ballot(take);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&s_ncand, (uint32_t)__popcll(m));
+                base = __shfl(base, leader);
+                if (take) {
+                    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (slot < (uint32_t)CAND_MAX) cand[slot] = ((uint64_t)key << 32) | (uint32_t)(~(uint32_t)j);
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t ncand = s_ncand;
+        if (ncand <= (uint32_t)CAND_MAX) {
+            block_rank_emit<THREADS>(cand, (int)ncand, p.cutoff, (uint32_t)p.cutoff, 0u, sc, out, nullptr);
+            return;
+        }
+        __syncthreads();
+        if (tid == 0) s_ncand = 0;
+        __syncthreads();
+    }
+    block_topk_emit<THREADS>(acc, p.n_items, p.cutoff, s_nfinite, 0u, TOPK_FINITE, aux, sc, &s_ncand, out, nullptr);
 }
 
 // ---- wide ranking: rows in HBM -----------------------------------------------------------------------------------------
