@@ -141,6 +141,52 @@ __global__ __launch_bounds__(256) void score_gemm_kernel(const ScoreParams p) {
     }
 }
 
+// THRESHOLD-FIRST ranking of a score row in LDS (round 6; the similarity build's selection, csrc/sim.hip): the cutoff largest scores are
+// all >= the cutoff-th largest of the THREADS thread maxima (the cutoff largest maxima are cutoff different cells), so one 16-bit radix
+// select over THREADS keys gives a bound, one pass over the row collects the cells at or above it -- a few times `cutoff` of them, ties
+// included -- and those are ranked exactly (value descending, ties towards the lower item, as block_topk_emit does).  Returns false --
+// nothing emitted, *ncand back at 0 -- where the full radix select over the row has to run instead: fewer finite scores than the cutoff,
+// a cutoff that is not small next to the number of maxima, a candidate list that overflows (a sparse model's row of zeros).
+// aux[0..255] must be zero on entry, `tmax` is the calling thread's largest score, *ncand 0.  Ends behind a barrier either way.
+template <int THREADS>
+__device__ __forceinline__ bool rank_threshold_first(const float *acc, int n, int cutoff, uint32_t nfinite, float tmax, uint32_t *aux, SelectScratch &sc,
+                                                     uint32_t *ncand_shared, int *out) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (!(nfinite >= (uint32_t)cutoff && 4 * cutoff <= THREADS)) return false;
+    const uint32_t prefix = block_kth_largest_prefix16<THREADS>(float_key(tmax), (uint32_t)cutoff, aux, sc);
+    const uint32_t T = prefix << 16;
+    if (tid == 0) sc.out_count = 0;
+    uint64_t *cand = reinterpret_cast<uint64_t *>(aux);
+    constexpr int CAND_MAX = AUX_WORDS / 2;
+    for (int j0 = 0; j0 < n; j0 += THREADS) {
+        const int j = j0 + tid;
+        const float v = j < n ? acc[j] : -INFINITY;
+        const uint32_t key = float_key(v);
+        const bool take = v > -INFINITY && key >= T;
+        const unsigned long long m = __ballot(take);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(ncand_shared, (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (take) {
+                const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (slot < (uint32_t)CAND_MAX) cand[slot] = ((uint64_t)key << 32) | (uint32_t)(~(uint32_t)j);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t ncand = *ncand_shared;
+    if (ncand <= (uint32_t)CAND_MAX) {
+        block_rank_emit<THREADS>(cand, (int)ncand, cutoff, (uint32_t)cutoff, 0u, sc, out, nullptr);
+        return true;
+    }
+    __syncthreads();
+    if (tid == 0) *ncand_shared = 0;
+    __syncthreads();
+    return false;
+}
+
 struct RankParams {
     int n_items, n_pad, cutoff, remove_seen;
     const int *users, *seen_ptr, *seen_idx;
@@ -186,45 +232,7 @@ __global__ __launch_bounds__(THREADS) void score_rank_kernel(const RankParams p)
     for (int w = tid; w < 256; w += THREADS) aux[w] = 0;           // (the bins of block_kth_largest_prefix16)
     __syncthreads();
     int *out = p.ranked + (size_t)b * p.cutoff;
-    // THRESHOLD-FIRST (round 6; the similarity build's selection, csrc/sim.hip): the cutoff largest scores are all >= the cutoff-th
-    // largest of the THREADS thread maxima (the cutoff largest maxima are cutoff different cells), so one 16-bit radix select over
-    // THREADS keys gives a bound, one pass over the row collects the cells at or above it -- a few times `cutoff` of them -- and those
-    // are ranked exactly (ties towards the lower item, as before).  The full radix select over the row (block_topk_emit: two or three
-    // passes of LDS atomics over n_items cells) remains for rows with fewer finite scores than the cutoff, cut-offs that are not small
-    // next to the number of maxima, and a candidate list that overflows.
-    if (s_nfinite >= (uint32_t)p.cutoff && 4 * p.cutoff <= THREADS) {
-        const uint32_t prefix = block_kth_largest_prefix16<THREADS>(float_key(tmax), (uint32_t)p.cutoff, aux, sc);
-        const uint32_t T = prefix << 16;
-        if (tid == 0) sc.out_count = 0;
-        uint64_t *cand = reinterpret_cast<uint64_t *>(aux);
-        constexpr int CAND_MAX = AUX_WORDS / 2;
-        for (int j0 = 0; j0 < p.n_items; j0 += THREADS) {
-            const int j = j0 + tid;
-            const float v = j < p.n_items ? acc[j] : -INFINITY;
-            const uint32_t key = float_key(v);
-            const bool take = v > -INFINITY && key >= T;
-            const unsigned long long m = __ballot(take);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&s_ncand, (uint32_t)__popcll(m));
-                base = __shfl(base, leader);
-                if (take) {
-                    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (slot < (uint32_t)CAND_MAX) cand[slot] = ((uint64_t)key << 32) | (uint32_t)(~(uint32_t)j);
-                }
-            }
-        }
-        __syncthreads();
-        const uint32_t ncand = s_ncand;
-        if (ncand <= (uint32_t)CAND_MAX) {
-            block_rank_emit<THREADS>(cand, (int)ncand, p.cutoff, (uint32_t)p.cutoff, 0u, sc, out, nullptr);
-            return;
-        }
-        __syncthreads();
-        if (tid == 0) s_ncand = 0;
-        __syncthreads();
-    }
+    if (rank_threshold_first<THREADS>(acc, p.n_items, p.cutoff, s_nfinite, tmax, aux, sc, &s_ncand, out)) return;
     block_topk_emit<THREADS>(acc, p.n_items, p.cutoff, s_nfinite, 0u, TOPK_FINITE, aux, sc, &s_ncand, out, nullptr);
 }
 
@@ -484,18 +492,24 @@ __global__ __launch_bounds__(THREADS) void spscore_kernel(const SpScoreParams p)
         for (int q = p.seen_ptr[u] + tid; q < p.seen_ptr[u + 1]; q += THREADS) acc[p.seen_idx[q]] = -INFINITY;
     __syncthreads();
     uint32_t nfin = 0;
+    float tmax = -INFINITY;
     float *row = p.scores + (size_t)b * p.n_out;
     for (int j = tid; j < p.n_out; j += THREADS) {
         const float v = acc[j];
         nfin += v > -INFINITY;
+        tmax = fmaxf(tmax, v);
         if (p.write_back) row[j] = v;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nfin += __shfl_down(nfin, off);
     if (lane == 0 && nfin) atomicAdd(&s_nfinite, nfin);
+    for (int w = tid; w < 256; w += THREADS) aux[w] = 0;           // (the bins of block_kth_largest_prefix16)
     __syncthreads();
-    block_topk_emit<THREADS>(acc, p.n_out, p.cutoff, s_nfinite, 0u, TOPK_FINITE, aux, sc, &s_ncand,
-                             p.ranked + (size_t)b * p.cutoff, nullptr);
+    int *out = p.ranked + (size_t)b * p.cutoff;
+    // (a user with few non-zero scores has a zero among the largest thread maxima: every cell of the row is then "at or above" the
+    // bound, the candidate list overflows and the full select below runs as before)
+    if (rank_threshold_first<THREADS>(acc, p.n_out, p.cutoff, s_nfinite, tmax, aux, sc, &s_ncand, out)) return;
+    block_topk_emit<THREADS>(acc, p.n_out, p.cutoff, s_nfinite, 0u, TOPK_FINITE, aux, sc, &s_ncand, out, nullptr);
 }
 
 // the same accumulation with the score row in HBM (rows that do not fit LDS): global float atomics
